@@ -1,0 +1,263 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes binding of oracle/liboracle.so (the CPU restatement of the reference algorithm) and, when present,
+oracle/_ref/libref_casadi_robot.so (the reference's own CasADi-generated C fixtures, compiled by oracle/Makefile).
+Import this only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg — never from polympc_amd.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboracle.so")
+REF_PATH = os.path.join(HERE, "_ref", "libref_casadi_robot.so")
+
+PIVOT_EIGEN, PIVOT_STATIC = 0, 1
+MODEL_ROBOT, MODEL_CSTR, MODEL_PARKING, MODEL_ROBOT_NG, MODEL_KITE_STANDIN = 0, 1, 2, 3, 4
+NLP_CONSTRAINED_ROSENBROCK, NLP_ROSENBROCK, NLP_SIMPLE, NLP_HS071 = 0, 1, 2, 3
+QP_SOLVED, QP_MAX_ITER_EXCEEDED, QP_UNSOLVED = 0, 1, 2
+SQP_SOLVED, SQP_MAX_ITER_EXCEEDED = 0, 1
+
+
+class QPSettings(C.Structure):
+    _fields_ = [("eps_rel", C.c_double), ("eps_abs", C.c_double), ("max_iter", C.c_int), ("rho", C.c_double),
+                ("sigma", C.c_double), ("alpha", C.c_double), ("check_termination", C.c_int),
+                ("adaptive_rho", C.c_int), ("adaptive_rho_tolerance", C.c_double), ("adaptive_rho_interval", C.c_int)]
+
+
+class QPInfo(C.Structure):
+    _fields_ = [("status", C.c_int), ("iter", C.c_int), ("rho_updates", C.c_int), ("rho_estimate", C.c_double),
+                ("res_prim", C.c_double), ("res_dual", C.c_double)]
+
+
+class SQPSettings(C.Structure):
+    _fields_ = [("tau", C.c_double), ("eta", C.c_double), ("rho", C.c_double), ("eps_prim", C.c_double),
+                ("eps_dual", C.c_double), ("max_iter", C.c_int), ("line_search_max_iter", C.c_int),
+                ("regularisation", C.c_int), ("exact_hessian_every_iter", C.c_int)]
+
+
+class SQPInfo(C.Structure):
+    _fields_ = [("iter", C.c_int), ("qp_solver_iter", C.c_int), ("status", C.c_int), ("primal_norm", C.c_double),
+                ("dual_norm", C.c_double), ("max_violation", C.c_double), ("cost", C.c_double)]
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", HERE, "-s", "all"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB_PATH)
+    return _lib
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def qp_default_settings():
+    s = QPSettings(); lib().orc_qp_default_settings(C.byref(s)); return s
+
+
+def sqp_qp_default_settings():
+    s = QPSettings(); lib().orc_sqp_qp_default_settings(C.byref(s)); return s
+
+
+def sqp_default_settings():
+    s = SQPSettings(); lib().orc_sqp_default_settings(C.byref(s)); return s
+
+
+def cheb(P):
+    nodes = np.zeros(P + 1); w = np.zeros(P + 1); D = np.zeros((P + 1) * (P + 1))
+    lib().orc_cheb(P, _p(nodes), _p(w), _p(D))
+    return nodes, w, D.reshape(P + 1, P + 1).T.copy()  # column-major -> D[i, j]
+
+
+def classify(lb, ub):
+    f = lib().orc_classify; f.argtypes = [C.c_double, C.c_double]; f.restype = C.c_int
+    return f(lb, ub)
+
+
+def bfgs(B, s, y):
+    n = len(s)
+    Bc = np.ascontiguousarray(np.asarray(B, dtype=np.float64).T).ravel().copy()  # column-major
+    lib().orc_bfgs(n, _p(Bc), _p(_f(s)), _p(_f(y)))
+    return Bc.reshape(n, n).T.copy()
+
+
+def regularise(kind, H):
+    n = H.shape[0]
+    Hc = np.ascontiguousarray(np.asarray(H, dtype=np.float64).T).ravel().copy()
+    lib().orc_regularise(kind, n, _p(Hc))
+    return Hc.reshape(n, n).T.copy()
+
+
+def ldlt_solve(K, b, pivot=PIVOT_EIGEN):
+    n = len(b)
+    Kc = np.ascontiguousarray(np.asarray(K, dtype=np.float64).T).ravel().copy()
+    x = np.zeros(n)
+    lib().orc_ldlt_solve(n, _p(Kc), _p(_f(b)), pivot, _p(x))
+    return x
+
+
+def qp_solve_batch(H, h, A, Alb, Aub, xlb, xub, settings=None, pivot=PIVOT_EIGEN, x0=None, y0=None, threads=1):
+    """All arrays instance-major; matrices column-major per instance: H[b] is (n*n,), A[b] is (m*n,)."""
+    H = _f(H); h = _f(h); A = _f(A); Alb = _f(Alb); Aub = _f(Aub); xlb = _f(xlb); xub = _f(xub)
+    B, n = h.shape
+    m = Alb.shape[1] if Alb.ndim == 2 else 0
+    s = settings or qp_default_settings()
+    x = np.zeros((B, n)); y = np.zeros((B, n + m)); info = (QPInfo * B)()
+    lib().orc_qp_solve_batch(B, n, m, _p(H), _p(h), _p(A), _p(Alb), _p(Aub), _p(xlb), _p(xub), _p(_f(x0)), _p(_f(y0)),
+                             C.byref(s), pivot, threads, _p(x), _p(y), info)
+    return x, y, info
+
+
+def ocp_dims(model, P, S):
+    v = [C.c_int() for _ in range(8)]
+    lib().orc_ocp_dims(model, P, S, *[C.byref(a) for a in v])
+    nx, nu, np_, nd, ng, n, me, mi = [a.value for a in v]
+    return dict(nx=nx, nu=nu, np=np_, nd=nd, ng=ng, n=n, m_eq=me, m_ineq=mi, m=me + mi, nn=P * S + 1)
+
+
+def ocp_time_nodes(model, P, S, t0, tf):
+    tn = np.zeros(P * S + 1)
+    f = lib().orc_ocp_time_nodes
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double)]
+    f(model, P, S, t0, tf, _p(tn))
+    return tn
+
+
+def ocp_eval(model, P, S, t0, tf, var, d, lam=None, mparams=None):
+    dm = ocp_dims(model, P, S)
+    n, m = dm["n"], dm["m"]
+    cost = C.c_double()
+    c_eq = np.zeros(dm["m_eq"]); g = np.zeros(max(dm["m_ineq"], 1)); jac = np.zeros(m * n)
+    cg = np.zeros(n); ch = np.zeros(n * n); lg = np.zeros(n); lh = np.zeros(n * n)
+    mp = _f(mparams) if mparams is not None else None
+    f = lib().orc_ocp_eval
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_int] + \
+                 [C.POINTER(C.c_double)] * 11
+    f(model, P, S, t0, tf, _p(mp), 0 if mp is None else len(mp), _p(_f(var)), _p(_f(d)), _p(_f(lam)),
+      C.byref(cost), _p(c_eq), _p(g), _p(jac), _p(cg), _p(ch), _p(lg), _p(lh))
+    return dict(cost=cost.value, c=c_eq, g=g[:dm["m_ineq"]], jac=jac.reshape(n, m).T.copy(), cost_grad=cg,
+                cost_hess=ch.reshape(n, n).T.copy(), lag_grad=lg, lag_hess=lh.reshape(n, n).T.copy())
+
+
+def _sqp_argtypes(extra_tail):
+    dp = C.POINTER(C.c_double)
+    return [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, dp, C.c_int] + extra_tail
+
+
+def sqp_solve_batch(model, P, S, t0, tf, B, d, lbx, ubx, lbg=None, ubg=None, x_guess=None, lam_guess=None,
+                    sqp_settings=None, qp_settings=None, pivot=PIVOT_EIGEN, mparams=None, threads=1):
+    dm = ocp_dims(model, P, S)
+    n, m = dm["n"], dm["m"]
+    ss = sqp_settings or sqp_default_settings(); qs = qp_settings or sqp_qp_default_settings()
+    x = np.zeros((B, n)); lam = np.zeros((B, m + n)); info = (SQPInfo * B)()
+    mp = _f(mparams) if mparams is not None else None
+    dp = C.POINTER(C.c_double)
+    f = lib().orc_sqp_solve_batch
+    f.argtypes = _sqp_argtypes([C.c_int] + [dp] * 7 + [C.POINTER(SQPSettings), C.POINTER(QPSettings), C.c_int, C.c_int,
+                                                      dp, dp, C.POINTER(SQPInfo)])
+    f(model, P, S, t0, tf, _p(mp), 0 if mp is None else len(mp), B, _p(_f(x_guess)), _p(_f(lam_guess)), _p(_f(d)),
+      _p(_f(lbx)), _p(_f(ubx)), _p(_f(lbg)), _p(_f(ubg)), C.byref(ss), C.byref(qs), pivot, threads, _p(x), _p(lam), info)
+    return x, lam, info
+
+
+def sqp_trace_qps(model, P, S, t0, tf, d, lbx, ubx, lbg=None, ubg=None, x_guess=None, lam_guess=None,
+                  sqp_settings=None, qp_settings=None, pivot=PIVOT_EIGEN, mparams=None, max_qps=32):
+    dm = ocp_dims(model, P, S)
+    n, m = dm["n"], dm["m"]
+    ss = sqp_settings or sqp_default_settings(); qs = qp_settings or sqp_qp_default_settings()
+    H = np.zeros((max_qps, n * n)); h = np.zeros((max_qps, n)); A = np.zeros((max_qps, m * n))
+    al = np.zeros((max_qps, m)); au = np.zeros((max_qps, m)); lx = np.zeros((max_qps, n)); ux = np.zeros((max_qps, n))
+    mp = _f(mparams) if mparams is not None else None
+    dp = C.POINTER(C.c_double)
+    f = lib().orc_sqp_trace_qps
+    f.restype = C.c_int
+    f.argtypes = _sqp_argtypes([dp] * 7 + [C.POINTER(SQPSettings), C.POINTER(QPSettings), C.c_int, C.c_int] + [dp] * 7)
+    k = f(model, P, S, t0, tf, _p(mp), 0 if mp is None else len(mp), _p(_f(x_guess)), _p(_f(lam_guess)), _p(_f(d)),
+          _p(_f(lbx)), _p(_f(ubx)), _p(_f(lbg)), _p(_f(ubg)), C.byref(ss), C.byref(qs), pivot, max_qps,
+          _p(H), _p(h), _p(A), _p(al), _p(au), _p(lx), _p(ux))
+    return dict(H=H[:k], h=h[:k], A=A[:k], al=al[:k], au=au[:k], lx=lx[:k], ux=ux[:k], n=n, m=m)
+
+
+def nlp_solve(problem, x0, lbx=None, ubx=None, lbg=None, ubg=None, sqp_settings=None, qp_settings=None,
+              pivot=PIVOT_EIGEN, lam0=None):
+    dims = {NLP_CONSTRAINED_ROSENBROCK: (2, 1, 0), NLP_ROSENBROCK: (2, 0, 0), NLP_SIMPLE: (2, 0, 1), NLP_HS071: (4, 1, 1)}
+    n, ne, ni = dims[problem]
+    ss = sqp_settings or sqp_default_settings(); qs = qp_settings or sqp_qp_default_settings()
+    x = np.zeros(n); lam = np.zeros(ne + ni + n); info = SQPInfo()
+    lib().orc_nlp_solve(problem, _p(_f(x0)), _p(_f(lam0)), _p(_f(lbx)), _p(_f(ubx)), _p(_f(lbg)), _p(_f(ubg)),
+                        C.byref(ss), C.byref(qs), pivot, _p(x), _p(lam), C.byref(info))
+    return x, lam, info
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the reference's own compiled CasADi fixtures (oracle/_ref), P=5 S=2 mobile robot, 55 vars / 33 eq
+class RefCasadiRobot:
+    N, M = 55, 33
+
+    def __init__(self):
+        if not os.path.exists(REF_PATH):
+            raise FileNotFoundError(REF_PATH)
+        self.l = C.CDLL(REF_PATH)
+
+    def _call(self, name, args, out_sizes):
+        fn = getattr(self.l, name)
+        work = getattr(self.l, name + "_work")
+        sz = [C.c_longlong() for _ in range(4)]
+        work(*[C.byref(a) for a in sz])
+        n_arg, n_res, n_iw, n_w = [max(int(a.value), 1) for a in sz]
+        argv = (C.POINTER(C.c_double) * n_arg)()
+        for i, a in enumerate(args):
+            argv[i] = _p(a)
+        outs = [np.zeros(s) for s in out_sizes]
+        resv = (C.POINTER(C.c_double) * n_res)()
+        for i, o in enumerate(outs):
+            resv[i] = _p(o)
+        iw = (C.c_longlong * n_iw)(); w = (C.c_double * n_w)()
+        fn(argv, resv, iw, w, None)
+        return outs
+
+    def _sparsity(self, name, idx=0):
+        f = getattr(self.l, name + "_sparsity_out"); f.restype = C.POINTER(C.c_longlong); f.argtypes = [C.c_longlong]
+        sp = f(idx)
+        nrow, ncol = sp[0], sp[1]
+        colind = [sp[2 + i] for i in range(ncol + 1)]
+        nnz = colind[-1]
+        rows = [sp[2 + ncol + 1 + i] for i in range(nnz)]
+        return nrow, ncol, colind, rows
+
+    def _dense(self, name, vals):
+        nrow, ncol, colind, rows = self._sparsity(name)
+        Md = np.zeros((nrow, ncol))
+        for j in range(ncol):
+            for k in range(colind[j], colind[j + 1]):
+                Md[rows[k], j] = vals[k]
+        return Md
+
+    def cost(self, x):
+        return self._call("fcost", [_f(x)], [1])[0][0]
+
+    def constraint(self, x):
+        return self._call("fconstraint", [_f(x)], [self.M])[0]
+
+    def nnz(self, name):
+        return self._sparsity(name)[2][-1]

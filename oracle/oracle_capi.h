@@ -1,0 +1,85 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY (CPU restatement of the reference algorithm).
+ * C entry points of the oracle shared library, bound with ctypes from tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg. Never linked by polympc_amd. */
+#ifndef ORACLE_CAPI_H
+#define ORACLE_CAPI_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    double eps_rel, eps_abs;
+    int max_iter;
+    double rho, sigma, alpha;
+    int check_termination;
+    int adaptive_rho;
+    double adaptive_rho_tolerance;
+    int adaptive_rho_interval;
+} orc_qp_settings;
+
+typedef struct {
+    int status, iter, rho_updates;
+    double rho_estimate, res_prim, res_dual;
+} orc_qp_info;
+
+typedef struct {
+    double tau, eta, rho, eps_prim, eps_dual;
+    int max_iter, line_search_max_iter;
+    int regularisation;            /* 0 none, 1 eigenvalue mirroring, 2 Gershgorin */
+    int exact_hessian_every_iter;  /* 0 = damped BFGS (default) */
+} orc_sqp_settings;
+
+typedef struct {
+    int iter, qp_solver_iter, status;
+    double primal_norm, dual_norm, max_violation, cost;
+} orc_sqp_info;
+
+enum { ORC_MODEL_ROBOT = 0, ORC_MODEL_CSTR = 1, ORC_MODEL_PARKING = 2, ORC_MODEL_ROBOT_NG = 3, ORC_MODEL_KITE_STANDIN = 4 };
+enum { ORC_NLP_CONSTRAINED_ROSENBROCK = 0, ORC_NLP_ROSENBROCK = 1, ORC_NLP_SIMPLE = 2, ORC_NLP_HS071 = 3 };
+
+void orc_qp_default_settings(orc_qp_settings* s);       /* qp_base.hpp:17-53 defaults */
+void orc_sqp_qp_default_settings(orc_qp_settings* s);   /* + SQP-ctor overrides sqp_base.hpp:83-90 */
+void orc_sqp_default_settings(orc_sqp_settings* s);
+
+void orc_cheb(int P, double* nodes, double* weights, double* D);
+int  orc_classify(double lb, double ub);
+void orc_bfgs(int n, double* B, const double* s, const double* y);
+void orc_regularise(int kind, int n, double* H);
+void orc_ldlt_solve(int n, const double* K, const double* b, int pivot, double* x);
+
+/* batch of B QPs, instance-major, column-major matrices; x0/y0 may be NULL (zero guesses). threads<=1: serial */
+void orc_qp_solve_batch(int B, int n, int m, const double* H, const double* h, const double* A, const double* Alb,
+                        const double* Aub, const double* xlb, const double* xub, const double* x0, const double* y0,
+                        const orc_qp_settings* s, int pivot, int threads, double* x, double* y, orc_qp_info* info);
+
+/* sizes of the transcription */
+void orc_ocp_dims(int model, int P, int S, int* nx, int* nu, int* np, int* nd, int* ng, int* n, int* m_eq, int* m_ineq);
+void orc_ocp_time_nodes(int model, int P, int S, double t0, double tf, double* tn);
+
+/* evaluate every collocation quantity at one point. Any output pointer may be NULL. */
+void orc_ocp_eval(int model, int P, int S, double t0, double tf, const double* mparams, int n_mparams, const double* var,
+                  const double* d, const double* lam, double* cost, double* c_eq, double* g_ineq, double* jac,
+                  double* cost_grad, double* cost_hess, double* lag_grad, double* lag_hess);
+
+/* batch SQP: B instances; lbx/ubx/lbg/ubg/x_guess/lam_guess/d are per-instance (instance-major). */
+void orc_sqp_solve_batch(int model, int P, int S, double t0, double tf, const double* mparams, int n_mparams, int B,
+                         const double* x_guess, const double* lam_guess, const double* d, const double* lbx,
+                         const double* ubx, const double* lbg, const double* ubg, const orc_sqp_settings* ss,
+                         const orc_qp_settings* qs, int pivot, int threads, double* x, double* lam, orc_sqp_info* info);
+
+/* run ONE instance and dump every QP it hands to the QP solver (at most max_qps). Returns the number recorded. */
+int orc_sqp_trace_qps(int model, int P, int S, double t0, double tf, const double* mparams, int n_mparams,
+                      const double* x_guess, const double* lam_guess, const double* d, const double* lbx,
+                      const double* ubx, const double* lbg, const double* ubg, const orc_sqp_settings* ss,
+                      const orc_qp_settings* qs, int pivot, int max_qps, double* H, double* h, double* A, double* al,
+                      double* au, double* lx, double* ux);
+
+/* generic NLP known-answer problems (sqp_test_autodiff.cpp) */
+void orc_nlp_solve(int problem, const double* x0, const double* lam0, const double* lbx, const double* ubx,
+                   const double* lbg, const double* ubg, const orc_sqp_settings* ss, const orc_qp_settings* qs,
+                   int pivot, double* x, double* lam, orc_sqp_info* info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,300 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (CPU restatement of the reference algorithm).
+//
+// Dense box-ADMM QP solver + the LDL^T it relies on.
+// Follows /root/reference/src/solvers/qp_base.hpp (settings :17-53, status :55-62, info :64-72,
+// parse_constraints_bounds :195-222, residuals :240-252, DIV_BY_ZERO_REGUL :79-82,126) and
+// /root/reference/src/solvers/box_admm.hpp (solve_impl :88-205, construct_kkt_matrix :209-223,
+// factorise :336-341, compute_kkt_rhs :351-355, rho_vec_update :357-396, residuals_update :398-415,
+// eps_prim/eps_dual/termination :417-431, estimate_rho :433-445, update_kkt_rho :448-452).
+//
+// Third-party arithmetic: the reference factorises with Eigen::LDLT<Matrix,Lower>
+// (src/utils/helpers.hpp:38-43; Eigen 3.3.7 pinned in ci/install-linux.sh:21). Eigen is NOT vendored in
+// /root/reference; the two pivot policies below restate its published algorithm:
+//   PIVOT_EIGEN  : symmetric max-|diag| pivoting, left-looking column update, D^+ solve (Eigen semantics)
+//   PIVOT_STATIC : identical arithmetic without the permutation, right-looking update order — the order
+//                  the HIP kernels use, so a GPU-vs-oracle comparison isolates kernel bugs from pivot effects.
+// All matrices column-major.
+#pragma once
+#include <cmath>
+#include <limits>
+#include <vector>
+
+namespace oracle {
+
+enum qp_status { QP_SOLVED = 0, QP_MAX_ITER_EXCEEDED = 1, QP_UNSOLVED = 2, QP_UNINITIALIZED = 3, QP_INFEASIBLE = 4, QP_INCONSISTENT = 5 };
+enum pivot_policy { PIVOT_EIGEN = 0, PIVOT_STATIC = 1 };
+
+struct qp_settings {  // qp_base.hpp:17-53 (ADMM-related subset)
+    double eps_rel = 1e-3, eps_abs = 1e-3;
+    int max_iter = 1000;
+    bool warm_start = false;
+    double rho = 1e-1, sigma = 1e-6, alpha = 1.0;
+    int check_termination = 25;
+    bool adaptive_rho = false;
+    double adaptive_rho_tolerance = 5;
+    int adaptive_rho_interval = 25;
+};
+
+struct qp_info {  // qp_base.hpp:64-72
+    int status = QP_UNINITIALIZED;
+    int iter = 0;
+    int rho_updates = 0;
+    double rho_estimate = 0;
+    double res_prim = 1, res_dual = 1;
+};
+
+// ---------------------------------------------------------------------------------------------
+// LDL^T of a symmetric matrix given by its LOWER triangle (Appendix B of SURVEY.md)
+struct LDLT {
+    int n = 0;
+    pivot_policy policy = PIVOT_EIGEN;
+    std::vector<double> M;   // factor: unit-lower L below the diagonal, D on the diagonal
+    std::vector<int> tr;     // transpositions
+    std::vector<double> temp;
+
+    void compute(const std::vector<double>& K, int n_, pivot_policy pol) {
+        n = n_; policy = pol; M = K; tr.assign(n, 0); temp.assign(n, 0.0);
+        if (policy == PIVOT_STATIC) { compute_static(); return; }
+        auto at = [&](int i, int j) -> double& { return M[i + j * n]; };
+        for (int k = 0; k < n; ++k) {
+            // largest remaining |diagonal| (first occurrence)
+            int big = k; double bv = std::fabs(at(k, k));
+            for (int i = k + 1; i < n; ++i) { double v = std::fabs(at(i, i)); if (v > bv) { bv = v; big = i; } }
+            tr[k] = big;
+            if (big != k) {
+                for (int j = 0; j < k; ++j) std::swap(at(k, j), at(big, j));
+                for (int i = big + 1; i < n; ++i) std::swap(at(i, k), at(i, big));
+                std::swap(at(k, k), at(big, big));
+                for (int i = k + 1; i < big; ++i) std::swap(at(i, k), at(big, i));
+            }
+            const int rs = n - k - 1;
+            if (k > 0) {
+                for (int j = 0; j < k; ++j) temp[j] = at(j, j) * at(k, j);
+                double acc = 0.0;
+                for (int j = 0; j < k; ++j) acc += at(k, j) * temp[j];
+                at(k, k) -= acc;
+                for (int i = k + 1; i < n; ++i) {
+                    double a = 0.0;
+                    for (int j = 0; j < k; ++j) a += at(i, j) * temp[j];
+                    at(i, k) -= a;
+                }
+            }
+            const double akk = at(k, k);
+            const bool valid = std::fabs(akk) > 0.0;
+            if (k == 0 && !valid) { for (int j = 0; j < n; ++j) tr[j] = j; return; }
+            if (rs > 0 && valid) for (int i = k + 1; i < n; ++i) at(i, k) /= akk;
+        }
+    }
+
+    // no pivoting; right-looking: after column k is scaled, a_ij -= a_ik(unscaled) * l_jk
+    void compute_static() {
+        auto at = [&](int i, int j) -> double& { return M[i + j * n]; };
+        for (int k = 0; k < n; ++k) tr[k] = k;
+        std::vector<double> col(n);
+        for (int k = 0; k < n; ++k) {
+            const double dk = at(k, k);
+            for (int i = k + 1; i < n; ++i) { col[i] = at(i, k); at(i, k) = col[i] / dk; }
+            for (int j = k + 1; j < n; ++j) {
+                const double ljk = at(j, k);
+                for (int i = j; i < n; ++i) at(i, j) = std::fma(-col[i], ljk, at(i, j));
+            }
+        }
+    }
+
+    void solve(const double* b, double* x) const {
+        auto at = [&](int i, int j) -> double { return M[i + j * n]; };
+        for (int i = 0; i < n; ++i) x[i] = b[i];
+        if (policy == PIVOT_EIGEN) for (int k = 0; k < n; ++k) if (tr[k] != k) std::swap(x[k], x[tr[k]]);
+        if (policy == PIVOT_STATIC) {
+            // column-oriented forward substitution, fma order of the HIP kernel
+            for (int j = 0; j < n; ++j) for (int i = j + 1; i < n; ++i) x[i] = std::fma(-at(i, j), x[j], x[i]);
+            for (int i = 0; i < n; ++i) x[i] = x[i] / at(i, i);
+            for (int j = n - 1; j >= 0; --j) for (int i = j - 1; i >= 0; --i) x[i] = std::fma(-at(j, i), x[j], x[i]);
+            return;
+        }
+        for (int i = 0; i < n; ++i) { double a = x[i]; for (int j = 0; j < i; ++j) a -= at(i, j) * x[j]; x[i] = a; }
+        const double tol = 1.0 / std::numeric_limits<double>::max();
+        for (int i = 0; i < n; ++i) { if (std::fabs(at(i, i)) > tol) x[i] /= at(i, i); else x[i] = 0.0; }
+        for (int i = n - 1; i >= 0; --i) { double a = x[i]; for (int j = i + 1; j < n; ++j) a -= at(j, i) * x[j]; x[i] = a; }
+        for (int k = n - 1; k >= 0; --k) if (tr[k] != k) std::swap(x[k], x[tr[k]]);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+struct BoxADMM {
+    static constexpr double RHO_MIN = 1e-6, RHO_MAX = 1e+6, RHO_EQ_FACTOR = 1e+3;   // box_admm.hpp:56-59
+    static constexpr double LOOSE_BOUNDS_THRESH = 1e+10, EQ_TOL = 1e-4;            // qp_base.hpp:124-125
+    static constexpr double DIV_BY_ZERO_REGUL = 10e-10;                            // qp_base.hpp:79-82
+    enum ctype { INEQUALITY_CONSTRAINT = 0, EQUALITY_CONSTRAINT = 1, LOOSE_BOUNDS = 2 };
+
+    int N, M;
+    qp_settings settings;
+    qp_info info;
+    pivot_policy pivot = PIVOT_EIGEN;
+    std::vector<double> x, y;  // primal N, dual M+N ([general | box])
+    std::vector<double> x_tilde, q, z, z_tilde, z_prev, rho_vec, rho_inv_vec, rho_box, rho_box_inv, rho_box_prev;
+    std::vector<int> constr_type, box_type;
+    std::vector<double> K;
+    LDLT ldlt;
+    double rho = 0, max_Ax_z_norm = 0, max_Hx_ATy_h_norm = 0;
+    int iter = 0;
+
+    BoxADMM(int n, int m) : N(n), M(m) {
+        x.assign(N, 0); y.assign(N + M, 0); x_tilde.assign(N, 0); q.assign(N, 0);
+        z.assign(M, 0); z_tilde.assign(M, 0); z_prev.assign(M, 0);
+        rho_vec.assign(M, settings.rho); rho_inv_vec.assign(M, 1 / settings.rho);
+        rho_box.assign(N, 0); rho_box_inv.assign(N, 0); rho_box_prev.assign(N, 0);
+        constr_type.assign(M, 0); box_type.assign(N, 0);
+        K.assign((N + M) * (N + M), 0.0);
+    }
+
+    static double inf_norm(const double* v, int n) { double r = 0; for (int i = 0; i < n; ++i) r = std::fmax(r, std::fabs(v[i])); return r; }
+
+    static int classify(double lb, double ub) {  // qp_base.hpp:195-222
+        if (lb < -LOOSE_BOUNDS_THRESH && ub > LOOSE_BOUNDS_THRESH) return LOOSE_BOUNDS;
+        if (ub - lb < EQ_TOL) return EQUALITY_CONSTRAINT;
+        return INEQUALITY_CONSTRAINT;
+    }
+
+    void rho_vec_update(double rho0) {  // box_admm.hpp:357-396
+        for (int i = 0; i < M; ++i) {
+            switch (constr_type[i]) {
+                case LOOSE_BOUNDS: rho_vec[i] = RHO_MIN; break;
+                case EQUALITY_CONSTRAINT: rho_vec[i] = RHO_EQ_FACTOR * rho0; break;
+                default: rho_vec[i] = rho0;
+            }
+            rho_inv_vec[i] = 1.0 / rho_vec[i];
+        }
+        rho = rho0;
+        for (int i = 0; i < N; ++i) {
+            switch (box_type[i]) {
+                case LOOSE_BOUNDS: rho_box[i] = RHO_MIN; break;
+                case EQUALITY_CONSTRAINT: rho_box[i] = RHO_EQ_FACTOR * rho0; break;
+                default: rho_box[i] = rho0;
+            }
+            rho_box_inv[i] = 1.0 / rho_box[i];
+        }
+        info.rho_updates += 1;
+    }
+
+    void matvec(const double* A, int rows, int cols, const double* v, double* out) const {
+        for (int i = 0; i < rows; ++i) { double a = 0; for (int j = 0; j < cols; ++j) a += A[i + j * rows] * v[j]; out[i] = a; }
+    }
+    void matTvec(const double* A, int rows, int cols, const double* v, double* out) const {
+        for (int j = 0; j < cols; ++j) { double a = 0; for (int i = 0; i < rows; ++i) a += A[i + j * rows] * v[i]; out[j] = a; }
+    }
+
+    void residuals_update(const double* H, const double* h, const double* A) {  // :398-415
+        std::vector<double> Ax(M), Hx(N), ATy(N);
+        matvec(A, M, N, x.data(), Ax.data());
+        const double norm_Ax = inf_norm(Ax.data(), M), norm_z = inf_norm(z.data(), M);
+        max_Ax_z_norm = std::fmax(norm_Ax, std::fmax(norm_z, inf_norm(x.data(), N)));
+        matvec(H, N, N, x.data(), Hx.data());
+        matTvec(A, M, N, y.data(), ATy.data());
+        const double norm_Hx = inf_norm(Hx.data(), N), norm_ATy = inf_norm(ATy.data(), N);
+        const double norm_h = inf_norm(h, N), norm_ybox = inf_norm(y.data() + M, N);
+        max_Hx_ATy_h_norm = std::fmax(norm_Hx, std::fmax(norm_ATy, std::fmax(norm_h, norm_ybox)));
+        double rp = 0, rq = 0, rd = 0;
+        for (int i = 0; i < M; ++i) rp = std::fmax(rp, std::fabs(Ax[i] - z[i]));
+        for (int i = 0; i < N; ++i) rq = std::fmax(rq, std::fabs(x[i] - q[i]));
+        info.res_prim = rp + rq;
+        for (int i = 0; i < N; ++i) rd = std::fmax(rd, std::fabs(((Hx[i] + h[i]) + ATy[i]) + y[M + i]));  // qp_base.hpp:251
+        info.res_dual = rd;
+    }
+    double eps_prim() const { return settings.eps_abs + settings.eps_rel * max_Ax_z_norm; }
+    double eps_dual() const { return settings.eps_abs + settings.eps_rel * max_Hx_ATy_h_norm; }
+    bool termination_criteria() const { return info.res_prim <= eps_prim() && info.res_dual <= eps_dual(); }
+    double estimate_rho(double rho0) const {  // :433-445
+        double rp = info.res_prim / (max_Ax_z_norm + DIV_BY_ZERO_REGUL);
+        double rd = info.res_dual / (max_Hx_ATy_h_norm + DIV_BY_ZERO_REGUL);
+        return rho0 * std::sqrt(rp / (rd + DIV_BY_ZERO_REGUL));
+    }
+
+    void construct_kkt(const double* H, const double* A) {  // :209-223 (lower triangle only)
+        const int NM = N + M;
+        std::fill(K.begin(), K.end(), 0.0);
+        for (int j = 0; j < N; ++j) for (int i = 0; i < N; ++i) K[i + j * NM] = H[i + j * N];
+        for (int i = 0; i < N; ++i) K[i + i * NM] += settings.sigma;
+        for (int i = 0; i < N; ++i) K[i + i * NM] += rho_box[i];
+        for (int j = 0; j < N; ++j) for (int i = 0; i < M; ++i) K[(N + i) + j * NM] = A[i + j * M];
+        for (int i = 0; i < M; ++i) K[(N + i) + (N + i) * NM] = -rho_inv_vec[i];
+    }
+    void update_kkt_rho() {  // :448-452
+        const int NM = N + M;
+        for (int i = 0; i < N; ++i) K[i + i * NM] += (rho_box[i] - rho_box_prev[i]);
+        for (int i = 0; i < M; ++i) K[(N + i) + (N + i) * NM] = -rho_inv_vec[i];
+    }
+    void factorise() { ldlt.compute(K, N + M, pivot); }
+
+    // 7-argument form (box_admm.hpp:81-86): zero guesses
+    int solve(const double* H, const double* h, const double* A, const double* Alb, const double* Aub,
+              const double* xlb, const double* xub) {
+        std::vector<double> x0(N, 0.0), y0(N + M, 0.0);
+        return solve(H, h, A, Alb, Aub, xlb, xub, x0.data(), y0.data());
+    }
+
+    // box_admm.hpp:88-205
+    int solve(const double* H, const double* h, const double* A, const double* Alb, const double* Aub,
+              const double* xlb, const double* xub, const double* x_guess, const double* y_guess) {
+        const int NM = N + M;
+        std::vector<double> rhs(NM), sol(NM);
+        bool check_termination = false;
+        for (int i = 0; i < N; ++i) x[i] = x_guess[i];
+        for (int i = 0; i < NM; ++i) y[i] = y_guess[i];
+        matvec(A, M, N, x_guess, z.data());
+        for (int i = 0; i < N; ++i) q[i] = x_guess[i];
+        for (int i = 0; i < M; ++i) constr_type[i] = classify(Alb[i], Aub[i]);
+        for (int i = 0; i < N; ++i) box_type[i] = classify(xlb[i], xub[i]);
+        rho_vec_update(settings.rho);
+        construct_kkt(H, A);
+        factorise();
+        info.status = QP_UNSOLVED;
+        const double alpha = settings.alpha;
+
+        for (iter = 1; iter <= settings.max_iter; iter++) {
+            z_prev = z;
+            // compute_kkt_rhs :351-355
+            for (int i = 0; i < N; ++i) rhs[i] = ((settings.sigma * x[i] - h[i]) + rho_box[i] * q[i]) - y[M + i];
+            for (int i = 0; i < M; ++i) rhs[N + i] = z[i] - rho_inv_vec[i] * y[i];
+            ldlt.solve(rhs.data(), sol.data());
+            for (int i = 0; i < N; ++i) x_tilde[i] = sol[i];
+            for (int i = 0; i < M; ++i) z_tilde[i] = z_prev[i] + rho_inv_vec[i] * (sol[N + i] - y[i]);
+            // quirk Q1 (:129-130): x = alpha*x_tilde; x += (1-alpha)*x
+            for (int i = 0; i < N; ++i) { x[i] = alpha * x_tilde[i]; x[i] += (1 - alpha) * x[i]; }
+            for (int i = 0; i < M; ++i) {
+                z[i] = alpha * z_tilde[i];
+                z[i] += (1 - alpha) * z_prev[i] + rho_inv_vec[i] * y[i];
+                z[i] = std::fmin(std::fmax(z[i], Alb[i]), Aub[i]);
+            }
+            for (int i = 0; i < N; ++i) {
+                q[i] = x[i] + rho_box_inv[i] * y[M + i];
+                q[i] = std::fmin(std::fmax(q[i], xlb[i]), xub[i]);
+            }
+            for (int i = 0; i < M; ++i) y[i] += rho_vec[i] * ((alpha * z_tilde[i] + (1 - alpha) * z_prev[i]) - z[i]);
+            for (int i = 0; i < N; ++i) y[M + i] += rho_box[i] * (x[i] - q[i]);
+
+            check_termination = (settings.check_termination != 0 && iter % settings.check_termination == 0);
+            if (check_termination) {
+                residuals_update(H, h, A);
+                if (termination_criteria()) { info.status = QP_SOLVED; break; }
+            }
+            if (settings.adaptive_rho && iter % settings.adaptive_rho_interval == 0) {
+                if (!check_termination) residuals_update(H, h, A);
+                double new_rho = estimate_rho(rho);
+                new_rho = std::fmax(RHO_MIN, std::fmin(new_rho, RHO_MAX));
+                info.rho_estimate = new_rho;
+                if (new_rho < rho / settings.adaptive_rho_tolerance || new_rho > rho * settings.adaptive_rho_tolerance) {
+                    rho_box_prev = rho_box;
+                    rho_vec_update(new_rho);
+                    update_kkt_rho();
+                    factorise();
+                }
+            }
+        }
+        if (iter > settings.max_iter) info.status = QP_MAX_ITER_EXCEEDED;
+        info.iter = iter;
+        return info.status;
+    }
+};
+
+}  // namespace oracle

@@ -1,0 +1,246 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (CPU restatement of the reference algorithm).
+//
+// Line-search SQP driver, damped BFGS and the two shipped Hessian-regularisation policies.
+// Follows /root/reference/src/solvers/sqp_base.hpp (settings :24-47, info :57-61, ctor QP overrides :83-90,
+// step_size_selection_impl :380-419, constraints_violation_impl :423-444, max_constraints_violation_impl
+// :448-474, update_linearisation_dense_impl :490-504, termination_criteria_impl :524-529, solve_qp :533-565,
+// solve :569-696), /root/reference/src/solvers/bfgs.hpp:23-52, and the regularisers at
+// tests/solvers/sqp/sqp_test_autodiff.cpp:29-45 (eigenvalue mirroring) and
+// tests/control/dense_sparse_compare.cpp:109-122 (Gershgorin shift).
+//
+// Problem concept (ContinuousOCP in ocp.hpp, GenericNLP in nlp.hpp):
+//   int VAR_SIZE, NUM_EQ, NUM_INEQ;
+//   cost(x,d,c); equalities(x,d,c); inequalities(x,d,g);
+//   lagrangian_gradient(x,d,lam,lag,lag_grad,cost_grad,g,jac);
+//   lagrangian_gradient_hessian(x,d,lam,lag,lag_grad,H,cost_grad,g,jac);
+#pragma once
+#include <cmath>
+#include <limits>
+#include <vector>
+#include "qp.hpp"
+
+namespace oracle {
+
+// bfgs.hpp:23-52 ; B is n x n column-major
+inline void BFGS_update(double* B, const double* s, const double* y, int n) {
+    std::vector<double> Bs(n), r(n);
+    for (int i = 0; i < n; ++i) { double a = 0; for (int j = 0; j < n; ++j) a += B[i + j * n] * s[j]; Bs[i] = a; }
+    double sBs = 0, sy = 0;
+    for (int i = 0; i < n; ++i) sBs += s[i] * Bs[i];
+    for (int i = 0; i < n; ++i) sy += s[i] * y[i];
+    double sr;
+    if (sy < 0.2 * sBs) {
+        const double theta = 0.8 * sBs / (sBs - sy);
+        for (int i = 0; i < n; ++i) r[i] = theta * y[i] + (1 - theta) * Bs[i];
+        sr = theta * sy + (1 - theta) * sBs;
+    } else {
+        for (int i = 0; i < n; ++i) r[i] = y[i];
+        sr = sy;
+    }
+    if (sr < std::numeric_limits<double>::epsilon()) return;
+    for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) B[i + j * n] += (-Bs[i] * Bs[j]) / sBs;
+    for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) B[i + j * n] += (r[i] * r[j]) / sr;
+}
+
+// cyclic Jacobi eigen-decomposition of a symmetric matrix (stand-in for Eigen::EigenSolver on a symmetric H)
+inline void jacobi_eig(std::vector<double> A, int n, std::vector<double>& w, std::vector<double>& V) {
+    V.assign(n * n, 0.0); for (int i = 0; i < n; ++i) V[i + i * n] = 1.0;
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0; for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) off += A[i + j * n] * A[i + j * n];
+        if (off < 1e-300) break;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                double apq = A[p + q * n]; if (std::fabs(apq) < 1e-300) continue;
+                double theta = (A[q + q * n] - A[p + p * n]) / (2 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
+                double c = 1 / std::sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < n; ++k) { double akp = A[k + p * n], akq = A[k + q * n]; A[k + p * n] = c * akp - s * akq; A[k + q * n] = s * akp + c * akq; }
+                for (int k = 0; k < n; ++k) { double apk = A[p + k * n], aqk = A[q + k * n]; A[p + k * n] = c * apk - s * aqk; A[q + k * n] = s * apk + c * aqk; }
+                for (int k = 0; k < n; ++k) { double vkp = V[k + p * n], vkq = V[k + q * n]; V[k + p * n] = c * vkp - s * vkq; V[k + q * n] = s * vkp + c * vkq; }
+            }
+    }
+    w.resize(n); for (int i = 0; i < n; ++i) w[i] = A[i + i * n];
+}
+
+enum regularisation { REG_NONE = 0, REG_EIG_MIRROR = 1, REG_GERSHGORIN = 2 };
+
+// sqp_test_autodiff.cpp:29-45
+inline void regularise_eig_mirror(double* H, int n) {
+    std::vector<double> w, V; jacobi_eig(std::vector<double>(H, H + n * n), n, w, V);
+    double mn = w[0]; for (int i = 1; i < n; ++i) mn = std::fmin(mn, w[i]);
+    if (mn <= 0) {
+        for (int i = 0; i < n; ++i) if (w[i] <= 0) w[i] = -1 * w[i] + 0.1;
+        for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) {
+            double a = 0; for (int k = 0; k < n; ++k) a += (V[i + k * n] * w[k]) * V[j + k * n];
+            H[i + j * n] = a;
+        }
+    }
+}
+// dense_sparse_compare.cpp:109-122
+inline void regularise_gershgorin(double* H, int n) {
+    for (int i = 0; i < n; ++i) {
+        double aii = H[i + i * n];
+        double ri = 0; for (int k = 0; k < n; ++k) ri += std::fabs(H[k + i * n]);
+        ri -= std::fabs(aii);
+        if (aii - ri <= 0) H[i + i * n] += (ri - aii) + 0.01;
+    }
+}
+
+struct sqp_settings {  // sqp_base.hpp:24-47
+    double tau = 0.5, eta = 0.25, rho = 0.5, eps_prim = 1e-3, eps_dual = 1e-3;
+    int max_iter = 100, line_search_max_iter = 100;
+    int regularisation = REG_NONE;          // hook of :277-306 (default no-op)
+    bool exact_hessian_every_iter = false;  // override used by codegen_test.cpp:381-398 / minimal_time_test.cpp:126-133
+};
+enum sqp_status { SQP_SOLVED = 0, SQP_MAX_ITER_EXCEEDED = 1, SQP_INVALID_SETTINGS = 2 };
+struct sqp_info { int iter = 0, qp_solver_iter = 0, status = SQP_MAX_ITER_EXCEEDED; };
+
+template <class Problem>
+struct SQP {
+    static constexpr double EPSILON = std::numeric_limits<double>::epsilon();
+    static constexpr double INF = std::numeric_limits<double>::infinity();
+
+    Problem& problem;
+    int n, me, mi, m;
+    std::vector<double> H, h, x, lam, lam_k, A, al, au, p_static, lbx, ubx, lx, ux, lbg, ubg, lag_gradient, step_prev;
+    double cost_ = 0, primal_norm = 0, dual_norm = 0, max_violation = 0;
+    sqp_settings settings;
+    sqp_info info;
+    BoxADMM qp;
+    // optional trace of every QP handed to the QP solver (used to build QP replay batches)
+    bool record_qps = false;
+    struct qp_record { std::vector<double> H, h, A, al, au, lx, ux; };
+    std::vector<qp_record> qp_trace;
+
+    SQP(Problem& prob, int nd)
+        : problem(prob), n(prob.VAR_SIZE), me(prob.NUM_EQ), mi(prob.NUM_INEQ), m(me + mi), qp(n, m) {
+        H.assign(n * n, 0); h.assign(n, 0); x.assign(n, 0); lam.assign(m + n, 0); lam_k.assign(m + n, 0);
+        A.assign(m * n, 0); al.assign(m, 0); au.assign(m, 0); p_static.assign(nd > 0 ? nd : 1, 0);
+        lbx.assign(n, -INF); ubx.assign(n, INF); lx.assign(n, 0); ux.assign(n, 0);
+        lbg.assign(mi, -INF); ubg.assign(mi, INF); lag_gradient.assign(n, 0); step_prev.assign(n, 0);
+        // sqp_base.hpp:83-90
+        qp.settings.warm_start = false; qp.settings.check_termination = 10;
+        qp.settings.eps_abs = 1e-4; qp.settings.eps_rel = 1e-4; qp.settings.max_iter = 100;
+        qp.settings.adaptive_rho = true; qp.settings.adaptive_rho_interval = 50; qp.settings.alpha = 1.0;
+    }
+
+    double constraints_violation(const double* xx) const {  // :423-444
+        double cl1 = EPSILON;
+        std::vector<double> c(me), g(mi);
+        problem.equalities(xx, p_static.data(), c.data());
+        double s = 0; for (int i = 0; i < me; ++i) s += std::fabs(c[i]); cl1 += s;
+        problem.inequalities(xx, p_static.data(), g.data());
+        s = 0; for (int i = 0; i < mi; ++i) s += std::fmax(lbg[i] - g[i], 0.0); cl1 += s;
+        s = 0; for (int i = 0; i < mi; ++i) s += std::fmax(g[i] - ubg[i], 0.0); cl1 += s;
+        s = 0; for (int i = 0; i < n; ++i) s += std::fmax(lbx[i] - xx[i], 0.0); cl1 += s;
+        s = 0; for (int i = 0; i < n; ++i) s += std::fmax(xx[i] - ubx[i], 0.0); cl1 += s;
+        return cl1;
+    }
+    double max_constraints_violation(const double* xx) const {  // :448-474
+        double c = 0;
+        if (me > 0) { std::vector<double> ce(me); problem.equalities(xx, p_static.data(), ce.data()); c = BoxADMM::inf_norm(ce.data(), me); }
+        if (mi > 0) {
+            std::vector<double> g(mi); problem.inequalities(xx, p_static.data(), g.data());
+            double a = -INF, b = -INF;
+            for (int i = 0; i < mi; ++i) { a = std::fmax(a, lbg[i] - g[i]); b = std::fmax(b, g[i] - ubg[i]); }
+            c = std::fmax(c, a); c = std::fmax(c, b);
+        }
+        double a = -INF, b = -INF;
+        for (int i = 0; i < n; ++i) { a = std::fmax(a, lbx[i] - xx[i]); b = std::fmax(b, xx[i] - ubx[i]); }
+        c = std::fmax(c, a); c = std::fmax(c, b);
+        return c;
+    }
+
+    double step_size_selection(const double* p) {  // :380-419
+        const double tau = settings.tau;
+        double constr_l1 = constraints_violation(x.data());
+        double mu = BoxADMM::inf_norm(lam_k.data(), m + n);
+        double cost_1; problem.cost(x.data(), p_static.data(), cost_1);
+        double phi_l1 = cost_1 + mu * constr_l1;
+        double gp = 0; for (int i = 0; i < n; ++i) gp += h[i] * p[i];
+        double Dp_phi_l1 = gp - mu * constr_l1;
+        double alpha = 1.0, cost_step;
+        std::vector<double> x_step(n);
+        for (int i = 1; i < settings.line_search_max_iter; i++) {
+            for (int j = 0; j < n; ++j) { x_step[j] = alpha * p[j]; x_step[j] += x[j]; }
+            problem.cost(x_step.data(), p_static.data(), cost_step);
+            cost_ = cost_step;
+            double phi_l1_step = cost_step + mu * constraints_violation(x_step.data());
+            if (phi_l1_step <= (phi_l1 + alpha * settings.eta * Dp_phi_l1)) return alpha;
+            else alpha = tau * alpha;
+        }
+        return alpha;
+    }
+
+    void hessian_regularisation() {
+        if (settings.regularisation == REG_EIG_MIRROR) regularise_eig_mirror(H.data(), n);
+        else if (settings.regularisation == REG_GERSHGORIN) regularise_gershgorin(H.data(), n);
+    }
+    void linearisation() {  // linearisation_dense_impl :310-318
+        double lag = 0;
+        problem.lagrangian_gradient_hessian(x.data(), p_static.data(), lam.data(), lag, lag_gradient.data(), H.data(),
+                                            h.data(), al.data(), A.data());
+        hessian_regularisation();
+    }
+    void update_linearisation() {  // :490-504
+        if (settings.exact_hessian_every_iter) { linearisation(); return; }
+        double lag; std::vector<double> lag_grad(n), yk(n);
+        problem.lagrangian_gradient(x.data(), p_static.data(), lam.data(), lag, lag_grad.data(), h.data(), al.data(), A.data());
+        for (int i = 0; i < n; ++i) yk[i] = lag_grad[i] - lag_gradient[i];
+        BFGS_update(H.data(), step_prev.data(), yk.data(), n);
+        lag_gradient = lag_grad;
+    }
+    void form_qp_bounds() {  // :588-593
+        for (int i = 0; i < m; ++i) { al[i] = -al[i]; au[i] = al[i]; }
+        for (int i = 0; i < mi; ++i) { al[me + i] += lbg[i]; au[me + i] += ubg[i]; }
+        for (int i = 0; i < n; ++i) { lx[i] = lbx[i] - x[i]; ux[i] = ubx[i] - x[i]; }
+    }
+    void solve_qp(std::vector<double>& p, std::vector<double>& p_lambda) {  // :533-565
+        if (record_qps) qp_trace.push_back({H, h, A, al, au, lx, ux});
+        qp.solve(H.data(), h.data(), A.data(), al.data(), au.data(), lx.data(), ux.data());
+        info.qp_solver_iter += qp.info.iter;
+        p = qp.x; p_lambda = qp.y;
+    }
+    bool termination_criteria() {  // :524-529
+        max_violation = max_constraints_violation(x.data());
+        return (primal_norm <= settings.eps_prim) && (dual_norm <= settings.eps_dual) && (max_violation <= settings.eps_prim);
+    }
+
+    void iterate_tail(std::vector<double>& p, std::vector<double>& p_lambda) {
+        lam_k = p_lambda;
+        for (int i = 0; i < m + n; ++i) p_lambda[i] -= lam[i];
+        const double alpha = step_size_selection(p.data());
+        for (int i = 0; i < n; ++i) x[i] += alpha * p[i];
+        for (int i = 0; i < m + n; ++i) lam[i] += alpha * p_lambda[i];
+        for (int i = 0; i < n; ++i) step_prev[i] = alpha * p[i];
+        primal_norm = alpha * BoxADMM::inf_norm(p.data(), n);
+        dual_norm = alpha * BoxADMM::inf_norm(p_lambda.data(), m + n);
+    }
+
+    void solve() {  // :569-696
+        info.status = SQP_MAX_ITER_EXCEEDED;
+        std::vector<double> p(n), p_lambda(m + n, 0.0);
+        info.qp_solver_iter = 0;
+        info.iter = 1;
+        linearisation();
+        form_qp_bounds();
+        solve_qp(p, p_lambda);
+        iterate_tail(p, p_lambda);
+        if (termination_criteria()) { info.status = SQP_SOLVED; return; }
+        while (info.iter < settings.max_iter) {
+            info.iter++;
+            update_linearisation();
+            form_qp_bounds();
+            solve_qp(p, p_lambda);
+            iterate_tail(p, p_lambda);
+            if (termination_criteria()) { info.status = SQP_SOLVED; break; }
+        }
+    }
+    void solve(const double* x_guess, const double* lam_guess) {
+        for (int i = 0; i < n; ++i) x[i] = x_guess[i];
+        for (int i = 0; i < m + n; ++i) lam[i] = lam_guess[i];
+        solve();
+    }
+};
+
+}  // namespace oracle

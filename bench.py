@@ -1,0 +1,155 @@
+#!/usr/bin/env python
+"""bench.py — box-ADMM QP subproblem solves/s of the fused SQP hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch: pmpc_sqp_solve_batch_dev on B = 4096 mobile-robot OCPs per GPU
+(BASELINE.json configs[1]: nx=3 nu=2, Chebyshev N=6 -> 7 nodes, n=35, m=21, KKT 56x56, fp64, randomised x0, zero
+guesses, SQP max_iter=10 / line search 10, QP settings = SQPBase constructor defaults). Every SQP iteration solves
+one box-ADMM QP subproblem (plus its linearisation, Hessian update and line search, all inside the same kernel), so
+value = (sum over instances of SQP iterations) * steps / wall time. Inputs are resident in HBM before the timed region.
+Multi-GPU: one process per GPU, the batch shards embarrassingly (each rank solves its own 4096 instances — weak
+scaling, no data-path collective); torch.distributed (RCCL) is used only for the barrier and the max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+PEAK_FP64_TFLOPS = 78.6      # fp64 vector peak, 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+
+
+def qp_algorithmic_bytes(n, m):
+    """read the QP data once, write the solution once."""
+    return 8 * (n * n + m * n + 3 * n + 2 * m) + 8 * (2 * n + m) + 32
+
+
+def qp_algorithmic_flops(n, m, it, f):
+    N = n + m
+    chk = it // 10
+    return f * N ** 3 / 3.0 + it * (2.0 * N * N + 12.0 * N) + chk * 2.0 * (n * n + 2 * m * n)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="OCP instances per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="instances in the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import polympc_amd as pa
+    from polympc_amd import workloads
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: polympc_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    B = args.batch
+    wl = workloads.robot_batch(B, first=rank * B)          # each rank owns its own contiguous shard of the instance stream
+    n, m = wl["n"], wl["m"]
+    stream = torch.cuda.current_stream(dev)
+    ctx = pa.Context(local_rank, stream=stream.cuda_stream)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_d, d_lbx, d_ubx = t(wl["d"]), t(wl["lbx"]), t(wl["ubx"])
+    d_x = torch.zeros(B, n, dtype=torch.float64, device=dev)
+    d_lam = torch.zeros(B, m + n, dtype=torch.float64, device=dev)
+    d_info = torch.zeros(B, 48, dtype=torch.uint8, device=dev)
+    ss = pa.sqp_settings_default(); ss.max_iter = wl["max_iter"]; ss.line_search_max_iter = wl["ls_max_iter"]
+    qs = pa.qp_settings_sqp_default()
+
+    def step():
+        ctx.sqp_solve_batch_dev(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, d_d, d_lbx, d_ubx, d_x, d_lam, d_info, ss, qs)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record(stream)
+        step()
+        e1.record(stream)
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
+
+    info = np.frombuffer(d_info.cpu().numpy().tobytes(), dtype=pa.capi.SQP_INFO_DTYPE)
+    qp_solves = int(info["iter"].sum())
+    admm_iters = int(info["qp_solver_iter"].sum())
+    solved = int((info["status"] == pa.SQP_SOLVED).sum())
+    tot = torch.tensor([float(qp_solves), float(admm_iters), float(solved), elapsed], dtype=torch.float64, device=dev)
+    if dist:
+        mx = tot[3:4].clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot[:3].clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed = float(mx.item()); qp_all, admm_all, solved_all = [float(v) for v in sm.tolist()]
+    else:
+        qp_all, admm_all, solved_all = float(qp_solves), float(admm_iters), float(solved)
+
+    if rank == 0:
+        value = qp_all * args.steps / elapsed
+        it_per_qp = admm_iters / max(qp_solves, 1)
+        # roofline of the dominant kernel (sqp_kernel<RobotOCP>), per launch on this rank
+        bytes_launch = qp_algorithmic_bytes(n, m) * qp_solves
+        flops_launch = qp_algorithmic_flops(n, m, it_per_qp, 1.0) * qp_solves
+        ach_gbs = bytes_launch / (kernel_ms * 1e-3) / 1e9
+        ach_tf = flops_launch / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "box-ADMM QP subproblem solves/s (fused SQP hot path)", "value": value, "unit": "QP solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "mobile_robot OCP nx=3 nu=2 N=6 (P=6,S=1; n=35 m=21 KKT 56), batch=%d per GPU, randomised x0, fp64, "
+                                   "SQP max_iter=10 ls=10, QP = SQPBase defaults" % B,
+                       "global_batch": B * world, "parallelism": "batch-shard x%d (no collectives)" % world},
+            "sqp_solves_per_s": B * world * args.steps / elapsed, "qp_solves_per_step": qp_all, "admm_iters_per_qp": admm_all / max(qp_all, 1),
+            "sqp_solved_fraction": solved_all / (B * world),
+            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach_gbs / PEAK_HBM_GBS,
+                         "traffic": None, "kernel": "sqp_kernel<RobotOCP>", "kernel_ms": kernel_ms,
+                         "note": "algorithmic bytes = 17616 B per QP subproblem x QPs per launch (SURVEY 8d); the path is fp64-VALU/latency bound, see roofline_fp64"},
+            "roofline_fp64": {"bound": "fp64-valu", "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / PEAK_FP64_TFLOPS},
+        }
+        if args.cpu_sample > 0 and world == 1:
+            from oracle import binding as ob   # CPU restatement of the reference algorithm: baseline only, never the product path
+            Bc = min(args.cpu_sample, B)
+            cores = os.cpu_count() or 1
+            oss = ob.sqp_default_settings(); oss.max_iter = wl["max_iter"]; oss.line_search_max_iter = wl["ls_max_iter"]
+            tc = time.perf_counter()
+            xo, lo, io = ob.sqp_solve_batch(ob.MODEL_ROBOT, wl["P"], wl["S"], wl["t0"], wl["tf"], Bc, wl["d"][:Bc], wl["lbx"][:Bc], wl["ubx"][:Bc],
+                                            sqp_settings=oss, pivot=ob.PIVOT_EIGEN, threads=cores)
+            tc = time.perf_counter() - tc
+            cpu_qps = sum(i.iter for i in io)
+            out["cpu_baseline"] = {"value": cpu_qps / tc, "unit": "QP solves/s", "cores": cores, "kind": "port",
+                                   "sample": "first %d instances of the same batch, CPU restatement of the reference SQP+boxADMM (Eigen-like pivoted LDLT), "
+                                             "OpenMP over instances, %.2f s" % (Bc, tc)}
+            xg = d_x.cpu().numpy()[:Bc]
+            same = np.array([i.iter for i in io]) == info["iter"][:Bc]
+            out["parity_vs_cpu_sample"] = {"same_iteration_count_fraction": float(same.mean()),
+                                           "max_abs_dx_on_matching": float(np.abs(xg - xo)[same].max()) if same.any() else None}
+        print(json.dumps(out))
+    ctx.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

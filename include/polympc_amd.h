@@ -1,0 +1,162 @@
+/* polympc_amd — C ABI of the MI355X-native batched SQP / box-ADMM engine.
+ *
+ * This is the ONLY boundary between host code and HIP. Plain C types, plain pointers and sizes, integer
+ * return codes, no exceptions. The reference (PREDICT-EPFL/polympc) has no FFI: its boundary is compile-time
+ * CRTP, so each entry point below names the reference member functions it replaces (file:line under
+ * /root/reference). A maintainer binds these from the reference's C++ with the stub shown in INTEGRATION.md.
+ *
+ * Data layout (all fp64, instance-major, every matrix column-major exactly as an Eigen default matrix):
+ *   H[b]  n*n     Hessian of QP b                 (qp_hessian_t,    qp_base.hpp:114-115)
+ *   A[b]  m*n     general-constraint matrix       (qp_constraint_t, qp_base.hpp:111-112)
+ *   h[b] n | Alb[b],Aub[b] m | xlb[b],xub[b] n     (qp_var_t / qp_dual_a_t)
+ *   x[b]  n primal, y[b] m+n dual = [general | box]  (QPBase::m_x / m_y, qp_base.hpp:129-130, :251)
+ * OCP variable layout: var = [x_0..x_{nn-1} | u_0..u_{nn-1} | p], node 0 = t_stop (continuous_ocp.hpp:757-765);
+ * dual lam = [lam_eq | lam_ineq | lam_box] (continuous_ocp.hpp:1919).
+ * +-inf bounds are passed as IEEE infinities, exactly as the reference does (sqp_base.hpp:75-78).
+ */
+#ifndef POLYMPC_AMD_H
+#define POLYMPC_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pmpc_context pmpc_context; /* one per host thread / device; owns a HIP stream + workspaces */
+
+typedef enum {
+    PMPC_OK = 0,
+    PMPC_ERR_INVALID_ARGUMENT = 1,
+    PMPC_ERR_NO_DEVICE = 2,
+    PMPC_ERR_HIP = 3,
+    PMPC_ERR_UNSUPPORTED_SIZE = 4,
+    PMPC_ERR_UNKNOWN_MODEL = 5
+} pmpc_status;
+
+/* status_t of qp_base.hpp:55-62 (same numeric values) */
+typedef enum {
+    PMPC_QP_SOLVED = 0,
+    PMPC_QP_MAX_ITER_EXCEEDED = 1,
+    PMPC_QP_UNSOLVED = 2,
+    PMPC_QP_UNINITIALIZED = 3,
+    PMPC_QP_INFEASIBLE = 4,
+    PMPC_QP_INCONSISTENT = 5
+} pmpc_qp_status;
+
+/* qp_solver_settings_t, ADMM-related members (qp_base.hpp:17-53). pmpc_qp_settings_default() fills the
+ * reference defaults; pmpc_qp_settings_sqp_default() additionally applies the SQPBase constructor overrides
+ * (sqp_base.hpp:83-90). */
+typedef struct {
+    double eps_rel, eps_abs;
+    int max_iter;
+    double rho, sigma, alpha;
+    int check_termination;
+    int adaptive_rho;
+    double adaptive_rho_tolerance;
+    int adaptive_rho_interval;
+} pmpc_qp_settings;
+
+/* qp_solver_info_t (qp_base.hpp:64-72), one per instance. rho_updates counts rho_vec_update calls of THIS solve
+ * (= number of KKT factorisations), the reference never resets its counter (box_admm.hpp:395). */
+typedef struct {
+    int status, iter, rho_updates;
+    int _pad;
+    double rho_estimate, res_prim, res_dual;
+} pmpc_qp_info;
+
+/* sqp_settings_t (sqp_base.hpp:24-47) + the two override points the reference's tests use:
+ * regularisation: 0 none (default hook, sqp_base.hpp:305), 2 Gershgorin shift (dense_sparse_compare.cpp:109-122)
+ * exact_hessian_every_iter: update_linearisation_dense_impl overridden to linearisation_dense_impl
+ *                           (codegen_test.cpp:381-398) instead of damped BFGS (bfgs.hpp:23-52). */
+typedef struct {
+    double tau, eta, rho, eps_prim, eps_dual;
+    int max_iter, line_search_max_iter;
+    int regularisation;
+    int exact_hessian_every_iter;
+} pmpc_sqp_settings;
+
+/* sqp_status_t (sqp_base.hpp:49-55) */
+typedef enum { PMPC_SQP_SOLVED = 0, PMPC_SQP_MAX_ITER_EXCEEDED = 1, PMPC_SQP_INVALID_SETTINGS = 2 } pmpc_sqp_status;
+
+/* sqp_info_t (sqp_base.hpp:57-61) + the getters primal_norm/dual_norm/constr_violation/cost (:192-195) */
+typedef struct {
+    int iter, qp_solver_iter, status;
+    int _pad;
+    double primal_norm, dual_norm, max_violation, cost;
+} pmpc_sqp_info;
+
+/* built-in OCP definitions (user OCPs are added with PMPC_REGISTER_OCP, see include/polympc/register_ocp.hpp) */
+typedef enum {
+    PMPC_MODEL_ROBOT = 0,        /* tests/control/mpc_wrapper_test.cpp:33-80   NX=3 NU=2 NP=0 ND=1 NG=0 */
+    PMPC_MODEL_CSTR = 1,         /* tests/control/cstr_control_test.cpp:30-113 NX=4 NU=2 */
+    PMPC_MODEL_PARKING = 2,      /* tests/control/dense_sparse_compare.cpp:22-55 NX=3 NU=2 NP=1 ND=1 */
+    PMPC_MODEL_ROBOT_NG = 3,     /* robot + path constraint g = x0^2+x1^2 (NG=1) */
+    PMPC_MODEL_KITE_STANDIN = 4  /* SYNTHETIC 13-state/3-input dimension stand-in (kiteNMPF.h is not in the reference) */
+} pmpc_model;
+
+/* ------------------------------------------------------------------------------------------------------------ */
+const char* pmpc_version(void);
+const char* pmpc_status_string(pmpc_status s);
+
+/* Create a context on HIP device `device` (its own stream). Fails with PMPC_ERR_NO_DEVICE when no GPU is
+ * visible: there is no CPU fallback. `stream` may be NULL (context creates one) or an existing hipStream_t. */
+pmpc_status pmpc_create(int device, void* stream, pmpc_context** ctx);
+pmpc_status pmpc_destroy(pmpc_context* ctx);
+pmpc_status pmpc_synchronize(pmpc_context* ctx);
+
+void pmpc_qp_settings_default(pmpc_qp_settings* s);      /* qp_base.hpp:17-53 */
+void pmpc_qp_settings_sqp_default(pmpc_qp_settings* s);  /* + sqp_base.hpp:83-90 */
+void pmpc_sqp_settings_default(pmpc_sqp_settings* s);    /* sqp_base.hpp:24-47 */
+
+/* Chebyshev–Gauss–Lobatto constants (replaces Chebyshev<P>::compute_nodes / compute_int_weights /
+ * compute_diff_matrix, src/polynomials/ebyshev.hpp:111-214). nodes, weights: P+1; D: (P+1)^2 column-major. */
+pmpc_status pmpc_chebyshev(int P, double* nodes, double* weights, double* D);
+
+/* Batched boxADMM::solve (replaces QPBase::solve -> boxADMM::solve_impl, qp_base.hpp:161-175,
+ * box_admm.hpp:81-205). Host buffers; copies in, solves on the GPU, copies out, synchronises.
+ * x0 / y0 may be NULL (the 7-argument form: zero guesses, box_admm.hpp:81-86). */
+pmpc_status pmpc_qp_boxadmm_solve_batch(pmpc_context* ctx, int B, int n, int m, const double* H, const double* h,
+                                        const double* A, const double* Alb, const double* Aub, const double* xlb,
+                                        const double* xub, const double* x0, const double* y0,
+                                        const pmpc_qp_settings* settings, double* x, double* y, pmpc_qp_info* info);
+
+/* Same with DEVICE pointers (inputs already resident in HBM); asynchronous on the context's stream. */
+pmpc_status pmpc_qp_boxadmm_solve_batch_dev(pmpc_context* ctx, int B, int n, int m, const double* H, const double* h,
+                                            const double* A, const double* Alb, const double* Aub, const double* xlb,
+                                            const double* xub, const double* x0, const double* y0,
+                                            const pmpc_qp_settings* settings, double* x, double* y, pmpc_qp_info* info);
+
+/* Dimensions of the transcription of `model` with Spline<Chebyshev<P>,S> (continuous_ocp.hpp:69-98). */
+pmpc_status pmpc_ocp_dims(int model, int P, int S, int* nx, int* nu, int* np, int* nd, int* ng, int* var_size,
+                          int* num_eq, int* num_ineq);
+
+/* Batched collocation assembly at given points (replaces ContinuousOCP::lagrangian_gradient_hessian<DENSE> and
+ * its callees equalities_linearised / cost_gradient_hessian / cost, continuous_ocp.hpp:797-878,1182-1367,
+ * 2100-2174). Host buffers. Any output may be NULL. var: B*n, d: B*ND, lam: B*(m+n) (NULL = zeros).
+ * mparams: optional model parameters (robot: {q, r, qn} diagonal weights), may be NULL. */
+pmpc_status pmpc_ocp_linearise_batch(pmpc_context* ctx, int model, int P, int S, double t0, double tf,
+                                     const double* mparams, int n_mparams, int B, const double* var, const double* d,
+                                     const double* lam, double* cost, double* constr, double* jac, double* cost_grad,
+                                     double* lag_grad, double* lag_hess);
+
+/* Batched SQPBase::solve (replaces Solver<OCP>::solve() = SQPBase::solve, sqp_base.hpp:569-696, with
+ * linearisation :310-318, update_linearisation :490-504 + BFGS_update bfgs.hpp:23-52, step_size_selection
+ * :380-419, termination :524-529, and the QP of box_admm.hpp:88-205 fused into one kernel per instance).
+ * Host buffers. x_guess/lam_guess may be NULL (zeros, sqp_base.hpp:80-81); lbg/ubg may be NULL when NG == 0.
+ * d: B*ND static parameters (Solver::parameters()). lbx/ubx: B*n (Solver::lower/upper_bound_x()). */
+pmpc_status pmpc_sqp_solve_batch(pmpc_context* ctx, int model, int P, int S, double t0, double tf,
+                                 const double* mparams, int n_mparams, int B, const double* x_guess,
+                                 const double* lam_guess, const double* d, const double* lbx, const double* ubx,
+                                 const double* lbg, const double* ubg, const pmpc_sqp_settings* sqp_settings,
+                                 const pmpc_qp_settings* qp_settings, double* x, double* lam, pmpc_sqp_info* info);
+
+/* Same with DEVICE pointers; asynchronous on the context's stream. */
+pmpc_status pmpc_sqp_solve_batch_dev(pmpc_context* ctx, int model, int P, int S, double t0, double tf,
+                                     const double* mparams, int n_mparams, int B, const double* x_guess,
+                                     const double* lam_guess, const double* d, const double* lbx, const double* ubx,
+                                     const double* lbg, const double* ubg, const pmpc_sqp_settings* sqp_settings,
+                                     const pmpc_qp_settings* qp_settings, double* x, double* lam, pmpc_sqp_info* info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POLYMPC_AMD_H */

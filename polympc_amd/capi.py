@@ -1,0 +1,214 @@
+"""ctypes binding of include/polympc_amd.h (the drop-in C ABI). Plumbing only — every numeric operation happens in
+the HIP library. Fails loudly if the library has not been built (no fallback path exists)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(HERE, "libpolympc_amd.so")
+
+MODEL_ROBOT, MODEL_CSTR, MODEL_PARKING, MODEL_ROBOT_NG, MODEL_KITE_STANDIN = 0, 1, 2, 3, 4
+QP_SOLVED, QP_MAX_ITER_EXCEEDED, QP_UNSOLVED = 0, 1, 2
+SQP_SOLVED, SQP_MAX_ITER_EXCEEDED = 0, 1
+
+EXPORTED_SYMBOLS = [
+    "pmpc_version", "pmpc_status_string", "pmpc_create", "pmpc_destroy", "pmpc_synchronize",
+    "pmpc_qp_settings_default", "pmpc_qp_settings_sqp_default", "pmpc_sqp_settings_default", "pmpc_chebyshev",
+    "pmpc_qp_boxadmm_solve_batch", "pmpc_qp_boxadmm_solve_batch_dev", "pmpc_ocp_dims", "pmpc_ocp_linearise_batch",
+    "pmpc_sqp_solve_batch", "pmpc_sqp_solve_batch_dev",
+]
+
+
+class QPSettings(C.Structure):
+    _fields_ = [("eps_rel", C.c_double), ("eps_abs", C.c_double), ("max_iter", C.c_int), ("rho", C.c_double),
+                ("sigma", C.c_double), ("alpha", C.c_double), ("check_termination", C.c_int),
+                ("adaptive_rho", C.c_int), ("adaptive_rho_tolerance", C.c_double), ("adaptive_rho_interval", C.c_int)]
+
+
+class QPInfo(C.Structure):
+    _fields_ = [("status", C.c_int), ("iter", C.c_int), ("rho_updates", C.c_int), ("_pad", C.c_int),
+                ("rho_estimate", C.c_double), ("res_prim", C.c_double), ("res_dual", C.c_double)]
+
+
+class SQPSettings(C.Structure):
+    _fields_ = [("tau", C.c_double), ("eta", C.c_double), ("rho", C.c_double), ("eps_prim", C.c_double),
+                ("eps_dual", C.c_double), ("max_iter", C.c_int), ("line_search_max_iter", C.c_int),
+                ("regularisation", C.c_int), ("exact_hessian_every_iter", C.c_int)]
+
+
+class SQPInfo(C.Structure):
+    _fields_ = [("iter", C.c_int), ("qp_solver_iter", C.c_int), ("status", C.c_int), ("_pad", C.c_int),
+                ("primal_norm", C.c_double), ("dual_norm", C.c_double), ("max_violation", C.c_double),
+                ("cost", C.c_double)]
+
+
+QP_INFO_DTYPE = np.dtype([("status", "i4"), ("iter", "i4"), ("rho_updates", "i4"), ("_pad", "i4"),
+                          ("rho_estimate", "f8"), ("res_prim", "f8"), ("res_dual", "f8")])
+SQP_INFO_DTYPE = np.dtype([("iter", "i4"), ("qp_solver_iter", "i4"), ("status", "i4"), ("_pad", "i4"),
+                           ("primal_norm", "f8"), ("dual_norm", "f8"), ("max_violation", "f8"), ("cost", "f8")])
+assert QP_INFO_DTYPE.itemsize == C.sizeof(QPInfo) == 40 and SQP_INFO_DTYPE.itemsize == C.sizeof(SQPInfo) == 48
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+def build_library(force=False, verbose=False):
+    """Cross-compile the HIP library for gfx950 in-tree (works without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
+    newest = max(os.path.getmtime(s) for s in srcs + [os.path.join(HERE, "..", "include", "polympc_amd.h")])
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, os.path.join(CSRC, "pmpc_api.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
+                "polympc_amd has no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.pmpc_version.restype = C.c_char_p
+        _lib.pmpc_status_string.restype = C.c_char_p
+    return _lib
+
+
+def _check(st):
+    if st != 0:
+        raise RuntimeError("polympc_amd: " + lib().pmpc_status_string(st).decode())
+
+
+def qp_settings_default():
+    s = QPSettings(); lib().pmpc_qp_settings_default(C.byref(s)); return s
+
+
+def qp_settings_sqp_default():
+    s = QPSettings(); lib().pmpc_qp_settings_sqp_default(C.byref(s)); return s
+
+
+def sqp_settings_default():
+    s = SQPSettings(); lib().pmpc_sqp_settings_default(C.byref(s)); return s
+
+
+def chebyshev(P):
+    nodes = np.zeros(P + 1); w = np.zeros(P + 1); D = np.zeros((P + 1) * (P + 1))
+    dp = C.POINTER(C.c_double)
+    _check(lib().pmpc_chebyshev(P, nodes.ctypes.data_as(dp), w.ctypes.data_as(dp), D.ctypes.data_as(dp)))
+    return nodes, w, D.reshape(P + 1, P + 1).T.copy()
+
+
+def ocp_dims(model, P, S):
+    v = [C.c_int() for _ in range(8)]
+    _check(lib().pmpc_ocp_dims(model, P, S, *[C.byref(a) for a in v]))
+    nx, nu, np_, nd, ng, n, me, mi = [a.value for a in v]
+    return dict(nx=nx, nu=nu, np=np_, nd=nd, ng=ng, n=n, m_eq=me, m_ineq=mi, m=me + mi, nn=P * S + 1)
+
+
+def _h(a):
+    """host array -> (keepalive, pointer)"""
+    if a is None:
+        return None, None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _d(t):
+    """torch CUDA tensor -> device pointer"""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous()
+    return C.cast(C.c_void_p(t.data_ptr()), C.POINTER(C.c_double))
+
+
+class Context:
+    """pmpc_context: one per host thread / GPU."""
+
+    def __init__(self, device=0, stream=None):
+        self._ctx = C.c_void_p()
+        _check(lib().pmpc_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._ctx)))
+
+    def close(self):
+        if self._ctx:
+            lib().pmpc_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(lib().pmpc_synchronize(self._ctx))
+
+    # ------------------------------------------------------------------ QP, host buffers
+    def qp_solve_batch(self, H, h, A, Alb, Aub, xlb, xub, settings=None, x0=None, y0=None):
+        hk, hp = _h(h); B, n = hk.shape
+        Hk, Hp = _h(H); Ak, Ap = _h(A); albk, albp = _h(Alb); aubk, aubp = _h(Aub); xlk, xlp = _h(xlb); xuk, xup = _h(xub)
+        m = albk.shape[1] if albk.ndim == 2 else 0
+        x0k, x0p = _h(x0); y0k, y0p = _h(y0)
+        s = settings or qp_settings_default()
+        x = np.zeros((B, n)); y = np.zeros((B, n + m)); info = np.zeros(B, dtype=QP_INFO_DTYPE)
+        _check(lib().pmpc_qp_boxadmm_solve_batch(self._ctx, B, n, m, Hp, hp, Ap, albp, aubp, xlp, xup, x0p, y0p, C.byref(s),
+                                                 x.ctypes.data_as(C.POINTER(C.c_double)),
+                                                 y.ctypes.data_as(C.POINTER(C.c_double)), C.c_void_p(info.ctypes.data)))
+        return x, y, info
+
+    # ------------------------------------------------------------------ QP, device buffers (torch tensors), asynchronous
+    def qp_solve_batch_dev(self, B, n, m, H, h, A, Alb, Aub, xlb, xub, x, y, info, settings, x0=None, y0=None):
+        _check(lib().pmpc_qp_boxadmm_solve_batch_dev(self._ctx, B, n, m, _d(H), _d(h), _d(A), _d(Alb), _d(Aub), _d(xlb), _d(xub),
+                                                     _d(x0), _d(y0), C.byref(settings), _d(x), _d(y), C.c_void_p(info.data_ptr())))
+
+    # ------------------------------------------------------------------ collocation assembly (host buffers)
+    def ocp_linearise_batch(self, model, P, S, t0, tf, var, d, lam=None, mparams=None):
+        dm = ocp_dims(model, P, S); n, m = dm["n"], dm["m"]
+        vk, vp = _h(var); B = vk.shape[0]
+        dk, dp_ = _h(d); lk, lp = _h(lam); mk, mp = _h(mparams)
+        cost = np.zeros((B, 2)); c = np.zeros((B, m)); jac = np.zeros((B, m * n)); cg = np.zeros((B, n)); lg = np.zeros((B, n))
+        lh = np.zeros((B, n * n))
+        P_ = C.POINTER(C.c_double)
+        f = lib().pmpc_ocp_linearise_batch
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, P_, C.c_int, C.c_int] + [P_] * 9
+        _check(f(self._ctx, model, P, S, t0, tf, mp, 0 if mk is None else len(mk), B, vp, dp_, lp,
+                 *[a.ctypes.data_as(P_) for a in (cost, c, jac, cg, lg, lh)]))
+        return dict(cost=cost[:, 0], cost_values_only=cost[:, 1], c=c, jac=jac.reshape(B, n, m).transpose(0, 2, 1).copy(),
+                    cost_grad=cg, lag_grad=lg, lag_hess=lh.reshape(B, n, n).transpose(0, 2, 1).copy())
+
+    # ------------------------------------------------------------------ SQP, host buffers
+    def sqp_solve_batch(self, model, P, S, t0, tf, B, d, lbx, ubx, lbg=None, ubg=None, x_guess=None, lam_guess=None,
+                        sqp_settings=None, qp_settings=None, mparams=None):
+        dm = ocp_dims(model, P, S); n, m = dm["n"], dm["m"]
+        ss = sqp_settings or sqp_settings_default(); qs = qp_settings or qp_settings_sqp_default()
+        x = np.zeros((B, n)); lam = np.zeros((B, m + n)); info = np.zeros(B, dtype=SQP_INFO_DTYPE)
+        keep = [_h(a) for a in (mparams, x_guess, lam_guess, d, lbx, ubx, lbg, ubg)]
+        P_ = C.POINTER(C.c_double)
+        f = lib().pmpc_sqp_solve_batch
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, P_, C.c_int, C.c_int] + [P_] * 7 + \
+                     [C.POINTER(SQPSettings), C.POINTER(QPSettings), P_, P_, C.c_void_p]
+        _check(f(self._ctx, model, P, S, t0, tf, keep[0][1], 0 if keep[0][0] is None else len(keep[0][0]), B,
+                 *[k[1] for k in keep[1:]], C.byref(ss), C.byref(qs), x.ctypes.data_as(P_), lam.ctypes.data_as(P_),
+                 C.c_void_p(info.ctypes.data)))
+        return x, lam, info
+
+    # ------------------------------------------------------------------ SQP, device buffers (torch tensors), asynchronous
+    def sqp_solve_batch_dev(self, model, P, S, t0, tf, B, d, lbx, ubx, x, lam, info, sqp_settings, qp_settings, lbg=None,
+                            ubg=None, x_guess=None, lam_guess=None, mparams=None):
+        mk, mp = _h(mparams)
+        P_ = C.POINTER(C.c_double)
+        f = lib().pmpc_sqp_solve_batch_dev
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, P_, C.c_int, C.c_int] + [P_] * 7 + \
+                     [C.POINTER(SQPSettings), C.POINTER(QPSettings), P_, P_, C.c_void_p]
+        _check(f(self._ctx, model, P, S, t0, tf, mp, 0 if mk is None else len(mk), B, _d(x_guess), _d(lam_guess), _d(d),
+                 _d(lbx), _d(ubx), _d(lbg), _d(ubg), C.byref(sqp_settings), C.byref(qp_settings), _d(x), _d(lam),
+                 C.c_void_p(info.data_ptr())))

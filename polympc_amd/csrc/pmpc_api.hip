@@ -1,0 +1,452 @@
+// polympc_amd — kernels + the C ABI declared in include/polympc_amd.h (gfx950 only, no CPU fallback).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <tuple>
+#include <vector>
+
+#include "../../include/polympc_amd.h"
+#include "pmpc_cheb.hpp"
+#include "pmpc_models.hpp"
+#include "pmpc_ocp.hpp"
+#include "pmpc_qp.hpp"
+#include "pmpc_sqp.hpp"
+
+using namespace pmpc;
+
+// =====================================================================================================================
+// kernels: one 64-lane workgroup (= one wavefront) per instance; grid = batch
+// =====================================================================================================================
+__global__ __launch_bounds__(64) void qp_boxadmm_kernel(int B, int n, int m, const double* __restrict__ H,
+                                                        const double* __restrict__ h, const double* __restrict__ A,
+                                                        const double* __restrict__ Alb, const double* __restrict__ Aub,
+                                                        const double* __restrict__ xlb, const double* __restrict__ xub,
+                                                        const double* __restrict__ x0, const double* __restrict__ y0,
+                                                        pmpc_qp_settings s, double* __restrict__ x, double* __restrict__ y,
+                                                        pmpc_qp_info* __restrict__ info) {
+    extern __shared__ double smem[];
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    QpLds w;
+    double* p = w.carve(smem, n, m);
+    // stage the vectors the ADMM loop touches every iteration: h, Alb, Aub, xlb, xub
+    double* hL = p; p += n; double* albL = p; p += m; double* aubL = p; p += m; double* xlbL = p; p += n; double* xubL = p; p += n;
+    const int ln = lane_id();
+    for (int i = ln; i < n; i += WAVE) { hL[i] = h[(size_t)b * n + i]; xlbL[i] = xlb[(size_t)b * n + i]; xubL[i] = xub[(size_t)b * n + i]; }
+    for (int i = ln; i < m; i += WAVE) { albL[i] = Alb[(size_t)b * m + i]; aubL[i] = Aub[(size_t)b * m + i]; }
+    wsync();
+    pmpc_qp_info qi;
+    boxadmm_solve(w, n, m, H + (size_t)b * n * n, hL, A + (size_t)b * m * n, albL, aubL, xlbL, xubL,
+                  x0 ? x0 + (size_t)b * n : nullptr, y0 ? y0 + (size_t)b * (n + m) : nullptr, s, qi);
+    for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = w.x[i];
+    for (int i = ln; i < n + m; i += WAVE) y[(size_t)b * (n + m) + i] = w.y[i];
+    if (ln == 0) info[b] = qi;
+}
+static size_t qp_kernel_lds_bytes(int n, int m) { return (QpLds::doubles(n, m) + 3 * (size_t)n + 2 * (size_t)m) * sizeof(double); }
+
+template <class Model>
+__global__ __launch_bounds__(64) void sqp_kernel(Model model, const ChebData* __restrict__ cd, int B,
+                                                 const double* __restrict__ x_guess, const double* __restrict__ lam_guess,
+                                                 const double* __restrict__ d, const double* __restrict__ lbx,
+                                                 const double* __restrict__ ubx, const double* __restrict__ lbg,
+                                                 const double* __restrict__ ubg, pmpc_sqp_settings ss, pmpc_qp_settings qs,
+                                                 double* __restrict__ Hws, double* __restrict__ Aws, double* __restrict__ x,
+                                                 double* __restrict__ lam, pmpc_sqp_info* __restrict__ info) {
+    extern __shared__ double smem[];
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const int P = cd->P, S = cd->S;
+    Ocp<Model> ocp(model, P, S, cd->t_scale);
+    const int n = ocp.dm.n, m = ocp.dm.m, mi = ocp.dm.mi;
+    QpLds qw; SqpLds v;
+    double* p = qw.carve(smem, n, m);
+    p = v.carve(p, n, m, mi);
+    p = ocp.s.carve(p, P, S);
+    double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
+    const int ln = lane_id();
+    for (int i = ln; i < Model::ND; i += WAVE) dL[i] = d[(size_t)b * Model::ND + i];
+    ocp.d = dL;
+    ocp.stage_constants(cd);
+    for (int i = ln; i < n; i += WAVE) {
+        v.x[i] = x_guess ? x_guess[(size_t)b * n + i] : 0.0;
+        v.lbx[i] = lbx[(size_t)b * n + i]; v.ubx[i] = ubx[(size_t)b * n + i];
+    }
+    for (int i = ln; i < m + n; i += WAVE) v.lam[i] = lam_guess ? lam_guess[(size_t)b * (m + n) + i] : 0.0;
+    for (int i = ln; i < mi; i += WAVE) {
+        v.lbg[i] = lbg ? lbg[(size_t)b * mi + i] : -INFINITY;
+        v.ubg[i] = ubg ? ubg[(size_t)b * mi + i] : INFINITY;
+    }
+    wsync();
+    SqpDevice<Model> sqp(ocp, v, qw, Hws + (size_t)b * n * n, Aws + (size_t)b * m * n, ss, qs);
+    pmpc_sqp_info si;
+    sqp.solve(si);
+    for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = v.x[i];
+    for (int i = ln; i < m + n; i += WAVE) lam[(size_t)b * (m + n) + i] = v.lam[i];
+    if (ln == 0) info[b] = si;
+}
+template <class Model> static size_t sqp_kernel_lds_bytes(int P, int S) {
+    OcpDims<Model> dm(P, S);
+    return (QpLds::doubles(dm.n, dm.m) + SqpLds::doubles(dm.n, dm.m, dm.mi) + OcpLds<Model>::doubles(P, S) + 8) * sizeof(double);
+}
+
+// collocation assembly only (used to check A2/A4/A6/A7/A8/A9/A10 against the reference's golden vectors)
+template <class Model>
+__global__ __launch_bounds__(64) void linearise_kernel(Model model, const ChebData* __restrict__ cd, int B,
+                                                       const double* __restrict__ var, const double* __restrict__ d,
+                                                       const double* __restrict__ lam, double* __restrict__ cost,
+                                                       double* __restrict__ constr, double* __restrict__ jac,
+                                                       double* __restrict__ cost_grad, double* __restrict__ lag_grad,
+                                                       double* __restrict__ lag_hess) {
+    extern __shared__ double smem[];
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const int P = cd->P, S = cd->S;
+    Ocp<Model> ocp(model, P, S, cd->t_scale);
+    const int n = ocp.dm.n, m = ocp.dm.m;
+    double* p = ocp.s.carve(smem, P, S);
+    double* xL = p; p += n; double* lamL = p; p += m + n; double* cL = p; p += m; double* gL = p; p += n;
+    double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
+    const int ln = lane_id();
+    for (int i = ln; i < Model::ND; i += WAVE) dL[i] = d[(size_t)b * Model::ND + i];
+    ocp.d = dL;
+    ocp.stage_constants(cd);
+    for (int i = ln; i < n; i += WAVE) xL[i] = var[(size_t)b * n + i];
+    for (int i = ln; i < m + n; i += WAVE) lamL[i] = lam ? lam[(size_t)b * (m + n) + i] : 0.0;
+    wsync();
+    ocp.stage_first_order(xL);
+    ocp.stage_second_order(xL, lamL);
+    double* J = jac + (size_t)b * m * n;
+    double* Hh = lag_hess + (size_t)b * n * n;
+    const double cst = ocp.assemble_first_order(cL, J, gL);
+    ocp.assemble_hessian(Hh);
+    for (int j = ln; j < n; j += WAVE) {
+        double a = 0.0;
+        for (int i = 0; i < m; ++i) a += J[(size_t)j * m + i] * lamL[i];
+        a += gL[j];
+        a += lamL[m + j];
+        lag_grad[(size_t)b * n + j] = a;
+        cost_grad[(size_t)b * n + j] = gL[j];
+    }
+    // values-only paths (cost / constraints), as the line search uses them
+    const double cst2 = ocp.cost(xL);
+    ocp.constraints(xL, cL);
+    for (int i = ln; i < m; i += WAVE) constr[(size_t)b * m + i] = cL[i];
+    if (ln == 0) { cost[2 * b] = cst; cost[2 * b + 1] = cst2; }
+}
+template <class Model> static size_t linearise_kernel_lds_bytes(int P, int S) {
+    OcpDims<Model> dm(P, S);
+    return (OcpLds<Model>::doubles(P, S) + 3 * (size_t)dm.n + 2 * (size_t)dm.m + 16) * sizeof(double);
+}
+
+// =====================================================================================================================
+// context
+// =====================================================================================================================
+struct pmpc_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    size_t lds_limit = 64 * 1024;
+    std::map<std::tuple<int, int, double, double>, ChebData*> cheb_cache;
+    double* ws = nullptr; size_t ws_bytes = 0;       // SQP HBM workspace (H, J)
+    void* scratch[24] = {nullptr}; size_t scratch_bytes[24] = {0};  // host-buffer API staging
+};
+
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "polympc_amd: %s failed: %s (%s:%d)\n", #call, hipGetErrorString(e_), __FILE__, __LINE__); return PMPC_ERR_HIP; } } while (0)
+
+static pmpc_status ensure_ws(pmpc_context* ctx, size_t bytes) {
+    if (ctx->ws_bytes >= bytes) return PMPC_OK;
+    if (ctx->ws) HIPCHK(hipFree(ctx->ws));
+    ctx->ws = nullptr; ctx->ws_bytes = 0;
+    HIPCHK(hipMalloc((void**)&ctx->ws, bytes));
+    ctx->ws_bytes = bytes;
+    return PMPC_OK;
+}
+static pmpc_status ensure_scratch(pmpc_context* ctx, int slot, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 8;
+    if (ctx->scratch_bytes[slot] < bytes) {
+        if (ctx->scratch[slot]) HIPCHK(hipFree(ctx->scratch[slot]));
+        ctx->scratch[slot] = nullptr; ctx->scratch_bytes[slot] = 0;
+        HIPCHK(hipMalloc(&ctx->scratch[slot], bytes));
+        ctx->scratch_bytes[slot] = bytes;
+    }
+    *out = ctx->scratch[slot];
+    return PMPC_OK;
+}
+static pmpc_status get_cheb(pmpc_context* ctx, int P, int S, double t0, double tf, const ChebData** out) {
+    auto key = std::make_tuple(P, S, t0, tf);
+    auto it = ctx->cheb_cache.find(key);
+    if (it != ctx->cheb_cache.end()) { *out = it->second; return PMPC_OK; }
+    ChebData cd;
+    if (!make_cheb_data(P, S, t0, tf, cd)) return PMPC_ERR_UNSUPPORTED_SIZE;
+    ChebData* dptr = nullptr;
+    HIPCHK(hipMalloc((void**)&dptr, sizeof(ChebData)));
+    HIPCHK(hipMemcpyAsync(dptr, &cd, sizeof(ChebData), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // cd is a stack object
+    ctx->cheb_cache[key] = dptr;
+    *out = dptr;
+    return PMPC_OK;
+}
+
+template <class Model> static Model make_model(const double* mp, int nmp) { Model mdl; mdl.set_params(mp, nmp); return mdl; }
+
+// =====================================================================================================================
+// C ABI
+// =====================================================================================================================
+extern "C" {
+
+const char* pmpc_version(void) { return "polympc_amd 0.1 (gfx950)"; }
+const char* pmpc_status_string(pmpc_status s) {
+    switch (s) {
+        case PMPC_OK: return "ok";
+        case PMPC_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case PMPC_ERR_NO_DEVICE: return "no HIP device (there is no CPU fallback)";
+        case PMPC_ERR_HIP: return "HIP runtime error";
+        case PMPC_ERR_UNSUPPORTED_SIZE: return "problem size not supported by the LDS-resident kernels";
+        case PMPC_ERR_UNKNOWN_MODEL: return "unknown model id";
+    }
+    return "?";
+}
+
+pmpc_status pmpc_create(int device, void* stream, pmpc_context** out) {
+    if (!out) return PMPC_ERR_INVALID_ARGUMENT;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return PMPC_ERR_NO_DEVICE;
+    HIPCHK(hipSetDevice(device));
+    pmpc_context* ctx = new pmpc_context();
+    ctx->device = device;
+    if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
+    else { HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    ctx->lds_limit = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 64 * 1024;
+    if (prop.sharedMemPerBlockOptin && (size_t)prop.sharedMemPerBlockOptin < ctx->lds_limit) ctx->lds_limit = prop.sharedMemPerBlockOptin;
+    *out = ctx;
+    return PMPC_OK;
+}
+pmpc_status pmpc_destroy(pmpc_context* ctx) {
+    if (!ctx) return PMPC_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->cheb_cache) (void)hipFree(kv.second);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    for (int i = 0; i < 24; ++i) if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PMPC_OK;
+}
+pmpc_status pmpc_synchronize(pmpc_context* ctx) {
+    if (!ctx) return PMPC_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PMPC_OK;
+}
+
+void pmpc_qp_settings_default(pmpc_qp_settings* s) {
+    s->eps_rel = 1e-3; s->eps_abs = 1e-3; s->max_iter = 1000; s->rho = 1e-1; s->sigma = 1e-6; s->alpha = 1.0;
+    s->check_termination = 25; s->adaptive_rho = 0; s->adaptive_rho_tolerance = 5; s->adaptive_rho_interval = 25;
+}
+void pmpc_qp_settings_sqp_default(pmpc_qp_settings* s) {
+    pmpc_qp_settings_default(s);
+    s->check_termination = 10; s->eps_abs = 1e-4; s->eps_rel = 1e-4; s->max_iter = 100; s->adaptive_rho = 1;
+    s->adaptive_rho_interval = 50; s->alpha = 1.0;
+}
+void pmpc_sqp_settings_default(pmpc_sqp_settings* s) {
+    s->tau = 0.5; s->eta = 0.25; s->rho = 0.5; s->eps_prim = 1e-3; s->eps_dual = 1e-3; s->max_iter = 100;
+    s->line_search_max_iter = 100; s->regularisation = 0; s->exact_hessian_every_iter = 0;
+}
+
+pmpc_status pmpc_chebyshev(int P, double* nodes, double* weights, double* D) {
+    if (P < 1 || !nodes || !weights || !D) return PMPC_ERR_INVALID_ARGUMENT;
+    cheb_nodes(P, nodes); cheb_weights(P, weights); cheb_diff_matrix(P, D);
+    return PMPC_OK;
+}
+
+pmpc_status pmpc_qp_boxadmm_solve_batch_dev(pmpc_context* ctx, int B, int n, int m, const double* H, const double* h,
+                                            const double* A, const double* Alb, const double* Aub, const double* xlb,
+                                            const double* xub, const double* x0, const double* y0,
+                                            const pmpc_qp_settings* settings, double* x, double* y, pmpc_qp_info* info) {
+    if (!ctx || B < 0 || n < 1 || m < 0 || !H || !h || !xlb || !xub || !settings || !x || !y || !info) return PMPC_ERR_INVALID_ARGUMENT;
+    if (m > 0 && (!A || !Alb || !Aub)) return PMPC_ERR_INVALID_ARGUMENT;
+    if ((x0 == nullptr) != (y0 == nullptr)) return PMPC_ERR_INVALID_ARGUMENT;
+    if (B == 0) return PMPC_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t lds = qp_kernel_lds_bytes(n, m);
+    if (lds > ctx->lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;
+    HIPCHK(hipFuncSetAttribute((const void*)qp_boxadmm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(qp_boxadmm_kernel, dim3(B), dim3(WAVE), lds, ctx->stream, B, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0,
+                       *settings, x, y, info);
+    HIPCHK(hipGetLastError());
+    return PMPC_OK;
+}
+
+#define H2D(slot, host, count, devptr)                                                                        \
+    do {                                                                                                      \
+        void* p_ = nullptr;                                                                                   \
+        if (host) {                                                                                           \
+            pmpc_status st_ = ensure_scratch(ctx, slot, (size_t)(count) * sizeof(double), &p_);               \
+            if (st_ != PMPC_OK) return st_;                                                                   \
+            HIPCHK(hipMemcpyAsync(p_, host, (size_t)(count) * sizeof(double), hipMemcpyHostToDevice, ctx->stream)); \
+        }                                                                                                     \
+        devptr = (double*)p_;                                                                                 \
+    } while (0)
+#define DEVOUT(slot, bytes, devptr)                                                \
+    do {                                                                           \
+        void* p_ = nullptr;                                                        \
+        pmpc_status st_ = ensure_scratch(ctx, slot, (size_t)(bytes), &p_);         \
+        if (st_ != PMPC_OK) return st_;                                            \
+        devptr = (decltype(devptr))p_;                                             \
+    } while (0)
+
+pmpc_status pmpc_qp_boxadmm_solve_batch(pmpc_context* ctx, int B, int n, int m, const double* H, const double* h,
+                                        const double* A, const double* Alb, const double* Aub, const double* xlb,
+                                        const double* xub, const double* x0, const double* y0,
+                                        const pmpc_qp_settings* settings, double* x, double* y, pmpc_qp_info* info) {
+    if (!ctx || B < 0 || n < 1 || m < 0 || !H || !h || !xlb || !xub || !settings || !x || !y || !info) return PMPC_ERR_INVALID_ARGUMENT;
+    if (B == 0) return PMPC_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    double *dH, *dh, *dA, *dAlb, *dAub, *dxlb, *dxub, *dx0, *dy0, *dx, *dy; pmpc_qp_info* dinfo;
+    const size_t Bn = (size_t)B * n, Bm = (size_t)B * m;
+    H2D(0, H, Bn * n, dH); H2D(1, h, Bn, dh); H2D(2, (m ? A : nullptr), Bm * n, dA); H2D(3, (m ? Alb : nullptr), Bm, dAlb);
+    H2D(4, (m ? Aub : nullptr), Bm, dAub); H2D(5, xlb, Bn, dxlb); H2D(6, xub, Bn, dxub); H2D(7, x0, Bn, dx0); H2D(8, y0, Bn + Bm, dy0);
+    DEVOUT(9, Bn * sizeof(double), dx); DEVOUT(10, (Bn + Bm) * sizeof(double), dy); DEVOUT(11, (size_t)B * sizeof(pmpc_qp_info), dinfo);
+    if (m == 0) { DEVOUT(2, 8, dA); DEVOUT(3, 8, dAlb); DEVOUT(4, 8, dAub); }
+    pmpc_status st = pmpc_qp_boxadmm_solve_batch_dev(ctx, B, n, m, dH, dh, dA, dAlb, dAub, dxlb, dxub, dx0, dy0, settings, dx, dy, dinfo);
+    if (st != PMPC_OK) return st;
+    HIPCHK(hipMemcpyAsync(x, dx, Bn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(y, dy, (Bn + Bm) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(info, dinfo, (size_t)B * sizeof(pmpc_qp_info), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PMPC_OK;
+}
+
+#define DISPATCH_MODEL(model, F, ...)                                            \
+    switch (model) {                                                             \
+        case PMPC_MODEL_ROBOT: return F<RobotOCP>(__VA_ARGS__);                  \
+        case PMPC_MODEL_CSTR: return F<CstrOCP>(__VA_ARGS__);                    \
+        case PMPC_MODEL_PARKING: return F<ParkingOCP>(__VA_ARGS__);              \
+        case PMPC_MODEL_ROBOT_NG: return F<RobotNGOCP>(__VA_ARGS__);             \
+        case PMPC_MODEL_KITE_STANDIN: return F<KiteStandInOCP>(__VA_ARGS__);     \
+        default: return PMPC_ERR_UNKNOWN_MODEL;                                  \
+    }
+
+}  // extern "C"
+
+template <class Model>
+static pmpc_status dims_impl(int P, int S, int* nx, int* nu, int* np, int* nd, int* ng, int* n, int* me, int* mi) {
+    if (P < 1 || P > MAX_P || S < 1 || P * S + 1 > MAX_NODES) return PMPC_ERR_UNSUPPORTED_SIZE;
+    OcpDims<Model> dm(P, S);
+    if (nx) *nx = Model::NX; if (nu) *nu = Model::NU; if (np) *np = Model::NP; if (nd) *nd = Model::ND; if (ng) *ng = Model::NG;
+    if (n) *n = dm.n; if (me) *me = dm.me; if (mi) *mi = dm.mi;
+    return PMPC_OK;
+}
+
+template <class Model>
+static pmpc_status sqp_dev_impl(pmpc_context* ctx, int P, int S, double t0, double tf, const double* mp, int nmp, int B,
+                                const double* x_guess, const double* lam_guess, const double* d, const double* lbx,
+                                const double* ubx, const double* lbg, const double* ubg, const pmpc_sqp_settings* ss,
+                                const pmpc_qp_settings* qs, double* x, double* lam, pmpc_sqp_info* info) {
+    const ChebData* cd = nullptr;
+    pmpc_status st = get_cheb(ctx, P, S, t0, tf, &cd);
+    if (st != PMPC_OK) return st;
+    OcpDims<Model> dm(P, S);
+    const size_t lds = sqp_kernel_lds_bytes<Model>(P, S);
+    if (lds > ctx->lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;
+    st = ensure_ws(ctx, (size_t)B * ((size_t)dm.n * dm.n + (size_t)dm.m * dm.n) * sizeof(double));
+    if (st != PMPC_OK) return st;
+    double* Hws = ctx->ws; double* Aws = ctx->ws + (size_t)B * dm.n * dm.n;
+    HIPCHK(hipFuncSetAttribute((const void*)sqp_kernel<Model>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    Model mdl = make_model<Model>(mp, nmp);
+    hipLaunchKernelGGL(sqp_kernel<Model>, dim3(B), dim3(WAVE), lds, ctx->stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
+                       *ss, *qs, Hws, Aws, x, lam, info);
+    HIPCHK(hipGetLastError());
+    return PMPC_OK;
+}
+
+template <class Model>
+static pmpc_status linearise_impl(pmpc_context* ctx, int P, int S, double t0, double tf, const double* mp, int nmp, int B,
+                                  const double* var, const double* d, const double* lam, double* cost, double* constr, double* jac,
+                                  double* cost_grad, double* lag_grad, double* lag_hess) {
+    const ChebData* cd = nullptr;
+    pmpc_status st = get_cheb(ctx, P, S, t0, tf, &cd);
+    if (st != PMPC_OK) return st;
+    OcpDims<Model> dm(P, S);
+    const int n = dm.n, m = dm.m;
+    const size_t lds = linearise_kernel_lds_bytes<Model>(P, S);
+    if (lds > ctx->lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;
+    double *dvar, *dd, *dlam, *dcost, *dc, *dj, *dcg, *dlg, *dlh;
+    H2D(0, var, (size_t)B * n, dvar); H2D(1, (Model::ND ? d : nullptr), (size_t)B * Model::ND, dd); H2D(2, lam, (size_t)B * (m + n), dlam);
+    if (!Model::ND) DEVOUT(1, 8, dd);
+    DEVOUT(3, (size_t)B * 2 * sizeof(double), dcost); DEVOUT(4, (size_t)B * m * sizeof(double), dc);
+    DEVOUT(5, (size_t)B * m * n * sizeof(double), dj); DEVOUT(6, (size_t)B * n * sizeof(double), dcg);
+    DEVOUT(7, (size_t)B * n * sizeof(double), dlg); DEVOUT(8, (size_t)B * n * n * sizeof(double), dlh);
+    HIPCHK(hipFuncSetAttribute((const void*)linearise_kernel<Model>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    Model mdl = make_model<Model>(mp, nmp);
+    hipLaunchKernelGGL(linearise_kernel<Model>, dim3(B), dim3(WAVE), lds, ctx->stream, mdl, cd, B, dvar, dd, dlam, dcost, dc, dj, dcg, dlg, dlh);
+    HIPCHK(hipGetLastError());
+    std::vector<double> c2((size_t)B * 2);
+    HIPCHK(hipMemcpyAsync(c2.data(), dcost, (size_t)B * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (constr) HIPCHK(hipMemcpyAsync(constr, dc, (size_t)B * m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (jac) HIPCHK(hipMemcpyAsync(jac, dj, (size_t)B * m * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (cost_grad) HIPCHK(hipMemcpyAsync(cost_grad, dcg, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (lag_grad) HIPCHK(hipMemcpyAsync(lag_grad, dlg, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (lag_hess) HIPCHK(hipMemcpyAsync(lag_hess, dlh, (size_t)B * n * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (cost) for (int b = 0; b < 2 * B; ++b) cost[b] = c2[b];
+    return PMPC_OK;
+}
+
+extern "C" {
+
+pmpc_status pmpc_ocp_dims(int model, int P, int S, int* nx, int* nu, int* np, int* nd, int* ng, int* var_size, int* num_eq, int* num_ineq) {
+    DISPATCH_MODEL(model, dims_impl, P, S, nx, nu, np, nd, ng, var_size, num_eq, num_ineq);
+}
+
+pmpc_status pmpc_ocp_linearise_batch(pmpc_context* ctx, int model, int P, int S, double t0, double tf, const double* mparams,
+                                     int n_mparams, int B, const double* var, const double* d, const double* lam, double* cost,
+                                     double* constr, double* jac, double* cost_grad, double* lag_grad, double* lag_hess) {
+    if (!ctx || B < 1 || !var) return PMPC_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(ctx->device));
+    DISPATCH_MODEL(model, linearise_impl, ctx, P, S, t0, tf, mparams, n_mparams, B, var, d, lam, cost, constr, jac, cost_grad, lag_grad, lag_hess);
+}
+
+pmpc_status pmpc_sqp_solve_batch_dev(pmpc_context* ctx, int model, int P, int S, double t0, double tf, const double* mparams,
+                                     int n_mparams, int B, const double* x_guess, const double* lam_guess, const double* d,
+                                     const double* lbx, const double* ubx, const double* lbg, const double* ubg,
+                                     const pmpc_sqp_settings* ss, const pmpc_qp_settings* qs, double* x, double* lam,
+                                     pmpc_sqp_info* info) {
+    if (!ctx || B < 0 || !lbx || !ubx || !ss || !qs || !x || !lam || !info) return PMPC_ERR_INVALID_ARGUMENT;
+    if (ss->regularisation != 0 && ss->regularisation != 2) return PMPC_ERR_INVALID_ARGUMENT;
+    if (B == 0) return PMPC_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    DISPATCH_MODEL(model, sqp_dev_impl, ctx, P, S, t0, tf, mparams, n_mparams, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, x, lam, info);
+}
+
+pmpc_status pmpc_sqp_solve_batch(pmpc_context* ctx, int model, int P, int S, double t0, double tf, const double* mparams,
+                                 int n_mparams, int B, const double* x_guess, const double* lam_guess, const double* d,
+                                 const double* lbx, const double* ubx, const double* lbg, const double* ubg,
+                                 const pmpc_sqp_settings* ss, const pmpc_qp_settings* qs, double* x, double* lam, pmpc_sqp_info* info) {
+    if (!ctx || B < 0 || !lbx || !ubx || !ss || !qs || !x || !lam || !info) return PMPC_ERR_INVALID_ARGUMENT;
+    if (B == 0) return PMPC_OK;
+    int nx, nu, np, nd, ng, n, me, mi;
+    pmpc_status st = pmpc_ocp_dims(model, P, S, &nx, &nu, &np, &nd, &ng, &n, &me, &mi);
+    if (st != PMPC_OK) return st;
+    if (nd > 0 && !d) return PMPC_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int m = me + mi;
+    double *dxg, *dlg, *dd, *dlbx, *dubx, *dlbg, *dubg, *dx, *dlam; pmpc_sqp_info* dinfo;
+    H2D(12, x_guess, (size_t)B * n, dxg); H2D(13, lam_guess, (size_t)B * (m + n), dlg); H2D(14, (nd ? d : nullptr), (size_t)B * nd, dd);
+    if (!nd) DEVOUT(14, 8, dd);
+    H2D(15, lbx, (size_t)B * n, dlbx); H2D(16, ubx, (size_t)B * n, dubx);
+    H2D(17, (mi ? lbg : nullptr), (size_t)B * mi, dlbg); H2D(18, (mi ? ubg : nullptr), (size_t)B * mi, dubg);
+    DEVOUT(19, (size_t)B * n * sizeof(double), dx); DEVOUT(20, (size_t)B * (m + n) * sizeof(double), dlam);
+    DEVOUT(21, (size_t)B * sizeof(pmpc_sqp_info), dinfo);
+    st = pmpc_sqp_solve_batch_dev(ctx, model, P, S, t0, tf, mparams, n_mparams, B, dxg, dlg, dd, dlbx, dubx, dlbg, dubg, ss, qs, dx, dlam, dinfo);
+    if (st != PMPC_OK) return st;
+    HIPCHK(hipMemcpyAsync(x, dx, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(lam, dlam, (size_t)B * (m + n) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(info, dinfo, (size_t)B * sizeof(pmpc_sqp_info), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PMPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,342 @@
+// polympc_amd — Chebyshev-collocation transcription on the device, one wavefront per OCP instance.
+//
+// Replaces the DENSE members of ContinuousOCP (/root/reference/src/control/continuous_ocp.hpp): equalities :739-766,
+// inequalities :770-782, equalities_linearised :797-878, _inequalities_linearised_dense :546-575, cost :1182-1207,
+// cost_gradient :1210-1249, cost_gradient_hessian :1256-1367, lagrangian_gradient :1960-1975,
+// lagrangian_gradient_hessian :2100-2174.
+//
+// Mapping: lane k evaluates collocation node k (dynamics / Lagrange term / path constraints with forward AD) and
+// stages the per-node values and derivative blocks in LDS; the wave then assembles the dense Jacobian (into the
+// instance's HBM workspace, column-major m x n) and Hessian (n x n). The Chebyshev differentiation matrix, the
+// Clenshaw–Curtis weights and the time grid are staged once per workgroup in LDS. Second derivatives are taken one
+// seed direction at a time (Dual<Dual<double,NDER>,1>) to keep the register footprint at 2*(NDER+1) doubles per AD
+// variable; every Hessian entry goes through the same operation sequence as the reference's nested AutoDiffScalar.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "pmpc_ad.hpp"
+#include "pmpc_models.hpp"
+#include "pmpc_qp.hpp"
+
+namespace pmpc {
+
+constexpr int MAX_P = 15;      // polynomial order per segment
+constexpr int MAX_NODES = 64;  // P*S+1
+
+// host-computed collocation constants (pmpc_chebyshev / pmpc_cheb.hpp), resident in HBM, staged to LDS per workgroup
+struct ChebData {
+    int P, S, NN, _pad;
+    double t_start, t_stop, t_scale;
+    double D[(MAX_P + 1) * (MAX_P + 1)];  // column-major (P+1)x(P+1)
+    double w[MAX_P + 1];
+    double tn[MAX_NODES];                 // time nodes, descending (node 0 = t_stop)
+};
+
+template <class Model>
+struct OcpDims {
+    enum { NX = Model::NX, NU = Model::NU, NP = Model::NP, ND = Model::ND, NG = Model::NG, NDER = NX + NU + NP };
+    int NN, VARX, VARU, n, me, mi, m;
+    __host__ __device__ OcpDims(int P, int S) {
+        NN = P * S + 1; VARX = NX * NN; VARU = NU * NN; n = VARX + VARU + NP; me = VARX; mi = NG * NN; m = me + mi;
+    }
+    __host__ __device__ int gidx(int k, int i) const {
+        return i < NX ? k * NX + i : (i < NX + NU ? VARX + k * NU + (i - NX) : VARX + VARU + (i - NX - NU));
+    }
+};
+
+// per-instance LDS staging for the transcription
+template <class Model>
+struct OcpLds {
+    using Dm = OcpDims<Model>;
+    enum { NX = Dm::NX, NU = Dm::NU, NP = Dm::NP, NG = Dm::NG, NDER = Dm::NDER };
+    double *D, *w, *tn;                                 // collocation constants
+    double *fval, *fjac, *Lval, *Lgrad, *gval, *gjac;   // per node: f (NX), df (NX*NDER), L, dL (NDER), g (NG), dg (NG*NDER)
+    double *Lhes, *dhes;                                // per node: d2L (NDER^2), sum lam * d2(f,g) (NDER^2)
+    double *Mval, *Mgrad, *Mhes;                        // Mayer term at node 0
+    double *DX;                                         // D*X per node (NX)
+    __host__ __device__ static size_t doubles(int P, int S) {
+        const int NN = P * S + 1;
+        return (size_t)(P + 1) * (P + 1) + (P + 1) + NN + (size_t)NN * (NX + NX * NDER + 1 + NDER + NG + NG * NDER + 2 * NDER * NDER + NX) +
+               1 + NDER + NDER * NDER + 8;
+    }
+    __device__ double* carve(double* p, int P, int S) {
+        const int NN = P * S + 1;
+        D = p; p += (P + 1) * (P + 1); w = p; p += P + 1; tn = p; p += NN;
+        fval = p; p += NN * NX; fjac = p; p += NN * NX * NDER; Lval = p; p += NN; Lgrad = p; p += NN * NDER;
+        gval = p; p += NN * NG; gjac = p; p += NN * NG * NDER; Lhes = p; p += NN * NDER * NDER; dhes = p; p += NN * NDER * NDER;
+        Mval = p; p += 1; Mgrad = p; p += NDER; Mhes = p; p += NDER * NDER; DX = p; p += NN * NX;
+        return p;
+    }
+};
+
+template <class Model>
+struct Ocp {
+    using Dm = OcpDims<Model>;
+    enum { NX = Dm::NX, NU = Dm::NU, NP = Dm::NP, ND = Dm::ND, NG = Dm::NG, NDER = Dm::NDER };
+    using ad1 = Dual<double, NDER>;
+    using ad2c = Dual<ad1, 1>;  // one outer seed direction at a time
+
+    const Model& model;
+    Dm dm;
+    int P, S;
+    double ts;
+    OcpLds<Model> s;
+    const double* d;  // static parameters of this instance (ND)
+
+    __device__ Ocp(const Model& mdl, int P_, int S_, double t_scale) : model(mdl), dm(P_, S_), P(P_), S(S_), ts(t_scale), d(nullptr) {}
+
+    __device__ void stage_constants(const ChebData* cd) {
+        const int ln = lane_id();
+        for (int i = ln; i < (P + 1) * (P + 1); i += WAVE) s.D[i] = cd->D[i];
+        for (int i = ln; i <= P; i += WAVE) s.w[i] = cd->w[i];
+        for (int i = ln; i < dm.NN; i += WAVE) s.tn[i] = cd->tn[i];
+        wsync();
+    }
+
+    // (segment, row) whose D row produces node k: later segments overwrite the junction row (:750-751)
+    __device__ void seg_row(int k, int& seg, int& row) const {
+        if (k == dm.NN - 1) { seg = S - 1; row = P; } else { seg = k / P; row = k % P; }
+    }
+
+    // ---- values only: c = D*X - t_scale*f, g (equalities :739-766, inequalities :770-782)
+    __device__ void constraints(const double* var, double* c) {
+        for (int k = lane_id(); k < dm.NN; k += WAVE) {
+            double f[NX > 0 ? NX : 1];
+            for (int q = 0; q < NX; ++q) f[q] = 0.0;
+            double tk = s.tn[k];
+            model.template dynamics_impl<double>(cref<double>(var + k * NX), cref<double>(var + dm.VARX + k * NU),
+                                                 cref<double>(var + dm.VARX + dm.VARU), cref<double>(d), tk, vref<double>(f));
+            int seg, row; seg_row(k, seg, row);
+            for (int q = 0; q < NX; ++q) {
+                double acc = 0.0;
+                for (int j = 0; j <= P; ++j) acc += s.D[row + j * (P + 1)] * var[(seg * P + j) * NX + q];
+                double cv = acc;
+                cv -= ts * f[q];
+                c[k * NX + q] = cv;
+            }
+            if (NG > 0) {
+                double g[NG > 0 ? NG : 1];
+                for (int q = 0; q < NG; ++q) g[q] = 0.0;
+                model.template inequality_constraints_impl<double>(cref<double>(var + k * NX), cref<double>(var + dm.VARX + k * NU),
+                                                                   cref<double>(var + dm.VARX + dm.VARU), cref<double>(d), tk, vref<double>(g));
+                for (int q = 0; q < NG; ++q) c[dm.me + k * NG + q] = g[q];
+            }
+        }
+        wsync();
+    }
+
+    // ---- cost (:1182-1207)
+    __device__ double cost(const double* var) {
+        for (int k = lane_id(); k < dm.NN; k += WAVE) {
+            double L = 0.0;
+            model.template lagrange_term_impl<double>(cref<double>(var + k * NX), cref<double>(var + dm.VARX + k * NU),
+                                                      cref<double>(var + dm.VARX + dm.VARU), cref<double>(d), s.tn[k], L);
+            s.Lval[k] = L;
+        }
+        wsync();
+        double c = 0.0;
+        for (int sg = 0; sg < S; ++sg)
+            for (int k = 0; k <= P; ++k) c += ts * s.w[k] * s.Lval[sg * P + k];
+        double M = 0.0;
+        model.template mayer_term_impl<double>(cref<double>(var), cref<double>(var + dm.VARX), cref<double>(var + dm.VARX + dm.VARU),
+                                               cref<double>(d), s.tn[0], M);
+        c += M;
+        wsync();
+        return c;
+    }
+
+    template <class T> __device__ void seed1(const double* var, int k, T* x, T* u, T* p) const {
+        int idx = 0;
+        for (int i = 0; i < NX; ++i, ++idx) { x[i] = T(var[k * NX + i]); x[i].d[idx] = 1.0; }
+        for (int i = 0; i < NU; ++i, ++idx) { u[i] = T(var[dm.VARX + k * NU + i]); u[i].d[idx] = 1.0; }
+        for (int i = 0; i < NP; ++i, ++idx) { p[i] = T(var[dm.VARX + dm.VARU + i]); p[i].d[idx] = 1.0; }
+    }
+    // second-order seeding for outer direction `dir` (continuous_ocp.hpp:691-735 restricted to one outer partial)
+    __device__ void seed2(const double* var, int k, int dir, ad2c* x, ad2c* u, ad2c* p) const {
+        int idx = 0;
+        auto mk = [&](double val, int id) { ad2c r; r.v = ad1(val); r.v.d[id] = 1.0; r.d[0] = ad1(id == dir ? 1.0 : 0.0); return r; };
+        for (int i = 0; i < NX; ++i, ++idx) x[i] = mk(var[k * NX + i], idx);
+        for (int i = 0; i < NU; ++i, ++idx) u[i] = mk(var[dm.VARX + k * NU + i], idx);
+        for (int i = 0; i < NP; ++i, ++idx) p[i] = mk(var[dm.VARX + dm.VARU + i], idx);
+    }
+
+    // ---- per-node first-order stage: f, df, L, dL, g, dg, DX, Mayer value+gradient
+    __device__ void stage_first_order(const double* var) {
+        for (int k = lane_id(); k < dm.NN; k += WAVE) {
+            ad1 x[NX > 0 ? NX : 1], u[NU > 0 ? NU : 1], p[NP > 0 ? NP : 1], y[NX > 0 ? NX : 1];
+            seed1<ad1>(var, k, x, u, p);
+            for (int q = 0; q < NX; ++q) y[q] = ad1(0.0);
+            ad1 tk(s.tn[k]);
+            model.template dynamics_impl<ad1>(cref<ad1>(x), cref<ad1>(u), cref<ad1>(p), cref<double>(d), tk, vref<ad1>(y));
+            for (int q = 0; q < NX; ++q) {
+                s.fval[k * NX + q] = y[q].v;
+                for (int i = 0; i < NDER; ++i) s.fjac[(k * NX + q) * NDER + i] = y[q].d[i];
+            }
+            ad1 L(0.0);
+            model.template lagrange_term_impl<ad1>(cref<ad1>(x), cref<ad1>(u), cref<ad1>(p), cref<double>(d), s.tn[k], L);
+            s.Lval[k] = L.v;
+            for (int i = 0; i < NDER; ++i) s.Lgrad[k * NDER + i] = L.d[i];
+            if (NG > 0) {
+                ad1 g[NG > 0 ? NG : 1];
+                for (int q = 0; q < NG; ++q) g[q] = ad1(0.0);
+                model.template inequality_constraints_impl<ad1>(cref<ad1>(x), cref<ad1>(u), cref<ad1>(p), cref<double>(d), s.tn[k], vref<ad1>(g));
+                for (int q = 0; q < NG; ++q) {
+                    s.gval[k * NG + q] = g[q].v;
+                    for (int i = 0; i < NDER; ++i) s.gjac[(k * NG + q) * NDER + i] = g[q].d[i];
+                }
+            }
+            int seg, row; seg_row(k, seg, row);
+            for (int q = 0; q < NX; ++q) {
+                double acc = 0.0;
+                for (int j = 0; j <= P; ++j) acc += s.D[row + j * (P + 1)] * var[(seg * P + j) * NX + q];
+                s.DX[k * NX + q] = acc;
+            }
+            if (k == 0) {
+                ad1 M(0.0);
+                model.template mayer_term_impl<ad1>(cref<ad1>(x), cref<ad1>(u), cref<ad1>(p), cref<double>(d), s.tn[0], M);
+                s.Mval[0] = M.v;
+                for (int i = 0; i < NDER; ++i) s.Mgrad[i] = M.d[i];
+            }
+        }
+        wsync();
+    }
+
+    // ---- per-node second-order stage: d2L, Mayer Hessian, and hes = -t_scale*sum lam_q d2f_q + sum lam_g d2g (:2128-2157)
+    __device__ void stage_second_order(const double* var, const double* lam) {
+        for (int k = lane_id(); k < dm.NN; k += WAVE) {
+            for (int dir = 0; dir < NDER; ++dir) {
+                ad2c x[NX > 0 ? NX : 1], u[NU > 0 ? NU : 1], p[NP > 0 ? NP : 1], y[NX > 0 ? NX : 1];
+                seed2(var, k, dir, x, u, p);
+                ad2c L(0.0);
+                model.template lagrange_term_impl<ad2c>(cref<ad2c>(x), cref<ad2c>(u), cref<ad2c>(p), cref<double>(d), s.tn[k], L);
+                // hes.col(dir) = L.d[dir].d  => hes(r, dir)
+                for (int r = 0; r < NDER; ++r) s.Lhes[(k * NDER + dir) * NDER + r] = L.d[0].d[r];
+                for (int q = 0; q < NX; ++q) y[q] = ad2c(0.0);
+                ad2c tk(s.tn[k]);
+                model.template dynamics_impl<ad2c>(cref<ad2c>(x), cref<ad2c>(u), cref<ad2c>(p), cref<double>(d), tk, vref<ad2c>(y));
+                double col[NDER];
+                for (int r = 0; r < NDER; ++r) col[r] = 0.0;
+                for (int q = 0; q < NX; ++q) {
+                    const double coeff = -lam[q + k * NX] * ts;
+                    for (int r = 0; r < NDER; ++r) col[r] += coeff * y[q].d[0].d[r];
+                }
+                if (NG > 0) {
+                    ad2c g[NG > 0 ? NG : 1];
+                    for (int q = 0; q < NG; ++q) g[q] = ad2c(0.0);
+                    model.template inequality_constraints_impl<ad2c>(cref<ad2c>(x), cref<ad2c>(u), cref<ad2c>(p), cref<double>(d), s.tn[k], vref<ad2c>(g));
+                    for (int q = 0; q < NG; ++q) {
+                        const double coeff = lam[q + k * NG + dm.me];
+                        for (int r = 0; r < NDER; ++r) col[r] += coeff * g[q].d[0].d[r];
+                    }
+                }
+                for (int r = 0; r < NDER; ++r) s.dhes[(k * NDER + dir) * NDER + r] = col[r];
+                if (k == 0) {
+                    ad2c M(0.0);
+                    model.template mayer_term_impl<ad2c>(cref<ad2c>(x), cref<ad2c>(u), cref<ad2c>(p), cref<double>(d), s.tn[0], M);
+                    for (int r = 0; r < NDER; ++r) s.Mhes[dir * NDER + r] = M.d[0].d[r];
+                }
+            }
+        }
+        wsync();
+    }
+
+    // ---- assemble c (m), Jacobian J (m x n column-major in HBM), cost value and cost gradient from the first-order stage
+    // equalities_linearised :797-878, _inequalities_linearised_dense :546-575, cost_gradient :1210-1249
+    __device__ double assemble_first_order(double* c, double* __restrict__ J, double* cost_grad) {
+        const int ln = lane_id();
+        const int n = dm.n, m = dm.m;
+        for (int e = ln; e < m * n; e += WAVE) J[e] = 0.0;
+        for (int i = ln; i < n; i += WAVE) cost_grad[i] = 0.0;
+        __threadfence_block();
+        wsync();
+        for (int k = ln; k < dm.NN; k += WAVE) {
+            int seg, row; seg_row(k, seg, row);
+            for (int q = 0; q < NX; ++q) {
+                const int r = k * NX + q;
+                if (k < dm.NN - 1) {
+                    for (int j = 0; j <= P; ++j) J[r + (size_t)((seg * P + j) * NX + q) * m] = s.D[row + j * (P + 1)] * 1.0;
+                } else {  // last node row = -reverse(first block row) (:845-846)
+                    for (int j = 0; j <= P; ++j) J[r + (size_t)(dm.VARX - NX * (P + 1) + j * NX + q) * m] = -s.D[0 + (P - j) * (P + 1)];
+                }
+                double cv = -ts * s.fval[r];
+                cv += s.DX[r];
+                c[r] = cv;
+                for (int i = 0; i < NDER; ++i) J[r + (size_t)dm.gidx(k, i) * m] -= ts * s.fjac[r * NDER + i];
+            }
+            for (int q = 0; q < NG; ++q) {
+                const int r = dm.me + k * NG + q;
+                c[r] = s.gval[k * NG + q];
+                for (int i = 0; i < NDER; ++i) J[r + (size_t)dm.gidx(k, i) * m] = s.gjac[(k * NG + q) * NDER + i];
+            }
+            // cost gradient, x/u parts: contributions in the reference's loop order (segment s-1 as node P, then segment s as node 0)
+            double gacc[NX + NU > 0 ? NX + NU : 1];
+            for (int i = 0; i < NX + NU; ++i) gacc[i] = 0.0;
+            if (k % P == 0 && k > 0) { const double wk = ts * s.w[P]; for (int i = 0; i < NX + NU; ++i) gacc[i] += wk * s.Lgrad[k * NDER + i]; }
+            if (k < dm.NN - 1) { const double wk = ts * s.w[k % P]; for (int i = 0; i < NX + NU; ++i) gacc[i] += wk * s.Lgrad[k * NDER + i]; }
+            if (k == 0) for (int i = 0; i < NX + NU; ++i) gacc[i] += s.Mgrad[i];
+            for (int i = 0; i < NX + NU; ++i) cost_grad[dm.gidx(k, i)] = gacc[i];
+        }
+        // p-part of the cost gradient: sequential over (segment, node) as in the reference, then Mayer
+        if constexpr (NP > 0) {
+            for (int i = ln; i < NP; i += WAVE) {
+                double a = 0.0;
+                for (int sg = 0; sg < S; ++sg)
+                    for (int k = 0; k <= P; ++k) a += (ts * s.w[k]) * s.Lgrad[(sg * P + k) * NDER + NX + NU + i];
+                a += s.Mgrad[NX + NU + i];
+                cost_grad[dm.VARX + dm.VARU + i] = a;
+            }
+        }
+        double cst = 0.0;
+        for (int sg = 0; sg < S; ++sg)
+            for (int k = 0; k <= P; ++k) cst += ts * s.w[k] * s.Lval[sg * P + k];
+        cst += s.Mval[0];
+        __threadfence_block();
+        wsync();
+        return cst;
+    }
+
+    // ---- assemble the Lagrangian Hessian H (n x n column-major in HBM) from the second-order stage
+    // cost_gradient_hessian :1256-1367 (+ quirk Q4) and the lam-weighted blocks of :2128-2173
+    __device__ void assemble_hessian(double* __restrict__ H) {
+        const int ln = lane_id();
+        const int n = dm.n;
+        for (int e = ln; e < n * n; e += WAVE) H[e] = 0.0;
+        __threadfence_block();
+        wsync();
+        // blocks that do not involve the (p,p) corner are private to their node
+        for (int k = ln; k < dm.NN; k += WAVE) {
+            for (int i = 0; i < NDER; ++i)
+                for (int r = 0; r < NDER; ++r) {
+                    if (r >= NX + NU && i >= NX + NU) continue;
+                    double a = 0.0;
+                    if (k % P == 0 && k > 0) a += (ts * s.w[P]) * s.Lhes[(k * NDER + i) * NDER + r];
+                    if (k < dm.NN - 1) a += (ts * s.w[k % P]) * s.Lhes[(k * NDER + i) * NDER + r];
+                    if (k == 0) a += s.Mhes[i * NDER + r];
+                    a += s.dhes[(k * NDER + i) * NDER + r];
+                    H[dm.gidx(k, r) + (size_t)dm.gidx(k, i) * n] = a;
+                }
+        }
+        if constexpr (NP > 0) {
+            __threadfence_block();
+            wsync();
+            // (p,p) corner: sequential accumulation in reference order; Mayer pp-block lands in the bottom-LEFT corner (Q4)
+            for (int e = ln; e < NP * NP; e += WAVE) {
+                const int r = e % NP, i = e / NP;
+                double a = 0.0;
+                for (int sg = 0; sg < S; ++sg)
+                    for (int k = 0; k <= P; ++k) a += (ts * s.w[k]) * s.Lhes[((sg * P + k) * NDER + NX + NU + i) * NDER + NX + NU + r];
+                for (int k = 0; k < dm.NN; ++k) a += s.dhes[(k * NDER + NX + NU + i) * NDER + NX + NU + r];
+                H[(n - NP + r) + (size_t)(n - NP + i) * n] = a;
+            }
+            __threadfence_block();
+            wsync();
+            for (int e = ln; e < NP * NP; e += WAVE) {
+                const int a_ = e % NP, b_ = e / NP;
+                H[(n - NP + a_) + (size_t)b_ * n] += s.Mhes[b_ * NDER + (NDER - NP + a_)];
+            }
+        }
+        __threadfence_block();
+        wsync();
+    }
+};
+
+}  // namespace pmpc

@@ -1,0 +1,277 @@
+// polympc_amd — wave-cooperative dense box-ADMM QP solve (device side), one 64-lane wavefront per QP instance.
+//
+// Replaces boxADMM::solve_impl and its helpers (/root/reference/src/solvers/box_admm.hpp:88-223,336-452) together with
+// the Eigen::LDLT factor/solve it calls (src/utils/helpers.hpp:38-43). Same update order, constants and quirks
+// (Q1: x = alpha*x_tilde; x += (1-alpha)*x — box_admm.hpp:129-130).
+//
+// Layout: the (n+m)x(n+m) KKT matrix lives in LDS, column-major with an odd leading dimension (bank-conflict-free
+// column AND row walks); lane i owns KKT row i (rows i, i+64, ... when n+m > 64). The LDL^T uses the static
+// elimination order (no pivoting — K is symmetric quasi-definite), right-looking, fused
+// multiply-add on the trailing update and the substitutions. H and A stay in HBM/L2 and are streamed only when the
+// residuals are evaluated (every check_termination-th iteration).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/polympc_amd.h"
+
+namespace pmpc {
+
+constexpr int WAVE = 64;
+constexpr double RHO_MIN = 1e-6, RHO_MAX = 1e+6, RHO_EQ_FACTOR = 1e+3;   // box_admm.hpp:56-59
+constexpr double LOOSE_BOUNDS_THRESH = 1e+10, EQ_TOL = 1e-4;            // qp_base.hpp:124-125
+constexpr double DIV_BY_ZERO_REGUL = 10e-10;                            // qp_base.hpp:79-82
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+// one wavefront per workgroup: this is a compiler + LDS ordering fence, not a cross-wave barrier
+__device__ __forceinline__ void wsync() { __syncthreads(); }
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+// sequential (index-ordered) sum of an LDS vector, evaluated redundantly by every lane (broadcast reads): the
+// same association order as the reference's scalar loops, no cross-lane traffic
+__device__ __forceinline__ double seq_sum(const double* v, int n) {
+    double a = 0.0;
+    for (int i = 0; i < n; ++i) a += v[i];
+    return a;
+}
+__device__ __forceinline__ double seq_dot(const double* a, const double* b, int n) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += a[i] * b[i];
+    return s;
+}
+__device__ __forceinline__ double lds_inf_norm(const double* v, int n) {
+    double r = 0.0;
+    for (int i = lane_id(); i < n; i += WAVE) r = fmax(r, fabs(v[i]));
+    return wave_max(r);
+}
+
+// qp_base.hpp:195-222 ; 0 inequality, 1 equality, 2 loose
+__device__ __forceinline__ int classify_bounds(double lb, double ub) {
+    if (lb < -LOOSE_BOUNDS_THRESH && ub > LOOSE_BOUNDS_THRESH) return 2;
+    if (ub - lb < EQ_TOL) return 1;
+    return 0;
+}
+__device__ __forceinline__ double rho_of(int type, double rho0) {  // box_admm.hpp:357-396
+    return type == 2 ? RHO_MIN : (type == 1 ? RHO_EQ_FACTOR * rho0 : rho0);
+}
+
+// LDS work area of one QP instance
+struct QpLds {
+    double* K; int ld;             // (n+m) x ld factor storage
+    double *x, *y, *z, *q, *zt, *zprev, *rho, *rhoinv, *rhob, *rhobinv, *kdiag, *rhs, *t1, *t2;
+    __host__ __device__ static int ld_of(int N) { return N | 1; }
+    __host__ __device__ static size_t doubles(int n, int m) {
+        const int N = n + m;
+        return (size_t)N * ld_of(N) + 3 * (size_t)n /*x q kdiag(n part)*/ + (size_t)N /*y*/ + 5 * (size_t)m /*z zt zprev rho rhoinv*/ +
+               2 * (size_t)n /*rhob rhobinv*/ + (size_t)N /*rhs*/ + 2 * (size_t)N /*t1 t2*/ + (size_t)m /*kdiag m part*/ + 8;
+    }
+    __device__ double* carve(double* base, int n, int m) {
+        const int N = n + m;
+        ld = ld_of(N);
+        double* p = base;
+        K = p; p += (size_t)N * ld;
+        x = p; p += n; q = p; p += n; kdiag = p; p += N; y = p; p += N;
+        z = p; p += m; zt = p; p += m; zprev = p; p += m; rho = p; p += m; rhoinv = p; p += m;
+        rhob = p; p += n; rhobinv = p; p += n; rhs = p; p += N; t1 = p; p += N; t2 = p; p += N;
+        return p;
+    }
+};
+
+// K (lower triangle) <- [H + diag(kdiag[0:n]) ; A, diag(kdiag[n:])]  (construct_kkt_matrix, box_admm.hpp:209-223)
+__device__ inline void kkt_build(const QpLds& w, int n, int m, const double* __restrict__ H, const double* __restrict__ A) {
+    const int ln = lane_id();
+    for (int j = 0; j < n; ++j) {
+        for (int i = j + ln; i < n; i += WAVE) w.K[j * w.ld + i] = (i == j) ? w.kdiag[i] : H[(size_t)j * n + i];
+        for (int r = ln; r < m; r += WAVE) w.K[j * w.ld + n + r] = A[(size_t)j * m + r];
+    }
+    for (int j = 0; j < m; ++j)
+        for (int i = j + ln; i < m; i += WAVE) w.K[(n + j) * w.ld + n + i] = (i == j) ? w.kdiag[n + i] : 0.0;
+    wsync();
+}
+
+// in-place LDL^T, static order, right-looking (factorise_kkt_matrix, box_admm.hpp:336-341)
+__device__ inline void kkt_factor(const QpLds& w, int N) {
+    const int ln = lane_id();
+    double* K = w.K; const int ld = w.ld;
+    for (int k = 0; k < N; ++k) {
+        const double dk = K[k * ld + k];
+        // scale column k, keep the unscaled entries in t1
+        for (int i = k + 1 + ln; i < N; i += WAVE) {
+            const double c = K[k * ld + i];
+            w.t1[i] = c;
+            K[k * ld + i] = c / dk;
+        }
+        wsync();
+        for (int j = k + 1; j < N; ++j) {
+            const double ljk = K[k * ld + j];
+            for (int i = j + ln; i < N; i += WAVE) K[j * ld + i] = fma(-w.t1[i], ljk, K[j * ld + i]);
+        }
+        wsync();
+    }
+}
+
+// v <- K^{-1} v  (linear_solver.solve, box_admm.hpp:123), v in LDS
+__device__ inline void kkt_solve(const QpLds& w, int N, double* v) {
+    const int ln = lane_id();
+    const double* K = w.K; const int ld = w.ld;
+    if (N <= WAVE) {
+        // single row per lane: keep the running entry in a register, broadcast the pivot entry by readlane
+        double c = (ln < N) ? v[ln] : 0.0;
+        for (int j = 0; j < N - 1; ++j) {
+            const double xj = __shfl(c, j, WAVE);
+            if (ln > j && ln < N) c = fma(-K[j * ld + ln], xj, c);
+        }
+        if (ln < N) c = c / K[ln * ld + ln];
+        for (int j = N - 1; j > 0; --j) {
+            const double xj = __shfl(c, j, WAVE);
+            if (ln < j) c = fma(-K[ln * ld + j], xj, c);
+        }
+        if (ln < N) v[ln] = c;
+        wsync();
+        return;
+    }
+    for (int j = 0; j < N - 1; ++j) {
+        const double xj = v[j];
+        for (int i = j + 1 + ln; i < N; i += WAVE) v[i] = fma(-K[j * ld + i], xj, v[i]);
+        wsync();
+    }
+    for (int i = ln; i < N; i += WAVE) v[i] = v[i] / K[i * ld + i];
+    wsync();
+    for (int j = N - 1; j > 0; --j) {
+        const double xj = v[j];
+        for (int i = ln; i < j; i += WAVE) v[i] = fma(-K[i * ld + j], xj, v[i]);
+        wsync();
+    }
+}
+
+struct QpResidualState { double max_Ax_z_norm, max_Hx_ATy_h_norm, res_prim, res_dual; };
+
+// residuals_update, box_admm.hpp:398-415 (H, A streamed from global memory, coalesced down the columns)
+__device__ inline void qp_residuals(const QpLds& w, int n, int m, const double* __restrict__ H, const double* __restrict__ h,
+                                    const double* __restrict__ A, QpResidualState& r) {
+    const int ln = lane_id();
+    double nAx = 0, nz = 0, nx = 0, rp = 0;
+    for (int i = ln; i < m; i += WAVE) {
+        double a = 0.0;
+        for (int j = 0; j < n; ++j) a += A[(size_t)j * m + i] * w.x[j];
+        nAx = fmax(nAx, fabs(a)); nz = fmax(nz, fabs(w.z[i])); rp = fmax(rp, fabs(a - w.z[i]));
+    }
+    double nHx = 0, nATy = 0, nh = 0, nyb = 0, rq = 0, rd = 0;
+    for (int i = ln; i < n; i += WAVE) {
+        double a = 0.0;
+        for (int j = 0; j < n; ++j) a += H[(size_t)j * n + i] * w.x[j];
+        double b = 0.0;
+        for (int k = 0; k < m; ++k) b += A[(size_t)i * m + k] * w.y[k];
+        nx = fmax(nx, fabs(w.x[i])); nHx = fmax(nHx, fabs(a)); nATy = fmax(nATy, fabs(b));
+        nh = fmax(nh, fabs(h[i])); nyb = fmax(nyb, fabs(w.y[m + i]));
+        rq = fmax(rq, fabs(w.x[i] - w.q[i]));
+        rd = fmax(rd, fabs(((a + h[i]) + b) + w.y[m + i]));
+    }
+    nAx = wave_max(nAx); nz = wave_max(nz); nx = wave_max(nx); rp = wave_max(rp);
+    nHx = wave_max(nHx); nATy = wave_max(nATy); nh = wave_max(nh); nyb = wave_max(nyb); rq = wave_max(rq); rd = wave_max(rd);
+    r.max_Ax_z_norm = fmax(nAx, fmax(nz, nx));
+    r.max_Hx_ATy_h_norm = fmax(nHx, fmax(nATy, fmax(nh, nyb)));
+    r.res_prim = rp + rq;
+    r.res_dual = rd;
+}
+
+__device__ inline void rho_vec_update(const QpLds& w, int n, int m, const double* Alb, const double* Aub, const double* xlb,
+                                      const double* xub, double rho0) {
+    const int ln = lane_id();
+    for (int i = ln; i < m; i += WAVE) { const double r = rho_of(classify_bounds(Alb[i], Aub[i]), rho0); w.rho[i] = r; w.rhoinv[i] = 1.0 / r; }
+    for (int i = ln; i < n; i += WAVE) { const double r = rho_of(classify_bounds(xlb[i], xub[i]), rho0); w.rhob[i] = r; w.rhobinv[i] = 1.0 / r; }
+}
+
+// boxADMM::solve_impl (box_admm.hpp:88-205). Result in w.x (n) and w.y (m+n). h/Alb/Aub/xlb/xub may live in LDS or HBM.
+__device__ inline void boxadmm_solve(QpLds& w, int n, int m, const double* __restrict__ H, const double* h,
+                                     const double* __restrict__ A, const double* Alb, const double* Aub, const double* xlb,
+                                     const double* xub, const double* x0, const double* y0, const pmpc_qp_settings& s,
+                                     pmpc_qp_info& info) {
+    const int ln = lane_id();
+    const int N = n + m;
+    // x = x_guess; y = y_guess; z = A*x_guess; q = x_guess  (:97-100)
+    for (int i = ln; i < n; i += WAVE) { const double v = x0 ? x0[i] : 0.0; w.x[i] = v; w.q[i] = v; }
+    for (int i = ln; i < N; i += WAVE) w.y[i] = y0 ? y0[i] : 0.0;
+    wsync();
+    for (int i = ln; i < m; i += WAVE) {
+        double a = 0.0;
+        if (x0) for (int j = 0; j < n; ++j) a += A[(size_t)j * m + i] * w.x[j];
+        w.z[i] = a;
+    }
+    double rho = s.rho;
+    int rho_updates = 1;
+    rho_vec_update(w, n, m, Alb, Aub, xlb, xub, rho);
+    wsync();
+    // K diagonal: (H_ii + sigma) + rho_box ; -1/rho   (:214-222)
+    for (int i = ln; i < n; i += WAVE) { double dgl = H[(size_t)i * n + i]; dgl += s.sigma; dgl += w.rhob[i]; w.kdiag[i] = dgl; }
+    for (int i = ln; i < m; i += WAVE) w.kdiag[n + i] = -w.rhoinv[i];
+    wsync();
+    kkt_build(w, n, m, H, A);
+    kkt_factor(w, N);
+
+    int status = PMPC_QP_UNSOLVED;
+    const double alpha = s.alpha;
+    QpResidualState rs{0, 0, 1, 1};
+    double rho_estimate = 0.0;
+    int iter;
+    for (iter = 1; iter <= s.max_iter; ++iter) {
+        // compute_kkt_rhs (:351-355), z_prev = z
+        for (int i = ln; i < n; i += WAVE) w.rhs[i] = ((s.sigma * w.x[i] - h[i]) + w.rhob[i] * w.q[i]) - w.y[m + i];
+        for (int i = ln; i < m; i += WAVE) { w.zprev[i] = w.z[i]; w.rhs[n + i] = w.z[i] - w.rhoinv[i] * w.y[i]; }
+        wsync();
+        kkt_solve(w, N, w.rhs);
+        for (int i = ln; i < m; i += WAVE) {
+            const double zt = w.zprev[i] + w.rhoinv[i] * (w.rhs[n + i] - w.y[i]);
+            double zz = alpha * zt;
+            zz += (1 - alpha) * w.zprev[i] + w.rhoinv[i] * w.y[i];
+            zz = fmin(fmax(zz, Alb[i]), Aub[i]);
+            w.z[i] = zz;
+            w.y[i] += w.rho[i] * ((alpha * zt + (1 - alpha) * w.zprev[i]) - zz);
+        }
+        for (int i = ln; i < n; i += WAVE) {
+            double xx = alpha * w.rhs[i];
+            xx += (1 - alpha) * xx;  // quirk Q1
+            w.x[i] = xx;
+            double qq = xx + w.rhobinv[i] * w.y[m + i];
+            qq = fmin(fmax(qq, xlb[i]), xub[i]);
+            w.q[i] = qq;
+            w.y[m + i] += w.rhob[i] * (xx - qq);
+        }
+        wsync();
+        const bool check = (s.check_termination != 0 && iter % s.check_termination == 0);
+        if (check) {
+            qp_residuals(w, n, m, H, h, A, rs);
+            const double ep = s.eps_abs + s.eps_rel * rs.max_Ax_z_norm, ed = s.eps_abs + s.eps_rel * rs.max_Hx_ATy_h_norm;
+            if (rs.res_prim <= ep && rs.res_dual <= ed) { status = PMPC_QP_SOLVED; break; }
+        }
+        if (s.adaptive_rho && iter % s.adaptive_rho_interval == 0) {
+            if (!check) qp_residuals(w, n, m, H, h, A, rs);
+            const double rpn = rs.res_prim / (rs.max_Ax_z_norm + DIV_BY_ZERO_REGUL);
+            const double rdn = rs.res_dual / (rs.max_Hx_ATy_h_norm + DIV_BY_ZERO_REGUL);
+            double new_rho = rho * sqrt(rpn / (rdn + DIV_BY_ZERO_REGUL));
+            new_rho = fmax(RHO_MIN, fmin(new_rho, RHO_MAX));
+            rho_estimate = new_rho;
+            if (new_rho < rho / s.adaptive_rho_tolerance || new_rho > rho * s.adaptive_rho_tolerance) {
+                // rho_vec_update + update_kkt_rho (:448-452) + refactor
+                for (int i = ln; i < n; i += WAVE) w.t2[i] = w.rhob[i];
+                wsync();
+                rho = new_rho;
+                rho_vec_update(w, n, m, Alb, Aub, xlb, xub, rho);
+                ++rho_updates;
+                wsync();
+                for (int i = ln; i < n; i += WAVE) w.kdiag[i] += (w.rhob[i] - w.t2[i]);
+                for (int i = ln; i < m; i += WAVE) w.kdiag[n + i] = -w.rhoinv[i];
+                wsync();
+                kkt_build(w, n, m, H, A);
+                kkt_factor(w, N);
+            }
+        }
+    }
+    if (iter > s.max_iter) status = PMPC_QP_MAX_ITER_EXCEEDED;
+    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info._pad = 0;
+    info.rho_estimate = rho_estimate; info.res_prim = rs.res_prim; info.res_dual = rs.res_dual;
+}
+
+}  // namespace pmpc

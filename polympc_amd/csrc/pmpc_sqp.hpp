@@ -1,0 +1,240 @@
+// polympc_amd — fused per-instance SQP loop on the device (one wavefront per OCP instance).
+//
+// Replaces SQPBase::solve and its default policies (/root/reference/src/solvers/sqp_base.hpp): solve :569-696,
+// linearisation_dense_impl :310-318, update_linearisation_dense_impl :490-504, solve_qp :533-565,
+// step_size_selection_impl :380-419, constraints_violation_impl :423-444, max_constraints_violation_impl :448-474,
+// termination_criteria_impl :524-529; BFGS_update (src/solvers/bfgs.hpp:23-52); the Gershgorin regulariser of
+// tests/control/dense_sparse_compare.cpp:109-122. Linearisation, Hessian update, KKT factorisation, ADMM iterations,
+// line search and step all run inside ONE kernel launch; the iterate, multipliers, bounds and QP vectors never leave
+// LDS between SQP iterations. H (n x n) and the Jacobian (m x n) live in a per-instance HBM workspace that stays
+// L2-resident (config A: 15.7 KB per instance).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "pmpc_ocp.hpp"
+#include "pmpc_qp.hpp"
+
+namespace pmpc {
+
+struct SqpLds {
+    double *x, *lam, *lam_k, *h, *lg, *lgn, *al, *au, *lx, *ux, *lbx, *ubx, *lbg, *ubg, *step, *xs, *cb, *t1, *t2, *t3;
+    __host__ __device__ static size_t doubles(int n, int m, int mi) {
+        return 12 * (size_t)n + 2 * (size_t)(m + n) + 3 * (size_t)m + 2 * (size_t)mi + 3 * (size_t)(n + m) + 8;
+    }
+    __device__ double* carve(double* p, int n, int m, int mi) {
+        x = p; p += n; lam = p; p += m + n; lam_k = p; p += m + n; h = p; p += n; lg = p; p += n; lgn = p; p += n;
+        al = p; p += m; au = p; p += m; lx = p; p += n; ux = p; p += n; lbx = p; p += n; ubx = p; p += n;
+        lbg = p; p += mi; ubg = p; p += mi; step = p; p += n; xs = p; p += n; cb = p; p += m;
+        t1 = p; p += n + m; t2 = p; p += n + m; t3 = p; p += n + m;
+        return p;
+    }
+};
+
+constexpr double DBL_EPS = 2.220446049250313e-16;
+
+template <class Model>
+struct SqpDevice {
+    using Dm = OcpDims<Model>;
+    Ocp<Model>& ocp;
+    SqpLds& v;
+    QpLds& qw;
+    double* Hw;  // n x n, HBM workspace
+    double* Aw;  // m x n, HBM workspace
+    const pmpc_sqp_settings& ss;
+    const pmpc_qp_settings& qs;
+    int n, m, me, mi;
+    double cost_log = 0.0, primal_norm = 0.0, dual_norm = 0.0, max_violation = 0.0;
+    int qp_iter_total = 0;
+
+    __device__ SqpDevice(Ocp<Model>& o, SqpLds& v_, QpLds& q_, double* H_, double* A_, const pmpc_sqp_settings& s, const pmpc_qp_settings& q)
+        : ocp(o), v(v_), qw(q_), Hw(H_), Aw(A_), ss(s), qs(q), n(o.dm.n), m(o.dm.m), me(o.dm.me), mi(o.dm.mi) {}
+
+    // constraints_violation_impl :423-444 (sequential sums, reference association order)
+    __device__ double constraints_violation(const double* xx) {
+        ocp.constraints(xx, v.cb);
+        double cl1 = DBL_EPS;
+        double s = 0.0;
+        for (int i = 0; i < me; ++i) s += fabs(v.cb[i]);
+        cl1 += s;
+        s = 0.0; for (int i = 0; i < mi; ++i) s += fmax(v.lbg[i] - v.cb[me + i], 0.0); cl1 += s;
+        s = 0.0; for (int i = 0; i < mi; ++i) s += fmax(v.cb[me + i] - v.ubg[i], 0.0); cl1 += s;
+        s = 0.0; for (int i = 0; i < n; ++i) s += fmax(v.lbx[i] - xx[i], 0.0); cl1 += s;
+        s = 0.0; for (int i = 0; i < n; ++i) s += fmax(xx[i] - v.ubx[i], 0.0); cl1 += s;
+        wsync();
+        return cl1;
+    }
+    // max_constraints_violation_impl :448-474
+    __device__ double max_constraints_violation(const double* xx) {
+        ocp.constraints(xx, v.cb);
+        const int ln = lane_id();
+        double c = 0.0, a = -INFINITY, b = -INFINITY, e = -INFINITY, f = -INFINITY;
+        for (int i = ln; i < me; i += WAVE) c = fmax(c, fabs(v.cb[i]));
+        for (int i = ln; i < mi; i += WAVE) { a = fmax(a, v.lbg[i] - v.cb[me + i]); b = fmax(b, v.cb[me + i] - v.ubg[i]); }
+        for (int i = ln; i < n; i += WAVE) { e = fmax(e, v.lbx[i] - xx[i]); f = fmax(f, xx[i] - v.ubx[i]); }
+        c = wave_max(c);
+        if (mi > 0) { c = fmax(c, wave_max(a)); c = fmax(c, wave_max(b)); }
+        c = fmax(c, wave_max(e)); c = fmax(c, wave_max(f));
+        wsync();
+        return c;
+    }
+
+    // step_size_selection_impl :380-419 ; p = QP primal step in qw.x
+    __device__ double step_size_selection() {
+        const double* p = qw.x;
+        const int ln = lane_id();
+        const double constr_l1 = constraints_violation(v.x);
+        const double mu = lds_inf_norm(v.lam_k, m + n);
+        const double cost_1 = ocp.cost(v.x);
+        const double phi_l1 = cost_1 + mu * constr_l1;
+        const double Dp_phi_l1 = seq_dot(v.h, p, n) - mu * constr_l1;
+        double alpha = 1.0;
+        for (int i = 1; i < ss.line_search_max_iter; ++i) {
+            for (int j = ln; j < n; j += WAVE) { double t = alpha * p[j]; t += v.x[j]; v.xs[j] = t; }
+            wsync();
+            const double cost_step = ocp.cost(v.xs);
+            cost_log = cost_step;
+            const double phi_step = cost_step + mu * constraints_violation(v.xs);
+            if (phi_step <= (phi_l1 + alpha * ss.eta * Dp_phi_l1)) return alpha;
+            alpha = ss.tau * alpha;
+        }
+        return alpha;
+    }
+
+    // lag_grad = J^T lam[0:m] + cost_grad + lam_box  (continuous_ocp.hpp:2112-2114)
+    __device__ void lagrangian_gradient(double* out) {
+        for (int j = lane_id(); j < n; j += WAVE) {
+            double a = 0.0;
+            for (int i = 0; i < m; ++i) a += Aw[(size_t)j * m + i] * v.lam[i];
+            a += v.h[j];
+            a += v.lam[m + j];
+            out[j] = a;
+        }
+        wsync();
+    }
+
+    // Gershgorin shift, dense_sparse_compare.cpp:109-122
+    __device__ void regularise_gershgorin() {
+        for (int i = lane_id(); i < n; i += WAVE) {
+            const double aii = Hw[(size_t)i * n + i];
+            double ri = 0.0;
+            for (int k = 0; k < n; ++k) ri += fabs(Hw[(size_t)i * n + k]);
+            ri -= fabs(aii);
+            if (aii - ri <= 0) Hw[(size_t)i * n + i] = aii + ((ri - aii) + 0.01);
+        }
+        __threadfence_block();
+        wsync();
+    }
+
+    // linearisation_dense_impl :310-318
+    __device__ void linearisation() {
+        ocp.stage_first_order(v.x);
+        ocp.stage_second_order(v.x, v.lam);
+        ocp.assemble_first_order(v.al, Aw, v.h);
+        ocp.assemble_hessian(Hw);
+        lagrangian_gradient(v.lg);
+        if (ss.regularisation == 2) regularise_gershgorin();
+    }
+
+    // BFGS_update, bfgs.hpp:23-52 ; s = v.step, y = lgn - lg
+    __device__ void bfgs_update() {
+        const int ln = lane_id();
+        double* Bs = v.t1; double* r = v.t2; double* y = v.t3;
+        for (int i = ln; i < n; i += WAVE) {
+            double a = 0.0;
+            for (int j = 0; j < n; ++j) a += Hw[(size_t)j * n + i] * v.step[j];
+            Bs[i] = a;
+            y[i] = v.lgn[i] - v.lg[i];
+        }
+        wsync();
+        const double sBs = seq_dot(v.step, Bs, n);
+        const double sy = seq_dot(v.step, y, n);
+        double sr;
+        if (sy < 0.2 * sBs) {
+            const double theta = 0.8 * sBs / (sBs - sy);
+            for (int i = ln; i < n; i += WAVE) r[i] = theta * y[i] + (1 - theta) * Bs[i];
+            sr = theta * sy + (1 - theta) * sBs;
+        } else {
+            for (int i = ln; i < n; i += WAVE) r[i] = y[i];
+            sr = sy;
+        }
+        wsync();
+        if (sr < DBL_EPS) return;
+        for (int j = 0; j < n; ++j) {
+            const double Bsj = Bs[j], rj = r[j];
+            for (int i = ln; i < n; i += WAVE) {
+                double b = Hw[(size_t)j * n + i];
+                b += (-Bs[i] * Bsj) / sBs;
+                b += (r[i] * rj) / sr;
+                Hw[(size_t)j * n + i] = b;
+            }
+        }
+        __threadfence_block();
+        wsync();
+    }
+
+    // update_linearisation_dense_impl :490-504
+    __device__ void update_linearisation() {
+        if (ss.exact_hessian_every_iter) { linearisation(); return; }
+        ocp.stage_first_order(v.x);
+        ocp.assemble_first_order(v.al, Aw, v.h);
+        lagrangian_gradient(v.lgn);
+        bfgs_update();
+        for (int i = lane_id(); i < n; i += WAVE) v.lg[i] = v.lgn[i];
+        wsync();
+    }
+
+    // QP bounds :588-593
+    __device__ void form_qp_bounds() {
+        const int ln = lane_id();
+        for (int i = ln; i < m; i += WAVE) {
+            double a = -v.al[i], b = a;
+            if (i >= me) { a += v.lbg[i - me]; b += v.ubg[i - me]; }
+            v.al[i] = a; v.au[i] = b;
+        }
+        for (int i = ln; i < n; i += WAVE) { v.lx[i] = v.lbx[i] - v.x[i]; v.ux[i] = v.ubx[i] - v.x[i]; }
+        wsync();
+    }
+
+    // one SQP iteration after (update_)linearisation: QP, line search, step, norms  (:588-632 / :652-683)
+    __device__ void qp_and_step() {
+        const int ln = lane_id();
+        form_qp_bounds();
+        pmpc_qp_info qi;
+        boxadmm_solve(qw, n, m, Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi);   // 7-argument form: zero guesses (Q2)
+        qp_iter_total += qi.iter;
+        // lam_k = p_lambda ; p_lambda -= lam
+        for (int i = ln; i < m + n; i += WAVE) { v.lam_k[i] = qw.y[i]; qw.y[i] = qw.y[i] - v.lam[i]; }
+        wsync();
+        const double alpha = step_size_selection();
+        const double pn = lds_inf_norm(qw.x, n), dn = lds_inf_norm(qw.y, m + n);
+        for (int i = ln; i < n; i += WAVE) { const double st = alpha * qw.x[i]; v.x[i] += st; v.step[i] = st; }
+        for (int i = ln; i < m + n; i += WAVE) v.lam[i] += alpha * qw.y[i];
+        primal_norm = alpha * pn;
+        dual_norm = alpha * dn;
+        wsync();
+    }
+    __device__ bool termination_criteria() {  // :524-529
+        max_violation = max_constraints_violation(v.x);
+        return (primal_norm <= ss.eps_prim) && (dual_norm <= ss.eps_dual) && (max_violation <= ss.eps_prim);
+    }
+
+    __device__ void solve(pmpc_sqp_info& info) {
+        int status = PMPC_SQP_MAX_ITER_EXCEEDED;
+        int iter = 1;
+        linearisation();
+        qp_and_step();
+        if (termination_criteria()) {
+            status = PMPC_SQP_SOLVED;
+        } else {
+            while (iter < ss.max_iter) {
+                ++iter;
+                update_linearisation();
+                qp_and_step();
+                if (termination_criteria()) { status = PMPC_SQP_SOLVED; break; }
+            }
+        }
+        info.iter = iter; info.qp_solver_iter = qp_iter_total; info.status = status; info._pad = 0;
+        info.primal_norm = primal_norm; info.dual_norm = dual_norm; info.max_violation = max_violation; info.cost = cost_log;
+    }
+};
+
+}  // namespace pmpc

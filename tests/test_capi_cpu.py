@@ -1,0 +1,81 @@
+"""CPU-side checks of the product boundary: the C-ABI library loads, exports every symbol include/polympc_amd.h declares,
+refuses to run without a GPU (no fallback), and its host-side collocation constants match the pinned oracle."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import polympc_amd
+    polympc_amd.build_library()
+    return polympc_amd
+
+
+def test_header_symbols_are_exported(pa):
+    hdr = open(os.path.join(ROOT, "include", "polympc_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(pmpc_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations found"
+    assert sorted(pa.EXPORTED_SYMBOLS) == declared
+    lib = pa.lib()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in include/polympc_amd.h but not exported"
+
+
+def test_struct_layouts_match_header(pa):
+    import ctypes as C
+    assert C.sizeof(pa.QPSettings) == 72 and C.sizeof(pa.QPInfo) == 40
+    assert C.sizeof(pa.SQPSettings) == 56 and C.sizeof(pa.SQPInfo) == 48
+
+
+def test_defaults_match_reference(pa):
+    q = pa.qp_settings_default()      # qp_base.hpp:17-53
+    assert (q.eps_rel, q.eps_abs, q.max_iter, q.rho, q.sigma, q.alpha) == (1e-3, 1e-3, 1000, 1e-1, 1e-6, 1.0)
+    assert (q.check_termination, q.adaptive_rho, q.adaptive_rho_tolerance, q.adaptive_rho_interval) == (25, 0, 5.0, 25)
+    s = pa.qp_settings_sqp_default()  # sqp_base.hpp:83-90
+    assert (s.check_termination, s.eps_abs, s.eps_rel, s.max_iter, s.adaptive_rho, s.adaptive_rho_interval, s.alpha) == (10, 1e-4, 1e-4, 100, 1, 50, 1.0)
+    n = pa.sqp_settings_default()     # sqp_base.hpp:24-47
+    assert (n.tau, n.eta, n.rho, n.eps_prim, n.eps_dual, n.max_iter, n.line_search_max_iter) == (0.5, 0.25, 0.5, 1e-3, 1e-3, 100, 100)
+
+
+def test_no_cpu_fallback(pa):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        pa.Context(0)
+
+
+@pytest.mark.parametrize("P", [2, 3, 5, 6, 10, 15])
+def test_host_chebyshev_matches_oracle(pa, oracle, P):
+    n1, w1, D1 = pa.chebyshev(P)
+    n2, w2, D2 = oracle.cheb(P)
+    assert np.array_equal(n1, n2) and np.array_equal(w1, w2) and np.array_equal(D1, D2)
+
+
+@pytest.mark.parametrize("model", [0, 1, 2, 3, 4])
+def test_dims_match_oracle(pa, oracle, model):
+    for P, S in ((6, 1), (5, 2), (5, 3), (3, 2)):
+        assert pa.ocp_dims(model, P, S) == oracle.ocp_dims(model, P, S)
+
+
+def test_product_does_not_touch_the_oracle():
+    """The oracle is test infrastructure: nothing under polympc_amd/ or include/ may import, include or link it."""
+    for base in ("polympc_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".hpp", ".h", ".hip", ".cpp")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    assert "oracle" not in txt.lower() or f == "__init__.py" and False, f"{os.path.join(dp, f)} mentions the oracle"
+
+
+def test_workload_generator_is_deterministic():
+    from polympc_amd import workloads
+    a = workloads.robot_batch(8); b = workloads.robot_batch(4, first=4)
+    assert np.array_equal(a["lbx"][4:], b["lbx"]) and np.array_equal(a["d"][4:], b["d"])
+    u = workloads.uniform_pm1(workloads.SEED, np.arange(1000), 0)
+    assert -1 <= u.min() < -0.9 and 0.9 < u.max() <= 1 and abs(u.mean()) < 0.1

@@ -1,0 +1,293 @@
+"""GPU parity tests: the HIP path (through the C ABI of include/polympc_amd.h) against the oracle (static elimination
+order — the order the kernels use) on the same seeded inputs, against the reference's golden vectors, and — at the
+benchmark's full size — through size-independent KKT properties. Tolerances are stated per assertion; all fp64."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "casadi_robot_P5S2.npz")
+inf = np.inf
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import polympc_amd as pa
+    c = pa.Context(0)
+    yield c
+    c.close()
+
+
+def _mat(Hc, n, m=None):
+    """column-major flat -> [rows, cols]"""
+    return Hc.reshape(n if m is None else n, -1).T if m is None else Hc.reshape(n, m).T
+
+
+def _qp_oracle(oracle, q, s, x0=None, y0=None):
+    os_ = oracle.qp_default_settings()
+    for f, _ in s._fields_:
+        setattr(os_, f, getattr(s, f))
+    return oracle.qp_solve_batch(q["H"], q["h"], q["A"], q["Alb"], q["Aub"], q["xlb"], q["xub"], settings=os_,
+                                 pivot=oracle.PIVOT_STATIC, x0=x0, y0=y0)
+
+
+# -------------------------------------------------------------------------------------------- A16-A18: box-ADMM QP
+def test_qp_reference_known_answers(ctx, oracle):
+    """box_admm_test.cpp:15-45, :266-297, :299-334 through the GPU path."""
+    import polympc_amd as pa
+    H = np.array([[4.0, 1.0], [1.0, 2.0]]).T.ravel()[None]
+    s = pa.qp_settings_default(); s.max_iter = 150
+    x, y, info = ctx.qp_solve_batch(H, [[1.0, 1.0]], [[1.0, 1.0]], [[1.0]], [[1.0]], [[0.0, 0.0]], [[0.7, 0.7]], settings=s)
+    assert np.linalg.norm(x[0] - [0.3, 0.7]) <= 1e-2 * np.linalg.norm([0.3, 0.7])
+    assert info["iter"][0] < 150 and info["status"][0] == pa.QP_SOLVED
+    z = np.zeros((1, 0))
+    s = pa.qp_settings_default(); s.max_iter = 200; s.adaptive_rho = 1; s.check_termination = 10
+    x, y, info = ctx.qp_solve_batch(np.zeros((1, 1)), np.ones((1, 1)), z, z, z, [[-1e6]], [[1e6]], settings=s)
+    assert abs(x[0, 0] + 1e6) <= 1e4 and info["iter"][0] < 200 and info["status"][0] == pa.QP_SOLVED
+    s.rho = 2
+    x, y, info = ctx.qp_solve_batch(-np.ones((1, 1)), np.zeros((1, 1)), z, z, z, [[-1.0]], [[2.0]], settings=s, x0=[[0.1]], y0=[[0.1]])
+    assert abs(x[0, 0] - 2.0) <= 2e-2 and info["iter"][0] < 200 and info["status"][0] == pa.QP_SOLVED
+
+
+@pytest.mark.parametrize("n,m,B", [(2, 1, 8), (1, 0, 4), (7, 3, 33), (35, 21, 64), (55, 33, 16), (66, 44, 8), (80, 48, 4), (3, 70, 4)])
+def test_qp_random_vs_oracle(ctx, oracle, n, m, B):
+    """Random convex QPs of many shapes (incl. ragged n+m > 64, m > n, m = 0): same iteration count, status and
+    rho updates as the oracle; x, y within 1e-9 (absolute, problem data O(1))."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    q = workloads.random_qp_batch(B, n, m, seed=n * 1000 + m)
+    s = pa.qp_settings_sqp_default()
+    x, y, info = ctx.qp_solve_batch(q["H"], q["h"], q["A"], q["Alb"], q["Aub"], q["xlb"], q["xub"], settings=s)
+    xo, yo, io = _qp_oracle(oracle, q, s)
+    assert [int(i) for i in info["iter"]] == [i.iter for i in io]
+    assert [int(i) for i in info["status"]] == [i.status for i in io]
+    assert [int(i) for i in info["rho_updates"]] == [i.rho_updates for i in io]
+    assert np.abs(x - xo).max() <= 1e-9 and np.abs(y - yo).max() <= 1e-9
+    assert np.abs(info["res_prim"] - [i.res_prim for i in io]).max() <= 1e-9
+    assert np.abs(info["res_dual"] - [i.res_dual for i in io]).max() <= 1e-9
+
+
+def test_qp_warm_start_guess(ctx, oracle):
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    B, n, m = 8, 12, 5
+    q = workloads.random_qp_batch(B, n, m, seed=77)
+    rng = np.random.default_rng(1)
+    x0 = rng.normal(size=(B, n)) * 0.1; y0 = rng.normal(size=(B, n + m)) * 0.1
+    s = pa.qp_settings_sqp_default()
+    x, y, info = ctx.qp_solve_batch(q["H"], q["h"], q["A"], q["Alb"], q["Aub"], q["xlb"], q["xub"], settings=s, x0=x0, y0=y0)
+    xo, yo, io = _qp_oracle(oracle, q, s, x0=x0, y0=y0)
+    assert [int(i) for i in info["iter"]] == [i.iter for i in io]
+    assert np.abs(x - xo).max() <= 1e-9 and np.abs(y - yo).max() <= 1e-9
+
+
+def test_qp_from_sqp_trace_vs_oracle(ctx, oracle):
+    """The QPs the oracle's SQP emits for config-A robot instances (true collocation structure and conditioning)."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    wl = workloads.robot_batch(6)
+    ss = oracle.sqp_default_settings(); ss.max_iter = 10; ss.line_search_max_iter = 10
+    Hs, hs, As, al, au, lx, ux = [], [], [], [], [], [], []
+    for b in range(6):
+        t = oracle.sqp_trace_qps(oracle.MODEL_ROBOT, 6, 1, 0.0, 2.0, wl["d"][b:b + 1], wl["lbx"][b:b + 1], wl["ubx"][b:b + 1],
+                                 sqp_settings=ss, pivot=oracle.PIVOT_STATIC)
+        Hs.append(t["H"]); hs.append(t["h"]); As.append(t["A"]); al.append(t["al"]); au.append(t["au"]); lx.append(t["lx"]); ux.append(t["ux"])
+    q = dict(H=np.concatenate(Hs), h=np.concatenate(hs), A=np.concatenate(As), Alb=np.concatenate(al), Aub=np.concatenate(au),
+             xlb=np.concatenate(lx), xub=np.concatenate(ux))
+    s = pa.qp_settings_sqp_default()
+    x, y, info = ctx.qp_solve_batch(q["H"], q["h"], q["A"], q["Alb"], q["Aub"], q["xlb"], q["xub"], settings=s)
+    xo, yo, io = _qp_oracle(oracle, q, s)
+    assert [int(i) for i in info["iter"]] == [i.iter for i in io]
+    assert np.abs(x - xo).max() <= 1e-9 and np.abs(y - yo).max() <= 1e-8
+    assert np.abs(info["res_prim"] - [i.res_prim for i in io]).max() <= 1e-8    # north_star: KKT residual within 1e-8
+    assert np.abs(info["res_dual"] - [i.res_dual for i in io]).max() <= 1e-8
+
+
+def test_qp_kkt_properties_full_size(ctx):
+    """Config-A-sized batch of 4096 QPs: every SOLVED instance satisfies the reference's own termination inequalities
+    when the residuals are recomputed on the host from the returned (x, y) (size-independent property)."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    B, n, m = 4096, 35, 21
+    q = workloads.random_qp_batch(B, n, m, seed=4096)
+    s = pa.qp_settings_sqp_default()
+    x, y, info = ctx.qp_solve_batch(q["H"], q["h"], q["A"], q["Alb"], q["Aub"], q["xlb"], q["xub"], settings=s)
+    H = q["H"].reshape(B, n, n).transpose(0, 2, 1); A = q["A"].reshape(B, n, m).transpose(0, 2, 1)
+    rd = np.abs(np.einsum("bij,bj->bi", H, x) + q["h"] + np.einsum("bji,bj->bi", A, y[:, :m]) + y[:, m:]).max(axis=1)
+    ok = info["status"] == pa.QP_SOLVED
+    assert ok.sum() > 0.9 * B
+    assert np.abs(rd[ok] - info["res_dual"][ok]).max() <= 1e-9
+    Ax = np.einsum("bij,bj->bi", A, x)
+    assert np.all(Ax[ok] >= q["Alb"][ok] - 1e-2) and np.all(Ax[ok] <= q["Aub"][ok] + 1e-2)
+    assert np.all(x[ok] >= q["xlb"][ok] - 1e-2) and np.all(x[ok] <= q["xub"][ok] + 1e-2)
+
+
+# -------------------------------------------------------------------------------------------- A1-A11: collocation
+def test_collocation_against_reference_golden(ctx):
+    """GPU assembly vs the vectors produced by the reference's own CasADi fixtures (tests/golden/make_golden.py)."""
+    import polympc_amd as pa
+    g = np.load(GOLD)
+    K = len(g["x"])
+    lam = np.concatenate([g["lam"], np.zeros((K, 55))], axis=1)
+    ev = ctx.ocp_linearise_batch(pa.MODEL_ROBOT, 5, 2, 0.0, 1.0, g["x"], np.ones((K, 1)), lam=lam)
+    assert np.abs(ev["cost"] - g["cost"]).max() <= 1e-13
+    assert np.abs(ev["cost_values_only"] - g["cost"]).max() <= 1e-13
+    assert np.abs(ev["c"] - g["c"]).max() <= 1e-13
+    assert np.abs(ev["jac"] - g["jac"]).max() <= 1e-13
+    assert np.abs(ev["cost_grad"] - g["cost_grad"]).max() <= 1e-13
+    assert np.abs(ev["lag_grad"] - g["lag_grad"]).max() <= 1e-13
+    assert np.abs(ev["lag_hess"] - g["lag_hess"]).max() <= 1e-13
+
+
+@pytest.mark.parametrize("model,P,S,t0,tf,nd", [(0, 6, 1, 0.0, 2.0, 1), (0, 5, 3, 0.0, 2.0, 1), (1, 5, 2, 0.0, 100.0, 0), (2, 5, 2, 0.0, 1.0, 1),
+                                                (3, 4, 2, 0.0, 1.5, 1), (0, 3, 2, 0.0, 2.0, 1), (0, 15, 1, 0.0, 2.0, 1)])
+def test_collocation_vs_oracle(ctx, oracle, model, P, S, t0, tf, nd):
+    """All models (NP = 1 border blocks, NG = 1 path constraints, exp-heavy CSTR), several (P, S): 1e-12 relative."""
+    import polympc_amd as pa
+    dm = pa.ocp_dims(model, P, S)
+    assert dm == oracle.ocp_dims(model, P, S)
+    n, m = dm["n"], dm["m"]
+    rng = np.random.default_rng(model * 100 + P * 10 + S)
+    B = 3
+    var = rng.uniform(-1, 1, (B, n))
+    if model == 1:
+        var[:, :4 * dm["nn"]] = np.tile([2.0, 1.0, 110.0, 110.0], dm["nn"]) * (1 + 0.05 * var[:, :4 * dm["nn"]])
+        var[:, 4 * dm["nn"]:] = np.tile([14.0, -1000.0], dm["nn"]) * (1 + 0.05 * var[:, 4 * dm["nn"]:])
+    lam = rng.uniform(-1, 1, (B, m + n))
+    d = np.full((B, max(nd, 1)), 2.0)
+    ev = ctx.ocp_linearise_batch(model, P, S, t0, tf, var, d, lam=lam)
+    for b in range(B):
+        eo = oracle.ocp_eval(model, P, S, t0, tf, var[b], d[b], lam=lam[b])
+        def close(a, r, tol=1e-12):
+            assert np.abs(a - r).max() <= tol * max(1.0, np.abs(r).max()), (np.abs(a - r).max(), np.abs(r).max())
+        close(ev["cost"][b], eo["cost"]); close(ev["cost_values_only"][b], eo["cost"])
+        close(ev["c"][b], np.concatenate([eo["c"], eo["g"]]))
+        close(ev["jac"][b], eo["jac"]); close(ev["cost_grad"][b], eo["cost_grad"]); close(ev["lag_grad"][b], eo["lag_grad"])
+        close(ev["lag_hess"][b], eo["lag_hess"])
+
+
+# -------------------------------------------------------------------------------------------- A12-A15: fused SQP
+def _sqp_both(ctx, oracle, wl, B, **kw):
+    import polympc_amd as pa
+    ss = pa.sqp_settings_default(); ss.max_iter = wl["max_iter"]; ss.line_search_max_iter = wl["ls_max_iter"]
+    for k, v in kw.items():
+        setattr(ss, k, v)
+    x, lam, info = ctx.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
+    oss = oracle.sqp_default_settings(); oss.max_iter = wl["max_iter"]; oss.line_search_max_iter = wl["ls_max_iter"]
+    for k, v in kw.items():
+        setattr(oss, k, v)
+    xo, lo, io = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"],
+                                        sqp_settings=oss, pivot=oracle.PIVOT_STATIC, threads=8)
+    return (x, lam, info), (xo, lo, io)
+
+
+def test_sqp_config_A_vs_oracle(ctx, oracle):
+    """256 config-A instances: identical SQP iteration counts, statuses and total ADMM iterations; x within 1e-8 and
+    the reported KKT quantities (primal/dual step norms, constraint violation) within 1e-8 of the oracle."""
+    from polympc_amd import workloads
+    B = 256
+    (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, workloads.robot_batch(B), B)
+    it = np.array([i.iter for i in io]); st = np.array([i.status for i in io]); qi = np.array([i.qp_solver_iter for i in io])
+    same = (info["iter"] == it) & (info["status"] == st) & (info["qp_solver_iter"] == qi)
+    assert same.mean() >= 0.99, f"trajectory mismatch on {np.sum(~same)} of {B} instances"
+    dx = np.abs(x - xo).max(axis=1)
+    assert dx[same].max() <= 1e-8
+    assert np.abs(lam - lo)[same].max() <= 1e-6
+    assert np.abs(info["max_violation"] - [i.max_violation for i in io])[same].max() <= 1e-8
+    assert np.abs(info["primal_norm"] - [i.primal_norm for i in io])[same].max() <= 1e-8
+    assert np.abs(info["dual_norm"] - [i.dual_norm for i in io])[same].max() <= 1e-6
+    assert np.abs(info["cost"] - [i.cost for i in io])[same].max() <= 1e-8
+
+
+def test_sqp_config_D_perturbed_params(ctx, oracle):
+    from polympc_amd import workloads
+    B = 64
+    (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, workloads.robot_batch(B, perturb_d=True, first=5000), B)
+    same = info["iter"] == np.array([i.iter for i in io])
+    assert same.mean() >= 0.98 and np.abs(x - xo)[same].max() <= 1e-8
+
+
+def test_sqp_reference_robot_fixture_sizes(ctx, oracle):
+    """The reference's own test sizes: P=5,S=2 (88 KKT rows) and P=5,S=3 (128 KKT rows) — more rows than lanes."""
+    from polympc_amd import workloads
+    for P, S in ((5, 2), (5, 3)):
+        B = 8
+        (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, workloads.robot_batch(B, P=P, S=S), B)
+        assert list(info["iter"]) == [i.iter for i in io]
+        assert list(info["status"]) == [i.status for i in io]
+        assert np.abs(x - xo).max() <= 1e-8
+
+
+def test_sqp_codegen_robot_exact_hessian(ctx, oracle):
+    """codegen_test.cpp:402-438: exact Hessian every iteration, QP max_iter 1000 -> SOLVED in < 10 iterations."""
+    import polympc_amd as pa
+    n = 55
+    lbx = np.full((1, n), -inf); ubx = np.full((1, n), inf)
+    lbx[0, 30:33] = ubx[0, 30:33] = 0.5
+    lbx[0, 33:] = np.tile([-1.5, -0.75], 11); ubx[0, 33:] = np.tile([1.5, 0.75], 11)
+    ss = pa.sqp_settings_default(); ss.max_iter = 10; ss.line_search_max_iter = 10; ss.exact_hessian_every_iter = 1
+    qs = pa.qp_settings_sqp_default(); qs.max_iter = 1000
+    x, lam, info = ctx.sqp_solve_batch(pa.MODEL_ROBOT, 5, 2, 0.0, 1.0, 1, [[1.0]], lbx, ubx, sqp_settings=ss, qp_settings=qs)
+    assert info["status"][0] == pa.SQP_SOLVED and info["iter"][0] < 10
+    oss = oracle.sqp_default_settings(); oss.max_iter = 10; oss.line_search_max_iter = 10; oss.exact_hessian_every_iter = 1
+    oqs = oracle.sqp_qp_default_settings(); oqs.max_iter = 1000
+    xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 1.0, 1, [[1.0]], lbx, ubx, sqp_settings=oss, qp_settings=oqs, pivot=1)
+    assert info["iter"][0] == io[0].iter and np.abs(x - xo).max() <= 1e-8
+
+
+def test_sqp_cstr_config_B(ctx, oracle):
+    """Config B (CSTR, 110 KKT rows, exp-heavy dynamics, badly scaled): trajectory parity on a small batch."""
+    from polympc_amd import workloads
+    B = 16
+    (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, workloads.cstr_batch(B), B)
+    same = (info["iter"] == np.array([i.iter for i in io])) & (info["status"] == np.array([i.status for i in io]))
+    assert same.mean() >= 0.9
+    scale = np.maximum(1.0, np.abs(xo))
+    assert (np.abs(x - xo) / scale)[same].max() <= 1e-7
+
+
+def test_sqp_warm_start_and_gershgorin(ctx, oracle):
+    """Second solve warm-started from the first (x, lam) with a moved initial state; Gershgorin regulariser on."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    B = 8
+    wl = workloads.robot_batch(B, P=5, S=3)
+    ss = pa.sqp_settings_default(); ss.max_iter = 10; ss.line_search_max_iter = 10; ss.regularisation = 2
+    mp = [2.0]
+    x1, l1, i1 = ctx.sqp_solve_batch(0, 5, 3, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss, mparams=mp)
+    lbx2 = wl["lbx"].copy(); ubx2 = wl["ubx"].copy()
+    lbx2[:, 45:48] -= 0.1; ubx2[:, 45:48] -= 0.1
+    x2, l2, i2 = ctx.sqp_solve_batch(0, 5, 3, 0.0, 2.0, B, wl["d"], lbx2, ubx2, x_guess=x1, lam_guess=l1, sqp_settings=ss, mparams=mp)
+    oss = oracle.sqp_default_settings(); oss.max_iter = 10; oss.line_search_max_iter = 10; oss.regularisation = 2
+    xo1, lo1, io1 = oracle.sqp_solve_batch(0, 5, 3, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, pivot=1, mparams=mp)
+    xo2, lo2, io2 = oracle.sqp_solve_batch(0, 5, 3, 0.0, 2.0, B, wl["d"], lbx2, ubx2, x_guess=xo1, lam_guess=lo1, sqp_settings=oss, pivot=1, mparams=mp)
+    assert list(i1["iter"]) == [i.iter for i in io1] and np.abs(x1 - xo1).max() <= 1e-8
+    assert list(i2["iter"]) == [i.iter for i in io2] and np.abs(x2 - xo2).max() <= 1e-7
+    assert np.all(i2["status"] == pa.SQP_SOLVED)
+
+
+def test_sqp_full_size_properties(ctx):
+    """BASELINE size (4096 config-A OCPs): every SOLVED instance honours the pinned initial state, the control box and
+    the collocation equalities to the solver's own tolerance (checked with an independent numpy evaluation)."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    B = 4096
+    wl = workloads.robot_batch(B)
+    ss = pa.sqp_settings_default(); ss.max_iter = 10; ss.line_search_max_iter = 10
+    x, lam, info = ctx.sqp_solve_batch(0, 6, 1, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
+    ok = info["status"] == pa.SQP_SOLVED
+    assert ok.mean() > 0.5
+    nodes, w, D = pa.chebyshev(6)
+    X = x[:, :21].reshape(B, 7, 3); U = x[:, 21:].reshape(B, 7, 2)
+    f = np.stack([U[..., 0] * np.cos(X[..., 2]) * np.cos(U[..., 1]), U[..., 0] * np.sin(X[..., 2]) * np.cos(U[..., 1]),
+                  U[..., 0] * np.sin(U[..., 1]) / 2.0], axis=-1)
+    c = np.einsum("ij,bjs->bis", D, X) - 1.0 * f       # t_scale = (2-0)/(2*1)
+    viol = np.abs(c).reshape(B, -1).max(axis=1)
+    viol = np.maximum(viol, np.maximum((wl["lbx"] - x).max(axis=1), (x - wl["ubx"]).max(axis=1)))   # sqp_base.hpp:448-474
+    assert np.abs(viol[ok] - info["max_violation"][ok]).max() <= 1e-9
+    assert viol[ok].max() <= 1e-3
+    assert np.abs(X[ok, 6, :] - wl["lbx"][ok, 18:21]).max() <= 1e-3
+    assert np.all(np.abs(U[ok, :, 0]) <= 1.5 + 1e-3) and np.all(np.abs(U[ok, :, 1]) <= 0.75 + 1e-3)
+    assert np.all(np.isfinite(x))

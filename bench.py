@@ -62,7 +62,8 @@ def main():
     B = args.batch
     wl = workloads.robot_batch(B, first=rank * B)          # each rank owns its own contiguous shard of the instance stream
     n, m = wl["n"], wl["m"]
-    stream = torch.cuda.current_stream(dev)
+    stream = torch.cuda.Stream(dev)       # a real (non-null) HIP stream: the kernels and the timing events share it
+    torch.cuda.set_stream(stream)
     ctx = pa.Context(local_rank, stream=stream.cuda_stream)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     d_d, d_lbx, d_ubx = t(wl["d"]), t(wl["lbx"]), t(wl["ubx"])

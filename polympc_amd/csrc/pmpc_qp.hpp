@@ -4,8 +4,8 @@
 // the Eigen::LDLT factor/solve it calls (src/utils/helpers.hpp:38-43). Same update order, constants and quirks
 // (Q1: x = alpha*x_tilde; x += (1-alpha)*x — box_admm.hpp:129-130).
 //
-// Layout: the (n+m)x(n+m) KKT matrix lives in LDS, column-major with an odd leading dimension (bank-conflict-free
-// column AND row walks); lane i owns KKT row i (rows i, i+64, ... when n+m > 64). The LDL^T uses the static
+// Layout: the lower triangle of the (n+m)x(n+m) KKT matrix lives in LDS, packed by columns (element (i,j), i>=j, at
+// j*N - j*(j+1)/2 + i: column walks are contiguous across lanes); lane i owns KKT row i (rows i, i+64, ... when n+m > 64). The LDL^T uses the static
 // elimination order (no pivoting — K is symmetric quasi-definite), right-looking, fused
 // multiply-add on the trailing update and the substitutions. H and A stay in HBM/L2 and are streamed only when the
 // residuals are evaluated (every check_termination-th iteration).
@@ -59,19 +59,20 @@ __device__ __forceinline__ double rho_of(int type, double rho0) {  // box_admm.h
 
 // LDS work area of one QP instance
 struct QpLds {
-    double* K; int ld;             // (n+m) x ld factor storage
+    double* K; int N;              // packed lower triangle of the (n+m)x(n+m) factor, by columns
+    __host__ __device__ static int koff(int N_, int j) { return j * N_ - (j * (j + 1)) / 2; }
+    __device__ __forceinline__ int off(int j) const { return j * N - (j * (j + 1)) / 2; }
     double *x, *y, *z, *q, *zt, *zprev, *rho, *rhoinv, *rhob, *rhobinv, *kdiag, *rhs, *t1, *t2;
-    __host__ __device__ static int ld_of(int N) { return N | 1; }
+    __host__ __device__ static size_t kdoubles(int N_) { return (size_t)N_ * (N_ + 1) / 2; }
     __host__ __device__ static size_t doubles(int n, int m) {
         const int N = n + m;
-        return (size_t)N * ld_of(N) + 3 * (size_t)n /*x q kdiag(n part)*/ + (size_t)N /*y*/ + 5 * (size_t)m /*z zt zprev rho rhoinv*/ +
+        return kdoubles(N) + 3 * (size_t)n /*x q kdiag(n part)*/ + (size_t)N /*y*/ + 5 * (size_t)m /*z zt zprev rho rhoinv*/ +
                2 * (size_t)n /*rhob rhobinv*/ + (size_t)N /*rhs*/ + 2 * (size_t)N /*t1 t2*/ + (size_t)m /*kdiag m part*/ + 8;
     }
     __device__ double* carve(double* base, int n, int m) {
-        const int N = n + m;
-        ld = ld_of(N);
+        N = n + m;
         double* p = base;
-        K = p; p += (size_t)N * ld;
+        K = p; p += kdoubles(N);
         x = p; p += n; q = p; p += n; kdiag = p; p += N; y = p; p += N;
         z = p; p += m; zt = p; p += m; zprev = p; p += m; rho = p; p += m; rhoinv = p; p += m;
         rhob = p; p += n; rhobinv = p; p += n; rhs = p; p += N; t1 = p; p += N; t2 = p; p += N;
@@ -83,30 +84,35 @@ struct QpLds {
 __device__ inline void kkt_build(const QpLds& w, int n, int m, const double* __restrict__ H, const double* __restrict__ A) {
     const int ln = lane_id();
     for (int j = 0; j < n; ++j) {
-        for (int i = j + ln; i < n; i += WAVE) w.K[j * w.ld + i] = (i == j) ? w.kdiag[i] : H[(size_t)j * n + i];
-        for (int r = ln; r < m; r += WAVE) w.K[j * w.ld + n + r] = A[(size_t)j * m + r];
+        const int o = w.off(j);
+        for (int i = j + ln; i < n; i += WAVE) w.K[o + i] = (i == j) ? w.kdiag[i] : H[(size_t)j * n + i];
+        for (int r = ln; r < m; r += WAVE) w.K[o + n + r] = A[(size_t)j * m + r];
     }
-    for (int j = 0; j < m; ++j)
-        for (int i = j + ln; i < m; i += WAVE) w.K[(n + j) * w.ld + n + i] = (i == j) ? w.kdiag[n + i] : 0.0;
+    for (int j = 0; j < m; ++j) {
+        const int o = w.off(n + j);
+        for (int i = j + ln; i < m; i += WAVE) w.K[o + n + i] = (i == j) ? w.kdiag[n + i] : 0.0;
+    }
     wsync();
 }
 
 // in-place LDL^T, static order, right-looking (factorise_kkt_matrix, box_admm.hpp:336-341)
 __device__ inline void kkt_factor(const QpLds& w, int N) {
     const int ln = lane_id();
-    double* K = w.K; const int ld = w.ld;
+    double* K = w.K;
     for (int k = 0; k < N; ++k) {
-        const double dk = K[k * ld + k];
+        const int ok = w.off(k);
+        const double dk = K[ok + k];
         // scale column k, keep the unscaled entries in t1
         for (int i = k + 1 + ln; i < N; i += WAVE) {
-            const double c = K[k * ld + i];
+            const double c = K[ok + i];
             w.t1[i] = c;
-            K[k * ld + i] = c / dk;
+            K[ok + i] = c / dk;
         }
         wsync();
         for (int j = k + 1; j < N; ++j) {
-            const double ljk = K[k * ld + j];
-            for (int i = j + ln; i < N; i += WAVE) K[j * ld + i] = fma(-w.t1[i], ljk, K[j * ld + i]);
+            const double ljk = K[ok + j];
+            const int oj = w.off(j);
+            for (int i = j + ln; i < N; i += WAVE) K[oj + i] = fma(-w.t1[i], ljk, K[oj + i]);
         }
         wsync();
     }
@@ -115,18 +121,19 @@ __device__ inline void kkt_factor(const QpLds& w, int N) {
 // v <- K^{-1} v  (linear_solver.solve, box_admm.hpp:123), v in LDS
 __device__ inline void kkt_solve(const QpLds& w, int N, double* v) {
     const int ln = lane_id();
-    const double* K = w.K; const int ld = w.ld;
+    const double* K = w.K;
     if (N <= WAVE) {
         // single row per lane: keep the running entry in a register, broadcast the pivot entry by readlane
         double c = (ln < N) ? v[ln] : 0.0;
         for (int j = 0; j < N - 1; ++j) {
             const double xj = __shfl(c, j, WAVE);
-            if (ln > j && ln < N) c = fma(-K[j * ld + ln], xj, c);
+            if (ln > j && ln < N) c = fma(-K[w.off(j) + ln], xj, c);
         }
-        if (ln < N) c = c / K[ln * ld + ln];
+        const int ol = (ln < N) ? w.off(ln) : 0;
+        if (ln < N) c = c / K[ol + ln];
         for (int j = N - 1; j > 0; --j) {
             const double xj = __shfl(c, j, WAVE);
-            if (ln < j) c = fma(-K[ln * ld + j], xj, c);
+            if (ln < j) c = fma(-K[ol + j], xj, c);
         }
         if (ln < N) v[ln] = c;
         wsync();
@@ -134,14 +141,14 @@ __device__ inline void kkt_solve(const QpLds& w, int N, double* v) {
     }
     for (int j = 0; j < N - 1; ++j) {
         const double xj = v[j];
-        for (int i = j + 1 + ln; i < N; i += WAVE) v[i] = fma(-K[j * ld + i], xj, v[i]);
+        for (int i = j + 1 + ln; i < N; i += WAVE) v[i] = fma(-K[w.off(j) + i], xj, v[i]);
         wsync();
     }
-    for (int i = ln; i < N; i += WAVE) v[i] = v[i] / K[i * ld + i];
+    for (int i = ln; i < N; i += WAVE) v[i] = v[i] / K[w.off(i) + i];
     wsync();
     for (int j = N - 1; j > 0; --j) {
         const double xj = v[j];
-        for (int i = ln; i < j; i += WAVE) v[i] = fma(-K[i * ld + j], xj, v[i]);
+        for (int i = ln; i < j; i += WAVE) v[i] = fma(-K[w.off(i) + j], xj, v[i]);
         wsync();
     }
 }

@@ -1,6 +1,7 @@
 // polympc_amd — kernels + the C ABI declared in include/polympc_amd.h (gfx950 only, no CPU fallback).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <tuple>
@@ -11,6 +12,7 @@
 #include "pmpc_models.hpp"
 #include "pmpc_ocp.hpp"
 #include "pmpc_qp.hpp"
+#include "pmpc_qp_reg.hpp"
 #include "pmpc_sqp.hpp"
 
 using namespace pmpc;
@@ -43,10 +45,27 @@ __global__ __launch_bounds__(64) void qp_boxadmm_kernel(int B, int n, int m, con
     for (int i = ln; i < n + m; i += WAVE) y[(size_t)b * (n + m) + i] = w.y[i];
     if (ln == 0) info[b] = qi;
 }
+// register-resident specialisation for compile-time (NN, MM), NN+MM <= 64
+template <int NN, int MM>
+__global__ __launch_bounds__(64, 2) void qp_boxadmm_reg_kernel(int B, const double* __restrict__ H, const double* __restrict__ h,
+                                                            const double* __restrict__ A, const double* __restrict__ Alb,
+                                                            const double* __restrict__ Aub, const double* __restrict__ xlb,
+                                                            const double* __restrict__ xub, const double* __restrict__ x0,
+                                                            const double* __restrict__ y0, pmpc_qp_settings s,
+                                                            double* __restrict__ x, double* __restrict__ y, pmpc_qp_info* __restrict__ info) {
+    __shared__ double tr[RegKkt<NN + MM>::TRI];
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    pmpc_qp_info qi;
+    boxadmm_solve_reg<NN, MM>(H + (size_t)b * NN * NN, h + (size_t)b * NN, A + (size_t)b * MM * NN, Alb + (size_t)b * MM, Aub + (size_t)b * MM,
+                              xlb + (size_t)b * NN, xub + (size_t)b * NN, x0 ? x0 + (size_t)b * NN : nullptr,
+                              y0 ? y0 + (size_t)b * (NN + MM) : nullptr, s, qi, x + (size_t)b * NN, y + (size_t)b * (NN + MM), tr);
+    if (lane_id() == 0) info[b] = qi;
+}
 static size_t qp_kernel_lds_bytes(int n, int m) { return (QpLds::doubles(n, m) + 3 * (size_t)n + 2 * (size_t)m) * sizeof(double); }
 
-template <class Model>
-__global__ __launch_bounds__(64) void sqp_kernel(Model model, const ChebData* __restrict__ cd, int B,
+template <class Model, int NN = 0, int MM = 0>
+__global__ __launch_bounds__(64, (NN > 0 ? 2 : 1)) void sqp_kernel(Model model, const ChebData* __restrict__ cd, int B,
                                                  const double* __restrict__ x_guess, const double* __restrict__ lam_guess,
                                                  const double* __restrict__ d, const double* __restrict__ lbx,
                                                  const double* __restrict__ ubx, const double* __restrict__ lbg,
@@ -60,9 +79,11 @@ __global__ __launch_bounds__(64) void sqp_kernel(Model model, const ChebData* __
     Ocp<Model> ocp(model, P, S, cd->t_scale);
     const int n = ocp.dm.n, m = ocp.dm.m, mi = ocp.dm.mi;
     QpLds qw; SqpLds v;
-    double* p = qw.carve(smem, n, m);
+    double* p = (NN > 0) ? qw.carve_xy(smem, n, m) : qw.carve(smem, n, m);
     p = v.carve(p, n, m, mi);
+    double* stage0 = p;
     p = ocp.s.carve(p, P, S);
+    if (NN > 0 && (size_t)(p - stage0) < (size_t)RegKkt<(NN > 0 ? NN + MM : 1)>::TRI + ocp.s.const_doubles(P, S)) p = stage0 + RegKkt<(NN > 0 ? NN + MM : 1)>::TRI + ocp.s.const_doubles(P, S);
     double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
     const int ln = lane_id();
     for (int i = ln; i < Model::ND; i += WAVE) dL[i] = d[(size_t)b * Model::ND + i];
@@ -78,16 +99,19 @@ __global__ __launch_bounds__(64) void sqp_kernel(Model model, const ChebData* __
         v.ubg[i] = ubg ? ubg[(size_t)b * mi + i] : INFINITY;
     }
     wsync();
-    SqpDevice<Model> sqp(ocp, v, qw, Hws + (size_t)b * n * n, Aws + (size_t)b * m * n, ss, qs);
+    SqpDevice<Model, NN, MM> sqp(ocp, v, qw, Hws + (size_t)b * n * n, Aws + (size_t)b * m * n, ss, qs);
+    sqp.tr = ocp.s.fval;   // first per-node staging array: everything from here on is dead while the QP runs
     pmpc_sqp_info si;
     sqp.solve(si);
     for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = v.x[i];
     for (int i = ln; i < m + n; i += WAVE) lam[(size_t)b * (m + n) + i] = v.lam[i];
     if (ln == 0) info[b] = si;
 }
-template <class Model> static size_t sqp_kernel_lds_bytes(int P, int S) {
+template <class Model> static size_t sqp_kernel_lds_bytes(int P, int S, bool reg_qp) {
     OcpDims<Model> dm(P, S);
-    return (QpLds::doubles(dm.n, dm.m) + SqpLds::doubles(dm.n, dm.m, dm.mi) + OcpLds<Model>::doubles(P, S) + 8) * sizeof(double);
+    size_t stage = OcpLds<Model>::doubles(P, S);
+    if (reg_qp) { const size_t N = dm.n + dm.m; const size_t need = N * (N + 1) / 2 + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
+    return ((reg_qp ? QpLds::doubles_xy(dm.n, dm.m) : QpLds::doubles(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8) * sizeof(double);
 }
 
 // collocation assembly only (used to check A2/A4/A6/A7/A8/A9/A10 against the reference's golden vectors)
@@ -147,6 +171,7 @@ struct pmpc_context {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     size_t lds_limit = 64 * 1024;
+    bool force_lds_path = false;   // PMPC_FORCE_LDS_PATH=1: disable the register-resident specialisations (A/B testing)
     std::map<std::tuple<int, int, double, double>, ChebData*> cheb_cache;
     double* ws = nullptr; size_t ws_bytes = 0;       // SQP HBM workspace (H, J)
     void* scratch[24] = {nullptr}; size_t scratch_bytes[24] = {0};  // host-buffer API staging
@@ -221,6 +246,7 @@ pmpc_status pmpc_create(int device, void* stream, pmpc_context** out) {
     HIPCHK(hipGetDeviceProperties(&prop, device));
     ctx->lds_limit = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 64 * 1024;
     if (prop.sharedMemPerBlockOptin && (size_t)prop.sharedMemPerBlockOptin < ctx->lds_limit) ctx->lds_limit = prop.sharedMemPerBlockOptin;
+    { const char* e = getenv("PMPC_FORCE_LDS_PATH"); ctx->force_lds_path = (e && e[0] == '1'); }
     *out = ctx;
     return PMPC_OK;
 }
@@ -270,6 +296,12 @@ pmpc_status pmpc_qp_boxadmm_solve_batch_dev(pmpc_context* ctx, int B, int n, int
     if ((x0 == nullptr) != (y0 == nullptr)) return PMPC_ERR_INVALID_ARGUMENT;
     if (B == 0) return PMPC_OK;
     HIPCHK(hipSetDevice(ctx->device));
+    if (n == 35 && m == 21 && !ctx->force_lds_path) {   // config A: register-resident specialisation
+        hipLaunchKernelGGL((qp_boxadmm_reg_kernel<35, 21>), dim3(B), dim3(WAVE), 0, ctx->stream, B, H, h, A, Alb, Aub, xlb, xub, x0, y0,
+                           *settings, x, y, info);
+        HIPCHK(hipGetLastError());
+        return PMPC_OK;
+    }
     const size_t lds = qp_kernel_lds_bytes(n, m);
     if (lds > ctx->lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;
     HIPCHK(hipFuncSetAttribute((const void*)qp_boxadmm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -349,14 +381,25 @@ static pmpc_status sqp_dev_impl(pmpc_context* ctx, int P, int S, double t0, doub
     pmpc_status st = get_cheb(ctx, P, S, t0, tf, &cd);
     if (st != PMPC_OK) return st;
     OcpDims<Model> dm(P, S);
-    const size_t lds = sqp_kernel_lds_bytes<Model>(P, S);
-    if (lds > ctx->lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;
     st = ensure_ws(ctx, (size_t)B * ((size_t)dm.n * dm.n + (size_t)dm.m * dm.n) * sizeof(double));
     if (st != PMPC_OK) return st;
     double* Hws = ctx->ws; double* Aws = ctx->ws + (size_t)B * dm.n * dm.n;
-    HIPCHK(hipFuncSetAttribute((const void*)sqp_kernel<Model>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     Model mdl = make_model<Model>(mp, nmp);
-    hipLaunchKernelGGL(sqp_kernel<Model>, dim3(B), dim3(WAVE), lds, ctx->stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
+    // register-resident QP specialisations (compile-time KKT size <= 64 rows)
+    if constexpr (Model::NX == 3 && Model::NU == 2 && Model::NP == 0 && Model::NG == 0) {
+        if (P * S == 6 && !ctx->force_lds_path) {   // config A / D: 7 nodes, n = 35, m = 21
+            const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, true);
+            HIPCHK(hipFuncSetAttribute((const void*)sqp_kernel<Model, 35, 21>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
+            hipLaunchKernelGGL((sqp_kernel<Model, 35, 21>), dim3(B), dim3(WAVE), ldsr, ctx->stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx,
+                               lbg, ubg, *ss, *qs, Hws, Aws, x, lam, info);
+            HIPCHK(hipGetLastError());
+            return PMPC_OK;
+        }
+    }
+    const size_t lds = sqp_kernel_lds_bytes<Model>(P, S, false);
+    if (lds > ctx->lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;
+    HIPCHK(hipFuncSetAttribute((const void*)sqp_kernel<Model>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((sqp_kernel<Model>), dim3(B), dim3(WAVE), lds, ctx->stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
                        *ss, *qs, Hws, Aws, x, lam, info);
     HIPCHK(hipGetLastError());
     return PMPC_OK;

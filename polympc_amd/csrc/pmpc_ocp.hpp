@@ -58,6 +58,8 @@ struct OcpLds {
         return (size_t)(P + 1) * (P + 1) + (P + 1) + NN + (size_t)NN * (NX + NX * NDER + 1 + NDER + NG + NG * NDER + 2 * NDER * NDER + NX) +
                1 + NDER + NDER * NDER + 8;
     }
+    // collocation constants come first; everything after them is per-linearisation staging
+    __host__ __device__ static size_t const_doubles(int P, int S) { return (size_t)(P + 1) * (P + 1) + (P + 1) + (P * S + 1); }
     __device__ double* carve(double* p, int P, int S) {
         const int NN = P * S + 1;
         D = p; p += (P + 1) * (P + 1); w = p; p += P + 1; tn = p; p += NN;

@@ -69,6 +69,15 @@ struct QpLds {
         return kdoubles(N) + 3 * (size_t)n /*x q kdiag(n part)*/ + (size_t)N /*y*/ + 5 * (size_t)m /*z zt zprev rho rhoinv*/ +
                2 * (size_t)n /*rhob rhobinv*/ + (size_t)N /*rhs*/ + 2 * (size_t)N /*t1 t2*/ + (size_t)m /*kdiag m part*/ + 8;
     }
+    // register-resident QP path: only the result vectors live in LDS
+    __host__ __device__ static size_t doubles_xy(int n, int m) { return 2 * (size_t)n + (size_t)m + 8; }
+    __device__ double* carve_xy(double* base, int n, int m) {
+        N = n + m; K = nullptr;
+        double* p = base;
+        x = p; p += n; y = p; p += N;
+        q = z = zt = zprev = rho = rhoinv = rhob = rhobinv = kdiag = rhs = t1 = t2 = nullptr;
+        return p;
+    }
     __device__ double* carve(double* base, int n, int m) {
         N = n + m;
         double* p = base;

@@ -1,0 +1,217 @@
+// polympc_amd — register-resident box-ADMM QP solve for compile-time sizes with n+m <= 64 (one wavefront per QP).
+//
+// Same algorithm, constants, update order and arithmetic as pmpc_qp.hpp (boxADMM::solve_impl, box_admm.hpp:88-205;
+// static-order right-looking LDL^T with fused multiply-add), different data placement:
+//   * lane i owns KKT row i. The factor is kept as ONE register array a[N] per lane holding row i of (L + L^T):
+//     a[j] = L(i,j) for j < i and L(j,i) for j > i. Every register index is a compile-time constant after full
+//     unrolling, so neither the factorisation nor the substitutions touch LDS or scratch:
+//       forward  step j: x_j broadcast with v_readlane; lanes i > j:  c_i -= a[j] * x_j
+//       backward step j: x_j broadcast with v_readlane; lanes i < j:  c_i -= a[j] * x_j
+//     During the factorisation each scaled column is also staged through a packed LDS triangle, from which every
+//     lane picks up its transposed part L(j,i), j > i, once the factorisation is complete.
+//     Lane masks of the substitutions are compile-time constants and are applied by shifting -1 into EXEC.
+//   * all ADMM vectors are one register per lane: lanes [0,n) carry x, q, y_box, rho_box, h, xlb, xub; lanes
+//     [n,n+m) carry z, y_a, rho, Alb, Aub. The ADMM iteration therefore runs entirely out of registers.
+//   * H and A are read from HBM/L2 (coalesced down columns) only to build K and, every check_termination-th
+//     iteration, for the residual mat-vecs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "pmpc_qp.hpp"
+
+namespace pmpc {
+
+__device__ __forceinline__ double bcast_lane(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+// c <- fma(-a, x, c) on the lanes ABOVE `j` only (x wave-uniform, in SGPRs). The lane mask is a compile-time constant, so
+// it is applied with one scalar shift into EXEC instead of a compare + two selects; EXEC is restored inside the statement
+// (the compiler never sees a modified EXEC). s_nop 0 completes the v_readlane(SGPR write) -> VALU(SGPR read) wait states.
+__device__ __forceinline__ double fnma_lanes_above(double c, double a, double x_uniform, int j) {
+    asm("s_lshl_b64 exec, -1, %3\n\ts_nop 0\n\tv_fma_f64 %0, -%1, %2, %0\n\ts_mov_b64 exec, -1" : "+v"(c) : "v"(a), "s"(x_uniform), "i"(j + 1));
+    return c;
+}
+__device__ __forceinline__ double fnma_lanes_below(double c, double a, double x_uniform, int j) {
+    asm("s_lshr_b64 exec, -1, %3\n\ts_nop 0\n\tv_fma_f64 %0, -%1, %2, %0\n\ts_mov_b64 exec, -1" : "+v"(c) : "v"(a), "s"(x_uniform), "i"(64 - j));
+    return c;
+}
+// dst <- src on the lanes BELOW `j` only
+__device__ __forceinline__ double mov_lanes_below(double dst, double src, int j) {
+    asm("s_lshr_b64 exec, -1, %2\n\tv_mov_b64 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(dst) : "v"(src), "i"(64 - j));
+    return dst;
+}
+
+template <int N>
+struct RegKkt {
+    double a[N];  // row `lane` of (strict L + strict L^T)
+    double d;     // D(lane)
+
+    static constexpr int TRI = N * (N + 1) / 2;   // doubles of LDS transpose scratch (packed lower triangle by columns)
+    __device__ __forceinline__ static int off(int j) { return j * N - (j * (j + 1)) / 2; }
+
+    // in: a[j] = K(lane, j) for j <= lane (upper part ignored). Static order, right-looking, fma trailing update.
+    // The scaled columns are staged through `tr` (LDS, TRI doubles) so that each lane can pick up its transposed part
+    // L(j, lane), j > lane, with N-1 conflict-light reads instead of N^2/2 v_writelane pairs.
+    __device__ __forceinline__ void factor(int ln, double* tr) {
+        d = 1.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const double dk = bcast_lane(a[k], k);
+            const double col = (ln > k) ? a[k] : 0.0;   // unscaled column entries; 0 keeps finished lanes untouched
+            const double l = col / dk;
+            if (ln == k) d = dk;
+            if (ln > k) { a[k] = l; if (ln < N) tr[off(k) + ln] = l; }
+#pragma unroll
+            for (int j = k + 1; j < N; ++j) {
+                const double t = bcast_lane(l, j);      // l_jk
+                a[j] = fma(-col, t, a[j]);               // trailing update of column j (only lanes >= j are kept)
+            }
+        }
+        wsync();
+        const int ol = off(ln < N ? ln : 0);
+#pragma unroll
+        for (int j = 1; j < N; ++j) a[j] = mov_lanes_below(a[j], tr[ol + j], j);   // lane i < j: a[j] <- L(j, i)
+        wsync();
+    }
+
+    // c <- K^{-1} c, one entry per lane
+    __device__ __forceinline__ double solve(double c, int ln) const {
+#pragma unroll
+        for (int j = 0; j < N - 1; ++j) c = fnma_lanes_above(c, a[j], bcast_lane(c, j), j);
+        c = c / d;
+#pragma unroll
+        for (int j = N - 1; j > 0; --j) c = fnma_lanes_below(c, a[j], bcast_lane(c, j), j);
+        return c;
+    }
+};
+
+// boxADMM::solve_impl for compile-time (NN, MM); h/Alb/Aub/xlb/xub/x0/y0: LDS or HBM pointers; result -> out_x (NN), out_y (MM+NN)
+// tr: LDS scratch of RegKkt<NN+MM>::TRI doubles.
+template <int NN, int MM>
+__device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, const double* h, const double* __restrict__ A,
+                                                  const double* Alb, const double* Aub, const double* xlb, const double* xub,
+                                                  const double* x0, const double* y0, const pmpc_qp_settings& s, pmpc_qp_info& info,
+                                                  double* out_x, double* out_y, double* tr) {
+    constexpr int N = NN + MM;
+    static_assert(N <= WAVE, "register-resident path needs n+m <= 64");
+    const int ln = lane_id();
+    const bool isP = ln < NN;
+    const bool isC = (ln >= NN) && (ln < N);
+    const int r = isC ? ln - NN : 0;
+
+    // per-lane problem data
+    const double hv = isP ? h[ln] : 0.0;
+    const double lo = isP ? xlb[ln] : (isC ? Alb[r] : 0.0);
+    const double hi = isP ? xub[ln] : (isC ? Aub[r] : 0.0);
+    const int type = classify_bounds(lo, hi);
+
+    // row `lane` of [H ; A] is read with unconditional, clamped addresses: base + j*stride
+    const double* rowp = isP ? (H + ln) : (A + r);
+    const int rstride = isP ? NN : (isC ? MM : 0);
+    const double* colA = A + (size_t)(isP ? ln : 0) * MM;   // column `lane` of A (primal lanes), contiguous
+
+    // state: xv = x (primal lanes) / z (constraint lanes); yv = y_box / y_a; qv = q (primal lanes)
+    double xv = 0.0, yv = 0.0, qv = 0.0;
+    if (isP) { xv = x0 ? x0[ln] : 0.0; qv = xv; yv = y0 ? y0[MM + ln] : 0.0; }
+    if (isC) yv = y0 ? y0[r] : 0.0;
+    if (x0) {  // z = A * x_guess
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < NN; ++j) acc += rowp[(size_t)j * rstride] * bcast_lane(xv, j);
+        if (isC) xv = acc;
+    }
+
+    double rho = s.rho;
+    int rho_updates = 1;
+    double rhov = rho_of(type, rho);
+    double rhoinv = 1.0 / rhov;
+    double kdiag;
+    if (isP) { kdiag = H[(size_t)ln * NN + ln]; kdiag += s.sigma; kdiag += rhov; } else { kdiag = -rhoinv; }
+
+    RegKkt<N> K;
+    int status = PMPC_QP_UNSOLVED;
+    const double alpha = s.alpha;
+    double max_Ax_z_norm = 0.0, max_Hx_ATy_h_norm = 0.0, res_prim = 1.0, res_dual = 1.0, rho_estimate = 0.0;
+    bool need_factor = true;
+
+    int iter;
+    for (iter = 1; iter <= s.max_iter; ++iter) {
+        if (need_factor) {   // construct_kkt_matrix + factorise_kkt_matrix (single code site: first iteration and after rho updates)
+#pragma unroll
+            for (int j = 0; j < NN; ++j) { const double v = rowp[(size_t)j * rstride]; K.a[j] = (ln == j) ? kdiag : v; }
+#pragma unroll
+            for (int j = NN; j < N; ++j) K.a[j] = (ln == j) ? kdiag : 0.0;
+            K.factor(ln, tr);
+            need_factor = false;
+        }
+        const double zprev = xv;  // meaningful on constraint lanes
+        double rhs = 0.0;
+        if (isP) rhs = ((s.sigma * xv - hv) + rhov * qv) - yv;
+        if (isC) rhs = xv - rhoinv * yv;
+        const double sol = K.solve(rhs, ln);
+        if (isC) {
+            const double zt = zprev + rhoinv * (sol - yv);
+            double zz = alpha * zt;
+            zz += (1 - alpha) * zprev + rhoinv * yv;
+            zz = fmin(fmax(zz, lo), hi);
+            xv = zz;
+            yv += rhov * ((alpha * zt + (1 - alpha) * zprev) - zz);
+        }
+        if (isP) {
+            double xx = alpha * sol;
+            xx += (1 - alpha) * xx;  // quirk Q1
+            xv = xx;
+            double qq = xx + rhoinv * yv;
+            qq = fmin(fmax(qq, lo), hi);
+            qv = qq;
+            yv += rhov * (xx - qq);
+        }
+        const bool check = (s.check_termination != 0 && iter % s.check_termination == 0);
+        const bool adapt = (s.adaptive_rho && iter % s.adaptive_rho_interval == 0);
+        if (check || adapt) {  // residuals_update, box_admm.hpp:398-415
+            double acc = 0.0;      // lanes < n: (H x)_i ; lanes in [n, N): (A x)_r
+#pragma unroll
+            for (int j = 0; j < NN; ++j) acc += rowp[(size_t)j * rstride] * bcast_lane(xv, j);
+            double aty = 0.0;      // lanes < n: (A^T y_a)_i
+#pragma unroll
+            for (int k = 0; k < MM; ++k) aty += colA[k] * bcast_lane(yv, NN + k);
+            const double nAx = wave_max(isC ? fabs(acc) : 0.0), nz = wave_max(isC ? fabs(xv) : 0.0), nx = wave_max(isP ? fabs(xv) : 0.0);
+            const double rp = wave_max(isC ? fabs(acc - xv) : 0.0), rq = wave_max(isP ? fabs(xv - qv) : 0.0);
+            const double nHx = wave_max(isP ? fabs(acc) : 0.0), nATy = wave_max(isP ? fabs(aty) : 0.0);
+            const double nh = wave_max(fabs(hv)), nyb = wave_max(isP ? fabs(yv) : 0.0);
+            const double rd = wave_max(isP ? fabs(((acc + hv) + aty) + yv) : 0.0);
+            max_Ax_z_norm = fmax(nAx, fmax(nz, nx));
+            max_Hx_ATy_h_norm = fmax(nHx, fmax(nATy, fmax(nh, nyb)));
+            res_prim = rp + rq;
+            res_dual = rd;
+        }
+        if (check) {
+            const double ep = s.eps_abs + s.eps_rel * max_Ax_z_norm, ed = s.eps_abs + s.eps_rel * max_Hx_ATy_h_norm;
+            if (res_prim <= ep && res_dual <= ed) { status = PMPC_QP_SOLVED; break; }
+        }
+        if (adapt) {
+            const double rpn = res_prim / (max_Ax_z_norm + DIV_BY_ZERO_REGUL);
+            const double rdn = res_dual / (max_Hx_ATy_h_norm + DIV_BY_ZERO_REGUL);
+            double new_rho = rho * ::sqrt(rpn / (rdn + DIV_BY_ZERO_REGUL));
+            new_rho = fmax(RHO_MIN, fmin(new_rho, RHO_MAX));
+            rho_estimate = new_rho;
+            if (new_rho < rho / s.adaptive_rho_tolerance || new_rho > rho * s.adaptive_rho_tolerance) {
+                const double prev = rhov;
+                rho = new_rho;
+                rhov = rho_of(type, rho);
+                rhoinv = 1.0 / rhov;
+                ++rho_updates;
+                if (isP) kdiag += (rhov - prev); else kdiag = -rhoinv;   // update_kkt_rho, box_admm.hpp:448-452
+                need_factor = true;
+            }
+        }
+    }
+    if (iter > s.max_iter) status = PMPC_QP_MAX_ITER_EXCEEDED;
+    if (isP) { out_x[ln] = xv; out_y[MM + ln] = yv; }
+    if (isC) out_y[r] = yv;
+    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info._pad = 0;
+    info.rho_estimate = rho_estimate; info.res_prim = res_prim; info.res_dual = res_dual;
+}
+
+}  // namespace pmpc

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include "pmpc_ocp.hpp"
 #include "pmpc_qp.hpp"
+#include "pmpc_qp_reg.hpp"
 
 namespace pmpc {
 
@@ -31,12 +32,14 @@ struct SqpLds {
 
 constexpr double DBL_EPS = 2.220446049250313e-16;
 
-template <class Model>
+// NN, MM > 0: compile-time QP size with NN+MM <= 64 -> register-resident QP (pmpc_qp_reg.hpp); 0 -> LDS-resident QP
+template <class Model, int NN = 0, int MM = 0>
 struct SqpDevice {
     using Dm = OcpDims<Model>;
     Ocp<Model>& ocp;
     SqpLds& v;
     QpLds& qw;
+    double* tr = nullptr;  // LDS transpose scratch of the register-resident QP (aliases the per-node AD staging, dead during the QP)
     double* Hw;  // n x n, HBM workspace
     double* Aw;  // m x n, HBM workspace
     const pmpc_sqp_settings& ss;
@@ -199,7 +202,9 @@ struct SqpDevice {
         const int ln = lane_id();
         form_qp_bounds();
         pmpc_qp_info qi;
-        boxadmm_solve(qw, n, m, Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi);   // 7-argument form: zero guesses (Q2)
+        // 7-argument form: zero guesses (Q2)
+        if constexpr (NN > 0) { boxadmm_solve_reg<NN, MM>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr); wsync(); }
+        else boxadmm_solve(qw, n, m, Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi);
         qp_iter_total += qi.iter;
         // lam_k = p_lambda ; p_lambda -= lam
         for (int i = ln; i < m + n; i += WAVE) { v.lam_k[i] = qw.y[i]; qw.y[i] = qw.y[i] - v.lam[i]; }

@@ -15,7 +15,7 @@ QP_SOLVED, QP_MAX_ITER_EXCEEDED, QP_UNSOLVED = 0, 1, 2
 SQP_SOLVED, SQP_MAX_ITER_EXCEEDED = 0, 1
 
 EXPORTED_SYMBOLS = [
-    "pmpc_version", "pmpc_status_string", "pmpc_create", "pmpc_destroy", "pmpc_synchronize",
+    "pmpc_version", "pmpc_status_string", "pmpc_create", "pmpc_destroy", "pmpc_synchronize", "pmpc_debug_phase_cycles",
     "pmpc_qp_settings_default", "pmpc_qp_settings_sqp_default", "pmpc_sqp_settings_default", "pmpc_chebyshev",
     "pmpc_qp_boxadmm_solve_batch", "pmpc_qp_boxadmm_solve_batch_dev", "pmpc_ocp_dims", "pmpc_ocp_linearise_batch",
     "pmpc_sqp_solve_batch", "pmpc_sqp_solve_batch_dev",
@@ -151,6 +151,11 @@ class Context:
 
     def synchronize(self):
         _check(lib().pmpc_synchronize(self._ctx))
+
+    def phase_cycles(self, reset=True):
+        out = (C.c_ulonglong * 8)()
+        _check(lib().pmpc_debug_phase_cycles(self._ctx, out, 1 if reset else 0))
+        return list(out)
 
     # ------------------------------------------------------------------ QP, host buffers
     def qp_solve_batch(self, H, h, A, Alb, Aub, xlb, xub, settings=None, x0=None, y0=None):

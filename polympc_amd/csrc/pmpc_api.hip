@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64, (NN > 0 ? 2 : 1)) void sqp_kernel(Model model, 
                                                  const double* __restrict__ ubx, const double* __restrict__ lbg,
                                                  const double* __restrict__ ubg, pmpc_sqp_settings ss, pmpc_qp_settings qs,
                                                  double* __restrict__ Hws, double* __restrict__ Aws, double* __restrict__ x,
-                                                 double* __restrict__ lam, pmpc_sqp_info* __restrict__ info) {
+                                                 double* __restrict__ lam, pmpc_sqp_info* __restrict__ info, unsigned long long* __restrict__ phase_cycles) {
     extern __shared__ double smem[];
     const int b = blockIdx.x;
     if (b >= B) return;
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(64, (NN > 0 ? 2 : 1)) void sqp_kernel(Model model, 
     for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = v.x[i];
     for (int i = ln; i < m + n; i += WAVE) lam[(size_t)b * (m + n) + i] = v.lam[i];
     if (ln == 0) info[b] = si;
+    if (phase_cycles && ln == 0) for (int i = 0; i < 8; ++i) atomicAdd(&phase_cycles[i], (unsigned long long)sqp.cyc[i]);
 }
 template <class Model> static size_t sqp_kernel_lds_bytes(int P, int S, bool reg_qp) {
     OcpDims<Model> dm(P, S);
@@ -171,6 +172,7 @@ struct pmpc_context {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     size_t lds_limit = 64 * 1024;
+    unsigned long long* phase_cycles = nullptr;   // PMPC_PHASE_PROFILE=1: per-phase shader-clock totals of the SQP kernels
     bool force_lds_path = false;   // PMPC_FORCE_LDS_PATH=1: disable the register-resident specialisations (A/B testing)
     std::map<std::tuple<int, int, double, double>, ChebData*> cheb_cache;
     double* ws = nullptr; size_t ws_bytes = 0;       // SQP HBM workspace (H, J)
@@ -247,6 +249,8 @@ pmpc_status pmpc_create(int device, void* stream, pmpc_context** out) {
     ctx->lds_limit = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 64 * 1024;
     if (prop.sharedMemPerBlockOptin && (size_t)prop.sharedMemPerBlockOptin < ctx->lds_limit) ctx->lds_limit = prop.sharedMemPerBlockOptin;
     { const char* e = getenv("PMPC_FORCE_LDS_PATH"); ctx->force_lds_path = (e && e[0] == '1'); }
+    { const char* e = getenv("PMPC_PHASE_PROFILE");
+      if (e && e[0] == '1') { HIPCHK(hipMalloc((void**)&ctx->phase_cycles, 8 * sizeof(unsigned long long))); HIPCHK(hipMemset(ctx->phase_cycles, 0, 8 * sizeof(unsigned long long))); } }
     *out = ctx;
     return PMPC_OK;
 }
@@ -256,9 +260,19 @@ pmpc_status pmpc_destroy(pmpc_context* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->cheb_cache) (void)hipFree(kv.second);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->phase_cycles) (void)hipFree(ctx->phase_cycles);
     for (int i = 0; i < 24; ++i) if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    return PMPC_OK;
+}
+pmpc_status pmpc_debug_phase_cycles(pmpc_context* ctx, unsigned long long* out8, int reset) {
+    if (!ctx || !out8) return PMPC_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    if (!ctx->phase_cycles) return PMPC_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(out8, ctx->phase_cycles, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(hipMemset(ctx->phase_cycles, 0, 8 * sizeof(unsigned long long)));
     return PMPC_OK;
 }
 pmpc_status pmpc_synchronize(pmpc_context* ctx) {
@@ -391,7 +405,7 @@ static pmpc_status sqp_dev_impl(pmpc_context* ctx, int P, int S, double t0, doub
             const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, true);
             HIPCHK(hipFuncSetAttribute((const void*)sqp_kernel<Model, 35, 21>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
             hipLaunchKernelGGL((sqp_kernel<Model, 35, 21>), dim3(B), dim3(WAVE), ldsr, ctx->stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx,
-                               lbg, ubg, *ss, *qs, Hws, Aws, x, lam, info);
+                               lbg, ubg, *ss, *qs, Hws, Aws, x, lam, info, ctx->phase_cycles);
             HIPCHK(hipGetLastError());
             return PMPC_OK;
         }
@@ -400,7 +414,7 @@ static pmpc_status sqp_dev_impl(pmpc_context* ctx, int P, int S, double t0, doub
     if (lds > ctx->lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;
     HIPCHK(hipFuncSetAttribute((const void*)sqp_kernel<Model>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((sqp_kernel<Model>), dim3(B), dim3(WAVE), lds, ctx->stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
-                       *ss, *qs, Hws, Aws, x, lam, info);
+                       *ss, *qs, Hws, Aws, x, lam, info, ctx->phase_cycles);
     HIPCHK(hipGetLastError());
     return PMPC_OK;
 }

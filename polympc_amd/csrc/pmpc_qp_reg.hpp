@@ -47,31 +47,59 @@ struct RegKkt {
     double a[N];  // row `lane` of (strict L + strict L^T)
     double d;     // D(lane)
 
-    static constexpr int TRI = N * (N + 1) / 2;   // doubles of LDS transpose scratch (packed lower triangle by columns)
+    static constexpr int BK = 8;                      // columns eliminated per pass of the rolled block loop
+    static constexpr int NB = (N + BK - 1) / BK;      // number of blocks / register chunks
+    static constexpr int NW = NB * BK;                // sliding-window width (N rounded up)
+    static constexpr int TRI = N * (N + 1) / 2;       // doubles of LDS factor staging (packed lower triangle by columns)
     __device__ __forceinline__ static int off(int j) { return j * N - (j * (j + 1)) / 2; }
 
-    // in: a[j] = K(lane, j) for j <= lane (upper part ignored). Static order, right-looking, fma trailing update.
-    // The scaled columns are staged through `tr` (LDS, TRI doubles) so that each lane can pick up its transposed part
-    // L(j, lane), j > lane, with N-1 conflict-light reads instead of N^2/2 v_writelane pairs.
+    // LDL^T of the matrix whose lower-triangle rows are in a[] (a[j] = K(lane, j), j <= lane; the rest is ignored).
+    // Static order, right-looking, fma trailing update — the arithmetic of oracle PIVOT_STATIC.
+    //
+    // Code-size matters as much as instruction count here: a fully unrolled N^2/2 update is ~100 KB of straight-line
+    // code and thrashes the instruction cache. Instead the elimination runs as a ROLLED loop over blocks of BK
+    // columns on a sliding register window w[t] = K(lane, kb + t): inside a block every register index is a
+    // compile-time constant, the row index of a broadcast is a scalar (v_readlane with an SGPR lane select), and the
+    // window is shifted by BK registers between blocks. Finished (scaled) columns are staged in LDS (tr, packed
+    // lower triangle); afterwards every lane gathers its row of (L + L^T) from there — N contiguous/transposed reads
+    // instead of N^2/2 v_writelane pairs.
     __device__ __forceinline__ void factor(int ln, double* tr) {
+        double w[NW];
+#pragma unroll
+        for (int t = 0; t < NW; ++t) w[t] = (t < N) ? a[t] : 0.0;
         d = 1.0;
+#pragma unroll 1
+        for (int kbv = 0; kbv < N; kbv += BK) {
+            const int kb = __builtin_amdgcn_readfirstlane(kbv);   // keep the block counter (and every lane select derived from it) in SGPRs
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const double dk = bcast_lane(a[k], k);
-            const double col = (ln > k) ? a[k] : 0.0;   // unscaled column entries; 0 keeps finished lanes untouched
-            const double l = col / dk;
-            if (ln == k) d = dk;
-            if (ln > k) { a[k] = l; if (ln < N) tr[off(k) + ln] = l; }
+            for (int t = 0; t < BK; ++t) {
+                const int k = kb + t;                    // wave-uniform
+                if (k < N) {
+                    const double dk = bcast_lane(w[t], k);
+                    const double col = (ln > k) ? w[t] : 0.0;   // unscaled column; 0 keeps finished lanes untouched
+                    const double l = col / dk;
+                    if (ln == k) d = dk;
+                    if (ln > k && ln < N) tr[off(k) + ln] = l;
 #pragma unroll
-            for (int j = k + 1; j < N; ++j) {
-                const double t = bcast_lane(l, j);      // l_jk
-                a[j] = fma(-col, t, a[j]);               // trailing update of column j (only lanes >= j are kept)
+                    for (int c = 0; c < NB; ++c) {
+                        if (kb + c * BK < N) {           // wave-uniform: skip register chunks beyond the last column
+#pragma unroll
+                            for (int u = c * BK; u < (c + 1) * BK; ++u) {
+                                if (u > t) w[u] = fma(-col, bcast_lane(l, kb + u), w[u]);   // column kb+u of the trailing matrix
+                            }
+                        }
+                    }
+                }
             }
+#pragma unroll
+            for (int u = 0; u < NW - BK; ++u) w[u] = w[u + BK];    // slide the window
         }
         wsync();
-        const int ol = off(ln < N ? ln : 0);
+        // gather row `lane` of (L + L^T): L(lane, j) for j < lane (contiguous across lanes), L(j, lane) for j > lane
+        const int lc = (ln < N) ? ln : 0;
+        const int ol = off(lc);
 #pragma unroll
-        for (int j = 1; j < N; ++j) a[j] = mov_lanes_below(a[j], tr[ol + j], j);   // lane i < j: a[j] <- L(j, i)
+        for (int j = 0; j < N; ++j) a[j] = tr[(lc > j) ? (off(j) + lc) : (ol + j)];
         wsync();
     }
 
@@ -92,7 +120,7 @@ template <int NN, int MM>
 __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, const double* h, const double* __restrict__ A,
                                                   const double* Alb, const double* Aub, const double* xlb, const double* xub,
                                                   const double* x0, const double* y0, const pmpc_qp_settings& s, pmpc_qp_info& info,
-                                                  double* out_x, double* out_y, double* tr) {
+                                                  double* out_x, double* out_y, double* tr, long long* dbg = nullptr) {
     constexpr int N = NN + MM;
     static_assert(N <= WAVE, "register-resident path needs n+m <= 64");
     const int ln = lane_id();
@@ -137,6 +165,7 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
 
     int iter;
     for (iter = 1; iter <= s.max_iter; ++iter) {
+        const long long f0 = clock64();
         if (need_factor) {   // construct_kkt_matrix + factorise_kkt_matrix (single code site: first iteration and after rho updates)
 #pragma unroll
             for (int j = 0; j < NN; ++j) { const double v = rowp[(size_t)j * rstride]; K.a[j] = (ln == j) ? kdiag : v; }
@@ -144,6 +173,7 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
             for (int j = NN; j < N; ++j) K.a[j] = (ln == j) ? kdiag : 0.0;
             K.factor(ln, tr);
             need_factor = false;
+            if (dbg) dbg[0] += clock64() - f0;
         }
         const double zprev = xv;  // meaningful on constraint lanes
         double rhs = 0.0;
@@ -169,13 +199,20 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
         }
         const bool check = (s.check_termination != 0 && iter % s.check_termination == 0);
         const bool adapt = (s.adaptive_rho && iter % s.adaptive_rho_interval == 0);
+        const long long r0 = clock64();
         if (check || adapt) {  // residuals_update, box_admm.hpp:398-415
+            // all loads first (independent, coalesced), then the two mat-vec chains: one memory round trip per check
+            double mrow[NN], mcol[MM];
+#pragma unroll
+            for (int j = 0; j < NN; ++j) mrow[j] = rowp[(size_t)j * rstride];
+#pragma unroll
+            for (int k = 0; k < MM; ++k) mcol[k] = colA[k];
             double acc = 0.0;      // lanes < n: (H x)_i ; lanes in [n, N): (A x)_r
 #pragma unroll
-            for (int j = 0; j < NN; ++j) acc += rowp[(size_t)j * rstride] * bcast_lane(xv, j);
+            for (int j = 0; j < NN; ++j) acc += mrow[j] * bcast_lane(xv, j);
             double aty = 0.0;      // lanes < n: (A^T y_a)_i
 #pragma unroll
-            for (int k = 0; k < MM; ++k) aty += colA[k] * bcast_lane(yv, NN + k);
+            for (int k = 0; k < MM; ++k) aty += mcol[k] * bcast_lane(yv, NN + k);
             const double nAx = wave_max(isC ? fabs(acc) : 0.0), nz = wave_max(isC ? fabs(xv) : 0.0), nx = wave_max(isP ? fabs(xv) : 0.0);
             const double rp = wave_max(isC ? fabs(acc - xv) : 0.0), rq = wave_max(isP ? fabs(xv - qv) : 0.0);
             const double nHx = wave_max(isP ? fabs(acc) : 0.0), nATy = wave_max(isP ? fabs(aty) : 0.0);
@@ -185,10 +222,11 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
             max_Hx_ATy_h_norm = fmax(nHx, fmax(nATy, fmax(nh, nyb)));
             res_prim = rp + rq;
             res_dual = rd;
+            if (dbg) dbg[1] += clock64() - r0;
         }
         if (check) {
             const double ep = s.eps_abs + s.eps_rel * max_Ax_z_norm, ed = s.eps_abs + s.eps_rel * max_Hx_ATy_h_norm;
-            if (res_prim <= ep && res_dual <= ed) { status = PMPC_QP_SOLVED; break; }
+            if (__builtin_amdgcn_readfirstlane((int)(res_prim <= ep && res_dual <= ed))) { status = PMPC_QP_SOLVED; break; }
         }
         if (adapt) {
             const double rpn = res_prim / (max_Ax_z_norm + DIV_BY_ZERO_REGUL);
@@ -196,7 +234,7 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
             double new_rho = rho * ::sqrt(rpn / (rdn + DIV_BY_ZERO_REGUL));
             new_rho = fmax(RHO_MIN, fmin(new_rho, RHO_MAX));
             rho_estimate = new_rho;
-            if (new_rho < rho / s.adaptive_rho_tolerance || new_rho > rho * s.adaptive_rho_tolerance) {
+            if (__builtin_amdgcn_readfirstlane((int)(new_rho < rho / s.adaptive_rho_tolerance || new_rho > rho * s.adaptive_rho_tolerance))) {
                 const double prev = rhov;
                 rho = new_rho;
                 rhov = rho_of(type, rho);

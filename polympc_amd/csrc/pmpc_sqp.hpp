@@ -47,6 +47,7 @@ struct SqpDevice {
     int n, m, me, mi;
     double cost_log = 0.0, primal_norm = 0.0, dual_norm = 0.0, max_violation = 0.0;
     int qp_iter_total = 0;
+    long long cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // shader-clock cycles: 0 linearise(+BFGS) 1 QP 2 line search 3 termination 4 total 5 BFGS 6 KKT build+factor 7 QP residuals
 
     __device__ SqpDevice(Ocp<Model>& o, SqpLds& v_, QpLds& q_, double* H_, double* A_, const pmpc_sqp_settings& s, const pmpc_qp_settings& q)
         : ocp(o), v(v_), qw(q_), Hw(H_), Aw(A_), ss(s), qs(q), n(o.dm.n), m(o.dm.m), me(o.dm.me), mi(o.dm.mi) {}
@@ -96,7 +97,7 @@ struct SqpDevice {
             const double cost_step = ocp.cost(v.xs);
             cost_log = cost_step;
             const double phi_step = cost_step + mu * constraints_violation(v.xs);
-            if (phi_step <= (phi_l1 + alpha * ss.eta * Dp_phi_l1)) return alpha;
+            if (__builtin_amdgcn_readfirstlane((int)(phi_step <= (phi_l1 + alpha * ss.eta * Dp_phi_l1)))) return alpha;
             alpha = ss.tau * alpha;
         }
         return alpha;
@@ -104,6 +105,20 @@ struct SqpDevice {
 
     // lag_grad = J^T lam[0:m] + cost_grad + lam_box  (continuous_ocp.hpp:2112-2114)
     __device__ void lagrangian_gradient(double* out) {
+        if constexpr (NN > 0) {   // compile-time sizes: one batch of independent loads (column j of J), then the chain
+            const int j = lane_id() < NN ? lane_id() : 0;
+            double col[MM];
+#pragma unroll
+            for (int i = 0; i < MM; ++i) col[i] = Aw[(size_t)j * MM + i];
+            double a = 0.0;
+#pragma unroll
+            for (int i = 0; i < MM; ++i) a += col[i] * v.lam[i];
+            a += v.h[j];
+            a += v.lam[MM + j];
+            if (lane_id() < NN) out[j] = a;
+            wsync();
+            return;
+        }
         for (int j = lane_id(); j < n; j += WAVE) {
             double a = 0.0;
             for (int i = 0; i < m; ++i) a += Aw[(size_t)j * m + i] * v.lam[i];
@@ -138,7 +153,51 @@ struct SqpDevice {
     }
 
     // BFGS_update, bfgs.hpp:23-52 ; s = v.step, y = lgn - lg
+    // register-row variant for compile-time n: lane i owns row i of B; ONE batch of loads, ONE batch of stores
+    __device__ void bfgs_update_reg() {
+        const int ln = lane_id();
+        const int i = ln < NN ? ln : 0;
+        double* Bs = v.t1; double* r = v.t2; double* y = v.t3;
+        double brow[NN > 0 ? NN : 1];
+#pragma unroll
+        for (int j = 0; j < NN; ++j) brow[j] = Hw[(size_t)j * NN + i];
+        {
+            double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < NN; ++j) a += brow[j] * v.step[j];
+            if (ln < NN) { Bs[i] = a; y[i] = v.lgn[i] - v.lg[i]; }
+        }
+        wsync();
+        const double sBs = seq_dot(v.step, Bs, NN);
+        const double sy = seq_dot(v.step, y, NN);
+        double sr;
+        if (sy < 0.2 * sBs) {
+            const double theta = 0.8 * sBs / (sBs - sy);
+            if (ln < NN) r[i] = theta * y[i] + (1 - theta) * Bs[i];
+            sr = theta * sy + (1 - theta) * sBs;
+        } else {
+            if (ln < NN) r[i] = y[i];
+            sr = sy;
+        }
+        wsync();
+        if (__builtin_amdgcn_readfirstlane((int)(sr < DBL_EPS))) return;
+        const double Bsi = Bs[i], ri = r[i];
+#pragma unroll
+        for (int j = 0; j < NN; ++j) {
+            double b = brow[j];
+            b += (-Bsi * Bs[j]) / sBs;
+            b += (ri * r[j]) / sr;
+            brow[j] = b;
+        }
+        if (ln < NN) {
+#pragma unroll
+            for (int j = 0; j < NN; ++j) Hw[(size_t)j * NN + i] = brow[j];
+        }
+        __threadfence_block();
+        wsync();
+    }
     __device__ void bfgs_update() {
+        if constexpr (NN > 0) { bfgs_update_reg(); return; }
         const int ln = lane_id();
         double* Bs = v.t1; double* r = v.t2; double* y = v.t3;
         for (int i = ln; i < n; i += WAVE) {
@@ -180,7 +239,9 @@ struct SqpDevice {
         ocp.stage_first_order(v.x);
         ocp.assemble_first_order(v.al, Aw, v.h);
         lagrangian_gradient(v.lgn);
+        const long long b0 = clock64();
         bfgs_update();
+        cyc[5] += clock64() - b0;
         for (int i = lane_id(); i < n; i += WAVE) v.lg[i] = v.lgn[i];
         wsync();
     }
@@ -200,16 +261,20 @@ struct SqpDevice {
     // one SQP iteration after (update_)linearisation: QP, line search, step, norms  (:588-632 / :652-683)
     __device__ void qp_and_step() {
         const int ln = lane_id();
+        const long long q0 = clock64();
         form_qp_bounds();
         pmpc_qp_info qi;
         // 7-argument form: zero guesses (Q2)
-        if constexpr (NN > 0) { boxadmm_solve_reg<NN, MM>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr); wsync(); }
+        if constexpr (NN > 0) { boxadmm_solve_reg<NN, MM>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, &cyc[6]); wsync(); }
         else boxadmm_solve(qw, n, m, Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi);
         qp_iter_total += qi.iter;
         // lam_k = p_lambda ; p_lambda -= lam
         for (int i = ln; i < m + n; i += WAVE) { v.lam_k[i] = qw.y[i]; qw.y[i] = qw.y[i] - v.lam[i]; }
         wsync();
+        const long long q1 = clock64();
         const double alpha = step_size_selection();
+        const long long q2 = clock64();
+        cyc[1] += q1 - q0; cyc[2] += q2 - q1;
         const double pn = lds_inf_norm(qw.x, n), dn = lds_inf_norm(qw.y, m + n);
         for (int i = ln; i < n; i += WAVE) { const double st = alpha * qw.x[i]; v.x[i] += st; v.step[i] = st; }
         for (int i = ln; i < m + n; i += WAVE) v.lam[i] += alpha * qw.y[i];
@@ -224,18 +289,20 @@ struct SqpDevice {
 
     __device__ void solve(pmpc_sqp_info& info) {
         int status = PMPC_SQP_MAX_ITER_EXCEEDED;
-        int iter = 1;
-        linearisation();
-        qp_and_step();
-        if (termination_criteria()) {
-            status = PMPC_SQP_SOLVED;
-        } else {
-            while (iter < ss.max_iter) {
-                ++iter;
-                update_linearisation();
-                qp_and_step();
-                if (termination_criteria()) { status = PMPC_SQP_SOLVED; break; }
-            }
+        int iter = 0;
+        // single code site for the (large) QP + line-search body: first pass = exact linearisation (:583), later = update (:649)
+        while (true) {
+            ++iter;
+            const long long c0 = clock64();
+            if (iter == 1) linearisation(); else update_linearisation();
+            const long long c1 = clock64();
+            qp_and_step();
+            const long long c2 = clock64();
+            const bool done = __builtin_amdgcn_readfirstlane((int)termination_criteria()) != 0;
+            const long long c3 = clock64();
+            cyc[0] += c1 - c0; cyc[3] += c3 - c2; cyc[4] += c3 - c0; (void)c2;
+            if (done) { status = PMPC_SQP_SOLVED; break; }
+            if (iter >= ss.max_iter) break;
         }
         info.iter = iter; info.qp_solver_iter = qp_iter_total; info.status = status; info._pad = 0;
         info.primal_norm = primal_norm; info.dual_norm = dual_norm; info.max_violation = max_violation; info.cost = cost_log;

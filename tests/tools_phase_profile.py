@@ -1,0 +1,23 @@
+"""Developer tool (not a test): per-phase shader-clock breakdown of the fused SQP kernel on config A.
+Run on a GPU box:  PMPC_PHASE_PROFILE=1 python tests/tools_phase_profile.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import polympc_amd as pa
+from polympc_amd import workloads
+
+B = int(os.environ.get("B", 4096))
+wl = workloads.robot_batch(B)
+ctx = pa.Context(0)
+ss = pa.sqp_settings_default(); ss.max_iter = 10; ss.line_search_max_iter = 10
+for rep in range(2):
+    t = time.perf_counter()
+    x, lam, info = ctx.sqp_solve_batch(0, 6, 1, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
+    t = time.perf_counter() - t
+cyc = ctx.phase_cycles()
+names = ["linearise(+update)", "QP", "line search", "termination", "total loop", "BFGS", "KKT build+factor", "QP residuals"]
+qps = info["iter"].sum()
+print(f"host wall {t*1e3:.2f} ms (incl. copies), {qps} QPs, {info['qp_solver_iter'].sum()/qps:.2f} ADMM it/QP")
+for nme, c in zip(names, cyc):
+    if nme != "-":
+        print(f"{nme:>20s}: {c/2/qps:12.0f} cycles per SQP iteration  ({100*c/max(cyc[4],1):5.1f}%)")

@@ -159,6 +159,23 @@ pmpc_status pmpc_sqp_solve_batch_dev(pmpc_context* ctx, int model, int P, int S,
                                      const double* lbg, const double* ubg, const pmpc_sqp_settings* sqp_settings,
                                      const pmpc_qp_settings* qp_settings, double* x, double* lam, pmpc_sqp_info* info);
 
+/* ---- user-defined OCPs ---------------------------------------------------------------------------------------------
+ * A user's OCP class (the reference's CRTP class with dynamics_impl / lagrange_term_impl / mayer_term_impl /
+ * inequality_constraints_impl, continuous_ocp.hpp:191-288) is compiled for the GPU by hipcc in the user's own
+ * translation unit with PMPC_REGISTER_OCP(Name) (include/polympc/register_ocp.hpp). The macro emits one C symbol
+ * pmpc_user_sqp_dev_<Name>, a pmpc_sqp_dev_fn working on device buffers. pmpc_sqp_solve_batch_user is the matching
+ * host-buffer wrapper. `model` points to the user's OCP parameter object (copied by value into the kernel). */
+typedef pmpc_status (*pmpc_sqp_dev_fn)(pmpc_context* ctx, const void* model, int P, int S, double t0, double tf, int B,
+                                       const double* x_guess, const double* lam_guess, const double* d, const double* lbx,
+                                       const double* ubx, const double* lbg, const double* ubg,
+                                       const pmpc_sqp_settings* sqp_settings, const pmpc_qp_settings* qp_settings, double* x,
+                                       double* lam, pmpc_sqp_info* info);
+pmpc_status pmpc_sqp_solve_batch_user(pmpc_context* ctx, pmpc_sqp_dev_fn fn, const void* model, int nx, int nu, int np, int nd,
+                                      int ng, int P, int S, double t0, double tf, int B, const double* x_guess,
+                                      const double* lam_guess, const double* d, const double* lbx, const double* ubx,
+                                      const double* lbg, const double* ubg, const pmpc_sqp_settings* sqp_settings,
+                                      const pmpc_qp_settings* qp_settings, double* x, double* lam, pmpc_sqp_info* info);
+
 #ifdef __cplusplus
 }
 #endif

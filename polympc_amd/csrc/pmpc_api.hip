@@ -14,6 +14,7 @@
 #include "pmpc_qp.hpp"
 #include "pmpc_qp_reg.hpp"
 #include "pmpc_sqp.hpp"
+#include "pmpc_launch.hpp"
 
 using namespace pmpc;
 
@@ -64,106 +65,6 @@ __global__ __launch_bounds__(64, 2) void qp_boxadmm_reg_kernel(int B, const doub
 }
 static size_t qp_kernel_lds_bytes(int n, int m) { return (QpLds::doubles(n, m) + 3 * (size_t)n + 2 * (size_t)m) * sizeof(double); }
 
-template <class Model, int NN = 0, int MM = 0>
-__global__ __launch_bounds__(64, (NN > 0 ? 2 : 1)) void sqp_kernel(Model model, const ChebData* __restrict__ cd, int B,
-                                                 const double* __restrict__ x_guess, const double* __restrict__ lam_guess,
-                                                 const double* __restrict__ d, const double* __restrict__ lbx,
-                                                 const double* __restrict__ ubx, const double* __restrict__ lbg,
-                                                 const double* __restrict__ ubg, pmpc_sqp_settings ss, pmpc_qp_settings qs,
-                                                 double* __restrict__ Hws, double* __restrict__ Aws, double* __restrict__ x,
-                                                 double* __restrict__ lam, pmpc_sqp_info* __restrict__ info, unsigned long long* __restrict__ phase_cycles) {
-    extern __shared__ double smem[];
-    const int b = blockIdx.x;
-    if (b >= B) return;
-    const int P = cd->P, S = cd->S;
-    Ocp<Model> ocp(model, P, S, cd->t_scale);
-    const int n = ocp.dm.n, m = ocp.dm.m, mi = ocp.dm.mi;
-    QpLds qw; SqpLds v;
-    double* p = (NN > 0) ? qw.carve_xy(smem, n, m) : qw.carve(smem, n, m);
-    p = v.carve(p, n, m, mi);
-    double* stage0 = p;
-    p = ocp.s.carve(p, P, S);
-    if (NN > 0 && (size_t)(p - stage0) < (size_t)RegKkt<(NN > 0 ? NN + MM : 1)>::TRI + ocp.s.const_doubles(P, S)) p = stage0 + RegKkt<(NN > 0 ? NN + MM : 1)>::TRI + ocp.s.const_doubles(P, S);
-    double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
-    const int ln = lane_id();
-    for (int i = ln; i < Model::ND; i += WAVE) dL[i] = d[(size_t)b * Model::ND + i];
-    ocp.d = dL;
-    ocp.stage_constants(cd);
-    for (int i = ln; i < n; i += WAVE) {
-        v.x[i] = x_guess ? x_guess[(size_t)b * n + i] : 0.0;
-        v.lbx[i] = lbx[(size_t)b * n + i]; v.ubx[i] = ubx[(size_t)b * n + i];
-    }
-    for (int i = ln; i < m + n; i += WAVE) v.lam[i] = lam_guess ? lam_guess[(size_t)b * (m + n) + i] : 0.0;
-    for (int i = ln; i < mi; i += WAVE) {
-        v.lbg[i] = lbg ? lbg[(size_t)b * mi + i] : -INFINITY;
-        v.ubg[i] = ubg ? ubg[(size_t)b * mi + i] : INFINITY;
-    }
-    wsync();
-    SqpDevice<Model, NN, MM> sqp(ocp, v, qw, Hws + (size_t)b * n * n, Aws + (size_t)b * m * n, ss, qs);
-    sqp.tr = ocp.s.fval;   // first per-node staging array: everything from here on is dead while the QP runs
-    pmpc_sqp_info si;
-    sqp.solve(si);
-    for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = v.x[i];
-    for (int i = ln; i < m + n; i += WAVE) lam[(size_t)b * (m + n) + i] = v.lam[i];
-    if (ln == 0) info[b] = si;
-    if (phase_cycles && ln == 0) for (int i = 0; i < 8; ++i) atomicAdd(&phase_cycles[i], (unsigned long long)sqp.cyc[i]);
-}
-template <class Model> static size_t sqp_kernel_lds_bytes(int P, int S, bool reg_qp) {
-    OcpDims<Model> dm(P, S);
-    size_t stage = OcpLds<Model>::doubles(P, S);
-    if (reg_qp) { const size_t N = dm.n + dm.m; const size_t need = N * (N + 1) / 2 + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
-    return ((reg_qp ? QpLds::doubles_xy(dm.n, dm.m) : QpLds::doubles(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8) * sizeof(double);
-}
-
-// collocation assembly only (used to check A2/A4/A6/A7/A8/A9/A10 against the reference's golden vectors)
-template <class Model>
-__global__ __launch_bounds__(64) void linearise_kernel(Model model, const ChebData* __restrict__ cd, int B,
-                                                       const double* __restrict__ var, const double* __restrict__ d,
-                                                       const double* __restrict__ lam, double* __restrict__ cost,
-                                                       double* __restrict__ constr, double* __restrict__ jac,
-                                                       double* __restrict__ cost_grad, double* __restrict__ lag_grad,
-                                                       double* __restrict__ lag_hess) {
-    extern __shared__ double smem[];
-    const int b = blockIdx.x;
-    if (b >= B) return;
-    const int P = cd->P, S = cd->S;
-    Ocp<Model> ocp(model, P, S, cd->t_scale);
-    const int n = ocp.dm.n, m = ocp.dm.m;
-    double* p = ocp.s.carve(smem, P, S);
-    double* xL = p; p += n; double* lamL = p; p += m + n; double* cL = p; p += m; double* gL = p; p += n;
-    double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
-    const int ln = lane_id();
-    for (int i = ln; i < Model::ND; i += WAVE) dL[i] = d[(size_t)b * Model::ND + i];
-    ocp.d = dL;
-    ocp.stage_constants(cd);
-    for (int i = ln; i < n; i += WAVE) xL[i] = var[(size_t)b * n + i];
-    for (int i = ln; i < m + n; i += WAVE) lamL[i] = lam ? lam[(size_t)b * (m + n) + i] : 0.0;
-    wsync();
-    ocp.stage_first_order(xL);
-    ocp.stage_second_order(xL, lamL);
-    double* J = jac + (size_t)b * m * n;
-    double* Hh = lag_hess + (size_t)b * n * n;
-    const double cst = ocp.assemble_first_order(cL, J, gL);
-    ocp.assemble_hessian(Hh);
-    for (int j = ln; j < n; j += WAVE) {
-        double a = 0.0;
-        for (int i = 0; i < m; ++i) a += J[(size_t)j * m + i] * lamL[i];
-        a += gL[j];
-        a += lamL[m + j];
-        lag_grad[(size_t)b * n + j] = a;
-        cost_grad[(size_t)b * n + j] = gL[j];
-    }
-    // values-only paths (cost / constraints), as the line search uses them
-    const double cst2 = ocp.cost(xL);
-    ocp.constraints(xL, cL);
-    for (int i = ln; i < m; i += WAVE) constr[(size_t)b * m + i] = cL[i];
-    if (ln == 0) { cost[2 * b] = cst; cost[2 * b + 1] = cst2; }
-}
-template <class Model> static size_t linearise_kernel_lds_bytes(int P, int S) {
-    OcpDims<Model> dm(P, S);
-    return (OcpLds<Model>::doubles(P, S) + 3 * (size_t)dm.n + 2 * (size_t)dm.m + 16) * sizeof(double);
-}
-
 // =====================================================================================================================
 // context
 // =====================================================================================================================
@@ -212,6 +113,20 @@ static pmpc_status get_cheb(pmpc_context* ctx, int P, int S, double t0, double t
     HIPCHK(hipStreamSynchronize(ctx->stream));  // cd is a stack object
     ctx->cheb_cache[key] = dptr;
     *out = dptr;
+    return PMPC_OK;
+}
+
+extern "C" pmpc_status pmpc_internal_services(pmpc_context* ctx, int P, int S, double t0, double tf, size_t ws_bytes, const void** cheb,
+                                               double** ws, void** stream, size_t* lds_limit, unsigned long long** phase_cycles, int* force_lds) {
+    if (!ctx) return PMPC_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(ctx->device));
+    const ChebData* cd = nullptr;
+    pmpc_status st = get_cheb(ctx, P, S, t0, tf, &cd);
+    if (st != PMPC_OK) return st;
+    st = ensure_ws(ctx, ws_bytes);
+    if (st != PMPC_OK) return st;
+    *cheb = cd; *ws = ctx->ws; *stream = (void*)ctx->stream; *lds_limit = ctx->lds_limit; *phase_cycles = ctx->phase_cycles;
+    *force_lds = ctx->force_lds_path ? 1 : 0;
     return PMPC_OK;
 }
 
@@ -387,36 +302,12 @@ static pmpc_status dims_impl(int P, int S, int* nx, int* nu, int* np, int* nd, i
 }
 
 template <class Model>
-static pmpc_status sqp_dev_impl(pmpc_context* ctx, int P, int S, double t0, double tf, const double* mp, int nmp, int B,
-                                const double* x_guess, const double* lam_guess, const double* d, const double* lbx,
-                                const double* ubx, const double* lbg, const double* ubg, const pmpc_sqp_settings* ss,
-                                const pmpc_qp_settings* qs, double* x, double* lam, pmpc_sqp_info* info) {
-    const ChebData* cd = nullptr;
-    pmpc_status st = get_cheb(ctx, P, S, t0, tf, &cd);
-    if (st != PMPC_OK) return st;
-    OcpDims<Model> dm(P, S);
-    st = ensure_ws(ctx, (size_t)B * ((size_t)dm.n * dm.n + (size_t)dm.m * dm.n) * sizeof(double));
-    if (st != PMPC_OK) return st;
-    double* Hws = ctx->ws; double* Aws = ctx->ws + (size_t)B * dm.n * dm.n;
-    Model mdl = make_model<Model>(mp, nmp);
-    // register-resident QP specialisations (compile-time KKT size <= 64 rows)
-    if constexpr (Model::NX == 3 && Model::NU == 2 && Model::NP == 0 && Model::NG == 0) {
-        if (P * S == 6 && !ctx->force_lds_path) {   // config A / D: 7 nodes, n = 35, m = 21
-            const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, true);
-            HIPCHK(hipFuncSetAttribute((const void*)sqp_kernel<Model, 35, 21>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
-            hipLaunchKernelGGL((sqp_kernel<Model, 35, 21>), dim3(B), dim3(WAVE), ldsr, ctx->stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx,
-                               lbg, ubg, *ss, *qs, Hws, Aws, x, lam, info, ctx->phase_cycles);
-            HIPCHK(hipGetLastError());
-            return PMPC_OK;
-        }
-    }
-    const size_t lds = sqp_kernel_lds_bytes<Model>(P, S, false);
-    if (lds > ctx->lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;
-    HIPCHK(hipFuncSetAttribute((const void*)sqp_kernel<Model>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((sqp_kernel<Model>), dim3(B), dim3(WAVE), lds, ctx->stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
-                       *ss, *qs, Hws, Aws, x, lam, info, ctx->phase_cycles);
-    HIPCHK(hipGetLastError());
-    return PMPC_OK;
+static pmpc_status sqp_builtin_dev(pmpc_context* ctx, int P, int S, double t0, double tf, const double* mp, int nmp, int B,
+                                   const double* x_guess, const double* lam_guess, const double* d, const double* lbx,
+                                   const double* ubx, const double* lbg, const double* ubg, const pmpc_sqp_settings* ss,
+                                   const pmpc_qp_settings* qs, double* x, double* lam, pmpc_sqp_info* info) {
+    const Model mdl = make_model<Model>(mp, nmp);
+    return pmpc::sqp_launch_dev<Model>(ctx, mdl, P, S, t0, tf, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, x, lam, info);
 }
 
 template <class Model>
@@ -475,7 +366,7 @@ pmpc_status pmpc_sqp_solve_batch_dev(pmpc_context* ctx, int model, int P, int S,
     if (ss->regularisation != 0 && ss->regularisation != 2) return PMPC_ERR_INVALID_ARGUMENT;
     if (B == 0) return PMPC_OK;
     HIPCHK(hipSetDevice(ctx->device));
-    DISPATCH_MODEL(model, sqp_dev_impl, ctx, P, S, t0, tf, mparams, n_mparams, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, x, lam, info);
+    DISPATCH_MODEL(model, sqp_builtin_dev, ctx, P, S, t0, tf, mparams, n_mparams, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, x, lam, info);
 }
 
 pmpc_status pmpc_sqp_solve_batch(pmpc_context* ctx, int model, int P, int S, double t0, double tf, const double* mparams,
@@ -498,6 +389,33 @@ pmpc_status pmpc_sqp_solve_batch(pmpc_context* ctx, int model, int P, int S, dou
     DEVOUT(19, (size_t)B * n * sizeof(double), dx); DEVOUT(20, (size_t)B * (m + n) * sizeof(double), dlam);
     DEVOUT(21, (size_t)B * sizeof(pmpc_sqp_info), dinfo);
     st = pmpc_sqp_solve_batch_dev(ctx, model, P, S, t0, tf, mparams, n_mparams, B, dxg, dlg, dd, dlbx, dubx, dlbg, dubg, ss, qs, dx, dlam, dinfo);
+    if (st != PMPC_OK) return st;
+    HIPCHK(hipMemcpyAsync(x, dx, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(lam, dlam, (size_t)B * (m + n) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(info, dinfo, (size_t)B * sizeof(pmpc_sqp_info), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PMPC_OK;
+}
+
+
+/* Host-buffer wrapper around a user-registered OCP's device entry (PMPC_REGISTER_OCP): stage in, launch, stage out. */
+pmpc_status pmpc_sqp_solve_batch_user(pmpc_context* ctx, pmpc_sqp_dev_fn fn, const void* model, int nx, int nu, int np, int nd, int ng,
+                                      int P, int S, double t0, double tf, int B, const double* x_guess, const double* lam_guess,
+                                      const double* d, const double* lbx, const double* ubx, const double* lbg, const double* ubg,
+                                      const pmpc_sqp_settings* ss, const pmpc_qp_settings* qs, double* x, double* lam, pmpc_sqp_info* info) {
+    if (!ctx || !fn || !model || B < 0 || !lbx || !ubx || !ss || !qs || !x || !lam || !info) return PMPC_ERR_INVALID_ARGUMENT;
+    if (B == 0) return PMPC_OK;
+    if (nd > 0 && !d) return PMPC_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int nn = P * S + 1, n = (nx + nu) * nn + np, me = nx * nn, mi = ng * nn, m = me + mi;
+    double *dxg, *dlg, *dd, *dlbx, *dubx, *dlbg, *dubg, *dx, *dlam; pmpc_sqp_info* dinfo;
+    H2D(12, x_guess, (size_t)B * n, dxg); H2D(13, lam_guess, (size_t)B * (m + n), dlg); H2D(14, (nd ? d : nullptr), (size_t)B * nd, dd);
+    if (!nd) DEVOUT(14, 8, dd);
+    H2D(15, lbx, (size_t)B * n, dlbx); H2D(16, ubx, (size_t)B * n, dubx);
+    H2D(17, (mi ? lbg : nullptr), (size_t)B * mi, dlbg); H2D(18, (mi ? ubg : nullptr), (size_t)B * mi, dubg);
+    DEVOUT(19, (size_t)B * n * sizeof(double), dx); DEVOUT(20, (size_t)B * (m + n) * sizeof(double), dlam);
+    DEVOUT(21, (size_t)B * sizeof(pmpc_sqp_info), dinfo);
+    pmpc_status st = fn(ctx, model, P, S, t0, tf, B, dxg, dlg, dd, dlbx, dubx, dlbg, dubg, ss, qs, dx, dlam, dinfo);
     if (st != PMPC_OK) return st;
     HIPCHK(hipMemcpyAsync(x, dx, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(lam, dlam, (size_t)B * (m + n) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -1,0 +1,170 @@
+// polympc_amd — SQP / linearisation kernels and their launch templates. Included by pmpc_api.hip for the built-in OCPs
+// and by include/polympc/register_ocp.hpp for user-defined OCPs (compiled by hipcc in the user's translation unit).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/polympc_amd.h"
+#include "pmpc_ocp.hpp"
+#include "pmpc_qp.hpp"
+#include "pmpc_qp_reg.hpp"
+#include "pmpc_sqp.hpp"
+
+// context services exported by libpolympc_amd.so (collocation constants cache, HBM workspace, stream, limits)
+extern "C" pmpc_status pmpc_internal_services(pmpc_context* ctx, int P, int S, double t0, double tf, size_t ws_bytes, const void** cheb,
+                                               double** ws, void** stream, size_t* lds_limit, unsigned long long** phase_cycles, int* force_lds);
+
+namespace pmpc {
+using ::pmpc_status;
+
+template <class Model, int NN = 0, int MM = 0>
+__global__ __launch_bounds__(64, (NN > 0 ? 2 : 1)) void sqp_kernel(Model model, const ChebData* __restrict__ cd, int B,
+                                                 const double* __restrict__ x_guess, const double* __restrict__ lam_guess,
+                                                 const double* __restrict__ d, const double* __restrict__ lbx,
+                                                 const double* __restrict__ ubx, const double* __restrict__ lbg,
+                                                 const double* __restrict__ ubg, pmpc_sqp_settings ss, pmpc_qp_settings qs,
+                                                 double* __restrict__ Hws, double* __restrict__ Aws, double* __restrict__ x,
+                                                 double* __restrict__ lam, pmpc_sqp_info* __restrict__ info, unsigned long long* __restrict__ phase_cycles) {
+    extern __shared__ double smem[];
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const int P = cd->P, S = cd->S;
+    Ocp<Model> ocp(model, P, S, cd->t_scale);
+    const int n = ocp.dm.n, m = ocp.dm.m, mi = ocp.dm.mi;
+    QpLds qw; SqpLds v;
+    double* p = (NN > 0) ? qw.carve_xy(smem, n, m) : qw.carve(smem, n, m);
+    p = v.carve(p, n, m, mi);
+    double* stage0 = p;
+    p = ocp.s.carve(p, P, S);
+    if (NN > 0 && (size_t)(p - stage0) < (size_t)RegKkt<(NN > 0 ? NN + MM : 1)>::TRI + ocp.s.const_doubles(P, S)) p = stage0 + RegKkt<(NN > 0 ? NN + MM : 1)>::TRI + ocp.s.const_doubles(P, S);
+    double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
+    const int ln = lane_id();
+    for (int i = ln; i < Model::ND; i += WAVE) dL[i] = d[(size_t)b * Model::ND + i];
+    ocp.d = dL;
+    ocp.stage_constants(cd);
+    for (int i = ln; i < n; i += WAVE) {
+        v.x[i] = x_guess ? x_guess[(size_t)b * n + i] : 0.0;
+        v.lbx[i] = lbx[(size_t)b * n + i]; v.ubx[i] = ubx[(size_t)b * n + i];
+    }
+    for (int i = ln; i < m + n; i += WAVE) v.lam[i] = lam_guess ? lam_guess[(size_t)b * (m + n) + i] : 0.0;
+    for (int i = ln; i < mi; i += WAVE) {
+        v.lbg[i] = lbg ? lbg[(size_t)b * mi + i] : -INFINITY;
+        v.ubg[i] = ubg ? ubg[(size_t)b * mi + i] : INFINITY;
+    }
+    wsync();
+    SqpDevice<Model, NN, MM> sqp(ocp, v, qw, Hws + (size_t)b * n * n, Aws + (size_t)b * m * n, ss, qs);
+    sqp.tr = ocp.s.fval;   // first per-node staging array: everything from here on is dead while the QP runs
+    pmpc_sqp_info si;
+    sqp.solve(si);
+    for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = v.x[i];
+    for (int i = ln; i < m + n; i += WAVE) lam[(size_t)b * (m + n) + i] = v.lam[i];
+    if (ln == 0) info[b] = si;
+    if (phase_cycles && ln == 0) for (int i = 0; i < 8; ++i) atomicAdd(&phase_cycles[i], (unsigned long long)sqp.cyc[i]);
+}
+template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, bool reg_qp) {
+    OcpDims<Model> dm(P, S);
+    size_t stage = OcpLds<Model>::doubles(P, S);
+    if (reg_qp) { const size_t N = dm.n + dm.m; const size_t need = N * (N + 1) / 2 + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
+    return ((reg_qp ? QpLds::doubles_xy(dm.n, dm.m) : QpLds::doubles(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8) * sizeof(double);
+}
+
+// collocation assembly only (used to check A2/A4/A6/A7/A8/A9/A10 against the reference's golden vectors)
+template <class Model>
+__global__ __launch_bounds__(64) void linearise_kernel(Model model, const ChebData* __restrict__ cd, int B,
+                                                       const double* __restrict__ var, const double* __restrict__ d,
+                                                       const double* __restrict__ lam, double* __restrict__ cost,
+                                                       double* __restrict__ constr, double* __restrict__ jac,
+                                                       double* __restrict__ cost_grad, double* __restrict__ lag_grad,
+                                                       double* __restrict__ lag_hess) {
+    extern __shared__ double smem[];
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const int P = cd->P, S = cd->S;
+    Ocp<Model> ocp(model, P, S, cd->t_scale);
+    const int n = ocp.dm.n, m = ocp.dm.m;
+    double* p = ocp.s.carve(smem, P, S);
+    double* xL = p; p += n; double* lamL = p; p += m + n; double* cL = p; p += m; double* gL = p; p += n;
+    double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
+    const int ln = lane_id();
+    for (int i = ln; i < Model::ND; i += WAVE) dL[i] = d[(size_t)b * Model::ND + i];
+    ocp.d = dL;
+    ocp.stage_constants(cd);
+    for (int i = ln; i < n; i += WAVE) xL[i] = var[(size_t)b * n + i];
+    for (int i = ln; i < m + n; i += WAVE) lamL[i] = lam ? lam[(size_t)b * (m + n) + i] : 0.0;
+    wsync();
+    ocp.stage_first_order(xL);
+    ocp.stage_second_order(xL, lamL);
+    double* J = jac + (size_t)b * m * n;
+    double* Hh = lag_hess + (size_t)b * n * n;
+    const double cst = ocp.assemble_first_order(cL, J, gL);
+    ocp.assemble_hessian(Hh);
+    for (int j = ln; j < n; j += WAVE) {
+        double a = 0.0;
+        for (int i = 0; i < m; ++i) a += J[(size_t)j * m + i] * lamL[i];
+        a += gL[j];
+        a += lamL[m + j];
+        lag_grad[(size_t)b * n + j] = a;
+        cost_grad[(size_t)b * n + j] = gL[j];
+    }
+    // values-only paths (cost / constraints), as the line search uses them
+    const double cst2 = ocp.cost(xL);
+    ocp.constraints(xL, cL);
+    for (int i = ln; i < m; i += WAVE) constr[(size_t)b * m + i] = cL[i];
+    if (ln == 0) { cost[2 * b] = cst; cost[2 * b + 1] = cst2; }
+}
+template <class Model> inline size_t linearise_kernel_lds_bytes(int P, int S) {
+    OcpDims<Model> dm(P, S);
+    return (OcpLds<Model>::doubles(P, S) + 3 * (size_t)dm.n + 2 * (size_t)dm.m + 16) * sizeof(double);
+}
+
+
+// Launch the fused SQP kernel for `Model` on DEVICE buffers (asynchronous on the context's stream).
+// Register-resident QP specialisations are selected from the compile-time model dimensions and the runtime node count
+// when the KKT system has at most 64 rows; otherwise the LDS-resident path is used.
+template <class Model, int NNODES>
+inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* cd, int P, int S, int B, const double* x_guess,
+                           const double* lam_guess, const double* d, const double* lbx, const double* ubx, const double* lbg,
+                           const double* ubg, const pmpc_sqp_settings* ss, const pmpc_qp_settings* qs, double* Hws, double* Aws, double* x,
+                           double* lam, pmpc_sqp_info* info, hipStream_t stream, size_t lds_limit, unsigned long long* phase, pmpc_status* st) {
+    constexpr int NN_ = (Model::NX + Model::NU) * NNODES + Model::NP;
+    constexpr int MM_ = (Model::NX + Model::NG) * NNODES;
+    if constexpr (NN_ + MM_ <= WAVE) {
+        if (P * S + 1 != NNODES) return false;
+        const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, true);
+        if (ldsr > lds_limit) return false;
+        if (hipFuncSetAttribute((const void*)sqp_kernel<Model, NN_, MM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
+        hipLaunchKernelGGL((sqp_kernel<Model, NN_, MM_>), dim3(B), dim3(WAVE), ldsr, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
+                           *ss, *qs, Hws, Aws, x, lam, info, phase);
+        *st = (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
+        return true;
+    } else {
+        return false;
+    }
+}
+
+template <class Model>
+inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, int S, double t0, double tf, int B, const double* x_guess,
+                                  const double* lam_guess, const double* d, const double* lbx, const double* ubx, const double* lbg,
+                                  const double* ubg, const pmpc_sqp_settings* ss, const pmpc_qp_settings* qs, double* x, double* lam,
+                                  pmpc_sqp_info* info) {
+    if (P < 1 || P > MAX_P || S < 1 || P * S + 1 > MAX_NODES) return PMPC_ERR_UNSUPPORTED_SIZE;
+    OcpDims<Model> dm(P, S);
+    const void* cdv = nullptr; double* ws = nullptr; void* streamv = nullptr; size_t lds_limit = 0; unsigned long long* phase = nullptr; int force_lds = 0;
+    pmpc_status st = pmpc_internal_services(ctx, P, S, t0, tf, (size_t)B * ((size_t)dm.n * dm.n + (size_t)dm.m * dm.n) * sizeof(double), &cdv, &ws,
+                                            &streamv, &lds_limit, &phase, &force_lds);
+    if (st != PMPC_OK) return st;
+    const ChebData* cd = (const ChebData*)cdv;
+    hipStream_t stream = (hipStream_t)streamv;
+    double* Hws = ws; double* Aws = ws + (size_t)B * dm.n * dm.n;
+    if (!force_lds) {   // node counts whose KKT system can fit 64 rows for small models (7 nodes: config A / D)
+        pmpc_status rst = PMPC_OK;
+        if (try_launch_reg<Model, 7>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst)) return rst;
+        if (try_launch_reg<Model, 5>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst)) return rst;
+    }
+    const size_t lds = sqp_kernel_lds_bytes<Model>(P, S, false);
+    if (lds > lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;
+    if (hipFuncSetAttribute((const void*)sqp_kernel<Model>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PMPC_ERR_HIP;
+    hipLaunchKernelGGL((sqp_kernel<Model>), dim3(B), dim3(WAVE), lds, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, *ss, *qs, Hws, Aws, x,
+                       lam, info, phase);
+    return (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
+}
+
+}  // namespace pmpc

@@ -54,7 +54,7 @@ struct RegKkt {
     __device__ __forceinline__ static int off(int j) { return j * N - (j * (j + 1)) / 2; }
 
     // LDL^T of the matrix whose lower-triangle rows are in a[] (a[j] = K(lane, j), j <= lane; the rest is ignored).
-    // Static order, right-looking, fma trailing update — the arithmetic of oracle PIVOT_STATIC.
+    // Static order, right-looking, fma trailing update — the same arithmetic as pmpc_qp.hpp.
     //
     // Code-size matters as much as instruction count here: a fully unrolled N^2/2 update is ~100 KB of straight-line
     // code and thrashes the instruction cache. Instead the elimination runs as a ROLLED loop over blocks of BK

@@ -1,0 +1,156 @@
+// Host-side tests written like the reference's own gtest cases, against include/polympc/polympc.hpp.
+//   box_admmSimpleQP / SimpleLP / NonConvex    tests/solvers/qp/box_admm_test.cpp:15-45, :266-297, :299-334
+//   MPCWrapperTest                              tests/control/mpc_wrapper_test.cpp:120-199 (dense-BFGS variant)
+//   user-registered OCP                         docs/source/ocp.rst:229-481 workflow, compiled by hipcc (user_ocp.hip)
+#include <cstdio>
+#include <cstring>
+#include <polympc/polympc.hpp>
+
+static int failures = 0;
+#define EXPECT_TRUE(c) do { if (!(c)) { std::printf("  EXPECT_TRUE failed: %s (%s:%d)\n", #c, __FILE__, __LINE__); ++failures; } } while (0)
+#define EXPECT_LT(a, b) EXPECT_TRUE((a) < (b))
+#define EXPECT_EQ(a, b) EXPECT_TRUE((a) == (b))
+
+using namespace polympc;
+
+static void box_admmSimpleQP() {
+    std::printf("box_admmSimpleQP\n");
+    boxADMM<2, 1>::qp_hessian_t H; boxADMM<2, 1>::qp_var_t h, xl, xu, solution; boxADMM<2, 1>::qp_constraint_t A; boxADMM<2, 1>::qp_dual_a_t Al, Au;
+    H(0, 0) = 4; H(0, 1) = 1; H(1, 0) = 1; H(1, 1) = 2;
+    h(0) = 1; h(1) = 1; A(0, 0) = 1; A(0, 1) = 1; Al(0) = 1; Au(0) = 1; xl(0) = 0; xl(1) = 0; xu(0) = 0.7; xu(1) = 0.7;
+    solution(0) = 0.3; solution(1) = 0.7;
+    boxADMM<2, 1> prob;
+    prob.settings().max_iter = 150;
+    prob.solve(H, h, A, Al, Au, xl, xu);
+    EXPECT_TRUE(prob.primal_solution().isApprox(solution, 1e-2));
+    EXPECT_LT(prob.iter, prob.settings().max_iter);
+    EXPECT_EQ(prob.info().status, SOLVED);
+}
+
+static void box_admmNonConvex() {
+    std::printf("box_admmNonConvex\n");
+    boxADMM<1, 0>::qp_hessian_t H; boxADMM<1, 0>::qp_var_t h, xl, xu, guess; boxADMM<1, 0>::qp_constraint_t A; boxADMM<1, 0>::qp_dual_a_t al, au;
+    boxADMM<1, 0>::qp_dual_t dual_guess;
+    H(0, 0) = -1; h(0) = 0; xl(0) = -1; xu(0) = 2; guess(0) = 0.1; dual_guess(0) = 0.1;
+    boxADMM<1, 0> prob;
+    prob.settings().max_iter = 200; prob.settings().alpha = 1.0; prob.settings().adaptive_rho = 1; prob.settings().rho = 2; prob.settings().check_termination = 10;
+    prob.solve(H, h, A, al, au, xl, xu, guess, dual_guess);
+    EXPECT_TRUE(std::fabs(prob.primal_solution()(0) - 2.0) <= 2e-2);
+    EXPECT_LT(prob.iter, prob.settings().max_iter);
+    EXPECT_EQ(prob.info().status, SOLVED);
+}
+
+using Polynomial = polympc::Chebyshev<5, polympc::GAUSS_LOBATTO, double>;
+using Approximation = polympc::Spline<Polynomial, 3>;
+using RobotOCP = polympc::models::MobileRobot<Approximation>;
+
+static void MPCWrapperTest() {
+    std::printf("MPCWrapperTest\n");
+    using mpc_t = MPC<RobotOCP>;
+    mpc_t mpc;
+    mpc.ocp().set_Q_coeff(2.0);
+    mpc.settings().max_iter = 10;
+    mpc.settings().line_search_max_iter = 10;
+    mpc.set_time_limits(0, 2);
+    mpc_t::static_param p; p(0) = 2.0;
+    mpc_t::state_t x0; x0(0) = 0.5; x0(1) = 0.5; x0(2) = 0.5;
+    mpc_t::control_t lbu, ubu; lbu(0) = -1.5; lbu(1) = -0.75; ubu(0) = 1.5; ubu(1) = 0.75;
+    mpc.set_static_parameters(p);
+    mpc.control_bounds(lbu, ubu);
+    mpc.initial_conditions(x0);
+    mpc.solve();
+    const int first_solve_iter = mpc.info().iter;
+    EXPECT_TRUE(mpc.info().status.value == sqp_status_t::SOLVED);
+    x0(0) = 0.3; x0(1) = 0.4; x0(2) = 0.5;
+    mpc.initial_conditions(x0, x0);
+    mpc.solve();
+    const int second_solve_iter = mpc.info().iter;
+    EXPECT_LT(second_solve_iter, first_solve_iter);
+    EXPECT_TRUE(mpc.info().status.value == sqp_status_t::SOLVED);
+    std::printf("  iterations: cold %d, warm %d; cost %.6f violation %.2e\n", first_solve_iter, second_solve_iter, mpc.cost(), mpc.constr_violation());
+    EXPECT_TRUE(mpc.solution_x_at(0).isApprox(mpc.solution_x_at(0.0), 1e-3));
+    EXPECT_TRUE(mpc.solution_x_at(5).isApprox(mpc.solution_x_at(0.666), 1e-3));
+    EXPECT_TRUE(mpc.solution_x_at(10).isApprox(mpc.solution_x_at(1.333), 1e-3));
+    EXPECT_TRUE(mpc.solution_u_at(0).isApprox(mpc.solution_u_at(0.0), 1e-3));
+    EXPECT_TRUE(mpc.solution_u_at(1).isApprox(mpc.solution_u_at(0.063), 1e-3));
+    EXPECT_TRUE(std::fabs(mpc.solution_x_at(0)(0) - 0.3) < 1e-3);   // the pinned initial state is the FIRST point in time
+}
+
+// ---- user-registered OCPs (device code in libuser_ocp.so, built from tests/cpp/user_ocp.hip) ------------------------------
+struct UserRobot { double q = 1.0; };          // must match the layout of the struct registered in user_ocp.hip
+struct Pendulum {};
+using ApproxA = polympc::Spline<polympc::Chebyshev<6>, 1>;
+POLYMPC_FORWARD_DECLARATION(UserRobotOCP, 3, 2, 0, 1, 0, double)
+class UserRobotOCP : public polympc::ContinuousOCP<UserRobotOCP, ApproxA, polympc::DENSE> {
+public:
+    UserRobot device_model() const { return UserRobot(); }
+};
+POLYMPC_FORWARD_DECLARATION(PendulumOCP, 2, 1, 0, 1, 1, double)
+class PendulumOCP : public polympc::ContinuousOCP<PendulumOCP, polympc::Spline<polympc::Chebyshev<5>, 2>, polympc::DENSE> {
+public:
+    Pendulum device_model() const { return Pendulum(); }
+};
+POLYMPC_USE_REGISTERED_OCP(UserRobotOCP, UserRobot)
+POLYMPC_USE_REGISTERED_OCP(PendulumOCP, Pendulum)
+
+static void UserRegisteredRobotMatchesBuiltin() {
+    std::printf("UserRegisteredRobotMatchesBuiltin\n");
+    using Builtin = polympc::models::MobileRobot<ApproxA>;
+    const int B = 32;
+    BatchSolver<UserRobotOCP> us(B); BatchSolver<Builtin> bs(B);
+    us.get_problem().set_time_limits(0, 2); bs.get_problem().set_time_limits(0, 2);
+    us.settings().max_iter = 10; us.settings().line_search_max_iter = 10; bs.settings() = us.settings();
+    for (int b = 0; b < B; ++b) {
+        for (int k = 0; k < 7; ++k) {
+            us.lower_bound_x(b)[21 + 2 * k] = -1.5; us.upper_bound_x(b)[21 + 2 * k] = 1.5;
+            us.lower_bound_x(b)[22 + 2 * k] = -0.75; us.upper_bound_x(b)[22 + 2 * k] = 0.75;
+        }
+        for (int i = 0; i < 3; ++i) { const double x0 = 0.5 + 0.01 * (b % 7) * (i + 1) - 0.02 * i; us.lower_bound_x(b)[18 + i] = x0; us.upper_bound_x(b)[18 + i] = x0; }
+        us.parameters(b)[0] = 2.0 + 0.01 * b;
+        std::memcpy(bs.lower_bound_x(b), us.lower_bound_x(b), sizeof(double) * 35);
+        std::memcpy(bs.upper_bound_x(b), us.upper_bound_x(b), sizeof(double) * 35);
+        bs.parameters(b)[0] = us.parameters(b)[0];
+    }
+    EXPECT_EQ(us.solve(), PMPC_OK);
+    EXPECT_EQ(bs.solve(), PMPC_OK);
+    int solved = 0; bool identical = true;
+    for (int b = 0; b < B; ++b) {
+        solved += us.info(b).status == PMPC_SQP_SOLVED;
+        identical = identical && us.info(b).iter == bs.info(b).iter && std::memcmp(us.primal_solution(b), bs.primal_solution(b), sizeof(double) * 35) == 0;
+    }
+    std::printf("  %d/%d solved, user == builtin bitwise: %s\n", solved, B, identical ? "yes" : "NO");
+    EXPECT_TRUE(identical);
+    EXPECT_TRUE(solved > B / 2);
+}
+
+static void UserPendulumWithPathConstraint() {
+    std::printf("UserPendulumWithPathConstraint\n");
+    Solver<PendulumOCP> solver;
+    solver.get_problem().set_time_limits(0, 2);
+    solver.settings().max_iter = 30; solver.settings().line_search_max_iter = 10;
+    const int nn = PendulumOCP::NUM_NODES;
+    solver.parameters()(0) = 1.0;
+    solver.lower_bound_x()(2 * nn - 2) = 0.5; solver.upper_bound_x()(2 * nn - 2) = 0.5;   // theta(0) = 0.5
+    solver.lower_bound_x()(2 * nn - 1) = 0.0; solver.upper_bound_x()(2 * nn - 1) = 0.0;   // omega(0) = 0
+    for (int k = 0; k < nn; ++k) { solver.lower_bound_x()(2 * nn + k) = -3.0; solver.upper_bound_x()(2 * nn + k) = 3.0; }
+    for (int k = 0; k < nn; ++k) { solver.lower_bound_g()(k) = -1.0; solver.upper_bound_g()(k) = 1.0; }
+    solver.solve();
+    std::printf("  status %d iter %d violation %.2e cost %.5f\n", (int)solver.info().status.value, solver.info().iter, solver.constr_violation(), solver.cost());
+    EXPECT_TRUE(solver.info().status.value == sqp_status_t::SOLVED);
+    EXPECT_TRUE(solver.constr_violation() <= 1e-3);
+    for (int k = 0; k < nn; ++k) {   // the path constraint holds at every node
+        const double g = solver.primal_solution()(2 * k + 1) + 0.5 * solver.primal_solution()(2 * nn + k);
+        EXPECT_TRUE(g <= 1.0 + 2e-3 && g >= -1.0 - 2e-3);
+    }
+}
+
+int main() {
+    if (!polympc::context()) { std::printf("no GPU: %s\n", pmpc_status_string(polympc::last_error())); return 77; }
+    box_admmSimpleQP();
+    box_admmNonConvex();
+    MPCWrapperTest();
+    UserRegisteredRobotMatchesBuiltin();
+    UserPendulumWithPathConstraint();
+    std::printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
+    return failures ? 1 : 0;
+}

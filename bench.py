@@ -45,7 +45,7 @@ def main():
     import numpy as np
     import torch
     import polympc_amd as pa
-    from polympc_amd import workloads
+    from polympc_amd import workloads, sharding
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -60,7 +60,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     B = args.batch
-    wl = workloads.robot_batch(B, first=rank * B)          # each rank owns its own contiguous shard of the instance stream
+    wl = workloads.robot_batch(B, first=sharding.shard_first_instance(rank, B))   # each rank owns a contiguous shard of the instance stream
     n, m = wl["n"], wl["m"]
     stream = torch.cuda.Stream(dev)       # a real (non-null) HIP stream: the kernels and the timing events share it
     torch.cuda.set_stream(stream)
@@ -99,13 +99,7 @@ def main():
     qp_solves = int(info["iter"].sum())
     admm_iters = int(info["qp_solver_iter"].sum())
     solved = int((info["status"] == pa.SQP_SOLVED).sum())
-    tot = torch.tensor([float(qp_solves), float(admm_iters), float(solved), elapsed], dtype=torch.float64, device=dev)
-    if dist:
-        mx = tot[3:4].clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = tot[:3].clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed = float(mx.item()); qp_all, admm_all, solved_all = [float(v) for v in sm.tolist()]
-    else:
-        qp_all, admm_all, solved_all = float(qp_solves), float(admm_iters), float(solved)
+    (qp_all, admm_all, solved_all), elapsed = sharding.combine_stats(dist, dev, [qp_solves, admm_iters, solved], elapsed)
 
     if rank == 0:
         value = qp_all * args.steps / elapsed

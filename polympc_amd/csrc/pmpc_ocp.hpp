@@ -262,7 +262,14 @@ struct Ocp {
                 double cv = -ts * s.fval[r];
                 cv += s.DX[r];
                 c[r] = cv;
-                for (int i = 0; i < NDER; ++i) J[r + (size_t)dm.gidx(k, i) * m] -= ts * s.fjac[r * NDER + i];
+                // J(r, own block) = [D entry on the node's own state column | 0] - t_scale * df: one store per entry, no
+                // read-modify-write round trips (same arithmetic as "= D(i,j)*I" followed by "-= t_scale*jac", :824,:870-872)
+                const double dself = (k < dm.NN - 1) ? s.D[row + row * (P + 1)] * 1.0 : -s.D[0];
+                for (int i = 0; i < NDER; ++i) {
+                    double v = (i == q) ? dself : 0.0;
+                    v -= ts * s.fjac[r * NDER + i];
+                    J[r + (size_t)dm.gidx(k, i) * m] = v;
+                }
             }
             for (int q = 0; q < NG; ++q) {
                 const int r = dm.me + k * NG + q;

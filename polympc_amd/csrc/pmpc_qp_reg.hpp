@@ -42,65 +42,134 @@ __device__ __forceinline__ double mov_lanes_below(double dst, double src, int j)
     return dst;
 }
 
+// One wavefront per workgroup: DS operations of a wave are executed in issue order, so a write followed by a read of the
+// same LDS address needs no s_waitcnt / s_barrier — only the compiler must not reorder them.
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+
 template <int N>
 struct RegKkt {
     double a[N];  // row `lane` of (strict L + strict L^T)
     double d;     // D(lane)
 
-    static constexpr int BK = 8;                      // columns eliminated per pass of the rolled block loop
-    static constexpr int NB = (N + BK - 1) / BK;      // number of blocks / register chunks
-    static constexpr int NW = NB * BK;                // sliding-window width (N rounded up)
-    static constexpr int TRI = N * (N + 1) / 2;       // doubles of LDS factor staging (packed lower triangle by columns)
-    __device__ __forceinline__ static int off(int j) { return j * N - (j * (j + 1)) / 2; }
+    using d4 = double __attribute__((ext_vector_type(4)));
+    static constexpr int BK = 8;                      // panel width (columns eliminated per block)
+    static constexpr int NB = (N + BK - 1) / BK;      // number of blocks
+    static constexpr int NT = (N + 15) / 16;          // 16x16 tiles per dimension
+    static constexpr int NP = NT * 16;                // padded dimension
+    static constexpr int TRI = 2 * BK * NP;           // doubles of LDS staging: A-operand panel (-col) and B-operand panel (l)
 
-    // LDL^T of the matrix whose lower-triangle rows are in a[] (a[j] = K(lane, j), j <= lane; the rest is ignored).
-    // Static order, right-looking, fma trailing update — the same arithmetic as pmpc_qp.hpp.
+    // LDL^T of the matrix whose rows are in a[] (a[j] = K(lane, j); only j <= lane matters). Static order, right-looking;
+    // every trailing entry receives  a_ij <- fma(-col_ik, l_jk, a_ij)  for k ascending — bit-identical to the scalar
+    // right-looking update of pmpc_qp.hpp, because v_mfma_f64_16x16x4_f64 IS a k-ascending fma chain (verified on
+    // gfx950, tests/experiments/mfma_f64_probe.hip).
     //
-    // Code-size matters as much as instruction count here: a fully unrolled N^2/2 update is ~100 KB of straight-line
-    // code and thrashes the instruction cache. Instead the elimination runs as a ROLLED loop over blocks of BK
-    // columns on a sliding register window w[t] = K(lane, kb + t): inside a block every register index is a
-    // compile-time constant, the row index of a broadcast is a scalar (v_readlane with an SGPR lane select), and the
-    // window is shifted by BK registers between blocks. Finished (scaled) columns are staged in LDS (tr, packed
-    // lower triangle); afterwards every lane gathers its row of (L + L^T) from there — N contiguous/transposed reads
-    // instead of N^2/2 v_writelane pairs.
-    __device__ __forceinline__ void factor(int ln, double* tr) {
-        double w[NW];
+    // Blocked: panels of BK = 8 columns are factorised in row-per-lane registers (v_readlane broadcasts, 28 pair
+    // updates); the (N-kb-8)^2 trailing matrix lives in 16x16 fp64 MFMA accumulator tiles and gets its rank-8 update
+    // from two v_mfma_f64_16x16x4_f64 per tile, with the A (-col) and B (l) operand panels staged through 8 KB of LDS.
+    // The next panel is pulled out of the tiles through the same staging buffer. The block loop is fully unrolled
+    // (7 blocks for 56 rows) so that all register indices are compile-time constants.
+    __device__ __forceinline__ void factor(int ln_in, double* st) {
+        int ln = ln_in;
+        asm volatile("" : "+v"(ln));   // keep the lane predicates below local to the factorisation (no hoisting into long-lived SGPR masks)
+        double* stA = st;
+        double* stB = st + BK * NP;
+        const int lr = ln >> 4, lc = ln & 15;
+        d4 T[NT][NT];
 #pragma unroll
-        for (int t = 0; t < NW; ++t) w[t] = (t < N) ? a[t] : 0.0;
+        for (int R = 0; R < NT; ++R)
+#pragma unroll
+            for (int C = 0; C < NT; ++C) T[R][C] = d4{0.0, 0.0, 0.0, 0.0};
+        // row layout -> accumulator tiles, 8 columns at a time
+#pragma unroll
+        for (int g = 0; g < NP / BK; ++g) {
+#pragma unroll
+            for (int t = 0; t < BK; ++t) stA[t * NP + ln] = (g * BK + t < N) ? a[(g * BK + t < N) ? g * BK + t : 0] : 0.0;
+            lds_order();
+            if ((lc >> 3) == (g % 2)) {
+#pragma unroll
+                for (int R = g / 2; R < NT; ++R)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T[R][g / 2][r] = stA[(lc & 7) * NP + 16 * R + lr + 4 * r];
+            }
+            lds_order();
+        }
         d = 1.0;
-#pragma unroll 1
-        for (int kbv = 0; kbv < N; kbv += BK) {
-            const int kb = __builtin_amdgcn_readfirstlane(kbv);   // keep the block counter (and every lane select derived from it) in SGPRs
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int kb = b * BK;
+            const int Cb = kb / 16, hb = (kb % 16) / BK;
+            // 1. next panel: tile column Cb, tile-local columns [8*hb, 8*hb+8) -> row-per-lane registers
+            if ((lc >> 3) == hb) {
+#pragma unroll
+                for (int R = Cb; R < NT; ++R)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) stA[(lc & 7) * NP + 16 * R + lr + 4 * r] = T[R][Cb][r];
+            }
+            lds_order();
+            double p[BK];
+#pragma unroll
+            for (int t = 0; t < BK; ++t) p[t] = stA[t * NP + ln];
+            lds_order();
+            // 2. panel factorisation (right-looking inside the panel)
 #pragma unroll
             for (int t = 0; t < BK; ++t) {
-                const int k = kb + t;                    // wave-uniform
+                const int k = kb + t;
                 if (k < N) {
-                    const double dk = bcast_lane(w[t], k);
-                    const double col = (ln > k) ? w[t] : 0.0;   // unscaled column; 0 keeps finished lanes untouched
+                    const double dk = bcast_lane(p[t], k);
+                    const double col = (ln > k) ? p[t] : 0.0;   // unscaled column; 0 keeps finished lanes untouched
                     const double l = col / dk;
                     if (ln == k) d = dk;
-                    if (ln > k && ln < N) tr[off(k) + ln] = l;
+                    if (ln > k) a[k] = l;
+                    stA[t * NP + ln] = -col;
+                    stB[t * NP + ln] = l;
 #pragma unroll
-                    for (int c = 0; c < NB; ++c) {
-                        if (kb + c * BK < N) {           // wave-uniform: skip register chunks beyond the last column
-#pragma unroll
-                            for (int u = c * BK; u < (c + 1) * BK; ++u) {
-                                if (u > t) w[u] = fma(-col, bcast_lane(l, kb + u), w[u]);   // column kb+u of the trailing matrix
-                            }
-                        }
-                    }
+                    for (int u = t + 1; u < BK; ++u)
+                        if (kb + u < N) p[u] = fma(-col, bcast_lane(l, kb + u), p[u]);
+                } else {
+                    stA[t * NP + ln] = 0.0;
+                    stB[t * NP + ln] = 0.0;
                 }
             }
+            lds_order();
+            // 4. rank-8 update of the trailing tiles (rows / columns >= kb + 8)
+            if (kb + BK < N) {
+                const int Rmin = (kb + BK) / 16;
 #pragma unroll
-            for (int u = 0; u < NW - BK; ++u) w[u] = w[u + BK];    // slide the window
+                for (int s2 = 0; s2 < BK / 4; ++s2) {
+                    double av[NT], bv[NT];
+#pragma unroll
+                    for (int R = 0; R < NT; ++R) {
+                        if (R >= Rmin) {
+                            av[R] = stA[(4 * s2 + lr) * NP + 16 * R + lc];
+                            bv[R] = stB[(4 * s2 + lr) * NP + 16 * R + lc];
+                        } else { av[R] = 0.0; bv[R] = 0.0; }
+                    }
+#pragma unroll
+                    for (int R = 0; R < NT; ++R)
+#pragma unroll
+                        for (int C = 0; C <= R; ++C)
+                            if (C >= Rmin) T[R][C] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[R], bv[C], T[R][C], 0, 0, 0);
+                }
+            }
+            lds_order();
         }
-        wsync();
-        // gather row `lane` of (L + L^T): L(lane, j) for j < lane (contiguous across lanes), L(j, lane) for j > lane
-        const int lc = (ln < N) ? ln : 0;
-        const int ol = off(lc);
+        // transposed part, after the tiles are dead (keeps the register peak below the spill threshold): the row parts
+        // a[k] = L(lane, k) are staged 8 columns at a time and lane i in that block picks up column i:  a[j] <- L(j, i), j > i
 #pragma unroll
-        for (int j = 0; j < N; ++j) a[j] = tr[(lc > j) ? (off(j) + lc) : (ol + j)];
-        wsync();
+        for (int b = 0; b < NB; ++b) {
+            const int kb = b * BK;
+#pragma unroll
+            for (int t = 0; t < BK; ++t) stB[t * NP + ln] = (kb + t < N) ? a[(kb + t < N) ? kb + t : 0] : 0.0;
+            lds_order();
+            const bool inblk = (ln >= kb) && (ln < kb + BK);
+            const int tcol = inblk ? ln - kb : 0;
+#pragma unroll
+            for (int j = kb + 1; j < N; ++j) {
+                const double v = stB[tcol * NP + j];
+                if (inblk && ln < j) a[j] = v;
+            }
+            lds_order();
+        }
     }
 
     // c <- K^{-1} c, one entry per lane
@@ -115,7 +184,7 @@ struct RegKkt {
 };
 
 // boxADMM::solve_impl for compile-time (NN, MM); h/Alb/Aub/xlb/xub/x0/y0: LDS or HBM pointers; result -> out_x (NN), out_y (MM+NN)
-// tr: LDS scratch of RegKkt<NN+MM>::TRI doubles.
+// tr: LDS staging of RegKkt<NN+MM>::TRI doubles.
 template <int NN, int MM>
 __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, const double* h, const double* __restrict__ A,
                                                   const double* Alb, const double* Aub, const double* xlb, const double* xub,

@@ -22,7 +22,8 @@ __global__ __launch_bounds__(64, (NN > 0 ? 2 : 1)) void sqp_kernel(Model model, 
                                                  const double* __restrict__ ubx, const double* __restrict__ lbg,
                                                  const double* __restrict__ ubg, pmpc_sqp_settings ss, pmpc_qp_settings qs,
                                                  double* __restrict__ Hws, double* __restrict__ Aws, double* __restrict__ x,
-                                                 double* __restrict__ lam, pmpc_sqp_info* __restrict__ info, unsigned long long* __restrict__ phase_cycles) {
+                                                 double* __restrict__ lam, pmpc_sqp_info* __restrict__ info, unsigned long long* __restrict__ phase_cycles,
+                                                 double* __restrict__ Kws) {
     extern __shared__ double smem[];
     const int b = blockIdx.x;
     if (b >= B) return;
@@ -30,11 +31,14 @@ __global__ __launch_bounds__(64, (NN > 0 ? 2 : 1)) void sqp_kernel(Model model, 
     Ocp<Model> ocp(model, P, S, cd->t_scale);
     const int n = ocp.dm.n, m = ocp.dm.m, mi = ocp.dm.mi;
     QpLds qw; SqpLds v;
-    double* p = (NN > 0) ? qw.carve_xy(smem, n, m) : qw.carve(smem, n, m);
+    // Kws != nullptr: large-instance mode — the KKT factor lives in an HBM workspace (does not fit LDS)
+    double* p = (NN > 0 || Kws) ? qw.carve_xy(smem, n, m) : qw.carve(smem, n, m);
     p = v.carve(p, n, m, mi);
     double* stage0 = p;
     p = ocp.s.carve(p, P, S);
     if (NN > 0 && (size_t)(p - stage0) < (size_t)RegKkt<(NN > 0 ? NN + MM : 1)>::TRI + ocp.s.const_doubles(P, S)) p = stage0 + RegKkt<(NN > 0 ? NN + MM : 1)>::TRI + ocp.s.const_doubles(P, S);
+    // large-instance mode: the remaining QP vectors reuse the second-order AD staging (dead while the QP runs)
+    if (NN == 0 && Kws) qw.carve_rest(ocp.s.Lhes, n, m, Kws + (size_t)b * QpLds::kdoubles(n + m));
     double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
     const int ln = lane_id();
     for (int i = ln; i < Model::ND; i += WAVE) dL[i] = d[(size_t)b * Model::ND + i];
@@ -59,11 +63,16 @@ __global__ __launch_bounds__(64, (NN > 0 ? 2 : 1)) void sqp_kernel(Model model, 
     if (ln == 0) info[b] = si;
     if (phase_cycles && ln == 0) for (int i = 0; i < 8; ++i) atomicAdd(&phase_cycles[i], (unsigned long long)sqp.cyc[i]);
 }
-template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, bool reg_qp) {
+// mode 0: KKT factor in LDS; 1: register-resident QP (n+m <= 64); 2: KKT factor in HBM (large instances)
+template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode) {
     OcpDims<Model> dm(P, S);
     size_t stage = OcpLds<Model>::doubles(P, S);
-    if (reg_qp) { const size_t N = dm.n + dm.m; const size_t need = N * (N + 1) / 2 + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
-    return ((reg_qp ? QpLds::doubles_xy(dm.n, dm.m) : QpLds::doubles(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8) * sizeof(double);
+    if (mode == 1) { const size_t N = dm.n + dm.m; const size_t need = 2 * 8 * ((N + 15) / 16) * 16 + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
+    return ((mode == 0 ? QpLds::doubles(dm.n, dm.m) : QpLds::doubles_xy(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8) * sizeof(double);
+}
+template <class Model> inline bool sqp_hbm_mode_fits(int P, int S) {   // do the QP vectors fit the second-order staging?
+    OcpDims<Model> dm(P, S);
+    return QpLds::doubles_rest(dm.n, dm.m) <= 2 * (size_t)dm.NN * OcpDims<Model>::NDER * OcpDims<Model>::NDER;
 }
 
 // collocation assembly only (used to check A2/A4/A6/A7/A8/A9/A10 against the reference's golden vectors)
@@ -128,11 +137,11 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
     constexpr int MM_ = (Model::NX + Model::NG) * NNODES;
     if constexpr (NN_ + MM_ <= WAVE) {
         if (P * S + 1 != NNODES) return false;
-        const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, true);
+        const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, 1);
         if (ldsr > lds_limit) return false;
         if (hipFuncSetAttribute((const void*)sqp_kernel<Model, NN_, MM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
         hipLaunchKernelGGL((sqp_kernel<Model, NN_, MM_>), dim3(B), dim3(WAVE), ldsr, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
-                           *ss, *qs, Hws, Aws, x, lam, info, phase);
+                           *ss, *qs, Hws, Aws, x, lam, info, phase, (double*)nullptr);
         *st = (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
         return true;
     } else {
@@ -159,11 +168,20 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
         if (try_launch_reg<Model, 7>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst)) return rst;
         if (try_launch_reg<Model, 5>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst)) return rst;
     }
-    const size_t lds = sqp_kernel_lds_bytes<Model>(P, S, false);
-    if (lds > lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;
+    size_t lds = sqp_kernel_lds_bytes<Model>(P, S, 0);
+    double* Kws = nullptr;
+    if (lds > lds_limit) {   // large instance: KKT factor in HBM, QP vectors over the AD staging
+        lds = sqp_kernel_lds_bytes<Model>(P, S, 2);
+        if (lds > lds_limit || !sqp_hbm_mode_fits<Model>(P, S)) return PMPC_ERR_UNSUPPORTED_SIZE;
+        const size_t base = (size_t)B * ((size_t)dm.n * dm.n + (size_t)dm.m * dm.n);
+        st = pmpc_internal_services(ctx, P, S, t0, tf, (base + (size_t)B * QpLds::kdoubles(dm.n + dm.m)) * sizeof(double), &cdv, &ws, &streamv,
+                                    &lds_limit, &phase, &force_lds);
+        if (st != PMPC_OK) return st;
+        Hws = ws; Aws = ws + (size_t)B * dm.n * dm.n; Kws = ws + base;
+    }
     if (hipFuncSetAttribute((const void*)sqp_kernel<Model>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PMPC_ERR_HIP;
     hipLaunchKernelGGL((sqp_kernel<Model>), dim3(B), dim3(WAVE), lds, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, *ss, *qs, Hws, Aws, x,
-                       lam, info, phase);
+                       lam, info, phase, Kws);
     return (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
 }
 

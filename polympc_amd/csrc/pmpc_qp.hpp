@@ -78,6 +78,14 @@ struct QpLds {
         q = z = zt = zprev = rho = rhoinv = rhob = rhobinv = kdiag = rhs = t1 = t2 = nullptr;
         return p;
     }
+    // large-instance mode: x, y as carve_xy; K in an HBM workspace; every other vector in a caller-provided LDS region
+    __host__ __device__ static size_t doubles_rest(int n, int m) { return 3 * (size_t)n + 5 * (size_t)m + 4 * (size_t)(n + m); }
+    __device__ void carve_rest(double* p, int n, int m, double* K_hbm) {
+        N = n + m; K = K_hbm;
+        q = p; p += n; kdiag = p; p += N;
+        z = p; p += m; zt = p; p += m; zprev = p; p += m; rho = p; p += m; rhoinv = p; p += m;
+        rhob = p; p += n; rhobinv = p; p += n; rhs = p; p += N; t1 = p; p += N; t2 = p; p += N;
+    }
     __device__ double* carve(double* base, int n, int m) {
         N = n + m;
         double* p = base;

@@ -54,6 +54,20 @@ def cstr_batch(B, seed=SEED, first=0):
     return dict(model=1, P=P, S=S, t0=0.0, tf=100.0, d=np.zeros((B, 1)), lbx=lbx, ubx=ubx, n=n, m=4 * nn, max_iter=20, ls_max_iter=20)
 
 
+def kite_standin_batch(B, seed=SEED, first=0):
+    """Config C dimension stand-in: SYNTHETIC 13-state / 3-input smooth dynamics (the reference's KiteDynamics is not in
+    the reference tree), P=5 S=3 -> 16 nodes, n=256, m=208, KKT 464 rows; u in [-1,1]^3, x0 = 0.3*U^13."""
+    P, S, nn = 5, 3, 16
+    n = 16 * nn
+    inst = np.arange(first, first + B, dtype=np.uint64)
+    lbx = np.full((B, n), -np.inf); ubx = np.full((B, n), np.inf)
+    for j in range(13):
+        x0 = 0.3 * uniform_pm1(seed, inst, j)
+        lbx[:, 13 * nn - 13 + j] = x0; ubx[:, 13 * nn - 13 + j] = x0
+    lbx[:, 13 * nn:] = -1.0; ubx[:, 13 * nn:] = 1.0
+    return dict(model=4, P=P, S=S, t0=0.0, tf=1.0, d=np.zeros((B, 1)), lbx=lbx, ubx=ubx, n=n, m=13 * nn, max_iter=5, ls_max_iter=10)
+
+
 def random_qp_batch(B, n, m, seed=SEED):
     """Dense strictly convex QPs with mixed equality / inequality / loose rows and boxes (any n, m)."""
     rng = np.random.default_rng(seed)

@@ -249,6 +249,30 @@ def test_sqp_cstr_config_B(ctx, oracle):
     assert (np.abs(x - xo) / scale)[same].max() <= 1e-7
 
 
+def test_sqp_kite_standin_config_C(ctx, oracle):
+    """Config C (synthetic 13-state / 3-input stand-in, 16 nodes, n=256, m=208: 464 KKT rows): the KKT factor does not
+    fit LDS, so the large-instance mode keeps it in an HBM workspace. Same algorithm, same parity bar."""
+    from polympc_amd import workloads
+    B = 3
+    (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, workloads.kite_standin_batch(B), B)
+    assert list(info["iter"]) == [i.iter for i in io] and list(info["status"]) == [i.status for i in io]
+    assert list(info["qp_solver_iter"]) == [i.qp_solver_iter for i in io]
+    assert np.abs(x - xo).max() <= 1e-8
+
+
+def test_collocation_kite_standin_vs_oracle(ctx, oracle):
+    import polympc_amd as pa
+    rng = np.random.default_rng(13)
+    dm = pa.ocp_dims(4, 5, 3)
+    var = rng.uniform(-1, 1, (2, dm["n"])); lam = rng.uniform(-1, 1, (2, dm["m"] + dm["n"]))
+    ev = ctx.ocp_linearise_batch(4, 5, 3, 0.0, 1.0, var, np.zeros((2, 1)), lam=lam)
+    for b in range(2):
+        eo = oracle.ocp_eval(4, 5, 3, 0.0, 1.0, var[b], [0.0], lam=lam[b])
+        for k in ("c", "jac", "cost_grad", "lag_grad", "lag_hess"):
+            ref = np.concatenate([eo["c"], eo["g"]]) if k == "c" else eo[k]
+            assert np.abs(ev[k][b] - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), k
+
+
 def test_sqp_warm_start_and_gershgorin(ctx, oracle):
     """Second solve warm-started from the first (x, lam) with a moved initial state; Gershgorin regulariser on."""
     import polympc_amd as pa

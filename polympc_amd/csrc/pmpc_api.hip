@@ -74,6 +74,8 @@ struct pmpc_context {
     bool own_stream = false;
     size_t lds_limit = 64 * 1024;
     unsigned long long* phase_cycles = nullptr;   // PMPC_PHASE_PROFILE=1: per-phase shader-clock totals of the SQP kernels
+    int sqp_slice = 0;             // PMPC_SQP_SLICE=k: run k SQP iterations per kernel launch with per-instance state in HBM (finished
+                                   // instances free their slots); 0 (default) = whole solve in one launch — measured faster on config A
     bool force_lds_path = false;   // PMPC_FORCE_LDS_PATH=1: disable the register-resident specialisations (A/B testing)
     std::map<std::tuple<int, int, double, double>, ChebData*> cheb_cache;
     double* ws = nullptr; size_t ws_bytes = 0;       // SQP HBM workspace (H, J)
@@ -130,6 +132,8 @@ extern "C" pmpc_status pmpc_internal_services(pmpc_context* ctx, int P, int S, d
     return PMPC_OK;
 }
 
+extern "C" int pmpc_internal_sqp_slice(pmpc_context* ctx) { return ctx ? ctx->sqp_slice : 0; }
+
 template <class Model> static Model make_model(const double* mp, int nmp) { Model mdl; mdl.set_params(mp, nmp); return mdl; }
 
 // =====================================================================================================================
@@ -164,6 +168,7 @@ pmpc_status pmpc_create(int device, void* stream, pmpc_context** out) {
     ctx->lds_limit = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 64 * 1024;
     if (prop.sharedMemPerBlockOptin && (size_t)prop.sharedMemPerBlockOptin < ctx->lds_limit) ctx->lds_limit = prop.sharedMemPerBlockOptin;
     { const char* e = getenv("PMPC_FORCE_LDS_PATH"); ctx->force_lds_path = (e && e[0] == '1'); }
+    { const char* e = getenv("PMPC_SQP_SLICE"); if (e && e[0]) ctx->sqp_slice = atoi(e) < 0 ? 0 : atoi(e); }
     { const char* e = getenv("PMPC_PHASE_PROFILE");
       if (e && e[0] == '1') { HIPCHK(hipMalloc((void**)&ctx->phase_cycles, 8 * sizeof(unsigned long long))); HIPCHK(hipMemset(ctx->phase_cycles, 0, 8 * sizeof(unsigned long long))); } }
     *out = ctx;

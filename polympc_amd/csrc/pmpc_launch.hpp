@@ -11,6 +11,7 @@
 // context services exported by libpolympc_amd.so (collocation constants cache, HBM workspace, stream, limits)
 extern "C" pmpc_status pmpc_internal_services(pmpc_context* ctx, int P, int S, double t0, double tf, size_t ws_bytes, const void** cheb,
                                                double** ws, void** stream, size_t* lds_limit, unsigned long long** phase_cycles, int* force_lds);
+extern "C" int pmpc_internal_sqp_slice(pmpc_context* ctx);   // SQP iterations per kernel launch (0 = whole solve in one launch)
 
 namespace pmpc {
 using ::pmpc_status;
@@ -23,10 +24,12 @@ __global__ __launch_bounds__(64, (NN > 0 ? 2 : 1)) void sqp_kernel(Model model, 
                                                  const double* __restrict__ ubg, pmpc_sqp_settings ss, pmpc_qp_settings qs,
                                                  double* __restrict__ Hws, double* __restrict__ Aws, double* __restrict__ x,
                                                  double* __restrict__ lam, pmpc_sqp_info* __restrict__ info, unsigned long long* __restrict__ phase_cycles,
-                                                 double* __restrict__ Kws) {
+                                                 double* __restrict__ Kws, int it_begin, int it_end, double* __restrict__ slice_state) {
     extern __shared__ double smem[];
     const int b = blockIdx.x;
     if (b >= B) return;
+    // iteration-sliced execution: instances that finished in an earlier slice give their slot back immediately
+    if (it_begin > 0 && __builtin_amdgcn_readfirstlane(info[b].status) != PMPC_SQP_IN_PROGRESS) return;
     const int P = cd->P, S = cd->S;
     Ocp<Model> ocp(model, P, S, cd->t_scale);
     const int n = ocp.dm.n, m = ocp.dm.m, mi = ocp.dm.mi;
@@ -44,11 +47,14 @@ __global__ __launch_bounds__(64, (NN > 0 ? 2 : 1)) void sqp_kernel(Model model, 
     for (int i = ln; i < Model::ND; i += WAVE) dL[i] = d[(size_t)b * Model::ND + i];
     ocp.d = dL;
     ocp.stage_constants(cd);
+    double* sst = slice_state ? slice_state + (size_t)b * 2 * n : nullptr;   // [previous Lagrangian gradient | previous step]
     for (int i = ln; i < n; i += WAVE) {
-        v.x[i] = x_guess ? x_guess[(size_t)b * n + i] : 0.0;
+        v.x[i] = (it_begin > 0) ? x[(size_t)b * n + i] : (x_guess ? x_guess[(size_t)b * n + i] : 0.0);
         v.lbx[i] = lbx[(size_t)b * n + i]; v.ubx[i] = ubx[(size_t)b * n + i];
+        if (it_begin > 0) { v.lg[i] = sst[i]; v.step[i] = sst[n + i]; }
     }
-    for (int i = ln; i < m + n; i += WAVE) v.lam[i] = lam_guess ? lam_guess[(size_t)b * (m + n) + i] : 0.0;
+    for (int i = ln; i < m + n; i += WAVE)
+        v.lam[i] = (it_begin > 0) ? lam[(size_t)b * (m + n) + i] : (lam_guess ? lam_guess[(size_t)b * (m + n) + i] : 0.0);
     for (int i = ln; i < mi; i += WAVE) {
         v.lbg[i] = lbg ? lbg[(size_t)b * mi + i] : -INFINITY;
         v.ubg[i] = ubg ? ubg[(size_t)b * mi + i] : INFINITY;
@@ -57,7 +63,9 @@ __global__ __launch_bounds__(64, (NN > 0 ? 2 : 1)) void sqp_kernel(Model model, 
     SqpDevice<Model, NN, MM> sqp(ocp, v, qw, Hws + (size_t)b * n * n, Aws + (size_t)b * m * n, ss, qs);
     sqp.tr = ocp.s.fval;   // first per-node staging array: everything from here on is dead while the QP runs
     pmpc_sqp_info si;
-    sqp.solve(si);
+    if (it_begin > 0) { const pmpc_sqp_info prev = info[b]; sqp.qp_iter_total = prev.qp_solver_iter; sqp.cost_log = prev.cost; }
+    sqp.solve(si, it_begin, it_end);
+    if (si.status == PMPC_SQP_IN_PROGRESS && sst) for (int i = ln; i < n; i += WAVE) { sst[i] = v.lg[i]; sst[n + i] = v.step[i]; }
     for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = v.x[i];
     for (int i = ln; i < m + n; i += WAVE) lam[(size_t)b * (m + n) + i] = v.lam[i];
     if (ln == 0) info[b] = si;
@@ -132,7 +140,8 @@ template <class Model, int NNODES>
 inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* cd, int P, int S, int B, const double* x_guess,
                            const double* lam_guess, const double* d, const double* lbx, const double* ubx, const double* lbg,
                            const double* ubg, const pmpc_sqp_settings* ss, const pmpc_qp_settings* qs, double* Hws, double* Aws, double* x,
-                           double* lam, pmpc_sqp_info* info, hipStream_t stream, size_t lds_limit, unsigned long long* phase, pmpc_status* st) {
+                           double* lam, pmpc_sqp_info* info, hipStream_t stream, size_t lds_limit, unsigned long long* phase, pmpc_status* st,
+                           double* slice_state, int slice_iters) {
     constexpr int NN_ = (Model::NX + Model::NU) * NNODES + Model::NP;
     constexpr int MM_ = (Model::NX + Model::NG) * NNODES;
     if constexpr (NN_ + MM_ <= WAVE) {
@@ -140,8 +149,10 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
         const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, 1);
         if (ldsr > lds_limit) return false;
         if (hipFuncSetAttribute((const void*)sqp_kernel<Model, NN_, MM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
-        hipLaunchKernelGGL((sqp_kernel<Model, NN_, MM_>), dim3(B), dim3(WAVE), ldsr, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
-                           *ss, *qs, Hws, Aws, x, lam, info, phase, (double*)nullptr);
+        const int slice = (slice_state && slice_iters > 0) ? slice_iters : ss->max_iter;
+        for (int it = 0; it < ss->max_iter; it += slice)
+            hipLaunchKernelGGL((sqp_kernel<Model, NN_, MM_>), dim3(B), dim3(WAVE), ldsr, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
+                               *ss, *qs, Hws, Aws, x, lam, info, phase, (double*)nullptr, it, it + slice, slice_state);
         *st = (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
         return true;
     } else {
@@ -157,31 +168,34 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     if (P < 1 || P > MAX_P || S < 1 || P * S + 1 > MAX_NODES) return PMPC_ERR_UNSUPPORTED_SIZE;
     OcpDims<Model> dm(P, S);
     const void* cdv = nullptr; double* ws = nullptr; void* streamv = nullptr; size_t lds_limit = 0; unsigned long long* phase = nullptr; int force_lds = 0;
-    pmpc_status st = pmpc_internal_services(ctx, P, S, t0, tf, (size_t)B * ((size_t)dm.n * dm.n + (size_t)dm.m * dm.n) * sizeof(double), &cdv, &ws,
-                                            &streamv, &lds_limit, &phase, &force_lds);
+    const size_t base = (size_t)B * ((size_t)dm.n * dm.n + (size_t)dm.m * dm.n + 2 * (size_t)dm.n);
+    pmpc_status st = pmpc_internal_services(ctx, P, S, t0, tf, base * sizeof(double), &cdv, &ws, &streamv, &lds_limit, &phase, &force_lds);
     if (st != PMPC_OK) return st;
     const ChebData* cd = (const ChebData*)cdv;
     hipStream_t stream = (hipStream_t)streamv;
     double* Hws = ws; double* Aws = ws + (size_t)B * dm.n * dm.n;
+    double* slice_state = Aws + (size_t)B * dm.m * dm.n;
+    const int slice_iters = pmpc_internal_sqp_slice(ctx);
     if (!force_lds) {   // node counts whose KKT system can fit 64 rows for small models (7 nodes: config A / D)
         pmpc_status rst = PMPC_OK;
-        if (try_launch_reg<Model, 7>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst)) return rst;
-        if (try_launch_reg<Model, 5>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst)) return rst;
+        if (try_launch_reg<Model, 7>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;
+        if (try_launch_reg<Model, 5>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;
     }
     size_t lds = sqp_kernel_lds_bytes<Model>(P, S, 0);
     double* Kws = nullptr;
     if (lds > lds_limit) {   // large instance: KKT factor in HBM, QP vectors over the AD staging
         lds = sqp_kernel_lds_bytes<Model>(P, S, 2);
         if (lds > lds_limit || !sqp_hbm_mode_fits<Model>(P, S)) return PMPC_ERR_UNSUPPORTED_SIZE;
-        const size_t base = (size_t)B * ((size_t)dm.n * dm.n + (size_t)dm.m * dm.n);
         st = pmpc_internal_services(ctx, P, S, t0, tf, (base + (size_t)B * QpLds::kdoubles(dm.n + dm.m)) * sizeof(double), &cdv, &ws, &streamv,
                                     &lds_limit, &phase, &force_lds);
         if (st != PMPC_OK) return st;
-        Hws = ws; Aws = ws + (size_t)B * dm.n * dm.n; Kws = ws + base;
+        Hws = ws; Aws = ws + (size_t)B * dm.n * dm.n; slice_state = Aws + (size_t)B * dm.m * dm.n; Kws = ws + base;
     }
     if (hipFuncSetAttribute((const void*)sqp_kernel<Model>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PMPC_ERR_HIP;
-    hipLaunchKernelGGL((sqp_kernel<Model>), dim3(B), dim3(WAVE), lds, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, *ss, *qs, Hws, Aws, x,
-                       lam, info, phase, Kws);
+    const int slice = (slice_iters > 0) ? slice_iters : ss->max_iter;
+    for (int it = 0; it < ss->max_iter; it += slice)
+        hipLaunchKernelGGL((sqp_kernel<Model>), dim3(B), dim3(WAVE), lds, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, *ss, *qs, Hws, Aws,
+                           x, lam, info, phase, Kws, it, it + slice, slice_state);
     return (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
 }
 

@@ -230,89 +230,104 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
     int status = PMPC_QP_UNSOLVED;
     const double alpha = s.alpha;
     double max_Ax_z_norm = 0.0, max_Hx_ATy_h_norm = 0.0, res_prim = 1.0, res_dual = 1.0, rho_estimate = 0.0;
-    bool need_factor = true;
-
-    int iter;
-    for (iter = 1; iter <= s.max_iter; ++iter) {
-        const long long f0 = clock64();
-        if (need_factor) {   // construct_kkt_matrix + factorise_kkt_matrix (single code site: first iteration and after rho updates)
+    // Outer loop = one KKT factorisation (first pass and after every accepted rho update); inner loop = ADMM iterations
+    // on that factor. Keeping the high-register-pressure factorisation OUT of the inner loop keeps the inner loop's
+    // state in registers (no scratch traffic inside the ADMM iterations).
+    int iter = 1;
+    bool running = true;
+    while (running) {
+        {   // construct_kkt_matrix + factorise_kkt_matrix
+            const long long f0 = clock64();
 #pragma unroll
             for (int j = 0; j < NN; ++j) { const double v = rowp[(size_t)j * rstride]; K.a[j] = (ln == j) ? kdiag : v; }
 #pragma unroll
             for (int j = NN; j < N; ++j) K.a[j] = (ln == j) ? kdiag : 0.0;
             K.factor(ln, tr);
-            need_factor = false;
             if (dbg) dbg[0] += clock64() - f0;
         }
-        const double zprev = xv;  // meaningful on constraint lanes
-        double rhs = 0.0;
-        if (isP) rhs = ((s.sigma * xv - hv) + rhov * qv) - yv;
-        if (isC) rhs = xv - rhoinv * yv;
-        const double sol = K.solve(rhs, ln);
-        if (isC) {
-            const double zt = zprev + rhoinv * (sol - yv);
-            double zz = alpha * zt;
-            zz += (1 - alpha) * zprev + rhoinv * yv;
-            zz = fmin(fmax(zz, lo), hi);
-            xv = zz;
-            yv += rhov * ((alpha * zt + (1 - alpha) * zprev) - zz);
-        }
-        if (isP) {
-            double xx = alpha * sol;
-            xx += (1 - alpha) * xx;  // quirk Q1
-            xv = xx;
-            double qq = xx + rhoinv * yv;
-            qq = fmin(fmax(qq, lo), hi);
-            qv = qq;
-            yv += rhov * (xx - qq);
-        }
-        const bool check = (s.check_termination != 0 && iter % s.check_termination == 0);
-        const bool adapt = (s.adaptive_rho && iter % s.adaptive_rho_interval == 0);
-        const long long r0 = clock64();
-        if (check || adapt) {  // residuals_update, box_admm.hpp:398-415
-            // all loads first (independent, coalesced), then the two mat-vec chains: one memory round trip per check
-            double mrow[NN], mcol[MM];
+        bool refactor = false;
+        for (; iter <= s.max_iter; ++iter) {
+            const double zprev = xv;  // meaningful on constraint lanes
+            double rhs = 0.0;
+            if (isP) rhs = ((s.sigma * xv - hv) + rhov * qv) - yv;
+            if (isC) rhs = xv - rhoinv * yv;
+            const double sol = K.solve(rhs, ln);
+            if (isC) {
+                const double zt = zprev + rhoinv * (sol - yv);
+                double zz = alpha * zt;
+                zz += (1 - alpha) * zprev + rhoinv * yv;
+                zz = fmin(fmax(zz, lo), hi);
+                xv = zz;
+                yv += rhov * ((alpha * zt + (1 - alpha) * zprev) - zz);
+            }
+            if (isP) {
+                double xx = alpha * sol;
+                xx += (1 - alpha) * xx;  // quirk Q1
+                xv = xx;
+                double qq = xx + rhoinv * yv;
+                qq = fmin(fmax(qq, lo), hi);
+                qv = qq;
+                yv += rhov * (xx - qq);
+            }
+            const bool check = (s.check_termination != 0 && iter % s.check_termination == 0);
+            const bool adapt = (s.adaptive_rho && iter % s.adaptive_rho_interval == 0);
+            if (check || adapt) {  // residuals_update, box_admm.hpp:398-415
+                const long long r0 = clock64();
+                // loads in chunks of RC columns (independent, coalesced), each followed by its slice of the mat-vec chain
+                constexpr int RC = 12;
+                double acc = 0.0;      // lanes < n: (H x)_i ; lanes in [n, N): (A x)_r
 #pragma unroll
-            for (int j = 0; j < NN; ++j) mrow[j] = rowp[(size_t)j * rstride];
+                for (int j0 = 0; j0 < NN; j0 += RC) {
+                    double mrow[RC];
 #pragma unroll
-            for (int k = 0; k < MM; ++k) mcol[k] = colA[k];
-            double acc = 0.0;      // lanes < n: (H x)_i ; lanes in [n, N): (A x)_r
+                    for (int j = 0; j < RC; ++j) mrow[j] = (j0 + j < NN) ? rowp[(size_t)(j0 + j < NN ? j0 + j : 0) * rstride] : 0.0;
 #pragma unroll
-            for (int j = 0; j < NN; ++j) acc += mrow[j] * bcast_lane(xv, j);
-            double aty = 0.0;      // lanes < n: (A^T y_a)_i
+                    for (int j = 0; j < RC; ++j) if (j0 + j < NN) acc += mrow[j] * bcast_lane(xv, j0 + j);
+                }
+                double aty = 0.0;      // lanes < n: (A^T y_a)_i
 #pragma unroll
-            for (int k = 0; k < MM; ++k) aty += mcol[k] * bcast_lane(yv, NN + k);
-            const double nAx = wave_max(isC ? fabs(acc) : 0.0), nz = wave_max(isC ? fabs(xv) : 0.0), nx = wave_max(isP ? fabs(xv) : 0.0);
-            const double rp = wave_max(isC ? fabs(acc - xv) : 0.0), rq = wave_max(isP ? fabs(xv - qv) : 0.0);
-            const double nHx = wave_max(isP ? fabs(acc) : 0.0), nATy = wave_max(isP ? fabs(aty) : 0.0);
-            const double nh = wave_max(fabs(hv)), nyb = wave_max(isP ? fabs(yv) : 0.0);
-            const double rd = wave_max(isP ? fabs(((acc + hv) + aty) + yv) : 0.0);
-            max_Ax_z_norm = fmax(nAx, fmax(nz, nx));
-            max_Hx_ATy_h_norm = fmax(nHx, fmax(nATy, fmax(nh, nyb)));
-            res_prim = rp + rq;
-            res_dual = rd;
-            if (dbg) dbg[1] += clock64() - r0;
-        }
-        if (check) {
-            const double ep = s.eps_abs + s.eps_rel * max_Ax_z_norm, ed = s.eps_abs + s.eps_rel * max_Hx_ATy_h_norm;
-            if (__builtin_amdgcn_readfirstlane((int)(res_prim <= ep && res_dual <= ed))) { status = PMPC_QP_SOLVED; break; }
-        }
-        if (adapt) {
-            const double rpn = res_prim / (max_Ax_z_norm + DIV_BY_ZERO_REGUL);
-            const double rdn = res_dual / (max_Hx_ATy_h_norm + DIV_BY_ZERO_REGUL);
-            double new_rho = rho * ::sqrt(rpn / (rdn + DIV_BY_ZERO_REGUL));
-            new_rho = fmax(RHO_MIN, fmin(new_rho, RHO_MAX));
-            rho_estimate = new_rho;
-            if (__builtin_amdgcn_readfirstlane((int)(new_rho < rho / s.adaptive_rho_tolerance || new_rho > rho * s.adaptive_rho_tolerance))) {
-                const double prev = rhov;
-                rho = new_rho;
-                rhov = rho_of(type, rho);
-                rhoinv = 1.0 / rhov;
-                ++rho_updates;
-                if (isP) kdiag += (rhov - prev); else kdiag = -rhoinv;   // update_kkt_rho, box_admm.hpp:448-452
-                need_factor = true;
+                for (int k0 = 0; k0 < MM; k0 += RC) {
+                    double mcol[RC];
+#pragma unroll
+                    for (int k = 0; k < RC; ++k) mcol[k] = (k0 + k < MM) ? colA[(k0 + k < MM) ? k0 + k : 0] : 0.0;
+#pragma unroll
+                    for (int k = 0; k < RC; ++k) if (k0 + k < MM) aty += mcol[k] * bcast_lane(yv, NN + k0 + k);
+                }
+                const double nAx = wave_max(isC ? fabs(acc) : 0.0), nz = wave_max(isC ? fabs(xv) : 0.0), nx = wave_max(isP ? fabs(xv) : 0.0);
+                const double rp = wave_max(isC ? fabs(acc - xv) : 0.0), rq = wave_max(isP ? fabs(xv - qv) : 0.0);
+                const double nHx = wave_max(isP ? fabs(acc) : 0.0), nATy = wave_max(isP ? fabs(aty) : 0.0);
+                const double nh = wave_max(fabs(hv)), nyb = wave_max(isP ? fabs(yv) : 0.0);
+                const double rd = wave_max(isP ? fabs(((acc + hv) + aty) + yv) : 0.0);
+                max_Ax_z_norm = fmax(nAx, fmax(nz, nx));
+                max_Hx_ATy_h_norm = fmax(nHx, fmax(nATy, fmax(nh, nyb)));
+                res_prim = rp + rq;
+                res_dual = rd;
+                if (dbg) dbg[1] += clock64() - r0;
+            }
+            if (check) {
+                const double ep = s.eps_abs + s.eps_rel * max_Ax_z_norm, ed = s.eps_abs + s.eps_rel * max_Hx_ATy_h_norm;
+                if (__builtin_amdgcn_readfirstlane((int)(res_prim <= ep && res_dual <= ed))) { status = PMPC_QP_SOLVED; running = false; break; }
+            }
+            if (adapt) {
+                const double rpn = res_prim / (max_Ax_z_norm + DIV_BY_ZERO_REGUL);
+                const double rdn = res_dual / (max_Hx_ATy_h_norm + DIV_BY_ZERO_REGUL);
+                double new_rho = rho * ::sqrt(rpn / (rdn + DIV_BY_ZERO_REGUL));
+                new_rho = fmax(RHO_MIN, fmin(new_rho, RHO_MAX));
+                rho_estimate = new_rho;
+                if (__builtin_amdgcn_readfirstlane((int)(new_rho < rho / s.adaptive_rho_tolerance || new_rho > rho * s.adaptive_rho_tolerance))) {
+                    const double prev = rhov;
+                    rho = new_rho;
+                    rhov = rho_of(type, rho);
+                    rhoinv = 1.0 / rhov;
+                    ++rho_updates;
+                    if (isP) kdiag += (rhov - prev); else kdiag = -rhoinv;   // update_kkt_rho, box_admm.hpp:448-452
+                    refactor = true;
+                    ++iter;
+                    break;
+                }
             }
         }
+        if (!refactor) running = false;
     }
     if (iter > s.max_iter) status = PMPC_QP_MAX_ITER_EXCEEDED;
     if (isP) { out_x[ln] = xv; out_y[MM + ln] = yv; }

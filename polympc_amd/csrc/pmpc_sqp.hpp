@@ -31,6 +31,7 @@ struct SqpLds {
 };
 
 constexpr double DBL_EPS = 2.220446049250313e-16;
+constexpr int PMPC_SQP_IN_PROGRESS = 3;   // internal: the instance continues in the next iteration-slice launch
 
 // NN, MM > 0: compile-time QP size with NN+MM <= 64 -> register-resident QP (pmpc_qp_reg.hpp); 0 -> LDS-resident QP
 template <class Model, int NN = 0, int MM = 0>
@@ -287,9 +288,10 @@ struct SqpDevice {
         return (primal_norm <= ss.eps_prim) && (dual_norm <= ss.eps_dual) && (max_violation <= ss.eps_prim);
     }
 
-    __device__ void solve(pmpc_sqp_info& info) {
+    // SQP iterations it_begin+1 .. min(it_end, max_iter). status PMPC_SQP_IN_PROGRESS (internal) when the slice ends first.
+    __device__ void solve(pmpc_sqp_info& info, int it_begin, int it_end) {
         int status = PMPC_SQP_MAX_ITER_EXCEEDED;
-        int iter = 0;
+        int iter = it_begin;
         // single code site for the (large) QP + line-search body: first pass = exact linearisation (:583), later = update (:649)
         while (true) {
             ++iter;
@@ -303,6 +305,7 @@ struct SqpDevice {
             cyc[0] += c1 - c0; cyc[3] += c3 - c2; cyc[4] += c3 - c0; (void)c2;
             if (done) { status = PMPC_SQP_SOLVED; break; }
             if (iter >= ss.max_iter) break;
+            if (iter >= it_end) { status = PMPC_SQP_IN_PROGRESS; break; }
         }
         info.iter = iter; info.qp_solver_iter = qp_iter_total; info.status = status; info._pad = 0;
         info.primal_norm = primal_norm; info.dual_norm = dual_norm; info.max_violation = max_violation; info.cost = cost_log;

@@ -24,8 +24,9 @@ __global__ __launch_bounds__(64, (NN > 0 ? 2 : 1)) void sqp_kernel(Model model, 
                                                  const double* __restrict__ ubg, pmpc_sqp_settings ss, pmpc_qp_settings qs,
                                                  double* __restrict__ Hws, double* __restrict__ Aws, double* __restrict__ x,
                                                  double* __restrict__ lam, pmpc_sqp_info* __restrict__ info, unsigned long long* __restrict__ phase_cycles,
-                                                 double* __restrict__ Kws, int it_begin, int it_end, double* __restrict__ slice_state) {
+                                                 double* __restrict__ Kws, int it_begin, int it_end, double* __restrict__ slice_state, unsigned lds_dyn_doubles) {
     extern __shared__ double smem[];
+    const size_t lds_doubles_total = __builtin_amdgcn_groupstaticsize() / sizeof(double) + lds_dyn_doubles;
     const int b = blockIdx.x;
     if (b >= B) return;
     // iteration-sliced execution: instances that finished in an earlier slice give their slot back immediately
@@ -62,6 +63,12 @@ __global__ __launch_bounds__(64, (NN > 0 ? 2 : 1)) void sqp_kernel(Model model, 
     wsync();
     SqpDevice<Model, NN, MM> sqp(ocp, v, qw, Hws + (size_t)b * n * n, Aws + (size_t)b * m * n, ss, qs);
     sqp.tr = ocp.s.fval;   // first per-node staging array: everything from here on is dead while the QP runs
+    {   // side-by-side line search: G candidates x (m constraint values + NN Lagrange values) + 3 scalars each, in the same region
+        const int G = WAVE / ocp.dm.NN;
+        const size_t need = (size_t)G * (m + ocp.dm.NN + 3);
+        const size_t have = (size_t)((smem + lds_doubles_total) - ocp.s.fval);
+        sqp.lsbuf = (G >= 2 && need <= have) ? ocp.s.fval : nullptr;
+    }
     pmpc_sqp_info si;
     if (it_begin > 0) { const pmpc_sqp_info prev = info[b]; sqp.qp_iter_total = prev.qp_solver_iter; sqp.cost_log = prev.cost; }
     sqp.solve(si, it_begin, it_end);
@@ -152,7 +159,7 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
         const int slice = (slice_state && slice_iters > 0) ? slice_iters : ss->max_iter;
         for (int it = 0; it < ss->max_iter; it += slice)
             hipLaunchKernelGGL((sqp_kernel<Model, NN_, MM_>), dim3(B), dim3(WAVE), ldsr, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
-                               *ss, *qs, Hws, Aws, x, lam, info, phase, (double*)nullptr, it, it + slice, slice_state);
+                               *ss, *qs, Hws, Aws, x, lam, info, phase, (double*)nullptr, it, it + slice, slice_state, (unsigned)(ldsr / sizeof(double)));
         *st = (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
         return true;
     } else {
@@ -195,7 +202,7 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     const int slice = (slice_iters > 0) ? slice_iters : ss->max_iter;
     for (int it = 0; it < ss->max_iter; it += slice)
         hipLaunchKernelGGL((sqp_kernel<Model>), dim3(B), dim3(WAVE), lds, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, *ss, *qs, Hws, Aws,
-                           x, lam, info, phase, Kws, it, it + slice, slice_state);
+                           x, lam, info, phase, Kws, it, it + slice, slice_state, (unsigned)(lds / sizeof(double)));
     return (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
 }
 

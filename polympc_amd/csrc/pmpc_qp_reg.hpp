@@ -27,18 +27,18 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {
 }
 // c <- fma(-a, x, c) on the lanes ABOVE `j` only (x wave-uniform, in SGPRs). The lane mask is a compile-time constant, so
 // it is applied with one scalar shift into EXEC instead of a compare + two selects; EXEC is restored inside the statement
-// (the compiler never sees a modified EXEC). s_nop 0 completes the v_readlane(SGPR write) -> VALU(SGPR read) wait states.
+// (the compiler never sees a modified EXEC; SCC, which the scalar shift overwrites, is declared clobbered). s_nop 0 completes the v_readlane(SGPR write) -> VALU(SGPR read) wait states.
 __device__ __forceinline__ double fnma_lanes_above(double c, double a, double x_uniform, int j) {
-    asm("s_lshl_b64 exec, -1, %3\n\ts_nop 0\n\tv_fma_f64 %0, -%1, %2, %0\n\ts_mov_b64 exec, -1" : "+v"(c) : "v"(a), "s"(x_uniform), "i"(j + 1));
+    asm("s_lshl_b64 exec, -1, %3\n\ts_nop 0\n\tv_fma_f64 %0, -%1, %2, %0\n\ts_mov_b64 exec, -1" : "+v"(c) : "v"(a), "s"(x_uniform), "i"(j + 1) : "scc");
     return c;
 }
 __device__ __forceinline__ double fnma_lanes_below(double c, double a, double x_uniform, int j) {
-    asm("s_lshr_b64 exec, -1, %3\n\ts_nop 0\n\tv_fma_f64 %0, -%1, %2, %0\n\ts_mov_b64 exec, -1" : "+v"(c) : "v"(a), "s"(x_uniform), "i"(64 - j));
+    asm("s_lshr_b64 exec, -1, %3\n\ts_nop 0\n\tv_fma_f64 %0, -%1, %2, %0\n\ts_mov_b64 exec, -1" : "+v"(c) : "v"(a), "s"(x_uniform), "i"(64 - j) : "scc");
     return c;
 }
 // dst <- src on the lanes BELOW `j` only
 __device__ __forceinline__ double mov_lanes_below(double dst, double src, int j) {
-    asm("s_lshr_b64 exec, -1, %2\n\tv_mov_b64 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(dst) : "v"(src), "i"(64 - j));
+    asm("s_lshr_b64 exec, -1, %2\n\tv_mov_b64 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(dst) : "v"(src), "i"(64 - j) : "scc");
     return dst;
 }
 
@@ -118,8 +118,8 @@ struct RegKkt {
                     const double dk = bcast_lane(p[t], k);
                     const double col = (ln > k) ? p[t] : 0.0;   // unscaled column; 0 keeps finished lanes untouched
                     const double l = col / dk;
-                    if (ln == k) d = dk;
-                    if (ln > k) a[k] = l;
+                    d = (ln == k) ? dk : d;
+                    a[k] = (ln > k) ? l : a[k];
                     stA[t * NP + ln] = -col;
                     stB[t * NP + ln] = l;
 #pragma unroll
@@ -198,9 +198,13 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
     const int r = isC ? ln - NN : 0;
 
     // per-lane problem data
-    const double hv = isP ? h[ln] : 0.0;
-    const double lo = isP ? xlb[ln] : (isC ? Alb[r] : 0.0);
-    const double hi = isP ? xub[ln] : (isC ? Aub[r] : 0.0);
+    // NOTE: lane-predicated code in this function is written branch-free (clamped unconditional loads + selects):
+    // hipcc (ROCm 7.2) may place VGPR spills inside the partial-EXEC "Flow" blocks of a divergent if/else, which loses the
+    // inactive lanes' copies of values that are live across the branch.
+    const int lp = isP ? ln : 0;                 // clamped primal index
+    const double hv = isP ? h[lp] : 0.0;
+    const double lo = isP ? xlb[lp] : (isC ? Alb[r] : 0.0);
+    const double hi = isP ? xub[lp] : (isC ? Aub[r] : 0.0);
     const int type = classify_bounds(lo, hi);
 
     // row `lane` of [H ; A] is read with unconditional, clamped addresses: base + j*stride
@@ -210,13 +214,15 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
 
     // state: xv = x (primal lanes) / z (constraint lanes); yv = y_box / y_a; qv = q (primal lanes)
     double xv = 0.0, yv = 0.0, qv = 0.0;
-    if (isP) { xv = x0 ? x0[ln] : 0.0; qv = xv; yv = y0 ? y0[MM + ln] : 0.0; }
-    if (isC) yv = y0 ? y0[r] : 0.0;
+    {
+        const double x0v = x0 ? x0[lp] : 0.0, ybv = y0 ? y0[MM + lp] : 0.0, yav = y0 ? y0[r] : 0.0;
+        xv = isP ? x0v : 0.0; qv = xv; yv = isP ? ybv : (isC ? yav : 0.0);
+    }
     if (x0) {  // z = A * x_guess
         double acc = 0.0;
 #pragma unroll
         for (int j = 0; j < NN; ++j) acc += rowp[(size_t)j * rstride] * bcast_lane(xv, j);
-        if (isC) xv = acc;
+        xv = isC ? acc : xv;
     }
 
     double rho = s.rho;
@@ -224,7 +230,10 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
     double rhov = rho_of(type, rho);
     double rhoinv = 1.0 / rhov;
     double kdiag;
-    if (isP) { kdiag = H[(size_t)ln * NN + ln]; kdiag += s.sigma; kdiag += rhov; } else { kdiag = -rhoinv; }
+    {
+        double kd = H[(size_t)lp * NN + lp]; kd += s.sigma; kd += rhov;
+        kdiag = isP ? kd : -rhoinv;
+    }
 
     RegKkt<N> K;
     int status = PMPC_QP_UNSOLVED;
@@ -248,27 +257,24 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
         bool refactor = false;
         for (; iter <= s.max_iter; ++iter) {
             const double zprev = xv;  // meaningful on constraint lanes
-            double rhs = 0.0;
-            if (isP) rhs = ((s.sigma * xv - hv) + rhov * qv) - yv;
-            if (isC) rhs = xv - rhoinv * yv;
+            const double rhsP = ((s.sigma * xv - hv) + rhov * qv) - yv;
+            const double rhsC = xv - rhoinv * yv;
+            const double rhs = isP ? rhsP : (isC ? rhsC : 0.0);
             const double sol = K.solve(rhs, ln);
-            if (isC) {
-                const double zt = zprev + rhoinv * (sol - yv);
-                double zz = alpha * zt;
-                zz += (1 - alpha) * zprev + rhoinv * yv;
-                zz = fmin(fmax(zz, lo), hi);
-                xv = zz;
-                yv += rhov * ((alpha * zt + (1 - alpha) * zprev) - zz);
-            }
-            if (isP) {
-                double xx = alpha * sol;
-                xx += (1 - alpha) * xx;  // quirk Q1
-                xv = xx;
-                double qq = xx + rhoinv * yv;
-                qq = fmin(fmax(qq, lo), hi);
-                qv = qq;
-                yv += rhov * (xx - qq);
-            }
+            // both role updates are evaluated on every lane and selected (branch-free)
+            const double zt = zprev + rhoinv * (sol - yv);
+            double zz = alpha * zt;
+            zz += (1 - alpha) * zprev + rhoinv * yv;
+            zz = fmin(fmax(zz, lo), hi);
+            const double yC = yv + rhov * ((alpha * zt + (1 - alpha) * zprev) - zz);
+            double xx = alpha * sol;
+            xx += (1 - alpha) * xx;  // quirk Q1
+            double qq = xx + rhoinv * yv;
+            qq = fmin(fmax(qq, lo), hi);
+            const double yP = yv + rhov * (xx - qq);
+            xv = isP ? xx : (isC ? zz : xv);
+            qv = isP ? qq : qv;
+            yv = isP ? yP : (isC ? yC : yv);
             const bool check = (s.check_termination != 0 && iter % s.check_termination == 0);
             const bool adapt = (s.adaptive_rho && iter % s.adaptive_rho_interval == 0);
             if (check || adapt) {  // residuals_update, box_admm.hpp:398-415
@@ -320,7 +326,7 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
                     rhov = rho_of(type, rho);
                     rhoinv = 1.0 / rhov;
                     ++rho_updates;
-                    if (isP) kdiag += (rhov - prev); else kdiag = -rhoinv;   // update_kkt_rho, box_admm.hpp:448-452
+                    kdiag = isP ? (kdiag + (rhov - prev)) : -rhoinv;   // update_kkt_rho, box_admm.hpp:448-452
                     refactor = true;
                     ++iter;
                     break;

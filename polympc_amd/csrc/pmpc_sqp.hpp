@@ -40,6 +40,8 @@ struct SqpDevice {
     Ocp<Model>& ocp;
     SqpLds& v;
     QpLds& qw;
+    double* lsbuf = nullptr;   // LDS scratch of the side-by-side line search (aliases the MFMA staging, free outside the QP)
+    bool cb_valid = false;     // v.cb holds the constraint values of the CURRENT iterate (set by the line search)
     double* tr = nullptr;  // LDS transpose scratch of the register-resident QP (aliases the per-node AD staging, dead during the QP)
     double* Hw;  // n x n, HBM workspace
     double* Aw;  // m x n, HBM workspace
@@ -69,7 +71,7 @@ struct SqpDevice {
     }
     // max_constraints_violation_impl :448-474
     __device__ double max_constraints_violation(const double* xx) {
-        ocp.constraints(xx, v.cb);
+        if (!cb_valid) ocp.constraints(xx, v.cb);   // otherwise the accepted line-search candidate already evaluated them at this point
         const int ln = lane_id();
         double c = 0.0, a = -INFINITY, b = -INFINITY, e = -INFINITY, f = -INFINITY;
         for (int i = ln; i < me; i += WAVE) c = fmax(c, fabs(v.cb[i]));
@@ -82,8 +84,8 @@ struct SqpDevice {
         return c;
     }
 
-    // step_size_selection_impl :380-419 ; p = QP primal step in qw.x
-    __device__ double step_size_selection() {
+    // step_size_selection_impl :380-419 ; p = QP primal step in qw.x  (one trial point at a time)
+    __device__ double step_size_selection_serial() {
         const double* p = qw.x;
         const int ln = lane_id();
         const double constr_l1 = constraints_violation(v.x);
@@ -92,16 +94,140 @@ struct SqpDevice {
         const double phi_l1 = cost_1 + mu * constr_l1;
         const double Dp_phi_l1 = seq_dot(v.h, p, n) - mu * constr_l1;
         double alpha = 1.0;
+        cb_valid = false;
         for (int i = 1; i < ss.line_search_max_iter; ++i) {
             for (int j = ln; j < n; j += WAVE) { double t = alpha * p[j]; t += v.x[j]; v.xs[j] = t; }
             wsync();
             const double cost_step = ocp.cost(v.xs);
             cost_log = cost_step;
             const double phi_step = cost_step + mu * constraints_violation(v.xs);
-            if (__builtin_amdgcn_readfirstlane((int)(phi_step <= (phi_l1 + alpha * ss.eta * Dp_phi_l1)))) return alpha;
+            if (__builtin_amdgcn_readfirstlane((int)(phi_step <= (phi_l1 + alpha * ss.eta * Dp_phi_l1)))) { cb_valid = true; return alpha; }
             alpha = ss.tau * alpha;
         }
         return alpha;
+    }
+
+    // The same line search with the trial points evaluated SIDE BY SIDE: a collocation grid has only NN nodes, so the
+    // 64 lanes hold G = 64/NN candidate points at once — the current iterate (alpha = 0) and the next G-1 backtracking
+    // trials alpha = 1, tau, tau^2, ... Each candidate goes through exactly the arithmetic of cost() / equalities() /
+    // constraints_violation_impl; the acceptance test then walks the candidates in the reference's order, so the chosen
+    // alpha and the logged cost are those of the sequential loop. The accepted candidate's constraint values are kept
+    // for the termination test (x + alpha*p is the same floating-point vector).
+    __device__ double step_size_selection() {
+        const int NNo = ocp.dm.NN;
+        const int G = WAVE / NNo;
+        if (G < 2 || lsbuf == nullptr || ss.rho < 0.0) return step_size_selection_serial();   // (sqp rho is unused by the reference; negative = debug switch)
+        constexpr int NX = Model::NX, NU = Model::NU, NP = Model::NP, NG = Model::NG;
+        const double* p = qw.x;
+        const int ln = lane_id();
+        const int P = ocp.P, S = ocp.S, VARX = ocp.dm.VARX, VARU = ocp.dm.VARU;
+        double* cand_c = lsbuf;                    // [G][m]
+        double* cand_L = cand_c + G * m;           // [G][NN]
+        double* cand_viol = cand_L + G * NNo;      // [G]
+        double* cand_cost = cand_viol + G;         // [G]
+        double* cand_alpha = cand_cost + G;        // [G]
+        const double mu = lds_inf_norm(v.lam_k, m + n);
+        const double gp = seq_dot(v.h, p, n);
+        double phi_l1 = 0.0, Dp_phi_l1 = 0.0;
+        double alpha = 1.0;      // alpha of the next trial to be evaluated
+        int trial = 1;           // index i of that trial in the reference loop (1 .. ls_max-1)
+        bool first = true;
+        cb_valid = false;
+        while (true) {
+            const int base = first ? 1 : 0;                            // candidate 0 of the first pass is the current iterate
+            int ntr = ss.line_search_max_iter - trial;                 // trials still allowed
+            if (ntr > G - base) ntr = G - base;
+            if (ntr < 0) ntr = 0;
+            const int ncand = base + ntr;
+            {   // alpha of every candidate of this pass (the reference's running product alpha = tau * alpha)
+                double al = alpha;
+                for (int g = 0; g < ncand; ++g) {
+                    if (first && g == 0) { if (ln == 0) cand_alpha[0] = 0.0; continue; }
+                    if (ln == 0) cand_alpha[g] = al;
+                    al = ss.tau * al;
+                }
+            }
+            wsync();
+            const int g = ln / NNo, k = ln - g * NNo;
+            if (g < ncand) {
+                const bool is_base = first && g == 0;
+                const double ag = cand_alpha[g];
+                auto xat = [&](int idx) -> double { if (is_base) return v.x[idx]; double t = ag * p[idx]; t += v.x[idx]; return t; };
+                double xk[NX > 0 ? NX : 1], uk[NU > 0 ? NU : 1], pk[NP > 0 ? NP : 1], f[NX > 0 ? NX : 1];
+                for (int q = 0; q < NX; ++q) { xk[q] = xat(k * NX + q); f[q] = 0.0; }
+                for (int q = 0; q < NU; ++q) uk[q] = xat(VARX + k * NU + q);
+                for (int q = 0; q < NP; ++q) pk[q] = xat(VARX + VARU + q);
+                const double tk = ocp.s.tn[k];
+                ocp.model.template dynamics_impl<double>(cref<double>(xk), cref<double>(uk), cref<double>(pk), cref<double>(ocp.d), tk, vref<double>(f));
+                int seg, row; ocp.seg_row(k, seg, row);
+                for (int q = 0; q < NX; ++q) {
+                    double acc = 0.0;
+                    for (int j = 0; j <= P; ++j) acc += ocp.s.D[row + j * (P + 1)] * xat((seg * P + j) * NX + q);
+                    double cv = acc;
+                    cv -= ocp.ts * f[q];
+                    cand_c[g * m + k * NX + q] = cv;
+                }
+                if (NG > 0) {
+                    double gg[NG > 0 ? NG : 1];
+                    for (int q = 0; q < NG; ++q) gg[q] = 0.0;
+                    ocp.model.template inequality_constraints_impl<double>(cref<double>(xk), cref<double>(uk), cref<double>(pk), cref<double>(ocp.d), tk, vref<double>(gg));
+                    for (int q = 0; q < NG; ++q) cand_c[g * m + me + k * NG + q] = gg[q];
+                }
+                double L = 0.0;
+                ocp.model.template lagrange_term_impl<double>(cref<double>(xk), cref<double>(uk), cref<double>(pk), cref<double>(ocp.d), tk, L);
+                cand_L[g * NNo + k] = L;
+            }
+            wsync();
+            if (ln < ncand) {   // one lane per candidate: the scalar sums, in the reference's association order
+                const int gc = ln;
+                const bool is_base = first && gc == 0;
+                const double ag = cand_alpha[gc];
+                auto xat = [&](int idx) -> double { if (is_base) return v.x[idx]; double t = ag * p[idx]; t += v.x[idx]; return t; };
+                double cl1 = DBL_EPS, sacc = 0.0;
+                for (int i = 0; i < me; ++i) sacc += fabs(cand_c[gc * m + i]);
+                cl1 += sacc;
+                sacc = 0.0; for (int i = 0; i < mi; ++i) sacc += fmax(v.lbg[i] - cand_c[gc * m + me + i], 0.0); cl1 += sacc;
+                sacc = 0.0; for (int i = 0; i < mi; ++i) sacc += fmax(cand_c[gc * m + me + i] - v.ubg[i], 0.0); cl1 += sacc;
+                sacc = 0.0; for (int i = 0; i < n; ++i) sacc += fmax(v.lbx[i] - xat(i), 0.0); cl1 += sacc;
+                sacc = 0.0; for (int i = 0; i < n; ++i) sacc += fmax(xat(i) - v.ubx[i], 0.0); cl1 += sacc;
+                cand_viol[gc] = cl1;
+                double c = 0.0;
+                for (int sg = 0; sg < S; ++sg)
+                    for (int kk = 0; kk <= P; ++kk) c += ocp.ts * ocp.s.w[kk] * cand_L[gc * NNo + sg * P + kk];
+                double x0[NX > 0 ? NX : 1], u0[NU > 0 ? NU : 1], p0[NP > 0 ? NP : 1];
+                for (int q = 0; q < NX; ++q) x0[q] = xat(q);
+                for (int q = 0; q < NU; ++q) u0[q] = xat(VARX + q);
+                for (int q = 0; q < NP; ++q) p0[q] = xat(VARX + VARU + q);
+                double M = 0.0;
+                ocp.model.template mayer_term_impl<double>(cref<double>(x0), cref<double>(u0), cref<double>(p0), cref<double>(ocp.d), ocp.s.tn[0], M);
+                c += M;
+                cand_cost[gc] = c;
+            }
+            wsync();
+            if (first) {
+                const double constr_l1 = cand_viol[0];
+                phi_l1 = cand_cost[0] + mu * constr_l1;
+                Dp_phi_l1 = gp - mu * constr_l1;
+            }
+            int accepted = -1;
+            for (int gc = base; gc < ncand; ++gc) {   // the reference's sequential acceptance order
+                const double ag = cand_alpha[gc];
+                const double cost_step = cand_cost[gc];
+                cost_log = cost_step;
+                const double phi_step = cost_step + mu * cand_viol[gc];
+                if (__builtin_amdgcn_readfirstlane((int)(phi_step <= (phi_l1 + ag * ss.eta * Dp_phi_l1)))) { accepted = gc; alpha = ag; break; }
+                alpha = ss.tau * ag;
+                ++trial;
+            }
+            if (accepted >= 0) {
+                for (int i = ln; i < m; i += WAVE) v.cb[i] = cand_c[accepted * m + i];   // constraint values at x + alpha*p for the termination test
+                cb_valid = true;
+                wsync();
+                return alpha;
+            }
+            first = false;
+            if (trial >= ss.line_search_max_iter) return alpha;
+        }
     }
 
     // lag_grad = J^T lam[0:m] + cost_grad + lam_box  (continuous_ocp.hpp:2112-2114)

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(64) void qp_boxadmm_kernel(int B, int n, int m, con
     for (int i = ln; i < m; i += WAVE) { albL[i] = Alb[(size_t)b * m + i]; aubL[i] = Aub[(size_t)b * m + i]; }
     wsync();
     pmpc_qp_info qi;
-    boxadmm_solve(w, n, m, H + (size_t)b * n * n, hL, A + (size_t)b * m * n, albL, aubL, xlbL, xubL,
+    boxadmm_solve(w, n, m, H + (size_t)b * n * n, n, hL, A + (size_t)b * m * n, m, albL, aubL, xlbL, xubL,
                   x0 ? x0 + (size_t)b * n : nullptr, y0 ? y0 + (size_t)b * (n + m) : nullptr, s, qi);
     for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = w.x[i];
     for (int i = ln; i < n + m; i += WAVE) y[(size_t)b * (n + m) + i] = w.y[i];

@@ -16,7 +16,7 @@ extern "C" int pmpc_internal_sqp_slice(pmpc_context* ctx);   // SQP iterations p
 namespace pmpc {
 using ::pmpc_status;
 
-template <class Model, int NN = 0, int MM = 0>
+template <class Model, int NN = 0, int MM = 0, bool PROF = false>
 __global__ __launch_bounds__(64, (NN > 0 ? 2 : 1)) void sqp_kernel(Model model, const ChebData* __restrict__ cd, int B,
                                                  const double* __restrict__ x_guess, const double* __restrict__ lam_guess,
                                                  const double* __restrict__ d, const double* __restrict__ lbx,
@@ -61,7 +61,10 @@ __global__ __launch_bounds__(64, (NN > 0 ? 2 : 1)) void sqp_kernel(Model model, 
         v.ubg[i] = ubg ? ubg[(size_t)b * mi + i] : INFINITY;
     }
     wsync();
-    SqpDevice<Model, NN, MM> sqp(ocp, v, qw, Hws + (size_t)b * n * n, Aws + (size_t)b * m * n, ss, qs);
+    // stacked workspace K0 = [H ; J] ((n+m) x n, column-major, leading dimension n+m): lane i reads row i of K0 with ONE stride
+    double* K0 = Hws + (size_t)b * (size_t)(n + m) * n;
+    (void)Aws;
+    SqpDevice<Model, NN, MM, PROF> sqp(ocp, v, qw, K0, K0 + n, ss, qs);
     sqp.tr = ocp.s.fval;   // first per-node staging array: everything from here on is dead while the QP runs
     {   // side-by-side line search: G candidates x (m constraint values + NN Lagrange values) + 3 scalars each, in the same region
         const int G = WAVE / ocp.dm.NN;
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(64, (NN > 0 ? 2 : 1)) void sqp_kernel(Model model, 
     for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = v.x[i];
     for (int i = ln; i < m + n; i += WAVE) lam[(size_t)b * (m + n) + i] = v.lam[i];
     if (ln == 0) info[b] = si;
-    if (phase_cycles && ln == 0) for (int i = 0; i < 8; ++i) atomicAdd(&phase_cycles[i], (unsigned long long)sqp.cyc[i]);
+    if constexpr (PROF) { if (phase_cycles && ln == 0) for (int i = 0; i < 8; ++i) atomicAdd(&phase_cycles[i], (unsigned long long)sqp.cyc[i]); }
 }
 // mode 0: KKT factor in LDS; 1: register-resident QP (n+m <= 64); 2: KKT factor in HBM (large instances)
 template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode) {
@@ -118,8 +121,8 @@ __global__ __launch_bounds__(64) void linearise_kernel(Model model, const ChebDa
     ocp.stage_second_order(xL, lamL);
     double* J = jac + (size_t)b * m * n;
     double* Hh = lag_hess + (size_t)b * n * n;
-    const double cst = ocp.assemble_first_order(cL, J, gL);
-    ocp.assemble_hessian(Hh);
+    const double cst = ocp.assemble_first_order(cL, J, gL, m);
+    ocp.assemble_hessian(Hh, n);
     for (int j = ln; j < n; j += WAVE) {
         double a = 0.0;
         for (int i = 0; i < m; ++i) a += J[(size_t)j * m + i] * lamL[i];
@@ -155,10 +158,11 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
         if (P * S + 1 != NNODES) return false;
         const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, 1);
         if (ldsr > lds_limit) return false;
-        if (hipFuncSetAttribute((const void*)sqp_kernel<Model, NN_, MM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
+        auto kern = phase ? sqp_kernel<Model, NN_, MM_, true> : sqp_kernel<Model, NN_, MM_, false>;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
         const int slice = (slice_state && slice_iters > 0) ? slice_iters : ss->max_iter;
         for (int it = 0; it < ss->max_iter; it += slice)
-            hipLaunchKernelGGL((sqp_kernel<Model, NN_, MM_>), dim3(B), dim3(WAVE), ldsr, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
+            hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), ldsr, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
                                *ss, *qs, Hws, Aws, x, lam, info, phase, (double*)nullptr, it, it + slice, slice_state, (unsigned)(ldsr / sizeof(double)));
         *st = (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
         return true;

@@ -243,10 +243,11 @@ struct Ocp {
 
     // ---- assemble c (m), Jacobian J (m x n column-major in HBM), cost value and cost gradient from the first-order stage
     // equalities_linearised :797-878, _inequalities_linearised_dense :546-575, cost_gradient :1210-1249
-    __device__ double assemble_first_order(double* c, double* __restrict__ J, double* cost_grad) {
+    // J(r, col) = J[r + col * ldj] (ldj = m for a plain m x n Jacobian; n+m when J is the lower block of the stacked [H;J] workspace)
+    __device__ double assemble_first_order(double* c, double* __restrict__ J, double* cost_grad, int ldj) {
         const int ln = lane_id();
         const int n = dm.n, m = dm.m;
-        for (int e = ln; e < m * n; e += WAVE) J[e] = 0.0;
+        for (int e = ln; e < m * n; e += WAVE) J[(e % m) + (size_t)(e / m) * ldj] = 0.0;
         for (int i = ln; i < n; i += WAVE) cost_grad[i] = 0.0;
         __threadfence_block();
         wsync();
@@ -255,9 +256,9 @@ struct Ocp {
             for (int q = 0; q < NX; ++q) {
                 const int r = k * NX + q;
                 if (k < dm.NN - 1) {
-                    for (int j = 0; j <= P; ++j) J[r + (size_t)((seg * P + j) * NX + q) * m] = s.D[row + j * (P + 1)] * 1.0;
+                    for (int j = 0; j <= P; ++j) J[r + (size_t)((seg * P + j) * NX + q) * ldj] = s.D[row + j * (P + 1)] * 1.0;
                 } else {  // last node row = -reverse(first block row) (:845-846)
-                    for (int j = 0; j <= P; ++j) J[r + (size_t)(dm.VARX - NX * (P + 1) + j * NX + q) * m] = -s.D[0 + (P - j) * (P + 1)];
+                    for (int j = 0; j <= P; ++j) J[r + (size_t)(dm.VARX - NX * (P + 1) + j * NX + q) * ldj] = -s.D[0 + (P - j) * (P + 1)];
                 }
                 double cv = -ts * s.fval[r];
                 cv += s.DX[r];
@@ -268,13 +269,13 @@ struct Ocp {
                 for (int i = 0; i < NDER; ++i) {
                     double v = (i == q) ? dself : 0.0;
                     v -= ts * s.fjac[r * NDER + i];
-                    J[r + (size_t)dm.gidx(k, i) * m] = v;
+                    J[r + (size_t)dm.gidx(k, i) * ldj] = v;
                 }
             }
             for (int q = 0; q < NG; ++q) {
                 const int r = dm.me + k * NG + q;
                 c[r] = s.gval[k * NG + q];
-                for (int i = 0; i < NDER; ++i) J[r + (size_t)dm.gidx(k, i) * m] = s.gjac[(k * NG + q) * NDER + i];
+                for (int i = 0; i < NDER; ++i) J[r + (size_t)dm.gidx(k, i) * ldj] = s.gjac[(k * NG + q) * NDER + i];
             }
             // cost gradient, x/u parts: contributions in the reference's loop order (segment s-1 as node P, then segment s as node 0)
             double gacc[NX + NU > 0 ? NX + NU : 1];
@@ -305,10 +306,10 @@ struct Ocp {
 
     // ---- assemble the Lagrangian Hessian H (n x n column-major in HBM) from the second-order stage
     // cost_gradient_hessian :1256-1367 (+ quirk Q4) and the lam-weighted blocks of :2128-2173
-    __device__ void assemble_hessian(double* __restrict__ H) {
+    __device__ void assemble_hessian(double* __restrict__ H, int ldh) {
         const int ln = lane_id();
         const int n = dm.n;
-        for (int e = ln; e < n * n; e += WAVE) H[e] = 0.0;
+        for (int e = ln; e < n * n; e += WAVE) H[(e % n) + (size_t)(e / n) * ldh] = 0.0;
         __threadfence_block();
         wsync();
         // blocks that do not involve the (p,p) corner are private to their node
@@ -321,7 +322,7 @@ struct Ocp {
                     if (k < dm.NN - 1) a += (ts * s.w[k % P]) * s.Lhes[(k * NDER + i) * NDER + r];
                     if (k == 0) a += s.Mhes[i * NDER + r];
                     a += s.dhes[(k * NDER + i) * NDER + r];
-                    H[dm.gidx(k, r) + (size_t)dm.gidx(k, i) * n] = a;
+                    H[dm.gidx(k, r) + (size_t)dm.gidx(k, i) * ldh] = a;
                 }
         }
         if constexpr (NP > 0) {
@@ -334,13 +335,13 @@ struct Ocp {
                 for (int sg = 0; sg < S; ++sg)
                     for (int k = 0; k <= P; ++k) a += (ts * s.w[k]) * s.Lhes[((sg * P + k) * NDER + NX + NU + i) * NDER + NX + NU + r];
                 for (int k = 0; k < dm.NN; ++k) a += s.dhes[(k * NDER + NX + NU + i) * NDER + NX + NU + r];
-                H[(n - NP + r) + (size_t)(n - NP + i) * n] = a;
+                H[(n - NP + r) + (size_t)(n - NP + i) * ldh] = a;
             }
             __threadfence_block();
             wsync();
             for (int e = ln; e < NP * NP; e += WAVE) {
                 const int a_ = e % NP, b_ = e / NP;
-                H[(n - NP + a_) + (size_t)b_ * n] += s.Mhes[b_ * NDER + (NDER - NP + a_)];
+                H[(n - NP + a_) + (size_t)b_ * ldh] += s.Mhes[b_ * NDER + (NDER - NP + a_)];
             }
         }
         __threadfence_block();

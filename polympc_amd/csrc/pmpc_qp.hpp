@@ -98,12 +98,12 @@ struct QpLds {
 };
 
 // K (lower triangle) <- [H + diag(kdiag[0:n]) ; A, diag(kdiag[n:])]  (construct_kkt_matrix, box_admm.hpp:209-223)
-__device__ inline void kkt_build(const QpLds& w, int n, int m, const double* __restrict__ H, const double* __restrict__ A) {
+__device__ inline void kkt_build(const QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ A, int lda) {
     const int ln = lane_id();
     for (int j = 0; j < n; ++j) {
         const int o = w.off(j);
-        for (int i = j + ln; i < n; i += WAVE) w.K[o + i] = (i == j) ? w.kdiag[i] : H[(size_t)j * n + i];
-        for (int r = ln; r < m; r += WAVE) w.K[o + n + r] = A[(size_t)j * m + r];
+        for (int i = j + ln; i < n; i += WAVE) w.K[o + i] = (i == j) ? w.kdiag[i] : H[(size_t)j * ldh + i];
+        for (int r = ln; r < m; r += WAVE) w.K[o + n + r] = A[(size_t)j * lda + r];
     }
     for (int j = 0; j < m; ++j) {
         const int o = w.off(n + j);
@@ -173,21 +173,21 @@ __device__ inline void kkt_solve(const QpLds& w, int N, double* v) {
 struct QpResidualState { double max_Ax_z_norm, max_Hx_ATy_h_norm, res_prim, res_dual; };
 
 // residuals_update, box_admm.hpp:398-415 (H, A streamed from global memory, coalesced down the columns)
-__device__ inline void qp_residuals(const QpLds& w, int n, int m, const double* __restrict__ H, const double* __restrict__ h,
-                                    const double* __restrict__ A, QpResidualState& r) {
+__device__ inline void qp_residuals(const QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ h,
+                                    const double* __restrict__ A, int lda, QpResidualState& r) {
     const int ln = lane_id();
     double nAx = 0, nz = 0, nx = 0, rp = 0;
     for (int i = ln; i < m; i += WAVE) {
         double a = 0.0;
-        for (int j = 0; j < n; ++j) a += A[(size_t)j * m + i] * w.x[j];
+        for (int j = 0; j < n; ++j) a += A[(size_t)j * lda + i] * w.x[j];
         nAx = fmax(nAx, fabs(a)); nz = fmax(nz, fabs(w.z[i])); rp = fmax(rp, fabs(a - w.z[i]));
     }
     double nHx = 0, nATy = 0, nh = 0, nyb = 0, rq = 0, rd = 0;
     for (int i = ln; i < n; i += WAVE) {
         double a = 0.0;
-        for (int j = 0; j < n; ++j) a += H[(size_t)j * n + i] * w.x[j];
+        for (int j = 0; j < n; ++j) a += H[(size_t)j * ldh + i] * w.x[j];
         double b = 0.0;
-        for (int k = 0; k < m; ++k) b += A[(size_t)i * m + k] * w.y[k];
+        for (int k = 0; k < m; ++k) b += A[(size_t)i * lda + k] * w.y[k];
         nx = fmax(nx, fabs(w.x[i])); nHx = fmax(nHx, fabs(a)); nATy = fmax(nATy, fabs(b));
         nh = fmax(nh, fabs(h[i])); nyb = fmax(nyb, fabs(w.y[m + i]));
         rq = fmax(rq, fabs(w.x[i] - w.q[i]));
@@ -209,8 +209,9 @@ __device__ inline void rho_vec_update(const QpLds& w, int n, int m, const double
 }
 
 // boxADMM::solve_impl (box_admm.hpp:88-205). Result in w.x (n) and w.y (m+n). h/Alb/Aub/xlb/xub may live in LDS or HBM.
-__device__ inline void boxadmm_solve(QpLds& w, int n, int m, const double* __restrict__ H, const double* h,
-                                     const double* __restrict__ A, const double* Alb, const double* Aub, const double* xlb,
+// H(i,j) = H[j*ldh + i], A(r,j) = A[j*lda + r]  (ldh = n, lda = m for plain column-major inputs)
+__device__ inline void boxadmm_solve(QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* h,
+                                     const double* __restrict__ A, int lda, const double* Alb, const double* Aub, const double* xlb,
                                      const double* xub, const double* x0, const double* y0, const pmpc_qp_settings& s,
                                      pmpc_qp_info& info) {
     const int ln = lane_id();
@@ -221,7 +222,7 @@ __device__ inline void boxadmm_solve(QpLds& w, int n, int m, const double* __res
     wsync();
     for (int i = ln; i < m; i += WAVE) {
         double a = 0.0;
-        if (x0) for (int j = 0; j < n; ++j) a += A[(size_t)j * m + i] * w.x[j];
+        if (x0) for (int j = 0; j < n; ++j) a += A[(size_t)j * lda + i] * w.x[j];
         w.z[i] = a;
     }
     double rho = s.rho;
@@ -229,10 +230,10 @@ __device__ inline void boxadmm_solve(QpLds& w, int n, int m, const double* __res
     rho_vec_update(w, n, m, Alb, Aub, xlb, xub, rho);
     wsync();
     // K diagonal: (H_ii + sigma) + rho_box ; -1/rho   (:214-222)
-    for (int i = ln; i < n; i += WAVE) { double dgl = H[(size_t)i * n + i]; dgl += s.sigma; dgl += w.rhob[i]; w.kdiag[i] = dgl; }
+    for (int i = ln; i < n; i += WAVE) { double dgl = H[(size_t)i * ldh + i]; dgl += s.sigma; dgl += w.rhob[i]; w.kdiag[i] = dgl; }
     for (int i = ln; i < m; i += WAVE) w.kdiag[n + i] = -w.rhoinv[i];
     wsync();
-    kkt_build(w, n, m, H, A);
+    kkt_build(w, n, m, H, ldh, A, lda);
     kkt_factor(w, N);
 
     int status = PMPC_QP_UNSOLVED;
@@ -266,12 +267,12 @@ __device__ inline void boxadmm_solve(QpLds& w, int n, int m, const double* __res
         wsync();
         const bool check = (s.check_termination != 0 && iter % s.check_termination == 0);
         if (check) {
-            qp_residuals(w, n, m, H, h, A, rs);
+            qp_residuals(w, n, m, H, ldh, h, A, lda, rs);
             const double ep = s.eps_abs + s.eps_rel * rs.max_Ax_z_norm, ed = s.eps_abs + s.eps_rel * rs.max_Hx_ATy_h_norm;
             if (rs.res_prim <= ep && rs.res_dual <= ed) { status = PMPC_QP_SOLVED; break; }
         }
         if (s.adaptive_rho && iter % s.adaptive_rho_interval == 0) {
-            if (!check) qp_residuals(w, n, m, H, h, A, rs);
+            if (!check) qp_residuals(w, n, m, H, ldh, h, A, lda, rs);
             const double rpn = rs.res_prim / (rs.max_Ax_z_norm + DIV_BY_ZERO_REGUL);
             const double rdn = rs.res_dual / (rs.max_Hx_ATy_h_norm + DIV_BY_ZERO_REGUL);
             double new_rho = rho * sqrt(rpn / (rdn + DIV_BY_ZERO_REGUL));
@@ -288,7 +289,7 @@ __device__ inline void boxadmm_solve(QpLds& w, int n, int m, const double* __res
                 for (int i = ln; i < n; i += WAVE) w.kdiag[i] += (w.rhob[i] - w.t2[i]);
                 for (int i = ln; i < m; i += WAVE) w.kdiag[n + i] = -w.rhoinv[i];
                 wsync();
-                kkt_build(w, n, m, H, A);
+                kkt_build(w, n, m, H, ldh, A, lda);
                 kkt_factor(w, N);
             }
         }

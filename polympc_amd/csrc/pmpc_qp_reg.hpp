@@ -45,6 +45,15 @@ __device__ __forceinline__ double mov_lanes_below(double dst, double src, int j)
 // One wavefront per workgroup: DS operations of a wave are executed in issue order, so a write followed by a read of the
 // same LDS address needs no s_waitcnt / s_barrier — only the compiler must not reorder them.
 __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+// scheduling fence: keeps the machine scheduler from hoisting dozens of v_readlane broadcasts (SGPR pairs) or LDS loads
+// across phase boundaries, which otherwise inflates the register demand far beyond the algorithm's live set
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
+// dst <- src on lanes [lo, hi) only (compile-time range, hi > lo)
+__device__ __forceinline__ double mov_lanes_range(double dst, double src, int lo, int hi) {
+    asm("s_bfm_b64 exec, %2, %3\n\tv_mov_b64 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(dst) : "v"(src), "i"(hi - lo), "i"(lo));
+    return dst;
+}
 
 template <int N>
 struct RegKkt {
@@ -68,7 +77,11 @@ struct RegKkt {
     // from two v_mfma_f64_16x16x4_f64 per tile, with the A (-col) and B (l) operand panels staged through 8 KB of LDS.
     // The next panel is pulled out of the tiles through the same staging buffer. The block loop is fully unrolled
     // (7 blocks for 56 rows) so that all register indices are compile-time constants.
-    __device__ __forceinline__ void factor(int ln_in, double* st) {
+    // kcol(j) returns K(lane, j) (only j <= lane matters); it is called 8 columns at a time, one group ahead of use, so the
+    // KKT rows never sit in registers next to the accumulator tiles.
+    // diag = K(lane, lane) (patched into the staging buffer by the 8 lanes of each column group).
+    template <class KCol>
+    __device__ __forceinline__ void factor(int ln_in, double* st, double diag, KCol kcol) {
         int ln = ln_in;
         asm volatile("" : "+v"(ln));   // keep the lane predicates below local to the factorisation (no hoisting into long-lived SGPR masks)
         double* stA = st;
@@ -79,11 +92,18 @@ struct RegKkt {
         for (int R = 0; R < NT; ++R)
 #pragma unroll
             for (int C = 0; C < NT; ++C) T[R][C] = d4{0.0, 0.0, 0.0, 0.0};
-        // row layout -> accumulator tiles, 8 columns at a time
+        // row layout -> accumulator tiles, 8 columns at a time (loads of the next group are in flight while this one is staged)
+        double cur[BK], nxt[BK];
+#pragma unroll
+        for (int t = 0; t < BK; ++t) cur[t] = (t < N) ? kcol(t) : 0.0;
 #pragma unroll
         for (int g = 0; g < NP / BK; ++g) {
 #pragma unroll
-            for (int t = 0; t < BK; ++t) stA[t * NP + ln] = (g * BK + t < N) ? a[(g * BK + t < N) ? g * BK + t : 0] : 0.0;
+            for (int t = 0; t < BK; ++t) nxt[t] = ((g + 1) * BK + t < N) ? kcol(((g + 1) * BK + t < N) ? (g + 1) * BK + t : 0) : 0.0;
+#pragma unroll
+            for (int t = 0; t < BK; ++t) stA[t * NP + ln] = cur[t];
+            lds_order();
+            if ((ln >> 3) == g) stA[(ln & 7) * NP + ln] = diag;      // the diagonal entries of this column group
             lds_order();
             if ((lc >> 3) == (g % 2)) {
 #pragma unroll
@@ -92,6 +112,9 @@ struct RegKkt {
                     for (int r = 0; r < 4; ++r) T[R][g / 2][r] = stA[(lc & 7) * NP + 16 * R + lr + 4 * r];
             }
             lds_order();
+            sched_fence();
+#pragma unroll
+            for (int t = 0; t < BK; ++t) cur[t] = nxt[t];
         }
         d = 1.0;
 #pragma unroll
@@ -125,6 +148,7 @@ struct RegKkt {
 #pragma unroll
                     for (int u = t + 1; u < BK; ++u)
                         if (kb + u < N) p[u] = fma(-col, bcast_lane(l, kb + u), p[u]);
+                    sched_fence();
                 } else {
                     stA[t * NP + ln] = 0.0;
                     stB[t * NP + ln] = 0.0;
@@ -149,9 +173,11 @@ struct RegKkt {
 #pragma unroll
                         for (int C = 0; C <= R; ++C)
                             if (C >= Rmin) T[R][C] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[R], bv[C], T[R][C], 0, 0, 0);
+                    sched_fence();
                 }
             }
             lds_order();
+            sched_fence();
         }
         // transposed part, after the tiles are dead (keeps the register peak below the spill threshold): the row parts
         // a[k] = L(lane, k) are staged 8 columns at a time and lane i in that block picks up column i:  a[j] <- L(j, i), j > i
@@ -185,7 +211,9 @@ struct RegKkt {
 
 // boxADMM::solve_impl for compile-time (NN, MM); h/Alb/Aub/xlb/xub/x0/y0: LDS or HBM pointers; result -> out_x (NN), out_y (MM+NN)
 // tr: LDS staging of RegKkt<NN+MM>::TRI doubles.
-template <int NN, int MM>
+// STACKED: H and A are the upper / lower block of ONE (n+m) x n column-major array (leading dimension n+m, A = H + n):
+// every lane then reads row `lane` of that array with a compile-time stride, i.e. one base address + immediate offsets.
+template <int NN, int MM, bool STACKED = false>
 __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, const double* h, const double* __restrict__ A,
                                                   const double* Alb, const double* Aub, const double* xlb, const double* xub,
                                                   const double* x0, const double* y0, const pmpc_qp_settings& s, pmpc_qp_info& info,
@@ -208,9 +236,10 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
     const int type = classify_bounds(lo, hi);
 
     // row `lane` of [H ; A] is read with unconditional, clamped addresses: base + j*stride
-    const double* rowp = isP ? (H + ln) : (A + r);
-    const int rstride = isP ? NN : (isC ? MM : 0);
-    const double* colA = A + (size_t)(isP ? ln : 0) * MM;   // column `lane` of A (primal lanes), contiguous
+    constexpr int LDH = STACKED ? N : NN, LDA = STACKED ? N : MM;
+    const double* rowp = STACKED ? (H + (ln < N ? ln : 0)) : (isP ? (H + ln) : (A + r));
+    const int rstride = STACKED ? N : (isP ? NN : (isC ? MM : 0));
+    const double* colA = A + (size_t)lp * LDA;   // column `lane` of A (primal lanes), contiguous
 
     // state: xv = x (primal lanes) / z (constraint lanes); yv = y_box / y_a; qv = q (primal lanes)
     double xv = 0.0, yv = 0.0, qv = 0.0;
@@ -231,7 +260,7 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
     double rhoinv = 1.0 / rhov;
     double kdiag;
     {
-        double kd = H[(size_t)lp * NN + lp]; kd += s.sigma; kd += rhov;
+        double kd = H[(size_t)lp * LDH + lp]; kd += s.sigma; kd += rhov;
         kdiag = isP ? kd : -rhoinv;
     }
 
@@ -246,12 +275,10 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
     bool running = true;
     while (running) {
         {   // construct_kkt_matrix + factorise_kkt_matrix
-            const long long f0 = clock64();
-#pragma unroll
-            for (int j = 0; j < NN; ++j) { const double v = rowp[(size_t)j * rstride]; K.a[j] = (ln == j) ? kdiag : v; }
-#pragma unroll
-            for (int j = NN; j < N; ++j) K.a[j] = (ln == j) ? kdiag : 0.0;
-            K.factor(ln, tr);
+            const long long f0 = dbg ? clock64() : 0;
+            K.factor(ln, tr, kdiag, [&](int j) -> double {   // row `lane` of [H ; A | 0] (construct_kkt_matrix, box_admm.hpp:209-223)
+                return (j < NN) ? rowp[(size_t)(j < NN ? j : 0) * rstride] : 0.0;
+            });
             if (dbg) dbg[0] += clock64() - f0;
         }
         bool refactor = false;
@@ -278,9 +305,9 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
             const bool check = (s.check_termination != 0 && iter % s.check_termination == 0);
             const bool adapt = (s.adaptive_rho && iter % s.adaptive_rho_interval == 0);
             if (check || adapt) {  // residuals_update, box_admm.hpp:398-415
-                const long long r0 = clock64();
+                const long long r0 = dbg ? clock64() : 0;
                 // loads in chunks of RC columns (independent, coalesced), each followed by its slice of the mat-vec chain
-                constexpr int RC = 12;
+                constexpr int RC = 8;
                 double acc = 0.0;      // lanes < n: (H x)_i ; lanes in [n, N): (A x)_r
 #pragma unroll
                 for (int j0 = 0; j0 < NN; j0 += RC) {
@@ -289,6 +316,7 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
                     for (int j = 0; j < RC; ++j) mrow[j] = (j0 + j < NN) ? rowp[(size_t)(j0 + j < NN ? j0 + j : 0) * rstride] : 0.0;
 #pragma unroll
                     for (int j = 0; j < RC; ++j) if (j0 + j < NN) acc += mrow[j] * bcast_lane(xv, j0 + j);
+                    sched_fence();
                 }
                 double aty = 0.0;      // lanes < n: (A^T y_a)_i
 #pragma unroll
@@ -298,6 +326,7 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
                     for (int k = 0; k < RC; ++k) mcol[k] = (k0 + k < MM) ? colA[(k0 + k < MM) ? k0 + k : 0] : 0.0;
 #pragma unroll
                     for (int k = 0; k < RC; ++k) if (k0 + k < MM) aty += mcol[k] * bcast_lane(yv, NN + k0 + k);
+                    sched_fence();
                 }
                 const double nAx = wave_max(isC ? fabs(acc) : 0.0), nz = wave_max(isC ? fabs(xv) : 0.0), nx = wave_max(isP ? fabs(xv) : 0.0);
                 const double rp = wave_max(isC ? fabs(acc - xv) : 0.0), rq = wave_max(isP ? fabs(xv - qv) : 0.0);

@@ -34,7 +34,8 @@ constexpr double DBL_EPS = 2.220446049250313e-16;
 constexpr int PMPC_SQP_IN_PROGRESS = 3;   // internal: the instance continues in the next iteration-slice launch
 
 // NN, MM > 0: compile-time QP size with NN+MM <= 64 -> register-resident QP (pmpc_qp_reg.hpp); 0 -> LDS-resident QP
-template <class Model, int NN = 0, int MM = 0>
+// PROF: accumulate per-phase shader-clock cycles (separate kernel instantiation; costs 16+ VGPRs, off by default)
+template <class Model, int NN = 0, int MM = 0, bool PROF = false>
 struct SqpDevice {
     using Dm = OcpDims<Model>;
     Ocp<Model>& ocp;
@@ -43,17 +44,20 @@ struct SqpDevice {
     double* lsbuf = nullptr;   // LDS scratch of the side-by-side line search (aliases the MFMA staging, free outside the QP)
     bool cb_valid = false;     // v.cb holds the constraint values of the CURRENT iterate (set by the line search)
     double* tr = nullptr;  // LDS transpose scratch of the register-resident QP (aliases the per-node AD staging, dead during the QP)
-    double* Hw;  // n x n, HBM workspace
-    double* Aw;  // m x n, HBM workspace
+    double* Hw;  // H(i,j) = Hw[j*ldw + i]  — upper block of the stacked (n+m) x n HBM workspace [H ; J]
+    double* Aw;  // J(r,j) = Aw[j*ldw + r]  — lower block (Aw = Hw + n)
+    int ldw;     // n + m
     const pmpc_sqp_settings& ss;
     const pmpc_qp_settings& qs;
     int n, m, me, mi;
     double cost_log = 0.0, primal_norm = 0.0, dual_norm = 0.0, max_violation = 0.0;
     int qp_iter_total = 0;
-    long long cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // shader-clock cycles: 0 linearise(+BFGS) 1 QP 2 line search 3 termination 4 total 5 BFGS 6 KKT build+factor 7 QP residuals
+    long long cyc[PROF ? 8 : 1] = {0};
+    __device__ __forceinline__ static long long now() { if constexpr (PROF) return clock64(); else return 0; }
+    __device__ __forceinline__ void acc(int i, long long dt) { if constexpr (PROF) cyc[i] += dt; }   // shader-clock cycles: 0 linearise(+BFGS) 1 QP 2 line search 3 termination 4 total 5 BFGS 6 KKT build+factor 7 QP residuals
 
     __device__ SqpDevice(Ocp<Model>& o, SqpLds& v_, QpLds& q_, double* H_, double* A_, const pmpc_sqp_settings& s, const pmpc_qp_settings& q)
-        : ocp(o), v(v_), qw(q_), Hw(H_), Aw(A_), ss(s), qs(q), n(o.dm.n), m(o.dm.m), me(o.dm.me), mi(o.dm.mi) {}
+        : ocp(o), v(v_), qw(q_), Hw(H_), Aw(A_), ldw(o.dm.n + o.dm.m), ss(s), qs(q), n(o.dm.n), m(o.dm.m), me(o.dm.me), mi(o.dm.mi) {}
 
     // constraints_violation_impl :423-444 (sequential sums, reference association order)
     __device__ double constraints_violation(const double* xx) {
@@ -236,7 +240,7 @@ struct SqpDevice {
             const int j = lane_id() < NN ? lane_id() : 0;
             double col[MM];
 #pragma unroll
-            for (int i = 0; i < MM; ++i) col[i] = Aw[(size_t)j * MM + i];
+            for (int i = 0; i < MM; ++i) col[i] = Aw[(size_t)j * (NN + MM) + i];
             double a = 0.0;
 #pragma unroll
             for (int i = 0; i < MM; ++i) a += col[i] * v.lam[i];
@@ -248,7 +252,7 @@ struct SqpDevice {
         }
         for (int j = lane_id(); j < n; j += WAVE) {
             double a = 0.0;
-            for (int i = 0; i < m; ++i) a += Aw[(size_t)j * m + i] * v.lam[i];
+            for (int i = 0; i < m; ++i) a += Aw[(size_t)j * ldw + i] * v.lam[i];
             a += v.h[j];
             a += v.lam[m + j];
             out[j] = a;
@@ -259,11 +263,11 @@ struct SqpDevice {
     // Gershgorin shift, dense_sparse_compare.cpp:109-122
     __device__ void regularise_gershgorin() {
         for (int i = lane_id(); i < n; i += WAVE) {
-            const double aii = Hw[(size_t)i * n + i];
+            const double aii = Hw[(size_t)i * ldw + i];
             double ri = 0.0;
-            for (int k = 0; k < n; ++k) ri += fabs(Hw[(size_t)i * n + k]);
+            for (int k = 0; k < n; ++k) ri += fabs(Hw[(size_t)i * ldw + k]);
             ri -= fabs(aii);
-            if (aii - ri <= 0) Hw[(size_t)i * n + i] = aii + ((ri - aii) + 0.01);
+            if (aii - ri <= 0) Hw[(size_t)i * ldw + i] = aii + ((ri - aii) + 0.01);
         }
         __threadfence_block();
         wsync();
@@ -273,8 +277,8 @@ struct SqpDevice {
     __device__ void linearisation() {
         ocp.stage_first_order(v.x);
         ocp.stage_second_order(v.x, v.lam);
-        ocp.assemble_first_order(v.al, Aw, v.h);
-        ocp.assemble_hessian(Hw);
+        ocp.assemble_first_order(v.al, Aw, v.h, ldw);
+        ocp.assemble_hessian(Hw, ldw);
         lagrangian_gradient(v.lg);
         if (ss.regularisation == 2) regularise_gershgorin();
     }
@@ -287,7 +291,7 @@ struct SqpDevice {
         double* Bs = v.t1; double* r = v.t2; double* y = v.t3;
         double brow[NN > 0 ? NN : 1];
 #pragma unroll
-        for (int j = 0; j < NN; ++j) brow[j] = Hw[(size_t)j * NN + i];
+        for (int j = 0; j < NN; ++j) brow[j] = Hw[(size_t)j * (NN + MM) + i];
         {
             double a = 0.0;
 #pragma unroll
@@ -318,7 +322,7 @@ struct SqpDevice {
         }
         if (ln < NN) {
 #pragma unroll
-            for (int j = 0; j < NN; ++j) Hw[(size_t)j * NN + i] = brow[j];
+            for (int j = 0; j < NN; ++j) Hw[(size_t)j * (NN + MM) + i] = brow[j];
         }
         __threadfence_block();
         wsync();
@@ -329,7 +333,7 @@ struct SqpDevice {
         double* Bs = v.t1; double* r = v.t2; double* y = v.t3;
         for (int i = ln; i < n; i += WAVE) {
             double a = 0.0;
-            for (int j = 0; j < n; ++j) a += Hw[(size_t)j * n + i] * v.step[j];
+            for (int j = 0; j < n; ++j) a += Hw[(size_t)j * ldw + i] * v.step[j];
             Bs[i] = a;
             y[i] = v.lgn[i] - v.lg[i];
         }
@@ -350,10 +354,10 @@ struct SqpDevice {
         for (int j = 0; j < n; ++j) {
             const double Bsj = Bs[j], rj = r[j];
             for (int i = ln; i < n; i += WAVE) {
-                double b = Hw[(size_t)j * n + i];
+                double b = Hw[(size_t)j * ldw + i];
                 b += (-Bs[i] * Bsj) / sBs;
                 b += (r[i] * rj) / sr;
-                Hw[(size_t)j * n + i] = b;
+                Hw[(size_t)j * ldw + i] = b;
             }
         }
         __threadfence_block();
@@ -364,11 +368,11 @@ struct SqpDevice {
     __device__ void update_linearisation() {
         if (ss.exact_hessian_every_iter) { linearisation(); return; }
         ocp.stage_first_order(v.x);
-        ocp.assemble_first_order(v.al, Aw, v.h);
+        ocp.assemble_first_order(v.al, Aw, v.h, ldw);
         lagrangian_gradient(v.lgn);
-        const long long b0 = clock64();
+        const long long b0 = now();
         bfgs_update();
-        cyc[5] += clock64() - b0;
+        acc(5, now() - b0);
         for (int i = lane_id(); i < n; i += WAVE) v.lg[i] = v.lgn[i];
         wsync();
     }
@@ -388,20 +392,20 @@ struct SqpDevice {
     // one SQP iteration after (update_)linearisation: QP, line search, step, norms  (:588-632 / :652-683)
     __device__ void qp_and_step() {
         const int ln = lane_id();
-        const long long q0 = clock64();
+        const long long q0 = now();
         form_qp_bounds();
         pmpc_qp_info qi;
         // 7-argument form: zero guesses (Q2)
-        if constexpr (NN > 0) { boxadmm_solve_reg<NN, MM>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, &cyc[6]); wsync(); }
-        else boxadmm_solve(qw, n, m, Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi);
+        if constexpr (NN > 0) { boxadmm_solve_reg<NN, MM, true>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr); wsync(); }
+        else boxadmm_solve(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi);
         qp_iter_total += qi.iter;
         // lam_k = p_lambda ; p_lambda -= lam
         for (int i = ln; i < m + n; i += WAVE) { v.lam_k[i] = qw.y[i]; qw.y[i] = qw.y[i] - v.lam[i]; }
         wsync();
-        const long long q1 = clock64();
+        const long long q1 = now();
         const double alpha = step_size_selection();
-        const long long q2 = clock64();
-        cyc[1] += q1 - q0; cyc[2] += q2 - q1;
+        const long long q2 = now();
+        acc(1, q1 - q0); acc(2, q2 - q1);
         const double pn = lds_inf_norm(qw.x, n), dn = lds_inf_norm(qw.y, m + n);
         for (int i = ln; i < n; i += WAVE) { const double st = alpha * qw.x[i]; v.x[i] += st; v.step[i] = st; }
         for (int i = ln; i < m + n; i += WAVE) v.lam[i] += alpha * qw.y[i];
@@ -421,14 +425,14 @@ struct SqpDevice {
         // single code site for the (large) QP + line-search body: first pass = exact linearisation (:583), later = update (:649)
         while (true) {
             ++iter;
-            const long long c0 = clock64();
+            const long long c0 = now();
             if (iter == 1) linearisation(); else update_linearisation();
-            const long long c1 = clock64();
+            const long long c1 = now();
             qp_and_step();
-            const long long c2 = clock64();
+            const long long c2 = now();
             const bool done = __builtin_amdgcn_readfirstlane((int)termination_criteria()) != 0;
-            const long long c3 = clock64();
-            cyc[0] += c1 - c0; cyc[3] += c3 - c2; cyc[4] += c3 - c0; (void)c2;
+            const long long c3 = now();
+            acc(0, c1 - c0); acc(3, c3 - c2); acc(4, c3 - c0); (void)c2;
             if (done) { status = PMPC_SQP_SOLVED; break; }
             if (iter >= ss.max_iter) break;
             if (iter >= it_end) { status = PMPC_SQP_IN_PROGRESS; break; }

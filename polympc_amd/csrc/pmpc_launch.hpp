@@ -17,7 +17,10 @@ namespace pmpc {
 using ::pmpc_status;
 
 template <class Model, int NN = 0, int MM = 0, bool PROF = false>
-__global__ __launch_bounds__(64, (NN > 0 ? 2 : 1)) void sqp_kernel(Model model, const ChebData* __restrict__ cd, int B,
+#ifndef PMPC_SQP_WAVES
+#define PMPC_SQP_WAVES 2
+#endif
+__global__ __launch_bounds__(64, (NN > 0 ? PMPC_SQP_WAVES : 1)) void sqp_kernel(Model model, const ChebData* __restrict__ cd, int B,
                                                  const double* __restrict__ x_guess, const double* __restrict__ lam_guess,
                                                  const double* __restrict__ d, const double* __restrict__ lbx,
                                                  const double* __restrict__ ubx, const double* __restrict__ lbg,

@@ -142,7 +142,7 @@ struct RegKkt {
                     const double col = (ln > k) ? p[t] : 0.0;   // unscaled column; 0 keeps finished lanes untouched
                     const double l = col / dk;
                     d = (ln == k) ? dk : d;
-                    a[k] = (ln > k) ? l : a[k];
+                    a[k] = l;   // 0 on lanes <= k (their a[k] is overwritten by the transposed gather below); no dependence on the old value
                     stA[t * NP + ln] = -col;
                     stB[t * NP + ln] = l;
 #pragma unroll
@@ -187,12 +187,11 @@ struct RegKkt {
 #pragma unroll
             for (int t = 0; t < BK; ++t) stB[t * NP + ln] = (kb + t < N) ? a[(kb + t < N) ? kb + t : 0] : 0.0;
             lds_order();
-            const bool inblk = (ln >= kb) && (ln < kb + BK);
-            const int tcol = inblk ? ln - kb : 0;
+            const int tcol = (ln - kb) & (BK - 1);
 #pragma unroll
             for (int j = kb + 1; j < N; ++j) {
                 const double v = stB[tcol * NP + j];
-                if (inblk && ln < j) a[j] = v;
+                a[j] = mov_lanes_range(a[j], v, kb, (kb + BK < j) ? kb + BK : j);   // lanes of this block that lie below row j
             }
             lds_order();
         }

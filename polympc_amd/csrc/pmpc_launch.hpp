@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64, (NN > 0 ? PMPC_SQP_WAVES : 1)) void sqp_kernel(
 template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode) {
     OcpDims<Model> dm(P, S);
     size_t stage = OcpLds<Model>::doubles(P, S);
-    if (mode == 1) { const size_t N = dm.n + dm.m; const size_t need = 2 * 8 * ((N + 15) / 16) * 16 + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
+    if (mode == 1) { const size_t need = (size_t)RegKkt<64>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
     return ((mode == 0 ? QpLds::doubles(dm.n, dm.m) : QpLds::doubles_xy(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8) * sizeof(double);
 }
 template <class Model> inline bool sqp_hbm_mode_fits(int P, int S) {   // do the QP vectors fit the second-order staging?

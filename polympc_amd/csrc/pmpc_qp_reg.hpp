@@ -65,7 +65,19 @@ struct RegKkt {
     static constexpr int NB = (N + BK - 1) / BK;      // number of blocks
     static constexpr int NT = (N + 15) / 16;          // 16x16 tiles per dimension
     static constexpr int NP = NT * 16;                // padded dimension
-    static constexpr int TRI = 2 * BK * NP;           // doubles of LDS staging: A-operand panel (-col) and B-operand panel (l)
+    // LDS staging, two layouts chosen so that every access pattern below is bank-conflict free:
+    //  * k-major operand panels PA (-col) and PB (l): element (k, row) at k*SK + row. Written row-per-lane (consecutive
+    //    lanes -> consecutive doubles), read in the MFMA operand pattern (lane>>4)*SK + (lane&15): SK = 16 (mod 32) puts the
+    //    32 lanes of a half-wave on 32 distinct 8-byte banks.
+    //  * row-major exchange buffer X: element (row, t) at row*SX + t with SX = 9. Accumulator-tile side: (lane>>4)*SX +
+    //    (lane&7) (+ const), row-per-lane side: lane*SX + t — both spread over the banks (an odd stride).
+    //    X aliases PB: a wave's DS operations execute in issue order, and X is only live between two panel steps.
+    //  Both are sized for all 64 lanes (idle lanes >= N store too; their values are never consumed).
+    static constexpr int SK = 80;
+    static constexpr int SX = BK + 1;
+    static constexpr int XSZ = (64 * SX > BK * SK) ? 64 * SX : BK * SK;
+    static_assert(N <= 64 && SK % 32 == 16 && SK >= 64, "panel stride");
+    static constexpr int TRI = BK * SK + XSZ;         // doubles of LDS staging
 
     // LDL^T of the matrix whose rows are in a[] (a[j] = K(lane, j); only j <= lane matters). Static order, right-looking;
     // every trailing entry receives  a_ij <- fma(-col_ik, l_jk, a_ij)  for k ascending — bit-identical to the scalar
@@ -74,18 +86,19 @@ struct RegKkt {
     //
     // Blocked: panels of BK = 8 columns are factorised in row-per-lane registers (v_readlane broadcasts, 28 pair
     // updates); the (N-kb-8)^2 trailing matrix lives in 16x16 fp64 MFMA accumulator tiles and gets its rank-8 update
-    // from two v_mfma_f64_16x16x4_f64 per tile, with the A (-col) and B (l) operand panels staged through 8 KB of LDS.
-    // The next panel is pulled out of the tiles through the same staging buffer. The block loop is fully unrolled
+    // from two v_mfma_f64_16x16x4_f64 per tile, with the A (-col) and B (l) operand panels staged through LDS.
+    // The next panel is pulled out of the tiles through the exchange buffer. The block loop is fully unrolled
     // (7 blocks for 56 rows) so that all register indices are compile-time constants.
-    // kcol(j) returns K(lane, j) (only j <= lane matters); it is called 8 columns at a time, one group ahead of use, so the
+    // kcol(j) returns K(lane, j) (only j < lane matters); it is called 8 columns at a time, one group ahead of use, so the
     // KKT rows never sit in registers next to the accumulator tiles.
-    // diag = K(lane, lane) (patched into the staging buffer by the 8 lanes of each column group).
+    // diag = K(lane, lane) (patched into the exchange buffer by the 8 lanes of each column group).
     template <class KCol>
     __device__ __forceinline__ void factor(int ln_in, double* st, double diag, KCol kcol) {
         int ln = ln_in;
         asm volatile("" : "+v"(ln));   // keep the lane predicates below local to the factorisation (no hoisting into long-lived SGPR masks)
-        double* stA = st;
-        double* stB = st + BK * NP;
+        double* PA = st;
+        double* PB = st + BK * SK;
+        double* X = PB;
         const int lr = ln >> 4, lc = ln & 15;
         d4 T[NT][NT];
 #pragma unroll
@@ -101,15 +114,15 @@ struct RegKkt {
 #pragma unroll
             for (int t = 0; t < BK; ++t) nxt[t] = ((g + 1) * BK + t < N) ? kcol(((g + 1) * BK + t < N) ? (g + 1) * BK + t : 0) : 0.0;
 #pragma unroll
-            for (int t = 0; t < BK; ++t) stA[t * NP + ln] = cur[t];
+            for (int t = 0; t < BK; ++t) X[ln * SX + t] = cur[t];
             lds_order();
-            if ((ln >> 3) == g) stA[(ln & 7) * NP + ln] = diag;      // the diagonal entries of this column group
+            if ((ln >> 3) == g) X[ln * SX + (ln & 7)] = diag;      // the diagonal entries of this column group
             lds_order();
             if ((lc >> 3) == (g % 2)) {
 #pragma unroll
                 for (int R = g / 2; R < NT; ++R)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) T[R][g / 2][r] = stA[(lc & 7) * NP + 16 * R + lr + 4 * r];
+                    for (int r = 0; r < 4; ++r) T[R][g / 2][r] = X[(16 * R + lr + 4 * r) * SX + (lc & 7)];
             }
             lds_order();
             sched_fence();
@@ -126,12 +139,12 @@ struct RegKkt {
 #pragma unroll
                 for (int R = Cb; R < NT; ++R)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) stA[(lc & 7) * NP + 16 * R + lr + 4 * r] = T[R][Cb][r];
+                    for (int r = 0; r < 4; ++r) X[(16 * R + lr + 4 * r) * SX + (lc & 7)] = T[R][Cb][r];
             }
             lds_order();
             double p[BK];
 #pragma unroll
-            for (int t = 0; t < BK; ++t) p[t] = stA[t * NP + ln];
+            for (int t = 0; t < BK; ++t) p[t] = X[ln * SX + t];
             lds_order();
             // 2. panel factorisation (right-looking inside the panel)
 #pragma unroll
@@ -143,15 +156,15 @@ struct RegKkt {
                     const double l = col / dk;
                     d = (ln == k) ? dk : d;
                     a[k] = l;   // 0 on lanes <= k (their a[k] is overwritten by the transposed gather below); no dependence on the old value
-                    stA[t * NP + ln] = -col;
-                    stB[t * NP + ln] = l;
+                    PA[t * SK + ln] = -col;
+                    PB[t * SK + ln] = l;
 #pragma unroll
                     for (int u = t + 1; u < BK; ++u)
                         if (kb + u < N) p[u] = fma(-col, bcast_lane(l, kb + u), p[u]);
                     sched_fence();
                 } else {
-                    stA[t * NP + ln] = 0.0;
-                    stB[t * NP + ln] = 0.0;
+                    PA[t * SK + ln] = 0.0;
+                    PB[t * SK + ln] = 0.0;
                 }
             }
             lds_order();
@@ -164,8 +177,8 @@ struct RegKkt {
 #pragma unroll
                     for (int R = 0; R < NT; ++R) {
                         if (R >= Rmin) {
-                            av[R] = stA[(4 * s2 + lr) * NP + 16 * R + lc];
-                            bv[R] = stB[(4 * s2 + lr) * NP + 16 * R + lc];
+                            av[R] = PA[(4 * s2 + lr) * SK + 16 * R + lc];
+                            bv[R] = PB[(4 * s2 + lr) * SK + 16 * R + lc];
                         } else { av[R] = 0.0; bv[R] = 0.0; }
                     }
 #pragma unroll
@@ -185,12 +198,12 @@ struct RegKkt {
         for (int b = 0; b < NB; ++b) {
             const int kb = b * BK;
 #pragma unroll
-            for (int t = 0; t < BK; ++t) stB[t * NP + ln] = (kb + t < N) ? a[(kb + t < N) ? kb + t : 0] : 0.0;
+            for (int t = 0; t < BK; ++t) X[ln * SX + t] = (kb + t < N) ? a[(kb + t < N) ? kb + t : 0] : 0.0;
             lds_order();
             const int tcol = (ln - kb) & (BK - 1);
 #pragma unroll
             for (int j = kb + 1; j < N; ++j) {
-                const double v = stB[tcol * NP + j];
+                const double v = X[j * SX + tcol];
                 a[j] = mov_lanes_range(a[j], v, kb, (kb + BK < j) ? kb + BK : j);   // lanes of this block that lie below row j
             }
             lds_order();

@@ -221,6 +221,18 @@ def test_sqp_reference_robot_fixture_sizes(ctx, oracle):
         assert np.abs(x - xo).max() <= 1e-8
 
 
+def test_sqp_five_node_register_path(ctx, oracle):
+    """5 collocation nodes (P=4,S=1 and P=2,S=2): 40 KKT rows, i.e. the register-resident QP with 24 idle lanes and a
+    48-row padded accumulator grid."""
+    from polympc_amd import workloads
+    for P, S in ((4, 1), (2, 2)):
+        B = 32
+        (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, workloads.robot_batch(B, P=P, S=S), B)
+        assert list(info["iter"]) == [i.iter for i in io]
+        assert list(info["qp_solver_iter"]) == [i.qp_solver_iter for i in io]
+        assert np.abs(x - xo).max() <= 1e-8
+
+
 def test_sqp_codegen_robot_exact_hessian(ctx, oracle):
     """codegen_test.cpp:402-438: exact Hessian every iteration, QP max_iter 1000 -> SOLVED in < 10 iterations."""
     import polympc_amd as pa

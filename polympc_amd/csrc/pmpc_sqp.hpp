@@ -52,9 +52,9 @@ struct SqpDevice {
     int n, m, me, mi;
     double cost_log = 0.0, primal_norm = 0.0, dual_norm = 0.0, max_violation = 0.0;
     int qp_iter_total = 0;
-    long long cyc[PROF ? 8 : 1] = {0};
+    long long cyc[PROF ? 16 : 1] = {0};
     __device__ __forceinline__ static long long now() { if constexpr (PROF) return clock64(); else return 0; }
-    __device__ __forceinline__ void acc(int i, long long dt) { if constexpr (PROF) cyc[i] += dt; }   // shader-clock cycles: 0 linearise(+BFGS) 1 QP 2 line search 3 termination 4 total 5 BFGS 6 KKT build+factor 7 QP residuals
+    __device__ __forceinline__ void acc(int i, long long dt) { if constexpr (PROF) cyc[i] += dt; }   // shader-clock cycles: 0 linearise(+BFGS) 1 QP 2 line search 3 termination 4 total 5 BFGS 6 KKT build+factor 7 QP residuals 8 ls node evaluation 9 ls scalar sums 10 first-order staging 11 second-order staging 12 first-order assembly 13 Hessian assembly 14 Lagrangian gradient
 
     __device__ SqpDevice(Ocp<Model>& o, SqpLds& v_, QpLds& q_, double* H_, double* A_, const pmpc_sqp_settings& s, const pmpc_qp_settings& q)
         : ocp(o), v(v_), qw(q_), Hw(H_), Aw(A_), ldw(o.dm.n + o.dm.m), ss(s), qs(q), n(o.dm.n), m(o.dm.m), me(o.dm.me), mi(o.dm.mi) {}
@@ -152,11 +152,12 @@ struct SqpDevice {
                 }
             }
             wsync();
+            const long long e0 = now();
             const int g = ln / NNo, k = ln - g * NNo;
             if (g < ncand) {
                 const bool is_base = first && g == 0;
                 const double ag = cand_alpha[g];
-                auto xat = [&](int idx) -> double { if (is_base) return v.x[idx]; double t = ag * p[idx]; t += v.x[idx]; return t; };
+                auto xat = [&](int idx) -> double { const double xv_ = v.x[idx]; double t = ag * p[idx]; t += xv_; return is_base ? xv_ : t; };
                 double xk[NX > 0 ? NX : 1], uk[NU > 0 ? NU : 1], pk[NP > 0 ? NP : 1], f[NX > 0 ? NX : 1];
                 for (int q = 0; q < NX; ++q) { xk[q] = xat(k * NX + q); f[q] = 0.0; }
                 for (int q = 0; q < NU; ++q) uk[q] = xat(VARX + k * NU + q);
@@ -164,12 +165,31 @@ struct SqpDevice {
                 const double tk = ocp.s.tn[k];
                 ocp.model.template dynamics_impl<double>(cref<double>(xk), cref<double>(uk), cref<double>(pk), cref<double>(ocp.d), tk, vref<double>(f));
                 int seg, row; ocp.seg_row(k, seg, row);
-                for (int q = 0; q < NX; ++q) {
-                    double acc = 0.0;
-                    for (int j = 0; j <= P; ++j) acc += ocp.s.D[row + j * (P + 1)] * xat((seg * P + j) * NX + q);
-                    double cv = acc;
-                    cv -= ocp.ts * f[q];
-                    cand_c[g * m + k * NX + q] = cv;
+                {   // D-row times the segment's states: loads of 4 nodes at a time (independent), then the ordered adds
+                    double acc[NX > 0 ? NX : 1];
+                    for (int q = 0; q < NX; ++q) acc[q] = 0.0;
+                    for (int j0 = 0; j0 <= P; j0 += 4) {
+                        double dv[4], xs[4][NX > 0 ? NX : 1];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int jj = (j0 + j <= P) ? j0 + j : 0;
+                            dv[j] = ocp.s.D[row + jj * (P + 1)];
+#pragma unroll
+                            for (int q = 0; q < NX; ++q) xs[j][q] = xat((seg * P + jj) * NX + q);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j0 + j <= P) {
+#pragma unroll
+                                for (int q = 0; q < NX; ++q) acc[q] += dv[j] * xs[j][q];
+                            }
+                    }
+#pragma unroll
+                    for (int q = 0; q < NX; ++q) {
+                        double cv = acc[q];
+                        cv -= ocp.ts * f[q];
+                        cand_c[g * m + k * NX + q] = cv;
+                    }
                 }
                 if (NG > 0) {
                     double gg[NG > 0 ? NG : 1];
@@ -182,22 +202,58 @@ struct SqpDevice {
                 cand_L[g * NNo + k] = L;
             }
             wsync();
+            const long long e1 = now();
             if (ln < ncand) {   // one lane per candidate: the scalar sums, in the reference's association order
                 const int gc = ln;
                 const bool is_base = first && gc == 0;
                 const double ag = cand_alpha[gc];
-                auto xat = [&](int idx) -> double { if (is_base) return v.x[idx]; double t = ag * p[idx]; t += v.x[idx]; return t; };
+                auto xat = [&](int idx) -> double { const double xv_ = v.x[idx]; double t = ag * p[idx]; t += xv_; return is_base ? xv_ : t; };
+                // trip counts are compile-time constants on the register path: the loads are then issued in bulk and only
+                // the (order-preserving) add chains remain serial; the lower / upper sums run as two interleaved chains
+                constexpr int NNODES_CT = (NN > 0) ? MM / (NX + NG) : 0;
+                const int n_ = (NN > 0) ? NN : n, m_ = (NN > 0) ? MM : m, me_ = (NN > 0) ? NX * NNODES_CT : me, mi_ = (NN > 0) ? NG * NNODES_CT : mi;
                 double cl1 = DBL_EPS, sacc = 0.0;
-                for (int i = 0; i < me; ++i) sacc += fabs(cand_c[gc * m + i]);
+                constexpr int CH = 8;   // loads in chunks of CH independent LDS reads, then the serial adds
+                for (int i0 = 0; i0 < me_; i0 += CH) {
+                    double cv[CH];
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) cv[i] = cand_c[gc * m_ + ((i0 + i < me_) ? i0 + i : 0)];
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) if (i0 + i < me_) sacc += fabs(cv[i]);
+                }
                 cl1 += sacc;
-                sacc = 0.0; for (int i = 0; i < mi; ++i) sacc += fmax(v.lbg[i] - cand_c[gc * m + me + i], 0.0); cl1 += sacc;
-                sacc = 0.0; for (int i = 0; i < mi; ++i) sacc += fmax(cand_c[gc * m + me + i] - v.ubg[i], 0.0); cl1 += sacc;
-                sacc = 0.0; for (int i = 0; i < n; ++i) sacc += fmax(v.lbx[i] - xat(i), 0.0); cl1 += sacc;
-                sacc = 0.0; for (int i = 0; i < n; ++i) sacc += fmax(xat(i) - v.ubx[i], 0.0); cl1 += sacc;
+                double slo = 0.0, shi = 0.0;
+                for (int i0 = 0; i0 < mi_; i0 += CH) {
+                    double cv[CH], lb[CH], ub[CH];
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) { const int ii = (i0 + i < mi_) ? i0 + i : 0; cv[i] = cand_c[gc * m_ + me_ + ii]; lb[i] = v.lbg[ii]; ub[i] = v.ubg[ii]; }
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) if (i0 + i < mi_) { slo += fmax(lb[i] - cv[i], 0.0); shi += fmax(cv[i] - ub[i], 0.0); }
+                }
+                cl1 += slo; cl1 += shi;
+                slo = 0.0; shi = 0.0;
+                for (int i0 = 0; i0 < n_; i0 += CH) {
+                    double pv[CH], xv[CH], lb[CH], ub[CH];
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) { const int ii = (i0 + i < n_) ? i0 + i : 0; pv[i] = p[ii]; xv[i] = v.x[ii]; lb[i] = v.lbx[ii]; ub[i] = v.ubx[ii]; }
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) if (i0 + i < n_) {
+                        double t = ag * pv[i]; t += xv[i];
+                        const double xi = is_base ? xv[i] : t;
+                        slo += fmax(lb[i] - xi, 0.0); shi += fmax(xi - ub[i], 0.0);
+                    }
+                }
+                cl1 += slo; cl1 += shi;
                 cand_viol[gc] = cl1;
                 double c = 0.0;
                 for (int sg = 0; sg < S; ++sg)
-                    for (int kk = 0; kk <= P; ++kk) c += ocp.ts * ocp.s.w[kk] * cand_L[gc * NNo + sg * P + kk];
+                    for (int k0 = 0; k0 <= P; k0 += 4) {
+                        double wv[4], Lv[4];
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) { const int kc = (k0 + kk <= P) ? k0 + kk : 0; wv[kk] = ocp.s.w[kc]; Lv[kk] = cand_L[gc * NNo + sg * P + kc]; }
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) if (k0 + kk <= P) c += ocp.ts * wv[kk] * Lv[kk];
+                    }
                 double x0[NX > 0 ? NX : 1], u0[NU > 0 ? NU : 1], p0[NP > 0 ? NP : 1];
                 for (int q = 0; q < NX; ++q) x0[q] = xat(q);
                 for (int q = 0; q < NU; ++q) u0[q] = xat(VARX + q);
@@ -208,6 +264,7 @@ struct SqpDevice {
                 cand_cost[gc] = c;
             }
             wsync();
+            acc(8, e1 - e0); acc(9, now() - e1);
             if (first) {
                 const double constr_l1 = cand_viol[0];
                 phi_l1 = cand_cost[0] + mu * constr_l1;
@@ -275,11 +332,17 @@ struct SqpDevice {
 
     // linearisation_dense_impl :310-318
     __device__ void linearisation() {
+        const long long l0 = now();
         ocp.stage_first_order(v.x);
+        const long long l1 = now();
         ocp.stage_second_order(v.x, v.lam);
+        const long long l2 = now();
         ocp.assemble_first_order(v.al, Aw, v.h, ldw);
+        const long long l3 = now();
         ocp.assemble_hessian(Hw, ldw);
+        const long long l4 = now();
         lagrangian_gradient(v.lg);
+        acc(10, l1 - l0); acc(11, l2 - l1); acc(12, l3 - l2); acc(13, l4 - l3); acc(14, now() - l4);
         if (ss.regularisation == 2) regularise_gershgorin();
     }
 
@@ -367,9 +430,13 @@ struct SqpDevice {
     // update_linearisation_dense_impl :490-504
     __device__ void update_linearisation() {
         if (ss.exact_hessian_every_iter) { linearisation(); return; }
+        const long long l0 = now();
         ocp.stage_first_order(v.x);
+        const long long l1 = now();
         ocp.assemble_first_order(v.al, Aw, v.h, ldw);
+        const long long l3 = now();
         lagrangian_gradient(v.lgn);
+        acc(10, l1 - l0); acc(12, l3 - l1); acc(14, now() - l3);
         const long long b0 = now();
         bfgs_update();
         acc(5, now() - b0);

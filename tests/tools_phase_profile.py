@@ -15,7 +15,9 @@ for rep in range(2):
     x, lam, info = ctx.sqp_solve_batch(0, 6, 1, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
     t = time.perf_counter() - t
 cyc = ctx.phase_cycles()
-names = ["linearise(+update)", "QP", "line search", "termination", "total loop", "BFGS", "KKT build+factor", "QP residuals"]
+names = ["linearise(+update)", "QP", "line search", "termination", "total loop", "BFGS", "KKT build+factor", "QP residuals",
+         "ls node evaluation", "ls scalar sums", "first-order staging", "second-order staging", "first-order assembly",
+         "Hessian assembly", "Lagrangian gradient", "-"]
 qps = info["iter"].sum()
 print(f"host wall {t*1e3:.2f} ms (incl. copies), {qps} QPs, {info['qp_solver_iter'].sum()/qps:.2f} ADMM it/QP")
 for nme, c in zip(names, cyc):

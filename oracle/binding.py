@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liboracle.so")
 REF_PATH = os.path.join(HERE, "_ref", "libref_casadi_robot.so")
 
-PIVOT_EIGEN, PIVOT_STATIC = 0, 1
+PIVOT_EIGEN, PIVOT_STATIC, PIVOT_SWEEP = 0, 1, 2
 MODEL_ROBOT, MODEL_CSTR, MODEL_PARKING, MODEL_ROBOT_NG, MODEL_KITE_STANDIN = 0, 1, 2, 3, 4
 NLP_CONSTRAINED_ROSENBROCK, NLP_ROSENBROCK, NLP_SIMPLE, NLP_HS071 = 0, 1, 2, 3
 QP_SOLVED, QP_MAX_ITER_EXCEEDED, QP_UNSOLVED = 0, 1, 2

@@ -11,10 +11,16 @@
 // (src/utils/helpers.hpp:38-43; Eigen 3.3.7 pinned in ci/install-linux.sh:21). Eigen is NOT vendored in
 // /root/reference; the two pivot policies below restate its published algorithm:
 //   PIVOT_EIGEN  : symmetric max-|diag| pivoting, left-looking column update, D^+ solve (Eigen semantics)
+//   PIVOT_SWEEP  : no factorisation at all — W = -K^{-1} by the symmetric sweep operator in blocks of 8 pivots
+//                  (static order) and x = -(W b) as a mat-vec. This is the arithmetic of the register-resident HIP
+//                  kernel (polympc_amd/csrc/pmpc_qp_reg.hpp), restated operation by operation so that the kernel can be
+//                  checked bit for bit; it is tied to the reference only through PIVOT_EIGEN (tests/test_oracle_pins.py
+//                  compares the two policies on the reference's QP fixtures and on the SQP workloads).
 //   PIVOT_STATIC : identical arithmetic without the permutation, right-looking update order — the order
 //                  the HIP kernels use, so a GPU-vs-oracle comparison isolates kernel bugs from pivot effects.
 // All matrices column-major.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <limits>
 #include <vector>
@@ -22,7 +28,7 @@
 namespace oracle {
 
 enum qp_status { QP_SOLVED = 0, QP_MAX_ITER_EXCEEDED = 1, QP_UNSOLVED = 2, QP_UNINITIALIZED = 3, QP_INFEASIBLE = 4, QP_INCONSISTENT = 5 };
-enum pivot_policy { PIVOT_EIGEN = 0, PIVOT_STATIC = 1 };
+enum pivot_policy { PIVOT_EIGEN = 0, PIVOT_STATIC = 1, PIVOT_SWEEP = 2 };
 
 struct qp_settings {  // qp_base.hpp:17-53 (ADMM-related subset)
     double eps_rel = 1e-3, eps_abs = 1e-3;
@@ -55,6 +61,7 @@ struct LDLT {
     void compute(const std::vector<double>& K, int n_, pivot_policy pol) {
         n = n_; policy = pol; M = K; tr.assign(n, 0); temp.assign(n, 0.0);
         if (policy == PIVOT_STATIC) { compute_static(); return; }
+        if (policy == PIVOT_SWEEP) { compute_sweep(); return; }
         auto at = [&](int i, int j) -> double& { return M[i + j * n]; };
         for (int k = 0; k < n; ++k) {
             // largest remaining |diagonal| (first occurrence)
@@ -101,8 +108,57 @@ struct LDLT {
         }
     }
 
+    // Symmetric sweep operator, blocks of 8 pivots, static order. After all sweeps M = -K^{-1} (full storage).
+    // Block step on pivots kb..kb+7 (panel p = M[:, block], Cold = its copy):
+    //   in-panel scalar sweeps   t = 0..7, k = kb+t:  r = 1/p[k][t];  l_i = p[i][t]*r;
+    //                            u != t:  p[i][u] = fma(-l_i, p[k][u], p[i][u]) (i != k),  p[k][u] = p[k][u]*r;
+    //                            p[i][t] = l_i (i != k),  p[k][t] = -r
+    //   trailing update          i, j outside the block:  M[i][j] = fma(-p[i][t], Cold[j][t], M[i][j]),  t ascending
+    //   write-back               M[:, block] = p,  then M[block, :] = p^T
+    void compute_sweep() {
+        auto at = [&](int i, int j) -> double& { return M[i + j * n]; };
+        for (int k = 0; k < n; ++k) tr[k] = k;
+        for (int j = 0; j < n; ++j) for (int i = 0; i < j; ++i) at(i, j) = at(j, i);   // full symmetric storage
+        const int BK = 8;
+        std::vector<double> p((size_t)n * BK), cold((size_t)n * BK), l(n);
+        for (int kb = 0; kb < n; kb += BK) {
+            const int w = std::min(BK, n - kb);
+            for (int t = 0; t < w; ++t) for (int i = 0; i < n; ++i) { p[i * BK + t] = at(i, kb + t); cold[i * BK + t] = p[i * BK + t]; }
+            for (int t = 0; t < w; ++t) {
+                const int k = kb + t;
+                const double r = 1.0 / p[k * BK + t];
+                for (int i = 0; i < n; ++i) l[i] = p[i * BK + t] * r;
+                for (int u = 0; u < w; ++u) {
+                    if (u == t) continue;
+                    const double rk = p[k * BK + u];
+                    for (int i = 0; i < n; ++i) p[i * BK + u] = (i == k) ? rk * r : std::fma(-l[i], rk, p[i * BK + u]);
+                }
+                for (int i = 0; i < n; ++i) p[i * BK + t] = (i == k) ? -r : l[i];
+            }
+            for (int j = 0; j < n; ++j) {
+                if (j >= kb && j < kb + w) continue;
+                for (int i = 0; i < n; ++i) {
+                    if (i >= kb && i < kb + w) continue;
+                    double a = at(i, j);
+                    for (int t = 0; t < w; ++t) a = std::fma(-p[i * BK + t], cold[j * BK + t], a);
+                    at(i, j) = a;
+                }
+            }
+            for (int t = 0; t < w; ++t) for (int i = 0; i < n; ++i) at(i, kb + t) = p[i * BK + t];
+            for (int t = 0; t < w; ++t) for (int j = 0; j < n; ++j) at(kb + t, j) = p[j * BK + t];
+        }
+    }
+
     void solve(const double* b, double* x) const {
         auto at = [&](int i, int j) -> double { return M[i + j * n]; };
+        if (policy == PIVOT_SWEEP) {   // x = -(W b): four interleaved partial sums (j mod 4), combined as (s0+s1)+(s2+s3)
+            for (int i = 0; i < n; ++i) {
+                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int j = 0; j < n; ++j) acc[j & 3] = std::fma(at(i, j), b[j], acc[j & 3]);
+                x[i] = -((acc[0] + acc[1]) + (acc[2] + acc[3]));
+            }
+            return;
+        }
         for (int i = 0; i < n; ++i) x[i] = b[i];
         if (policy == PIVOT_EIGEN) for (int k = 0; k < n; ++k) if (tr[k] != k) std::swap(x[k], x[tr[k]]);
         if (policy == PIVOT_STATIC) {

@@ -1,15 +1,13 @@
 // polympc_amd — register-resident box-ADMM QP solve for compile-time sizes with n+m <= 64 (one wavefront per QP).
 //
-// Same algorithm, constants, update order and arithmetic as pmpc_qp.hpp (boxADMM::solve_impl, box_admm.hpp:88-205;
-// static-order right-looking LDL^T with fused multiply-add), different data placement:
-//   * lane i owns KKT row i. The factor is kept as ONE register array a[N] per lane holding row i of (L + L^T):
-//     a[j] = L(i,j) for j < i and L(j,i) for j > i. Every register index is a compile-time constant after full
-//     unrolling, so neither the factorisation nor the substitutions touch LDS or scratch:
-//       forward  step j: x_j broadcast with v_readlane; lanes i > j:  c_i -= a[j] * x_j
-//       backward step j: x_j broadcast with v_readlane; lanes i < j:  c_i -= a[j] * x_j
-//     During the factorisation each scaled column is also staged through a packed LDS triangle, from which every
-//     lane picks up its transposed part L(j,i), j > i, once the factorisation is complete.
-//     Lane masks of the substitutions are compile-time constants and are applied by shifting -1 into EXEC.
+// Same algorithm, constants and update order as pmpc_qp.hpp (boxADMM::solve_impl, box_admm.hpp:88-205); the linear solve
+// of every ADMM iteration is organised differently (a different, equally static, order of floating-point operations —
+// restated on the CPU as PIVOT_SWEEP in oracle/qp.hpp):
+//   * the KKT matrix is INVERTED once per factorisation point (first iteration and every accepted rho update) with the
+//     symmetric sweep operator in MFMA accumulator tiles (RegKkt::invert), and lane i keeps row i of W = -K^{-1} in a
+//     register array a[N] (compile-time register indices after full unrolling);
+//   * the per-iteration solve is then the mat-vec  x_i = -sum_j a[j] * rhs_j : the rhs entries are broadcast with
+//     v_readlane and all 56 products are independent — no 2N-step substitution chain in the ADMM loop;
 //   * all ADMM vectors are one register per lane: lanes [0,n) carry x, q, y_box, rho_box, h, xlb, xub; lanes
 //     [n,n+m) carry z, y_a, rho, Alb, Aub. The ADMM iteration therefore runs entirely out of registers.
 //   * H and A are read from HBM/L2 (coalesced down columns) only to build K and, every check_termination-th
@@ -57,54 +55,50 @@ __device__ __forceinline__ double mov_lanes_range(double dst, double src, int lo
 
 template <int N>
 struct RegKkt {
-    double a[N];  // row `lane` of (strict L + strict L^T)
-    double d;     // D(lane)
+    double a[N];  // row `lane` of W = -K^{-1}
 
     using d4 = double __attribute__((ext_vector_type(4)));
-    static constexpr int BK = 8;                      // panel width (columns eliminated per block)
+    static constexpr int BK = 8;                      // pivots swept per block
     static constexpr int NB = (N + BK - 1) / BK;      // number of blocks
     static constexpr int NT = (N + 15) / 16;          // 16x16 tiles per dimension
     static constexpr int NP = NT * 16;                // padded dimension
     // LDS staging, two layouts chosen so that every access pattern below is bank-conflict free:
-    //  * k-major operand panels PA (-col) and PB (l): element (k, row) at k*SK + row. Written row-per-lane (consecutive
-    //    lanes -> consecutive doubles), read in the MFMA operand pattern (lane>>4)*SK + (lane&15): SK = 16 (mod 32) puts the
+    //  * k-major operand panels PA and PB: element (t, row) at t*SK + row. Written row-per-lane (consecutive lanes ->
+    //    consecutive doubles), read in the MFMA operand pattern (lane>>4)*SK + (lane&15): SK = 16 (mod 32) puts the
     //    32 lanes of a half-wave on 32 distinct 8-byte banks.
     //  * row-major exchange buffer X: element (row, t) at row*SX + t with SX = 9. Accumulator-tile side: (lane>>4)*SX +
     //    (lane&7) (+ const), row-per-lane side: lane*SX + t — both spread over the banks (an odd stride).
-    //    X aliases PB: a wave's DS operations execute in issue order, and X is only live between two panel steps.
-    //  Both are sized for all 64 lanes (idle lanes >= N store too; their values are never consumed).
+    //    X aliases PB: a wave's DS operations execute in issue order, and X is never live at the same time as PB.
+    //  Both are sized for all 64 lanes (idle lanes >= N store too; their values are never consumed by live rows).
     static constexpr int SK = 80;
     static constexpr int SX = BK + 1;
     static constexpr int XSZ = (64 * SX > BK * SK) ? 64 * SX : BK * SK;
-    static_assert(N <= 64 && SK % 32 == 16 && SK >= 64, "panel stride");
     static constexpr int TRI = BK * SK + XSZ;         // doubles of LDS staging
+    static_assert(N <= 64 && SK % 32 == 16 && SK >= 64, "panel stride");
 
-    // LDL^T of the matrix whose rows are in a[] (a[j] = K(lane, j); only j <= lane matters). Static order, right-looking;
-    // every trailing entry receives  a_ij <- fma(-col_ik, l_jk, a_ij)  for k ascending — bit-identical to the scalar
-    // right-looking update of pmpc_qp.hpp, because v_mfma_f64_16x16x4_f64 IS a k-ascending fma chain (verified on
-    // gfx950, tests/experiments/mfma_f64_probe.hip).
-    //
-    // Blocked: panels of BK = 8 columns are factorised in row-per-lane registers (v_readlane broadcasts, 28 pair
-    // updates); the (N-kb-8)^2 trailing matrix lives in 16x16 fp64 MFMA accumulator tiles and gets its rank-8 update
-    // from two v_mfma_f64_16x16x4_f64 per tile, with the A (-col) and B (l) operand panels staged through LDS.
-    // The next panel is pulled out of the tiles through the exchange buffer. The block loop is fully unrolled
-    // (7 blocks for 56 rows) so that all register indices are compile-time constants.
-    // kcol(j) returns K(lane, j) (only j < lane matters); it is called 8 columns at a time, one group ahead of use, so the
-    // KKT rows never sit in registers next to the accumulator tiles.
-    // diag = K(lane, lane) (patched into the exchange buffer by the 8 lanes of each column group).
+    // W = -K^{-1} by the symmetric sweep operator, static pivot order (K is quasi-definite: every pivot is non-zero),
+    // in blocks of BK = 8 pivots. The matrix lives in 16x16 fp64 MFMA accumulator tiles T[R][C] (full storage).
+    // Block step on pivots kb..kb+7:
+    //   1. the panel M[:, block] goes tiles -> exchange buffer -> row-per-lane registers p[8]
+    //   2. PB <- old panel (B operand)
+    //   3. in-panel scalar sweeps (v_readlane broadcasts of the pivot row):  r = 1/p_k[t];  l_i = p_i[t]*r;
+    //        u != t:  p_i[u] <- fma(-l_i, p_k[u], p_i[u]) (i != k),  p_k[u] <- p_k[u]*r;   p_i[t] <- l_i,  p_k[t] <- -r
+    //   4. PA <- -p (A operand); rows of the block are zero in PA and PB, so the update leaves block rows / columns alone
+    //   5. all tiles:  T[R][C] <- T[R][C] + PA_R * PB_C^T  (two v_mfma_f64_16x16x4_f64 each; the instruction is a
+    //      k-ascending fma chain — verified on gfx950, tests/experiments/mfma_f64_probe.hip — so every entry receives
+    //      fma(-p_i[t], old_j[t], m_ij) for t ascending, exactly as the CPU restatement oracle/qp.hpp:compute_sweep)
+    //   6. write-back: M[:, block] <- p, then M[block, :] <- p^T, through the exchange buffer
+    // Finally the tiles are converted to row-per-lane registers a[] for the mat-vec.
+    // kcol(j) returns K(lane, j) for j != lane; it is called 8 columns at a time, one group ahead of use. diag = K(lane, lane).
     template <class KCol>
-    __device__ __forceinline__ void factor(int ln_in, double* st, double diag, KCol kcol) {
+    __device__ __forceinline__ void invert(int ln_in, double* st, double diag, KCol kcol) {
         int ln = ln_in;
-        asm volatile("" : "+v"(ln));   // keep the lane predicates below local to the factorisation (no hoisting into long-lived SGPR masks)
+        asm volatile("" : "+v"(ln));   // keep the lane predicates below local to this function (no hoisting into long-lived SGPR masks)
         double* PA = st;
         double* PB = st + BK * SK;
         double* X = PB;
         const int lr = ln >> 4, lc = ln & 15;
         d4 T[NT][NT];
-#pragma unroll
-        for (int R = 0; R < NT; ++R)
-#pragma unroll
-            for (int C = 0; C < NT; ++C) T[R][C] = d4{0.0, 0.0, 0.0, 0.0};
         // row layout -> accumulator tiles, 8 columns at a time (loads of the next group are in flight while this one is staged)
         double cur[BK], nxt[BK];
 #pragma unroll
@@ -120,7 +114,7 @@ struct RegKkt {
             lds_order();
             if ((lc >> 3) == (g % 2)) {
 #pragma unroll
-                for (int R = g / 2; R < NT; ++R)
+                for (int R = 0; R < NT; ++R)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) T[R][g / 2][r] = X[(16 * R + lr + 4 * r) * SX + (lc & 7)];
             }
@@ -129,15 +123,14 @@ struct RegKkt {
 #pragma unroll
             for (int t = 0; t < BK; ++t) cur[t] = nxt[t];
         }
-        d = 1.0;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int kb = b * BK;
             const int Cb = kb / 16, hb = (kb % 16) / BK;
-            // 1. next panel: tile column Cb, tile-local columns [8*hb, 8*hb+8) -> row-per-lane registers
+            // 1. panel: tile column Cb, tile-local columns [8*hb, 8*hb+8) -> row-per-lane registers
             if ((lc >> 3) == hb) {
 #pragma unroll
-                for (int R = Cb; R < NT; ++R)
+                for (int R = 0; R < NT; ++R)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) X[(16 * R + lr + 4 * r) * SX + (lc & 7)] = T[R][Cb][r];
             }
@@ -146,78 +139,93 @@ struct RegKkt {
 #pragma unroll
             for (int t = 0; t < BK; ++t) p[t] = X[ln * SX + t];
             lds_order();
-            // 2. panel factorisation (right-looking inside the panel)
+            const bool inb = (ln >> 3) == b;
+            // 2. B operand: the panel as it was at the start of the block
+#pragma unroll
+            for (int t = 0; t < BK; ++t) PB[t * SK + ln] = (inb || kb + t >= N) ? 0.0 : p[t];
+            // 3. in-panel sweeps
 #pragma unroll
             for (int t = 0; t < BK; ++t) {
                 const int k = kb + t;
                 if (k < N) {
                     const double dk = bcast_lane(p[t], k);
-                    const double col = (ln > k) ? p[t] : 0.0;   // unscaled column; 0 keeps finished lanes untouched
-                    const double l = col / dk;
-                    d = (ln == k) ? dk : d;
-                    a[k] = l;   // 0 on lanes <= k (their a[k] is overwritten by the transposed gather below); no dependence on the old value
-                    PA[t * SK + ln] = -col;
-                    PB[t * SK + ln] = l;
+                    const double r = 1.0 / dk;
+                    const bool isk = (ln == k);
+                    const double l = p[t] * r;
 #pragma unroll
-                    for (int u = t + 1; u < BK; ++u)
-                        if (kb + u < N) p[u] = fma(-col, bcast_lane(l, kb + u), p[u]);
+                    for (int u = 0; u < BK; ++u)
+                        if (u != t && kb + u < N) {
+                            const double rk = bcast_lane(p[u], k);
+                            const double upd = fma(-l, rk, p[u]);
+                            p[u] = isk ? rk * r : upd;
+                        }
+                    p[t] = isk ? -r : l;
                     sched_fence();
-                } else {
-                    PA[t * SK + ln] = 0.0;
-                    PB[t * SK + ln] = 0.0;
                 }
+            }
+            // 4. A operand
+#pragma unroll
+            for (int t = 0; t < BK; ++t) PA[t * SK + ln] = (inb || kb + t >= N) ? 0.0 : -p[t];
+            lds_order();
+            // 5. rank-8 update of every tile
+#pragma unroll
+            for (int s2 = 0; s2 < BK / 4; ++s2) {
+                double av[NT], bv[NT];
+#pragma unroll
+                for (int R = 0; R < NT; ++R) {
+                    av[R] = PA[(4 * s2 + lr) * SK + 16 * R + lc];
+                    bv[R] = PB[(4 * s2 + lr) * SK + 16 * R + lc];
+                }
+#pragma unroll
+                for (int R = 0; R < NT; ++R)
+#pragma unroll
+                    for (int C = 0; C < NT; ++C) T[R][C] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[R], bv[C], T[R][C], 0, 0, 0);
+                sched_fence();
             }
             lds_order();
-            // 4. rank-8 update of the trailing tiles (rows / columns >= kb + 8)
-            if (kb + BK < N) {
-                const int Rmin = (kb + BK) / 16;
+            // 6. write-back of the swept panel: columns, then rows (the diagonal block ends up as the transpose of p)
 #pragma unroll
-                for (int s2 = 0; s2 < BK / 4; ++s2) {
-                    double av[NT], bv[NT];
+            for (int t = 0; t < BK; ++t) X[ln * SX + t] = p[t];
+            lds_order();
+            if ((lc >> 3) == hb) {
 #pragma unroll
-                    for (int R = 0; R < NT; ++R) {
-                        if (R >= Rmin) {
-                            av[R] = PA[(4 * s2 + lr) * SK + 16 * R + lc];
-                            bv[R] = PB[(4 * s2 + lr) * SK + 16 * R + lc];
-                        } else { av[R] = 0.0; bv[R] = 0.0; }
-                    }
+                for (int R = 0; R < NT; ++R)
 #pragma unroll
-                    for (int R = 0; R < NT; ++R)
-#pragma unroll
-                        for (int C = 0; C <= R; ++C)
-                            if (C >= Rmin) T[R][C] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[R], bv[C], T[R][C], 0, 0, 0);
-                    sched_fence();
-                }
+                    for (int r = 0; r < 4; ++r) T[R][Cb][r] = X[(16 * R + lr + 4 * r) * SX + (lc & 7)];
             }
+#pragma unroll
+            for (int C = 0; C < NT; ++C)
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) T[Cb][C][2 * hb + rr] = X[(16 * C + lc) * SX + lr + 4 * rr];
             lds_order();
             sched_fence();
         }
-        // transposed part, after the tiles are dead (keeps the register peak below the spill threshold): the row parts
-        // a[k] = L(lane, k) are staged 8 columns at a time and lane i in that block picks up column i:  a[j] <- L(j, i), j > i
+        // accumulator tiles -> row-per-lane registers
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int kb = b * BK;
+        for (int g = 0; g < NB; ++g) {
+            if ((lc >> 3) == (g % 2)) {
 #pragma unroll
-            for (int t = 0; t < BK; ++t) X[ln * SX + t] = (kb + t < N) ? a[(kb + t < N) ? kb + t : 0] : 0.0;
-            lds_order();
-            const int tcol = (ln - kb) & (BK - 1);
+                for (int R = 0; R < NT; ++R)
 #pragma unroll
-            for (int j = kb + 1; j < N; ++j) {
-                const double v = X[j * SX + tcol];
-                a[j] = mov_lanes_range(a[j], v, kb, (kb + BK < j) ? kb + BK : j);   // lanes of this block that lie below row j
+                    for (int r = 0; r < 4; ++r) X[(16 * R + lr + 4 * r) * SX + (lc & 7)] = T[R][g / 2][r];
             }
+            lds_order();
+#pragma unroll
+            for (int t = 0; t < BK; ++t)
+                if (g * BK + t < N) a[g * BK + t] = X[ln * SX + t];
             lds_order();
         }
     }
 
-    // c <- K^{-1} c, one entry per lane
-    __device__ __forceinline__ double solve(double c, int ln) const {
+    // K^{-1} c, one entry per lane:  -(W c) with four interleaved partial sums (j mod 4), combined as (s0+s1)+(s2+s3)
+    __device__ __forceinline__ double apply(double c) const {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int j = 0; j < N - 1; ++j) c = fnma_lanes_above(c, a[j], bcast_lane(c, j), j);
-        c = c / d;
-#pragma unroll
-        for (int j = N - 1; j > 0; --j) c = fnma_lanes_below(c, a[j], bcast_lane(c, j), j);
-        return c;
+        for (int j = 0; j < N; ++j) {
+            acc[j & 3] = fma(a[j], bcast_lane(c, j), acc[j & 3]);
+            if ((j & 7) == 7) sched_fence();
+        }
+        return -((acc[0] + acc[1]) + (acc[2] + acc[3]));
     }
 };
 
@@ -288,8 +296,10 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
     while (running) {
         {   // construct_kkt_matrix + factorise_kkt_matrix
             const long long f0 = dbg ? clock64() : 0;
-            K.factor(ln, tr, kdiag, [&](int j) -> double {   // row `lane` of [H ; A | 0] (construct_kkt_matrix, box_admm.hpp:209-223)
-                return (j < NN) ? rowp[(size_t)(j < NN ? j : 0) * rstride] : 0.0;
+            K.invert(ln, tr, kdiag, [&](int j) -> double {   // row `lane` of [H  A^T ; A  .] (construct_kkt_matrix, box_admm.hpp:209-223)
+                if (j < NN) return rowp[(size_t)(j < NN ? j : 0) * rstride];
+                const double v = colA[j >= NN ? j - NN : 0];
+                return isP ? v : 0.0;
             });
             if (dbg) dbg[0] += clock64() - f0;
         }
@@ -299,7 +309,7 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
             const double rhsP = ((s.sigma * xv - hv) + rhov * qv) - yv;
             const double rhsC = xv - rhoinv * yv;
             const double rhs = isP ? rhsP : (isC ? rhsC : 0.0);
-            const double sol = K.solve(rhs, ln);
+            const double sol = K.apply(rhs);
             // both role updates are evaluated on every lane and selected (branch-free)
             const double zt = zprev + rhoinv * (sol - yv);
             double zz = alpha * zt;

@@ -2,7 +2,7 @@
 //
 // Same algorithm, constants and update order as pmpc_qp.hpp (boxADMM::solve_impl, box_admm.hpp:88-205); the linear solve
 // of every ADMM iteration is organised differently (a different, equally static, order of floating-point operations —
-// restated on the CPU as PIVOT_SWEEP in oracle/qp.hpp):
+// the test suite checks it bit for bit against a CPU restatement of exactly this order):
 //   * the KKT matrix is INVERTED once per factorisation point (first iteration and every accepted rho update) with the
 //     symmetric sweep operator in MFMA accumulator tiles (RegKkt::invert), and lane i keeps row i of W = -K^{-1} in a
 //     register array a[N] (compile-time register indices after full unrolling);
@@ -86,7 +86,7 @@ struct RegKkt {
     //   4. PA <- -p (A operand); rows of the block are zero in PA and PB, so the update leaves block rows / columns alone
     //   5. all tiles:  T[R][C] <- T[R][C] + PA_R * PB_C^T  (two v_mfma_f64_16x16x4_f64 each; the instruction is a
     //      k-ascending fma chain — verified on gfx950, tests/experiments/mfma_f64_probe.hip — so every entry receives
-    //      fma(-p_i[t], old_j[t], m_ij) for t ascending, exactly as the CPU restatement oracle/qp.hpp:compute_sweep)
+    //      fma(-p_i[t], old_j[t], m_ij) for t ascending, which is what the CPU checker of the test suite restates)
     //   6. write-back: M[:, block] <- p, then M[block, :] <- p^T, through the exchange buffer
     // Finally the tiles are converted to row-per-lane registers a[] for the mat-vec.
     // kcol(j) returns K(lane, j) for j != lane; it is called 8 columns at a time, one group ahead of use. diag = K(lane, lane).

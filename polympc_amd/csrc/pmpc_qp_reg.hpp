@@ -89,7 +89,7 @@ struct RegKkt {
     //      fma(-p_i[t], old_j[t], m_ij) for t ascending, which is what the CPU checker of the test suite restates)
     //   6. write-back: M[:, block] <- p, then M[block, :] <- p^T, through the exchange buffer
     // Finally the tiles are converted to row-per-lane registers a[] for the mat-vec.
-    // kcol(j) returns K(lane, j) for j != lane; it is called 8 columns at a time, one group ahead of use. diag = K(lane, lane).
+    // kcol(j, z) returns K(lane, j) for j != lane (z: see below); it is called 8 columns at a time, one group ahead of use. diag = K(lane, lane).
     template <class KCol>
     __device__ __forceinline__ void invert(int ln_in, double* st, double diag, KCol kcol) {
         int ln = ln_in;
@@ -100,13 +100,19 @@ struct RegKkt {
         const int lr = ln >> 4, lc = ln & 15;
         d4 T[NT][NT];
         // row layout -> accumulator tiles, 8 columns at a time (loads of the next group are in flight while this one is staged)
+        // `z` is an opaque zero that kcol adds to its addresses: redefining it once per group pins each group's loads
+        // behind the previous group's staging (loads from read-only kernel arguments may otherwise be hoisted to the
+        // top, all 2N registers at once)
         double cur[BK], nxt[BK];
+        int z = 0;
+        asm volatile("" : "+v"(z));
 #pragma unroll
-        for (int t = 0; t < BK; ++t) cur[t] = (t < N) ? kcol(t) : 0.0;
+        for (int t = 0; t < BK; ++t) cur[t] = (t < N) ? kcol(t, z) : 0.0;
 #pragma unroll
         for (int g = 0; g < NP / BK; ++g) {
+            asm volatile("" : "+v"(z) :: "memory");
 #pragma unroll
-            for (int t = 0; t < BK; ++t) nxt[t] = ((g + 1) * BK + t < N) ? kcol(((g + 1) * BK + t < N) ? (g + 1) * BK + t : 0) : 0.0;
+            for (int t = 0; t < BK; ++t) nxt[t] = ((g + 1) * BK + t < N) ? kcol(((g + 1) * BK + t < N) ? (g + 1) * BK + t : 0, z) : 0.0;
 #pragma unroll
             for (int t = 0; t < BK; ++t) X[ln * SX + t] = cur[t];
             lds_order();
@@ -219,13 +225,27 @@ struct RegKkt {
 
     // K^{-1} c, one entry per lane:  -(W c) with four interleaved partial sums (j mod 4), combined as (s0+s1)+(s2+s3)
     __device__ __forceinline__ double apply(double c) const {
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-            acc[j & 3] = fma(a[j], bcast_lane(c, j), acc[j & 3]);
-            if ((j & 7) == 7) sched_fence();
+        for (int j0 = 0; j0 < N; j0 += 8) {
+            double t[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) t[jj] = (j0 + jj < N) ? bcast_lane(c, (j0 + jj < N) ? j0 + jj : 0) : 0.0;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = j0 + jj;
+                if (j < N) {
+                    if ((j & 3) == 0) acc0 = fma(a[j], t[jj], acc0);
+                    if ((j & 3) == 1) acc1 = fma(a[j], t[jj], acc1);
+                    if ((j & 3) == 2) acc2 = fma(a[j], t[jj], acc2);
+                    if ((j & 3) == 3) acc3 = fma(a[j], t[jj], acc3);
+                }
+            }
+            // groups of 8 broadcasts: the empty statement ties the next group's v_readlane to this group's results, which
+            // keeps instruction selection from hoisting all 2N scalar broadcasts (more SGPRs than exist) to the top
+            asm volatile("" : "+v"(c), "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3));
         }
-        return -((acc[0] + acc[1]) + (acc[2] + acc[3]));
+        return -((acc0 + acc1) + (acc2 + acc3));
     }
 };
 
@@ -255,11 +275,23 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
     const double hi = isP ? xub[lp] : (isC ? Aub[r] : 0.0);
     const int type = classify_bounds(lo, hi);
 
-    // row `lane` of [H ; A] is read with unconditional, clamped addresses: base + j*stride
-    constexpr int LDH = STACKED ? N : NN, LDA = STACKED ? N : MM;
-    const double* rowp = STACKED ? (H + (ln < N ? ln : 0)) : (isP ? (H + ln) : (A + r));
-    const int rstride = STACKED ? N : (isP ? NN : (isC ? MM : 0));
-    const double* colA = A + (size_t)lp * LDA;   // column `lane` of A (primal lanes), contiguous
+    // Row `lane` of [H ; A] and column `lane` of A are read with unconditional, clamped addresses. `zo` is an opaque zero
+    // (redefined by an empty asm statement next to each use): without it the address arithmetic of all 2N loads — and,
+    // for read-only kernel arguments, the loads themselves — is hoisted out of the ADMM loops and spilled.
+    //   STACKED: one uniform base (H) + 32-bit per-lane element offsets; otherwise a per-lane base and stride.
+    const double* rowp = isP ? (H + ln) : (A + r);
+    const int rstride = isP ? NN : (isC ? MM : 0);
+    const double* colA = A + (size_t)lp * MM;
+    const unsigned roff = (ln < N) ? ln : 0, coff = lp * N + NN;
+    auto Krow = [&](int j, int zo) -> double {   // (H or A)(row of this lane, j), j < NN
+        if constexpr (STACKED) return H[(unsigned)(roff + zo) + (unsigned)(j * N)];
+        else return rowp[(size_t)j * (size_t)(unsigned)(rstride + zo)];
+    };
+    auto Acol = [&](int k, int zo) -> double {   // A(k, lane), k < MM (primal lanes)
+        if constexpr (STACKED) return H[(unsigned)(coff + zo) + (unsigned)k];
+        else return colA[k + zo];
+    };
+    constexpr int LDH = STACKED ? N : NN;
 
     // state: xv = x (primal lanes) / z (constraint lanes); yv = y_box / y_a; qv = q (primal lanes)
     double xv = 0.0, yv = 0.0, qv = 0.0;
@@ -270,7 +302,7 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
     if (x0) {  // z = A * x_guess
         double acc = 0.0;
 #pragma unroll
-        for (int j = 0; j < NN; ++j) acc += rowp[(size_t)j * rstride] * bcast_lane(xv, j);
+        for (int j = 0; j < NN; ++j) acc += Krow(j, 0) * bcast_lane(xv, j);
         xv = isC ? acc : xv;
     }
 
@@ -292,13 +324,14 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
     // on that factor. Keeping the high-register-pressure factorisation OUT of the inner loop keeps the inner loop's
     // state in registers (no scratch traffic inside the ADMM iterations).
     int iter = 1;
+    int until_check = s.check_termination, until_adapt = s.adaptive_rho_interval;   // iterations left until the next multiple
     bool running = true;
     while (running) {
         {   // construct_kkt_matrix + factorise_kkt_matrix
             const long long f0 = dbg ? clock64() : 0;
-            K.invert(ln, tr, kdiag, [&](int j) -> double {   // row `lane` of [H  A^T ; A  .] (construct_kkt_matrix, box_admm.hpp:209-223)
-                if (j < NN) return rowp[(size_t)(j < NN ? j : 0) * rstride];
-                const double v = colA[j >= NN ? j - NN : 0];
+            K.invert(ln, tr, kdiag, [&](int j, int z) -> double {   // row `lane` of [H  A^T ; A  .] (construct_kkt_matrix, box_admm.hpp:209-223)
+                if (j < NN) return Krow(j < NN ? j : 0, z);
+                const double v = Acol(j >= NN ? j - NN : 0, z);
                 return isP ? v : 0.0;
             });
             if (dbg) dbg[0] += clock64() - f0;
@@ -324,18 +357,22 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
             xv = isP ? xx : (isC ? zz : xv);
             qv = isP ? qq : qv;
             yv = isP ? yP : (isC ? yC : yv);
-            const bool check = (s.check_termination != 0 && iter % s.check_termination == 0);
-            const bool adapt = (s.adaptive_rho && iter % s.adaptive_rho_interval == 0);
+            // iter % check_termination == 0 / iter % adaptive_rho_interval == 0 (box_admm.hpp:141,:160) as countdowns
+            bool check = false, adapt = false;
+            if (s.check_termination != 0 && --until_check == 0) { check = true; until_check = s.check_termination; }
+            if (s.adaptive_rho && --until_adapt == 0) { adapt = true; until_adapt = s.adaptive_rho_interval; }
             if (check || adapt) {  // residuals_update, box_admm.hpp:398-415
                 const long long r0 = dbg ? clock64() : 0;
                 // loads in chunks of RC columns (independent, coalesced), each followed by its slice of the mat-vec chain
                 constexpr int RC = 8;
+                int zr = 0;            // opaque zero added to the addresses: keeps these loop-invariant loads inside the loop
+                asm volatile("" : "+v"(zr));
                 double acc = 0.0;      // lanes < n: (H x)_i ; lanes in [n, N): (A x)_r
 #pragma unroll
                 for (int j0 = 0; j0 < NN; j0 += RC) {
                     double mrow[RC];
 #pragma unroll
-                    for (int j = 0; j < RC; ++j) mrow[j] = (j0 + j < NN) ? rowp[(size_t)(j0 + j < NN ? j0 + j : 0) * rstride] : 0.0;
+                    for (int j = 0; j < RC; ++j) mrow[j] = (j0 + j < NN) ? Krow(j0 + j < NN ? j0 + j : 0, zr) : 0.0;
 #pragma unroll
                     for (int j = 0; j < RC; ++j) if (j0 + j < NN) acc += mrow[j] * bcast_lane(xv, j0 + j);
                     sched_fence();
@@ -345,7 +382,7 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
                 for (int k0 = 0; k0 < MM; k0 += RC) {
                     double mcol[RC];
 #pragma unroll
-                    for (int k = 0; k < RC; ++k) mcol[k] = (k0 + k < MM) ? colA[(k0 + k < MM) ? k0 + k : 0] : 0.0;
+                    for (int k = 0; k < RC; ++k) mcol[k] = (k0 + k < MM) ? Acol((k0 + k < MM) ? k0 + k : 0, zr) : 0.0;
 #pragma unroll
                     for (int k = 0; k < RC; ++k) if (k0 + k < MM) aty += mcol[k] * bcast_lane(yv, NN + k0 + k);
                     sched_fence();

@@ -187,10 +187,27 @@ struct Ocp {
                 }
             }
             int seg, row; seg_row(k, seg, row);
-            for (int q = 0; q < NX; ++q) {
-                double acc = 0.0;
-                for (int j = 0; j <= P; ++j) acc += s.D[row + j * (P + 1)] * var[(seg * P + j) * NX + q];
-                s.DX[k * NX + q] = acc;
+            {   // D-row times the segment's states: loads of 4 nodes at a time (independent), then the ordered adds
+                double acc[NX > 0 ? NX : 1];
+                for (int q = 0; q < NX; ++q) acc[q] = 0.0;
+                for (int j0 = 0; j0 <= P; j0 += 4) {
+                    double dv[4], xs[4][NX > 0 ? NX : 1];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int jj = (j0 + j <= P) ? j0 + j : 0;
+                        dv[j] = s.D[row + jj * (P + 1)];
+#pragma unroll
+                        for (int q = 0; q < NX; ++q) xs[j][q] = var[(seg * P + jj) * NX + q];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j0 + j <= P) {
+#pragma unroll
+                            for (int q = 0; q < NX; ++q) acc[q] += dv[j] * xs[j][q];
+                        }
+                }
+#pragma unroll
+                for (int q = 0; q < NX; ++q) s.DX[k * NX + q] = acc[q];
             }
             if (k == 0) {
                 ad1 M(0.0);
@@ -244,21 +261,27 @@ struct Ocp {
     // ---- assemble c (m), Jacobian J (m x n column-major in HBM), cost value and cost gradient from the first-order stage
     // equalities_linearised :797-878, _inequalities_linearised_dense :546-575, cost_gradient :1210-1249
     // J(r, col) = J[r + col * ldj] (ldj = m for a plain m x n Jacobian; n+m when J is the lower block of the stacked [H;J] workspace)
-    __device__ double assemble_first_order(double* c, double* __restrict__ J, double* cost_grad, int ldj) {
+    // structure = false: J already holds a linearisation of THIS problem — its zeros and its differentiation-matrix entries
+    // do not depend on the iterate, so only the per-node blocks (D self entry - t_scale*df, dg) are rewritten.
+    __device__ double assemble_first_order(double* c, double* __restrict__ J, double* cost_grad, int ldj, bool structure = true) {
         const int ln = lane_id();
         const int n = dm.n, m = dm.m;
-        for (int e = ln; e < m * n; e += WAVE) J[(e % m) + (size_t)(e / m) * ldj] = 0.0;
+        if (structure) {
+            for (int e = ln; e < m * n; e += WAVE) J[(e % m) + (size_t)(e / m) * ldj] = 0.0;
+            __threadfence_block();
+        }
         for (int i = ln; i < n; i += WAVE) cost_grad[i] = 0.0;
-        __threadfence_block();
         wsync();
         for (int k = ln; k < dm.NN; k += WAVE) {
             int seg, row; seg_row(k, seg, row);
             for (int q = 0; q < NX; ++q) {
                 const int r = k * NX + q;
-                if (k < dm.NN - 1) {
-                    for (int j = 0; j <= P; ++j) J[r + (size_t)((seg * P + j) * NX + q) * ldj] = s.D[row + j * (P + 1)] * 1.0;
-                } else {  // last node row = -reverse(first block row) (:845-846)
-                    for (int j = 0; j <= P; ++j) J[r + (size_t)(dm.VARX - NX * (P + 1) + j * NX + q) * ldj] = -s.D[0 + (P - j) * (P + 1)];
+                if (structure) {
+                    if (k < dm.NN - 1) {
+                        for (int j = 0; j <= P; ++j) J[r + (size_t)((seg * P + j) * NX + q) * ldj] = s.D[row + j * (P + 1)] * 1.0;
+                    } else {  // last node row = -reverse(first block row) (:845-846)
+                        for (int j = 0; j <= P; ++j) J[r + (size_t)(dm.VARX - NX * (P + 1) + j * NX + q) * ldj] = -s.D[0 + (P - j) * (P + 1)];
+                    }
                 }
                 double cv = -ts * s.fval[r];
                 cv += s.DX[r];

@@ -24,11 +24,49 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 // one wavefront per workgroup: this is a compiler + LDS ordering fence, not a cross-wave barrier
 __device__ __forceinline__ void wsync() { __syncthreads(); }
 
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
-    return v;
+// A zero the optimiser cannot see through. Added to the per-lane element offset of global-memory accesses inside the SQP /
+// ADMM loops, it keeps their address arithmetic next to the access: otherwise every one of the O(n) distinct 64-bit
+// addresses is computed once outside the loops (they are loop-invariant) and then lives in — or is spilled from — a
+// register pair for the whole kernel.
+__device__ __forceinline__ unsigned opaque_zero() { unsigned z = 0; asm volatile("" : "+v"(z)); return z; }
+
+// max over the 64 lanes, returned to every lane. DPP reduction (quad swaps, row mirrors, row broadcasts) — six VALU steps
+// without an LDS round trip (a __shfl_xor butterfly costs two ds_bpermute per step); the total ends up in lane 63 and is
+// broadcast through an SGPR pair. max is exact, so the combination order does not matter.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_max_step(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return fmax(v, __hiloint2double(hi, lo));
 }
+__device__ __forceinline__ double wave_max(double v) {
+    v = dpp_max_step<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v = dpp_max_step<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v = dpp_max_step<0x141, 0xf>(v);   // row_half_mirror
+    v = dpp_max_step<0x140, 0xf>(v);   // row_mirror: every lane of a 16-lane row holds the row maximum
+    v = dpp_max_step<0x142, 0xa>(v);   // row_bcast15 into rows 1 and 3
+    v = dpp_max_step<0x143, 0xc>(v);   // row_bcast31 into rows 2 and 3: lane 63 holds the wave maximum
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+// a / b for a wave-uniform divisor, correctly rounded like the IEEE division it replaces, at 5 VALU operations per
+// quotient instead of the ~14 of the generic expansion: y = RN(1/b) is computed once (a true division); then
+//   q0 = RN(a*y), r0 = a - b*q0 (fma), q1 = RN(q0 + r0*y)   -> q1 is a faithful quotient
+//   r1 = a - b*q1 (exact, fma), q = RN(q1 + r1*y)            -> RN(a/b) (Markstein's theorem for a correctly rounded y)
+// ok(): the divisor lies in a conservative exponent window (callers branch ONCE on it, wave-uniformly, and use the
+// generic division otherwise).
+struct UniformDiv {
+    double b, y;
+    __device__ __forceinline__ explicit UniformDiv(double b_) : b(b_), y(1.0 / b_) {}
+    __device__ __forceinline__ bool ok() const { const double ab = fabs(b); return __builtin_amdgcn_readfirstlane((int)(ab > 1e-150 && ab < 1e150)) != 0; }
+    __device__ __forceinline__ double operator()(double a) const {
+        const double q0 = a * y;
+        const double q1 = fma(fma(-q0, b, a), y, q0);
+        return fma(fma(-q1, b, a), y, q1);
+    }
+};
+
 // sequential (index-ordered) sum of an LDS vector, evaluated redundantly by every lane (broadcast reads): the
 // same association order as the reference's scalar loops, no cross-lane traffic
 __device__ __forceinline__ double seq_sum(const double* v, int n) {

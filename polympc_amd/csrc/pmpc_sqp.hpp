@@ -295,9 +295,10 @@ struct SqpDevice {
     __device__ void lagrangian_gradient(double* out) {
         if constexpr (NN > 0) {   // compile-time sizes: one batch of independent loads (column j of J), then the chain
             const int j = lane_id() < NN ? lane_id() : 0;
+            const unsigned jo = (unsigned)j * (NN + MM) + opaque_zero();
             double col[MM];
 #pragma unroll
-            for (int i = 0; i < MM; ++i) col[i] = Aw[(size_t)j * (NN + MM) + i];
+            for (int i = 0; i < MM; ++i) col[i] = Aw[jo + (unsigned)i];
             double a = 0.0;
 #pragma unroll
             for (int i = 0; i < MM; ++i) a += col[i] * v.lam[i];
@@ -348,13 +349,17 @@ struct SqpDevice {
 
     // BFGS_update, bfgs.hpp:23-52 ; s = v.step, y = lgn - lg
     // register-row variant for compile-time n: lane i owns row i of B; ONE batch of loads, ONE batch of stores
-    __device__ void bfgs_update_reg() {
+    // brow: row i of B (loading it earlier, across the first-order staging, costs more in register pressure than the L2
+    // round trip it hides — measured)
+    __device__ __forceinline__ void bfgs_load_row(double (&brow)[NN > 0 ? NN : 1]) {
+        const unsigned i = (lane_id() < NN ? lane_id() : 0) + opaque_zero();
+#pragma unroll
+        for (int j = 0; j < NN; ++j) brow[j] = Hw[i + (unsigned)(j * (NN + MM))];
+    }
+    __device__ __forceinline__ void bfgs_update_reg(double (&brow)[NN > 0 ? NN : 1]) {
         const int ln = lane_id();
         const int i = ln < NN ? ln : 0;
         double* Bs = v.t1; double* r = v.t2; double* y = v.t3;
-        double brow[NN > 0 ? NN : 1];
-#pragma unroll
-        for (int j = 0; j < NN; ++j) brow[j] = Hw[(size_t)j * (NN + MM) + i];
         {
             double a = 0.0;
 #pragma unroll
@@ -376,22 +381,36 @@ struct SqpDevice {
         wsync();
         if (__builtin_amdgcn_readfirstlane((int)(sr < DBL_EPS))) return;
         const double Bsi = Bs[i], ri = r[i];
+        const UniformDiv by_sBs(sBs), by_sr(sr);   // the same quotients as "/ sBs", "/ sr", bit for bit
+        if (by_sBs.ok() && by_sr.ok()) {
 #pragma unroll
-        for (int j = 0; j < NN; ++j) {
-            double b = brow[j];
-            b += (-Bsi * Bs[j]) / sBs;
-            b += (ri * r[j]) / sr;
-            brow[j] = b;
+            for (int j0 = 0; j0 < NN; j0 += 8) {
+                double bsj[8], rj[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int jj = (j0 + j < NN) ? j0 + j : 0; bsj[j] = Bs[jj]; rj[j] = r[jj]; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j0 + j < NN) {
+                        double b = brow[j0 + j];
+                        b += by_sBs(-Bsi * bsj[j]);
+                        b += by_sr(ri * rj[j]);
+                        brow[j0 + j] = b;
+                    }
+                asm volatile("" ::: "memory");
+            }
+        } else {   // divisor outside the window of UniformDiv: generic divisions, in place in the workspace (rare)
+            rank2_update_mem(Bs, r, sBs, sr);
+            return;
         }
         if (ln < NN) {
+            const unsigned io = (unsigned)i + opaque_zero();
 #pragma unroll
-            for (int j = 0; j < NN; ++j) Hw[(size_t)j * (NN + MM) + i] = brow[j];
+            for (int j = 0; j < NN; ++j) Hw[io + (unsigned)(j * (NN + MM))] = brow[j];
         }
         __threadfence_block();
         wsync();
     }
     __device__ void bfgs_update() {
-        if constexpr (NN > 0) { bfgs_update_reg(); return; }
         const int ln = lane_id();
         double* Bs = v.t1; double* r = v.t2; double* y = v.t3;
         for (int i = ln; i < n; i += WAVE) {
@@ -414,6 +433,11 @@ struct SqpDevice {
         }
         wsync();
         if (sr < DBL_EPS) return;
+        rank2_update_mem(Bs, r, sBs, sr);
+    }
+    // B += -(Bs Bs^T)/sBs + (r r^T)/sr, element by element in the HBM workspace
+    __device__ void rank2_update_mem(const double* Bs, const double* r, double sBs, double sr) {
+        const int ln = lane_id();
         for (int j = 0; j < n; ++j) {
             const double Bsj = Bs[j], rj = r[j];
             for (int i = ln; i < n; i += WAVE) {
@@ -433,12 +457,12 @@ struct SqpDevice {
         const long long l0 = now();
         ocp.stage_first_order(v.x);
         const long long l1 = now();
-        ocp.assemble_first_order(v.al, Aw, v.h, ldw);
+        ocp.assemble_first_order(v.al, Aw, v.h, ldw, false);   // J's zeros and D entries are already in place
         const long long l3 = now();
         lagrangian_gradient(v.lgn);
         acc(10, l1 - l0); acc(12, l3 - l1); acc(14, now() - l3);
         const long long b0 = now();
-        bfgs_update();
+        if constexpr (NN > 0) { double brow[NN > 0 ? NN : 1]; bfgs_load_row(brow); bfgs_update_reg(brow); } else bfgs_update();
         acc(5, now() - b0);
         for (int i = lane_id(); i < n; i += WAVE) v.lg[i] = v.lgn[i];
         wsync();

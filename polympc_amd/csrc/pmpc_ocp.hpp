@@ -268,7 +268,7 @@ struct Ocp {
         const int n = dm.n, m = dm.m;
         if (structure) {
             for (int e = ln; e < m * n; e += WAVE) J[(e % m) + (size_t)(e / m) * ldj] = 0.0;
-            __threadfence_block();
+            wfence();
         }
         for (int i = ln; i < n; i += WAVE) cost_grad[i] = 0.0;
         wsync();
@@ -322,7 +322,7 @@ struct Ocp {
         for (int sg = 0; sg < S; ++sg)
             for (int k = 0; k <= P; ++k) cst += ts * s.w[k] * s.Lval[sg * P + k];
         cst += s.Mval[0];
-        __threadfence_block();
+        wfence();
         wsync();
         return cst;
     }
@@ -333,7 +333,7 @@ struct Ocp {
         const int ln = lane_id();
         const int n = dm.n;
         for (int e = ln; e < n * n; e += WAVE) H[(e % n) + (size_t)(e / n) * ldh] = 0.0;
-        __threadfence_block();
+        wfence();
         wsync();
         // blocks that do not involve the (p,p) corner are private to their node
         for (int k = ln; k < dm.NN; k += WAVE) {
@@ -349,7 +349,7 @@ struct Ocp {
                 }
         }
         if constexpr (NP > 0) {
-            __threadfence_block();
+            wfence();
             wsync();
             // (p,p) corner: sequential accumulation in reference order; Mayer pp-block lands in the bottom-LEFT corner (Q4)
             for (int e = ln; e < NP * NP; e += WAVE) {
@@ -360,14 +360,14 @@ struct Ocp {
                 for (int k = 0; k < dm.NN; ++k) a += s.dhes[(k * NDER + NX + NU + i) * NDER + NX + NU + r];
                 H[(n - NP + r) + (size_t)(n - NP + i) * ldh] = a;
             }
-            __threadfence_block();
+            wfence();
             wsync();
             for (int e = ln; e < NP * NP; e += WAVE) {
                 const int a_ = e % NP, b_ = e / NP;
                 H[(n - NP + a_) + (size_t)b_ * ldh] += s.Mhes[b_ * NDER + (NDER - NP + a_)];
             }
         }
-        __threadfence_block();
+        wfence();
         wsync();
     }
 };

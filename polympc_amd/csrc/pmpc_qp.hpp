@@ -20,9 +20,15 @@ constexpr double RHO_MIN = 1e-6, RHO_MAX = 1e+6, RHO_EQ_FACTOR = 1e+3;   // box_
 constexpr double LOOSE_BOUNDS_THRESH = 1e+10, EQ_TOL = 1e-4;            // qp_base.hpp:124-125
 constexpr double DIV_BY_ZERO_REGUL = 10e-10;                            // qp_base.hpp:79-82
 
-__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
-// one wavefront per workgroup: this is a compiler + LDS ordering fence, not a cross-wave barrier
-__device__ __forceinline__ void wsync() { __syncthreads(); }
+// opaque on purpose: per-lane index arithmetic derived from it is recomputed where it is used instead of being hoisted
+// to the kernel prologue and kept (or spilled) for the whole SQP loop
+__device__ __forceinline__ int lane_id() { int l = threadIdx.x & (WAVE - 1); asm volatile("" : "+v"(l)); return l; }
+// One wavefront per workgroup: every producer / consumer pair of LDS or workspace data sits in the SAME wavefront, whose
+// memory instructions are issued and performed in program order. Synchronisation is therefore a wavefront-scope fence
+// (orders the compiler, emits no s_waitcnt vmcnt(0) / s_barrier — a workgroup-scope __syncthreads would stall every
+// phase boundary until all outstanding workspace stores have been acknowledged by L2).
+__device__ __forceinline__ void wfence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+__device__ __forceinline__ void wsync() { wfence(); __builtin_amdgcn_wave_barrier(); }
 
 // A zero the optimiser cannot see through. Added to the per-lane element offset of global-memory accesses inside the SQP /
 // ADMM loops, it keeps their address arithmetic next to the access: otherwise every one of the O(n) distinct 64-bit

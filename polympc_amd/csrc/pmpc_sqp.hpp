@@ -327,7 +327,7 @@ struct SqpDevice {
             ri -= fabs(aii);
             if (aii - ri <= 0) Hw[(size_t)i * ldw + i] = aii + ((ri - aii) + 0.01);
         }
-        __threadfence_block();
+        wfence();
         wsync();
     }
 
@@ -407,7 +407,7 @@ struct SqpDevice {
 #pragma unroll
             for (int j = 0; j < NN; ++j) Hw[io + (unsigned)(j * (NN + MM))] = brow[j];
         }
-        __threadfence_block();
+        wfence();
         wsync();
     }
     __device__ void bfgs_update() {
@@ -447,7 +447,7 @@ struct SqpDevice {
                 Hw[(size_t)j * ldw + i] = b;
             }
         }
-        __threadfence_block();
+        wfence();
         wsync();
     }
 

@@ -33,13 +33,30 @@ def qp_algorithmic_flops(n, m, it, f):
     return f * N ** 3 / 3.0 + it * (2.0 * N * N + 12.0 * N) + chk * 2.0 * (n * n + 2 * m * n)
 
 
+def measured_traffic():
+    """HBM bytes per launch of the bench kernel from the committed PMC summary of this round (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate passes, corrected by the calibration kernel; tests/tools_pmc.sh + tests/tools_pmc_summary.py).
+    bench.py cannot run rocprofv3 around itself, so it reports the number measured on the same command line."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json"))):
+        try:
+            t = json.load(open(f)).get("traffic")
+        except Exception:
+            t = None
+        if t:
+            best = (t["bytes_per_launch"], os.path.basename(f))
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="OCP instances per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=2048, help="instances in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="instances per pass of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="minimum wall time of the CPU-baseline sample")
     args = ap.parse_args()
 
     import numpy as np
@@ -109,6 +126,7 @@ def main():
         flops_launch = qp_algorithmic_flops(n, m, it_per_qp, 1.0) * qp_solves
         ach_gbs = bytes_launch / (kernel_ms * 1e-3) / 1e9
         ach_tf = flops_launch / (kernel_ms * 1e-3) / 1e12
+        tr = measured_traffic() if B == 4096 else None
         out = {
             "metric": "box-ADMM QP subproblem solves/s (fused SQP hot path)", "value": value, "unit": "QP solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -119,8 +137,10 @@ def main():
             "sqp_solves_per_s": B * world * args.steps / elapsed, "qp_solves_per_step": qp_all, "admm_iters_per_qp": admm_all / max(qp_all, 1),
             "sqp_solved_fraction": solved_all / (B * world),
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach_gbs / PEAK_HBM_GBS,
-                         "traffic": None, "kernel": "sqp_kernel<RobotOCP>", "kernel_ms": kernel_ms,
-                         "note": "algorithmic bytes = 17616 B per QP subproblem x QPs per launch (SURVEY 8d); the path is fp64-VALU/latency bound, see roofline_fp64"},
+                         "traffic": (tr[0] if tr else None), "traffic_source": (("profiles/" + tr[1]) if tr else None),
+                         "algorithmic_bytes_per_launch": bytes_launch, "kernel": "sqp_kernel<RobotOCP,35,21>", "kernel_ms": kernel_ms,
+                         "note": "algorithmic bytes = 17616 B per QP subproblem x QPs per launch (SURVEY 8d); the path is bound by fp64 issue / "
+                                 "dependent-chain latency, not by HBM: see roofline_fp64 and DESIGN.md"},
             "roofline_fp64": {"bound": "fp64-valu", "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / PEAK_FP64_TFLOPS},
         }
         if args.cpu_sample > 0 and world == 1:
@@ -128,14 +148,17 @@ def main():
             Bc = min(args.cpu_sample, B)
             cores = os.cpu_count() or 1
             oss = ob.sqp_default_settings(); oss.max_iter = wl["max_iter"]; oss.line_search_max_iter = wl["ls_max_iter"]
-            tc = time.perf_counter()
-            xo, lo, io = ob.sqp_solve_batch(ob.MODEL_ROBOT, wl["P"], wl["S"], wl["t0"], wl["tf"], Bc, wl["d"][:Bc], wl["lbx"][:Bc], wl["ubx"][:Bc],
-                                            sqp_settings=oss, pivot=ob.PIVOT_EIGEN, threads=cores)
-            tc = time.perf_counter() - tc
-            cpu_qps = sum(i.iter for i in io)
+            tc, cpu_qps, passes = 0.0, 0, 0
+            while tc < args.cpu_seconds and passes < 2000:   # bounded sample: repeated passes over the same instances
+                t1 = time.perf_counter()
+                xo, lo, io = ob.sqp_solve_batch(ob.MODEL_ROBOT, wl["P"], wl["S"], wl["t0"], wl["tf"], Bc, wl["d"][:Bc], wl["lbx"][:Bc], wl["ubx"][:Bc],
+                                                sqp_settings=oss, pivot=ob.PIVOT_EIGEN, threads=cores)
+                tc += time.perf_counter() - t1
+                cpu_qps += sum(i.iter for i in io)
+                passes += 1
             out["cpu_baseline"] = {"value": cpu_qps / tc, "unit": "QP solves/s", "cores": cores, "kind": "port",
-                                   "sample": "first %d instances of the same batch, CPU restatement of the reference SQP+boxADMM (Eigen-like pivoted LDLT), "
-                                             "OpenMP over instances, %.2f s" % (Bc, tc)}
+                                   "sample": "%d passes over the first %d instances of the same batch, CPU restatement of the reference SQP+boxADMM "
+                                             "(Eigen-like pivoted LDLT, gcc -O2 AVX2), OpenMP over instances on all host threads, %.1f s" % (passes, Bc, tc)}
             xg = d_x.cpu().numpy()[:Bc]
             same = np.array([i.iter for i in io]) == info["iter"][:Bc]
             out["parity_vs_cpu_sample"] = {"same_iteration_count_fraction": float(same.mean()),

@@ -14,5 +14,23 @@ for name in ["sq1", "sq2", "fetch", "write", "calfetch", "calwrite"]:
             agg[(kn.split("(")[0][-60:], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (kn, cn), v in agg.items():
         out.setdefault(name, {})[f"{cn} [{kn}]"] = {"per_launch_mean": sum(v) / len(v), "launches": len(v)}
+# HBM traffic per launch of the bench kernel, corrected with the calibration run (MI355X_MICROARCH.md, HBM / rocprofv3
+# section): the counters are in KiB-sized units; the calibration kernel reads 2^30 B and writes 2^29 B with the same
+# 8-byte-per-lane access width, which gives the byte value of one counter unit for this access pattern.
+def _one(d, key):
+    for k, v in d.items():
+        if k.startswith(key):
+            return v["per_launch_mean"]
+    return None
+try:
+    f_unit = (1 << 30) / _one(out["calfetch"], "FETCH_SIZE")
+    w_unit = (1 << 29) / _one(out["calwrite"], "WRITE_SIZE")
+    fetch = _one(out["fetch"], "FETCH_SIZE") * f_unit
+    write = _one(out["write"], "WRITE_SIZE") * w_unit
+    out["traffic"] = {"fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "bytes_per_launch": fetch + write,
+                      "bytes_per_counter_unit": {"FETCH_SIZE": f_unit, "WRITE_SIZE": w_unit},
+                      "workload": "bench.py --steps 5 --warmup 1 (config A, batch 4096), sqp_kernel<RobotOCP,35,21>"}
+except Exception as e:  # incomplete collection
+    out["traffic"] = None
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -113,7 +113,8 @@ struct LDLT {
     //   in-panel scalar sweeps   t = 0..7, k = kb+t:  r = 1/p[k][t];  l_i = p[i][t]*r;
     //                            u != t:  p[i][u] = fma(-l_i, p[k][u], p[i][u]) (i != k),  p[k][u] = p[k][u]*r;
     //                            p[i][t] = l_i (i != k),  p[k][t] = -r
-    //   trailing update          i, j outside the block:  M[i][j] = fma(-p[i][t], Cold[j][t], M[i][j]),  t ascending
+    //   trailing update          i, j outside the block, i/16 >= j/16 (block-lower storage in 16x16 tiles; the other
+    //                            entries are their mirror images):  M[i][j] = fma(-p[i][t], Cold[j][t], M[i][j]),  t ascending
     //   write-back               M[:, block] = p,  then M[block, :] = p^T
     void compute_sweep() {
         auto at = [&](int i, int j) -> double& { return M[i + j * n]; };
@@ -135,10 +136,11 @@ struct LDLT {
                 }
                 for (int i = 0; i < n; ++i) p[i * BK + t] = (i == k) ? -r : l[i];
             }
+            // block-lower storage in 16x16 tiles: an entry (i, j) with i/16 < j/16 is not stored, it IS entry (j, i)
             for (int j = 0; j < n; ++j) {
                 if (j >= kb && j < kb + w) continue;
                 for (int i = 0; i < n; ++i) {
-                    if (i >= kb && i < kb + w) continue;
+                    if ((i >= kb && i < kb + w) || i / 16 < j / 16) continue;
                     double a = at(i, j);
                     for (int t = 0; t < w; ++t) a = std::fma(-p[i * BK + t], cold[j * BK + t], a);
                     at(i, j) = a;
@@ -146,6 +148,7 @@ struct LDLT {
             }
             for (int t = 0; t < w; ++t) for (int i = 0; i < n; ++i) at(i, kb + t) = p[i * BK + t];
             for (int t = 0; t < w; ++t) for (int j = 0; j < n; ++j) at(kb + t, j) = p[j * BK + t];
+            for (int j = 0; j < n; ++j) for (int i = 0; i < j; ++i) if (i / 16 < j / 16) at(i, j) = at(j, i);
         }
     }
 

@@ -53,6 +53,13 @@ __device__ __forceinline__ double mov_lanes_range(double dst, double src, int lo
     return dst;
 }
 
+// a0..a6 <- 0 on lane `k` only (compile-time k): one EXEC switch for the seven moves
+__device__ __forceinline__ void zero_on_lane(double& a0, double& a1, double& a2, double& a3, double& a4, double& a5, double& a6, int k) {
+    asm("s_lshl_b64 exec, 1, %7\n\tv_mov_b64 %0, 0\n\tv_mov_b64 %1, 0\n\tv_mov_b64 %2, 0\n\tv_mov_b64 %3, 0\n\tv_mov_b64 %4, 0\n\tv_mov_b64 %5, 0\n\t"
+        "v_mov_b64 %6, 0\n\ts_mov_b64 exec, -1"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6) : "i"(k) : "scc");
+}
+
 template <int N>
 struct RegKkt {
     double a[N];  // row `lane` of W = -K^{-1}
@@ -77,19 +84,22 @@ struct RegKkt {
     static_assert(N <= 64 && SK % 32 == 16 && SK >= 64, "panel stride");
 
     // W = -K^{-1} by the symmetric sweep operator, static pivot order (K is quasi-definite: every pivot is non-zero),
-    // in blocks of BK = 8 pivots. The matrix lives in 16x16 fp64 MFMA accumulator tiles T[R][C] (full storage).
+    // in blocks of BK = 8 pivots. The matrix lives in 16x16 fp64 MFMA accumulator tiles T[R][C], C <= R (block-lower
+    // storage: a tile above the block diagonal is the transpose of its mirror image and is never materialised).
     // Block step on pivots kb..kb+7:
-    //   1. the panel M[:, block] goes tiles -> exchange buffer -> row-per-lane registers p[8]
+    //   1. the panel M[:, block] goes tiles -> exchange buffer -> row-per-lane registers p[8] (rows above the pivot tile
+    //      row come out of the pivot tile ROW, transposed)
     //   2. PB <- old panel (B operand)
-    //   3. in-panel scalar sweeps (v_readlane broadcasts of the pivot row):  r = 1/p_k[t];  l_i = p_i[t]*r;
-    //        u != t:  p_i[u] <- fma(-l_i, p_k[u], p_i[u]) (i != k),  p_k[u] <- p_k[u]*r;   p_i[t] <- l_i,  p_k[t] <- -r
+    //   3. in-panel scalar sweeps (v_readlane broadcasts of the pivot row):  r = 1/p_k[t];  l_i = p_i[t]*r (i != k), l_k = -r;
+    //        u != t:  p_k[u] <- 0, then p_i[u] <- fma(-l_i, pivotrow[u], p_i[u]) on every lane (lane k: = pivotrow[u]*r);  p[t] <- l
     //   4. PA <- -p (A operand); rows of the block are zero in PA and PB, so the update leaves block rows / columns alone
-    //   5. all tiles:  T[R][C] <- T[R][C] + PA_R * PB_C^T  (two v_mfma_f64_16x16x4_f64 each; the instruction is a
+    //   5. stored tiles:  T[R][C] <- T[R][C] + PA_R * PB_C^T  (two v_mfma_f64_16x16x4_f64 each; the instruction is a
     //      k-ascending fma chain — verified on gfx950, tests/experiments/mfma_f64_probe.hip — so every entry receives
     //      fma(-p_i[t], old_j[t], m_ij) for t ascending, which is what the CPU checker of the test suite restates)
-    //   6. write-back: M[:, block] <- p, then M[block, :] <- p^T, through the exchange buffer
+    //   6. write-back: M[:, block] <- p into the pivot tile column, then M[block, :] <- p^T into the pivot tile row
     // Finally the tiles are converted to row-per-lane registers a[] for the mat-vec.
-    // kcol(j, z) returns K(lane, j) for j != lane (z: see below); it is called 8 columns at a time, one group ahead of use. diag = K(lane, lane).
+    // kcol(j, z) returns K(lane, j) for j != lane, needed for j <= 16*(lane/16)+15 only (z: see below); it is called 8
+    // columns at a time, one group ahead of use. diag = K(lane, lane).
     template <class KCol>
     __device__ __forceinline__ void invert(int ln_in, double* st, double diag, KCol kcol) {
         int ln = ln_in;
@@ -98,7 +108,7 @@ struct RegKkt {
         double* PB = st + BK * SK;
         double* X = PB;
         const int lr = ln >> 4, lc = ln & 15;
-        d4 T[NT][NT];
+        d4 T[NT][NT];   // only C <= R is used
         // row layout -> accumulator tiles, 8 columns at a time (loads of the next group are in flight while this one is staged)
         // `z` is an opaque zero that kcol adds to its addresses: redefining it once per group pins each group's loads
         // behind the previous group's staging (loads from read-only kernel arguments may otherwise be hoisted to the
@@ -120,7 +130,7 @@ struct RegKkt {
             lds_order();
             if ((lc >> 3) == (g % 2)) {
 #pragma unroll
-                for (int R = 0; R < NT; ++R)
+                for (int R = g / 2; R < NT; ++R)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) T[R][g / 2][r] = X[(16 * R + lr + 4 * r) * SX + (lc & 7)];
             }
@@ -133,13 +143,18 @@ struct RegKkt {
         for (int b = 0; b < NB; ++b) {
             const int kb = b * BK;
             const int Cb = kb / 16, hb = (kb % 16) / BK;
-            // 1. panel: tile column Cb, tile-local columns [8*hb, 8*hb+8) -> row-per-lane registers
+            // 1. panel -> row-per-lane registers: rows of tile rows >= Cb from tile column Cb (tile-local columns
+            //    [8*hb, 8*hb+8)), rows of tile rows < Cb from tile row Cb (tile-local rows [8*hb, 8*hb+8), transposed)
             if ((lc >> 3) == hb) {
 #pragma unroll
-                for (int R = 0; R < NT; ++R)
+                for (int R = Cb; R < NT; ++R)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) X[(16 * R + lr + 4 * r) * SX + (lc & 7)] = T[R][Cb][r];
             }
+#pragma unroll
+            for (int C = 0; C < Cb; ++C)
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) X[(16 * C + lc) * SX + lr + 4 * rr] = T[Cb][C][2 * hb + rr];
             lds_order();
             double p[BK];
 #pragma unroll
@@ -156,16 +171,16 @@ struct RegKkt {
                 if (k < N) {
                     const double dk = bcast_lane(p[t], k);
                     const double r = 1.0 / dk;
-                    const bool isk = (ln == k);
-                    const double l = p[t] * r;
+                    double rk[BK];
+#pragma unroll
+                    for (int u = 0; u < BK; ++u) rk[u] = (u != t) ? bcast_lane(p[u], k) : 0.0;
+                    const double l = (ln == k) ? -r : p[t] * r;
+                    // the seven other columns of lane k start from zero, so that one fma serves every lane
+                    zero_on_lane(p[(t + 1) & 7], p[(t + 2) & 7], p[(t + 3) & 7], p[(t + 4) & 7], p[(t + 5) & 7], p[(t + 6) & 7], p[(t + 7) & 7], k);
 #pragma unroll
                     for (int u = 0; u < BK; ++u)
-                        if (u != t && kb + u < N) {
-                            const double rk = bcast_lane(p[u], k);
-                            const double upd = fma(-l, rk, p[u]);
-                            p[u] = isk ? rk * r : upd;
-                        }
-                    p[t] = isk ? -r : l;
+                        if (u != t) p[u] = fma(-l, rk[u], p[u]);
+                    p[t] = l;
                     sched_fence();
                 }
             }
@@ -173,7 +188,7 @@ struct RegKkt {
 #pragma unroll
             for (int t = 0; t < BK; ++t) PA[t * SK + ln] = (inb || kb + t >= N) ? 0.0 : -p[t];
             lds_order();
-            // 5. rank-8 update of every tile
+            // 5. rank-8 update of every stored tile
 #pragma unroll
             for (int s2 = 0; s2 < BK / 4; ++s2) {
                 double av[NT], bv[NT];
@@ -185,36 +200,40 @@ struct RegKkt {
 #pragma unroll
                 for (int R = 0; R < NT; ++R)
 #pragma unroll
-                    for (int C = 0; C < NT; ++C) T[R][C] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[R], bv[C], T[R][C], 0, 0, 0);
+                    for (int C = 0; C <= R; ++C) T[R][C] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[R], bv[C], T[R][C], 0, 0, 0);
                 sched_fence();
             }
             lds_order();
-            // 6. write-back of the swept panel: columns, then rows (the diagonal block ends up as the transpose of p)
+            // 6. write-back of the swept panel: pivot tile column, then pivot tile row (the diagonal block ends up as the transpose of p)
 #pragma unroll
             for (int t = 0; t < BK; ++t) X[ln * SX + t] = p[t];
             lds_order();
             if ((lc >> 3) == hb) {
 #pragma unroll
-                for (int R = 0; R < NT; ++R)
+                for (int R = Cb; R < NT; ++R)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) T[R][Cb][r] = X[(16 * R + lr + 4 * r) * SX + (lc & 7)];
             }
 #pragma unroll
-            for (int C = 0; C < NT; ++C)
+            for (int C = 0; C <= Cb; ++C)
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) T[Cb][C][2 * hb + rr] = X[(16 * C + lc) * SX + lr + 4 * rr];
             lds_order();
             sched_fence();
         }
-        // accumulator tiles -> row-per-lane registers
+        // accumulator tiles -> row-per-lane registers (columns of tile rows above the diagonal come from the mirror tiles)
 #pragma unroll
         for (int g = 0; g < NB; ++g) {
             if ((lc >> 3) == (g % 2)) {
 #pragma unroll
-                for (int R = 0; R < NT; ++R)
+                for (int R = g / 2; R < NT; ++R)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) X[(16 * R + lr + 4 * r) * SX + (lc & 7)] = T[R][g / 2][r];
             }
+#pragma unroll
+            for (int C = 0; C < g / 2; ++C)
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) X[(16 * C + lc) * SX + lr + 4 * rr] = T[g / 2][C][2 * (g % 2) + rr];
             lds_order();
 #pragma unroll
             for (int t = 0; t < BK; ++t)

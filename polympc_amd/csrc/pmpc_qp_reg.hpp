@@ -383,7 +383,7 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
             if (check || adapt) {  // residuals_update, box_admm.hpp:398-415
                 const long long r0 = dbg ? clock64() : 0;
                 // loads in chunks of RC columns (independent, coalesced), each followed by its slice of the mat-vec chain
-                constexpr int RC = 8;
+                constexpr int RC = 12;
                 int zr = 0;            // opaque zero added to the addresses: keeps these loop-invariant loads inside the loop
                 asm volatile("" : "+v"(zr));
                 double acc = 0.0;      // lanes < n: (H x)_i ; lanes in [n, N): (A x)_r

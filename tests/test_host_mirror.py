@@ -35,3 +35,11 @@ def test_host_mirror_reference_style_cases():
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ALL PASSED" in r.stdout
+
+
+def test_uniform_divisor_quotient_is_the_ieee_quotient():
+    """The 5-operation corrected quotient the BFGS update uses for its two wave-uniform divisors (UniformDiv) equals a / b
+    bit for bit: 20 M random and structured (significands next to 1 and 2) operand pairs, restated on the CPU."""
+    _build()
+    r = subprocess.run([os.path.join(CPP, "uniform_div_check"), "20000000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout + r.stderr

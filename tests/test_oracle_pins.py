@@ -106,7 +106,7 @@ def _is_approx(a, b, prec):
     return np.linalg.norm(a - b) <= prec * min(np.linalg.norm(a), np.linalg.norm(b))
 
 
-@pytest.mark.parametrize("pivot", [0, 1])
+@pytest.mark.parametrize("pivot", [0, 1, 2])
 def test_boxadmm_simple_qp(oracle, pivot):  # :15-45
     s = oracle.qp_default_settings(); s.max_iter = 150
     x, y, info = oracle.qp_solve_batch(*_simple_qp(), settings=s, pivot=pivot)
@@ -114,7 +114,7 @@ def test_boxadmm_simple_qp(oracle, pivot):  # :15-45
     assert info[0].iter < 150 and info[0].status == oracle.QP_SOLVED
 
 
-@pytest.mark.parametrize("pivot", [0, 1])
+@pytest.mark.parametrize("pivot", [0, 1, 2])
 def test_boxadmm_constraint_violation(oracle, pivot):  # :117-155
     s = oracle.qp_default_settings(); s.eps_rel = 1e-4; s.eps_abs = 1e-4
     x, y, info = oracle.qp_solve_batch(*_simple_qp(), settings=s, pivot=pivot)
@@ -153,9 +153,26 @@ def test_ldlt_policies_agree(oracle):
     K = np.block([[H, A.T], [A, -np.diag(rng.uniform(0.01, 10, m))]])
     b = rng.normal(size=n + m)
     x_ref = np.linalg.solve(K, b)
-    for piv in (0, 1):
+    for piv in (0, 1, 2):
         x = oracle.ldlt_solve(np.tril(K), b, piv)          # only the lower triangle is read
         assert np.abs(x - x_ref).max() < 1e-9
+
+
+@pytest.mark.parametrize("n,m", [(35, 21), (25, 15), (5, 3), (40, 24)])
+def test_sweep_inverse_policy_matches_factorisations(oracle, n, m):
+    """The swept-inverse restatement (block-lower 16x16 tile storage, blocks of 8 pivots) against numpy and against both LDL^T
+    policies on quasi-definite KKT matrices with the conditioning of the ADMM (sigma = 1e-6, rho between 1e-1 and 1e2);
+    sizes cover n+m = 56 (config A), 40 (5-node grids), one partial block (8) and the 64-row limit."""
+    rng = np.random.default_rng(n * 100 + m)
+    G = rng.normal(size=(n, n)); H = G @ G.T / n + (1e-6 + 0.1) * np.eye(n); A = rng.normal(size=(m, n))
+    K = np.block([[H, A.T], [A, -np.diag(1.0 / rng.choice([0.1, 100.0], m))]])
+    b = rng.normal(size=n + m)
+    x_ref = np.linalg.solve(K, b)
+    scale = np.abs(x_ref).max()
+    xs = oracle.ldlt_solve(np.tril(K), b, oracle.PIVOT_SWEEP)
+    assert np.abs(xs - x_ref).max() < 1e-9 * scale
+    for piv in (oracle.PIVOT_EIGEN, oracle.PIVOT_STATIC):
+        assert np.abs(xs - oracle.ldlt_solve(np.tril(K), b, piv)).max() < 1e-9 * scale
 
 
 # ---------------------------------------------------------------- A12: BFGS (bfgs_test.cpp:21-66)
@@ -266,8 +283,8 @@ def test_sqp_cstr(oracle):  # cstr_control_test.cpp:137-183 (Eigen pivot policy)
 
 
 def test_static_and_eigen_pivot_agree_on_config_A(oracle):
-    """The static (GPU) elimination order and Eigen's pivoted order give the same SQP trajectory to rounding on the
-    benchmark configuration (H positive definite throughout)."""
+    """The two GPU-order restatements (static LDL^T, swept inverse) and Eigen's pivoted order give the same SQP trajectory
+    to rounding on the benchmark configuration (H positive definite throughout)."""
     ss = oracle.sqp_default_settings(); ss.max_iter = 10; ss.line_search_max_iter = 10
     rng = np.random.default_rng(0)
     B = 8
@@ -277,7 +294,26 @@ def test_static_and_eigen_pivot_agree_on_config_A(oracle):
     d = np.full((B, 1), 2.0)
     xe, le, ie = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 6, 1, 0.0, 2.0, B, d, np.array(lb), np.array(ub), sqp_settings=ss, pivot=0)
     xs, ls, is_ = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 6, 1, 0.0, 2.0, B, d, np.array(lb), np.array(ub), sqp_settings=ss, pivot=1)
+    xw, lw, iw = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 6, 1, 0.0, 2.0, B, d, np.array(lb), np.array(ub), sqp_settings=ss, pivot=2)
     for b in range(B):
-        assert ie[b].iter == is_[b].iter and ie[b].status == is_[b].status
-        assert ie[b].qp_solver_iter == is_[b].qp_solver_iter
-    assert np.abs(xe - xs).max() < 1e-8
+        assert ie[b].iter == is_[b].iter == iw[b].iter and ie[b].status == is_[b].status == iw[b].status
+        assert ie[b].qp_solver_iter == is_[b].qp_solver_iter == iw[b].qp_solver_iter
+    assert np.abs(xe - xs).max() < 1e-8 and np.abs(xe - xw).max() < 1e-8
+    assert np.abs(le - lw).max() < 1e-6
+
+
+def test_sweep_policy_on_benchmark_stream(oracle):
+    """256 instances of the benchmark's own synthetic stream: the swept-inverse order follows the Eigen-pivoted trajectory
+    (same SQP and ADMM iteration counts) with |dx| <= 1e-8 — the tolerance north_star states."""
+    from polympc_amd import workloads
+    B = 256
+    wl = workloads.robot_batch(B)
+    ss = oracle.sqp_default_settings(); ss.max_iter = wl["max_iter"]; ss.line_search_max_iter = wl["ls_max_iter"]
+    r = {}
+    for piv in (oracle.PIVOT_EIGEN, oracle.PIVOT_SWEEP):
+        x, l, info = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"],
+                                            sqp_settings=ss, pivot=piv, threads=8)
+        r[piv] = (x, np.array([i.iter for i in info]), np.array([i.qp_solver_iter for i in info]))
+    same = (r[0][1] == r[2][1]) & (r[0][2] == r[2][2])
+    assert same.mean() >= 0.99
+    assert np.abs(r[0][0] - r[2][0])[same].max() <= 1e-8

@@ -27,9 +27,12 @@ struct RobotOCP {
     }
     template <class T>
     __device__ void dynamics_impl(cref<T> x, cref<T> u, cref<T>, cref<double> d, const T&, vref<T> xdot) const {
-        xdot(0) = u(0) * cos(x(2)) * cos(u(1));
-        xdot(1) = u(0) * sin(x(2)) * cos(u(1));
-        xdot(2) = u(0) * sin(u(1)) / T(d(0));
+        // the reference's expressions with each angle's sine and cosine evaluated once (same values, same products)
+        T s2, c2, s1, c1;
+        sincos(x(2), s2, c2); sincos(u(1), s1, c1);
+        xdot(0) = u(0) * c2 * c1;
+        xdot(1) = u(0) * s2 * c1;
+        xdot(2) = u(0) * s1 / T(d(0));
     }
     template <class T>
     __device__ void lagrange_term_impl(cref<T> x, cref<T> u, cref<T>, cref<double>, double, T& lagrange) const {
@@ -103,9 +106,11 @@ struct ParkingOCP {
     __host__ void set_params(const double*, int) {}
     template <class T>
     __device__ void dynamics_impl(cref<T> x, cref<T> u, cref<T> p, cref<double> d, const T&, vref<T> xdot) const {
-        xdot(0) = p(0) * u(0) * cos(x(2)) * cos(u(1));
-        xdot(1) = p(0) * u(0) * sin(x(2)) * cos(u(1));
-        xdot(2) = p(0) * u(0) * sin(u(1)) / T(d(0));
+        T s2, c2, s1, c1;
+        sincos(x(2), s2, c2); sincos(u(1), s1, c1);
+        xdot(0) = p(0) * u(0) * c2 * c1;
+        xdot(1) = p(0) * u(0) * s2 * c1;
+        xdot(2) = p(0) * u(0) * s1 / T(d(0));
     }
     template <class T>
     __device__ void lagrange_term_impl(cref<T>, cref<T>, cref<T>, cref<double>, double, T&) const {}

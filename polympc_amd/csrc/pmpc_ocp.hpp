@@ -221,8 +221,11 @@ struct Ocp {
 
     // ---- per-node second-order stage: d2L, Mayer Hessian, and hes = -t_scale*sum lam_q d2f_q + sum lam_g d2g (:2128-2157)
     __device__ void stage_second_order(const double* var, const double* lam) {
-        for (int k = lane_id(); k < dm.NN; k += WAVE) {
-            for (int dir = 0; dir < NDER; ++dir) {
+        // one lane per (node, outer seed direction): the NDER directional passes of a node are independent, so they run
+        // side by side on NN*NDER lanes instead of one after the other on NN lanes (same arithmetic per entry)
+        for (int kd = lane_id(); kd < dm.NN * NDER; kd += WAVE) {
+            const int k = kd % dm.NN, dir = kd / dm.NN;
+            {
                 ad2c x[NX > 0 ? NX : 1], u[NU > 0 ? NU : 1], p[NP > 0 ? NP : 1], y[NX > 0 ? NX : 1];
                 seed2(var, k, dir, x, u, p);
                 ad2c L(0.0);

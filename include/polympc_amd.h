@@ -104,8 +104,8 @@ pmpc_status pmpc_destroy(pmpc_context* ctx);
 pmpc_status pmpc_synchronize(pmpc_context* ctx);
 /* Profiling aid (PMPC_PHASE_PROFILE=1 at pmpc_create): shader-clock cycles summed over instances since the last reset:
  * [0] linearisation (+Hessian update) [1] QP [2] line search [3] termination test [4] whole SQP loop [5] BFGS
- * [6] KKT build + factorisation [7] QP residuals [8..15] finer slices (see tests/tools_phase_profile.py). 16 values. */
-pmpc_status pmpc_debug_phase_cycles(pmpc_context* ctx, unsigned long long* out16, int reset);
+ * [6] KKT build + factorisation [7] QP residuals [8..23] finer slices (see tests/tools_phase_profile.py). 24 values. */
+pmpc_status pmpc_debug_phase_cycles(pmpc_context* ctx, unsigned long long* out24, int reset);
 
 void pmpc_qp_settings_default(pmpc_qp_settings* s);      /* qp_base.hpp:17-53 */
 void pmpc_qp_settings_sqp_default(pmpc_qp_settings* s);  /* + sqp_base.hpp:83-90 */

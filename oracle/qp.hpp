@@ -12,7 +12,7 @@
 // /root/reference; the two pivot policies below restate its published algorithm:
 //   PIVOT_EIGEN  : symmetric max-|diag| pivoting, left-looking column update, D^+ solve (Eigen semantics)
 //   PIVOT_SWEEP  : no factorisation at all — W = -K^{-1} by the symmetric sweep operator in blocks of 8 pivots
-//                  (static order) and x = -(W b) as a mat-vec. This is the arithmetic of the register-resident HIP
+//                  (static order) and x = -(W b) as a mat-vec (block partial sums). This is the arithmetic of the register-resident HIP
 //                  kernel (polympc_amd/csrc/pmpc_qp_reg.hpp), restated operation by operation so that the kernel can be
 //                  checked bit for bit; it is tied to the reference only through PIVOT_EIGEN (tests/test_oracle_pins.py
 //                  compares the two policies on the reference's QP fixtures and on the SQP workloads).
@@ -154,11 +154,11 @@ struct LDLT {
 
     void solve(const double* b, double* x) const {
         auto at = [&](int i, int j) -> double { return M[i + j * n]; };
-        if (policy == PIVOT_SWEEP) {   // x = -(W b): four interleaved partial sums (j mod 4), combined as (s0+s1)+(s2+s3)
+        if (policy == PIVOT_SWEEP) {   // x = -(W b): one fma chain per block of 16 columns (P_r, r = j/16), combined as (P0+P2)+(P1+P3)
             for (int i = 0; i < n; ++i) {
                 double acc[4] = {0.0, 0.0, 0.0, 0.0};
-                for (int j = 0; j < n; ++j) acc[j & 3] = std::fma(at(i, j), b[j], acc[j & 3]);
-                x[i] = -((acc[0] + acc[1]) + (acc[2] + acc[3]));
+                for (int j = 0; j < n; ++j) acc[j >> 4] = std::fma(at(i, j), b[j], acc[j >> 4]);
+                x[i] = -((acc[0] + acc[2]) + (acc[1] + acc[3]));
             }
             return;
         }

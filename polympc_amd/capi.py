@@ -153,7 +153,7 @@ class Context:
         _check(lib().pmpc_synchronize(self._ctx))
 
     def phase_cycles(self, reset=True):
-        out = (C.c_ulonglong * 16)()
+        out = (C.c_ulonglong * 24)()
         _check(lib().pmpc_debug_phase_cycles(self._ctx, out, 1 if reset else 0))
         return list(out)
 

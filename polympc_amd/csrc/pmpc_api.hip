@@ -170,7 +170,7 @@ pmpc_status pmpc_create(int device, void* stream, pmpc_context** out) {
     { const char* e = getenv("PMPC_FORCE_LDS_PATH"); ctx->force_lds_path = (e && e[0] == '1'); }
     { const char* e = getenv("PMPC_SQP_SLICE"); if (e && e[0]) ctx->sqp_slice = atoi(e) < 0 ? 0 : atoi(e); }
     { const char* e = getenv("PMPC_PHASE_PROFILE");
-      if (e && e[0] == '1') { HIPCHK(hipMalloc((void**)&ctx->phase_cycles, 16 * sizeof(unsigned long long))); HIPCHK(hipMemset(ctx->phase_cycles, 0, 16 * sizeof(unsigned long long))); } }
+      if (e && e[0] == '1') { HIPCHK(hipMalloc((void**)&ctx->phase_cycles, 24 * sizeof(unsigned long long))); HIPCHK(hipMemset(ctx->phase_cycles, 0, 24 * sizeof(unsigned long long))); } }
     *out = ctx;
     return PMPC_OK;
 }
@@ -186,13 +186,13 @@ pmpc_status pmpc_destroy(pmpc_context* ctx) {
     delete ctx;
     return PMPC_OK;
 }
-pmpc_status pmpc_debug_phase_cycles(pmpc_context* ctx, unsigned long long* out16, int reset) {
-    if (!ctx || !out16) return PMPC_ERR_INVALID_ARGUMENT;
-    for (int i = 0; i < 16; ++i) out16[i] = 0;
+pmpc_status pmpc_debug_phase_cycles(pmpc_context* ctx, unsigned long long* out24, int reset) {
+    if (!ctx || !out24) return PMPC_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < 24; ++i) out24[i] = 0;
     if (!ctx->phase_cycles) return PMPC_OK;
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipMemcpy(out16, ctx->phase_cycles, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (reset) HIPCHK(hipMemset(ctx->phase_cycles, 0, 16 * sizeof(unsigned long long)));
+    HIPCHK(hipMemcpy(out24, ctx->phase_cycles, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(hipMemset(ctx->phase_cycles, 0, 24 * sizeof(unsigned long long)));
     return PMPC_OK;
 }
 pmpc_status pmpc_synchronize(pmpc_context* ctx) {

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64, (NN > 0 ? PMPC_SQP_WAVES : 1)) void sqp_kernel(
     for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = v.x[i];
     for (int i = ln; i < m + n; i += WAVE) lam[(size_t)b * (m + n) + i] = v.lam[i];
     if (ln == 0) info[b] = si;
-    if constexpr (PROF) { if (phase_cycles && ln == 0) for (int i = 0; i < 16; ++i) atomicAdd(&phase_cycles[i], (unsigned long long)sqp.cyc[i]); }
+    if constexpr (PROF) { if (phase_cycles && ln == 0) for (int i = 0; i < 24; ++i) atomicAdd(&phase_cycles[i], (unsigned long long)sqp.cyc[i]); }
 }
 // mode 0: KKT factor in LDS; 1: register-resident QP (n+m <= 64); 2: KKT factor in HBM (large instances)
 template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode) {

@@ -4,10 +4,12 @@
 // of every ADMM iteration is organised differently (a different, equally static, order of floating-point operations —
 // the test suite checks it bit for bit against a CPU restatement of exactly this order):
 //   * the KKT matrix is INVERTED once per factorisation point (first iteration and every accepted rho update) with the
-//     symmetric sweep operator in MFMA accumulator tiles (RegKkt::invert), and lane i keeps row i of W = -K^{-1} in a
-//     register array a[N] (compile-time register indices after full unrolling);
-//   * the per-iteration solve is then the mat-vec  x_i = -sum_j a[j] * rhs_j : the rhs entries are broadcast with
-//     v_readlane and all 56 products are independent — no 2N-step substitution chain in the ADMM loop;
+//     symmetric sweep operator in MFMA accumulator tiles (RegKkt::invert), and every lane keeps a 4 x 16 slice of
+//     W = -K^{-1} in a register array (compile-time register indices after full unrolling);
+//   * the per-iteration solve is then the mat-vec  x = -W rhs : lane 16r+c multiplies the 16 columns of block r (rhs entries
+//     broadcast inside the 16-lane row by the DPP modifier of v_fmac_f64 — no v_readlane, no SGPRs) against rows c, c+16,
+//     c+32, c+48, and two permlane swaps add the four block partial sums of every row — no 2N-step substitution chain
+//     in the ADMM loop;
 //   * all ADMM vectors are one register per lane: lanes [0,n) carry x, q, y_box, rho_box, h, xlb, xub; lanes
 //     [n,n+m) carry z, y_a, rho, Alb, Aub. The ADMM iteration therefore runs entirely out of registers.
 //   * H and A are read from HBM/L2 (coalesced down columns) only to build K and, every check_termination-th
@@ -60,9 +62,30 @@ __device__ __forceinline__ void zero_on_lane(double& a0, double& a1, double& a2,
         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6) : "i"(k) : "scc");
 }
 
+// acc <- fma(x of lane J of this lane's 16-lane row, w, acc): the broadcast is a DPP operand modifier of the fma itself
+// (row_newbcast, the one DPP control 64-bit VALU operations accept), so a mat-vec needs no v_readlane / SGPR traffic.
+template <int J>
+__device__ __forceinline__ double fmac_rowbcast(double acc, double x, double w) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(w), "i"(J));
+    return acc;
+}
+// a <-> b exchanges: swap32 trades a's lanes 32..63 with b's lanes 0..31, swap16 a's odd 16-lane rows with b's even rows
+__device__ __forceinline__ void swap32(double& a, double& b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    a = __hiloint2double(hi[0], lo[0]); b = __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ void swap16(double& a, double& b) {
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    a = __hiloint2double(hi[0], lo[0]); b = __hiloint2double(hi[1], lo[1]);
+}
+
 template <int N>
 struct RegKkt {
-    double a[N];  // row `lane` of W = -K^{-1}
+    // W = -K^{-1} in mat-vec layout: lane 16*r + c holds  a[16*q + j] = W(16*q + c, 16*r + j)  (q < NT, j < 16; zero where the
+    // column index is >= N): the 16 columns of block r against the rows c, c+16, c+32, ... — see apply()
+    double a[((N + 15) / 16) * 16];
 
     using d4 = double __attribute__((ext_vector_type(4)));
     static constexpr int BK = 8;                      // pivots swept per block
@@ -79,9 +102,13 @@ struct RegKkt {
     //  Both are sized for all 64 lanes (idle lanes >= N store too; their values are never consumed by live rows).
     static constexpr int SK = 80;
     static constexpr int SX = BK + 1;
-    static constexpr int XSZ = (64 * SX > BK * SK) ? 64 * SX : BK * SK;
+    static constexpr int XSZ = (64 * SX + 64 > BK * SK) ? 64 * SX + 64 : BK * SK;   // 64 exchange rows + the diagonal slots
     static constexpr int TRI = BK * SK + XSZ;         // doubles of LDS staging
     static_assert(N <= 64 && SK % 32 == 16 && SK >= 64, "panel stride");
+    // final conversion buffer Y: 16 rows of one tile row, all columns, row stride SY = 78 (14 mod 32, 2 mod 4): the mirror-tile
+    // writes and the row reads are bank-conflict free, the direct-tile writes collide on 2 of 32 banks
+    static constexpr int SY = 78;
+    static_assert(16 * SY <= TRI, "conversion buffer fits the staging");
 
     // W = -K^{-1} by the symmetric sweep operator, static pivot order (K is quasi-definite: every pivot is non-zero),
     // in blocks of BK = 8 pivots. The matrix lives in 16x16 fp64 MFMA accumulator tiles T[R][C], C <= R (block-lower
@@ -97,11 +124,12 @@ struct RegKkt {
     //      k-ascending fma chain — verified on gfx950, tests/experiments/mfma_f64_probe.hip — so every entry receives
     //      fma(-p_i[t], old_j[t], m_ij) for t ascending, which is what the CPU checker of the test suite restates)
     //   6. write-back: M[:, block] <- p into the pivot tile column, then M[block, :] <- p^T into the pivot tile row
-    // Finally the tiles are converted to row-per-lane registers a[] for the mat-vec.
+    // Finally the tiles are converted to the mat-vec layout a[] (see the member's comment).
     // kcol(j, z) returns K(lane, j) for j != lane, needed for j <= 16*(lane/16)+15 only (z: see below); it is called 8
     // columns at a time, one group ahead of use. diag = K(lane, lane).
     template <class KCol>
-    __device__ __forceinline__ void invert(int ln_in, double* st, double diag, KCol kcol) {
+    __device__ __forceinline__ void invert(int ln_in, double* st, double diag, KCol kcol, long long* tm = nullptr) {
+        long long tq0 = tm ? clock64() : 0;
         int ln = ln_in;
         asm volatile("" : "+v"(ln));   // keep the lane predicates below local to this function (no hoisting into long-lived SGPR masks)
         double* PA = st;
@@ -109,24 +137,25 @@ struct RegKkt {
         double* X = PB;
         const int lr = ln >> 4, lc = ln & 15;
         d4 T[NT][NT];   // only C <= R is used
-        // row layout -> accumulator tiles, 8 columns at a time (loads of the next group are in flight while this one is staged)
-        // `z` is an opaque zero that kcol adds to its addresses: redefining it once per group pins each group's loads
-        // behind the previous group's staging (loads from read-only kernel arguments may otherwise be hoisted to the
-        // top, all 2N registers at once)
-        double cur[BK], nxt[BK];
+        // row layout -> accumulator tiles, 8 columns at a time through X.
+        // All N row entries are requested in ONE batch (the workspace rows come from L2 / HBM: a round trip per group of 8
+        // columns cost 7 x ~2.5k cycles); they land in a[], which holds nothing live while the inverse is rebuilt.
+        // `z` is an opaque zero that kcol adds to its addresses: it keeps the loads (read-only kernel arguments) and their
+        // address arithmetic at this point instead of hoisted to the kernel prologue.
+        // K(lane, lane) = diag replaces the loaded entry once the tiles are staged. It travels through LDS (slot 64*SX + lane
+        // of X, beyond the exchange rows) and is written BEFORE the loads are issued: held in a register it was spilled,
+        // and a scratch reload waits on vmcnt behind every outstanding load.
+        X[64 * SX + ln] = diag;
+        sched_fence();
         int z = 0;
         asm volatile("" : "+v"(z));
 #pragma unroll
-        for (int t = 0; t < BK; ++t) cur[t] = (t < N) ? kcol(t, z) : 0.0;
+        for (int j = 0; j < NP; ++j) a[j] = (j < N) ? kcol(j < N ? j : 0, z) : 0.0;
+        sched_fence();
 #pragma unroll
         for (int g = 0; g < NP / BK; ++g) {
-            asm volatile("" : "+v"(z) :: "memory");
 #pragma unroll
-            for (int t = 0; t < BK; ++t) nxt[t] = ((g + 1) * BK + t < N) ? kcol(((g + 1) * BK + t < N) ? (g + 1) * BK + t : 0, z) : 0.0;
-#pragma unroll
-            for (int t = 0; t < BK; ++t) X[ln * SX + t] = cur[t];
-            lds_order();
-            if ((ln >> 3) == g) X[ln * SX + (ln & 7)] = diag;      // the diagonal entries of this column group
+            for (int t = 0; t < BK; ++t) X[ln * SX + t] = a[g * BK + t];
             lds_order();
             if ((lc >> 3) == (g % 2)) {
 #pragma unroll
@@ -136,9 +165,16 @@ struct RegKkt {
             }
             lds_order();
             sched_fence();
-#pragma unroll
-            for (int t = 0; t < BK; ++t) cur[t] = nxt[t];
         }
+        // diagonal patch: entry (16R + lc, 16R + lc) of tile (R, R) sits in component lc/4 of the lanes with lc = lr + 4*(lc/4)
+#pragma unroll
+        for (int R = 0; R < NT; ++R) {
+            const double dR = X[64 * SX + 16 * R + lc];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[R][R][r] = (lc == lr + 4 * r) ? dR : T[R][R][r];
+        }
+        lds_order();
+        if (tm) { long long t = clock64(); tm[0] += t - tq0; tq0 = t; }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int kb = b * BK;
@@ -161,6 +197,7 @@ struct RegKkt {
             for (int t = 0; t < BK; ++t) p[t] = X[ln * SX + t];
             lds_order();
             const bool inb = (ln >> 3) == b;
+            if (tm) { long long t = clock64(); tm[1] += t - tq0; tq0 = t; }
             // 2. B operand: the panel as it was at the start of the block
 #pragma unroll
             for (int t = 0; t < BK; ++t) PB[t * SK + ln] = (inb || kb + t >= N) ? 0.0 : p[t];
@@ -184,6 +221,7 @@ struct RegKkt {
                     sched_fence();
                 }
             }
+            if (tm) { long long t = clock64(); tm[2] += t - tq0; tq0 = t; }
             // 4. A operand
 #pragma unroll
             for (int t = 0; t < BK; ++t) PA[t * SK + ln] = (inb || kb + t >= N) ? 0.0 : -p[t];
@@ -204,6 +242,7 @@ struct RegKkt {
                 sched_fence();
             }
             lds_order();
+            if (tm) { long long t = clock64(); tm[3] += t - tq0; tq0 = t; }
             // 6. write-back of the swept panel: pivot tile column, then pivot tile row (the diagonal block ends up as the transpose of p)
 #pragma unroll
             for (int t = 0; t < BK; ++t) X[ln * SX + t] = p[t];
@@ -221,50 +260,58 @@ struct RegKkt {
             lds_order();
             sched_fence();
         }
-        // accumulator tiles -> row-per-lane registers (columns of tile rows above the diagonal come from the mirror tiles)
+        if (tm) { long long t = clock64(); tm[1] += t - tq0; tq0 = t; }
+        // accumulator tiles -> mat-vec layout, one tile row q at a time through Y (rows 16q..16q+15, all columns; blocks right of
+        // the diagonal come from the mirror tiles, transposed). Columns >= N (never-consumed padding that may hold anything)
+        // become exact zeros so that they drop out of the mat-vec.
+        double* Y = st;
 #pragma unroll
-        for (int g = 0; g < NB; ++g) {
-            if ((lc >> 3) == (g % 2)) {
+        for (int q = 0; q < NT; ++q) {
 #pragma unroll
-                for (int R = g / 2; R < NT; ++R)
+            for (int C = 0; C < NT; ++C) {
+                if (C <= q) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) X[(16 * R + lr + 4 * r) * SX + (lc & 7)] = T[R][g / 2][r];
-            }
+                    for (int r = 0; r < 4; ++r) Y[(lr + 4 * r) * SY + 16 * C + lc] = T[q][C][r];
+                } else {
 #pragma unroll
-            for (int C = 0; C < g / 2; ++C)
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr) X[(16 * C + lc) * SX + lr + 4 * rr] = T[g / 2][C][2 * (g % 2) + rr];
-            lds_order();
-#pragma unroll
-            for (int t = 0; t < BK; ++t)
-                if (g * BK + t < N) a[g * BK + t] = X[ln * SX + t];
-            lds_order();
-        }
-    }
-
-    // K^{-1} c, one entry per lane:  -(W c) with four interleaved partial sums (j mod 4), combined as (s0+s1)+(s2+s3)
-    __device__ __forceinline__ double apply(double c) const {
-        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-#pragma unroll
-        for (int j0 = 0; j0 < N; j0 += 8) {
-            double t[8];
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) t[jj] = (j0 + jj < N) ? bcast_lane(c, (j0 + jj < N) ? j0 + jj : 0) : 0.0;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const int j = j0 + jj;
-                if (j < N) {
-                    if ((j & 3) == 0) acc0 = fma(a[j], t[jj], acc0);
-                    if ((j & 3) == 1) acc1 = fma(a[j], t[jj], acc1);
-                    if ((j & 3) == 2) acc2 = fma(a[j], t[jj], acc2);
-                    if ((j & 3) == 3) acc3 = fma(a[j], t[jj], acc3);
+                    for (int r = 0; r < 4; ++r) Y[lc * SY + 16 * C + lr + 4 * r] = T[C][q][r];
                 }
             }
-            // groups of 8 broadcasts: the empty statement ties the next group's v_readlane to this group's results, which
-            // keeps instruction selection from hoisting all 2N scalar broadcasts (more SGPRs than exist) to the top
-            asm volatile("" : "+v"(c), "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3));
+            lds_order();
+            const int yo = lc * SY + 16 * (lr < NT ? lr : 0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double y = Y[yo + j];
+                a[16 * q + j] = (16 * (NT - 1) + j < N && NT == 4) ? y : ((16 * lr + j < N) ? y : 0.0);
+            }
+            lds_order();
+            sched_fence();
         }
-        return -((acc0 + acc1) + (acc2 + acc3));
+        if (tm) { long long t = clock64(); tm[4] += t - tq0; tq0 = t; }
+    }
+
+    // K^{-1} c, one entry per lane (c = 0 on lanes >= N). Lane 16r+c forms, for each tile row q, the partial sum
+    //   P_r(16q+c) = sum_j W(16q+c, 16r+j) * c_{16r+j}   (j ascending, one fma chain per q, the operand broadcast inside its row)
+    // and a two-step exchange (half-waves, then neighbouring rows) adds the four partial sums of every output row and leaves
+    // row i on lane i:   x_i = -((P_0 + P_2) + (P_1 + P_3)).
+    __device__ __forceinline__ double apply(double c) const {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        asm volatile("s_nop 1" : "+v"(c));   // VALU write -> DPP read of the same register: 2 wait states (inline asm is not covered by the hazard recogniser)
+        unroll_j<0>(acc, c);
+        asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));   // VALU write -> v_permlane*_swap read: 2 wait states
+        swap32(acc[0], acc[2]);
+        swap32(acc[1], acc[3]);
+        double s0 = acc[0] + acc[2], s1 = acc[1] + acc[3];
+        swap16(s0, s1);
+        return -(s0 + s1);
+    }
+    template <int J>
+    __device__ __forceinline__ void unroll_j(double (&acc)[4], double c) const {
+        if constexpr (J < 16) {
+#pragma unroll
+            for (int q = 0; q < NT; ++q) acc[q] = fmac_rowbcast<J>(acc[q], c, a[16 * q + J]);
+            unroll_j<J + 1>(acc, c);
+        }
     }
 };
 
@@ -276,7 +323,7 @@ template <int NN, int MM, bool STACKED = false>
 __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, const double* h, const double* __restrict__ A,
                                                   const double* Alb, const double* Aub, const double* xlb, const double* xub,
                                                   const double* x0, const double* y0, const pmpc_qp_settings& s, pmpc_qp_info& info,
-                                                  double* out_x, double* out_y, double* tr, long long* dbg = nullptr) {
+                                                  double* out_x, double* out_y, double* tr, long long* dbg = nullptr, long long* tm = nullptr) {
     constexpr int N = NN + MM;
     static_assert(N <= WAVE, "register-resident path needs n+m <= 64");
     const int ln = lane_id();
@@ -302,12 +349,19 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
     const int rstride = isP ? NN : (isC ? MM : 0);
     const double* colA = A + (size_t)lp * MM;
     const unsigned roff = (ln < N) ? ln : 0, coff = lp * N + NN;
+    // STACKED: the per-lane base offset goes through an empty asm statement AFTER the opaque zero is added — otherwise the
+    // sum is reassociated to (roff + j*N) + zo, the loop-invariant halves are hoisted for every j and spilled (their
+    // scratch reloads then sit between the loads and serialise them on vmcnt)
+    // They are derived from a lane id that is re-materialised next to the loads (two v_mbcnt, tied to the opaque zero):
+    // a long-lived per-lane offset is spilled, and its scratch reload in the middle of a batch of loads waits on vmcnt
+    // for every load issued before it.
+    auto lane_near = [](int zo) -> unsigned { unsigned l; asm("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l) : "v"(zo)); return l; };
     auto Krow = [&](int j, int zo) -> double {   // (H or A)(row of this lane, j), j < NN
-        if constexpr (STACKED) return H[(unsigned)(roff + zo) + (unsigned)(j * N)];
+        if constexpr (STACKED) { const unsigned l = lane_near(zo); unsigned b = (l < (unsigned)N ? l : 0u) + (unsigned)zo; asm("" : "+v"(b)); return H[b + (unsigned)(j * N)]; }
         else return rowp[(size_t)j * (size_t)(unsigned)(rstride + zo)];
     };
     auto Acol = [&](int k, int zo) -> double {   // A(k, lane), k < MM (primal lanes)
-        if constexpr (STACKED) return H[(unsigned)(coff + zo) + (unsigned)k];
+        if constexpr (STACKED) { const unsigned l = lane_near(zo); unsigned b = (l < (unsigned)NN ? l : 0u) * N + NN + (unsigned)zo; asm("" : "+v"(b)); return H[b + (unsigned)k]; }
         else return colA[k + zo];
     };
     constexpr int LDH = STACKED ? N : NN;
@@ -351,8 +405,9 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
             K.invert(ln, tr, kdiag, [&](int j, int z) -> double {   // row `lane` of [H  A^T ; A  .] (construct_kkt_matrix, box_admm.hpp:209-223)
                 if (j < NN) return Krow(j < NN ? j : 0, z);
                 const double v = Acol(j >= NN ? j - NN : 0, z);
+                if constexpr (STACKED) return lane_near(z) < (unsigned)NN ? v : 0.0;
                 return isP ? v : 0.0;
-            });
+            }, tm);
             if (dbg) dbg[0] += clock64() - f0;
         }
         bool refactor = false;

@@ -52,9 +52,9 @@ struct SqpDevice {
     int n, m, me, mi;
     double cost_log = 0.0, primal_norm = 0.0, dual_norm = 0.0, max_violation = 0.0;
     int qp_iter_total = 0;
-    long long cyc[PROF ? 16 : 1] = {0};
+    long long cyc[PROF ? 24 : 1] = {0};
     __device__ __forceinline__ static long long now() { if constexpr (PROF) return clock64(); else return 0; }
-    __device__ __forceinline__ void acc(int i, long long dt) { if constexpr (PROF) cyc[i] += dt; }   // shader-clock cycles: 0 linearise(+BFGS) 1 QP 2 line search 3 termination 4 total 5 BFGS 6 KKT build+factor 7 QP residuals 8 ls node evaluation 9 ls scalar sums 10 first-order staging 11 second-order staging 12 first-order assembly 13 Hessian assembly 14 Lagrangian gradient
+    __device__ __forceinline__ void acc(int i, long long dt) { if constexpr (PROF) cyc[i] += dt; }   // shader-clock cycles: 0 linearise(+BFGS) 1 QP 2 line search 3 termination 4 total 5 BFGS 6 KKT build+factor 7 QP residuals 8 ls node evaluation 9 ls scalar sums 10 first-order staging 11 second-order staging 12 first-order assembly 13 Hessian assembly 14 Lagrangian gradient 16..20 KKT inverse: row loads+staging, panel moves, sweeps, MFMA updates, final conversion
 
     __device__ SqpDevice(Ocp<Model>& o, SqpLds& v_, QpLds& q_, double* H_, double* A_, const pmpc_sqp_settings& s, const pmpc_qp_settings& q)
         : ocp(o), v(v_), qw(q_), Hw(H_), Aw(A_), ldw(o.dm.n + o.dm.m), ss(s), qs(q), n(o.dm.n), m(o.dm.m), me(o.dm.me), mi(o.dm.mi) {}
@@ -487,7 +487,7 @@ struct SqpDevice {
         form_qp_bounds();
         pmpc_qp_info qi;
         // 7-argument form: zero guesses (Q2)
-        if constexpr (NN > 0) { boxadmm_solve_reg<NN, MM, true>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr); wsync(); }
+        if constexpr (NN > 0) { boxadmm_solve_reg<NN, MM, true>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr); wsync(); }
         else boxadmm_solve(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi);
         qp_iter_total += qi.iter;
         // lam_k = p_lambda ; p_lambda -= lam

@@ -162,7 +162,7 @@ struct Ocp {
     }
 
     // ---- per-node first-order stage: f, df, L, dL, g, dg, DX, Mayer value+gradient
-    __device__ void stage_first_order(const double* var) {
+    __device__ __forceinline__ void stage_first_order(const double* var) {
         for (int k = lane_id(); k < dm.NN; k += WAVE) {
             ad1 x[NX > 0 ? NX : 1], u[NU > 0 ? NU : 1], p[NP > 0 ? NP : 1], y[NX > 0 ? NX : 1];
             seed1<ad1>(var, k, x, u, p);

@@ -331,20 +331,37 @@ struct SqpDevice {
         wsync();
     }
 
-    // linearisation_dense_impl :310-318
-    __device__ void linearisation() {
+    // linearisation_dense_impl :310-318 (exact = true) and update_linearisation_dense_impl :490-504 (exact = false) share ONE
+    // inlined copy of the first-order stage (as a called function it kept the whole Ocp object in private memory and
+    // spilled the live registers around every call).
+    //   exact:  f, df, L, dL -> c, J, cost gradient; second-order stage -> H; lag_grad
+    //   update: f, df, L, dL -> c, J (per-node blocks only), cost gradient; new lag_grad; damped BFGS on H
+    __device__ __forceinline__ void linearise(bool exact, bool structure) {
         const long long l0 = now();
         ocp.stage_first_order(v.x);
         const long long l1 = now();
-        ocp.stage_second_order(v.x, v.lam);
-        const long long l2 = now();
-        ocp.assemble_first_order(v.al, Aw, v.h, ldw);
-        const long long l3 = now();
-        ocp.assemble_hessian(Hw, ldw);
-        const long long l4 = now();
-        lagrangian_gradient(v.lg);
-        acc(10, l1 - l0); acc(11, l2 - l1); acc(12, l3 - l2); acc(13, l4 - l3); acc(14, now() - l4);
-        if (ss.regularisation == 2) regularise_gershgorin();
+        acc(10, l1 - l0);
+        if (exact) {
+            ocp.stage_second_order(v.x, v.lam);
+            const long long l2 = now();
+            ocp.assemble_first_order(v.al, Aw, v.h, ldw, structure);
+            const long long l3 = now();
+            ocp.assemble_hessian(Hw, ldw);
+            const long long l4 = now();
+            lagrangian_gradient(v.lg);
+            acc(11, l2 - l1); acc(12, l3 - l2); acc(13, l4 - l3); acc(14, now() - l4);
+            if (ss.regularisation == 2) regularise_gershgorin();
+        } else {
+            ocp.assemble_first_order(v.al, Aw, v.h, ldw, false);   // J's zeros and D entries are already in place
+            const long long l3 = now();
+            lagrangian_gradient(v.lgn);
+            acc(12, l3 - l1); acc(14, now() - l3);
+            const long long b0 = now();
+            if constexpr (NN > 0) { double brow[NN > 0 ? NN : 1]; bfgs_load_row(brow); bfgs_update_reg(brow); } else bfgs_update();
+            acc(5, now() - b0);
+            for (int i = lane_id(); i < n; i += WAVE) v.lg[i] = v.lgn[i];
+            wsync();
+        }
     }
 
     // BFGS_update, bfgs.hpp:23-52 ; s = v.step, y = lgn - lg
@@ -451,23 +468,6 @@ struct SqpDevice {
         wsync();
     }
 
-    // update_linearisation_dense_impl :490-504
-    __device__ void update_linearisation() {
-        if (ss.exact_hessian_every_iter) { linearisation(); return; }
-        const long long l0 = now();
-        ocp.stage_first_order(v.x);
-        const long long l1 = now();
-        ocp.assemble_first_order(v.al, Aw, v.h, ldw, false);   // J's zeros and D entries are already in place
-        const long long l3 = now();
-        lagrangian_gradient(v.lgn);
-        acc(10, l1 - l0); acc(12, l3 - l1); acc(14, now() - l3);
-        const long long b0 = now();
-        if constexpr (NN > 0) { double brow[NN > 0 ? NN : 1]; bfgs_load_row(brow); bfgs_update_reg(brow); } else bfgs_update();
-        acc(5, now() - b0);
-        for (int i = lane_id(); i < n; i += WAVE) v.lg[i] = v.lgn[i];
-        wsync();
-    }
-
     // QP bounds :588-593
     __device__ void form_qp_bounds() {
         const int ln = lane_id();
@@ -517,7 +517,7 @@ struct SqpDevice {
         while (true) {
             ++iter;
             const long long c0 = now();
-            if (iter == 1) linearisation(); else update_linearisation();
+            linearise(iter == 1 || ss.exact_hessian_every_iter, true);
             const long long c1 = now();
             qp_and_step();
             const long long c2 = now();

@@ -155,6 +155,7 @@ struct sqp_settings_t {   // sqp_base.hpp:24-47 (+ the two override points as fl
     int max_iter = 100, line_search_max_iter = 100;
     int regularisation = 0;            // 0: default no-op hook (sqp_base.hpp:305); 2: Gershgorin (dense_sparse_compare.cpp:109-122)
     bool exact_hessian_every_iter = false;
+    int preconditioner = 0;            // SQPBase's Preconditioner template argument: 0 IdentityPreconditioner, 1 RuizEquilibration
 };
 using qp_solver_settings_t = pmpc_qp_settings;   // same member names as qp_base.hpp:17-53 (ADMM subset)
 
@@ -194,6 +195,7 @@ public:
         ss.tau = m_settings.tau; ss.eta = m_settings.eta; ss.rho = m_settings.rho; ss.eps_prim = m_settings.eps_prim;
         ss.eps_dual = m_settings.eps_dual; ss.max_iter = m_settings.max_iter; ss.line_search_max_iter = m_settings.line_search_max_iter;
         ss.regularisation = m_settings.regularisation; ss.exact_hessian_every_iter = m_settings.exact_hessian_every_iter ? 1 : 0;
+        ss.preconditioner = m_settings.preconditioner;
         std::vector<double> xo(m_x.size()), lo(m_lam.size());
         const pmpc_status st = device_binding<OCP>::solve(ctx, problem, OCP::POLY_ORDER, OCP::NUM_SEGMENTS, problem.t_start, problem.t_stop, B,
                                                           m_x.data(), m_lam.data(), m_p.data(), m_lbx.data(), m_ubx.data(),
@@ -320,6 +322,30 @@ private:
         return m_info.status;
     }
     settings_t m_settings; info_t m_info; qp_var_t m_x; qp_dual_t m_y;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RuizEquilibration<N, M> (qp_preconditioners.hpp:114-385, DENSE): compute() scales the QP data in place on the device,
+// unscale(x, y) maps a solution of the scaled QP back (usage: tests/solvers/qp/box_admm_test.cpp:47-83).
+template <int N, int M>
+class RuizEquilibration {
+public:
+    Vector<N> D; Vector<M> E;
+    RuizEquilibration() { for (int i = 0; i < N; ++i) D(i) = 1.0; for (int i = 0; i < M; ++i) E(i) = 1.0; }
+    const double& c() const noexcept { return m_c; }
+    void compute(Matrix<N, N>& H, Vector<N>& h, Matrix<M, N>& A, Vector<M>& Al, Vector<M>& Au, Vector<N>& l, Vector<N>& u) noexcept {
+        pmpc_context* ctx = context();
+        if (!ctx) return;
+        last_error() = pmpc_qp_ruiz_compute_batch(ctx, 1, N, M, H.data(), h.data(), A.data(), Al.data(), Au.data(), l.data(), u.data(),
+                                                  D.data(), E.data(), &m_c);
+    }
+    void unscale(Vector<N>& x, Vector<N + M>& y) const noexcept {
+        pmpc_context* ctx = context();
+        if (!ctx) return;
+        last_error() = pmpc_qp_ruiz_unscale_batch(ctx, 1, N, M, D.data(), E.data(), &m_c, x.data(), y.data());
+    }
+private:
+    double m_c{1.0};
 };
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -72,6 +72,8 @@ typedef struct {
     int max_iter, line_search_max_iter;
     int regularisation;
     int exact_hessian_every_iter;
+    int preconditioner;   /* SQPBase's Preconditioner argument (sqp_base.hpp:64-68): 0 IdentityPreconditioner (default),
+                           * 1 RuizEquilibration (qp_preconditioners.hpp:114-385), applied around every QP (sqp_base.hpp:605-611) */
 } pmpc_sqp_settings;
 
 /* sqp_status_t (sqp_base.hpp:49-55) */
@@ -128,6 +130,20 @@ pmpc_status pmpc_qp_boxadmm_solve_batch_dev(pmpc_context* ctx, int B, int n, int
                                             const double* A, const double* Alb, const double* Aub, const double* xlb,
                                             const double* xub, const double* x0, const double* y0,
                                             const pmpc_qp_settings* settings, double* x, double* y, pmpc_qp_info* info);
+
+/* Batched RuizEquilibration<Scalar,N,M,DENSE>::compute (qp_preconditioners.hpp:160-233): scales H, h, A, Alb, Aub, xlb, xub
+ * of B QPs IN PLACE and returns the accumulated scalings D (B*n), E (B*m) and the cost scaling c (B). Host buffers. */
+pmpc_status pmpc_qp_ruiz_compute_batch(pmpc_context* ctx, int B, int n, int m, double* H, double* h, double* A, double* Alb,
+                                       double* Aub, double* xlb, double* xub, double* D, double* E, double* c);
+/* Same with DEVICE pointers; asynchronous on the context's stream. */
+pmpc_status pmpc_qp_ruiz_compute_batch_dev(pmpc_context* ctx, int B, int n, int m, double* H, double* h, double* A, double* Alb,
+                                           double* Aub, double* xlb, double* xub, double* D, double* E, double* c);
+/* RuizEquilibration::unscale(x, y) (qp_preconditioners.hpp:359-364): x <- x.*D, y <- (1/c) [y_A.*E ; y_box./D], in place.
+ * Host buffers / device pointers. */
+pmpc_status pmpc_qp_ruiz_unscale_batch(pmpc_context* ctx, int B, int n, int m, const double* D, const double* E, const double* c,
+                                       double* x, double* y);
+pmpc_status pmpc_qp_ruiz_unscale_batch_dev(pmpc_context* ctx, int B, int n, int m, const double* D, const double* E, const double* c,
+                                           double* x, double* y);
 
 /* Dimensions of the transcription of `model` with Spline<Chebyshev<P>,S> (continuous_ocp.hpp:69-98). */
 pmpc_status pmpc_ocp_dims(int model, int P, int S, int* nx, int* nu, int* np, int* nd, int* ng, int* var_size,

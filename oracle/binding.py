@@ -35,7 +35,7 @@ class QPInfo(C.Structure):
 class SQPSettings(C.Structure):
     _fields_ = [("tau", C.c_double), ("eta", C.c_double), ("rho", C.c_double), ("eps_prim", C.c_double),
                 ("eps_dual", C.c_double), ("max_iter", C.c_int), ("line_search_max_iter", C.c_int),
-                ("regularisation", C.c_int), ("exact_hessian_every_iter", C.c_int)]
+                ("regularisation", C.c_int), ("exact_hessian_every_iter", C.c_int), ("preconditioner", C.c_int)]
 
 
 class SQPInfo(C.Structure):
@@ -126,6 +126,23 @@ def qp_solve_batch(H, h, A, Alb, Aub, xlb, xub, settings=None, pivot=PIVOT_EIGEN
     lib().orc_qp_solve_batch(B, n, m, _p(H), _p(h), _p(A), _p(Alb), _p(Aub), _p(xlb), _p(xub), _p(_f(x0)), _p(_f(y0)),
                              C.byref(s), pivot, threads, _p(x), _p(y), info)
     return x, y, info
+
+
+def ruiz_compute_batch(H, h, A, Alb, Aub, xlb, xub):
+    """In-place Ruiz equilibration of a batch (copies are made and returned): -> (H, h, A, Alb, Aub, xlb, xub, D, E, c)."""
+    h = _f(h).copy(); B, n = h.shape
+    Alb = _f(Alb).copy().reshape(B, -1); m = Alb.shape[1]
+    H = _f(H).copy(); A = _f(A).copy(); Aub = _f(Aub).copy(); xlb = _f(xlb).copy(); xub = _f(xub).copy()
+    D = np.zeros((B, n)); E = np.zeros((B, m)); c = np.zeros(B)
+    lib().orc_ruiz_compute_batch(C.c_int(B), C.c_int(n), C.c_int(m), _p(H), _p(h), _p(A), _p(Alb), _p(Aub), _p(xlb), _p(xub), _p(D), _p(E), _p(c))
+    return H, h, A, Alb, Aub, xlb, xub, D, E, c
+
+
+def ruiz_unscale_solution_batch(D, E, c, x, y):
+    x = _f(x).copy(); y = _f(y).copy(); D = _f(D); E = _f(E); c = _f(c)
+    B, n = x.shape; m = y.shape[1] - n
+    lib().orc_ruiz_unscale_solution_batch(C.c_int(B), C.c_int(n), C.c_int(m), _p(D), _p(E), _p(c), _p(x), _p(y))
+    return x, y
 
 
 def ocp_dims(model, P, S):

@@ -30,6 +30,7 @@ static sqp_settings to_sqp(const orc_sqp_settings* s) {
     q.tau = s->tau; q.eta = s->eta; q.rho = s->rho; q.eps_prim = s->eps_prim; q.eps_dual = s->eps_dual;
     q.max_iter = s->max_iter; q.line_search_max_iter = s->line_search_max_iter;
     q.regularisation = s->regularisation; q.exact_hessian_every_iter = s->exact_hessian_every_iter != 0;
+    q.preconditioner = s->preconditioner;
     return q;
 }
 
@@ -72,7 +73,7 @@ void orc_sqp_default_settings(orc_sqp_settings* s) {
     sqp_settings q;
     s->tau = q.tau; s->eta = q.eta; s->rho = q.rho; s->eps_prim = q.eps_prim; s->eps_dual = q.eps_dual;
     s->max_iter = q.max_iter; s->line_search_max_iter = q.line_search_max_iter;
-    s->regularisation = 0; s->exact_hessian_every_iter = 0;
+    s->regularisation = 0; s->exact_hessian_every_iter = 0; s->preconditioner = 0;
 }
 
 void orc_cheb(int P, double* nodes, double* weights, double* D) {
@@ -89,6 +90,27 @@ void orc_regularise(int kind, int n, double* H) {
 }
 void orc_ldlt_solve(int n, const double* K, const double* b, int pivot, double* x) {
     LDLT f; f.compute(std::vector<double>(K, K + n * n), n, (pivot_policy)pivot); f.solve(b, x);
+}
+
+void orc_ruiz_compute_batch(int B, int n, int m, double* H, double* h, double* A, double* Al, double* Au, double* l, double* u,
+                            double* D, double* E, double* c) {
+    for (int b = 0; b < B; ++b) {
+        Ruiz r(n, m);
+        r.compute(H + (size_t)b * n * n, h + (size_t)b * n, A + (size_t)b * m * n, Al + (size_t)b * m, Au + (size_t)b * m,
+                  l + (size_t)b * n, u + (size_t)b * n);
+        for (int k = 0; k < n; ++k) D[(size_t)b * n + k] = r.D[k];
+        for (int k = 0; k < m; ++k) E[(size_t)b * m + k] = r.E[k];
+        c[b] = r.c;
+    }
+}
+void orc_ruiz_unscale_solution_batch(int B, int n, int m, const double* D, const double* E, const double* c, double* x, double* y) {
+    for (int b = 0; b < B; ++b) {
+        Ruiz r(n, m);
+        for (int k = 0; k < n; ++k) r.D[k] = D[(size_t)b * n + k];
+        for (int k = 0; k < m; ++k) r.E[k] = E[(size_t)b * m + k];
+        r.c = c[b];
+        r.unscale(x + (size_t)b * n, y + (size_t)b * (n + m));
+    }
 }
 
 void orc_qp_solve_batch(int B, int n, int m, const double* H, const double* h, const double* A, const double* Alb,

@@ -27,6 +27,7 @@ typedef struct {
     int max_iter, line_search_max_iter;
     int regularisation;            /* 0 none, 1 eigenvalue mirroring, 2 Gershgorin */
     int exact_hessian_every_iter;  /* 0 = damped BFGS (default) */
+    int preconditioner;            /* 0 identity (default), 1 Ruiz equilibration */
 } orc_sqp_settings;
 
 typedef struct {
@@ -51,6 +52,12 @@ void orc_ldlt_solve(int n, const double* K, const double* b, int pivot, double* 
 void orc_qp_solve_batch(int B, int n, int m, const double* H, const double* h, const double* A, const double* Alb,
                         const double* Aub, const double* xlb, const double* xub, const double* x0, const double* y0,
                         const orc_qp_settings* s, int pivot, int threads, double* x, double* y, orc_qp_info* info);
+
+/* Ruiz equilibration of B QPs in place (qp_preconditioners.hpp:160-233); outputs D (B x n), E (B x m), c (B) */
+void orc_ruiz_compute_batch(int B, int n, int m, double* H, double* h, double* A, double* Al, double* Au, double* l, double* u,
+                            double* D, double* E, double* c);
+/* x <- x.*D, y <- (1/c) [y_A.*E ; y_box./D]  (qp_preconditioners.hpp:359-364) */
+void orc_ruiz_unscale_solution_batch(int B, int n, int m, const double* D, const double* E, const double* c, double* x, double* y);
 
 /* sizes of the transcription */
 void orc_ocp_dims(int model, int P, int S, int* nx, int* nu, int* np, int* nd, int* ng, int* n, int* m_eq, int* m_ineq);

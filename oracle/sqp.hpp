@@ -18,6 +18,7 @@
 #include <limits>
 #include <vector>
 #include "qp.hpp"
+#include "ruiz.hpp"
 
 namespace oracle {
 
@@ -91,6 +92,7 @@ struct sqp_settings {  // sqp_base.hpp:24-47
     int max_iter = 100, line_search_max_iter = 100;
     int regularisation = REG_NONE;          // hook of :277-306 (default no-op)
     bool exact_hessian_every_iter = false;  // override used by codegen_test.cpp:381-398 / minimal_time_test.cpp:126-133
+    int preconditioner = 0;                 // SQPBase's Preconditioner template argument: 0 IdentityPreconditioner (default), 1 RuizEquilibration
 };
 enum sqp_status { SQP_SOLVED = 0, SQP_MAX_ITER_EXCEEDED = 1, SQP_INVALID_SETTINGS = 2 };
 struct sqp_info { int iter = 0, qp_solver_iter = 0, status = SQP_MAX_ITER_EXCEEDED; };
@@ -196,10 +198,18 @@ struct SQP {
         for (int i = 0; i < n; ++i) { lx[i] = lbx[i] - x[i]; ux[i] = ubx[i] - x[i]; }
     }
     void solve_qp(std::vector<double>& p, std::vector<double>& p_lambda) {  // :533-565
+        // m_preconditioner.compute / solve_qp / unscale(p, p_lambda) / unscale(H, h, A, ...): sqp_base.hpp:605-611, :661-665.
+        // The matrices are scaled and unscaled IN PLACE every iteration, as in the reference (H carries the rounding).
+        Ruiz ruiz(n, m);
+        if (settings.preconditioner == 1) ruiz.compute(H.data(), h.data(), A.data(), al.data(), au.data(), lx.data(), ux.data());
         if (record_qps) qp_trace.push_back({H, h, A, al, au, lx, ux});
         qp.solve(H.data(), h.data(), A.data(), al.data(), au.data(), lx.data(), ux.data());
         info.qp_solver_iter += qp.info.iter;
         p = qp.x; p_lambda = qp.y;
+        if (settings.preconditioner == 1) {
+            ruiz.unscale(p.data(), p_lambda.data());
+            ruiz.unscale(H.data(), h.data(), A.data(), al.data(), au.data(), lx.data(), ux.data());
+        }
     }
     bool termination_criteria() {  // :524-529
         max_violation = max_constraints_violation(x.data());

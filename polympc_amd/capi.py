@@ -19,6 +19,7 @@ EXPORTED_SYMBOLS = [
     "pmpc_qp_settings_default", "pmpc_qp_settings_sqp_default", "pmpc_sqp_settings_default", "pmpc_chebyshev",
     "pmpc_qp_boxadmm_solve_batch", "pmpc_qp_boxadmm_solve_batch_dev", "pmpc_ocp_dims", "pmpc_ocp_linearise_batch",
     "pmpc_sqp_solve_batch", "pmpc_sqp_solve_batch_dev", "pmpc_sqp_solve_batch_user",
+    "pmpc_qp_ruiz_compute_batch", "pmpc_qp_ruiz_compute_batch_dev", "pmpc_qp_ruiz_unscale_batch", "pmpc_qp_ruiz_unscale_batch_dev",
 ]
 
 
@@ -36,7 +37,7 @@ class QPInfo(C.Structure):
 class SQPSettings(C.Structure):
     _fields_ = [("tau", C.c_double), ("eta", C.c_double), ("rho", C.c_double), ("eps_prim", C.c_double),
                 ("eps_dual", C.c_double), ("max_iter", C.c_int), ("line_search_max_iter", C.c_int),
-                ("regularisation", C.c_int), ("exact_hessian_every_iter", C.c_int)]
+                ("regularisation", C.c_int), ("exact_hessian_every_iter", C.c_int), ("preconditioner", C.c_int)]
 
 
 class SQPInfo(C.Structure):
@@ -171,6 +172,25 @@ class Context:
         return x, y, info
 
     # ------------------------------------------------------------------ QP, device buffers (torch tensors), asynchronous
+    def qp_ruiz_compute_batch(self, H, h, A, Alb, Aub, xlb, xub):
+        """RuizEquilibration::compute on copies of the host arrays -> (H, h, A, Alb, Aub, xlb, xub, D, E, c)."""
+        P_ = C.POINTER(C.c_double)
+        h = np.array(h, dtype=np.float64, order="C"); B, n = h.shape
+        Alb = np.array(Alb, dtype=np.float64, order="C").reshape(B, -1); m = Alb.shape[1]
+        H, A, Aub, xlb, xub = (np.array(a, dtype=np.float64, order="C") for a in (H, A, Aub, xlb, xub))
+        D = np.zeros((B, n)); E = np.zeros((B, max(m, 1))); c = np.zeros(B)
+        _check(lib().pmpc_qp_ruiz_compute_batch(self._ctx, B, n, m, *[a.ctypes.data_as(P_) for a in (H, h, A, Alb, Aub, xlb, xub, D, E, c)]))
+        return H, h, A, Alb, Aub, xlb, xub, D, E[:, :m], c
+
+    def qp_ruiz_unscale_batch(self, D, E, c, x, y):
+        P_ = C.POINTER(C.c_double)
+        x = np.array(x, dtype=np.float64, order="C"); y = np.array(y, dtype=np.float64, order="C")
+        D, E, c = (np.ascontiguousarray(a, dtype=np.float64) for a in (D, E, c))
+        B, n = x.shape; m = y.shape[1] - n
+        Ep = np.ascontiguousarray(E if m > 0 else np.zeros((B, 1)))
+        _check(lib().pmpc_qp_ruiz_unscale_batch(self._ctx, B, n, m, *[a.ctypes.data_as(P_) for a in (D, Ep, c, x, y)]))
+        return x, y
+
     def qp_solve_batch_dev(self, B, n, m, H, h, A, Alb, Aub, xlb, xub, x, y, info, settings, x0=None, y0=None):
         _check(lib().pmpc_qp_boxadmm_solve_batch_dev(self._ctx, B, n, m, _d(H), _d(h), _d(A), _d(Alb), _d(Aub), _d(xlb), _d(xub),
                                                      _d(x0), _d(y0), C.byref(settings), _d(x), _d(y), C.c_void_p(info.data_ptr())))

@@ -15,6 +15,7 @@
 #include "pmpc_qp_reg.hpp"
 #include "pmpc_sqp.hpp"
 #include "pmpc_launch.hpp"
+#include "pmpc_ruiz.hpp"
 
 using namespace pmpc;
 
@@ -212,7 +213,7 @@ void pmpc_qp_settings_sqp_default(pmpc_qp_settings* s) {
 }
 void pmpc_sqp_settings_default(pmpc_sqp_settings* s) {
     s->tau = 0.5; s->eta = 0.25; s->rho = 0.5; s->eps_prim = 1e-3; s->eps_dual = 1e-3; s->max_iter = 100;
-    s->line_search_max_iter = 100; s->regularisation = 0; s->exact_hessian_every_iter = 0;
+    s->line_search_max_iter = 100; s->regularisation = 0; s->exact_hessian_every_iter = 0; s->preconditioner = 0;
 }
 
 pmpc_status pmpc_chebyshev(int P, double* nodes, double* weights, double* D) {
@@ -281,6 +282,64 @@ pmpc_status pmpc_qp_boxadmm_solve_batch(pmpc_context* ctx, int B, int n, int m, 
     HIPCHK(hipMemcpyAsync(x, dx, Bn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(y, dy, (Bn + Bm) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(info, dinfo, (size_t)B * sizeof(pmpc_qp_info), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PMPC_OK;
+}
+
+pmpc_status pmpc_qp_ruiz_compute_batch_dev(pmpc_context* ctx, int B, int n, int m, double* H, double* h, double* A, double* Alb,
+                                           double* Aub, double* xlb, double* xub, double* D, double* E, double* c) {
+    if (!ctx || B < 0 || n < 1 || m < 0 || !H || !h || !xlb || !xub || !D || !c) return PMPC_ERR_INVALID_ARGUMENT;
+    if (m > 0 && (!A || !Alb || !Aub || !E)) return PMPC_ERR_INVALID_ARGUMENT;
+    if (B == 0) return PMPC_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    double* scratch = nullptr;
+    DEVOUT(23, (size_t)B * (n + m) * sizeof(double), scratch);
+    hipLaunchKernelGGL(ruiz_compute_kernel, dim3(B), dim3(WAVE), 0, ctx->stream, B, n, m, H, h, A, Alb, Aub, xlb, xub, D, E, c, scratch);
+    HIPCHK(hipGetLastError());
+    return PMPC_OK;
+}
+pmpc_status pmpc_qp_ruiz_unscale_batch_dev(pmpc_context* ctx, int B, int n, int m, const double* D, const double* E, const double* c,
+                                           double* x, double* y) {
+    if (!ctx || B < 0 || n < 1 || m < 0 || !D || !c || !x || !y || (m > 0 && !E)) return PMPC_ERR_INVALID_ARGUMENT;
+    if (B == 0) return PMPC_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(ruiz_unscale_solution_kernel, dim3(B), dim3(WAVE), 0, ctx->stream, B, n, m, D, E, c, x, y);
+    HIPCHK(hipGetLastError());
+    return PMPC_OK;
+}
+pmpc_status pmpc_qp_ruiz_compute_batch(pmpc_context* ctx, int B, int n, int m, double* H, double* h, double* A, double* Alb,
+                                       double* Aub, double* xlb, double* xub, double* D, double* E, double* c) {
+    if (!ctx || B < 0 || n < 1 || m < 0 || !H || !h || !xlb || !xub || !D || !c) return PMPC_ERR_INVALID_ARGUMENT;
+    if (m > 0 && (!A || !Alb || !Aub || !E)) return PMPC_ERR_INVALID_ARGUMENT;
+    if (B == 0) return PMPC_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    double *dH, *dh, *dA, *dAlb, *dAub, *dxlb, *dxub, *dD, *dE, *dc;
+    const size_t Bn = (size_t)B * n, Bm = (size_t)B * m;
+    H2D(0, H, Bn * n, dH); H2D(1, h, Bn, dh); H2D(2, (m ? A : nullptr), Bm * n, dA); H2D(3, (m ? Alb : nullptr), Bm, dAlb);
+    H2D(4, (m ? Aub : nullptr), Bm, dAub); H2D(5, xlb, Bn, dxlb); H2D(6, xub, Bn, dxub);
+    DEVOUT(7, Bn * sizeof(double), dD); DEVOUT(8, (Bm + 1) * sizeof(double), dE); DEVOUT(9, (size_t)B * sizeof(double), dc);
+    if (m == 0) { DEVOUT(2, 8, dA); DEVOUT(3, 8, dAlb); DEVOUT(4, 8, dAub); }
+    pmpc_status st = pmpc_qp_ruiz_compute_batch_dev(ctx, B, n, m, dH, dh, dA, dAlb, dAub, dxlb, dxub, dD, dE, dc);
+    if (st != PMPC_OK) return st;
+#define D2H_(host, dev, count) HIPCHK(hipMemcpyAsync(host, dev, (size_t)(count) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream))
+    D2H_(H, dH, Bn * n); D2H_(h, dh, Bn); D2H_(xlb, dxlb, Bn); D2H_(xub, dxub, Bn); D2H_(D, dD, Bn); D2H_(c, dc, B);
+    if (m > 0) { D2H_(A, dA, Bm * n); D2H_(Alb, dAlb, Bm); D2H_(Aub, dAub, Bm); D2H_(E, dE, Bm); }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PMPC_OK;
+}
+pmpc_status pmpc_qp_ruiz_unscale_batch(pmpc_context* ctx, int B, int n, int m, const double* D, const double* E, const double* c,
+                                       double* x, double* y) {
+    if (!ctx || B < 0 || n < 1 || m < 0 || !D || !c || !x || !y || (m > 0 && !E)) return PMPC_ERR_INVALID_ARGUMENT;
+    if (B == 0) return PMPC_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    double *dD, *dE, *dc, *dx, *dy;
+    const size_t Bn = (size_t)B * n, Bm = (size_t)B * m;
+    H2D(0, D, Bn, dD); H2D(1, (m ? E : nullptr), Bm, dE); H2D(2, c, B, dc); H2D(3, x, Bn, dx); H2D(4, y, Bn + Bm, dy);
+    if (m == 0) DEVOUT(1, 8, dE);
+    pmpc_status st = pmpc_qp_ruiz_unscale_batch_dev(ctx, B, n, m, dD, dE, dc, dx, dy);
+    if (st != PMPC_OK) return st;
+    D2H_(x, dx, Bn); D2H_(y, dy, Bn + Bm);
+#undef D2H_
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return PMPC_OK;
 }

@@ -180,6 +180,7 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
                                   const double* ubg, const pmpc_sqp_settings* ss, const pmpc_qp_settings* qs, double* x, double* lam,
                                   pmpc_sqp_info* info) {
     if (P < 1 || P > MAX_P || S < 1 || P * S + 1 > MAX_NODES) return PMPC_ERR_UNSUPPORTED_SIZE;
+    if (ss->preconditioner != 0 && (ss->preconditioner != 1 || (int)OcpDims<Model>::NDER > RUIZ_MAX_NDER)) return PMPC_ERR_UNSUPPORTED_SIZE;
     OcpDims<Model> dm(P, S);
     const void* cdv = nullptr; double* ws = nullptr; void* streamv = nullptr; size_t lds_limit = 0; unsigned long long* phase = nullptr; int force_lds = 0;
     const size_t base = (size_t)B * ((size_t)dm.n * dm.n + (size_t)dm.m * dm.n + 2 * (size_t)dm.n);

@@ -13,6 +13,7 @@
 #include "pmpc_ocp.hpp"
 #include "pmpc_qp.hpp"
 #include "pmpc_qp_reg.hpp"
+#include "pmpc_ruiz.hpp"
 
 namespace pmpc {
 
@@ -31,6 +32,7 @@ struct SqpLds {
 };
 
 constexpr double DBL_EPS = 2.220446049250313e-16;
+constexpr int RUIZ_MAX_NDER = 8;   // see SqpDevice::qp_and_step
 constexpr int PMPC_SQP_IN_PROGRESS = 3;   // internal: the instance continues in the next iteration-slice launch
 
 // NN, MM > 0: compile-time QP size with NN+MM <= 64 -> register-resident QP (pmpc_qp_reg.hpp); 0 -> LDS-resident QP
@@ -38,6 +40,7 @@ constexpr int PMPC_SQP_IN_PROGRESS = 3;   // internal: the instance continues in
 template <class Model, int NN = 0, int MM = 0, bool PROF = false>
 struct SqpDevice {
     using Dm = OcpDims<Model>;
+    static constexpr bool RUIZ_COMPILED = (int)Dm::NDER <= RUIZ_MAX_NDER;
     Ocp<Model>& ocp;
     SqpLds& v;
     QpLds& qw;
@@ -486,10 +489,25 @@ struct SqpDevice {
         const long long q0 = now();
         form_qp_bounds();
         pmpc_qp_info qi;
+        // m_preconditioner.compute(m_H, m_h, m_A, m_al, m_au, m_lx, m_ux), sqp_base.hpp:605 / :661 — in place in the workspace
+        // (compiled for models with at most RUIZ_MAX_NDER derivative directions: the 16-direction stand-in's kernel, whose AD
+        // arrays already live in private memory, returned NaNs as soon as this never-taken branch was added to it — hipcc 7.2;
+        // the launcher rejects preconditioner = 1 for such models)
+        bool ruiz = false;
+        const RuizScratch rz{v.t1, v.t1 + n, v.t2, v.t2 + n};
+        double rz_c = 1.0;
+        if constexpr (RUIZ_COMPILED) {
+            ruiz = __builtin_amdgcn_readfirstlane(ss.preconditioner) == 1;
+            if (ruiz) rz_c = ruiz_compute_wave(n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, rz);
+        }
         // 7-argument form: zero guesses (Q2)
         if constexpr (NN > 0) { boxadmm_solve_reg<NN, MM, true>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr); wsync(); }
         else boxadmm_solve(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi);
         qp_iter_total += qi.iter;
+        if constexpr (RUIZ_COMPILED) if (ruiz) {   // unscale(p, p_lambda); unscale(m_H, m_h, m_A, ...), sqp_base.hpp:608-609 / :664-665
+            ruiz_unscale_solution_wave(n, m, rz.D, rz.E, rz_c, qw.x, qw.y);
+            ruiz_unscale_problem_wave(n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, rz.D, rz.E, rz_c);
+        }
         // lam_k = p_lambda ; p_lambda -= lam
         for (int i = ln; i < m + n; i += WAVE) { v.lam_k[i] = qw.y[i]; qw.y[i] = qw.y[i] - v.lam[i]; }
         wsync();

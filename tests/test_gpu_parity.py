@@ -180,6 +180,50 @@ def test_collocation_vs_oracle(ctx, oracle, model, P, S, t0, tf, nd):
         close(ev["lag_hess"][b], eo["lag_hess"])
 
 
+# -------------------------------------------------------------------------------------------- §8f-2: Ruiz equilibration
+def test_ruiz_reference_known_answer(ctx, oracle):
+    """box_admm_test.cpp:47-83 through the GPU path: compute -> solve -> unscale gives (0.3, 0.7), SOLVED in < 150 iterations."""
+    import polympc_amd as pa
+    H = np.array([[4.0, 1.0], [1.0, 2.0]]).T.ravel()[None]
+    Hs, hs, As, al, au, xl, xu, D, E, c = ctx.qp_ruiz_compute_batch(H, [[1.0, 1.0]], [[1.0, 1.0]], [[1.0]], [[1.0]], [[0.0, 0.0]], [[0.7, 0.7]])
+    s = pa.qp_settings_default(); s.max_iter = 150
+    x, y, info = ctx.qp_solve_batch(Hs, hs, As, al, au, xl, xu, settings=s)
+    sol, dual = ctx.qp_ruiz_unscale_batch(D, E, c, x, y)
+    assert np.linalg.norm(sol[0] - [0.3, 0.7]) <= 1e-2 * np.linalg.norm([0.3, 0.7])
+    assert info["iter"][0] < 150 and info["status"][0] == pa.QP_SOLVED
+
+
+@pytest.mark.parametrize("n,m,B,scale", [(2, 1, 4, 1.0), (7, 3, 9, 50.0), (35, 21, 16, 1e-3), (66, 44, 4, 1.0), (5, 0, 3, 1.0), (3, 70, 2, 7.0)])
+def test_ruiz_compute_bit_exact_vs_oracle(ctx, oracle, n, m, B, scale):
+    """Scaled problem data, D, E, c and the unscaled solution are IDENTICAL to the CPU restatement (sqrt, division and the
+    association order of the diagonal products are the IEEE operations of the reference's expressions). Small `scale`
+    keeps the norms below 1 so that all four sweeps run; ragged shapes (m = 0, m > 64) included."""
+    from polympc_amd import workloads
+    q = workloads.random_qp_batch(B, n, m, seed=11)
+    args = (q["H"] * scale, q["h"], q["A"] * scale, q["Alb"], q["Aub"], q["xlb"], q["xub"])
+    g = ctx.qp_ruiz_compute_batch(*args)
+    o = oracle.ruiz_compute_batch(*args)
+    for a, b_ in zip(g, o):
+        assert np.array_equal(np.asarray(a).reshape(-1), np.asarray(b_).reshape(-1))
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(B, n)); y = rng.normal(size=(B, n + m))
+    gx, gy = ctx.qp_ruiz_unscale_batch(g[7], g[8], g[9], x, y)
+    ox, oy = oracle.ruiz_unscale_solution_batch(o[7], o[8], o[9], x, y)
+    assert np.array_equal(gx, ox) and np.array_equal(gy, oy)
+
+
+def test_sqp_with_ruiz_preconditioner_vs_oracle(ctx, oracle):
+    """SQPBase<..., RuizEquilibration> (sqp_base.hpp:605-611, :661-665): the fused kernel scales / unscales the QP data in place
+    around every QP exactly as the restatement does — register-resident QP (7 nodes) and LDS-resident QP (11 nodes)."""
+    from polympc_amd import workloads
+    for P, S, B in ((6, 1, 48), (5, 2, 8)):
+        (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, workloads.robot_batch(B, P=P, S=S), B, preconditioner=1)
+        same = (info["iter"] == np.array([i.iter for i in io])) & (info["status"] == np.array([i.status for i in io]))
+        assert same.mean() >= 0.95, (P, S, same.mean())
+        assert np.abs(x - xo)[same].max() <= 1e-8
+        assert np.abs(info["max_violation"] - [i.max_violation for i in io])[same].max() <= 1e-8
+
+
 # -------------------------------------------------------------------------------------------- A12-A15: fused SQP
 def _sqp_both(ctx, oracle, wl, B, **kw):
     import polympc_amd as pa

@@ -131,6 +131,49 @@ def test_boxadmm_adaptive_rho_helps(oracle):  # :190-231
     assert i1[0].iter < 1000 and i1[0].iter < i0[0].iter and i1[0].status == oracle.QP_SOLVED
 
 
+@pytest.mark.parametrize("pivot", [0, 1, 2])
+def test_boxadmm_ruiz_equilibration(oracle, pivot):  # box_admm_test.cpp:47-83 — the reference's known-answer test of RuizEquilibration
+    s = oracle.qp_default_settings(); s.max_iter = 150
+    H, h, A, al, au, xl, xu, D, E, c = oracle.ruiz_compute_batch(*_simple_qp())
+    x, y, info = oracle.qp_solve_batch(H, h, A, al, au, xl, xu, settings=s, pivot=pivot)
+    sol, dual = oracle.ruiz_unscale_solution_batch(D, E, c, x, y)
+    assert _is_approx(sol[0], np.array([0.3, 0.7]), 1e-2)
+    assert info[0].iter < 150 and info[0].status == oracle.QP_SOLVED
+
+
+def test_ruiz_scaling_is_a_congruence(oracle):
+    """compute() returns D, E, c with  H_s = c D H D,  A_s = E A D,  h_s = c D h,  bounds scaled by E and 1/D
+    (qp_preconditioners.hpp:197-232), and a badly scaled problem leaves the loop after one sweep (the loop condition
+    tests the norm measured BEFORE the sweep, :178,:187)."""
+    from polympc_amd import workloads
+    n, m, B = 7, 4, 6
+    qp = workloads.random_qp_batch(B, n, m, seed=3)
+    H0 = qp["H"].reshape(B, n, n).transpose(0, 2, 1) * 50.0; A0 = qp["A"].reshape(B, n, m).transpose(0, 2, 1)
+    Hc = np.ascontiguousarray(H0.transpose(0, 2, 1)).reshape(B, n * n)
+    H, h, A, al, au, xl, xu, D, E, c = oracle.ruiz_compute_batch(Hc, qp["h"], qp["A"], qp["Alb"], qp["Aub"], qp["xlb"], qp["xub"])
+    Hs = H.reshape(B, n, n).transpose(0, 2, 1); As = A.reshape(B, n, m).transpose(0, 2, 1)
+    for b in range(B):
+        assert np.allclose(Hs[b], c[b] * (D[b][:, None] * H0[b] * D[b][None, :]), rtol=1e-13)
+        assert np.allclose(As[b], E[b][:, None] * A0[b] * D[b][None, :], rtol=1e-13)
+        assert np.allclose(h[b], c[b] * D[b] * qp["h"][b], rtol=1e-13)
+        fin = np.isfinite(qp["Alb"][b]); assert np.allclose(al[b][fin], (qp["Alb"][b] * E[b])[fin], rtol=1e-14)
+        fin = np.isfinite(qp["xub"][b]); assert np.allclose(xu[b][fin], (qp["xub"][b] / D[b])[fin], rtol=1e-14)
+        # one sweep only: D = 1/sqrt(column norms of the ORIGINAL matrices)
+        d1 = 1.0 / np.sqrt(np.maximum(np.abs(H0[b]).max(axis=0), np.abs(A0[b]).max(axis=0)))
+        assert np.allclose(D[b], d1, rtol=1e-14)
+
+
+def test_sqp_with_ruiz_preconditioner(oracle):
+    """SQPBase<..., RuizEquilibration> (sqp_base.hpp:605-611): scaling the QP must not change what the SQP converges to."""
+    ss = oracle.sqp_default_settings(); ss.max_iter = 10; ss.line_search_max_iter = 10
+    lbx, ubx = _robot_bounds(7, [0.5, 0.5, 0.5])
+    x0, _, i0 = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 6, 1, 0.0, 2.0, 1, [[2.0]], lbx, ubx, sqp_settings=ss)
+    ss.preconditioner = 1
+    x1, _, i1 = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 6, 1, 0.0, 2.0, 1, [[2.0]], lbx, ubx, sqp_settings=ss)
+    assert i0[0].status == oracle.SQP_SOLVED and i1[0].status == oracle.SQP_SOLVED
+    assert np.abs(x0 - x1).max() < 5e-3
+
+
 def test_boxadmm_simple_lp(oracle):  # :266-297
     s = oracle.qp_default_settings(); s.max_iter = 200; s.alpha = 1.0; s.adaptive_rho = 1; s.check_termination = 10
     z = np.zeros((1, 0))

@@ -176,6 +176,19 @@ pmpc_status pmpc_sqp_solve_batch_dev(pmpc_context* ctx, int model, int P, int S,
                                      const double* lbg, const double* ubg, const pmpc_sqp_settings* sqp_settings,
                                      const pmpc_qp_settings* qp_settings, double* x, double* lam, pmpc_sqp_info* info);
 
+/* One receding-horizon step of B MPC<OCP> controllers, everything resident on the device (replaces the caller's loop around
+ * MPC::initial_conditions(x0) + MPC::solve() + MPC::solution_u_at(t_start), mpc_wrapper.hpp:89-93, :298, :241-244):
+ *   1. pins x0 (B*NX) on the LAST nx entries of the x block of lbx / ubx (in place),
+ *   2. solves every OCP warm-started from the CURRENT contents of x (B*n) and lam (B*(m+n)) — zeros for a cold start —
+ *      and overwrites them with the new primal / dual solution (Solver::solve() keeps m_x / m_lam between calls),
+ *   3. writes the control to apply now, u(t_start) = the last node of the u block, to u0 (B*NU; may be NULL).
+ * Device pointers, asynchronous on the context's stream: the plant model / next x0 can be produced on the same stream
+ * without any host round trip. */
+pmpc_status pmpc_mpc_step_batch_dev(pmpc_context* ctx, int model, int P, int S, double t0, double tf, const double* mparams,
+                                    int n_mparams, int B, const double* x0, const double* d, double* lbx, double* ubx,
+                                    const double* lbg, const double* ubg, const pmpc_sqp_settings* sqp_settings,
+                                    const pmpc_qp_settings* qp_settings, double* x, double* lam, pmpc_sqp_info* info, double* u0);
+
 /* ---- user-defined OCPs ---------------------------------------------------------------------------------------------
  * A user's OCP class (the reference's CRTP class with dynamics_impl / lagrange_term_impl / mayer_term_impl /
  * inequality_constraints_impl, continuous_ocp.hpp:191-288) is compiled for the GPU by hipcc in the user's own

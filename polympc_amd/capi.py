@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "pmpc_qp_settings_default", "pmpc_qp_settings_sqp_default", "pmpc_sqp_settings_default", "pmpc_chebyshev",
     "pmpc_qp_boxadmm_solve_batch", "pmpc_qp_boxadmm_solve_batch_dev", "pmpc_ocp_dims", "pmpc_ocp_linearise_batch",
     "pmpc_sqp_solve_batch", "pmpc_sqp_solve_batch_dev", "pmpc_sqp_solve_batch_user",
-    "pmpc_qp_ruiz_compute_batch", "pmpc_qp_ruiz_compute_batch_dev", "pmpc_qp_ruiz_unscale_batch", "pmpc_qp_ruiz_unscale_batch_dev",
+    "pmpc_mpc_step_batch_dev", "pmpc_qp_ruiz_compute_batch", "pmpc_qp_ruiz_compute_batch_dev", "pmpc_qp_ruiz_unscale_batch", "pmpc_qp_ruiz_unscale_batch_dev",
 ]
 
 
@@ -225,6 +225,17 @@ class Context:
                  *[k[1] for k in keep[1:]], C.byref(ss), C.byref(qs), x.ctypes.data_as(P_), lam.ctypes.data_as(P_),
                  C.c_void_p(info.ctypes.data)))
         return x, lam, info
+
+    # ------------------------------------------------------------------ MPC step, device buffers (torch tensors), asynchronous
+    def mpc_step_batch_dev(self, model, P, S, t0, tf, B, x0, d, lbx, ubx, x, lam, info, sqp_settings, qp_settings, u0=None, lbg=None,
+                           ubg=None, mparams=None):
+        mk, mp = _h(mparams)
+        P_ = C.POINTER(C.c_double)
+        f = lib().pmpc_mpc_step_batch_dev
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, P_, C.c_int, C.c_int] + [P_] * 6 + \
+                     [C.POINTER(SQPSettings), C.POINTER(QPSettings), P_, P_, C.c_void_p, P_]
+        _check(f(self._ctx, model, P, S, t0, tf, mp, 0 if mk is None else len(mk), B, _d(x0), _d(d), _d(lbx), _d(ubx), _d(lbg), _d(ubg),
+                 C.byref(sqp_settings), C.byref(qp_settings), _d(x), _d(lam), C.c_void_p(info.data_ptr()), _d(u0)))
 
     # ------------------------------------------------------------------ SQP, device buffers (torch tensors), asynchronous
     def sqp_solve_batch_dev(self, model, P, S, t0, tf, B, d, lbx, ubx, x, lam, info, sqp_settings, qp_settings, lbg=None,

@@ -433,6 +433,46 @@ pmpc_status pmpc_sqp_solve_batch_dev(pmpc_context* ctx, int model, int P, int S,
     DISPATCH_MODEL(model, sqp_builtin_dev, ctx, P, S, t0, tf, mparams, n_mparams, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, x, lam, info);
 }
 
+/* MPC façade, batched (mpc_wrapper.hpp:89-93 initial_conditions, :298 solve, :241-244 solution_u_at): one receding-horizon step */
+__global__ void mpc_pin_initial_state_kernel(int B, int n, int varx, int nx, const double* __restrict__ x0, double* __restrict__ lbx,
+                                             double* __restrict__ ubx) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * nx) return;
+    const int b = idx / nx, q = idx - b * nx;
+    const size_t e = (size_t)b * n + varx - nx + q;   // the LAST nx entries of the x block are the state at t_start
+    lbx[e] = x0[idx]; ubx[e] = x0[idx];
+}
+__global__ void mpc_first_control_kernel(int B, int n, int varx, int nu, int nn, const double* __restrict__ x, double* __restrict__ u0) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * nu) return;
+    const int b = idx / nu, i = idx - b * nu;
+    u0[idx] = x[(size_t)b * n + varx + (size_t)(nn - 1) * nu + i];
+}
+pmpc_status pmpc_mpc_step_batch_dev(pmpc_context* ctx, int model, int P, int S, double t0, double tf, const double* mparams, int n_mparams,
+                                    int B, const double* x0, const double* d, double* lbx, double* ubx, const double* lbg,
+                                    const double* ubg, const pmpc_sqp_settings* ss, const pmpc_qp_settings* qs, double* x, double* lam,
+                                    pmpc_sqp_info* info, double* u0) {
+    if (!ctx || B < 0 || !x0 || !lbx || !ubx || !ss || !qs || !x || !lam || !info) return PMPC_ERR_INVALID_ARGUMENT;
+    if (B == 0) return PMPC_OK;
+    int nx, nu, np, nd, ng, n, me, mi;
+    pmpc_status st = pmpc_ocp_dims(model, P, S, &nx, &nu, &np, &nd, &ng, &n, &me, &mi);
+    if (st != PMPC_OK) return st;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int m = me + mi, nn = P * S + 1, varx = nx * nn;
+    hipLaunchKernelGGL(mpc_pin_initial_state_kernel, dim3((B * nx + 255) / 256), dim3(256), 0, ctx->stream, B, n, varx, nx, x0, lbx, ubx);
+    // warm start: the previous solution is the guess (SQPBase::solve() starts from m_x / m_lam, sqp_base.hpp:569-581); the
+    // kernel's guess and result pointers must not alias, so the guess is a device-to-device copy
+    double *xg, *lg;
+    DEVOUT(12, (size_t)B * n * sizeof(double), xg); DEVOUT(13, (size_t)B * (m + n) * sizeof(double), lg);
+    HIPCHK(hipMemcpyAsync(xg, x, (size_t)B * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(lg, lam, (size_t)B * (m + n) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    st = pmpc_sqp_solve_batch_dev(ctx, model, P, S, t0, tf, mparams, n_mparams, B, xg, lg, d, lbx, ubx, lbg, ubg, ss, qs, x, lam, info);
+    if (st != PMPC_OK) return st;
+    if (u0) hipLaunchKernelGGL(mpc_first_control_kernel, dim3((B * nu + 255) / 256), dim3(256), 0, ctx->stream, B, n, varx, nu, nn, x, u0);
+    HIPCHK(hipGetLastError());
+    return PMPC_OK;
+}
+
 pmpc_status pmpc_sqp_solve_batch(pmpc_context* ctx, int model, int P, int S, double t0, double tf, const double* mparams,
                                  int n_mparams, int B, const double* x_guess, const double* lam_guess, const double* d,
                                  const double* lbx, const double* ubx, const double* lbg, const double* ubg,

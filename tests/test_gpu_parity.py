@@ -368,6 +368,21 @@ def test_sqp_codegen_robot_exact_hessian(ctx, oracle):
     assert info["iter"][0] == io[0].iter and np.abs(x - xo).max() <= 1e-8
 
 
+def test_sqp_minimal_time_valet_parking(ctx, oracle):
+    """minimal_time_test.cpp:146-188 through the GPU path (NP = 1 border blocks, exact Hessian every iteration, Gershgorin shift,
+    parameter / final-state bounds, primal guess): SOLVED in < 20 iterations like the reference asserts, same iteration count
+    as the CPU restatement, x within 1e-7."""
+    import polympc_amd as pa
+    from test_oracle_pins import _minimal_time_parking
+    lbx, ubx, xg = _minimal_time_parking()
+    ss = pa.sqp_settings_default(); ss.max_iter = 20; ss.line_search_max_iter = 10; ss.regularisation = 2; ss.exact_hessian_every_iter = 1
+    x, lam, info = ctx.sqp_solve_batch(pa.MODEL_PARKING, 5, 2, 0.0, 1.0, 1, [[1.0]], lbx, ubx, x_guess=xg, sqp_settings=ss)
+    oss = oracle.sqp_default_settings(); oss.max_iter = 20; oss.line_search_max_iter = 10; oss.regularisation = 2; oss.exact_hessian_every_iter = 1
+    xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_PARKING, 5, 2, 0.0, 1.0, 1, [[1.0]], lbx, ubx, x_guess=xg, sqp_settings=oss, pivot=oracle.PIVOT_STATIC)
+    assert info["status"][0] == pa.SQP_SOLVED and info["iter"][0] < 20
+    assert info["iter"][0] == io[0].iter and np.abs(x - xo).max() <= 1e-7
+
+
 def test_sqp_cstr_config_B(ctx, oracle):
     """Config B (CSTR, 110 KKT rows, exp-heavy dynamics, badly scaled): trajectory parity on a small batch."""
     from polympc_amd import workloads

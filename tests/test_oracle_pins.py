@@ -312,6 +312,30 @@ def test_sqp_robot_mpc_warm_start(oracle, pivot):  # mpc_wrapper_test.cpp:120-16
     assert np.all(x2[0, 48:] <= np.tile([1.5, 0.75], 16) + 1e-3) and np.all(x2[0, 48:] >= -np.tile([1.5, 0.75], 16) - 1e-3)
 
 
+def _minimal_time_parking():
+    """minimal_time_test.cpp:146-184: parking OCP with a free time-scaling parameter (NP = 1), P=5 S=2, d = 1, x0 = (1.5, .5, .5)
+    pinned on the last node, final state within +-0.05 (first nx entries, mpc_wrapper.hpp:132-137), p in [0, 10], guesses
+    p = 0.5 and x = x0 at every node."""
+    nn = 11; n = 5 * nn + 1
+    lbx = np.full(n, -inf); ubx = np.full(n, inf)
+    lbx[3 * nn:5 * nn] = np.tile([-1.5, -0.75], nn); ubx[3 * nn:5 * nn] = np.tile([1.5, 0.75], nn)
+    lbx[5 * nn] = 0.0; ubx[5 * nn] = 10.0
+    lbx[0:3] = -0.05; ubx[0:3] = 0.05
+    lbx[3 * nn - 3:3 * nn] = [1.5, 0.5, 0.5]; ubx[3 * nn - 3:3 * nn] = [1.5, 0.5, 0.5]
+    xg = np.zeros(n); xg[:3 * nn] = np.tile([1.5, 0.5, 0.5], nn); xg[5 * nn] = 0.5
+    return lbx[None], ubx[None], xg[None]
+
+
+@pytest.mark.parametrize("pivot", [0, 1])
+def test_sqp_minimal_time_valet_parking(oracle, pivot):  # minimal_time_test.cpp:146-188 — exact Hessian every iteration + Gershgorin
+    ss = oracle.sqp_default_settings(); ss.max_iter = 20; ss.line_search_max_iter = 10
+    ss.regularisation = 2; ss.exact_hessian_every_iter = 1
+    lbx, ubx, xg = _minimal_time_parking()
+    x, lam, info = oracle.sqp_solve_batch(oracle.MODEL_PARKING, 5, 2, 0.0, 1.0, 1, [[1.0]], lbx, ubx, x_guess=xg, sqp_settings=ss, pivot=pivot)
+    assert info[0].status == oracle.SQP_SOLVED and info[0].iter < 20          # the reference's two assertions (:186-187)
+    assert 0.0 < x[0, 55] < 10.0 and np.abs(x[0, 0:3]).max() <= 0.05 + 1e-3   # a time inside its bounds, parked within tolerance
+
+
 def test_sqp_cstr(oracle):  # cstr_control_test.cpp:137-183 (Eigen pivot policy)
     ss = oracle.sqp_default_settings(); ss.max_iter = 20; ss.line_search_max_iter = 20
     n = 66

@@ -383,6 +383,27 @@ def test_sqp_minimal_time_valet_parking(ctx, oracle):
     assert info["iter"][0] == io[0].iter and np.abs(x - xo).max() <= 1e-7
 
 
+def test_sqp_valet_parking_with_ruiz(ctx, oracle):
+    """valet_parking_mpc_test.cpp:183-240 through the GPU path (Ruiz preconditioner, QP max_iter 1000, cold + warm-started
+    solve, l1 / dense-BFGS variant — see tests/test_oracle_pins.py): both solves SOLVED in < 10 iterations as the reference
+    asserts, same iteration counts as the CPU restatement, x within 1e-7."""
+    import polympc_amd as pa
+    from test_oracle_pins import _valet_bounds
+    ss = pa.sqp_settings_default(); ss.max_iter = 10; ss.line_search_max_iter = 10; ss.preconditioner = 1
+    qs = pa.qp_settings_sqp_default(); qs.max_iter = 1000
+    oss = oracle.sqp_default_settings(); oss.max_iter = 10; oss.line_search_max_iter = 10; oss.preconditioner = 1
+    oqs = oracle.sqp_qp_default_settings(); oqs.max_iter = 1000
+    xg = lg = xo = lo = None
+    for x0 in ([0.5, 0.5, 0.5], [0.3, 0.4, 0.45]):
+        lbx, ubx = _valet_bounds(x0)
+        xg, lg, info = ctx.sqp_solve_batch(pa.MODEL_ROBOT, 5, 2, 0.0, 2.0, 1, [[2.0]], lbx, ubx, x_guess=xg, lam_guess=lg, sqp_settings=ss,
+                                           qp_settings=qs, mparams=[1.0])
+        xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 2.0, 1, [[2.0]], lbx, ubx, x_guess=xo, lam_guess=lo, sqp_settings=oss,
+                                            qp_settings=oqs, pivot=oracle.PIVOT_STATIC, mparams=[1.0])
+        assert info["status"][0] == pa.SQP_SOLVED and info["iter"][0] < 10
+        assert info["iter"][0] == io[0].iter and np.abs(xg - xo).max() <= 1e-7
+
+
 def test_sqp_cstr_config_B(ctx, oracle):
     """Config B (CSTR, 110 KKT rows, exp-heavy dynamics, badly scaled): trajectory parity on a small batch."""
     from polympc_amd import workloads

@@ -336,6 +336,31 @@ def test_sqp_minimal_time_valet_parking(oracle, pivot):  # minimal_time_test.cpp
     assert 0.0 < x[0, 55] < 10.0 and np.abs(x[0, 0:3]).max() <= 0.05 + 1e-3   # a time inside its bounds, parked within tolerance
 
 
+def _valet_bounds(x0):
+    nn = 11; n = 5 * nn
+    lbx = np.full(n, -inf); ubx = np.full(n, inf)
+    lbx[3 * nn:] = np.tile([-1.5, -0.75], nn); ubx[3 * nn:] = np.tile([1.5, 0.75], nn)
+    lbx[30:33] = x0; ubx[30:33] = x0
+    return lbx[None], ubx[None]
+
+
+@pytest.mark.parametrize("pivot", [0, 1])
+def test_sqp_valet_parking_with_ruiz(oracle, pivot):
+    """valet_parking_mpc_test.cpp:183-240 — SQP with the RuizEquilibration preconditioner, QP max_iter 1000, cold solve then a
+    warm-started solve from a moved initial state; both must be SOLVED in < 10 iterations. (Variant: the reference's solver
+    there also swaps in a filter line search and the block BFGS of ContinuousOCP, which are out of scope; this runs the
+    default l1 line search and dense damped BFGS.)"""
+    ss = oracle.sqp_default_settings(); ss.max_iter = 10; ss.line_search_max_iter = 10; ss.preconditioner = 1
+    qs = oracle.sqp_qp_default_settings(); qs.max_iter = 1000
+    kw = dict(sqp_settings=ss, qp_settings=qs, pivot=pivot, mparams=[1.0])
+    lbx, ubx = _valet_bounds([0.5, 0.5, 0.5])
+    x, lam, i1 = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 2.0, 1, [[2.0]], lbx, ubx, **kw)
+    assert i1[0].status == oracle.SQP_SOLVED and i1[0].iter < 10
+    lbx, ubx = _valet_bounds([0.3, 0.4, 0.45])
+    x2, lam2, i2 = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 2.0, 1, [[2.0]], lbx, ubx, x_guess=x, lam_guess=lam, **kw)
+    assert i2[0].status == oracle.SQP_SOLVED and i2[0].iter < 10
+
+
 def test_sqp_cstr(oracle):  # cstr_control_test.cpp:137-183 (Eigen pivot policy)
     ss = oracle.sqp_default_settings(); ss.max_iter = 20; ss.line_search_max_iter = 20
     n = 66

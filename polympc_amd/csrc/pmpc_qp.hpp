@@ -75,14 +75,28 @@ struct UniformDiv {
 
 // sequential (index-ordered) sum of an LDS vector, evaluated redundantly by every lane (broadcast reads): the
 // same association order as the reference's scalar loops, no cross-lane traffic
+// (loads in chunks of 8 independent reads, then the ordered add chain: a loop with one load per iteration waits a full
+// LDS round trip per element)
 __device__ __forceinline__ double seq_sum(const double* v, int n) {
     double a = 0.0;
-    for (int i = 0; i < n; ++i) a += v[i];
+    for (int i0 = 0; i0 < n; i0 += 8) {
+        double t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = v[(i0 + j < n) ? i0 + j : 0];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (i0 + j < n) a += t[j];
+    }
     return a;
 }
 __device__ __forceinline__ double seq_dot(const double* a, const double* b, int n) {
     double s = 0.0;
-    for (int i = 0; i < n; ++i) s += a[i] * b[i];
+    for (int i0 = 0; i0 < n; i0 += 8) {
+        double ta[8], tb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int i = (i0 + j < n) ? i0 + j : 0; ta[j] = a[i]; tb[j] = b[i]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (i0 + j < n) s += ta[j] * tb[j];
+    }
     return s;
 }
 __device__ __forceinline__ double lds_inf_norm(const double* v, int n) {

@@ -55,11 +55,24 @@ __device__ __forceinline__ double mov_lanes_range(double dst, double src, int lo
     return dst;
 }
 
-// a0..a6 <- 0 on lane `k` only (compile-time k): one EXEC switch for the seven moves
-__device__ __forceinline__ void zero_on_lane(double& a0, double& a1, double& a2, double& a3, double& a4, double& a5, double& a6, int k) {
-    asm("s_lshl_b64 exec, 1, %7\n\tv_mov_b64 %0, 0\n\tv_mov_b64 %1, 0\n\tv_mov_b64 %2, 0\n\tv_mov_b64 %3, 0\n\tv_mov_b64 %4, 0\n\tv_mov_b64 %5, 0\n\t"
-        "v_mov_b64 %6, 0\n\ts_mov_b64 exec, -1"
-        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6) : "i"(k) : "scc");
+// a0..a6 <- 0 and l <- lk on lane `k` only (compile-time k): one EXEC switch for the eight moves
+__device__ __forceinline__ void pivot_lane_setup(double& a0, double& a1, double& a2, double& a3, double& a4, double& a5, double& a6, double& l,
+                                                 double lk, int k) {
+    asm("s_lshl_b64 exec, 1, %9\n\tv_mov_b64 %0, 0\n\tv_mov_b64 %1, 0\n\tv_mov_b64 %2, 0\n\tv_mov_b64 %3, 0\n\tv_mov_b64 %4, 0\n\tv_mov_b64 %5, 0\n\t"
+        "v_mov_b64 %6, 0\n\tv_mov_b64 %7, %8\n\ts_mov_b64 exec, -1"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(l) : "v"(lk), "i"(k) : "scc");
+}
+// 1 / d, branch-free: the generic IEEE division expansion (v_rcp_f64, two Newton steps, residual correction, v_div_fixup for
+// 0 / inf / NaN) WITHOUT its v_div_scale pre-scaling — 8 VALU operations instead of 12. The pre-scaling only matters when d or
+// 1/d is subnormal (|d| beyond 2^+-1021); everywhere else the result is the correctly rounded quotient, bit for bit what the
+// CPU checker's 1.0 / d gives. (A scalar range test + branch to the generic division was measured: the branch latency in
+// front of every pivot costs more than the four operations it saves.)
+__device__ __forceinline__ double recip_uniform(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    y = fma(fma(-d, y, 1.0), y, y);
+    y = fma(fma(-d, y, 1.0), y, y);
+    y = fma(fma(-d, y, 1.0), y, y);
+    return __builtin_amdgcn_div_fixup(y, d, 1.0);
 }
 
 // acc <- fma(x of lane J of this lane's 16-lane row, w, acc): the broadcast is a DPP operand modifier of the fma itself
@@ -207,13 +220,13 @@ struct RegKkt {
                 const int k = kb + t;
                 if (k < N) {
                     const double dk = bcast_lane(p[t], k);
-                    const double r = 1.0 / dk;
+                    const double r = recip_uniform(dk);
                     double rk[BK];
 #pragma unroll
                     for (int u = 0; u < BK; ++u) rk[u] = (u != t) ? bcast_lane(p[u], k) : 0.0;
-                    const double l = (ln == k) ? -r : p[t] * r;
-                    // the seven other columns of lane k start from zero, so that one fma serves every lane
-                    zero_on_lane(p[(t + 1) & 7], p[(t + 2) & 7], p[(t + 3) & 7], p[(t + 4) & 7], p[(t + 5) & 7], p[(t + 6) & 7], p[(t + 7) & 7], k);
+                    double l = p[t] * r;
+                    // lane k: l = -r, and its seven other columns start from zero, so that one fma serves every lane
+                    pivot_lane_setup(p[(t + 1) & 7], p[(t + 2) & 7], p[(t + 3) & 7], p[(t + 4) & 7], p[(t + 5) & 7], p[(t + 6) & 7], p[(t + 7) & 7], l, -r, k);
 #pragma unroll
                     for (int u = 0; u < BK; ++u)
                         if (u != t) p[u] = fma(-l, rk[u], p[u]);
@@ -461,15 +474,15 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
                     for (int k = 0; k < RC; ++k) if (k0 + k < MM) aty += mcol[k] * bcast_lane(yv, NN + k0 + k);
                     sched_fence();
                 }
-                const double nAx = wave_max(isC ? fabs(acc) : 0.0), nz = wave_max(isC ? fabs(xv) : 0.0), nx = wave_max(isP ? fabs(xv) : 0.0);
+                // max is exact and order-free: the maximum of several infinity norms is ONE wave reduction of the per-lane maxima
+                //   max(|Ax|, |z|, |x|):  constraint lanes carry |(Ax)_r| and |z_r|, primal lanes |x_i|
+                //   max(|Hx|, |A'y|, |h|, |y_box|):  primal lanes only (hv is zero elsewhere)
+                const double ax = fabs(xv);
+                max_Ax_z_norm = wave_max(isC ? fmax(fabs(acc), ax) : (isP ? ax : 0.0));
+                max_Hx_ATy_h_norm = wave_max(isP ? fmax(fmax(fabs(acc), fabs(aty)), fmax(fabs(hv), fabs(yv))) : 0.0);
                 const double rp = wave_max(isC ? fabs(acc - xv) : 0.0), rq = wave_max(isP ? fabs(xv - qv) : 0.0);
-                const double nHx = wave_max(isP ? fabs(acc) : 0.0), nATy = wave_max(isP ? fabs(aty) : 0.0);
-                const double nh = wave_max(fabs(hv)), nyb = wave_max(isP ? fabs(yv) : 0.0);
-                const double rd = wave_max(isP ? fabs(((acc + hv) + aty) + yv) : 0.0);
-                max_Ax_z_norm = fmax(nAx, fmax(nz, nx));
-                max_Hx_ATy_h_norm = fmax(nHx, fmax(nATy, fmax(nh, nyb)));
                 res_prim = rp + rq;
-                res_dual = rd;
+                res_dual = wave_max(isP ? fabs(((acc + hv) + aty) + yv) : 0.0);
                 if (dbg) dbg[1] += clock64() - r0;
             }
             if (check) {

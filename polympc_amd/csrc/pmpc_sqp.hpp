@@ -84,9 +84,9 @@ struct SqpDevice {
         for (int i = ln; i < me; i += WAVE) c = fmax(c, fabs(v.cb[i]));
         for (int i = ln; i < mi; i += WAVE) { a = fmax(a, v.lbg[i] - v.cb[me + i]); b = fmax(b, v.cb[me + i] - v.ubg[i]); }
         for (int i = ln; i < n; i += WAVE) { e = fmax(e, v.lbx[i] - xx[i]); f = fmax(f, xx[i] - v.ubx[i]); }
+        // one reduction of the per-lane maxima (max is exact and order-free)
+        c = fmax(fmax(c, fmax(a, b)), fmax(e, f));
         c = wave_max(c);
-        if (mi > 0) { c = fmax(c, wave_max(a)); c = fmax(c, wave_max(b)); }
-        c = fmax(c, wave_max(e)); c = fmax(c, wave_max(f));
         wsync();
         return c;
     }

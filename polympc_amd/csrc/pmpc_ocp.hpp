@@ -162,32 +162,44 @@ struct Ocp {
     }
 
     // ---- per-node first-order stage: f, df, L, dL, g, dg, DX, Mayer value+gradient
+    // One lane per (node, derivative direction): the NDER partial derivatives of a node are independent columns of the same
+    // forward sweep, so each lane carries ONE derivative component (Dual<double,1>: 4 operations per product instead of
+    // 1 + 3*NDER) and NN*NDER lanes work side by side. Every value and every derivative goes through exactly the operations
+    // it went through as component `dir` of a Dual<double,NDER>; the lanes of direction 0 store the values.
     __device__ __forceinline__ void stage_first_order(const double* var) {
-        for (int k = lane_id(); k < dm.NN; k += WAVE) {
-            ad1 x[NX > 0 ? NX : 1], u[NU > 0 ? NU : 1], p[NP > 0 ? NP : 1], y[NX > 0 ? NX : 1];
-            seed1<ad1>(var, k, x, u, p);
-            for (int q = 0; q < NX; ++q) y[q] = ad1(0.0);
-            ad1 tk(s.tn[k]);
-            model.template dynamics_impl<ad1>(cref<ad1>(x), cref<ad1>(u), cref<ad1>(p), cref<double>(d), tk, vref<ad1>(y));
-            for (int q = 0; q < NX; ++q) {
-                s.fval[k * NX + q] = y[q].v;
-                for (int i = 0; i < NDER; ++i) s.fjac[(k * NX + q) * NDER + i] = y[q].d[i];
+        using ad = Dual<double, 1>;
+        for (int kd = lane_id(); kd < dm.NN * NDER; kd += WAVE) {
+            const int k = kd % dm.NN, dir = kd / dm.NN;
+            ad x[NX > 0 ? NX : 1], u[NU > 0 ? NU : 1], p[NP > 0 ? NP : 1], y[NX > 0 ? NX : 1];
+            {
+                int idx = 0;
+                for (int i = 0; i < NX; ++i, ++idx) { x[i] = ad(var[k * NX + i]); x[i].d[0] = (idx == dir) ? 1.0 : 0.0; }
+                for (int i = 0; i < NU; ++i, ++idx) { u[i] = ad(var[dm.VARX + k * NU + i]); u[i].d[0] = (idx == dir) ? 1.0 : 0.0; }
+                for (int i = 0; i < NP; ++i, ++idx) { p[i] = ad(var[dm.VARX + dm.VARU + i]); p[i].d[0] = (idx == dir) ? 1.0 : 0.0; }
             }
-            ad1 L(0.0);
-            model.template lagrange_term_impl<ad1>(cref<ad1>(x), cref<ad1>(u), cref<ad1>(p), cref<double>(d), s.tn[k], L);
-            s.Lval[k] = L.v;
-            for (int i = 0; i < NDER; ++i) s.Lgrad[k * NDER + i] = L.d[i];
+            for (int q = 0; q < NX; ++q) y[q] = ad(0.0);
+            ad tk(s.tn[k]);
+            model.template dynamics_impl<ad>(cref<ad>(x), cref<ad>(u), cref<ad>(p), cref<double>(d), tk, vref<ad>(y));
+            for (int q = 0; q < NX; ++q) {
+                if (dir == 0) s.fval[k * NX + q] = y[q].v;
+                s.fjac[(k * NX + q) * NDER + dir] = y[q].d[0];
+            }
+            ad L(0.0);
+            model.template lagrange_term_impl<ad>(cref<ad>(x), cref<ad>(u), cref<ad>(p), cref<double>(d), s.tn[k], L);
+            if (dir == 0) s.Lval[k] = L.v;
+            s.Lgrad[k * NDER + dir] = L.d[0];
             if (NG > 0) {
-                ad1 g[NG > 0 ? NG : 1];
-                for (int q = 0; q < NG; ++q) g[q] = ad1(0.0);
-                model.template inequality_constraints_impl<ad1>(cref<ad1>(x), cref<ad1>(u), cref<ad1>(p), cref<double>(d), s.tn[k], vref<ad1>(g));
+                ad g[NG > 0 ? NG : 1];
+                for (int q = 0; q < NG; ++q) g[q] = ad(0.0);
+                model.template inequality_constraints_impl<ad>(cref<ad>(x), cref<ad>(u), cref<ad>(p), cref<double>(d), s.tn[k], vref<ad>(g));
                 for (int q = 0; q < NG; ++q) {
-                    s.gval[k * NG + q] = g[q].v;
-                    for (int i = 0; i < NDER; ++i) s.gjac[(k * NG + q) * NDER + i] = g[q].d[i];
+                    if (dir == 0) s.gval[k * NG + q] = g[q].v;
+                    s.gjac[(k * NG + q) * NDER + dir] = g[q].d[0];
                 }
             }
-            int seg, row; seg_row(k, seg, row);
-            {   // D-row times the segment's states: loads of 4 nodes at a time (independent), then the ordered adds
+            if (dir == 0) {
+                int seg, row; seg_row(k, seg, row);
+                // D-row times the segment's states: loads of 4 nodes at a time (independent), then the ordered adds
                 double acc[NX > 0 ? NX : 1];
                 for (int q = 0; q < NX; ++q) acc[q] = 0.0;
                 for (int j0 = 0; j0 <= P; j0 += 4) {
@@ -210,10 +222,10 @@ struct Ocp {
                 for (int q = 0; q < NX; ++q) s.DX[k * NX + q] = acc[q];
             }
             if (k == 0) {
-                ad1 M(0.0);
-                model.template mayer_term_impl<ad1>(cref<ad1>(x), cref<ad1>(u), cref<ad1>(p), cref<double>(d), s.tn[0], M);
-                s.Mval[0] = M.v;
-                for (int i = 0; i < NDER; ++i) s.Mgrad[i] = M.d[i];
+                ad M(0.0);
+                model.template mayer_term_impl<ad>(cref<ad>(x), cref<ad>(u), cref<ad>(p), cref<double>(d), s.tn[0], M);
+                if (dir == 0) s.Mval[0] = M.v;
+                s.Mgrad[dir] = M.d[0];
             }
         }
         wsync();

@@ -417,6 +417,9 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
             const long long f0 = dbg ? clock64() : 0;
             K.invert(ln, tr, kdiag, [&](int j, int z) -> double {   // row `lane` of [H  A^T ; A  .] (construct_kkt_matrix, box_admm.hpp:209-223)
                 if (j < NN) return Krow(j < NN ? j : 0, z);
+                // block-lower tile storage: column j is staged for the lanes of tile rows >= j/16 only, and the A' block is
+                // non-zero on primal lanes only — past the last primal tile row it is never consumed, so it is not loaded
+                if (16 * (j / 16) >= NN) return 0.0;
                 const double v = Acol(j >= NN ? j - NN : 0, z);
                 if constexpr (STACKED) return lane_near(z) < (unsigned)NN ? v : 0.0;
                 return isP ? v : 0.0;

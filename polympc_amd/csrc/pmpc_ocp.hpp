@@ -49,20 +49,25 @@ struct OcpLds {
     using Dm = OcpDims<Model>;
     enum { NX = Dm::NX, NU = Dm::NU, NP = Dm::NP, NG = Dm::NG, NDER = Dm::NDER };
     double *D, *w, *tn;                                 // collocation constants
+    double *nd, *nw1, *nw2; int* nsr;                   // per node: D self entry, the two quadrature weights * t_scale, packed (flags, segment, row)
     double *fval, *fjac, *Lval, *Lgrad, *gval, *gjac;   // per node: f (NX), df (NX*NDER), L, dL (NDER), g (NG), dg (NG*NDER)
     double *Lhes, *dhes;                                // per node: d2L (NDER^2), sum lam * d2(f,g) (NDER^2)
     double *Mval, *Mgrad, *Mhes;                        // Mayer term at node 0
     double *DX;                                         // D*X per node (NX)
     __host__ __device__ static size_t doubles(int P, int S) {
         const int NN = P * S + 1;
-        return (size_t)(P + 1) * (P + 1) + (P + 1) + NN + (size_t)NN * (NX + NX * NDER + 1 + NDER + NG + NG * NDER + 2 * NDER * NDER + NX) +
+        return const_doubles(P, S) + (size_t)NN * (NX + NX * NDER + 1 + NDER + NG + NG * NDER + 2 * NDER * NDER + NX) +
                1 + NDER + NDER * NDER + 8;
     }
     // collocation constants come first; everything after them is per-linearisation staging
-    __host__ __device__ static size_t const_doubles(int P, int S) { return (size_t)(P + 1) * (P + 1) + (P + 1) + (P * S + 1); }
+    __host__ __device__ static size_t const_doubles(int P, int S) {
+        const int NN = P * S + 1;
+        return (size_t)(P + 1) * (P + 1) + (P + 1) + NN + 3 * (size_t)NN + (size_t)(NN + 1) / 2;
+    }
     __device__ double* carve(double* p, int P, int S) {
         const int NN = P * S + 1;
         D = p; p += (P + 1) * (P + 1); w = p; p += P + 1; tn = p; p += NN;
+        nd = p; p += NN; nw1 = p; p += NN; nw2 = p; p += NN; nsr = (int*)p; p += (NN + 1) / 2;
         fval = p; p += NN * NX; fjac = p; p += NN * NX * NDER; Lval = p; p += NN; Lgrad = p; p += NN * NDER;
         gval = p; p += NN * NG; gjac = p; p += NN * NG * NDER; Lhes = p; p += NN * NDER * NDER; dhes = p; p += NN * NDER * NDER;
         Mval = p; p += 1; Mgrad = p; p += NDER; Mhes = p; p += NDER * NDER; DX = p; p += NN * NX;
@@ -91,12 +96,25 @@ struct Ocp {
         for (int i = ln; i < (P + 1) * (P + 1); i += WAVE) s.D[i] = cd->D[i];
         for (int i = ln; i <= P; i += WAVE) s.w[i] = cd->w[i];
         for (int i = ln; i < dm.NN; i += WAVE) s.tn[i] = cd->tn[i];
+        // per-node table: everything the hot loops would otherwise derive from k / P and k % P (integer divisions by a run-time
+        // value) — (segment, row) of seg_row, the node's own D entry, and the cost-gradient weights of :1218-1240 with the
+        // conditions under which they apply (bit 30: node closes a segment, bit 29: node opens / lies inside one)
+        for (int k = ln; k < dm.NN; k += WAVE) {
+            int seg, row;
+            if (k == dm.NN - 1) { seg = S - 1; row = P; } else { seg = k / P; row = k % P; }
+            const bool closes = (k % P == 0) && k > 0, inside = k < dm.NN - 1;
+            s.nsr[k] = (closes ? (1 << 30) : 0) | (inside ? (1 << 29) : 0) | (seg << 5) | row;
+            s.nd[k] = inside ? cd->D[row + row * (P + 1)] * 1.0 : -cd->D[0];
+            s.nw1[k] = ts * cd->w[P];
+            s.nw2[k] = ts * cd->w[k % P];
+        }
         wsync();
     }
 
     // (segment, row) whose D row produces node k: later segments overwrite the junction row (:750-751)
-    __device__ void seg_row(int k, int& seg, int& row) const {
-        if (k == dm.NN - 1) { seg = S - 1; row = P; } else { seg = k / P; row = k % P; }
+    __device__ __forceinline__ void seg_row(int k, int& seg, int& row) const {
+        const int v = s.nsr[k];
+        seg = (v >> 5) & 0xffffff; row = v & 31;
     }
 
     // ---- values only: c = D*X - t_scale*f, g (equalities :739-766, inequalities :770-782)
@@ -278,50 +296,60 @@ struct Ocp {
     // J(r, col) = J[r + col * ldj] (ldj = m for a plain m x n Jacobian; n+m when J is the lower block of the stacked [H;J] workspace)
     // structure = false: J already holds a linearisation of THIS problem — its zeros and its differentiation-matrix entries
     // do not depend on the iterate, so only the per-node blocks (D self entry - t_scale*df, dg) are rewritten.
+    template <bool WANT_COST = true>
     __device__ double assemble_first_order(double* c, double* __restrict__ J, double* cost_grad, int ldj, bool structure = true) {
         const int ln = lane_id();
         const int n = dm.n, m = dm.m;
         if (structure) {
             for (int e = ln; e < m * n; e += WAVE) J[(e % m) + (size_t)(e / m) * ldj] = 0.0;
             wfence();
-        }
-        for (int i = ln; i < n; i += WAVE) cost_grad[i] = 0.0;
-        wsync();
-        for (int k = ln; k < dm.NN; k += WAVE) {
-            int seg, row; seg_row(k, seg, row);
-            for (int q = 0; q < NX; ++q) {
-                const int r = k * NX + q;
-                if (structure) {
+            wsync();
+            for (int k = ln; k < dm.NN; k += WAVE) {
+                int seg, row; seg_row(k, seg, row);
+                for (int q = 0; q < NX; ++q) {
+                    const int r = k * NX + q;
                     if (k < dm.NN - 1) {
                         for (int j = 0; j <= P; ++j) J[r + (size_t)((seg * P + j) * NX + q) * ldj] = s.D[row + j * (P + 1)] * 1.0;
                     } else {  // last node row = -reverse(first block row) (:845-846)
                         for (int j = 0; j <= P; ++j) J[r + (size_t)(dm.VARX - NX * (P + 1) + j * NX + q) * ldj] = -s.D[0 + (P - j) * (P + 1)];
                     }
                 }
-                double cv = -ts * s.fval[r];
-                cv += s.DX[r];
-                c[r] = cv;
-                // J(r, own block) = [D entry on the node's own state column | 0] - t_scale * df: one store per entry, no
-                // read-modify-write round trips (same arithmetic as "= D(i,j)*I" followed by "-= t_scale*jac", :824,:870-872)
-                const double dself = (k < dm.NN - 1) ? s.D[row + row * (P + 1)] * 1.0 : -s.D[0];
-                for (int i = 0; i < NDER; ++i) {
-                    double v = (i == q) ? dself : 0.0;
-                    v -= ts * s.fjac[r * NDER + i];
-                    J[r + (size_t)dm.gidx(k, i) * ldj] = v;
-                }
             }
-            for (int q = 0; q < NG; ++q) {
-                const int r = dm.me + k * NG + q;
-                c[r] = s.gval[k * NG + q];
-                for (int i = 0; i < NDER; ++i) J[r + (size_t)dm.gidx(k, i) * ldj] = s.gjac[(k * NG + q) * NDER + i];
+            wfence();
+            wsync();
+        }
+        // own-node blocks, one lane per ENTRY (node k, state row q, derivative column i):
+        // J(r, own block) = [D entry on the node's own state column | 0] - t_scale * df: one store per entry, no read-modify-write
+        // round trips (same arithmetic as "= D(i,j)*I" followed by "-= t_scale*jac", :824,:870-872)
+        for (int e = ln; e < dm.NN * NX * NDER; e += WAVE) {
+            const int k = e / (NX * NDER), rem = e - k * (NX * NDER), q = rem / NDER, i = rem - q * NDER;
+            double v = (i == q) ? s.nd[k] : 0.0;
+            v -= ts * s.fjac[e];
+            J[(k * NX + q) + (size_t)dm.gidx(k, i) * ldj] = v;
+        }
+        for (int r = ln; r < dm.me; r += WAVE) {
+            double cv = -ts * s.fval[r];
+            cv += s.DX[r];
+            c[r] = cv;
+        }
+        if (NG > 0) {
+            for (int e = ln; e < dm.NN * NG * NDER; e += WAVE) {
+                const int kq = e / NDER, i = e - kq * NDER, k = kq / NG;
+                J[(dm.me + kq) + (size_t)dm.gidx(k, i) * ldj] = s.gjac[e];
             }
-            // cost gradient, x/u parts: contributions in the reference's loop order (segment s-1 as node P, then segment s as node 0)
-            double gacc[NX + NU > 0 ? NX + NU : 1];
-            for (int i = 0; i < NX + NU; ++i) gacc[i] = 0.0;
-            if (k % P == 0 && k > 0) { const double wk = ts * s.w[P]; for (int i = 0; i < NX + NU; ++i) gacc[i] += wk * s.Lgrad[k * NDER + i]; }
-            if (k < dm.NN - 1) { const double wk = ts * s.w[k % P]; for (int i = 0; i < NX + NU; ++i) gacc[i] += wk * s.Lgrad[k * NDER + i]; }
-            if (k == 0) for (int i = 0; i < NX + NU; ++i) gacc[i] += s.Mgrad[i];
-            for (int i = 0; i < NX + NU; ++i) cost_grad[dm.gidx(k, i)] = gacc[i];
+            for (int r = ln; r < dm.mi; r += WAVE) c[dm.me + r] = s.gval[r];
+        }
+        // cost gradient, x/u parts, one lane per (node, variable): contributions in the reference's loop order (segment s-1 as
+        // node P, then segment s as node 0)
+        for (int e = ln; e < dm.NN * (NX + NU); e += WAVE) {
+            const int k = e / (NX + NU), i = e - k * (NX + NU);
+            double gacc = 0.0;
+            const int fl = s.nsr[k];
+            const double lg = s.Lgrad[k * NDER + i];
+            if (fl & (1 << 30)) gacc += s.nw1[k] * lg;
+            if (fl & (1 << 29)) gacc += s.nw2[k] * lg;
+            if (k == 0) gacc += s.Mgrad[i];
+            cost_grad[dm.gidx(k, i)] = gacc;
         }
         // p-part of the cost gradient: sequential over (segment, node) as in the reference, then Mayer
         if constexpr (NP > 0) {
@@ -334,9 +362,11 @@ struct Ocp {
             }
         }
         double cst = 0.0;
-        for (int sg = 0; sg < S; ++sg)
-            for (int k = 0; k <= P; ++k) cst += ts * s.w[k] * s.Lval[sg * P + k];
-        cst += s.Mval[0];
+        if constexpr (WANT_COST) {
+            for (int sg = 0; sg < S; ++sg)
+                for (int k = 0; k <= P; ++k) cst += ts * s.w[k] * s.Lval[sg * P + k];
+            cst += s.Mval[0];
+        }
         wfence();
         wsync();
         return cst;

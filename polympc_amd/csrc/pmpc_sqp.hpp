@@ -347,7 +347,7 @@ struct SqpDevice {
         if (exact) {
             ocp.stage_second_order(v.x, v.lam);
             const long long l2 = now();
-            ocp.assemble_first_order(v.al, Aw, v.h, ldw, structure);
+            ocp.template assemble_first_order<false>(v.al, Aw, v.h, ldw, structure);
             const long long l3 = now();
             ocp.assemble_hessian(Hw, ldw);
             const long long l4 = now();
@@ -355,7 +355,7 @@ struct SqpDevice {
             acc(11, l2 - l1); acc(12, l3 - l2); acc(13, l4 - l3); acc(14, now() - l4);
             if (ss.regularisation == 2) regularise_gershgorin();
         } else {
-            ocp.assemble_first_order(v.al, Aw, v.h, ldw, false);   // J's zeros and D entries are already in place
+            ocp.template assemble_first_order<false>(v.al, Aw, v.h, ldw, false);   // J's zeros and D entries are already in place
             const long long l3 = now();
             lagrangian_gradient(v.lgn);
             acc(12, l3 - l1); acc(14, now() - l3);

@@ -53,11 +53,18 @@ struct SqpDevice {
     const pmpc_sqp_settings& ss;
     const pmpc_qp_settings& qs;
     int n, m, me, mi;
+    // the same sizes as compile-time constants on the register path (NN, MM > 0): loops over them unroll, their uniform guards
+    // fold away and the LDS loads of a reduction are issued in one batch
+    static constexpr int NNODES_CT_ = (NN > 0) ? MM / (Model::NX + Model::NG) : 0;
+    __device__ __forceinline__ int n_ct() const { if constexpr (NN > 0) return NN; else return n; }
+    __device__ __forceinline__ int m_ct() const { if constexpr (NN > 0) return MM; else return m; }
+    __device__ __forceinline__ int me_ct() const { if constexpr (NN > 0) return Model::NX * NNODES_CT_; else return me; }
+    __device__ __forceinline__ int mi_ct() const { if constexpr (NN > 0) return Model::NG * NNODES_CT_; else return mi; }
     double cost_log = 0.0, primal_norm = 0.0, dual_norm = 0.0, max_violation = 0.0;
     int qp_iter_total = 0;
     long long cyc[PROF ? 24 : 1] = {0};
     __device__ __forceinline__ static long long now() { if constexpr (PROF) return clock64(); else return 0; }
-    __device__ __forceinline__ void acc(int i, long long dt) { if constexpr (PROF) cyc[i] += dt; }   // shader-clock cycles: 0 linearise(+BFGS) 1 QP 2 line search 3 termination 4 total 5 BFGS 6 KKT build+factor 7 QP residuals 8 ls node evaluation 9 ls scalar sums 10 first-order staging 11 second-order staging 12 first-order assembly 13 Hessian assembly 14 Lagrangian gradient 16..20 KKT inverse: row loads+staging, panel moves, sweeps, MFMA updates, final conversion
+    __device__ __forceinline__ void acc(int i, long long dt) { if constexpr (PROF) cyc[i] += dt; }   // shader-clock cycles: 0 linearise(+BFGS) 1 QP 2 line search 3 termination 4 total 5 BFGS 6 KKT build+factor 7 QP residuals 8 ls node evaluation 9 ls scalar sums 10 first-order staging 11 second-order staging 12 first-order assembly 13 Hessian assembly 14 Lagrangian gradient 16..20 KKT inverse: row loads+staging, panel moves, sweeps, MFMA updates, final conversion 21 ls prologue (mu, grad'p) 22 ls acceptance
 
     __device__ SqpDevice(Ocp<Model>& o, SqpLds& v_, QpLds& q_, double* H_, double* A_, const pmpc_sqp_settings& s, const pmpc_qp_settings& q)
         : ocp(o), v(v_), qw(q_), Hw(H_), Aw(A_), ldw(o.dm.n + o.dm.m), ss(s), qs(q), n(o.dm.n), m(o.dm.m), me(o.dm.me), mi(o.dm.mi) {}
@@ -80,6 +87,7 @@ struct SqpDevice {
     __device__ double max_constraints_violation(const double* xx) {
         if (!cb_valid) ocp.constraints(xx, v.cb);   // otherwise the accepted line-search candidate already evaluated them at this point
         const int ln = lane_id();
+        const int n = n_ct(), me = me_ct(), mi = mi_ct();
         double c = 0.0, a = -INFINITY, b = -INFINITY, e = -INFINITY, f = -INFINITY;
         for (int i = ln; i < me; i += WAVE) c = fmax(c, fabs(v.cb[i]));
         for (int i = ln; i < mi; i += WAVE) { a = fmax(a, v.lbg[i] - v.cb[me + i]); b = fmax(b, v.cb[me + i] - v.ubg[i]); }
@@ -127,14 +135,17 @@ struct SqpDevice {
         constexpr int NX = Model::NX, NU = Model::NU, NP = Model::NP, NG = Model::NG;
         const double* p = qw.x;
         const int ln = lane_id();
+        const int n = n_ct(), m = m_ct(), me = me_ct();
         const int P = ocp.P, S = ocp.S, VARX = ocp.dm.VARX, VARU = ocp.dm.VARU;
         double* cand_c = lsbuf;                    // [G][m]
         double* cand_L = cand_c + G * m;           // [G][NN]
         double* cand_viol = cand_L + G * NNo;      // [G]
         double* cand_cost = cand_viol + G;         // [G]
         double* cand_alpha = cand_cost + G;        // [G]
+        const long long p0_ = now();
         const double mu = lds_inf_norm(v.lam_k, m + n);
         const double gp = seq_dot(v.h, p, n);
+        acc(21, now() - p0_);
         double phi_l1 = 0.0, Dp_phi_l1 = 0.0;
         double alpha = 1.0;      // alpha of the next trial to be evaluated
         int trial = 1;           // index i of that trial in the reference loop (1 .. ls_max-1)
@@ -267,7 +278,8 @@ struct SqpDevice {
                 cand_cost[gc] = c;
             }
             wsync();
-            acc(8, e1 - e0); acc(9, now() - e1);
+            const long long e2 = now();
+            acc(8, e1 - e0); acc(9, e2 - e1);
             if (first) {
                 const double constr_l1 = cand_viol[0];
                 phi_l1 = cand_cost[0] + mu * constr_l1;
@@ -287,6 +299,7 @@ struct SqpDevice {
                 for (int i = ln; i < m; i += WAVE) v.cb[i] = cand_c[accepted * m + i];   // constraint values at x + alpha*p for the termination test
                 cb_valid = true;
                 wsync();
+                acc(22, now() - e2);
                 return alpha;
             }
             first = false;
@@ -474,6 +487,7 @@ struct SqpDevice {
     // QP bounds :588-593
     __device__ void form_qp_bounds() {
         const int ln = lane_id();
+        const int n = n_ct(), m = m_ct(), me = me_ct();
         for (int i = ln; i < m; i += WAVE) {
             double a = -v.al[i], b = a;
             if (i >= me) { a += v.lbg[i - me]; b += v.ubg[i - me]; }
@@ -486,6 +500,7 @@ struct SqpDevice {
     // one SQP iteration after (update_)linearisation: QP, line search, step, norms  (:588-632 / :652-683)
     __device__ void qp_and_step() {
         const int ln = lane_id();
+        const int n = n_ct(), m = m_ct();
         const long long q0 = now();
         form_qp_bounds();
         pmpc_qp_info qi;

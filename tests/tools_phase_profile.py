@@ -18,7 +18,7 @@ cyc = ctx.phase_cycles()
 names = ["linearise(+update)", "QP", "line search", "termination", "total loop", "BFGS", "KKT build+factor", "QP residuals",
          "ls node evaluation", "ls scalar sums", "first-order staging", "second-order staging", "first-order assembly",
          "Hessian assembly", "Lagrangian gradient", "-", "inv: row loads + staging", "inv: panel moves", "inv: sweeps", "inv: MFMA updates",
-         "inv: final conversion", "-", "-", "-"]
+         "inv: final conversion", "ls prologue", "ls acceptance", "-"]
 qps = info["iter"].sum()
 print(f"host wall {t*1e3:.2f} ms (incl. copies), {qps} QPs, {info['qp_solver_iter'].sum()/qps:.2f} ADMM it/QP")
 for nme, c in zip(names, cyc):

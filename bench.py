@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="OCP instances per GPU")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="instances per pass of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="minimum wall time of the CPU-baseline sample")
+    ap.add_argument("--streams", type=int, default=1, help="1 (default, the contract's configuration): every step is one launch on one "
+                    "stream. S > 1: consecutive steps alternate over S contexts (own stream, workspace and output buffers), so that a "
+                    "step's tail overlaps the next step's start — a pipelined-server figure, reported in DESIGN.md, not the bench line")
     args = ap.parse_args()
 
     import numpy as np
@@ -79,19 +82,27 @@ def main():
     B = args.batch
     wl = workloads.robot_batch(B, first=sharding.shard_first_instance(rank, B))   # each rank owns a contiguous shard of the instance stream
     n, m = wl["n"], wl["m"]
-    stream = torch.cuda.Stream(dev)       # a real (non-null) HIP stream: the kernels and the timing events share it
+    S_ = max(1, args.streams)
+    streams = [torch.cuda.Stream(dev) for _ in range(S_)]   # real (non-null) HIP streams: the kernels and the timing events share them
+    stream = streams[0]
     torch.cuda.set_stream(stream)
-    ctx = pa.Context(local_rank, stream=stream.cuda_stream)
+    ctxs = [pa.Context(local_rank, stream=st.cuda_stream) for st in streams]
+    ctx = ctxs[0]
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     d_d, d_lbx, d_ubx = t(wl["d"]), t(wl["lbx"]), t(wl["ubx"])
-    d_x = torch.zeros(B, n, dtype=torch.float64, device=dev)
-    d_lam = torch.zeros(B, m + n, dtype=torch.float64, device=dev)
-    d_info = torch.zeros(B, 48, dtype=torch.uint8, device=dev)
+    outs = [(torch.zeros(B, n, dtype=torch.float64, device=dev), torch.zeros(B, m + n, dtype=torch.float64, device=dev),
+             torch.zeros(B, 48, dtype=torch.uint8, device=dev)) for _ in range(S_)]
+    d_x, d_lam, d_info = outs[0]
     ss = pa.sqp_settings_default(); ss.max_iter = wl["max_iter"]; ss.line_search_max_iter = wl["ls_max_iter"]
     qs = pa.qp_settings_sqp_default()
+    torch.cuda.synchronize(dev)
+    counter = [0]
 
     def step():
-        ctx.sqp_solve_batch_dev(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, d_d, d_lbx, d_ubx, d_x, d_lam, d_info, ss, qs)
+        k = counter[0] % S_; counter[0] += 1
+        ox, ol, oi = outs[k]
+        ctxs[k].sqp_solve_batch_dev(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, d_d, d_lbx, d_ubx, ox, ol, oi, ss, qs)
+        return streams[k]
 
     for _ in range(args.warmup):
         step()
@@ -102,9 +113,10 @@ def main():
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for e0, e1 in evs:
-        e0.record(stream)
+        st = streams[counter[0] % S_]
+        e0.record(st)
         step()
-        e1.record(stream)
+        e1.record(st)
     torch.cuda.synchronize(dev)
     if dist:
         dist.barrier()
@@ -133,7 +145,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "mobile_robot OCP nx=3 nu=2 N=6 (P=6,S=1; n=35 m=21 KKT 56), batch=%d per GPU, randomised x0, fp64, "
                                    "SQP max_iter=10 ls=10, QP = SQPBase defaults" % B,
-                       "global_batch": B * world, "parallelism": "batch-shard x%d (no collectives)" % world},
+                       "global_batch": B * world, "parallelism": "batch-shard x%d (no collectives)" % world,
+                       **({"streams": S_, "note": "steps pipelined over %d streams: NOT the contract's configuration" % S_} if S_ > 1 else {})},
             "sqp_solves_per_s": B * world * args.steps / elapsed, "qp_solves_per_step": qp_all, "admm_iters_per_qp": admm_all / max(qp_all, 1),
             "sqp_solved_fraction": solved_all / (B * world),
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach_gbs / PEAK_HBM_GBS,
@@ -164,7 +177,8 @@ def main():
             out["parity_vs_cpu_sample"] = {"same_iteration_count_fraction": float(same.mean()),
                                            "max_abs_dx_on_matching": float(np.abs(xg - xo)[same].max()) if same.any() else None}
         print(json.dumps(out))
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if dist:
         dist.destroy_process_group()
 

@@ -180,6 +180,18 @@ def test_collocation_vs_oracle(ctx, oracle, model, P, S, t0, tf, nd):
         close(ev["lag_hess"][b], eo["lag_hess"])
 
 
+def test_pivot_reciprocal_equals_ieee_division():
+    """The 8-operation reciprocal of the sweep pivots (v_rcp_f64 + 2 Newton steps + residual correction + v_div_fixup) gives the
+    correctly rounded quotient: 0 mismatches against 1.0 / d on 2^26 doubles with exponents in [-1000, 1000] and the special
+    values (tests/experiments/recip_check.hip, built by __graft_entry__.build())."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "experiments", "recip_check")
+    if not os.path.exists(exe):
+        pytest.skip("tests/experiments/recip_check not built")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and " 0 mismatches in the normal range" in out.stdout, out.stdout + out.stderr
+
+
 # -------------------------------------------------------------------------------------------- §8f-2: Ruiz equilibration
 def test_ruiz_reference_known_answer(ctx, oracle):
     """box_admm_test.cpp:47-83 through the GPU path: compute -> solve -> unscale gives (0.3, 0.7), SOLVED in < 150 iterations."""

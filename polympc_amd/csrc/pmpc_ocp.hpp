@@ -250,7 +250,16 @@ struct Ocp {
     }
 
     // ---- per-node second-order stage: d2L, Mayer Hessian, and hes = -t_scale*sum lam_q d2f_q + sum lam_g d2g (:2128-2157)
-    __device__ void stage_second_order(const double* var, const double* lam) {
+    // Two lane mappings with identical arithmetic per entry. Up to WIDE_MAX_NDER derivative directions the inner dual number
+    // is kept whole (one pass over NN*NDER lanes); beyond that one lane per Hessian entry — the wide variant's AD arrays then
+    // live in private memory (7.9 KB per lane for 16 directions) and that kernel proved fragile (compiler hazard 8).
+    // (forced inline: as a called member function the stage drags the whole Ocp object into private memory — hazard 6)
+    static constexpr int WIDE_MAX_NDER = 8;
+    __device__ __forceinline__ void stage_second_order(const double* var, const double* lam) {
+        if constexpr ((int)NDER <= WIDE_MAX_NDER) stage_second_order_wide(var, lam); else stage_second_order_entry(var, lam);
+    }
+    // variant for few derivative directions: one lane per (node, outer direction), the inner dual carries all NDER components
+    __device__ __forceinline__ void stage_second_order_wide(const double* var, const double* lam) {
         // one lane per (node, outer seed direction): the NDER directional passes of a node are independent, so they run
         // side by side on NN*NDER lanes instead of one after the other on NN lanes (same arithmetic per entry)
         for (int kd = lane_id(); kd < dm.NN * NDER; kd += WAVE) {
@@ -286,6 +295,55 @@ struct Ocp {
                     model.template mayer_term_impl<ad2c>(cref<ad2c>(x), cref<ad2c>(u), cref<ad2c>(p), cref<double>(d), s.tn[0], M);
                     for (int r = 0; r < NDER; ++r) s.Mhes[dir * NDER + r] = M.d[0].d[r];
                 }
+            }
+        }
+        wsync();
+    }
+
+    // ---- per-node second-order stage: d2L, Mayer Hessian, and hes = -t_scale*sum lam_q d2f_q + sum lam_g d2g (:2128-2157)
+    // One lane per Hessian ENTRY (node k, outer seed direction dir, inner derivative component r): the inner components of a
+    // nested dual number never mix, so each lane carries Dual<Dual<double,1>,1> (4 doubles per AD variable instead of
+    // 2*(NDER+1): no private-memory arrays, a small register footprint even for 16 derivative directions) and every entry
+    // goes through exactly the operations it went through as component r of the wide inner dual.
+    __device__ __forceinline__ void stage_second_order_entry(const double* var, const double* lam) {
+        using adi = Dual<double, 1>;
+        using ad2 = Dual<adi, 1>;
+        for (int e = lane_id(); e < dm.NN * NDER * NDER; e += WAVE) {
+            const int k = e % dm.NN, dr = e / dm.NN, dir = dr / NDER, r = dr - dir * NDER;
+            ad2 x[NX > 0 ? NX : 1], u[NU > 0 ? NU : 1], p[NP > 0 ? NP : 1], y[NX > 0 ? NX : 1];
+            {   // second-order seeding (continuous_ocp.hpp:691-735 restricted to one outer and one inner partial)
+                int idx = 0;
+                auto mk = [&](double val, int id) { ad2 v_; v_.v = adi(val); v_.v.d[0] = (id == r) ? 1.0 : 0.0; v_.d[0] = adi(id == dir ? 1.0 : 0.0); return v_; };
+                for (int i = 0; i < NX; ++i, ++idx) x[i] = mk(var[k * NX + i], idx);
+                for (int i = 0; i < NU; ++i, ++idx) u[i] = mk(var[dm.VARX + k * NU + i], idx);
+                for (int i = 0; i < NP; ++i, ++idx) p[i] = mk(var[dm.VARX + dm.VARU + i], idx);
+            }
+            ad2 L(0.0);
+            model.template lagrange_term_impl<ad2>(cref<ad2>(x), cref<ad2>(u), cref<ad2>(p), cref<double>(d), s.tn[k], L);
+            // hes.col(dir) = L.d[dir].d  => hes(r, dir)
+            s.Lhes[(k * NDER + dir) * NDER + r] = L.d[0].d[0];
+            for (int q = 0; q < NX; ++q) y[q] = ad2(0.0);
+            ad2 tk(s.tn[k]);
+            model.template dynamics_impl<ad2>(cref<ad2>(x), cref<ad2>(u), cref<ad2>(p), cref<double>(d), tk, vref<ad2>(y));
+            double col = 0.0;
+            for (int q = 0; q < NX; ++q) {
+                const double coeff = -lam[q + k * NX] * ts;
+                col += coeff * y[q].d[0].d[0];
+            }
+            if (NG > 0) {
+                ad2 g[NG > 0 ? NG : 1];
+                for (int q = 0; q < NG; ++q) g[q] = ad2(0.0);
+                model.template inequality_constraints_impl<ad2>(cref<ad2>(x), cref<ad2>(u), cref<ad2>(p), cref<double>(d), s.tn[k], vref<ad2>(g));
+                for (int q = 0; q < NG; ++q) {
+                    const double coeff = lam[q + k * NG + dm.me];
+                    col += coeff * g[q].d[0].d[0];
+                }
+            }
+            s.dhes[(k * NDER + dir) * NDER + r] = col;
+            if (k == 0) {
+                ad2 M(0.0);
+                model.template mayer_term_impl<ad2>(cref<ad2>(x), cref<ad2>(u), cref<ad2>(p), cref<double>(d), s.tn[0], M);
+                s.Mhes[dir * NDER + r] = M.d[0].d[0];
             }
         }
         wsync();
@@ -374,7 +432,7 @@ struct Ocp {
 
     // ---- assemble the Lagrangian Hessian H (n x n column-major in HBM) from the second-order stage
     // cost_gradient_hessian :1256-1367 (+ quirk Q4) and the lam-weighted blocks of :2128-2173
-    __device__ void assemble_hessian(double* __restrict__ H, int ldh) {
+    __device__ __forceinline__ void assemble_hessian(double* __restrict__ H, int ldh) {
         const int ln = lane_id();
         const int n = dm.n;
         for (int e = ln; e < n * n; e += WAVE) H[(e % n) + (size_t)(e / n) * ldh] = 0.0;

@@ -32,7 +32,7 @@ struct SqpLds {
 };
 
 constexpr double DBL_EPS = 2.220446049250313e-16;
-constexpr int RUIZ_MAX_NDER = 8;   // see SqpDevice::qp_and_step
+constexpr int RUIZ_MAX_NDER = 64;   // see SqpDevice::qp_and_step
 constexpr int PMPC_SQP_IN_PROGRESS = 3;   // internal: the instance continues in the next iteration-slice launch
 
 // NN, MM > 0: compile-time QP size with NN+MM <= 64 -> register-resident QP (pmpc_qp_reg.hpp); 0 -> LDS-resident QP
@@ -40,7 +40,9 @@ constexpr int PMPC_SQP_IN_PROGRESS = 3;   // internal: the instance continues in
 template <class Model, int NN = 0, int MM = 0, bool PROF = false>
 struct SqpDevice {
     using Dm = OcpDims<Model>;
-    static constexpr bool RUIZ_COMPILED = (int)Dm::NDER <= RUIZ_MAX_NDER;
+    // Ruiz scaling is compiled into the LDS / HBM-resident QP kernels only: the launcher routes preconditioner = 1 there. In the
+    // register-resident kernels its three (cold, out-of-line) calls cost private-memory frames and call-ABI spills on the hot path.
+    static constexpr bool RUIZ_COMPILED = (NN == 0) && (int)Dm::NDER <= RUIZ_MAX_NDER;
     Ocp<Model>& ocp;
     SqpLds& v;
     QpLds& qw;
@@ -505,9 +507,9 @@ struct SqpDevice {
         form_qp_bounds();
         pmpc_qp_info qi;
         // m_preconditioner.compute(m_H, m_h, m_A, m_al, m_au, m_lx, m_ux), sqp_base.hpp:605 / :661 — in place in the workspace
-        // (compiled for models with at most RUIZ_MAX_NDER derivative directions: the 16-direction stand-in's kernel, whose AD
-        // arrays already live in private memory, returned NaNs as soon as this never-taken branch was added to it — hipcc 7.2;
-        // the launcher rejects preconditioner = 1 for such models)
+        // (RUIZ_COMPILED: a guard from the time when the 16-direction stand-in kernel — then with 7.9 KB of private AD arrays per
+        // lane — returned NaNs as soon as this never-taken branch was compiled into it, hipcc 7.2; with the entry-per-lane
+        // second-order stage that kernel has no such arrays and the fault no longer reproduces, so the guard admits every model)
         bool ruiz = false;
         const RuizScratch rz{v.t1, v.t1 + n, v.t2, v.t2 + n};
         double rz_c = 1.0;

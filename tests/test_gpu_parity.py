@@ -226,7 +226,7 @@ def test_ruiz_compute_bit_exact_vs_oracle(ctx, oracle, n, m, B, scale):
 
 def test_sqp_with_ruiz_preconditioner_vs_oracle(ctx, oracle):
     """SQPBase<..., RuizEquilibration> (sqp_base.hpp:605-611, :661-665): the fused kernel scales / unscales the QP data in place
-    around every QP exactly as the restatement does — register-resident QP (7 nodes) and LDS-resident QP (11 nodes)."""
+    around every QP exactly as the restatement does (7-node and 11-node grids, both on the LDS-resident QP kernels)."""
     from polympc_amd import workloads
     for P, S, B in ((6, 1, 48), (5, 2, 8)):
         (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, workloads.robot_batch(B, P=P, S=S), B, preconditioner=1)
@@ -309,8 +309,10 @@ def _sqp_both(ctx, oracle, wl, B, **kw):
     for k, v in kw.items():
         setattr(oss, k, v)
     n = wl["lbx"].shape[1]; dm = oracle.ocp_dims(wl["model"], wl["P"], wl["S"])
+    # (preconditioner = 1 is served by the LDS-resident QP kernels whatever the size: static LDL^T order)
+    order = oracle.PIVOT_STATIC if kw.get("preconditioner", 0) else _gpu_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1)
     xo, lo, io = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"],
-                                        sqp_settings=oss, pivot=_gpu_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1), threads=8)
+                                        sqp_settings=oss, pivot=order, threads=8)
     return (x, lam, info), (xo, lo, io)
 
 

@@ -125,7 +125,7 @@ __device__ __noinline__ void ruiz_unscale_problem_wave(int n, int m, double* H, 
 }
 
 // ---- batched kernels behind pmpc_qp_ruiz_*_batch: one wavefront per QP, problem data in place in global memory
-__global__ __launch_bounds__(64) void ruiz_compute_kernel(int B, int n, int m, double* H, double* h, double* A, double* Alb, double* Aub,
+static __global__ __launch_bounds__(64) void ruiz_compute_kernel(int B, int n, int m, double* H, double* h, double* A, double* Alb, double* Aub,
                                                           double* xlb, double* xub, double* D, double* E, double* c, double* scratch) {
     const int b = blockIdx.x;
     if (b >= B) return;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64) void ruiz_compute_kernel(int B, int n, int m, d
                                         Aub + (size_t)b * m, xlb + (size_t)b * n, xub + (size_t)b * n, w);
     if (lane_id() == 0) c[b] = cb;
 }
-__global__ __launch_bounds__(64) void ruiz_unscale_solution_kernel(int B, int n, int m, const double* D, const double* E, const double* c,
+static __global__ __launch_bounds__(64) void ruiz_unscale_solution_kernel(int B, int n, int m, const double* D, const double* E, const double* c,
                                                                    double* x, double* y) {
     const int b = blockIdx.x;
     if (b >= B) return;

@@ -11,7 +11,7 @@
 // (src/utils/helpers.hpp:38-43; Eigen 3.3.7 pinned in ci/install-linux.sh:21). Eigen is NOT vendored in
 // /root/reference; the two pivot policies below restate its published algorithm:
 //   PIVOT_EIGEN  : symmetric max-|diag| pivoting, left-looking column update, D^+ solve (Eigen semantics)
-//   PIVOT_SWEEP  : no factorisation at all — W = -K^{-1} by the symmetric sweep operator in blocks of 8 pivots
+//   PIVOT_SWEEP  : no factorisation at all — W = -K^{-1} by the symmetric sweep operator in blocks of 4 pivots
 //                  (static order) and x = -(W b) as a mat-vec (block partial sums). This is the arithmetic of the register-resident HIP
 //                  kernel (polympc_amd/csrc/pmpc_qp_reg.hpp), restated operation by operation so that the kernel can be
 //                  checked bit for bit; it is tied to the reference only through PIVOT_EIGEN (tests/test_oracle_pins.py
@@ -108,9 +108,9 @@ struct LDLT {
         }
     }
 
-    // Symmetric sweep operator, blocks of 8 pivots, static order. After all sweeps M = -K^{-1} (full storage).
-    // Block step on pivots kb..kb+7 (panel p = M[:, block], Cold = its copy):
-    //   in-panel scalar sweeps   t = 0..7, k = kb+t:  r = 1/p[k][t];  l_i = p[i][t]*r;
+    // Symmetric sweep operator, blocks of BK = 4 pivots, static order. After all sweeps M = -K^{-1} (full storage).
+    // Block step on pivots kb..kb+BK-1 (panel p = M[:, block], Cold = its copy):
+    //   in-panel scalar sweeps   t = 0..BK-1, k = kb+t:  r = 1/p[k][t];  l_i = p[i][t]*r;
     //                            u != t:  p[i][u] = fma(-l_i, p[k][u], p[i][u]) (i != k),  p[k][u] = p[k][u]*r;
     //                            p[i][t] = l_i (i != k),  p[k][t] = -r
     //   trailing update          i, j outside the block, i/16 >= j/16 (block-lower storage in 16x16 tiles; the other
@@ -120,7 +120,7 @@ struct LDLT {
         auto at = [&](int i, int j) -> double& { return M[i + j * n]; };
         for (int k = 0; k < n; ++k) tr[k] = k;
         for (int j = 0; j < n; ++j) for (int i = 0; i < j; ++i) at(i, j) = at(j, i);   // full symmetric storage
-        const int BK = 8;
+        const int BK = 4;   // block size of the kernel (RegKkt::BK)
         std::vector<double> p((size_t)n * BK), cold((size_t)n * BK), l(n);
         for (int kb = 0; kb < n; kb += BK) {
             const int w = std::min(BK, n - kb);

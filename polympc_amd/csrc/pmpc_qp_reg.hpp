@@ -62,6 +62,10 @@ __device__ __forceinline__ void pivot_lane_setup(double& a0, double& a1, double&
         "v_mov_b64 %6, 0\n\tv_mov_b64 %7, %8\n\ts_mov_b64 exec, -1"
         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(l) : "v"(lk), "i"(k) : "scc");
 }
+__device__ __forceinline__ void pivot_lane_setup(double& a0, double& a1, double& a2, double& l, double lk, int k) {
+    asm("s_lshl_b64 exec, 1, %5\n\tv_mov_b64 %0, 0\n\tv_mov_b64 %1, 0\n\tv_mov_b64 %2, 0\n\tv_mov_b64 %3, %4\n\ts_mov_b64 exec, -1"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(l) : "v"(lk), "i"(k) : "scc");
+}
 // 1 / d, branch-free: the generic IEEE division expansion (v_rcp_f64, two Newton steps, residual correction, v_div_fixup for
 // 0 / inf / NaN) WITHOUT its v_div_scale pre-scaling — 8 VALU operations instead of 12. The pre-scaling only matters when d or
 // 1/d is subnormal (|d| beyond 2^+-1021); everywhere else the result is the correctly rounded quotient, bit for bit what the
@@ -101,7 +105,10 @@ struct RegKkt {
     double a[((N + 15) / 16) * 16];
 
     using d4 = double __attribute__((ext_vector_type(4)));
-    static constexpr int BK = 8;                      // pivots swept per block
+    static constexpr int BK = 4;                      // pivots swept per block (4: one MFMA k-step; the scalar in-panel sweep costs
+                                                      // 16 + 2*BK broadcast/setup operations per pivot next to BK-1 useful fma — measured
+                                                      // against BK = 8: 1000 fewer VALU operations per inverse, same number of MFMA)
+    static constexpr int SG = 8;                      // columns per group of the initial row -> tile staging
     static constexpr int NB = (N + BK - 1) / BK;      // number of blocks
     static constexpr int NT = (N + 15) / 16;          // 16x16 tiles per dimension
     static constexpr int NP = NT * 16;                // padded dimension
@@ -114,26 +121,26 @@ struct RegKkt {
     //    X aliases PB: a wave's DS operations execute in issue order, and X is never live at the same time as PB.
     //  Both are sized for all 64 lanes (idle lanes >= N store too; their values are never consumed by live rows).
     static constexpr int SK = 80;
-    static constexpr int SX = BK + 1;
+    static constexpr int SX = SG + 1;
     static constexpr int XSZ = (64 * SX + 64 > BK * SK) ? 64 * SX + 64 : BK * SK;   // 64 exchange rows + the diagonal slots
-    static constexpr int TRI = BK * SK + XSZ;         // doubles of LDS staging
+    static constexpr int SY = 78;                     // final conversion buffer Y, see below
+    static constexpr int TRI = (BK * SK + XSZ > 16 * SY) ? BK * SK + XSZ : 16 * SY;   // doubles of LDS staging
     static_assert(N <= 64 && SK % 32 == 16 && SK >= 64, "panel stride");
     // final conversion buffer Y: 16 rows of one tile row, all columns, row stride SY = 78 (14 mod 32, 2 mod 4): the mirror-tile
     // writes and the row reads are bank-conflict free, the direct-tile writes collide on 2 of 32 banks
-    static constexpr int SY = 78;
-    static_assert(16 * SY <= TRI, "conversion buffer fits the staging");
+    static_assert(16 * SY <= TRI && BK % 4 == 0 && 16 % BK == 0 && BK <= SG, "conversion buffer fits the staging; block size divides a tile");
 
     // W = -K^{-1} by the symmetric sweep operator, static pivot order (K is quasi-definite: every pivot is non-zero),
-    // in blocks of BK = 8 pivots. The matrix lives in 16x16 fp64 MFMA accumulator tiles T[R][C], C <= R (block-lower
+    // in blocks of BK pivots. The matrix lives in 16x16 fp64 MFMA accumulator tiles T[R][C], C <= R (block-lower
     // storage: a tile above the block diagonal is the transpose of its mirror image and is never materialised).
-    // Block step on pivots kb..kb+7:
-    //   1. the panel M[:, block] goes tiles -> exchange buffer -> row-per-lane registers p[8] (rows above the pivot tile
+    // Block step on pivots kb..kb+BK-1:
+    //   1. the panel M[:, block] goes tiles -> exchange buffer -> row-per-lane registers p[BK] (rows above the pivot tile
     //      row come out of the pivot tile ROW, transposed)
     //   2. PB <- old panel (B operand)
     //   3. in-panel scalar sweeps (v_readlane broadcasts of the pivot row):  r = 1/p_k[t];  l_i = p_i[t]*r (i != k), l_k = -r;
     //        u != t:  p_k[u] <- 0, then p_i[u] <- fma(-l_i, pivotrow[u], p_i[u]) on every lane (lane k: = pivotrow[u]*r);  p[t] <- l
     //   4. PA <- -p (A operand); rows of the block are zero in PA and PB, so the update leaves block rows / columns alone
-    //   5. stored tiles:  T[R][C] <- T[R][C] + PA_R * PB_C^T  (two v_mfma_f64_16x16x4_f64 each; the instruction is a
+    //   5. stored tiles:  T[R][C] <- T[R][C] + PA_R * PB_C^T  (BK/4 v_mfma_f64_16x16x4_f64 each; the instruction is a
     //      k-ascending fma chain — verified on gfx950, tests/experiments/mfma_f64_probe.hip — so every entry receives
     //      fma(-p_i[t], old_j[t], m_ij) for t ascending, which is what the CPU checker of the test suite restates)
     //   6. write-back: M[:, block] <- p into the pivot tile column, then M[block, :] <- p^T into the pivot tile row
@@ -166,9 +173,9 @@ struct RegKkt {
         for (int j = 0; j < NP; ++j) a[j] = (j < N) ? kcol(j < N ? j : 0, z) : 0.0;
         sched_fence();
 #pragma unroll
-        for (int g = 0; g < NP / BK; ++g) {
+        for (int g = 0; g < NP / SG; ++g) {
 #pragma unroll
-            for (int t = 0; t < BK; ++t) X[ln * SX + t] = a[g * BK + t];
+            for (int t = 0; t < SG; ++t) X[ln * SX + t] = a[g * SG + t];
             lds_order();
             if ((lc >> 3) == (g % 2)) {
 #pragma unroll
@@ -192,24 +199,25 @@ struct RegKkt {
         for (int b = 0; b < NB; ++b) {
             const int kb = b * BK;
             const int Cb = kb / 16, hb = (kb % 16) / BK;
+            constexpr int RPB = BK / 4;   // accumulator registers (tile-local row groups of 4) per block
             // 1. panel -> row-per-lane registers: rows of tile rows >= Cb from tile column Cb (tile-local columns
-            //    [8*hb, 8*hb+8)), rows of tile rows < Cb from tile row Cb (tile-local rows [8*hb, 8*hb+8), transposed)
-            if ((lc >> 3) == hb) {
+            //    [BK*hb, BK*hb+BK)), rows of tile rows < Cb from tile row Cb (tile-local rows [BK*hb, BK*hb+BK), transposed)
+            if ((lc / BK) == hb) {
 #pragma unroll
                 for (int R = Cb; R < NT; ++R)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) X[(16 * R + lr + 4 * r) * SX + (lc & 7)] = T[R][Cb][r];
+                    for (int r = 0; r < 4; ++r) X[(16 * R + lr + 4 * r) * SX + (lc % BK)] = T[R][Cb][r];
             }
 #pragma unroll
             for (int C = 0; C < Cb; ++C)
 #pragma unroll
-                for (int rr = 0; rr < 2; ++rr) X[(16 * C + lc) * SX + lr + 4 * rr] = T[Cb][C][2 * hb + rr];
+                for (int rr = 0; rr < RPB; ++rr) X[(16 * C + lc) * SX + lr + 4 * rr] = T[Cb][C][RPB * hb + rr];
             lds_order();
             double p[BK];
 #pragma unroll
             for (int t = 0; t < BK; ++t) p[t] = X[ln * SX + t];
             lds_order();
-            const bool inb = (ln >> 3) == b;
+            const bool inb = (ln / BK) == b;
             if (tm) { long long t = clock64(); tm[1] += t - tq0; tq0 = t; }
             // 2. B operand: the panel as it was at the start of the block
 #pragma unroll
@@ -225,8 +233,9 @@ struct RegKkt {
 #pragma unroll
                     for (int u = 0; u < BK; ++u) rk[u] = (u != t) ? bcast_lane(p[u], k) : 0.0;
                     double l = p[t] * r;
-                    // lane k: l = -r, and its seven other columns start from zero, so that one fma serves every lane
-                    pivot_lane_setup(p[(t + 1) & 7], p[(t + 2) & 7], p[(t + 3) & 7], p[(t + 4) & 7], p[(t + 5) & 7], p[(t + 6) & 7], p[(t + 7) & 7], l, -r, k);
+                    // lane k: l = -r, and its other columns start from zero, so that one fma serves every lane
+                    if constexpr (BK == 8) pivot_lane_setup(p[(t + 1) & 7], p[(t + 2) & 7], p[(t + 3) & 7], p[(t + 4) & 7], p[(t + 5) & 7], p[(t + 6) & 7], p[(t + 7) & 7], l, -r, k);
+                    else pivot_lane_setup(p[(t + 1) & 3], p[(t + 2) & 3], p[(t + 3) & 3], l, -r, k);
 #pragma unroll
                     for (int u = 0; u < BK; ++u)
                         if (u != t) p[u] = fma(-l, rk[u], p[u]);
@@ -239,7 +248,7 @@ struct RegKkt {
 #pragma unroll
             for (int t = 0; t < BK; ++t) PA[t * SK + ln] = (inb || kb + t >= N) ? 0.0 : -p[t];
             lds_order();
-            // 5. rank-8 update of every stored tile
+            // 5. rank-BK update of every stored tile
 #pragma unroll
             for (int s2 = 0; s2 < BK / 4; ++s2) {
                 double av[NT], bv[NT];
@@ -260,16 +269,16 @@ struct RegKkt {
 #pragma unroll
             for (int t = 0; t < BK; ++t) X[ln * SX + t] = p[t];
             lds_order();
-            if ((lc >> 3) == hb) {
+            if ((lc / BK) == hb) {
 #pragma unroll
                 for (int R = Cb; R < NT; ++R)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) T[R][Cb][r] = X[(16 * R + lr + 4 * r) * SX + (lc & 7)];
+                    for (int r = 0; r < 4; ++r) T[R][Cb][r] = X[(16 * R + lr + 4 * r) * SX + (lc % BK)];
             }
 #pragma unroll
             for (int C = 0; C <= Cb; ++C)
 #pragma unroll
-                for (int rr = 0; rr < 2; ++rr) T[Cb][C][2 * hb + rr] = X[(16 * C + lc) * SX + lr + 4 * rr];
+                for (int rr = 0; rr < RPB; ++rr) T[Cb][C][RPB * hb + rr] = X[(16 * C + lc) * SX + lr + 4 * rr];
             lds_order();
             sched_fence();
         }

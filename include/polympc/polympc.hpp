@@ -284,6 +284,7 @@ private:
 
 // ---------------------------------------------------------------------------------------------------------------------
 // boxADMM<N, M>: the QP seam (qp_base.hpp:148-175, box_admm.hpp:81-91). Matrices column-major.
+template <int N, int M> class ADMM;
 template <int N, int M>
 class boxADMM {
 public:
@@ -312,8 +313,8 @@ private:
         m_info.status = UNINITIALIZED;
         if (!ctx) return m_info.status;
         pmpc_qp_info qi;
-        const pmpc_status st = pmpc_qp_boxadmm_solve_batch(ctx, 1, N, M, H.data(), h.data(), A.data(), Alb.data(), Aub.data(), xlb.data(), xub.data(),
-                                                           x0, y0, &m_settings, m_x.data(), m_y.data(), &qi);
+        const pmpc_status st = (m_osqp_form ? pmpc_qp_admm_solve_batch : pmpc_qp_boxadmm_solve_batch)(ctx, 1, N, M, H.data(), h.data(), A.data(), Alb.data(),
+                                                           Aub.data(), xlb.data(), xub.data(), x0, y0, &m_settings, m_x.data(), m_y.data(), &qi);
         last_error() = st;
         if (st != PMPC_OK) return m_info.status;
         m_info.status = (status_t)qi.status; m_info.iter = qi.iter; m_info.rho_updates = qi.rho_updates;
@@ -322,6 +323,14 @@ private:
         return m_info.status;
     }
     settings_t m_settings; info_t m_info; qp_var_t m_x; qp_dual_t m_y;
+    bool m_osqp_form{false};
+    friend class ADMM<N, M>;
+};
+// ADMM<N, M>: the reference's OSQP-style solver (admm.hpp) — same seam, the stacked (2N+M)-row KKT system on the device
+template <int N, int M>
+class ADMM : public boxADMM<N, M> {
+public:
+    ADMM() { this->m_osqp_form = true; }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -131,6 +131,16 @@ pmpc_status pmpc_qp_boxadmm_solve_batch_dev(pmpc_context* ctx, int B, int n, int
                                             const double* xub, const double* x0, const double* y0,
                                             const pmpc_qp_settings* settings, double* x, double* y, pmpc_qp_info* info);
 
+/* Batched ADMM::solve — the reference's OSQP-style solver (replaces QPBase::solve -> ADMM::solve_impl, admm.hpp:104-212: box
+ * constraints stacked under the general ones, one (2n+m)-row KKT system). Same arguments, layouts and dual ordering
+ * [general (m) | box (n)] as pmpc_qp_boxadmm_solve_batch. Host buffers / device pointers. */
+pmpc_status pmpc_qp_admm_solve_batch(pmpc_context* ctx, int B, int n, int m, const double* H, const double* h, const double* A,
+                                     const double* Alb, const double* Aub, const double* xlb, const double* xub, const double* x0,
+                                     const double* y0, const pmpc_qp_settings* settings, double* x, double* y, pmpc_qp_info* info);
+pmpc_status pmpc_qp_admm_solve_batch_dev(pmpc_context* ctx, int B, int n, int m, const double* H, const double* h, const double* A,
+                                         const double* Alb, const double* Aub, const double* xlb, const double* xub, const double* x0,
+                                         const double* y0, const pmpc_qp_settings* settings, double* x, double* y, pmpc_qp_info* info);
+
 /* Batched RuizEquilibration<Scalar,N,M,DENSE>::compute (qp_preconditioners.hpp:160-233): scales H, h, A, Alb, Aub, xlb, xub
  * of B QPs IN PLACE and returns the accumulated scalings D (B*n), E (B*m) and the cost scaling c (B). Host buffers. */
 pmpc_status pmpc_qp_ruiz_compute_batch(pmpc_context* ctx, int B, int n, int m, double* H, double* h, double* A, double* Alb,

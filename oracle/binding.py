@@ -128,6 +128,18 @@ def qp_solve_batch(H, h, A, Alb, Aub, xlb, xub, settings=None, pivot=PIVOT_EIGEN
     return x, y, info
 
 
+def qp_admm_solve_batch(H, h, A, Alb, Aub, xlb, xub, settings=None, pivot=PIVOT_EIGEN, x0=None, y0=None, threads=1):
+    """The OSQP-style ADMM solver of admm.hpp; same array layout as qp_solve_batch."""
+    H = _f(H); h = _f(h); A = _f(A); Alb = _f(Alb); Aub = _f(Aub); xlb = _f(xlb); xub = _f(xub)
+    B, n = h.shape
+    m = Alb.shape[1] if Alb.ndim == 2 else 0
+    s = settings or qp_default_settings()
+    x = np.zeros((B, n)); y = np.zeros((B, n + m)); info = (QPInfo * B)()
+    lib().orc_qp_admm_solve_batch(B, n, m, _p(H), _p(h), _p(A), _p(Alb), _p(Aub), _p(xlb), _p(xub), _p(_f(x0)), _p(_f(y0)),
+                                  C.byref(s), pivot, threads, _p(x), _p(y), info)
+    return x, y, info
+
+
 def ruiz_compute_batch(H, h, A, Alb, Aub, xlb, xub):
     """In-place Ruiz equilibration of a batch (copies are made and returned): -> (H, h, A, Alb, Aub, xlb, xub, D, E, c)."""
     h = _f(h).copy(); B, n = h.shape

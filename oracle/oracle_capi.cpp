@@ -8,6 +8,7 @@
 #include "nlp.hpp"
 #include "ocp.hpp"
 #include "qp.hpp"
+#include "admm.hpp"
 #include "sqp.hpp"
 
 using namespace oracle;
@@ -90,6 +91,23 @@ void orc_regularise(int kind, int n, double* H) {
 }
 void orc_ldlt_solve(int n, const double* K, const double* b, int pivot, double* x) {
     LDLT f; f.compute(std::vector<double>(K, K + n * n), n, (pivot_policy)pivot); f.solve(b, x);
+}
+
+void orc_qp_admm_solve_batch(int B, int n, int m, const double* H, const double* h, const double* A, const double* Alb,
+                             const double* Aub, const double* xlb, const double* xub, const double* x0, const double* y0,
+                             const orc_qp_settings* s, int pivot, int threads, double* x, double* y, orc_qp_info* info) {
+#pragma omp parallel for schedule(dynamic) num_threads(threads > 1 ? threads : 1)
+    for (int b = 0; b < B; ++b) {
+        ADMM qp(n, m);
+        qp.settings = to_qp(s);
+        qp.pivot = (pivot_policy)pivot;
+        qp.solve(H + (size_t)b * n * n, h + (size_t)b * n, A + (size_t)b * m * n, Alb + (size_t)b * m, Aub + (size_t)b * m, xlb + (size_t)b * n,
+                 xub + (size_t)b * n, x0 ? x0 + (size_t)b * n : nullptr, y0 ? y0 + (size_t)b * (n + m) : nullptr);
+        for (int i = 0; i < n; ++i) x[(size_t)b * n + i] = qp.x[i];
+        for (int i = 0; i < n + m; ++i) y[(size_t)b * (n + m) + i] = qp.y[i];
+        info[b].status = qp.info.status; info[b].iter = qp.info.iter; info[b].rho_updates = qp.info.rho_updates;
+        info[b].rho_estimate = qp.info.rho_estimate; info[b].res_prim = qp.info.res_prim; info[b].res_dual = qp.info.res_dual;
+    }
 }
 
 void orc_ruiz_compute_batch(int B, int n, int m, double* H, double* h, double* A, double* Al, double* Au, double* l, double* u,

@@ -53,6 +53,11 @@ void orc_qp_solve_batch(int B, int n, int m, const double* H, const double* h, c
                         const double* Aub, const double* xlb, const double* xub, const double* x0, const double* y0,
                         const orc_qp_settings* s, int pivot, int threads, double* x, double* y, orc_qp_info* info);
 
+/* the OSQP-style ADMM solver (admm.hpp) on the same batch layout; y has m+n entries per instance ([general | box]) */
+void orc_qp_admm_solve_batch(int B, int n, int m, const double* H, const double* h, const double* A, const double* Alb,
+                             const double* Aub, const double* xlb, const double* xub, const double* x0, const double* y0,
+                             const orc_qp_settings* s, int pivot, int threads, double* x, double* y, orc_qp_info* info);
+
 /* Ruiz equilibration of B QPs in place (qp_preconditioners.hpp:160-233); outputs D (B x n), E (B x m), c (B) */
 void orc_ruiz_compute_batch(int B, int n, int m, double* H, double* h, double* A, double* Al, double* Au, double* l, double* u,
                             double* D, double* E, double* c);

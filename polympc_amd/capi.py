@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "pmpc_qp_settings_default", "pmpc_qp_settings_sqp_default", "pmpc_sqp_settings_default", "pmpc_chebyshev",
     "pmpc_qp_boxadmm_solve_batch", "pmpc_qp_boxadmm_solve_batch_dev", "pmpc_ocp_dims", "pmpc_ocp_linearise_batch",
     "pmpc_sqp_solve_batch", "pmpc_sqp_solve_batch_dev", "pmpc_sqp_solve_batch_user",
-    "pmpc_mpc_step_batch_dev", "pmpc_qp_ruiz_compute_batch", "pmpc_qp_ruiz_compute_batch_dev", "pmpc_qp_ruiz_unscale_batch", "pmpc_qp_ruiz_unscale_batch_dev",
+    "pmpc_mpc_step_batch_dev", "pmpc_qp_admm_solve_batch", "pmpc_qp_admm_solve_batch_dev", "pmpc_qp_ruiz_compute_batch", "pmpc_qp_ruiz_compute_batch_dev", "pmpc_qp_ruiz_unscale_batch", "pmpc_qp_ruiz_unscale_batch_dev",
 ]
 
 
@@ -159,14 +159,18 @@ class Context:
         return list(out)
 
     # ------------------------------------------------------------------ QP, host buffers
-    def qp_solve_batch(self, H, h, A, Alb, Aub, xlb, xub, settings=None, x0=None, y0=None):
+    def qp_admm_solve_batch(self, H, h, A, Alb, Aub, xlb, xub, settings=None, x0=None, y0=None):
+        """The OSQP-style ADMM solver (admm.hpp); same layout as qp_solve_batch."""
+        return self.qp_solve_batch(H, h, A, Alb, Aub, xlb, xub, settings=settings, x0=x0, y0=y0, _entry="pmpc_qp_admm_solve_batch")
+
+    def qp_solve_batch(self, H, h, A, Alb, Aub, xlb, xub, settings=None, x0=None, y0=None, _entry="pmpc_qp_boxadmm_solve_batch"):
         hk, hp = _h(h); B, n = hk.shape
         Hk, Hp = _h(H); Ak, Ap = _h(A); albk, albp = _h(Alb); aubk, aubp = _h(Aub); xlk, xlp = _h(xlb); xuk, xup = _h(xub)
         m = albk.shape[1] if albk.ndim == 2 else 0
         x0k, x0p = _h(x0); y0k, y0p = _h(y0)
         s = settings or qp_settings_default()
         x = np.zeros((B, n)); y = np.zeros((B, n + m)); info = np.zeros(B, dtype=QP_INFO_DTYPE)
-        _check(lib().pmpc_qp_boxadmm_solve_batch(self._ctx, B, n, m, Hp, hp, Ap, albp, aubp, xlp, xup, x0p, y0p, C.byref(s),
+        _check(getattr(lib(), _entry)(self._ctx, B, n, m, Hp, hp, Ap, albp, aubp, xlp, xup, x0p, y0p, C.byref(s),
                                                  x.ctypes.data_as(C.POINTER(C.c_double)),
                                                  y.ctypes.data_as(C.POINTER(C.c_double)), C.c_void_p(info.ctypes.data)))
         return x, y, info

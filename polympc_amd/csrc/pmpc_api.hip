@@ -16,6 +16,7 @@
 #include "pmpc_sqp.hpp"
 #include "pmpc_launch.hpp"
 #include "pmpc_ruiz.hpp"
+#include "pmpc_admm.hpp"
 
 using namespace pmpc;
 
@@ -278,6 +279,42 @@ pmpc_status pmpc_qp_boxadmm_solve_batch(pmpc_context* ctx, int B, int n, int m, 
     DEVOUT(9, Bn * sizeof(double), dx); DEVOUT(10, (Bn + Bm) * sizeof(double), dy); DEVOUT(11, (size_t)B * sizeof(pmpc_qp_info), dinfo);
     if (m == 0) { DEVOUT(2, 8, dA); DEVOUT(3, 8, dAlb); DEVOUT(4, 8, dAub); }
     pmpc_status st = pmpc_qp_boxadmm_solve_batch_dev(ctx, B, n, m, dH, dh, dA, dAlb, dAub, dxlb, dxub, dx0, dy0, settings, dx, dy, dinfo);
+    if (st != PMPC_OK) return st;
+    HIPCHK(hipMemcpyAsync(x, dx, Bn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(y, dy, (Bn + Bm) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(info, dinfo, (size_t)B * sizeof(pmpc_qp_info), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PMPC_OK;
+}
+
+pmpc_status pmpc_qp_admm_solve_batch_dev(pmpc_context* ctx, int B, int n, int m, const double* H, const double* h, const double* A,
+                                         const double* Alb, const double* Aub, const double* xlb, const double* xub, const double* x0,
+                                         const double* y0, const pmpc_qp_settings* settings, double* x, double* y, pmpc_qp_info* info) {
+    if (!ctx || B < 0 || n < 1 || m < 0 || !H || !h || !xlb || !xub || !settings || !x || !y || !info) return PMPC_ERR_INVALID_ARGUMENT;
+    if (m > 0 && (!A || !Alb || !Aub)) return PMPC_ERR_INVALID_ARGUMENT;
+    if ((x0 == nullptr) != (y0 == nullptr)) return PMPC_ERR_INVALID_ARGUMENT;
+    if (B == 0) return PMPC_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t lds = QpLds::doubles(n, m + n) * sizeof(double);   // the (2n+m)-row KKT factor + vectors of the stacked system
+    if (lds > ctx->lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;
+    HIPCHK(hipFuncSetAttribute((const void*)qp_admm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(qp_admm_kernel, dim3(B), dim3(WAVE), lds, ctx->stream, B, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0, *settings, x, y, info);
+    HIPCHK(hipGetLastError());
+    return PMPC_OK;
+}
+pmpc_status pmpc_qp_admm_solve_batch(pmpc_context* ctx, int B, int n, int m, const double* H, const double* h, const double* A,
+                                     const double* Alb, const double* Aub, const double* xlb, const double* xub, const double* x0,
+                                     const double* y0, const pmpc_qp_settings* settings, double* x, double* y, pmpc_qp_info* info) {
+    if (!ctx || B < 0 || n < 1 || m < 0 || !H || !h || !xlb || !xub || !settings || !x || !y || !info) return PMPC_ERR_INVALID_ARGUMENT;
+    if (B == 0) return PMPC_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    double *dH, *dh, *dA, *dAlb, *dAub, *dxlb, *dxub, *dx0, *dy0, *dx, *dy; pmpc_qp_info* dinfo;
+    const size_t Bn = (size_t)B * n, Bm = (size_t)B * m;
+    H2D(0, H, Bn * n, dH); H2D(1, h, Bn, dh); H2D(2, (m ? A : nullptr), Bm * n, dA); H2D(3, (m ? Alb : nullptr), Bm, dAlb);
+    H2D(4, (m ? Aub : nullptr), Bm, dAub); H2D(5, xlb, Bn, dxlb); H2D(6, xub, Bn, dxub); H2D(7, x0, Bn, dx0); H2D(8, y0, Bn + Bm, dy0);
+    DEVOUT(9, Bn * sizeof(double), dx); DEVOUT(10, (Bn + Bm) * sizeof(double), dy); DEVOUT(11, (size_t)B * sizeof(pmpc_qp_info), dinfo);
+    if (m == 0) { DEVOUT(2, 8, dA); DEVOUT(3, 8, dAlb); DEVOUT(4, 8, dAub); }
+    pmpc_status st = pmpc_qp_admm_solve_batch_dev(ctx, B, n, m, dH, dh, dA, dAlb, dAub, dxlb, dxub, dx0, dy0, settings, dx, dy, dinfo);
     if (st != PMPC_OK) return st;
     HIPCHK(hipMemcpyAsync(x, dx, Bn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(y, dy, (Bn + Bm) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

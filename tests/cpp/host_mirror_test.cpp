@@ -46,6 +46,20 @@ static void box_admmRuizEquilibration() {   // box_admm_test.cpp:47-83
     EXPECT_EQ(prob.info().status, SOLVED);
 }
 
+static void admmSimpleQP() {   // admm_solver_test.cpp:16-45
+    std::printf("admmSimpleQP\n");
+    ADMM<2, 1>::qp_hessian_t H; ADMM<2, 1>::qp_var_t h, xl, xu, solution; ADMM<2, 1>::qp_constraint_t A; ADMM<2, 1>::qp_dual_a_t Al, Au;
+    H(0, 0) = 4; H(0, 1) = 1; H(1, 0) = 1; H(1, 1) = 2;
+    h(0) = 1; h(1) = 1; A(0, 0) = 1; A(0, 1) = 1; Al(0) = 1; Au(0) = 1; xl(0) = 0; xl(1) = 0; xu(0) = 0.7; xu(1) = 0.7;
+    solution(0) = 0.3; solution(1) = 0.7;
+    ADMM<2, 1> prob;
+    prob.settings().max_iter = 1000;
+    prob.solve(H, h, A, Al, Au, xl, xu);
+    EXPECT_TRUE(prob.primal_solution().isApprox(solution, 1e-2));
+    EXPECT_LT(prob.iter, prob.settings().max_iter);
+    EXPECT_EQ(prob.info().status, SOLVED);
+}
+
 static void box_admmNonConvex() {
     std::printf("box_admmNonConvex\n");
     boxADMM<1, 0>::qp_hessian_t H; boxADMM<1, 0>::qp_var_t h, xl, xu, guess; boxADMM<1, 0>::qp_constraint_t A; boxADMM<1, 0>::qp_dual_a_t al, au;
@@ -167,6 +181,7 @@ int main() {
     if (!polympc::context()) { std::printf("no GPU: %s\n", pmpc_status_string(polympc::last_error())); return 77; }
     box_admmSimpleQP();
     box_admmRuizEquilibration();
+    admmSimpleQP();
     box_admmNonConvex();
     MPCWrapperTest();
     UserRegisteredRobotMatchesBuiltin();

@@ -192,6 +192,42 @@ def test_pivot_reciprocal_equals_ieee_division():
     assert out.returncode == 0 and " 0 mismatches in the normal range" in out.stdout, out.stdout + out.stderr
 
 
+# -------------------------------------------------------------------------------------------- §8f-4: OSQP-style ADMM
+def test_admm_reference_known_answers(ctx, oracle):
+    """admm_solver_test.cpp:16-45, :303-334, :336-371 through the GPU path."""
+    import polympc_amd as pa
+    H = np.array([[4.0, 1.0], [1.0, 2.0]]).T.ravel()[None]
+    s = pa.qp_settings_default(); s.max_iter = 1000
+    x, y, info = ctx.qp_admm_solve_batch(H, [[1.0, 1.0]], [[1.0, 1.0]], [[1.0]], [[1.0]], [[0.0, 0.0]], [[0.7, 0.7]], settings=s)
+    assert np.linalg.norm(x[0] - [0.3, 0.7]) <= 1e-2 * np.linalg.norm([0.3, 0.7]) and info["iter"][0] < 1000 and info["status"][0] == pa.QP_SOLVED
+    z = np.zeros((1, 0))
+    s = pa.qp_settings_default(); s.max_iter = 200; s.adaptive_rho = 1; s.check_termination = 10
+    x, y, info = ctx.qp_admm_solve_batch(np.zeros((1, 1)), np.ones((1, 1)), z, z, z, [[-1e6]], [[1e6]], settings=s)
+    assert abs(x[0, 0] + 1e6) <= 1e4 and info["iter"][0] < 200 and info["status"][0] == pa.QP_SOLVED
+    s.rho = 2
+    x, y, info = ctx.qp_admm_solve_batch(-np.ones((1, 1)), np.zeros((1, 1)), z, z, z, [[-1.0]], [[2.0]], settings=s, x0=[[0.1]], y0=[[0.1]])
+    assert abs(x[0, 0] - 2.0) <= 2e-2 and info["iter"][0] < 200 and info["status"][0] == pa.QP_SOLVED
+
+
+@pytest.mark.parametrize("n,m,B", [(2, 1, 8), (1, 0, 4), (7, 3, 33), (35, 21, 16), (20, 45, 4)])
+def test_admm_random_vs_oracle(ctx, oracle, n, m, B):
+    """Random QPs (mixed equality / inequality / loose rows and boxes), adaptive rho on: identical iteration counts, status and
+    rho updates as the CPU restatement in the same static elimination order; |dx|, |dy|, residuals within 1e-9."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    q = workloads.random_qp_batch(B, n, m, seed=7)
+    s = pa.qp_settings_default(); s.max_iter = 400; s.adaptive_rho = 1; s.adaptive_rho_interval = 25; s.check_termination = 25
+    x, y, info = ctx.qp_admm_solve_batch(q["H"], q["h"], q["A"], q["Alb"], q["Aub"], q["xlb"], q["xub"], settings=s)
+    os_ = oracle.qp_default_settings()
+    for f, _ in s._fields_:
+        setattr(os_, f, getattr(s, f))
+    xo, yo, io = oracle.qp_admm_solve_batch(q["H"], q["h"], q["A"], q["Alb"], q["Aub"], q["xlb"], q["xub"], settings=os_, pivot=oracle.PIVOT_STATIC)
+    assert list(info["iter"]) == [i.iter for i in io] and list(info["status"]) == [i.status for i in io]
+    assert list(info["rho_updates"]) == [i.rho_updates for i in io]
+    assert np.abs(x - xo).max() <= 1e-9 and np.abs(y - yo).max() <= 1e-9 * max(1.0, np.abs(yo).max())
+    assert np.abs(info["res_prim"] - [i.res_prim for i in io]).max() <= 1e-9 and np.abs(info["res_dual"] - [i.res_dual for i in io]).max() <= 1e-9
+
+
 # -------------------------------------------------------------------------------------------- §8f-2: Ruiz equilibration
 def test_ruiz_reference_known_answer(ctx, oracle):
     """box_admm_test.cpp:47-83 through the GPU path: compute -> solve -> unscale gives (0.3, 0.7), SOLVED in < 150 iterations."""

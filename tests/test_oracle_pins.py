@@ -189,6 +189,51 @@ def test_boxadmm_nonconvex(oracle):  # :299-334
     assert _is_approx(x[0], np.array([2.0]), 1e-2) and info[0].iter < 200 and info[0].status == oracle.QP_SOLVED
 
 
+# ---------------------------------------------------------------- §8f-4: the OSQP-style ADMM solver (admm_solver_test.cpp)
+@pytest.mark.parametrize("pivot", [0, 1])
+def test_admm_simple_qp(oracle, pivot):  # admm_solver_test.cpp:16-45
+    s = oracle.qp_default_settings(); s.max_iter = 1000
+    x, y, info = oracle.qp_admm_solve_batch(*_simple_qp(), settings=s, pivot=pivot)
+    assert _is_approx(x[0], np.array([0.3, 0.7]), 1e-2) and info[0].iter < 1000 and info[0].status == oracle.QP_SOLVED
+
+
+def test_admm_ruiz_equilibration(oracle):  # :47-82
+    s = oracle.qp_default_settings(); s.max_iter = 1000
+    H, h, A, al, au, xl, xu, D, E, c = oracle.ruiz_compute_batch(*_simple_qp())
+    x, y, info = oracle.qp_admm_solve_batch(H, h, A, al, au, xl, xu, settings=s)
+    sol, dual = oracle.ruiz_unscale_solution_batch(D, E, c, x, y)
+    assert _is_approx(sol[0], np.array([0.3, 0.7]), 1e-2) and info[0].iter < 1000 and info[0].status == oracle.QP_SOLVED
+
+
+def test_admm_constraint_violation(oracle):  # :114-151
+    s = oracle.qp_default_settings(); s.eps_rel = 1e-4; s.eps_abs = 1e-4
+    x, y, info = oracle.qp_admm_solve_batch(*_simple_qp(), settings=s)
+    sol = x[0]
+    lower = np.array([sol.sum() - 1, sol[0], sol[1]]); upper = np.array([sol.sum() - 1, sol[0] - 0.7, sol[1] - 0.7])
+    assert lower.min() >= -1e-3 and upper.max() <= 1e-3
+
+
+def test_admm_adaptive_rho(oracle):  # :153-183 (default settings solve it) and :185-225 (adaptive rho needs fewer iterations)
+    s = oracle.qp_default_settings(); s.adaptive_rho = 0; s.adaptive_rho_interval = 10
+    _, _, i = oracle.qp_admm_solve_batch(*_simple_qp(), settings=s)
+    assert i[0].status == oracle.QP_SOLVED
+    s = oracle.qp_default_settings(); s.max_iter = 1000; s.rho = 0.1; s.adaptive_rho = 0
+    _, _, i0 = oracle.qp_admm_solve_batch(*_simple_qp(), settings=s)
+    s.adaptive_rho = 1; s.adaptive_rho_interval = 10
+    _, _, i1 = oracle.qp_admm_solve_batch(*_simple_qp(), settings=s)
+    assert i1[0].iter < 1000 and i1[0].iter < i0[0].iter and i1[0].status == oracle.QP_SOLVED
+
+
+def test_admm_lp_and_nonconvex(oracle):  # :303-334, :336-371
+    z = np.zeros((1, 0))
+    s = oracle.qp_default_settings(); s.max_iter = 200; s.alpha = 1.0; s.adaptive_rho = 1; s.check_termination = 10
+    x, y, info = oracle.qp_admm_solve_batch(np.zeros((1, 1)), np.ones((1, 1)), z, z, z, [[-1e6]], [[1e6]], settings=s)
+    assert _is_approx(x[0], np.array([-1e6]), 1e-2) and info[0].iter < 200 and info[0].status == oracle.QP_SOLVED
+    s.rho = 2
+    x, y, info = oracle.qp_admm_solve_batch(-np.ones((1, 1)), np.zeros((1, 1)), z, z, z, [[-1.0]], [[2.0]], settings=s, x0=[[0.1]], y0=[[0.1]])
+    assert _is_approx(x[0], np.array([2.0]), 1e-2) and info[0].iter < 200 and info[0].status == oracle.QP_SOLVED
+
+
 def test_ldlt_policies_agree(oracle):
     rng = np.random.default_rng(5)
     n, m = 12, 7

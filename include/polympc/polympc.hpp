@@ -156,6 +156,7 @@ struct sqp_settings_t {   // sqp_base.hpp:24-47 (+ the two override points as fl
     int regularisation = 0;            // 0: default no-op hook (sqp_base.hpp:305); 2: Gershgorin (dense_sparse_compare.cpp:109-122)
     bool exact_hessian_every_iter = false;
     int preconditioner = 0;            // SQPBase's Preconditioner template argument: 0 IdentityPreconditioner, 1 RuizEquilibration
+    int hessian_update = 0;            // hessian_update_impl: 0 dense damped BFGS, 1 ContinuousOCP's block BFGS
 };
 using qp_solver_settings_t = pmpc_qp_settings;   // same member names as qp_base.hpp:17-53 (ADMM subset)
 
@@ -195,7 +196,7 @@ public:
         ss.tau = m_settings.tau; ss.eta = m_settings.eta; ss.rho = m_settings.rho; ss.eps_prim = m_settings.eps_prim;
         ss.eps_dual = m_settings.eps_dual; ss.max_iter = m_settings.max_iter; ss.line_search_max_iter = m_settings.line_search_max_iter;
         ss.regularisation = m_settings.regularisation; ss.exact_hessian_every_iter = m_settings.exact_hessian_every_iter ? 1 : 0;
-        ss.preconditioner = m_settings.preconditioner;
+        ss.preconditioner = m_settings.preconditioner; ss.hessian_update = m_settings.hessian_update;
         std::vector<double> xo(m_x.size()), lo(m_lam.size());
         const pmpc_status st = device_binding<OCP>::solve(ctx, problem, OCP::POLY_ORDER, OCP::NUM_SEGMENTS, problem.t_start, problem.t_stop, B,
                                                           m_x.data(), m_lam.data(), m_p.data(), m_lbx.data(), m_ubx.data(),

@@ -74,6 +74,9 @@ typedef struct {
     int exact_hessian_every_iter;
     int preconditioner;   /* SQPBase's Preconditioner argument (sqp_base.hpp:64-68): 0 IdentityPreconditioner (default),
                            * 1 RuizEquilibration (qp_preconditioners.hpp:114-385), applied around every QP (sqp_base.hpp:605-611) */
+    int hessian_update;   /* SQPBase::hessian_update_impl: 0 damped BFGS on the whole matrix (bfgs.hpp:23-52, the DENSE default),
+                           * 1 the sparsity-preserving block BFGS of ContinuousOCP (continuous_ocp.hpp:2304-2431) that the reference's
+                           * MPC tests plug in (mpc_wrapper_test.cpp:100-105); served by the LDS-resident QP kernels */
 } pmpc_sqp_settings;
 
 /* sqp_status_t (sqp_base.hpp:49-55) */

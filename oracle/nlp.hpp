@@ -18,6 +18,7 @@ struct GenericNLP {
     using ad2 = Dual<ad1, NXV>;
     Def def;
     int VAR_SIZE = NXV, NUM_EQ = NE, NUM_INEQ = NI;
+    static constexpr bool HAS_BLOCK_BFGS = false;
 
     void seed1(const double* x, ad1* v) const { for (int i = 0; i < NXV; ++i) { v[i] = ad1(x[i]); v[i].d[i] = 1.0; } }
     void seed2(const double* x, ad2* v) const {

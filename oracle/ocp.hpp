@@ -48,6 +48,52 @@ struct ContinuousOCP {
         set_time_limits(0.0, 1.0);
     }
 
+    // Sparsity-preserving block BFGS, continuous_ocp.hpp:2304-2431 (hessian_update_impl<SPARSE>; the update the reference's MPC
+    // tests select with "this->problem.hessian_update_impl", mpc_wrapper_test.cpp:100-105), restated on dense column-major
+    // storage: per node k only the (x_k, u_k) diagonal block receives the damped rank-2 update, with the GLOBAL scalars
+    // s'Bs, s'y, s'r; with NP > 0 also the parameter border and corner. Coefficients in the reference's association order:
+    //   (-scaling_inv * v_i) * v_j  then  += (c_inv * w_i) * w_j  (w = y, c = s'y, or the damped r, c = s'r); hes_xu = hes_ux'.
+    static constexpr bool HAS_BLOCK_BFGS = true;
+    void hessian_update_block(double* Hm, const double* s, const double* y) const {
+        const int n = VAR_SIZE;
+        std::vector<double> v(n), r(n);
+        for (int i = 0; i < n; ++i) { double a = 0; for (int j = 0; j < n; ++j) a += Hm[i + j * n] * s[j]; v[i] = a; }
+        double scaling = 0, sy = 0;
+        for (int i = 0; i < n; ++i) scaling += s[i] * v[i];
+        const double scaling_inv = 1.0 / scaling;
+        for (int i = 0; i < n; ++i) sy += s[i] * y[i];
+        const double sy_inv = 1.0 / sy;
+        const bool plain = sy >= 0.2 * scaling;
+        const double* w = y; double c_inv = sy_inv;
+        if (!plain) {
+            const double theta = 0.8 * scaling / (scaling - sy);
+            for (int i = 0; i < n; ++i) r[i] = theta * y[i] + (1 - theta) * v[i];
+            double sr = 0; for (int i = 0; i < n; ++i) sr += s[i] * r[i];
+            c_inv = 1.0 / sr; w = r.data();
+        }
+        auto term = [&](int i, int j) { double t = (-scaling_inv * v[i]) * v[j]; t += (c_inv * w[i]) * w[j]; return t; };
+        for (int k = 0; k < NN; ++k) {
+            for (int j = 0; j < NX; ++j) {
+                const int cj = k * NX + j;
+                for (int i = 0; i < NX; ++i) Hm[(k * NX + i) + cj * n] += term(k * NX + i, cj);            // hes_xx
+                for (int i = 0; i < NU; ++i) Hm[(VARX + k * NU + i) + cj * n] += term(VARX + k * NU + i, cj);   // hes_ux
+            }
+            for (int j = 0; j < NU; ++j) {
+                const int cj = VARX + k * NU + j;
+                for (int i = 0; i < NX; ++i) Hm[(k * NX + i) + cj * n] += term(cj, k * NX + i);            // hes_xu = hes_ux'
+                for (int i = 0; i < NU; ++i) Hm[(VARX + k * NU + i) + cj * n] += term(VARX + k * NU + i, cj);   // hes_uu
+            }
+        }
+        if (NP > 0) {
+            const int a = VARX + VARU;
+            for (int j = 0; j < NP; ++j) {
+                for (int i = 0; i < a; ++i) Hm[i + (a + j) * n] += term(i, a + j);          // hes_ap into the parameter columns
+                for (int i = 0; i < NP; ++i) Hm[(a + i) + (a + j) * n] += term(a + i, a + j);   // hes_pp
+            }
+            for (int j = 0; j < a; ++j) for (int i = 0; i < NP; ++i) Hm[(a + i) + j * n] += term(j, a + i);   // rows: hes_ap(j, :)
+        }
+    }
+
     // continuous_ocp.hpp:147-159
     void set_time_limits(double t0, double tf) {
         t_start = t0; t_stop = tf;

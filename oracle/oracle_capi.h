@@ -28,6 +28,7 @@ typedef struct {
     int regularisation;            /* 0 none, 1 eigenvalue mirroring, 2 Gershgorin */
     int exact_hessian_every_iter;  /* 0 = damped BFGS (default) */
     int preconditioner;            /* 0 identity (default), 1 Ruiz equilibration */
+    int hessian_update;            /* 0 dense damped BFGS (default), 1 block BFGS of ContinuousOCP */
 } orc_sqp_settings;
 
 typedef struct {

@@ -93,6 +93,8 @@ struct sqp_settings {  // sqp_base.hpp:24-47
     int regularisation = REG_NONE;          // hook of :277-306 (default no-op)
     bool exact_hessian_every_iter = false;  // override used by codegen_test.cpp:381-398 / minimal_time_test.cpp:126-133
     int preconditioner = 0;                 // SQPBase's Preconditioner template argument: 0 IdentityPreconditioner (default), 1 RuizEquilibration
+    int hessian_update = 0;                 // hessian_update_impl: 0 damped BFGS on the whole matrix (bfgs.hpp, DENSE default), 1 the block BFGS of
+                                            // ContinuousOCP (continuous_ocp.hpp:2304-2431), which keeps the Hessian block-diagonal per node
 };
 enum sqp_status { SQP_SOLVED = 0, SQP_MAX_ITER_EXCEEDED = 1, SQP_INVALID_SETTINGS = 2 };
 struct sqp_info { int iter = 0, qp_solver_iter = 0, status = SQP_MAX_ITER_EXCEEDED; };
@@ -189,7 +191,10 @@ struct SQP {
         double lag; std::vector<double> lag_grad(n), yk(n);
         problem.lagrangian_gradient(x.data(), p_static.data(), lam.data(), lag, lag_grad.data(), h.data(), al.data(), A.data());
         for (int i = 0; i < n; ++i) yk[i] = lag_grad[i] - lag_gradient[i];
-        BFGS_update(H.data(), step_prev.data(), yk.data(), n);
+        if constexpr (Problem::HAS_BLOCK_BFGS) {
+            if (settings.hessian_update == 1) problem.hessian_update_block(H.data(), step_prev.data(), yk.data());
+            else BFGS_update(H.data(), step_prev.data(), yk.data(), n);
+        } else BFGS_update(H.data(), step_prev.data(), yk.data(), n);
         lag_gradient = lag_grad;
     }
     void form_qp_bounds() {  // :588-593

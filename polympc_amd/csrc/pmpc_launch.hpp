@@ -191,7 +191,8 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     double* Hws = ws; double* Aws = ws + (size_t)B * dm.n * dm.n;
     double* slice_state = Aws + (size_t)B * dm.m * dm.n;
     const int slice_iters = pmpc_internal_sqp_slice(ctx);
-    if (!force_lds && ss->preconditioner == 0) {   // node counts whose KKT system can fit 64 rows for small models (7 nodes: config A / D); Ruiz: LDS path
+    if (ss->hessian_update != 0 && ss->hessian_update != 1) return PMPC_ERR_INVALID_ARGUMENT;
+    if (!force_lds && ss->preconditioner == 0 && ss->hessian_update == 0) {   // node counts whose KKT system can fit 64 rows for small models (7 nodes: config A / D); Ruiz: LDS path
         pmpc_status rst = PMPC_OK;
         if (try_launch_reg<Model, 7>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;
         if (try_launch_reg<Model, 5>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;

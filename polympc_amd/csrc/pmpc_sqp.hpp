@@ -375,7 +375,8 @@ struct SqpDevice {
             lagrangian_gradient(v.lgn);
             acc(12, l3 - l1); acc(14, now() - l3);
             const long long b0 = now();
-            if constexpr (NN > 0) { double brow[NN > 0 ? NN : 1]; bfgs_load_row(brow); bfgs_update_reg(brow); } else bfgs_update();
+            if constexpr (NN > 0) { double brow[NN > 0 ? NN : 1]; bfgs_load_row(brow); bfgs_update_reg(brow); }
+            else { if (__builtin_amdgcn_readfirstlane(ss.hessian_update) == 1) bfgs_update_block(); else bfgs_update(); }   // (the launcher routes hessian_update = 1 to these kernels)
             acc(5, now() - b0);
             for (int i = lane_id(); i < n; i += WAVE) v.lg[i] = v.lgn[i];
             wsync();
@@ -469,6 +470,56 @@ struct SqpDevice {
         wsync();
         if (sr < DBL_EPS) return;
         rank2_update_mem(Bs, r, sBs, sr);
+    }
+    // Sparsity-preserving block BFGS: ContinuousOCP::hessian_update_impl<SPARSE>, continuous_ocp.hpp:2304-2431 (what the reference's
+    // MPC tests plug into SQPBase::hessian_update_impl, mpc_wrapper_test.cpp:100-105), on the dense workspace: per node k only the
+    // (x_k, u_k) diagonal block gets the damped rank-2 update, with the global scalars s'Bs, s'y, s'r; NP > 0 adds the parameter
+    // border and corner. One lane per updated entry; coefficients in the reference's association order
+    //   (-scaling_inv * v_i) * v_j  then  += (c_inv * w_i) * w_j   (w = y or the damped r);  hes_xu = hes_ux'.
+    __device__ void bfgs_update_block() {
+        constexpr int NX = Model::NX, NU = Model::NU, NP = Model::NP, NB = NX + NU;
+        const int ln = lane_id();
+        const int VARX = ocp.dm.VARX, VARU = ocp.dm.VARU, NNo = ocp.dm.NN;
+        double* vv = v.t1; double* r = v.t2; double* y = v.t3;
+        for (int i = ln; i < n; i += WAVE) {
+            double a = 0.0;
+            for (int j = 0; j < n; ++j) a += Hw[(size_t)j * ldw + i] * v.step[j];
+            vv[i] = a;
+            y[i] = v.lgn[i] - v.lg[i];
+        }
+        wsync();
+        const double scaling = seq_dot(v.step, vv, n);
+        const double scaling_inv = 1.0 / scaling;
+        const double sy = seq_dot(v.step, y, n);
+        const double sy_inv = 1.0 / sy;
+        const double* w = y; double c_inv = sy_inv;
+        if (!(sy >= 0.2 * scaling)) {
+            const double theta = 0.8 * scaling / (scaling - sy);
+            for (int i = ln; i < n; i += WAVE) r[i] = theta * y[i] + (1 - theta) * vv[i];
+            wsync();
+            c_inv = 1.0 / seq_dot(v.step, r, n);
+            w = r;
+        }
+        auto term = [&](int i, int j) { double t = (-scaling_inv * vv[i]) * vv[j]; t += (c_inv * w[i]) * w[j]; return t; };
+        auto gidx = [&](int k, int b) { return b < NX ? k * NX + b : VARX + k * NU + (b - NX); };
+        for (int e = ln; e < NNo * NB * NB; e += WAVE) {
+            const int k = e / (NB * NB), rem = e - k * (NB * NB), bj = rem / NB, bi = rem - bj * NB;
+            const int gi = gidx(k, bi), gj = gidx(k, bj);
+            const double t = (bi < NX && bj >= NX) ? term(gj, gi) : term(gi, gj);   // the xu block is the transpose of the ux block
+            Hw[(size_t)gj * ldw + gi] += t;
+        }
+        if constexpr (NP > 0) {
+            const int a = VARX + VARU;
+            for (int e = ln; e < a * NP; e += WAVE) {   // border: column block and its transposed copy in the rows
+                const int j = e / a, i = e - j * a;
+                const double t = term(i, a + j);
+                Hw[(size_t)(a + j) * ldw + i] += t;
+                Hw[(size_t)i * ldw + (a + j)] += t;
+            }
+            for (int e = ln; e < NP * NP; e += WAVE) { const int j = e / NP, i = e - j * NP; Hw[(size_t)(a + j) * ldw + (a + i)] += term(a + i, a + j); }
+        }
+        wfence();
+        wsync();
     }
     // B += -(Bs Bs^T)/sBs + (r r^T)/sr, element by element in the HBM workspace
     __device__ void rank2_update_mem(const double* Bs, const double* r, double sBs, double sr) {

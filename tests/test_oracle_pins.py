@@ -406,6 +406,33 @@ def test_sqp_valet_parking_with_ruiz(oracle, pivot):
     assert i2[0].status == oracle.SQP_SOLVED and i2[0].iter < 10
 
 
+@pytest.mark.parametrize("pivot", [0, 1])
+def test_sqp_robot_mpc_warm_start_block_bfgs(oracle, pivot):
+    """mpc_wrapper_test.cpp:120-166 with the Hessian update that test actually selects (MySolver::hessian_update_impl ->
+    ContinuousOCP::hessian_update_impl, the block BFGS of continuous_ocp.hpp:2304-2431): SOLVED, and the warm-started second solve
+    needs fewer iterations (:159)."""
+    ss = oracle.sqp_default_settings(); ss.max_iter = 10; ss.line_search_max_iter = 10; ss.hessian_update = 1
+    lbx, ubx = _robot_bounds(16, [0.5, 0.5, 0.5])
+    kw = dict(sqp_settings=ss, pivot=pivot, mparams=[2.0])
+    x, lam, i1 = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 3, 0.0, 2.0, 1, [[2.0]], lbx, ubx, **kw)
+    assert i1[0].status == oracle.SQP_SOLVED
+    lbx2, ubx2 = _robot_bounds(16, [0.3, 0.4, 0.5])
+    x2, lam2, i2 = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 3, 0.0, 2.0, 1, [[2.0]], lbx2, ubx2, x_guess=x, lam_guess=lam, **kw)
+    assert i2[0].status == oracle.SQP_SOLVED and i2[0].iter < i1[0].iter
+
+
+def test_block_bfgs_keeps_the_hessian_block_diagonal(oracle):
+    """Started from a block-diagonal exact Hessian, SQP iterates with hessian_update = 1 must reach the same optimum as dense BFGS
+    (the problem is the same) — and the two updates are different algorithms, so the trajectories may differ."""
+    ss = oracle.sqp_default_settings(); ss.max_iter = 20; ss.line_search_max_iter = 10
+    lbx, ubx = _robot_bounds(7, [0.5, 0.5, 0.5])
+    x0, _, i0 = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 6, 1, 0.0, 2.0, 1, [[2.0]], lbx, ubx, sqp_settings=ss)
+    ss.hessian_update = 1
+    x1, _, i1 = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 6, 1, 0.0, 2.0, 1, [[2.0]], lbx, ubx, sqp_settings=ss)
+    assert i0[0].status == oracle.SQP_SOLVED and i1[0].status == oracle.SQP_SOLVED
+    assert np.abs(x0 - x1).max() < 5e-2
+
+
 def test_sqp_cstr(oracle):  # cstr_control_test.cpp:137-183 (Eigen pivot policy)
     ss = oracle.sqp_default_settings(); ss.max_iter = 20; ss.line_search_max_iter = 20
     n = 66

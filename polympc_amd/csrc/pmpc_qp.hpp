@@ -117,6 +117,7 @@ __device__ __forceinline__ double rho_of(int type, double rho0) {  // box_admm.h
 
 // LDS work area of one QP instance
 struct QpLds {
+    static constexpr int WAVE_DUMMY = 64;
     double* K; int N;              // packed lower triangle of the (n+m)x(n+m) factor, by columns
     __host__ __device__ static int koff(int N_, int j) { return j * N_ - (j * (j + 1)) / 2; }
     __device__ __forceinline__ int off(int j) const { return j * N - (j * (j + 1)) / 2; }
@@ -124,7 +125,7 @@ struct QpLds {
     __host__ __device__ static size_t kdoubles(int N_) { return (size_t)N_ * (N_ + 1) / 2; }
     __host__ __device__ static size_t doubles(int n, int m) {
         const int N = n + m;
-        return kdoubles(N) + 3 * (size_t)n /*x q kdiag(n part)*/ + (size_t)N /*y*/ + 5 * (size_t)m /*z zt zprev rho rhoinv*/ +
+        return kdoubles(N) + 2 * WAVE_DUMMY /*per-lane dummy slots behind K*/ + 3 * (size_t)n /*x q kdiag(n part)*/ + (size_t)N /*y*/ + 5 * (size_t)m /*z zt zprev rho rhoinv*/ +
                2 * (size_t)n /*rhob rhobinv*/ + (size_t)N /*rhs*/ + 2 * (size_t)N /*t1 t2*/ + (size_t)m /*kdiag m part*/ + 8;
     }
     // register-resident QP path: only the result vectors live in LDS
@@ -147,7 +148,7 @@ struct QpLds {
     __device__ double* carve(double* base, int n, int m) {
         N = n + m;
         double* p = base;
-        K = p; p += kdoubles(N);
+        K = p; p += kdoubles(N) + 2 * WAVE_DUMMY;   // K[kdoubles(N) + lane], K[kdoubles(N) + 64 + lane]: dummy slots of the branch-free factor
         x = p; p += n; q = p; p += n; kdiag = p; p += N; y = p; p += N;
         z = p; p += m; zt = p; p += m; zprev = p; p += m; rho = p; p += m; rhoinv = p; p += m;
         rhob = p; p += n; rhobinv = p; p += n; rhs = p; p += N; t1 = p; p += N; t2 = p; p += N;
@@ -170,10 +171,56 @@ __device__ inline void kkt_build(const QpLds& w, int n, int m, const double* __r
     wsync();
 }
 
+// wave-uniform lane broadcast of a double (v_readlane with a scalar lane index: no LDS crossbar round trip)
+__device__ __forceinline__ double bcast_uniform(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
 // in-place LDL^T, static order, right-looking (factorise_kkt_matrix, box_admm.hpp:336-341)
 __device__ inline void kkt_factor(const QpLds& w, int N) {
     const int ln = lane_id();
     double* K = w.K;
+    if (N <= 2 * WAVE) {
+        // at most two rows per lane (i0 = lane, i1 = lane + 64): the unscaled column stays in two registers, and the trailing
+        // update takes four columns at a time — their loads are issued together, then the fma and the stores (one LDS round
+        // trip per four columns instead of per column; same operations on every entry, in the same order). Branch-free: a
+        // lane without an entry in a column reads and rewrites a private dummy slot behind the packed triangle instead of being
+        // masked off — divergent branches around single LDS operations cost more than the operations.
+        const int i0 = ln, i1 = ln + WAVE;
+        const int d0 = (int)QpLds::kdoubles(N) + ln, d1 = d0 + QpLds::WAVE_DUMMY;   // dummy slots behind the packed triangle (indices, not
+                                                                                    // pointers: see compiler hazard 7 in DESIGN.md)
+        for (int k = 0; k < N; ++k) {
+            const int ok = w.off(k);
+            const double dk = K[ok + k];
+            const bool a0 = i0 > k && i0 < N, a1 = i1 > k && i1 < N;
+            const int p0 = a0 ? ok + i0 : d0, p1 = a1 ? ok + i1 : d1;
+            const double c0 = K[p0], c1 = K[p1];
+            K[p0] = c0 / dk;
+            K[p1] = c1 / dk;
+            wsync();
+            for (int j0 = k + 1; j0 < N; j0 += 4) {
+                double l[4], e0[4], e1[4];
+                int q0[4], q1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u;
+                    const int jc = (j < N) ? j : N - 1;
+                    const int oj = w.off(jc);
+                    l[u] = K[ok + jc];
+                    q0[u] = (j < N && i0 >= j && i0 < N) ? oj + i0 : d0;
+                    q1[u] = (j < N && i1 >= j && i1 < N) ? oj + i1 : d1;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { e0[u] = K[q0[u]]; e1[u] = K[q1[u]]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { K[q0[u]] = fma(-c0, l[u], e0[u]); K[q1[u]] = fma(-c1, l[u], e1[u]); }
+            }
+            wsync();
+        }
+        return;
+    }
     for (int k = 0; k < N; ++k) {
         const int ok = w.off(k);
         const double dk = K[ok + k];
@@ -197,20 +244,87 @@ __device__ inline void kkt_factor(const QpLds& w, int N) {
 __device__ inline void kkt_solve(const QpLds& w, int N, double* v) {
     const int ln = lane_id();
     const double* K = w.K;
-    if (N <= WAVE) {
-        // single row per lane: keep the running entry in a register, broadcast the pivot entry by readlane
-        double c = (ln < N) ? v[ln] : 0.0;
-        for (int j = 0; j < N - 1; ++j) {
-            const double xj = __shfl(c, j, WAVE);
-            if (ln > j && ln < N) c = fma(-K[w.off(j) + ln], xj, c);
+    if (N <= 2 * WAVE) {
+        // at most two rows per lane, held in registers (c0: row lane, c1: row lane + 64); the pivot entry of every step is
+        // broadcast with v_readlane and the factor entries of eight steps are loaded ahead of the (serial) fma chain — no LDS
+        // write/read round trip per column. Branch-free (clamped loads + selects); pivots below 64 come out of c0, the others
+        // out of c1, so each sweep is two loops without a per-step case distinction.
+        const int i0 = ln, i1 = ln + WAVE;
+        const bool h0 = i0 < N, h1 = i1 < N;
+        const int r0 = h0 ? i0 : 0, r1 = h1 ? i1 : 0;   // clamped row indices for the loads
+        double c0 = h0 ? v[i0] : 0.0, c1 = h1 ? v[i1] : 0.0;
+        const int nA = (N - 1 < WAVE) ? N - 1 : WAVE;   // forward steps whose pivot lives in c0: j in [0, nA)
+        for (int j0 = 0; j0 < nA; j0 += 8) {
+            double f0[8], f1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = (j0 + u < nA) ? j0 + u : nA - 1;
+                const int o = w.off(j);
+                f0[u] = K[o + (r0 > j ? r0 : j)];
+                f1[u] = K[o + (r1 > j ? r1 : j)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u;
+                const double xj = bcast_uniform(c0, j < nA ? j : 0);
+                const double t0 = fma(-f0[u], xj, c0), t1 = fma(-f1[u], xj, c1);
+                c0 = (j < nA && h0 && i0 > j) ? t0 : c0;
+                c1 = (j < nA && h1) ? t1 : c1;
+            }
         }
-        const int ol = (ln < N) ? w.off(ln) : 0;
-        if (ln < N) c = c / K[ol + ln];
-        for (int j = N - 1; j > 0; --j) {
-            const double xj = __shfl(c, j, WAVE);
-            if (ln < j) c = fma(-K[ol + j], xj, c);
+        for (int j0 = WAVE; j0 < N - 1; j0 += 8) {      // pivots in c1; only the rows above 64 are still below them
+            double f1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = (j0 + u < N - 1) ? j0 + u : N - 2;
+                f1[u] = K[w.off(j) + (r1 > j ? r1 : j)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u;
+                const double xj = bcast_uniform(c1, (j < N - 1 ? j : WAVE) - WAVE);
+                const double t1 = fma(-f1[u], xj, c1);
+                c1 = (j < N - 1 && h1 && i1 > j) ? t1 : c1;
+            }
         }
-        if (ln < N) v[ln] = c;
+        const int o0 = w.off(r0), o1 = w.off(r1);
+        { const double q0 = c0 / K[o0 + r0], q1 = c1 / K[o1 + r1]; c0 = h0 ? q0 : c0; c1 = h1 ? q1 : c1; }
+        for (int j0 = N - 1; j0 >= WAVE; j0 -= 8) {     // backward, pivots in c1: every row below 64 and the rows i1 < j
+            double f0[8], f1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = (j0 - u >= WAVE) ? j0 - u : WAVE;
+                f0[u] = K[o0 + j];
+                f1[u] = K[o1 + (r1 < j ? j : r1)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 - u;
+                const double xj = bcast_uniform(c1, (j >= WAVE ? j : WAVE) - WAVE);
+                const double t0 = fma(-f0[u], xj, c0), t1 = fma(-f1[u], xj, c1);
+                c0 = (j >= WAVE && h0) ? t0 : c0;
+                c1 = (j >= WAVE && h1 && i1 < j) ? t1 : c1;
+            }
+        }
+        const int jtop = (N - 1 < WAVE - 1) ? N - 1 : WAVE - 1;
+        for (int j0 = jtop; j0 > 0; j0 -= 8) {          // backward, pivots in c0: rows i0 < j only
+            double f0[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = (j0 - u > 0) ? j0 - u : 1;
+                f0[u] = K[o0 + (r0 < j ? j : r0)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 - u;
+                const double xj = bcast_uniform(c0, j > 0 ? j : 0);
+                const double t0 = fma(-f0[u], xj, c0);
+                c0 = (j > 0 && h0 && i0 < j) ? t0 : c0;
+            }
+        }
+        wsync();
+        if (h0) v[i0] = c0;
+        if (h1) v[i1] = c1;
         wsync();
         return;
     }

@@ -448,6 +448,72 @@ private:
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
+// BatchMPC<OCP>: B independent MPC<OCP> controllers whose bounds, static parameters and primal / dual iterate stay in HBM between
+// steps (pmpc_mpc_batch_*). Per step only the measured states go up and the controls to apply come down. Built-in OCPs.
+template <typename OCP>
+class BatchMPC {
+public:
+    static constexpr int nx = OCP::NX, nu = OCP::NU, nd = OCP::ND, var_size = OCP::VAR_SIZE, varx_size = OCP::VARX_SIZE,
+                         num_nodes = OCP::NUM_NODES, num_ineq = OCP::NUM_INEQ, dual_size = OCP::DUAL_SIZE;
+    explicit BatchMPC(int batch) : B(batch) {
+        const double INF = std::numeric_limits<double>::infinity();
+        m_lbx.assign((size_t)B * var_size, -INF); m_ubx.assign((size_t)B * var_size, INF);
+        m_lbg.assign((size_t)B * (num_ineq > 0 ? num_ineq : 1), -INF); m_ubg.assign((size_t)B * (num_ineq > 0 ? num_ineq : 1), INF);
+        m_p.assign((size_t)B * (nd > 0 ? nd : 1), 0.0);
+        m_info.resize(B);
+        pmpc_qp_settings_sqp_default(&m_qp_settings);
+    }
+    ~BatchMPC() { if (m_batch) pmpc_mpc_batch_destroy(m_batch); }
+    BatchMPC(const BatchMPC&) = delete; BatchMPC& operator=(const BatchMPC&) = delete;
+    OCP& ocp() noexcept { return problem; }
+    sqp_settings_t& settings() noexcept { return m_settings; }
+    qp_solver_settings_t& qp_settings() noexcept { return m_qp_settings; }
+    void set_time_limits(const double& t0, const double& tf) noexcept { problem.set_time_limits(t0, tf); }
+    // the setters of mpc_wrapper.hpp:103-187 for instance b; they are uploaded by the first step()
+    void control_bounds(int b, const Vector<nu>& lb, const Vector<nu>& ub) noexcept {
+        for (int k = 0; k < num_nodes; ++k) for (int i = 0; i < nu; ++i) { lbx(b)[varx_size + k * nu + i] = lb(i); ubx(b)[varx_size + k * nu + i] = ub(i); }
+    }
+    void state_bounds(int b, const Vector<nx>& lb, const Vector<nx>& ub) noexcept {
+        for (int k = 0; k < num_nodes - 1; ++k) for (int i = 0; i < nx; ++i) { lbx(b)[k * nx + i] = lb(i); ubx(b)[k * nx + i] = ub(i); }
+    }
+    void final_state_bounds(int b, const Vector<nx>& lb, const Vector<nx>& ub) noexcept { for (int i = 0; i < nx; ++i) { lbx(b)[i] = lb(i); ubx(b)[i] = ub(i); } }
+    void set_static_parameters(int b, const Vector<nd>& p) noexcept { for (int i = 0; i < nd; ++i) m_p[(size_t)b * (nd > 0 ? nd : 1) + i] = p(i); }
+    // initial_conditions(x0) + solve() + solution_u_at(t_start) for every controller: x0 holds B*nx states, u0 receives B*nu controls
+    pmpc_status step(const double* x0, double* u0) noexcept {
+        pmpc_context* ctx = context();
+        if (!ctx) return last_error();
+        if (!m_batch) {
+            const std::vector<double> mp = problem.model_params();
+            const pmpc_status st = pmpc_mpc_batch_create(ctx, device_binding<OCP>::model_id, OCP::POLY_ORDER, OCP::NUM_SEGMENTS, problem.t_start, problem.t_stop,
+                                                         mp.empty() ? nullptr : mp.data(), (int)mp.size(), B, m_p.data(), m_lbx.data(), m_ubx.data(),
+                                                         num_ineq > 0 ? m_lbg.data() : nullptr, num_ineq > 0 ? m_ubg.data() : nullptr, nullptr, nullptr, &m_batch);
+            if (st != PMPC_OK) return last_error() = st;
+        }
+        pmpc_sqp_settings ss;
+        ss.tau = m_settings.tau; ss.eta = m_settings.eta; ss.rho = m_settings.rho; ss.eps_prim = m_settings.eps_prim; ss.eps_dual = m_settings.eps_dual;
+        ss.max_iter = m_settings.max_iter; ss.line_search_max_iter = m_settings.line_search_max_iter; ss.regularisation = m_settings.regularisation;
+        ss.exact_hessian_every_iter = m_settings.exact_hessian_every_iter ? 1 : 0; ss.preconditioner = m_settings.preconditioner;
+        ss.hessian_update = m_settings.hessian_update;
+        return last_error() = pmpc_mpc_batch_step(m_batch, x0, &ss, &m_qp_settings, u0, m_info.data());
+    }
+    const pmpc_sqp_info& info(int b) const noexcept { return m_info[b]; }
+    // current primal solution of every controller (B * var_size), downloaded on demand
+    pmpc_status solution(std::vector<double>& x) noexcept {
+        if (!m_batch) return PMPC_ERR_INVALID_ARGUMENT;
+        x.resize((size_t)B * var_size);
+        return last_error() = pmpc_mpc_batch_solution(m_batch, x.data(), nullptr);
+    }
+private:
+    double* lbx(int b) noexcept { return &m_lbx[(size_t)b * var_size]; }
+    double* ubx(int b) noexcept { return &m_ubx[(size_t)b * var_size]; }
+    OCP problem; int B;
+    std::vector<double> m_lbx, m_ubx, m_lbg, m_ubg, m_p;
+    std::vector<pmpc_sqp_info> m_info;
+    sqp_settings_t m_settings; qp_solver_settings_t m_qp_settings;
+    pmpc_mpc_batch* m_batch{nullptr};
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
 // device bindings
 #define POLYMPC_USE_BUILTIN_OCP(Name, MODEL_ID)                                                                                       \
     template <> struct polympc::device_binding<Name> {                                                                                \
@@ -508,6 +574,7 @@ public:
 };
 }  // namespace models
 template <typename A> struct device_binding<models::MobileRobot<A>> {
+    static constexpr int model_id = PMPC_MODEL_ROBOT;   // built-in device code: usable with BatchMPC
     static pmpc_status solve(pmpc_context* ctx, const models::MobileRobot<A>& ocp, int P, int S, double t0, double tf, int B, const double* xg,
                              const double* lg, const double* d, const double* lbx, const double* ubx, const double* lbg, const double* ubg,
                              const pmpc_sqp_settings* ss, const pmpc_qp_settings* qs, double* x, double* lam, pmpc_sqp_info* info) {
@@ -516,6 +583,7 @@ template <typename A> struct device_binding<models::MobileRobot<A>> {
     }
 };
 template <typename A> struct device_binding<models::CSTR<A>> {
+    static constexpr int model_id = PMPC_MODEL_CSTR;
     static pmpc_status solve(pmpc_context* ctx, const models::CSTR<A>&, int P, int S, double t0, double tf, int B, const double* xg,
                              const double* lg, const double* d, const double* lbx, const double* ubx, const double* lbg, const double* ubg,
                              const pmpc_sqp_settings* ss, const pmpc_qp_settings* qs, double* x, double* lam, pmpc_sqp_info* info) {

@@ -202,6 +202,19 @@ pmpc_status pmpc_mpc_step_batch_dev(pmpc_context* ctx, int model, int P, int S, 
                                     const double* lbg, const double* ubg, const pmpc_sqp_settings* sqp_settings,
                                     const pmpc_qp_settings* qp_settings, double* x, double* lam, pmpc_sqp_info* info, double* u0);
 
+/* The same for callers that hold no device pointers (plain C / C++ hosts): an opaque batch of B controllers that keeps bounds,
+ * static parameters, primal / dual iterate and results in HBM between steps. create uploads the problem data once (x_guess /
+ * lam_guess may be NULL: zeros); step uploads only x0 (B*NX), runs pmpc_mpc_step_batch_dev and downloads u(t_start) (B*NU) and,
+ * if wanted, the per-instance info; solution downloads the current primal / dual iterate (either pointer may be NULL). */
+typedef struct pmpc_mpc_batch pmpc_mpc_batch;
+pmpc_status pmpc_mpc_batch_create(pmpc_context* ctx, int model, int P, int S, double t0, double tf, const double* mparams, int n_mparams,
+                                  int B, const double* d, const double* lbx, const double* ubx, const double* lbg, const double* ubg,
+                                  const double* x_guess, const double* lam_guess, pmpc_mpc_batch** batch);
+pmpc_status pmpc_mpc_batch_step(pmpc_mpc_batch* batch, const double* x0, const pmpc_sqp_settings* sqp_settings,
+                                const pmpc_qp_settings* qp_settings, double* u0, pmpc_sqp_info* info);
+pmpc_status pmpc_mpc_batch_solution(pmpc_mpc_batch* batch, double* x, double* lam);
+pmpc_status pmpc_mpc_batch_destroy(pmpc_mpc_batch* batch);
+
 /* ---- user-defined OCPs ---------------------------------------------------------------------------------------------
  * A user's OCP class (the reference's CRTP class with dynamics_impl / lagrange_term_impl / mayer_term_impl /
  * inequality_constraints_impl, continuous_ocp.hpp:191-288) is compiled for the GPU by hipcc in the user's own

@@ -510,6 +510,69 @@ pmpc_status pmpc_mpc_step_batch_dev(pmpc_context* ctx, int model, int P, int S, 
     return PMPC_OK;
 }
 
+/* ---- a batch of MPC controllers whose state lives on the device between steps (host-side callers without HIP) ---- */
+struct pmpc_mpc_batch {
+    pmpc_context* ctx; int model, P, S, B, nx, nu, nd, n, m, mi; double t0, tf; std::vector<double> mparams;
+    double *d = nullptr, *lbx = nullptr, *ubx = nullptr, *lbg = nullptr, *ubg = nullptr, *x = nullptr, *lam = nullptr, *x0 = nullptr, *u0 = nullptr;
+    pmpc_sqp_info* info = nullptr;
+};
+pmpc_status pmpc_mpc_batch_destroy(pmpc_mpc_batch* h) {
+    if (!h) return PMPC_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(h->ctx->device);
+    (void)hipStreamSynchronize(h->ctx->stream);
+    for (void* q : {(void*)h->d, (void*)h->lbx, (void*)h->ubx, (void*)h->lbg, (void*)h->ubg, (void*)h->x, (void*)h->lam, (void*)h->x0, (void*)h->u0, (void*)h->info})
+        if (q) (void)hipFree(q);
+    delete h;
+    return PMPC_OK;
+}
+pmpc_status pmpc_mpc_batch_create(pmpc_context* ctx, int model, int P, int S, double t0, double tf, const double* mparams, int n_mparams, int B,
+                                  const double* d, const double* lbx, const double* ubx, const double* lbg, const double* ubg,
+                                  const double* x_guess, const double* lam_guess, pmpc_mpc_batch** out) {
+    if (!ctx || !out || B < 1 || !lbx || !ubx) return PMPC_ERR_INVALID_ARGUMENT;
+    int nx, nu, np, nd, ng, n, me, mi;
+    pmpc_status st = pmpc_ocp_dims(model, P, S, &nx, &nu, &np, &nd, &ng, &n, &me, &mi);
+    if (st != PMPC_OK) return st;
+    if ((nd > 0 && !d) || (mi > 0 && (!lbg || !ubg))) return PMPC_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(ctx->device));
+    pmpc_mpc_batch* h = new pmpc_mpc_batch{ctx, model, P, S, B, nx, nu, nd, n, me + mi, mi, t0, tf, std::vector<double>(mparams ? mparams : nullptr, mparams ? mparams + n_mparams : nullptr)};
+    const size_t Bn = (size_t)B * n, Bd = (size_t)B * (n + h->m);
+    auto up = [&](double** dst, const double* src, size_t count, bool zero) -> bool {
+        if (hipMalloc((void**)dst, (count ? count : 1) * sizeof(double)) != hipSuccess) return false;
+        if (src) return hipMemcpyAsync(*dst, src, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+        return !zero || hipMemsetAsync(*dst, 0, (count ? count : 1) * sizeof(double), ctx->stream) == hipSuccess;
+    };
+    bool ok = up(&h->d, nd ? d : nullptr, (size_t)B * nd, true) && up(&h->lbx, lbx, Bn, false) && up(&h->ubx, ubx, Bn, false) &&
+              up(&h->x, x_guess, Bn, true) && up(&h->lam, lam_guess, Bd, true) && up(&h->x0, nullptr, (size_t)B * nx, true) &&
+              up(&h->u0, nullptr, (size_t)B * nu, true) && hipMalloc((void**)&h->info, (size_t)B * sizeof(pmpc_sqp_info)) == hipSuccess;
+    if (ok && mi > 0) ok = up(&h->lbg, lbg, (size_t)B * mi, false) && up(&h->ubg, ubg, (size_t)B * mi, false);
+    if (ok) ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
+    if (!ok) { (void)pmpc_mpc_batch_destroy(h); return PMPC_ERR_HIP; }
+    *out = h;
+    return PMPC_OK;
+}
+pmpc_status pmpc_mpc_batch_step(pmpc_mpc_batch* h, const double* x0, const pmpc_sqp_settings* ss, const pmpc_qp_settings* qs, double* u0,
+                                pmpc_sqp_info* info) {
+    if (!h || !x0 || !ss || !qs) return PMPC_ERR_INVALID_ARGUMENT;
+    pmpc_context* ctx = h->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(h->x0, x0, (size_t)h->B * h->nx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    pmpc_status st = pmpc_mpc_step_batch_dev(ctx, h->model, h->P, h->S, h->t0, h->tf, h->mparams.empty() ? nullptr : h->mparams.data(), (int)h->mparams.size(),
+                                             h->B, h->x0, h->d, h->lbx, h->ubx, h->lbg, h->ubg, ss, qs, h->x, h->lam, h->info, h->u0);
+    if (st != PMPC_OK) return st;
+    if (u0) HIPCHK(hipMemcpyAsync(u0, h->u0, (size_t)h->B * h->nu * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (info) HIPCHK(hipMemcpyAsync(info, h->info, (size_t)h->B * sizeof(pmpc_sqp_info), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PMPC_OK;
+}
+pmpc_status pmpc_mpc_batch_solution(pmpc_mpc_batch* h, double* x, double* lam) {
+    if (!h) return PMPC_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(h->ctx->device));
+    if (x) HIPCHK(hipMemcpyAsync(x, h->x, (size_t)h->B * h->n * sizeof(double), hipMemcpyDeviceToHost, h->ctx->stream));
+    if (lam) HIPCHK(hipMemcpyAsync(lam, h->lam, (size_t)h->B * (h->n + h->m) * sizeof(double), hipMemcpyDeviceToHost, h->ctx->stream));
+    HIPCHK(hipStreamSynchronize(h->ctx->stream));
+    return PMPC_OK;
+}
+
 pmpc_status pmpc_sqp_solve_batch(pmpc_context* ctx, int model, int P, int S, double t0, double tf, const double* mparams,
                                  int n_mparams, int B, const double* x_guess, const double* lam_guess, const double* d,
                                  const double* lbx, const double* ubx, const double* lbg, const double* ubg,

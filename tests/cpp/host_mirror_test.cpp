@@ -77,6 +77,40 @@ using Polynomial = polympc::Chebyshev<5, polympc::GAUSS_LOBATTO, double>;
 using Approximation = polympc::Spline<Polynomial, 3>;
 using RobotOCP = polympc::models::MobileRobot<Approximation>;
 
+static void BatchMPCTest() {   // B controllers whose state stays on the device between steps (mpc_wrapper_test.cpp:120-166 per controller)
+    std::printf("BatchMPCTest\n");
+    const int B = 6;
+    BatchMPC<RobotOCP> mpc(B);
+    mpc.ocp().set_Q_coeff(2.0);
+    mpc.settings().max_iter = 10; mpc.settings().line_search_max_iter = 10;
+    mpc.set_time_limits(0, 2);
+    Vector<2> lbu, ubu; lbu(0) = -1.5; lbu(1) = -0.75; ubu(0) = 1.5; ubu(1) = 0.75;
+    Vector<1> p; p(0) = 2.0;
+    for (int b = 0; b < B; ++b) { mpc.control_bounds(b, lbu, ubu); mpc.set_static_parameters(b, p); }
+    std::vector<double> x0(B * 3), u0(B * 2), u1(B * 2);
+    for (int b = 0; b < B; ++b) { x0[3 * b] = 0.5 + 0.01 * b; x0[3 * b + 1] = 0.5; x0[3 * b + 2] = 0.5; }
+    EXPECT_EQ(mpc.step(x0.data(), u0.data()), PMPC_OK);
+    int first = 0, second = 0;
+    for (int b = 0; b < B; ++b) { EXPECT_EQ(mpc.info(b).status, (int)PMPC_SQP_SOLVED); first += mpc.info(b).iter; }
+    for (int b = 0; b < B; ++b) { EXPECT_TRUE(u0[2 * b] >= -1.5 - 1e-3 && u0[2 * b] <= 1.5 + 1e-3 && std::fabs(u0[2 * b + 1]) <= 0.75 + 1e-3); }
+    // the single-controller facade solves controller 0's problem to the same control
+    {
+        MPC<RobotOCP> one; one.ocp().set_Q_coeff(2.0); one.settings().max_iter = 10; one.settings().line_search_max_iter = 10; one.set_time_limits(0, 2);
+        MPC<RobotOCP>::static_param pp; pp(0) = 2.0; MPC<RobotOCP>::state_t s0; s0(0) = 0.5; s0(1) = 0.5; s0(2) = 0.5;
+        MPC<RobotOCP>::control_t l2, u2; l2(0) = -1.5; l2(1) = -0.75; u2(0) = 1.5; u2(1) = 0.75;
+        one.set_static_parameters(pp); one.control_bounds(l2, u2); one.initial_conditions(s0); one.solve();
+        const auto uu = one.solution_u_at(0);   // index 0 = t_start: the accessor counts nodes from the end of the block (mpc_wrapper.hpp:241-244)
+        EXPECT_TRUE(std::fabs(uu(0) - u0[0]) <= 1e-9 && std::fabs(uu(1) - u0[1]) <= 1e-9);
+    }
+    for (int b = 0; b < B; ++b) { x0[3 * b] = 0.3; x0[3 * b + 1] = 0.4; x0[3 * b + 2] = 0.5; }   // moved state, warm start from the resident solution
+    EXPECT_EQ(mpc.step(x0.data(), u1.data()), PMPC_OK);
+    for (int b = 0; b < B; ++b) { EXPECT_EQ(mpc.info(b).status, (int)PMPC_SQP_SOLVED); second += mpc.info(b).iter; }
+    EXPECT_LT(second, first);
+    std::vector<double> xs;
+    EXPECT_EQ(mpc.solution(xs), PMPC_OK);
+    for (int b = 0; b < B; ++b) EXPECT_TRUE(std::fabs(xs[(size_t)b * 80 + 45] - 0.3) <= 1e-3);   // pinned initial state honoured (last nx entries of the x block)
+}
+
 static void MPCWrapperTest() {
     std::printf("MPCWrapperTest\n");
     using mpc_t = MPC<RobotOCP>;
@@ -184,6 +218,7 @@ int main() {
     admmSimpleQP();
     box_admmNonConvex();
     MPCWrapperTest();
+    BatchMPCTest();
     UserRegisteredRobotMatchesBuiltin();
     UserPendulumWithPathConstraint();
     std::printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);

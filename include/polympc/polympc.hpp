@@ -157,6 +157,7 @@ struct sqp_settings_t {   // sqp_base.hpp:24-47 (+ the two override points as fl
     bool exact_hessian_every_iter = false;
     int preconditioner = 0;            // SQPBase's Preconditioner template argument: 0 IdentityPreconditioner, 1 RuizEquilibration
     int hessian_update = 0;            // hessian_update_impl: 0 dense damped BFGS, 1 ContinuousOCP's block BFGS
+    int qp_solver = 0;                 // QPSolver template argument: 0 boxADMM, 1 ADMM (OSQP form)
 };
 using qp_solver_settings_t = pmpc_qp_settings;   // same member names as qp_base.hpp:17-53 (ADMM subset)
 
@@ -196,7 +197,7 @@ public:
         ss.tau = m_settings.tau; ss.eta = m_settings.eta; ss.rho = m_settings.rho; ss.eps_prim = m_settings.eps_prim;
         ss.eps_dual = m_settings.eps_dual; ss.max_iter = m_settings.max_iter; ss.line_search_max_iter = m_settings.line_search_max_iter;
         ss.regularisation = m_settings.regularisation; ss.exact_hessian_every_iter = m_settings.exact_hessian_every_iter ? 1 : 0;
-        ss.preconditioner = m_settings.preconditioner; ss.hessian_update = m_settings.hessian_update;
+        ss.preconditioner = m_settings.preconditioner; ss.hessian_update = m_settings.hessian_update; ss.qp_solver = m_settings.qp_solver;
         std::vector<double> xo(m_x.size()), lo(m_lam.size());
         const pmpc_status st = device_binding<OCP>::solve(ctx, problem, OCP::POLY_ORDER, OCP::NUM_SEGMENTS, problem.t_start, problem.t_stop, B,
                                                           m_x.data(), m_lam.data(), m_p.data(), m_lbx.data(), m_ubx.data(),
@@ -493,7 +494,7 @@ public:
         ss.tau = m_settings.tau; ss.eta = m_settings.eta; ss.rho = m_settings.rho; ss.eps_prim = m_settings.eps_prim; ss.eps_dual = m_settings.eps_dual;
         ss.max_iter = m_settings.max_iter; ss.line_search_max_iter = m_settings.line_search_max_iter; ss.regularisation = m_settings.regularisation;
         ss.exact_hessian_every_iter = m_settings.exact_hessian_every_iter ? 1 : 0; ss.preconditioner = m_settings.preconditioner;
-        ss.hessian_update = m_settings.hessian_update;
+        ss.hessian_update = m_settings.hessian_update; ss.qp_solver = m_settings.qp_solver;
         return last_error() = pmpc_mpc_batch_step(m_batch, x0, &ss, &m_qp_settings, u0, m_info.data());
     }
     const pmpc_sqp_info& info(int b) const noexcept { return m_info[b]; }

@@ -77,6 +77,8 @@ typedef struct {
     int hessian_update;   /* SQPBase::hessian_update_impl: 0 damped BFGS on the whole matrix (bfgs.hpp:23-52, the DENSE default),
                            * 1 the sparsity-preserving block BFGS of ContinuousOCP (continuous_ocp.hpp:2304-2431) that the reference's
                            * MPC tests plug in (mpc_wrapper_test.cpp:100-105); served by the LDS-resident QP kernels */
+    int qp_solver;        /* SQPBase's QPSolver argument: 0 boxADMM (box_admm.hpp, default), 1 ADMM (admm.hpp, OSQP form: (2n+m)-row KKT);
+                           * 1 is served by the LDS-resident kernels */
 } pmpc_sqp_settings;
 
 /* sqp_status_t (sqp_base.hpp:49-55) */

@@ -31,7 +31,7 @@ static sqp_settings to_sqp(const orc_sqp_settings* s) {
     q.tau = s->tau; q.eta = s->eta; q.rho = s->rho; q.eps_prim = s->eps_prim; q.eps_dual = s->eps_dual;
     q.max_iter = s->max_iter; q.line_search_max_iter = s->line_search_max_iter;
     q.regularisation = s->regularisation; q.exact_hessian_every_iter = s->exact_hessian_every_iter != 0;
-    q.preconditioner = s->preconditioner; q.hessian_update = s->hessian_update;
+    q.preconditioner = s->preconditioner; q.hessian_update = s->hessian_update; q.qp_solver = s->qp_solver;
     return q;
 }
 
@@ -74,7 +74,7 @@ void orc_sqp_default_settings(orc_sqp_settings* s) {
     sqp_settings q;
     s->tau = q.tau; s->eta = q.eta; s->rho = q.rho; s->eps_prim = q.eps_prim; s->eps_dual = q.eps_dual;
     s->max_iter = q.max_iter; s->line_search_max_iter = q.line_search_max_iter;
-    s->regularisation = 0; s->exact_hessian_every_iter = 0; s->preconditioner = 0; s->hessian_update = 0;
+    s->regularisation = 0; s->exact_hessian_every_iter = 0; s->preconditioner = 0; s->hessian_update = 0; s->qp_solver = 0;
 }
 
 void orc_cheb(int P, double* nodes, double* weights, double* D) {

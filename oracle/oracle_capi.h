@@ -29,6 +29,7 @@ typedef struct {
     int exact_hessian_every_iter;  /* 0 = damped BFGS (default) */
     int preconditioner;            /* 0 identity (default), 1 Ruiz equilibration */
     int hessian_update;            /* 0 dense damped BFGS (default), 1 block BFGS of ContinuousOCP */
+    int qp_solver;                 /* 0 boxADMM (default), 1 ADMM (OSQP form) */
 } orc_sqp_settings;
 
 typedef struct {

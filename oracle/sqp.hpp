@@ -19,6 +19,7 @@
 #include <vector>
 #include "qp.hpp"
 #include "ruiz.hpp"
+#include "admm.hpp"
 
 namespace oracle {
 
@@ -93,6 +94,7 @@ struct sqp_settings {  // sqp_base.hpp:24-47
     int regularisation = REG_NONE;          // hook of :277-306 (default no-op)
     bool exact_hessian_every_iter = false;  // override used by codegen_test.cpp:381-398 / minimal_time_test.cpp:126-133
     int preconditioner = 0;                 // SQPBase's Preconditioner template argument: 0 IdentityPreconditioner (default), 1 RuizEquilibration
+    int qp_solver = 0;                      // SQPBase's QPSolver template argument: 0 boxADMM (box_admm.hpp, default), 1 ADMM (admm.hpp, OSQP form)
     int hessian_update = 0;                 // hessian_update_impl: 0 damped BFGS on the whole matrix (bfgs.hpp, DENSE default), 1 the block BFGS of
                                             // ContinuousOCP (continuous_ocp.hpp:2304-2431), which keeps the Hessian block-diagonal per node
 };
@@ -111,13 +113,14 @@ struct SQP {
     sqp_settings settings;
     sqp_info info;
     BoxADMM qp;
+    ADMM qp_admm;   // used when settings.qp_solver == 1 (same settings and pivot policy as qp)
     // optional trace of every QP handed to the QP solver (used to build QP replay batches)
     bool record_qps = false;
     struct qp_record { std::vector<double> H, h, A, al, au, lx, ux; };
     std::vector<qp_record> qp_trace;
 
     SQP(Problem& prob, int nd)
-        : problem(prob), n(prob.VAR_SIZE), me(prob.NUM_EQ), mi(prob.NUM_INEQ), m(me + mi), qp(n, m) {
+        : problem(prob), n(prob.VAR_SIZE), me(prob.NUM_EQ), mi(prob.NUM_INEQ), m(me + mi), qp(n, m), qp_admm(n, m) {
         H.assign(n * n, 0); h.assign(n, 0); x.assign(n, 0); lam.assign(m + n, 0); lam_k.assign(m + n, 0);
         A.assign(m * n, 0); al.assign(m, 0); au.assign(m, 0); p_static.assign(nd > 0 ? nd : 1, 0);
         lbx.assign(n, -INF); ubx.assign(n, INF); lx.assign(n, 0); ux.assign(n, 0);
@@ -208,9 +211,16 @@ struct SQP {
         Ruiz ruiz(n, m);
         if (settings.preconditioner == 1) ruiz.compute(H.data(), h.data(), A.data(), al.data(), au.data(), lx.data(), ux.data());
         if (record_qps) qp_trace.push_back({H, h, A, al, au, lx, ux});
-        qp.solve(H.data(), h.data(), A.data(), al.data(), au.data(), lx.data(), ux.data());
-        info.qp_solver_iter += qp.info.iter;
-        p = qp.x; p_lambda = qp.y;
+        if (settings.qp_solver == 1) {   // Solver<Problem, ADMM<...>>: zero guesses as in the 7-argument form (admm.hpp:104-109)
+            qp_admm.settings = qp.settings; qp_admm.pivot = qp.pivot;
+            qp_admm.solve(H.data(), h.data(), A.data(), al.data(), au.data(), lx.data(), ux.data(), nullptr, nullptr);
+            info.qp_solver_iter += qp_admm.info.iter;
+            p = qp_admm.x; p_lambda = qp_admm.y;
+        } else {
+            qp.solve(H.data(), h.data(), A.data(), al.data(), au.data(), lx.data(), ux.data());
+            info.qp_solver_iter += qp.info.iter;
+            p = qp.x; p_lambda = qp.y;
+        }
         if (settings.preconditioner == 1) {
             ruiz.unscale(p.data(), p_lambda.data());
             ruiz.unscale(H.data(), h.data(), A.data(), al.data(), au.data(), lx.data(), ux.data());

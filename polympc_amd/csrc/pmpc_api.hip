@@ -214,7 +214,7 @@ void pmpc_qp_settings_sqp_default(pmpc_qp_settings* s) {
 }
 void pmpc_sqp_settings_default(pmpc_sqp_settings* s) {
     s->tau = 0.5; s->eta = 0.25; s->rho = 0.5; s->eps_prim = 1e-3; s->eps_dual = 1e-3; s->max_iter = 100;
-    s->line_search_max_iter = 100; s->regularisation = 0; s->exact_hessian_every_iter = 0; s->preconditioner = 0; s->hessian_update = 0;
+    s->line_search_max_iter = 100; s->regularisation = 0; s->exact_hessian_every_iter = 0; s->preconditioner = 0; s->hessian_update = 0; s->qp_solver = 0;
 }
 
 pmpc_status pmpc_chebyshev(int P, double* nodes, double* weights, double* D) {

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64, (NN > 0 ? PMPC_SQP_WAVES : 1)) void sqp_kernel(
     const int n = ocp.dm.n, m = ocp.dm.m, mi = ocp.dm.mi;
     QpLds qw; SqpLds v;
     // Kws != nullptr: large-instance mode — the KKT factor lives in an HBM workspace (does not fit LDS)
-    double* p = (NN > 0 || Kws) ? qw.carve_xy(smem, n, m) : qw.carve(smem, n, m);
+    double* p = (NN > 0 || Kws) ? qw.carve_xy(smem, n, m) : qw.carve(smem, n, ss.qp_solver == 1 ? m + n : m);   // ADMM: stacked constraint rows
     p = v.carve(p, n, m, mi);
     double* stage0 = p;
     p = ocp.s.carve(p, P, S);
@@ -85,8 +85,10 @@ __global__ __launch_bounds__(64, (NN > 0 ? PMPC_SQP_WAVES : 1)) void sqp_kernel(
     if constexpr (PROF) { if (phase_cycles && ln == 0) for (int i = 0; i < 24; ++i) atomicAdd(&phase_cycles[i], (unsigned long long)sqp.cyc[i]); }
 }
 // mode 0: KKT factor in LDS; 1: register-resident QP (n+m <= 64); 2: KKT factor in HBM (large instances)
-template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode) {
+template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode, int qp_solver = 0) {
     OcpDims<Model> dm(P, S);
+    if (mode == 0 && qp_solver == 1)
+        return (QpLds::doubles(dm.n, dm.m + dm.n) + SqpLds::doubles(dm.n, dm.m, dm.mi) + OcpLds<Model>::doubles(P, S) + 8) * sizeof(double);
     size_t stage = OcpLds<Model>::doubles(P, S);
     if (mode == 1) { const size_t need = (size_t)RegKkt<64>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
     return ((mode == 0 ? QpLds::doubles(dm.n, dm.m) : QpLds::doubles_xy(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8) * sizeof(double);
@@ -191,14 +193,15 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     double* Hws = ws; double* Aws = ws + (size_t)B * dm.n * dm.n;
     double* slice_state = Aws + (size_t)B * dm.m * dm.n;
     const int slice_iters = pmpc_internal_sqp_slice(ctx);
-    if (ss->hessian_update != 0 && ss->hessian_update != 1) return PMPC_ERR_INVALID_ARGUMENT;
-    if (!force_lds && ss->preconditioner == 0 && ss->hessian_update == 0) {   // node counts whose KKT system can fit 64 rows for small models (7 nodes: config A / D); Ruiz: LDS path
+    if ((ss->hessian_update != 0 && ss->hessian_update != 1) || (ss->qp_solver != 0 && ss->qp_solver != 1)) return PMPC_ERR_INVALID_ARGUMENT;
+    if (!force_lds && ss->preconditioner == 0 && ss->hessian_update == 0 && ss->qp_solver == 0) {   // node counts whose KKT system can fit 64 rows for small models (7 nodes: config A / D); Ruiz: LDS path
         pmpc_status rst = PMPC_OK;
         if (try_launch_reg<Model, 7>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;
         if (try_launch_reg<Model, 5>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;
     }
-    size_t lds = sqp_kernel_lds_bytes<Model>(P, S, 0);
+    size_t lds = sqp_kernel_lds_bytes<Model>(P, S, 0, ss->qp_solver);
     double* Kws = nullptr;
+    if (lds > lds_limit && ss->qp_solver == 1) return PMPC_ERR_UNSUPPORTED_SIZE;   // the stacked system lives in LDS only
     if (lds > lds_limit) {   // large instance: KKT factor in HBM, QP vectors over the AD staging
         lds = sqp_kernel_lds_bytes<Model>(P, S, 2);
         if (lds > lds_limit || !sqp_hbm_mode_fits<Model>(P, S)) return PMPC_ERR_UNSUPPORTED_SIZE;

@@ -14,6 +14,7 @@
 #include "pmpc_qp.hpp"
 #include "pmpc_qp_reg.hpp"
 #include "pmpc_ruiz.hpp"
+#include "pmpc_admm.hpp"
 
 namespace pmpc {
 
@@ -570,7 +571,11 @@ struct SqpDevice {
         }
         // 7-argument form: zero guesses (Q2)
         if constexpr (NN > 0) { boxadmm_solve_reg<NN, MM, true>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr); wsync(); }
-        else boxadmm_solve(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi);
+        else {
+            // Solver<Problem, ADMM<...>>: the launcher sized the QP's LDS for the stacked (2n+m)-row system when qp_solver = 1
+            if (RUIZ_COMPILED && __builtin_amdgcn_readfirstlane(ss.qp_solver) == 1) admm_solve(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi);
+            else boxadmm_solve(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi);
+        }
         qp_iter_total += qi.iter;
         if constexpr (RUIZ_COMPILED) if (ruiz) {   // unscale(p, p_lambda); unscale(m_H, m_h, m_A, ...), sqp_base.hpp:608-609 / :664-665
             ruiz_unscale_solution_wave(n, m, rz.D, rz.E, rz_c, qw.x, qw.y);

@@ -30,7 +30,7 @@ def test_header_symbols_are_exported(pa):
 def test_struct_layouts_match_header(pa):
     import ctypes as C
     assert C.sizeof(pa.QPSettings) == 72 and C.sizeof(pa.QPInfo) == 40
-    assert C.sizeof(pa.SQPSettings) == 64 and C.sizeof(pa.SQPInfo) == 48
+    assert C.sizeof(pa.SQPSettings) == 72 and C.sizeof(pa.SQPInfo) == 48
 
 
 def test_defaults_match_reference(pa):

@@ -346,7 +346,7 @@ def _sqp_both(ctx, oracle, wl, B, **kw):
         setattr(oss, k, v)
     n = wl["lbx"].shape[1]; dm = oracle.ocp_dims(wl["model"], wl["P"], wl["S"])
     # (preconditioner = 1 and hessian_update = 1 are served by the LDS-resident QP kernels whatever the size: static LDL^T order)
-    order = oracle.PIVOT_STATIC if (kw.get("preconditioner", 0) or kw.get("hessian_update", 0)) else _gpu_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1)
+    order = oracle.PIVOT_STATIC if (kw.get("preconditioner", 0) or kw.get("hessian_update", 0) or kw.get("qp_solver", 0)) else _gpu_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1)
     xo, lo, io = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"],
                                         sqp_settings=oss, pivot=order, threads=8)
     return (x, lam, info), (xo, lo, io)
@@ -474,6 +474,17 @@ def test_sqp_block_bfgs_vs_oracle(ctx, oracle):
     xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_PARKING, 5, 2, 0.0, 1.0, 1, [[1.0]], lbx, ubx, x_guess=xg, sqp_settings=oss, pivot=oracle.PIVOT_STATIC)
     assert info["iter"][0] == io[0].iter == 3 and info["qp_solver_iter"][0] == io[0].qp_solver_iter
     assert np.abs(x - xo).max() <= 1e-9 * max(1.0, np.abs(xo).max())
+
+
+def test_sqp_admm_qp_solver_vs_oracle(ctx, oracle):
+    """qp_solver = 1 (Solver<Problem, ADMM<...>>, the OSQP-form QP of admm.hpp inside the fused SQP kernel): identical SQP and ADMM
+    iteration counts and x within 1e-8 of the CPU restatement, on config A's grid (91-row stacked KKT) and on P=5, S=2 (143 rows)."""
+    from polympc_amd import workloads
+    for P, S, B in ((6, 1, 24), (5, 2, 6)):
+        (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, workloads.robot_batch(B, P=P, S=S), B, qp_solver=1)
+        same = (info["iter"] == np.array([i.iter for i in io])) & (info["qp_solver_iter"] == np.array([i.qp_solver_iter for i in io]))
+        assert same.mean() >= 0.95, (P, S, same.mean())
+        assert np.abs(x - xo)[same].max() <= 1e-8
 
 
 def test_sqp_cstr_config_B(ctx, oracle):

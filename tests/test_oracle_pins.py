@@ -433,6 +433,22 @@ def test_block_bfgs_keeps_the_hessian_block_diagonal(oracle):
     assert np.abs(x0 - x1).max() < 5e-2
 
 
+@pytest.mark.parametrize("pivot", [0, 1])
+def test_sqp_with_admm_qp_solver(oracle, pivot):
+    """Solver<Problem, ADMM<...>> (the admm_solver alias of mpc_wrapper_test.cpp:109-110): the OSQP-form QP solver inside the SQP
+    loop reaches the optimum boxADMM reaches, cold and warm-started (mpc_wrapper_test.cpp:120-166's assertions)."""
+    ss = oracle.sqp_default_settings(); ss.max_iter = 10; ss.line_search_max_iter = 10
+    lbx, ubx = _robot_bounds(16, [0.5, 0.5, 0.5])
+    kw = dict(pivot=pivot, mparams=[2.0])
+    xb, _, ib = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 3, 0.0, 2.0, 1, [[2.0]], lbx, ubx, sqp_settings=ss, **kw)
+    ss.qp_solver = 1
+    x, lam, i1 = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 3, 0.0, 2.0, 1, [[2.0]], lbx, ubx, sqp_settings=ss, **kw)
+    assert i1[0].status == oracle.SQP_SOLVED and np.abs(x - xb).max() < 5e-3
+    lbx2, ubx2 = _robot_bounds(16, [0.3, 0.4, 0.5])
+    x2, lam2, i2 = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 3, 0.0, 2.0, 1, [[2.0]], lbx2, ubx2, x_guess=x, lam_guess=lam, sqp_settings=ss, **kw)
+    assert i2[0].status == oracle.SQP_SOLVED and i2[0].iter < i1[0].iter
+
+
 def test_sqp_cstr(oracle):  # cstr_control_test.cpp:137-183 (Eigen pivot policy)
     ss = oracle.sqp_default_settings(); ss.max_iter = 20; ss.line_search_max_iter = 20
     n = 66

@@ -191,31 +191,60 @@ __device__ inline void kkt_factor(const QpLds& w, int N) {
         const int i0 = ln, i1 = ln + WAVE;
         const int d0 = (int)QpLds::kdoubles(N) + ln, d1 = d0 + QpLds::WAVE_DUMMY;   // dummy slots behind the packed triangle (indices, not
                                                                                     // pointers: see compiler hazard 7 in DESIGN.md)
+        const bool h0 = i0 < N, h1 = i1 < N;
         for (int k = 0; k < N; ++k) {
             const int ok = w.off(k);
             const double dk = K[ok + k];
-            const bool a0 = i0 > k && i0 < N, a1 = i1 > k && i1 < N;
+            const bool a0 = i0 > k && h0, a1 = i1 > k && h1;
             const int p0 = a0 ? ok + i0 : d0, p1 = a1 ? ok + i1 : d1;
             const double c0 = K[p0], c1 = K[p1];
-            K[p0] = c0 / dk;
-            K[p1] = c1 / dk;
-            wsync();
-            for (int j0 = k + 1; j0 < N; j0 += 4) {
-                double l[4], e0[4], e1[4];
-                int q0[4], q1[4];
+            const double s0 = c0 / dk, s1 = c1 / dk;   // scaled column entries: l_jk for row j lives in lane j (s0) / lane j-64 (s1)
+            K[p0] = s0;
+            K[p1] = s1;
+            // trailing update, columns j below 64: row lane + 64 is always in the column, row lane from j on; the multiplier l_jk
+            // comes out of the scaled registers with v_readlane (no LDS round trip through the column just written)
+            int oj = w.off(k + 1);
+            int j = k + 1;
+            for (; j + 3 < N && j + 3 < WAVE; j += 4) {
+                double l[4], e0[4], e1[4]; int q0[4], q1[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int j = j0 + u;
-                    const int jc = (j < N) ? j : N - 1;
-                    const int oj = w.off(jc);
-                    l[u] = K[ok + jc];
-                    q0[u] = (j < N && i0 >= j && i0 < N) ? oj + i0 : d0;
-                    q1[u] = (j < N && i1 >= j && i1 < N) ? oj + i1 : d1;
+                    l[u] = bcast_uniform(s0, j + u);
+                    q0[u] = (h0 && i0 >= j + u) ? oj + i0 : d0;
+                    q1[u] = h1 ? oj + i1 : d1;
+                    oj += N - 1 - (j + u);   // off(j+1) - off(j)
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { e0[u] = K[q0[u]]; e1[u] = K[q1[u]]; }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { K[q0[u]] = fma(-c0, l[u], e0[u]); K[q1[u]] = fma(-c1, l[u], e1[u]); }
+            }
+            for (; j < N && j < WAVE; ++j) {   // remainder of the columns below 64
+                const double l = bcast_uniform(s0, j);
+                const int q0 = (h0 && i0 >= j) ? oj + i0 : d0, q1 = h1 ? oj + i1 : d1;
+                const double e0 = K[q0], e1 = K[q1];
+                K[q0] = fma(-c0, l, e0); K[q1] = fma(-c1, l, e1);
+                oj += N - 1 - j;
+            }
+            for (; j + 3 < N; j += 4) {        // columns from 64 on: only row lane + 64 (from j on) is in them
+                double l[4], e1[4]; int q1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    l[u] = bcast_uniform(s1, j + u - WAVE);
+                    q1[u] = (h1 && i1 >= j + u) ? oj + i1 : d1;
+                    oj += N - 1 - (j + u);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) e1[u] = K[q1[u]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) K[q1[u]] = fma(-c1, l[u], e1[u]);
+            }
+            for (; j < N; ++j) {
+                const double l = bcast_uniform(s1, j - WAVE);
+                const int q1 = (h1 && i1 >= j) ? oj + i1 : d1;
+                const double e1 = K[q1];
+                K[q1] = fma(-c1, l, e1);
+                oj += N - 1 - j;
             }
             wsync();
         }

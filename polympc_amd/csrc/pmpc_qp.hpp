@@ -283,14 +283,17 @@ __device__ inline void kkt_solve(const QpLds& w, int N, double* v) {
         const int r0 = h0 ? i0 : 0, r1 = h1 ? i1 : 0;   // clamped row indices for the loads
         double c0 = h0 ? v[i0] : 0.0, c1 = h1 ? v[i1] : 0.0;
         const int nA = (N - 1 < WAVE) ? N - 1 : WAVE;   // forward steps whose pivot lives in c0: j in [0, nA)
+        int oc = 0;   // off(j) of the column being loaded, advanced incrementally: off(j+1) - off(j) = N - 1 - j
         for (int j0 = 0; j0 < nA; j0 += 8) {
             double f0[8], f1[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int j = (j0 + u < nA) ? j0 + u : nA - 1;
-                const int o = w.off(j);
+                const bool in = j0 + u < nA;
+                const int j = in ? j0 + u : nA - 1;
+                const int o = in ? oc : w.off(nA - 1);
                 f0[u] = K[o + (r0 > j ? r0 : j)];
                 f1[u] = K[o + (r1 > j ? r1 : j)];
+                if (in) oc += N - 1 - j;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -301,12 +304,15 @@ __device__ inline void kkt_solve(const QpLds& w, int N, double* v) {
                 c1 = (j < nA && h1) ? t1 : c1;
             }
         }
-        for (int j0 = WAVE; j0 < N - 1; j0 += 8) {      // pivots in c1; only the rows above 64 are still below them
+        for (int j0 = WAVE; j0 < N - 1; j0 += 8) {      // pivots in c1; only the rows above 64 are still below them (oc = off(64) here)
             double f1[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int j = (j0 + u < N - 1) ? j0 + u : N - 2;
-                f1[u] = K[w.off(j) + (r1 > j ? r1 : j)];
+                const bool in = j0 + u < N - 1;
+                const int j = in ? j0 + u : N - 2;
+                const int o = in ? oc : w.off(N - 2);
+                f1[u] = K[o + (r1 > j ? r1 : j)];
+                if (in) oc += N - 1 - j;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {

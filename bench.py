@@ -72,12 +72,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: polympc_amd has no CPU fallback")
+    # developer switches for exercising the N > 1 code path on a box with ONE GPU (every rank on device 0, gloo for the barrier and
+    # the two reductions); the driver's multi-GPU runs use neither: one rank per GPU, nccl (= RCCL)
+    backend = os.environ.get("PMPC_BENCH_BACKEND", "nccl")
+    if os.environ.get("PMPC_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")   # where the statistics tensors of the reductions live
 
     B = args.batch
     wl = workloads.robot_batch(B, first=sharding.shard_first_instance(rank, B))   # each rank owns a contiguous shard of the instance stream
@@ -128,7 +137,7 @@ def main():
     qp_solves = int(info["iter"].sum())
     admm_iters = int(info["qp_solver_iter"].sum())
     solved = int((info["status"] == pa.SQP_SOLVED).sum())
-    (qp_all, admm_all, solved_all), elapsed = sharding.combine_stats(dist, dev, [qp_solves, admm_iters, solved], elapsed)
+    (qp_all, admm_all, solved_all), elapsed = sharding.combine_stats(dist, red_dev, [qp_solves, admm_iters, solved], elapsed)
 
     if rank == 0:
         value = qp_all * args.steps / elapsed

@@ -97,7 +97,8 @@ typedef enum {
     PMPC_MODEL_CSTR = 1,         /* tests/control/cstr_control_test.cpp:30-113 NX=4 NU=2 */
     PMPC_MODEL_PARKING = 2,      /* tests/control/dense_sparse_compare.cpp:22-55 NX=3 NU=2 NP=1 ND=1 */
     PMPC_MODEL_ROBOT_NG = 3,     /* robot + path constraint g = x0^2+x1^2 (NG=1) */
-    PMPC_MODEL_KITE_STANDIN = 4  /* SYNTHETIC 13-state/3-input dimension stand-in (kiteNMPF.h is not in the reference) */
+    PMPC_MODEL_KITE_STANDIN = 4, /* SYNTHETIC 13-state/3-input dimension stand-in (kiteNMPF.h is not in the reference) */
+    PMPC_MODEL_PARKING_NG = 5    /* tests/control/nonlinear_constraints_test.cpp:31-75  parking + g = u0^2 cos(u1): NP=1, NG=1 */
 } pmpc_model;
 
 /* ------------------------------------------------------------------------------------------------------------ */

@@ -15,7 +15,13 @@ LIB_PATH = os.path.join(HERE, "liboracle.so")
 REF_PATH = os.path.join(HERE, "_ref", "libref_casadi_robot.so")
 
 PIVOT_EIGEN, PIVOT_STATIC, PIVOT_SWEEP = 0, 1, 2
-MODEL_ROBOT, MODEL_CSTR, MODEL_PARKING, MODEL_ROBOT_NG, MODEL_KITE_STANDIN = 0, 1, 2, 3, 4
+
+
+def _check_sweep(pivot, rows):
+    """PIVOT_SWEEP restates the register-resident kernel, which exists for KKT systems of at most 64 rows."""
+    if pivot == PIVOT_SWEEP and rows > 64:
+        raise ValueError(f"PIVOT_SWEEP supports at most 64 KKT rows (got {rows}); use PIVOT_STATIC or PIVOT_EIGEN")
+MODEL_ROBOT, MODEL_CSTR, MODEL_PARKING, MODEL_ROBOT_NG, MODEL_KITE_STANDIN, MODEL_PARKING_NG = 0, 1, 2, 3, 4, 5
 NLP_CONSTRAINED_ROSENBROCK, NLP_ROSENBROCK, NLP_SIMPLE, NLP_HS071 = 0, 1, 2, 3
 QP_SOLVED, QP_MAX_ITER_EXCEEDED, QP_UNSOLVED = 0, 1, 2
 SQP_SOLVED, SQP_MAX_ITER_EXCEEDED = 0, 1
@@ -110,6 +116,7 @@ def regularise(kind, H):
 
 def ldlt_solve(K, b, pivot=PIVOT_EIGEN):
     n = len(b)
+    _check_sweep(pivot, n)
     Kc = np.ascontiguousarray(np.asarray(K, dtype=np.float64).T).ravel().copy()
     x = np.zeros(n)
     lib().orc_ldlt_solve(n, _p(Kc), _p(_f(b)), pivot, _p(x))
@@ -121,6 +128,7 @@ def qp_solve_batch(H, h, A, Alb, Aub, xlb, xub, settings=None, pivot=PIVOT_EIGEN
     H = _f(H); h = _f(h); A = _f(A); Alb = _f(Alb); Aub = _f(Aub); xlb = _f(xlb); xub = _f(xub)
     B, n = h.shape
     m = Alb.shape[1] if Alb.ndim == 2 else 0
+    _check_sweep(pivot, n + m)
     s = settings or qp_default_settings()
     x = np.zeros((B, n)); y = np.zeros((B, n + m)); info = (QPInfo * B)()
     lib().orc_qp_solve_batch(B, n, m, _p(H), _p(h), _p(A), _p(Alb), _p(Aub), _p(xlb), _p(xub), _p(_f(x0)), _p(_f(y0)),
@@ -133,6 +141,7 @@ def qp_admm_solve_batch(H, h, A, Alb, Aub, xlb, xub, settings=None, pivot=PIVOT_
     H = _f(H); h = _f(h); A = _f(A); Alb = _f(Alb); Aub = _f(Aub); xlb = _f(xlb); xub = _f(xub)
     B, n = h.shape
     m = Alb.shape[1] if Alb.ndim == 2 else 0
+    _check_sweep(pivot, 2 * n + m)
     s = settings or qp_default_settings()
     x = np.zeros((B, n)); y = np.zeros((B, n + m)); info = (QPInfo * B)()
     lib().orc_qp_admm_solve_batch(B, n, m, _p(H), _p(h), _p(A), _p(Alb), _p(Aub), _p(xlb), _p(xub), _p(_f(x0)), _p(_f(y0)),
@@ -197,6 +206,7 @@ def sqp_solve_batch(model, P, S, t0, tf, B, d, lbx, ubx, lbg=None, ubg=None, x_g
                     sqp_settings=None, qp_settings=None, pivot=PIVOT_EIGEN, mparams=None, threads=1):
     dm = ocp_dims(model, P, S)
     n, m = dm["n"], dm["m"]
+    _check_sweep(pivot, n + m)
     ss = sqp_settings or sqp_default_settings(); qs = qp_settings or sqp_qp_default_settings()
     x = np.zeros((B, n)); lam = np.zeros((B, m + n)); info = (SQPInfo * B)()
     mp = _f(mparams) if mparams is not None else None
@@ -213,6 +223,7 @@ def sqp_trace_qps(model, P, S, t0, tf, d, lbx, ubx, lbg=None, ubg=None, x_guess=
                   sqp_settings=None, qp_settings=None, pivot=PIVOT_EIGEN, mparams=None, max_qps=32):
     dm = ocp_dims(model, P, S)
     n, m = dm["n"], dm["m"]
+    _check_sweep(pivot, n + m)
     ss = sqp_settings or sqp_default_settings(); qs = qp_settings or sqp_qp_default_settings()
     H = np.zeros((max_qps, n * n)); h = np.zeros((max_qps, n)); A = np.zeros((max_qps, m * n))
     al = np.zeros((max_qps, m)); au = np.zeros((max_qps, m)); lx = np.zeros((max_qps, n)); ux = np.zeros((max_qps, n))

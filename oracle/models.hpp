@@ -107,6 +107,16 @@ struct RobotNGOCP : RobotOCP {
     }
 };
 
+// Parking OCP with a free time-scaling parameter AND a nonlinear path constraint g = u0^2 cos(u1):
+// /root/reference/tests/control/nonlinear_constraints_test.cpp:31-75 (NX=3 NU=2 NP=1 ND=1 NG=1) — NP > 0 and NG > 0 together.
+struct ParkingNGOCP : ParkingOCP {
+    enum { NX = 3, NU = 2, NP = 1, ND = 1, NG = 1 };
+    template <class T> void inequality(const T*, const T* u, const T*, const double*, double, T* g) const {
+        using std::cos;
+        g[0] = u[0] * u[0] * cos(u[1]);
+    }
+};
+
 // "Kite stand-in": SYNTHETIC smooth 13-state / 3-input dynamics (the reference's KiteDynamics / kiteNMPF.h is
 // not in /root/reference — SURVEY.md fact 4); a dimension stand-in for config C, not a parity target of the
 // reference's physics. Chain of coupled pendulum-like terms with fixed coefficients.

@@ -58,6 +58,7 @@ template <> RobotNGOCP make_model<RobotNGOCP>(const double* mp, int nmp) {
         case ORC_MODEL_PARKING: F<ParkingOCP>(__VA_ARGS__); break;      \
         case ORC_MODEL_ROBOT_NG: F<RobotNGOCP>(__VA_ARGS__); break;     \
         case ORC_MODEL_KITE_STANDIN: F<KiteStandInOCP>(__VA_ARGS__); break; \
+        case ORC_MODEL_PARKING_NG: F<ParkingNGOCP>(__VA_ARGS__); break;    \
         default: break;                                                 \
     }
 

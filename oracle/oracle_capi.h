@@ -37,7 +37,7 @@ typedef struct {
     double primal_norm, dual_norm, max_violation, cost;
 } orc_sqp_info;
 
-enum { ORC_MODEL_ROBOT = 0, ORC_MODEL_CSTR = 1, ORC_MODEL_PARKING = 2, ORC_MODEL_ROBOT_NG = 3, ORC_MODEL_KITE_STANDIN = 4 };
+enum { ORC_MODEL_ROBOT = 0, ORC_MODEL_CSTR = 1, ORC_MODEL_PARKING = 2, ORC_MODEL_ROBOT_NG = 3, ORC_MODEL_KITE_STANDIN = 4, ORC_MODEL_PARKING_NG = 5 };
 enum { ORC_NLP_CONSTRAINED_ROSENBROCK = 0, ORC_NLP_ROSENBROCK = 1, ORC_NLP_SIMPLE = 2, ORC_NLP_HS071 = 3 };
 
 void orc_qp_default_settings(orc_qp_settings* s);       /* qp_base.hpp:17-53 defaults */

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <stdexcept>
 #include <vector>
 
 namespace oracle {
@@ -61,7 +62,10 @@ struct LDLT {
     void compute(const std::vector<double>& K, int n_, pivot_policy pol) {
         n = n_; policy = pol; M = K; tr.assign(n, 0); temp.assign(n, 0.0);
         if (policy == PIVOT_STATIC) { compute_static(); return; }
-        if (policy == PIVOT_SWEEP) { compute_sweep(); return; }
+        if (policy == PIVOT_SWEEP) {   // mirrors the register-resident kernel, which exists for at most 64 KKT rows (4 column blocks of 16)
+            if (n > 64) throw std::invalid_argument("oracle: PIVOT_SWEEP restates the 64-row register kernel; use PIVOT_STATIC / PIVOT_EIGEN for larger systems");
+            compute_sweep(); return;
+        }
         auto at = [&](int i, int j) -> double& { return M[i + j * n]; };
         for (int k = 0; k < n; ++k) {
             // largest remaining |diagonal| (first occurrence)

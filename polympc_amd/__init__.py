@@ -9,6 +9,6 @@ loudly when the HIP library is missing, and context creation fails when no GPU i
 from .capi import (  # noqa: F401
     LIB_PATH, Context, QPSettings, QPInfo, SQPSettings, SQPInfo, build_library, chebyshev, lib, ocp_dims,
     qp_settings_default, qp_settings_sqp_default, sqp_settings_default,
-    MODEL_ROBOT, MODEL_CSTR, MODEL_PARKING, MODEL_ROBOT_NG, MODEL_KITE_STANDIN,
+    MODEL_ROBOT, MODEL_CSTR, MODEL_PARKING, MODEL_ROBOT_NG, MODEL_KITE_STANDIN, MODEL_PARKING_NG,
     QP_SOLVED, QP_MAX_ITER_EXCEEDED, SQP_SOLVED, SQP_MAX_ITER_EXCEEDED, EXPORTED_SYMBOLS,
 )

@@ -388,6 +388,7 @@ pmpc_status pmpc_qp_ruiz_unscale_batch(pmpc_context* ctx, int B, int n, int m, c
         case PMPC_MODEL_PARKING: return F<ParkingOCP>(__VA_ARGS__);              \
         case PMPC_MODEL_ROBOT_NG: return F<RobotNGOCP>(__VA_ARGS__);             \
         case PMPC_MODEL_KITE_STANDIN: return F<KiteStandInOCP>(__VA_ARGS__);     \
+        case PMPC_MODEL_PARKING_NG: return F<ParkingNGOCP>(__VA_ARGS__);         \
         default: return PMPC_ERR_UNKNOWN_MODEL;                                  \
     }
 

@@ -129,6 +129,16 @@ struct RobotNGOCP : RobotOCP {
     }
 };
 
+// Parking with a free time-scaling parameter and the nonlinear path constraint g = u0^2 cos(u1):
+// tests/control/nonlinear_constraints_test.cpp:31-75 (NP = 1 and NG = 1 together)
+struct ParkingNGOCP : ParkingOCP {
+    enum { NX = 3, NU = 2, NP = 1, ND = 1, NG = 1 };
+    template <class T>
+    __device__ void inequality_constraints_impl(cref<T>, cref<T> u, cref<T>, cref<double>, double, vref<T> g) const {
+        g(0) = u(0) * u(0) * cos(u(1));
+    }
+};
+
 // SYNTHETIC 13-state / 3-input smooth dynamics: dimension stand-in for the kite NMPC config (the reference's
 // KiteDynamics / kiteNMPF.h is not in the reference tree). Not a model of anything.
 struct KiteStandInOCP {

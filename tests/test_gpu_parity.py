@@ -433,6 +433,38 @@ def test_sqp_minimal_time_valet_parking(ctx, oracle):
     assert info["iter"][0] == io[0].iter and np.abs(x - xo).max() <= 1e-7
 
 
+@pytest.mark.parametrize("P,S,ubg,qp_max", [(5, 2, 10.0, 100), (5, 2, 10.0, 300), (5, 2, 1.2, 100), (6, 1, 10.0, 300), (6, 1, 1.2, 100)])
+def test_sqp_parking_nonlinear_path_constraint(ctx, oracle, P, S, ubg, qp_max):
+    """nonlinear_constraints_test.cpp:159-184 through the GPU path (NP = 1 and NG = 1 together, exact linearisation every iteration
+    + Gershgorin): the reference's grid (P=5, S=2: 100 KKT rows, LDS path, static-order CPU restatement) with the reference's bound
+    (inactive) and a binding one, and a 7-node grid whose KKT system has exactly 64 rows — the largest the register-resident path
+    takes (CPU restatement in the kernel's sweep order). Same outcome, same SQP and QP iteration counts, minimal time within 1e-8, x within 1e-5
+    (the steering-angle profile of this minimal-time problem is nearly flat in the cost and most QPs stop at their iteration cap, so
+    last-bit sin/cos differences are carried un-damped through up to 20 iterations; observed up to 1.8e-6)."""
+    import polympc_amd as pa
+    from test_oracle_pins import _minimal_time_parking
+    nn = P * S + 1
+    lbx, ubx, xg = _minimal_time_parking(nn)
+    lbg = np.full((1, nn), -10.0); ubgv = np.full((1, nn), ubg)
+    ss = pa.sqp_settings_default(); oss = oracle.sqp_default_settings()
+    for st in (ss, oss):
+        st.max_iter = 20; st.line_search_max_iter = 10; st.regularisation = 2; st.exact_hessian_every_iter = 1
+    qs = pa.qp_settings_sqp_default(); qs.max_iter = qp_max
+    oqs = oracle.sqp_qp_default_settings(); oqs.max_iter = qp_max
+    x, lam, info = ctx.sqp_solve_batch(pa.MODEL_PARKING_NG, P, S, 0.0, 1.0, 1, [[1.0]], lbx, ubx, lbg=lbg, ubg=ubgv, x_guess=xg,
+                                       sqp_settings=ss, qp_settings=qs)
+    pivot = oracle.PIVOT_SWEEP if nn == 7 else oracle.PIVOT_STATIC
+    xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_PARKING_NG, P, S, 0.0, 1.0, 1, [[1.0]], lbx, ubx, lbg=lbg, ubg=ubgv, x_guess=xg,
+                                        sqp_settings=oss, qp_settings=oqs, pivot=pivot)
+    assert info["status"][0] == io[0].status and info["iter"][0] == io[0].iter and info["qp_solver_iter"][0] == io[0].qp_solver_iter
+    assert abs(x[0, 5 * nn] - xo[0, 5 * nn]) <= 1e-8 and np.abs(x - xo).max() <= 1e-5
+    assert np.abs(lam - lo).max() <= 1e-4 * max(1.0, np.abs(lo).max())
+    if not (ubg == 10.0 and qp_max == 100):
+        assert info["status"][0] == pa.SQP_SOLVED
+    u = x[0, 3 * nn:5 * nn].reshape(nn, 2)
+    assert (u[:, 0] ** 2 * np.cos(u[:, 1])).max() <= ubg + 1e-3
+
+
 def test_sqp_valet_parking_with_ruiz(ctx, oracle):
     """valet_parking_mpc_test.cpp:183-240 through the GPU path (Ruiz preconditioner, QP max_iter 1000, cold + warm-started
     solve, l1 / dense-BFGS variant — see tests/test_oracle_pins.py): both solves SOLVED in < 10 iterations as the reference

@@ -357,11 +357,11 @@ def test_sqp_robot_mpc_warm_start(oracle, pivot):  # mpc_wrapper_test.cpp:120-16
     assert np.all(x2[0, 48:] <= np.tile([1.5, 0.75], 16) + 1e-3) and np.all(x2[0, 48:] >= -np.tile([1.5, 0.75], 16) - 1e-3)
 
 
-def _minimal_time_parking():
-    """minimal_time_test.cpp:146-184: parking OCP with a free time-scaling parameter (NP = 1), P=5 S=2, d = 1, x0 = (1.5, .5, .5)
-    pinned on the last node, final state within +-0.05 (first nx entries, mpc_wrapper.hpp:132-137), p in [0, 10], guesses
-    p = 0.5 and x = x0 at every node."""
-    nn = 11; n = 5 * nn + 1
+def _minimal_time_parking(nn=11):
+    """minimal_time_test.cpp:146-184: parking OCP with a free time-scaling parameter (NP = 1), P=5 S=2 (nn = 11 nodes), d = 1,
+    x0 = (1.5, .5, .5) pinned on the last node, final state within +-0.05 (first nx entries, mpc_wrapper.hpp:132-137), p in [0, 10],
+    guesses p = 0.5 and x = x0 at every node."""
+    n = 5 * nn + 1
     lbx = np.full(n, -inf); ubx = np.full(n, inf)
     lbx[3 * nn:5 * nn] = np.tile([-1.5, -0.75], nn); ubx[3 * nn:5 * nn] = np.tile([1.5, 0.75], nn)
     lbx[5 * nn] = 0.0; ubx[5 * nn] = 10.0
@@ -379,6 +379,61 @@ def test_sqp_minimal_time_valet_parking(oracle, pivot):  # minimal_time_test.cpp
     x, lam, info = oracle.sqp_solve_batch(oracle.MODEL_PARKING, 5, 2, 0.0, 1.0, 1, [[1.0]], lbx, ubx, x_guess=xg, sqp_settings=ss, pivot=pivot)
     assert info[0].status == oracle.SQP_SOLVED and info[0].iter < 20          # the reference's two assertions (:186-187)
     assert 0.0 < x[0, 55] < 10.0 and np.abs(x[0, 0:3]).max() <= 0.05 + 1e-3   # a time inside its bounds, parked within tolerance
+
+
+def _ng_settings(st):
+    st.max_iter = 20; st.line_search_max_iter = 10; st.regularisation = 2; st.exact_hessian_every_iter = 1
+    return st
+
+
+def _parking_ng(oracle, ubg, pivot, qp_max_iter=100, max_iter=20):
+    lbx, ubx, xg = _minimal_time_parking()
+    nn = 11
+    ss = _ng_settings(oracle.sqp_default_settings()); ss.max_iter = max_iter
+    qs = oracle.sqp_qp_default_settings(); qs.max_iter = qp_max_iter
+    x, lam, info = oracle.sqp_solve_batch(oracle.MODEL_PARKING_NG, 5, 2, 0.0, 1.0, 1, [[1.0]], lbx, ubx, lbg=np.full((1, nn), -10.0),
+                                          ubg=np.full((1, nn), ubg), x_guess=xg, sqp_settings=ss, qp_settings=qs, pivot=pivot)
+    u = x[0, 33:55].reshape(nn, 2)
+    return x[0], lam[0], info[0], u[:, 0] ** 2 * np.cos(u[:, 1])
+
+
+@pytest.mark.parametrize("pivot", [0, 1])
+def test_sqp_parking_with_nonlinear_path_constraint(oracle, pivot):
+    """nonlinear_constraints_test.cpp:159-184 — the minimal-time parking problem with g = u0^2 cos(u1) in [-10, 10] at every node
+    (NP = 1 and NG = 1 together; exact linearisation every iteration + Gershgorin, :97-145). The reference program only prints
+    its result and asserts nothing. With |u0| <= 1.5 the constraint can never bind (g <= 2.25), so the optimum is that of
+    minimal_time_test.cpp. What this restatement does with the reference's settings (SQP 20 iterations, QP 100): every QP stops at
+    its iteration cap, after 20 iterations the iterate sits within 0.1 % of the minimal time and 2e-3 of feasibility, and the SQP
+    termination test is not met; with a QP budget of 300 the same solve is SOLVED in < 20 iterations. Both are recorded."""
+    lbx, ubx, xg = _minimal_time_parking()
+    ss = _ng_settings(oracle.sqp_default_settings())
+    x0, _, i0 = oracle.sqp_solve_batch(oracle.MODEL_PARKING, 5, 2, 0.0, 1.0, 1, [[1.0]], lbx, ubx, x_guess=xg, sqp_settings=ss, pivot=pivot)
+    x, lam, info, g = _parking_ng(oracle, 10.0, pivot)
+    assert info.iter == 20 and info.qp_solver_iter == 20 * 101 and info.status == oracle.SQP_MAX_ITER_EXCEEDED
+    assert abs(x[55] - x0[0, 55]) <= 1e-3 * x0[0, 55] and np.abs(x[0:3]).max() <= 0.05 + 2e-3 and g.max() <= 2.25 + 1e-9
+    x, lam, info, g = _parking_ng(oracle, 10.0, pivot, qp_max_iter=300)
+    assert info.status == oracle.SQP_SOLVED and info.iter < 20
+    assert abs(x[55] - x0[0, 55]) <= 1e-3 * x0[0, 55]
+    assert np.abs(lam[33:44]).max() <= 1e-6                              # rows 33..43 are g: inactive, no multiplier
+
+
+@pytest.mark.parametrize("pivot", [0, 1])
+def test_sqp_parking_active_nonlinear_path_constraint(oracle, pivot):
+    """The same problem with the bound tightened until it binds (u0^2 cos(u1) <= 1.2; the free optimum reaches 2.19): SOLVED with
+    the reference's settings, g at the bound on the nodes, non-zero multipliers on the g rows, and a longer manoeuvre."""
+    free, _, _, gfree = _parking_ng(oracle, 10.0, pivot, qp_max_iter=300)
+    x, lam, info, g = _parking_ng(oracle, 1.2, pivot)
+    assert gfree.max() > 2.0
+    assert info.status == oracle.SQP_SOLVED and info.iter < 20
+    assert g.max() <= 1.2 + 1e-3 and g.max() >= 1.2 - 1e-3
+    assert x[55] > 1.2 * free[55] and np.abs(lam[33:44]).max() > 1e-2
+
+
+def test_sweep_policy_rejects_systems_over_64_rows(oracle):
+    """PIVOT_SWEEP restates the register-resident kernel (at most 64 KKT rows); larger systems must be refused, not mis-solved."""
+    lbx, ubx, xg = _minimal_time_parking()
+    with pytest.raises(ValueError):
+        oracle.sqp_solve_batch(oracle.MODEL_PARKING, 5, 2, 0.0, 1.0, 1, [[1.0]], lbx, ubx, x_guess=xg, pivot=oracle.PIVOT_SWEEP)
 
 
 def _valet_bounds(x0):

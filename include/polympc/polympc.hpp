@@ -30,6 +30,7 @@
 #include <cstddef>
 #include <limits>
 #include <string>
+#include <utility>
 #include <vector>
 #include "../polympc_amd.h"
 
@@ -158,6 +159,44 @@ struct sqp_settings_t {   // sqp_base.hpp:24-47 (+ the two override points as fl
     int preconditioner = 0;            // SQPBase's Preconditioner template argument: 0 IdentityPreconditioner, 1 RuizEquilibration
     int hessian_update = 0;            // hessian_update_impl: 0 dense damped BFGS, 1 ContinuousOCP's block BFGS
     int qp_solver = 0;                 // QPSolver template argument: 0 boxADMM, 1 ADMM (OSQP form)
+    int line_search = 0;               // step_size_selection_impl: 0 l1-merit backtracking (sqp_base.hpp:380-419), 1 the filter line search
+                                       // of valet_parking_mpc_test.cpp:116-158 on LSFilter (line_search.hpp:31-98)
+};
+
+// LSFilter's tunables under the reference's member names (`solver.filter.beta = 0.1`, valet_parking_mpc_test.cpp:192); the list itself
+// lives in HBM, one per solver object of the batch, and is carried from one solve() to the next as the reference's member is.
+struct LSFilterHandle {
+    int max_depth = PMPC_FILTER_MAX_DEPTH;
+    double beta = 1e-5;
+    LSFilterHandle() = default;
+    LSFilterHandle(const LSFilterHandle& o) : max_depth(o.max_depth), beta(o.beta) {}   // a copied solver starts with empty filters
+    LSFilterHandle& operator=(const LSFilterHandle& o) { max_depth = o.max_depth; beta = o.beta; return *this; }
+    ~LSFilterHandle() { if (m_dev) pmpc_filter_state_destroy(m_ctx, m_dev); }
+    void clear() noexcept { if (m_dev) pmpc_filter_state_clear(m_ctx, m_B, m_dev); }    // LSFilter::clear(), line_search.hpp:52
+    // number of pairs and the pairs (cost, violation), newest first, of instance b (downloaded on demand)
+    std::vector<std::pair<double, double>> entries(int b) const {
+        std::vector<std::pair<double, double>> out;
+        if (!m_dev || b < 0 || b >= m_B) return out;
+        std::vector<double> st((size_t)m_B * PMPC_FILTER_STATE_DOUBLES);
+        if (pmpc_filter_state_download(m_ctx, m_B, m_dev, st.data()) != PMPC_OK) return out;
+        const double* f = &st[(size_t)b * PMPC_FILTER_STATE_DOUBLES];
+        for (int i = 0; i < (int)f[0]; ++i) out.emplace_back(f[1 + 2 * i], f[2 + 2 * i]);
+        return out;
+    }
+    // fills the C settings; allocates the device list on first use
+    pmpc_status bind(pmpc_context* ctx, int B, int line_search, pmpc_sqp_settings& ss) noexcept {
+        ss.line_search = line_search; ss.filter_max_depth = max_depth; ss.filter_beta = beta; ss.filter_state = nullptr;
+        if (line_search != 1) return PMPC_OK;
+        if (!m_dev) {
+            const pmpc_status st = pmpc_filter_state_create(ctx, B, &m_dev);
+            if (st != PMPC_OK) return st;
+            m_ctx = ctx; m_B = B;
+        }
+        ss.filter_state = m_dev;
+        return PMPC_OK;
+    }
+private:
+    double* m_dev = nullptr; pmpc_context* m_ctx = nullptr; int m_B = 0;
 };
 using qp_solver_settings_t = pmpc_qp_settings;   // same member names as qp_base.hpp:17-53 (ADMM subset)
 
@@ -198,6 +237,7 @@ public:
         ss.eps_dual = m_settings.eps_dual; ss.max_iter = m_settings.max_iter; ss.line_search_max_iter = m_settings.line_search_max_iter;
         ss.regularisation = m_settings.regularisation; ss.exact_hessian_every_iter = m_settings.exact_hessian_every_iter ? 1 : 0;
         ss.preconditioner = m_settings.preconditioner; ss.hessian_update = m_settings.hessian_update; ss.qp_solver = m_settings.qp_solver;
+        { const pmpc_status fs = filter.bind(ctx, B, m_settings.line_search, ss); if (fs != PMPC_OK) return last_error() = fs; }
         std::vector<double> xo(m_x.size()), lo(m_lam.size());
         const pmpc_status st = device_binding<OCP>::solve(ctx, problem, OCP::POLY_ORDER, OCP::NUM_SEGMENTS, problem.t_start, problem.t_stop, B,
                                                           m_x.data(), m_lam.data(), m_p.data(), m_lbx.data(), m_ubx.data(),
@@ -214,6 +254,7 @@ public:
     std::vector<pmpc_sqp_info> m_info;
     sqp_settings_t m_settings;
     qp_solver_settings_t m_qp_settings;
+    LSFilterHandle filter;   // `MySolver::filter` of valet_parking_mpc_test.cpp:114 for every instance (used when settings().line_search == 1)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -282,6 +323,8 @@ public:
     double m_primal_norm = 0, m_dual_norm = 0, m_max_violation = 0, m_cost = 0;
 private:
     BatchSolver<OCP> m_batch;
+public:
+    LSFilterHandle& filter = m_batch.filter;   // `solver.filter.beta = 0.1`, valet_parking_mpc_test.cpp:192 (settings().line_search = 1)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -495,6 +538,7 @@ public:
         ss.max_iter = m_settings.max_iter; ss.line_search_max_iter = m_settings.line_search_max_iter; ss.regularisation = m_settings.regularisation;
         ss.exact_hessian_every_iter = m_settings.exact_hessian_every_iter ? 1 : 0; ss.preconditioner = m_settings.preconditioner;
         ss.hessian_update = m_settings.hessian_update; ss.qp_solver = m_settings.qp_solver;
+        { const pmpc_status fs = filter.bind(ctx, B, m_settings.line_search, ss); if (fs != PMPC_OK) return last_error() = fs; }
         return last_error() = pmpc_mpc_batch_step(m_batch, x0, &ss, &m_qp_settings, u0, m_info.data());
     }
     const pmpc_sqp_info& info(int b) const noexcept { return m_info[b]; }
@@ -512,6 +556,8 @@ private:
     std::vector<pmpc_sqp_info> m_info;
     sqp_settings_t m_settings; qp_solver_settings_t m_qp_settings;
     pmpc_mpc_batch* m_batch{nullptr};
+public:
+    LSFilterHandle filter;   // the solvers' LSFilter members (used when settings().line_search == 1)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -79,7 +79,18 @@ typedef struct {
                            * MPC tests plug in (mpc_wrapper_test.cpp:100-105); served by the LDS-resident QP kernels */
     int qp_solver;        /* SQPBase's QPSolver argument: 0 boxADMM (box_admm.hpp, default), 1 ADMM (admm.hpp, OSQP form: (2n+m)-row KKT);
                            * 1 is served by the LDS-resident kernels */
+    int line_search;      /* SQPBase::step_size_selection_impl: 0 l1-merit backtracking (sqp_base.hpp:380-419, default), 1 the filter line
+                           * search on LSFilter (src/solvers/line_search.hpp:31-98) that valet_parking_mpc_test.cpp:116-158 plugs in;
+                           * 1 is served by the LDS-resident kernels */
+    int filter_max_depth; /* LSFilter::max_depth (line_search.hpp:38; default 10 = PMPC_FILTER_MAX_DEPTH, the largest accepted) */
+    double filter_beta;   /* LSFilter::beta (line_search.hpp:39; default 1e-5) */
+    double* filter_state; /* the solver member `filter`, which outlives solve(): NULL (default) = every call starts from an empty filter;
+                           * else a DEVICE buffer of B x PMPC_FILTER_STATE_DOUBLES, read when the solve starts and written back when it
+                           * ends — per instance [count, cost_0, violation_0, cost_1, violation_1, ...], newest pair first
+                           * (pmpc_filter_state_create / _clear / _destroy manage one for hosts without device pointers) */
 } pmpc_sqp_settings;
+#define PMPC_FILTER_MAX_DEPTH 10
+#define PMPC_FILTER_STATE_DOUBLES (1 + 2 * PMPC_FILTER_MAX_DEPTH)
 
 /* sqp_status_t (sqp_base.hpp:49-55) */
 typedef enum { PMPC_SQP_SOLVED = 0, PMPC_SQP_MAX_ITER_EXCEEDED = 1, PMPC_SQP_INVALID_SETTINGS = 2 } pmpc_sqp_status;
@@ -191,6 +202,14 @@ pmpc_status pmpc_sqp_solve_batch_dev(pmpc_context* ctx, int model, int P, int S,
                                      const double* lam_guess, const double* d, const double* lbx, const double* ubx,
                                      const double* lbg, const double* ubg, const pmpc_sqp_settings* sqp_settings,
                                      const pmpc_qp_settings* qp_settings, double* x, double* lam, pmpc_sqp_info* info);
+
+/* LSFilter state of B solver objects in device memory (zeroed = empty filters) for pmpc_sqp_settings::filter_state.
+ * clear is LSFilter::clear() for all B (line_search.hpp:52), asynchronous on the context's stream; download copies the B x
+ * PMPC_FILTER_STATE_DOUBLES values to the host after synchronising the stream. */
+pmpc_status pmpc_filter_state_create(pmpc_context* ctx, int B, double** filter_state);
+pmpc_status pmpc_filter_state_clear(pmpc_context* ctx, int B, double* filter_state);
+pmpc_status pmpc_filter_state_download(pmpc_context* ctx, int B, const double* filter_state, double* host_out);
+pmpc_status pmpc_filter_state_destroy(pmpc_context* ctx, double* filter_state);
 
 /* One receding-horizon step of B MPC<OCP> controllers, everything resident on the device (replaces the caller's loop around
  * MPC::initial_conditions(x0) + MPC::solve() + MPC::solution_u_at(t_start), mpc_wrapper.hpp:89-93, :298, :241-244):

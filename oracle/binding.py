@@ -41,7 +41,21 @@ class QPInfo(C.Structure):
 class SQPSettings(C.Structure):
     _fields_ = [("tau", C.c_double), ("eta", C.c_double), ("rho", C.c_double), ("eps_prim", C.c_double),
                 ("eps_dual", C.c_double), ("max_iter", C.c_int), ("line_search_max_iter", C.c_int),
-                ("regularisation", C.c_int), ("exact_hessian_every_iter", C.c_int), ("preconditioner", C.c_int), ("hessian_update", C.c_int), ("qp_solver", C.c_int)]
+                ("regularisation", C.c_int), ("exact_hessian_every_iter", C.c_int), ("preconditioner", C.c_int), ("hessian_update", C.c_int), ("qp_solver", C.c_int),
+                ("line_search", C.c_int), ("filter_max_depth", C.c_int), ("filter_beta", C.c_double), ("filter_state", C.POINTER(C.c_double))]
+
+
+FILTER_STATE_DOUBLES = 21
+
+
+def bind_filter_state(ss, state):
+    """Attach a (B, FILTER_STATE_DOUBLES) float64 array as the LSFilter member that outlives solve(); None detaches it."""
+    if state is None:
+        ss.filter_state = C.POINTER(C.c_double)()
+    else:
+        assert state.dtype == np.float64 and state.flags.c_contiguous and state.shape[-1] == FILTER_STATE_DOUBLES
+        ss.filter_state = state.ctypes.data_as(C.POINTER(C.c_double))
+        ss._keep_filter = state
 
 
 class SQPInfo(C.Structure):

@@ -32,6 +32,7 @@ static sqp_settings to_sqp(const orc_sqp_settings* s) {
     q.max_iter = s->max_iter; q.line_search_max_iter = s->line_search_max_iter;
     q.regularisation = s->regularisation; q.exact_hessian_every_iter = s->exact_hessian_every_iter != 0;
     q.preconditioner = s->preconditioner; q.hessian_update = s->hessian_update; q.qp_solver = s->qp_solver;
+    q.line_search = s->line_search; q.filter_max_depth = s->filter_max_depth; q.filter_beta = s->filter_beta;
     return q;
 }
 
@@ -76,6 +77,7 @@ void orc_sqp_default_settings(orc_sqp_settings* s) {
     s->tau = q.tau; s->eta = q.eta; s->rho = q.rho; s->eps_prim = q.eps_prim; s->eps_dual = q.eps_dual;
     s->max_iter = q.max_iter; s->line_search_max_iter = q.line_search_max_iter;
     s->regularisation = 0; s->exact_hessian_every_iter = 0; s->preconditioner = 0; s->hessian_update = 0; s->qp_solver = 0;
+    s->line_search = q.line_search; s->filter_max_depth = q.filter_max_depth; s->filter_beta = q.filter_beta; s->filter_state = nullptr;
 }
 
 void orc_cheb(int P, double* nodes, double* weights, double* D) {
@@ -226,7 +228,9 @@ static void sqp_batch_impl(int P, int S, double t0, double tf, const double* mp,
         ocp.set_time_limits(t0, tf);
         SQP<ContinuousOCP<Model>> sqp(ocp, Model::ND);
         setup_solver<Model>(sqp, b, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, pivot);
+        if (ss->filter_state) sqp.filter.load(ss->filter_state + (size_t)b * ORC_FILTER_STATE_DOUBLES);
         sqp.solve();
+        if (ss->filter_state) sqp.filter.store(ss->filter_state + (size_t)b * ORC_FILTER_STATE_DOUBLES);
         const int n = sqp.n, m = sqp.m;
         std::memcpy(x + (size_t)b * n, sqp.x.data(), sizeof(double) * n);
         std::memcpy(lam + (size_t)b * (m + n), sqp.lam.data(), sizeof(double) * (m + n));

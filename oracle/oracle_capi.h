@@ -30,7 +30,13 @@ typedef struct {
     int preconditioner;            /* 0 identity (default), 1 Ruiz equilibration */
     int hessian_update;            /* 0 dense damped BFGS (default), 1 block BFGS of ContinuousOCP */
     int qp_solver;                 /* 0 boxADMM (default), 1 ADMM (OSQP form) */
+    int line_search;               /* 0 l1-merit backtracking (default), 1 filter line search (LSFilter) */
+    int filter_max_depth;          /* LSFilter::max_depth (10) */
+    double filter_beta;            /* LSFilter::beta (1e-5) */
+    double* filter_state;          /* NULL: every solve starts with an empty filter; else B x ORC_FILTER_STATE_DOUBLES, read before and
+                                    * written after the solve (the solver member that outlives solve()): [count, cost0, viol0, cost1, ...] */
 } orc_sqp_settings;
+enum { ORC_FILTER_STATE_DOUBLES = 21 };
 
 typedef struct {
     int iter, qp_solver_iter, status;

@@ -16,6 +16,7 @@
 #pragma once
 #include <cmath>
 #include <limits>
+#include <utility>
 #include <vector>
 #include "qp.hpp"
 #include "ruiz.hpp"
@@ -97,6 +98,42 @@ struct sqp_settings {  // sqp_base.hpp:24-47
     int qp_solver = 0;                      // SQPBase's QPSolver template argument: 0 boxADMM (box_admm.hpp, default), 1 ADMM (admm.hpp, OSQP form)
     int hessian_update = 0;                 // hessian_update_impl: 0 damped BFGS on the whole matrix (bfgs.hpp, DENSE default), 1 the block BFGS of
                                             // ContinuousOCP (continuous_ocp.hpp:2304-2431), which keeps the Hessian block-diagonal per node
+    int line_search = 0;                    // step_size_selection_impl: 0 l1-merit backtracking (:380-419, default), 1 the filter line search the
+                                            // reference's valet-parking test plugs in (valet_parking_mpc_test.cpp:116-158) on LSFilter
+    int filter_max_depth = 10;              // LSFilter::max_depth (line_search.hpp:38)
+    double filter_beta = 1e-5;              // LSFilter::beta (line_search.hpp:39)
+};
+
+// LSFilter, /root/reference/src/solvers/line_search.hpp:31-98: a list of (cost, constraint violation) pairs, newest first.
+// State layout shared with the GPU path: st[0] = number of pairs, then the pairs front to back (FILTER_CAPACITY at most).
+struct LSFilter {
+    static constexpr int CAPACITY = 10, STATE_DOUBLES = 1 + 2 * CAPACITY;
+    std::vector<std::pair<double, double>> f;   // front = index 0
+    int max_depth = 10;
+    double beta = 1e-5;
+    void clear() { f.clear(); }
+    bool is_acceptable(double cost, double constraint) const {   // :65-74
+        for (const auto& e : f)
+            if (((e.first - beta * e.second) <= cost) && ((e.second - beta * e.second) <= constraint)) return false;
+        return true;
+    }
+    void add(double cost, double constraint) {                   // :76-92
+        if ((int)f.size() < max_depth) {
+            std::vector<std::pair<double, double>> keep;             // remove_if(dominated_by(cost, constraint)) :14-29, order preserved
+            for (const auto& e : f) if (!((e.first >= cost) && (e.second >= constraint))) keep.push_back(e);
+            f.swap(keep);
+            f.insert(f.begin(), std::make_pair(cost, constraint));
+        } else {
+            f.pop_back();
+            f.insert(f.begin(), std::make_pair(cost, constraint));
+        }
+    }
+    void load(const double* st) { f.clear(); const int k = (int)st[0]; for (int i = 0; i < k && i < CAPACITY; ++i) f.emplace_back(st[1 + 2 * i], st[2 + 2 * i]); }
+    void store(double* st) const {
+        for (int i = 0; i < STATE_DOUBLES; ++i) st[i] = 0.0;
+        st[0] = (double)f.size();
+        for (size_t i = 0; i < f.size(); ++i) { st[1 + 2 * i] = f[i].first; st[2 + 2 * i] = f[i].second; }
+    }
 };
 enum sqp_status { SQP_SOLVED = 0, SQP_MAX_ITER_EXCEEDED = 1, SQP_INVALID_SETTINGS = 2 };
 struct sqp_info { int iter = 0, qp_solver_iter = 0, status = SQP_MAX_ITER_EXCEEDED; };
@@ -158,7 +195,30 @@ struct SQP {
         return c;
     }
 
+    LSFilter filter;   // member of the reference's test solver: it outlives solve() (valet_parking_mpc_test.cpp:114)
+
+    // step_size_selection_impl of valet_parking_mpc_test.cpp:116-158
+    double step_size_selection_filter(const double* p) {
+        const double tau = settings.tau;
+        filter.max_depth = settings.filter_max_depth; filter.beta = settings.filter_beta;
+        double constr_l1 = constraints_violation(x.data());
+        double cost_1; problem.cost(x.data(), p_static.data(), cost_1);
+        if (filter.is_acceptable(cost_1, constr_l1)) filter.add(cost_1, constr_l1);
+        double alpha = 1.0, cost_step;
+        std::vector<double> x_step(n);
+        for (int i = 1; i < settings.line_search_max_iter; i++) {
+            for (int j = 0; j < n; ++j) { x_step[j] = alpha * p[j]; x_step[j] += x[j]; }
+            problem.cost(x_step.data(), p_static.data(), cost_step);
+            const double constr_step = constraints_violation(x_step.data());
+            cost_ = cost_step;
+            if (filter.is_acceptable(cost_step, constr_step)) { filter.add(cost_step, constr_step); return alpha; }
+            else alpha *= tau;
+        }
+        return alpha;
+    }
+
     double step_size_selection(const double* p) {  // :380-419
+        if (settings.line_search == 1) return step_size_selection_filter(p);
         const double tau = settings.tau;
         double constr_l1 = constraints_violation(x.data());
         double mu = BoxADMM::inf_norm(lam_k.data(), m + n);

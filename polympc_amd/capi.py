@@ -21,6 +21,7 @@ EXPORTED_SYMBOLS = [
     "pmpc_sqp_solve_batch", "pmpc_sqp_solve_batch_dev", "pmpc_sqp_solve_batch_user",
     "pmpc_mpc_step_batch_dev", "pmpc_mpc_batch_create", "pmpc_mpc_batch_step", "pmpc_mpc_batch_solution", "pmpc_mpc_batch_destroy",
     "pmpc_qp_admm_solve_batch", "pmpc_qp_admm_solve_batch_dev", "pmpc_qp_ruiz_compute_batch", "pmpc_qp_ruiz_compute_batch_dev", "pmpc_qp_ruiz_unscale_batch", "pmpc_qp_ruiz_unscale_batch_dev",
+    "pmpc_filter_state_create", "pmpc_filter_state_clear", "pmpc_filter_state_download", "pmpc_filter_state_destroy",
 ]
 
 
@@ -38,7 +39,12 @@ class QPInfo(C.Structure):
 class SQPSettings(C.Structure):
     _fields_ = [("tau", C.c_double), ("eta", C.c_double), ("rho", C.c_double), ("eps_prim", C.c_double),
                 ("eps_dual", C.c_double), ("max_iter", C.c_int), ("line_search_max_iter", C.c_int),
-                ("regularisation", C.c_int), ("exact_hessian_every_iter", C.c_int), ("preconditioner", C.c_int), ("hessian_update", C.c_int), ("qp_solver", C.c_int)]
+                ("regularisation", C.c_int), ("exact_hessian_every_iter", C.c_int), ("preconditioner", C.c_int), ("hessian_update", C.c_int), ("qp_solver", C.c_int),
+                ("line_search", C.c_int), ("filter_max_depth", C.c_int), ("filter_beta", C.c_double), ("filter_state", C.c_void_p)]
+
+
+FILTER_MAX_DEPTH = 10
+FILTER_STATE_DOUBLES = 1 + 2 * FILTER_MAX_DEPTH
 
 
 class SQPInfo(C.Structure):
@@ -230,6 +236,32 @@ class Context:
                  *[k[1] for k in keep[1:]], C.byref(ss), C.byref(qs), x.ctypes.data_as(P_), lam.ctypes.data_as(P_),
                  C.c_void_p(info.ctypes.data)))
         return x, lam, info
+
+    # ------------------------------------------------------------------ LSFilter state of B solver objects (line_search = 1)
+    def filter_state_create(self, B):
+        """Device buffer of B empty filters; put the returned handle into SQPSettings.filter_state to carry the filter between solves."""
+        out = C.c_void_p()
+        f = lib().pmpc_filter_state_create
+        f.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        _check(f(self._ctx, B, C.byref(out)))
+        return out.value
+
+    def filter_state_clear(self, B, handle):
+        f = lib().pmpc_filter_state_clear
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        _check(f(self._ctx, B, handle))
+
+    def filter_state_download(self, B, handle):
+        out = np.zeros((B, FILTER_STATE_DOUBLES))
+        f = lib().pmpc_filter_state_download
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
+        _check(f(self._ctx, B, handle, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def filter_state_destroy(self, handle):
+        f = lib().pmpc_filter_state_destroy
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        _check(f(self._ctx, handle))
 
     # ------------------------------------------------------------------ MPC step, device buffers (torch tensors), asynchronous
     def mpc_step_batch_dev(self, model, P, S, t0, tf, B, x0, d, lbx, ubx, x, lam, info, sqp_settings, qp_settings, u0=None, lbg=None,

@@ -203,6 +203,33 @@ pmpc_status pmpc_synchronize(pmpc_context* ctx) {
     return PMPC_OK;
 }
 
+pmpc_status pmpc_filter_state_create(pmpc_context* ctx, int B, double** filter_state) {
+    if (!ctx || B < 1 || !filter_state) return PMPC_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(ctx->device));
+    double* p = nullptr;
+    const size_t bytes = (size_t)B * PMPC_FILTER_STATE_DOUBLES * sizeof(double);
+    HIPCHK(hipMalloc((void**)&p, bytes));
+    HIPCHK(hipMemsetAsync(p, 0, bytes, ctx->stream));
+    *filter_state = p;
+    return PMPC_OK;
+}
+pmpc_status pmpc_filter_state_clear(pmpc_context* ctx, int B, double* filter_state) {
+    if (!ctx || B < 1 || !filter_state) return PMPC_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipMemsetAsync(filter_state, 0, (size_t)B * PMPC_FILTER_STATE_DOUBLES * sizeof(double), ctx->stream));
+    return PMPC_OK;
+}
+pmpc_status pmpc_filter_state_download(pmpc_context* ctx, int B, const double* filter_state, double* host_out) {
+    if (!ctx || B < 1 || !filter_state || !host_out) return PMPC_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipMemcpyAsync(host_out, filter_state, (size_t)B * PMPC_FILTER_STATE_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PMPC_OK;
+}
+pmpc_status pmpc_filter_state_destroy(pmpc_context* ctx, double* filter_state) {
+    if (!ctx) return PMPC_ERR_INVALID_ARGUMENT;
+    if (filter_state) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(filter_state)); }
+    return PMPC_OK;
+}
+
 void pmpc_qp_settings_default(pmpc_qp_settings* s) {
     s->eps_rel = 1e-3; s->eps_abs = 1e-3; s->max_iter = 1000; s->rho = 1e-1; s->sigma = 1e-6; s->alpha = 1.0;
     s->check_termination = 25; s->adaptive_rho = 0; s->adaptive_rho_tolerance = 5; s->adaptive_rho_interval = 25;
@@ -215,6 +242,7 @@ void pmpc_qp_settings_sqp_default(pmpc_qp_settings* s) {
 void pmpc_sqp_settings_default(pmpc_sqp_settings* s) {
     s->tau = 0.5; s->eta = 0.25; s->rho = 0.5; s->eps_prim = 1e-3; s->eps_dual = 1e-3; s->max_iter = 100;
     s->line_search_max_iter = 100; s->regularisation = 0; s->exact_hessian_every_iter = 0; s->preconditioner = 0; s->hessian_update = 0; s->qp_solver = 0;
+    s->line_search = 0; s->filter_max_depth = PMPC_FILTER_MAX_DEPTH; s->filter_beta = 1e-5; s->filter_state = nullptr;
 }
 
 pmpc_status pmpc_chebyshev(int P, double* nodes, double* weights, double* D) {

@@ -16,6 +16,8 @@ extern "C" int pmpc_internal_sqp_slice(pmpc_context* ctx);   // SQP iterations p
 namespace pmpc {
 using ::pmpc_status;
 
+constexpr int FILTER_LDS_DOUBLES = 24;   // PMPC_FILTER_STATE_DOUBLES rounded up
+
 template <class Model, int NN = 0, int MM = 0, bool PROF = false>
 #ifndef PMPC_SQP_WAVES
 #define PMPC_SQP_WAVES 2
@@ -50,6 +52,12 @@ __global__ __launch_bounds__(64, (NN > 0 ? PMPC_SQP_WAVES : 1)) void sqp_kernel(
     const int ln = lane_id();
     for (int i = ln; i < Model::ND; i += WAVE) dL[i] = d[(size_t)b * Model::ND + i];
     ocp.d = dL;
+    double* filt = nullptr;   // LSFilter of this instance (line_search = 1; the register-resident specialisations do not carry it)
+    if constexpr (NN == 0) {
+        filt = p; p += FILTER_LDS_DOUBLES;
+        const bool carried = ss.line_search == 1 && ss.filter_state != nullptr;
+        if (ln < PMPC_FILTER_STATE_DOUBLES) filt[ln] = carried ? ss.filter_state[(size_t)b * PMPC_FILTER_STATE_DOUBLES + ln] : 0.0;
+    }
     ocp.stage_constants(cd);
     double* sst = slice_state ? slice_state + (size_t)b * 2 * n : nullptr;   // [previous Lagrangian gradient | previous step]
     for (int i = ln; i < n; i += WAVE) {
@@ -68,6 +76,7 @@ __global__ __launch_bounds__(64, (NN > 0 ? PMPC_SQP_WAVES : 1)) void sqp_kernel(
     double* K0 = Hws + (size_t)b * (size_t)(n + m) * n;
     (void)Aws;
     SqpDevice<Model, NN, MM, PROF> sqp(ocp, v, qw, K0, K0 + n, ss, qs);
+    sqp.filt = filt;
     sqp.tr = ocp.s.fval;   // first per-node staging array: everything from here on is dead while the QP runs
     {   // side-by-side line search: G candidates x (m constraint values + NN Lagrange values) + 3 scalars each, in the same region
         const int G = WAVE / ocp.dm.NN;
@@ -82,16 +91,20 @@ __global__ __launch_bounds__(64, (NN > 0 ? PMPC_SQP_WAVES : 1)) void sqp_kernel(
     for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = v.x[i];
     for (int i = ln; i < m + n; i += WAVE) lam[(size_t)b * (m + n) + i] = v.lam[i];
     if (ln == 0) info[b] = si;
+    if constexpr (NN == 0) {
+        if (ss.line_search == 1 && ss.filter_state != nullptr && ln < PMPC_FILTER_STATE_DOUBLES) ss.filter_state[(size_t)b * PMPC_FILTER_STATE_DOUBLES + ln] = filt[ln];
+    }
     if constexpr (PROF) { if (phase_cycles && ln == 0) for (int i = 0; i < 24; ++i) atomicAdd(&phase_cycles[i], (unsigned long long)sqp.cyc[i]); }
 }
 // mode 0: KKT factor in LDS; 1: register-resident QP (n+m <= 64); 2: KKT factor in HBM (large instances)
 template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode, int qp_solver = 0) {
     OcpDims<Model> dm(P, S);
     if (mode == 0 && qp_solver == 1)
-        return (QpLds::doubles(dm.n, dm.m + dm.n) + SqpLds::doubles(dm.n, dm.m, dm.mi) + OcpLds<Model>::doubles(P, S) + 8) * sizeof(double);
+        return (QpLds::doubles(dm.n, dm.m + dm.n) + SqpLds::doubles(dm.n, dm.m, dm.mi) + OcpLds<Model>::doubles(P, S) + 8 + FILTER_LDS_DOUBLES) * sizeof(double);
     size_t stage = OcpLds<Model>::doubles(P, S);
     if (mode == 1) { const size_t need = (size_t)RegKkt<64>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
-    return ((mode == 0 ? QpLds::doubles(dm.n, dm.m) : QpLds::doubles_xy(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8) * sizeof(double);
+    return ((mode == 0 ? QpLds::doubles(dm.n, dm.m) : QpLds::doubles_xy(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8 +
+            (mode == 1 ? 0 : FILTER_LDS_DOUBLES)) * sizeof(double);
 }
 template <class Model> inline bool sqp_hbm_mode_fits(int P, int S) {   // do the QP vectors fit the second-order staging?
     OcpDims<Model> dm(P, S);
@@ -192,9 +205,11 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     hipStream_t stream = (hipStream_t)streamv;
     double* Hws = ws; double* Aws = ws + (size_t)B * dm.n * dm.n;
     double* slice_state = Aws + (size_t)B * dm.m * dm.n;
-    const int slice_iters = pmpc_internal_sqp_slice(ctx);
+    const int slice_iters = ss->line_search == 1 ? 0 : pmpc_internal_sqp_slice(ctx);   // (the filter lives in LDS for the whole solve)
     if ((ss->hessian_update != 0 && ss->hessian_update != 1) || (ss->qp_solver != 0 && ss->qp_solver != 1)) return PMPC_ERR_INVALID_ARGUMENT;
-    if (!force_lds && ss->preconditioner == 0 && ss->hessian_update == 0 && ss->qp_solver == 0) {   // node counts whose KKT system can fit 64 rows for small models (7 nodes: config A / D); Ruiz: LDS path
+    if ((ss->line_search != 0 && ss->line_search != 1) ||
+        (ss->line_search == 1 && (ss->filter_max_depth < 1 || ss->filter_max_depth > PMPC_FILTER_MAX_DEPTH))) return PMPC_ERR_INVALID_ARGUMENT;
+    if (!force_lds && ss->preconditioner == 0 && ss->hessian_update == 0 && ss->qp_solver == 0 && ss->line_search == 0) {   // node counts whose KKT system can fit 64 rows for small models (7 nodes: config A / D); Ruiz: LDS path
         pmpc_status rst = PMPC_OK;
         if (try_launch_reg<Model, 7>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;
         if (try_launch_reg<Model, 5>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;

@@ -102,6 +102,45 @@ struct SqpDevice {
         return c;
     }
 
+    // ---- LSFilter, src/solvers/line_search.hpp:31-98, for the filter line search of valet_parking_mpc_test.cpp:116-158 (line_search = 1).
+    // filt = [count, (cost, constraint violation) pairs, newest first] in LDS. Every lane evaluates the same acceptance test on the
+    // same values; lane 0 alone edits the list. Compiled into the LDS-resident kernels only (the launcher routes line_search = 1 there).
+    double* filt = nullptr;
+    __device__ __forceinline__ bool filter_mode() const { if constexpr (NN == 0) return __builtin_amdgcn_readfirstlane(ss.line_search) == 1; else return false; }
+    __device__ bool filter_is_acceptable(double cost, double constraint) const {   // :65-74
+        int cnt = (int)filt[0];
+        if (cnt > PMPC_FILTER_MAX_DEPTH) cnt = PMPC_FILTER_MAX_DEPTH;
+        const double beta = ss.filter_beta;
+        bool ok = true;
+        for (int i = 0; i < cnt; ++i) {
+            const double f = filt[1 + 2 * i], c = filt[2 + 2 * i];
+            const double bc = beta * c;
+            if (((f - bc) <= cost) && ((c - bc) <= constraint)) ok = false;
+        }
+        return __builtin_amdgcn_readfirstlane((int)ok) != 0;
+    }
+    __device__ void filter_add(double cost, double constraint) {                   // :76-92 (remove_if(dominated_by) :14-29 keeps the order)
+        wsync();
+        if (lane_id() == 0) {
+            int cnt = (int)filt[0];
+            if (cnt > PMPC_FILTER_MAX_DEPTH) cnt = PMPC_FILTER_MAX_DEPTH;
+            if (cnt < ss.filter_max_depth) {
+                int k = 0;
+                for (int i = 0; i < cnt; ++i) {
+                    const double f = filt[1 + 2 * i], c = filt[2 + 2 * i];
+                    if (!((f >= cost) && (c >= constraint))) { filt[1 + 2 * k] = f; filt[2 + 2 * k] = c; ++k; }
+                }
+                cnt = k + 1;
+            }
+            // emplace_front; when the filter was full its last entry falls off (pop_back)
+            for (int i = cnt - 1; i > 0; --i) { filt[1 + 2 * i] = filt[2 * i - 1]; filt[2 + 2 * i] = filt[2 * i]; }
+            filt[1] = cost; filt[2] = constraint;
+            for (int i = cnt; i < PMPC_FILTER_MAX_DEPTH; ++i) { filt[1 + 2 * i] = 0.0; filt[2 + 2 * i] = 0.0; }
+            filt[0] = (double)cnt;
+        }
+        wsync();
+    }
+
     // step_size_selection_impl :380-419 ; p = QP primal step in qw.x  (one trial point at a time)
     __device__ double step_size_selection_serial() {
         const double* p = qw.x;
@@ -111,6 +150,8 @@ struct SqpDevice {
         const double cost_1 = ocp.cost(v.x);
         const double phi_l1 = cost_1 + mu * constr_l1;
         const double Dp_phi_l1 = seq_dot(v.h, p, n) - mu * constr_l1;
+        const bool fmode = filter_mode();
+        if constexpr (NN == 0) { if (fmode && filter_is_acceptable(cost_1, constr_l1)) filter_add(cost_1, constr_l1); }
         double alpha = 1.0;
         cb_valid = false;
         for (int i = 1; i < ss.line_search_max_iter; ++i) {
@@ -118,7 +159,15 @@ struct SqpDevice {
             wsync();
             const double cost_step = ocp.cost(v.xs);
             cost_log = cost_step;
-            const double phi_step = cost_step + mu * constraints_violation(v.xs);
+            const double constr_step = constraints_violation(v.xs);
+            if constexpr (NN == 0) {
+                if (fmode) {
+                    if (filter_is_acceptable(cost_step, constr_step)) { filter_add(cost_step, constr_step); cb_valid = true; return alpha; }
+                    alpha = ss.tau * alpha;
+                    continue;
+                }
+            }
+            const double phi_step = cost_step + mu * constr_step;
             if (__builtin_amdgcn_readfirstlane((int)(phi_step <= (phi_l1 + alpha * ss.eta * Dp_phi_l1)))) { cb_valid = true; return alpha; }
             alpha = ss.tau * alpha;
         }
@@ -283,18 +332,27 @@ struct SqpDevice {
             wsync();
             const long long e2 = now();
             acc(8, e1 - e0); acc(9, e2 - e1);
+            const bool fmode = filter_mode();
             if (first) {
                 const double constr_l1 = cand_viol[0];
                 phi_l1 = cand_cost[0] + mu * constr_l1;
                 Dp_phi_l1 = gp - mu * constr_l1;
+                if constexpr (NN == 0) { if (fmode && filter_is_acceptable(cand_cost[0], constr_l1)) filter_add(cand_cost[0], constr_l1); }
             }
             int accepted = -1;
             for (int gc = base; gc < ncand; ++gc) {   // the reference's sequential acceptance order
                 const double ag = cand_alpha[gc];
                 const double cost_step = cand_cost[gc];
                 cost_log = cost_step;
-                const double phi_step = cost_step + mu * cand_viol[gc];
-                if (__builtin_amdgcn_readfirstlane((int)(phi_step <= (phi_l1 + ag * ss.eta * Dp_phi_l1)))) { accepted = gc; alpha = ag; break; }
+                bool ok;
+                if constexpr (NN == 0) {
+                    if (fmode) { ok = filter_is_acceptable(cost_step, cand_viol[gc]); if (ok) filter_add(cost_step, cand_viol[gc]); }
+                    else ok = __builtin_amdgcn_readfirstlane((int)((cost_step + mu * cand_viol[gc]) <= (phi_l1 + ag * ss.eta * Dp_phi_l1))) != 0;
+                } else {
+                    const double phi_step = cost_step + mu * cand_viol[gc];
+                    ok = __builtin_amdgcn_readfirstlane((int)(phi_step <= (phi_l1 + ag * ss.eta * Dp_phi_l1))) != 0;
+                }
+                if (ok) { accepted = gc; alpha = ag; break; }
                 alpha = ss.tau * ag;
                 ++trial;
             }

@@ -1,6 +1,7 @@
 // Host-side tests written like the reference's own gtest cases, against include/polympc/polympc.hpp.
 //   box_admmSimpleQP / SimpleLP / NonConvex    tests/solvers/qp/box_admm_test.cpp:15-45, :266-297, :299-334
 //   MPCWrapperTest                              tests/control/mpc_wrapper_test.cpp:120-199 (dense-BFGS variant)
+//   ValetParkingTest                            tests/control/valet_parking_mpc_test.cpp:183-240 (Ruiz + filter line search + block BFGS)
 //   user-registered OCP                         docs/source/ocp.rst:229-481 workflow, compiled by hipcc (user_ocp.hip)
 #include <cstdio>
 #include <cstring>
@@ -143,6 +144,44 @@ static void MPCWrapperTest() {
     EXPECT_TRUE(std::fabs(mpc.solution_x_at(0)(0) - 0.3) < 1e-3);   // the pinned initial state is the FIRST point in time
 }
 
+// valet_parking_mpc_test.cpp:183-240 — the reference plugs three hooks into SQPBase there (Ruiz preconditioner as template argument,
+// filter line search :116-158, block BFGS :160-165); here they are the three settings flags, `solver.filter.beta` keeps its name.
+static void ValetParkingTest() {
+    std::printf("ValetParkingTest\n");
+    using OCP = polympc::models::MobileRobot<polympc::Spline<polympc::Chebyshev<5>, 2>>;
+    Solver<OCP> solver;
+    solver.get_problem().set_Q_coeff(1.0);
+    solver.get_problem().set_time_limits(0, 2);
+    solver.settings().max_iter = 10;
+    solver.settings().line_search_max_iter = 10;
+    solver.settings().preconditioner = 1; solver.settings().hessian_update = 1; solver.settings().line_search = 1;
+    solver.qp_settings().max_iter = 1000;
+    solver.parameters()(0) = 2.0;
+    solver.filter.beta = 0.1;
+    double init_cond[3] = {0.5, 0.5, 0.5};
+    for (int k = 0; k < 11; ++k) {
+        solver.upper_bound_x()(33 + 2 * k) = 1.5;  solver.upper_bound_x()(34 + 2 * k) = 0.75;
+        solver.lower_bound_x()(33 + 2 * k) = -1.5; solver.lower_bound_x()(34 + 2 * k) = -0.75;
+    }
+    for (int i = 0; i < 3; ++i) { solver.upper_bound_x()(30 + i) = init_cond[i]; solver.lower_bound_x()(30 + i) = init_cond[i]; }
+    solver.solve();
+    const int cold = solver.info().iter;
+    EXPECT_TRUE(solver.info().status.value == sqp_status_t::SOLVED);
+    EXPECT_LT(solver.info().iter, solver.settings().max_iter);
+    const size_t kept = solver.filter.entries(0).size();
+    EXPECT_TRUE(kept >= 1 && kept <= 10);
+    // warm started iteration
+    init_cond[0] = 0.3; init_cond[1] = 0.4; init_cond[2] = 0.45;
+    for (int i = 0; i < 3; ++i) { solver.upper_bound_x()(30 + i) = init_cond[i]; solver.lower_bound_x()(30 + i) = init_cond[i]; }
+    solver.solve();
+    EXPECT_TRUE(solver.info().status.value == sqp_status_t::SOLVED);
+    EXPECT_LT(solver.info().iter, solver.settings().max_iter);
+    std::printf("  iterations: cold %d, warm %d; filter entries after cold solve %zu, after warm solve %zu\n", cold, solver.info().iter, kept,
+                solver.filter.entries(0).size());
+    solver.filter.clear();
+    EXPECT_TRUE(solver.filter.entries(0).empty());
+}
+
 // ---- user-registered OCPs (device code in libuser_ocp.so, built from tests/cpp/user_ocp.hip) ------------------------------
 struct UserRobot { double q = 1.0; };          // must match the layout of the struct registered in user_ocp.hip
 struct Pendulum {};
@@ -215,6 +254,7 @@ int main() {
     if (!polympc::context()) { std::printf("no GPU: %s\n", pmpc_status_string(polympc::last_error())); return 77; }
     box_admmSimpleQP();
     box_admmRuizEquilibration();
+    ValetParkingTest();
     admmSimpleQP();
     box_admmNonConvex();
     MPCWrapperTest();

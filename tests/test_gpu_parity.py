@@ -486,6 +486,86 @@ def test_sqp_valet_parking_with_ruiz(ctx, oracle):
         assert info["iter"][0] == io[0].iter and np.abs(xg - xo).max() <= 1e-7
 
 
+def test_sqp_valet_parking_as_the_reference_runs_it(ctx, oracle):
+    """valet_parking_mpc_test.cpp:183-240 through the GPU path with every hook that test installs: Ruiz preconditioner, QP max_iter
+    1000, the filter line search on LSFilter (beta = 0.1, carried from the cold solve into the warm-started one in a device buffer)
+    and the block BFGS. Both solves SOLVED in < 10 iterations as the reference asserts; same SQP / QP iteration counts, the same
+    filter contents (1e-9) and x within 1e-7 of the CPU restatement."""
+    import polympc_amd as pa
+    from test_oracle_pins import _valet_bounds
+    ss = pa.sqp_settings_default(); oss = oracle.sqp_default_settings()
+    for st in (ss, oss):
+        st.max_iter = 10; st.line_search_max_iter = 10; st.preconditioner = 1; st.hessian_update = 1; st.line_search = 1; st.filter_beta = 0.1
+    qs = pa.qp_settings_sqp_default(); qs.max_iter = 1000
+    oqs = oracle.sqp_qp_default_settings(); oqs.max_iter = 1000
+    handle = ctx.filter_state_create(1); ss.filter_state = handle
+    ofilt = np.zeros((1, oracle.FILTER_STATE_DOUBLES)); oracle.bind_filter_state(oss, ofilt)
+    try:
+        xg = lg = xo = lo = None
+        for x0 in ([0.5, 0.5, 0.5], [0.3, 0.4, 0.45]):
+            lbx, ubx = _valet_bounds(x0)
+            xg, lg, info = ctx.sqp_solve_batch(pa.MODEL_ROBOT, 5, 2, 0.0, 2.0, 1, [[2.0]], lbx, ubx, x_guess=xg, lam_guess=lg, sqp_settings=ss,
+                                               qp_settings=qs, mparams=[1.0])
+            xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 2.0, 1, [[2.0]], lbx, ubx, x_guess=xo, lam_guess=lo, sqp_settings=oss,
+                                                qp_settings=oqs, pivot=oracle.PIVOT_STATIC, mparams=[1.0])
+            assert info["status"][0] == pa.SQP_SOLVED and info["iter"][0] < 10
+            assert info["iter"][0] == io[0].iter and info["qp_solver_iter"][0] == io[0].qp_solver_iter
+            assert np.abs(xg - xo).max() <= 1e-7
+            filt = ctx.filter_state_download(1, handle)
+            assert filt[0, 0] == ofilt[0, 0] >= 1 and np.abs(filt - ofilt).max() <= 1e-9
+        ctx.filter_state_clear(1, handle)
+        assert not ctx.filter_state_download(1, handle).any()
+    finally:
+        ctx.filter_state_destroy(handle)
+
+
+def test_sqp_filter_line_search_batch_vs_oracle(ctx, oracle):
+    """line_search = 1 on batches of randomised robot OCPs (P=5 S=3 and config A's grid, both on the LDS-resident path), with and
+    without a carried filter: identical iteration counts and filter lengths, x and filter entries within 1e-7 of the CPU restatement; a second solve from the
+    first one's solution with the carried filter must again agree (the filter then holds the first solve's history)."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    for P, S, B in ((5, 3, 6), (6, 1, 32)):
+        wl = workloads.robot_batch(B, P=P, S=S)
+        ss = pa.sqp_settings_default(); oss = oracle.sqp_default_settings()
+        for st in (ss, oss):
+            st.max_iter = 10; st.line_search_max_iter = 10; st.line_search = 1
+        handle = ctx.filter_state_create(B); ss.filter_state = handle
+        ofilt = np.zeros((B, oracle.FILTER_STATE_DOUBLES)); oracle.bind_filter_state(oss, ofilt)
+        try:
+            xg = lg = xo = lo = None
+            for rep in range(2):
+                xg, lg, info = ctx.sqp_solve_batch(pa.MODEL_ROBOT, P, S, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], x_guess=xg, lam_guess=lg, sqp_settings=ss)
+                xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, P, S, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], x_guess=xo, lam_guess=lo,
+                                                    sqp_settings=oss, pivot=oracle.PIVOT_STATIC)
+                same = info["iter"] == np.array([i.iter for i in io])
+                assert same.mean() >= 0.95, (P, S, rep, same.mean())
+                assert np.abs(xg - xo)[same].max() <= 1e-7
+                filt = ctx.filter_state_download(B, handle)
+                assert np.array_equal(filt[same, 0], ofilt[same, 0]) and np.abs(filt - ofilt)[same].max() <= 1e-7
+                xo, lo = xg.copy(), lg.copy()   # continue both sides from the same point
+                ofilt[:] = filt
+        finally:
+            ctx.filter_state_destroy(handle)
+    # without a carried state every call starts from an empty filter
+    wl = workloads.robot_batch(8, P=5, S=2)
+    ss = pa.sqp_settings_default(); ss.max_iter = 10; ss.line_search_max_iter = 10; ss.line_search = 1
+    oss = oracle.sqp_default_settings(); oss.max_iter = 10; oss.line_search_max_iter = 10; oss.line_search = 1
+    x, lam, info = ctx.sqp_solve_batch(pa.MODEL_ROBOT, 5, 2, 0.0, 2.0, 8, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
+    xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 2.0, 8, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, pivot=oracle.PIVOT_STATIC)
+    assert list(info["iter"]) == [i.iter for i in io] and np.abs(x - xo).max() <= 1e-7
+
+
+def test_filter_settings_are_validated(ctx):
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    wl = workloads.robot_batch(2, P=5, S=2)
+    for ls, depth in ((2, 10), (1, 0), (1, 11)):
+        ss = pa.sqp_settings_default(); ss.line_search = ls; ss.filter_max_depth = depth
+        with pytest.raises(RuntimeError):
+            ctx.sqp_solve_batch(pa.MODEL_ROBOT, 5, 2, 0.0, 2.0, 2, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
+
+
 def test_sqp_block_bfgs_vs_oracle(ctx, oracle):
     """hessian_update = 1 (ContinuousOCP's sparsity-preserving block BFGS, continuous_ocp.hpp:2304-2431): identical iteration counts
     and x within 1e-8 of the CPU restatement on the reference's MPC-test grid (P=5, S=3), on config A's grid and, with a free

@@ -462,6 +462,44 @@ def test_sqp_valet_parking_with_ruiz(oracle, pivot):
 
 
 @pytest.mark.parametrize("pivot", [0, 1])
+def test_sqp_valet_parking_as_the_reference_runs_it(oracle, pivot):
+    """valet_parking_mpc_test.cpp:183-240 with every hook that test installs: RuizEquilibration preconditioner, QP max_iter 1000,
+    the filter line search on LSFilter with beta = 0.1 (:116-158, :192; line_search.hpp:31-98) and ContinuousOCP's block BFGS
+    (:160-165). The filter is a member of the solver, so it is carried from the cold solve into the warm-started one. Both solves
+    must be SOLVED in < 10 iterations (:216-217, :238-239)."""
+    ss = oracle.sqp_default_settings(); ss.max_iter = 10; ss.line_search_max_iter = 10
+    ss.preconditioner = 1; ss.hessian_update = 1; ss.line_search = 1; ss.filter_beta = 0.1
+    filt = np.zeros((1, oracle.FILTER_STATE_DOUBLES)); oracle.bind_filter_state(ss, filt)
+    qs = oracle.sqp_qp_default_settings(); qs.max_iter = 1000
+    kw = dict(sqp_settings=ss, qp_settings=qs, pivot=pivot, mparams=[1.0])
+    lbx, ubx = _valet_bounds([0.5, 0.5, 0.5])
+    x, lam, i1 = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 2.0, 1, [[2.0]], lbx, ubx, **kw)
+    assert i1[0].status == oracle.SQP_SOLVED and i1[0].iter < 10
+    assert 1 <= filt[0, 0] <= 10 and filt[0, 1] > 0                        # the filter now holds the accepted (cost, violation) pairs
+    lbx, ubx = _valet_bounds([0.3, 0.4, 0.45])
+    x2, lam2, i2 = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 2.0, 1, [[2.0]], lbx, ubx, x_guess=x, lam_guess=lam, **kw)
+    assert i2[0].status == oracle.SQP_SOLVED and i2[0].iter < 10
+    assert np.abs(x2[0, 30:33] - [0.3, 0.4, 0.45]).max() < 1e-3
+
+
+def test_ls_filter_list_semantics(oracle):
+    """LSFilter (line_search.hpp:31-98) through the state the solver exports: a dominated entry is removed when a better point is
+    added (below max_depth), the newest pair sits in front, and a full filter drops its oldest entry instead."""
+    ss = oracle.sqp_default_settings(); ss.max_iter = 1; ss.line_search_max_iter = 10; ss.line_search = 1; ss.filter_beta = 0.1
+    lbx, ubx = _valet_bounds([0.5, 0.5, 0.5])
+    # a pre-loaded filter whose single entry is dominated by the start point (cost 0, violation 1.5): replaced, then the step is added in front
+    filt = np.zeros((1, oracle.FILTER_STATE_DOUBLES)); filt[0, :3] = [1, 5.0, 9.0]; oracle.bind_filter_state(ss, filt)
+    oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 2.0, 1, [[2.0]], lbx, ubx, sqp_settings=ss, mparams=[1.0])
+    assert filt[0, 0] == 2 and filt[0, 3] == 0.0 and abs(filt[0, 4] - 1.5) < 1e-12 and filt[0, 2] < 1.5
+    # a full filter (10 entries that nothing dominates and that block nothing): the oldest entry leaves, the count stays 10
+    full = np.zeros((1, oracle.FILTER_STATE_DOUBLES)); full[0, 0] = 10
+    for i in range(10): full[0, 1 + 2 * i], full[0, 2 + 2 * i] = 100.0 + i, 100.0 + i
+    oracle.bind_filter_state(ss, full)
+    oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 2.0, 1, [[2.0]], lbx, ubx, sqp_settings=ss, mparams=[1.0])
+    assert full[0, 0] == 10 and full[0, 19] == 100.0 + 7 and full[0, 3] == 0.0 and abs(full[0, 4] - 1.5) < 1e-12
+
+
+@pytest.mark.parametrize("pivot", [0, 1])
 def test_sqp_robot_mpc_warm_start_block_bfgs(oracle, pivot):
     """mpc_wrapper_test.cpp:120-166 with the Hessian update that test actually selects (MySolver::hessian_update_impl ->
     ContinuousOCP::hessian_update_impl, the block BFGS of continuous_ocp.hpp:2304-2431): SOLVED, and the warm-started second solve

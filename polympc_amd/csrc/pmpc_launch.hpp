@@ -18,7 +18,7 @@ using ::pmpc_status;
 
 constexpr int FILTER_LDS_DOUBLES = 24;   // PMPC_FILTER_STATE_DOUBLES rounded up
 
-template <class Model, int NN = 0, int MM = 0, bool PROF = false>
+template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0>
 #ifndef PMPC_SQP_WAVES
 #define PMPC_SQP_WAVES 2
 #endif
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64, (NN > 0 ? PMPC_SQP_WAVES : 1)) void sqp_kernel(
     // stacked workspace K0 = [H ; J] ((n+m) x n, column-major, leading dimension n+m): lane i reads row i of K0 with ONE stride
     double* K0 = Hws + (size_t)b * (size_t)(n + m) * n;
     (void)Aws;
-    SqpDevice<Model, NN, MM, PROF> sqp(ocp, v, qw, K0, K0 + n, ss, qs);
+    SqpDevice<Model, NN, MM, PROF, HU> sqp(ocp, v, qw, K0, K0 + n, ss, qs);
     sqp.filt = filt;
     sqp.tr = ocp.s.fval;   // first per-node staging array: everything from here on is dead while the QP runs
     {   // side-by-side line search: G candidates x (m constraint values + NN Lagrange values) + 3 scalars each, in the same region
@@ -176,7 +176,8 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
         if (P * S + 1 != NNODES) return false;
         const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, 1);
         if (ldsr > lds_limit) return false;
-        auto kern = phase ? sqp_kernel<Model, NN_, MM_, true> : sqp_kernel<Model, NN_, MM_, false>;
+        auto kern = (ss->hessian_update == 1) ? sqp_kernel<Model, NN_, MM_, false, 1>   // (no phase timers in the block-BFGS specialisation)
+                                              : (phase ? sqp_kernel<Model, NN_, MM_, true> : sqp_kernel<Model, NN_, MM_, false>);
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
         const int slice = (slice_state && slice_iters > 0) ? slice_iters : ss->max_iter;
         for (int it = 0; it < ss->max_iter; it += slice)
@@ -209,7 +210,7 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     if ((ss->hessian_update != 0 && ss->hessian_update != 1) || (ss->qp_solver != 0 && ss->qp_solver != 1)) return PMPC_ERR_INVALID_ARGUMENT;
     if ((ss->line_search != 0 && ss->line_search != 1) ||
         (ss->line_search == 1 && (ss->filter_max_depth < 1 || ss->filter_max_depth > PMPC_FILTER_MAX_DEPTH))) return PMPC_ERR_INVALID_ARGUMENT;
-    if (!force_lds && ss->preconditioner == 0 && ss->hessian_update == 0 && ss->qp_solver == 0 && ss->line_search == 0) {   // node counts whose KKT system can fit 64 rows for small models (7 nodes: config A / D); Ruiz: LDS path
+    if (!force_lds && ss->preconditioner == 0 && ss->qp_solver == 0 && ss->line_search == 0) {   // node counts whose KKT system can fit 64 rows for small models (7 nodes: config A / D); Ruiz: LDS path
         pmpc_status rst = PMPC_OK;
         if (try_launch_reg<Model, 7>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;
         if (try_launch_reg<Model, 5>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;

@@ -38,7 +38,9 @@ constexpr int PMPC_SQP_IN_PROGRESS = 3;   // internal: the instance continues in
 
 // NN, MM > 0: compile-time QP size with NN+MM <= 64 -> register-resident QP (pmpc_qp_reg.hpp); 0 -> LDS-resident QP
 // PROF: accumulate per-phase shader-clock cycles (separate kernel instantiation; costs 16+ VGPRs, off by default)
-template <class Model, int NN = 0, int MM = 0, bool PROF = false>
+// HU: Hessian-update policy compiled into a register-resident specialisation (0 dense damped BFGS, 1 block BFGS); the LDS-resident
+// kernels (NN == 0) select it at run time from settings.hessian_update
+template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0>
 struct SqpDevice {
     using Dm = OcpDims<Model>;
     // Ruiz scaling is compiled into the LDS / HBM-resident QP kernels only: the launcher routes preconditioner = 1 there. In the
@@ -434,7 +436,8 @@ struct SqpDevice {
             lagrangian_gradient(v.lgn);
             acc(12, l3 - l1); acc(14, now() - l3);
             const long long b0 = now();
-            if constexpr (NN > 0) { double brow[NN > 0 ? NN : 1]; bfgs_load_row(brow); bfgs_update_reg(brow); }
+            if constexpr (NN > 0 && HU == 1) bfgs_update_block();
+            else if constexpr (NN > 0) { double brow[NN > 0 ? NN : 1]; bfgs_load_row(brow); bfgs_update_reg(brow); }
             else { if (__builtin_amdgcn_readfirstlane(ss.hessian_update) == 1) bfgs_update_block(); else bfgs_update(); }   // (the launcher routes hessian_update = 1 to these kernels)
             acc(5, now() - b0);
             for (int i = lane_id(); i < n; i += WAVE) v.lg[i] = v.lgn[i];

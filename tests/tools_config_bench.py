@@ -27,6 +27,8 @@ for name in (sys.argv[1:] or ["A", "B", "C", "D"]):
     d_lam = torch.zeros(B, m + n, dtype=torch.float64, device=dev)
     d_info = torch.zeros(B, 48, dtype=torch.uint8, device=dev)
     ss = pa.sqp_settings_default(); ss.max_iter = wl["max_iter"]; ss.line_search_max_iter = wl["ls_max_iter"]
+    for fld in ("hessian_update", "preconditioner", "qp_solver", "line_search"):   # policy flags: HESSIAN_UPDATE=1 python tests/tools_config_bench.py A
+        if fld.upper() in os.environ: setattr(ss, fld, int(os.environ[fld.upper()]))
     qs = pa.qp_settings_sqp_default()
     step = lambda: ctx.sqp_solve_batch_dev(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, d_d, d_lbx, d_ubx, d_x, d_lam, d_info, ss, qs)
     step(); torch.cuda.synchronize(dev)

@@ -165,6 +165,24 @@ def main():
                                  "dependent-chain latency, not by HBM: see roofline_fp64 and DESIGN.md"},
             "roofline_fp64": {"bound": "fp64-valu", "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / PEAK_FP64_TFLOPS},
         }
+        if world == 1:
+            # the same batch with the Hessian update the reference's own mobile-robot MPC test plugs in (mpc_wrapper_test.cpp:100-105:
+            # ContinuousOCP's block BFGS). Reported beside the bench line, which stays on SQPBase's defaults (dense damped BFGS).
+            ss2 = pa.sqp_settings_default(); ss2.max_iter = wl["max_iter"]; ss2.line_search_max_iter = wl["ls_max_iter"]; ss2.hessian_update = 1
+            vx, vl, vi = torch.zeros_like(d_x), torch.zeros_like(d_lam), torch.zeros_like(d_info)
+            vstep = lambda: ctx.sqp_solve_batch_dev(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, d_d, d_lbx, d_ubx, vx, vl, vi, ss2, qs)
+            for _ in range(args.warmup):
+                vstep()
+            torch.cuda.synchronize(dev)
+            tv = time.perf_counter()
+            for _ in range(args.steps):
+                vstep()
+            torch.cuda.synchronize(dev)
+            tv = (time.perf_counter() - tv) / args.steps
+            vinfo = np.frombuffer(vi.cpu().numpy().tobytes(), dtype=pa.capi.SQP_INFO_DTYPE)
+            out["variant_block_bfgs"] = {"settings": "hessian_update = 1 (continuous_ocp.hpp:2304-2431), everything else as the bench line",
+                                         "ms_per_step": tv * 1e3, "qp_solves_per_s": int(vinfo["iter"].sum()) / tv,
+                                         "sqp_solves_per_s": B / tv, "sqp_solved_fraction": float((vinfo["status"] == pa.SQP_SOLVED).mean())}
         if args.cpu_sample > 0 and world == 1:
             from oracle import binding as ob   # CPU restatement of the reference algorithm: baseline only, never the product path
             Bc = min(args.cpu_sample, B)

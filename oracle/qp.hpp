@@ -29,7 +29,7 @@
 namespace oracle {
 
 enum qp_status { QP_SOLVED = 0, QP_MAX_ITER_EXCEEDED = 1, QP_UNSOLVED = 2, QP_UNINITIALIZED = 3, QP_INFEASIBLE = 4, QP_INCONSISTENT = 5 };
-enum pivot_policy { PIVOT_EIGEN = 0, PIVOT_STATIC = 1, PIVOT_SWEEP = 2 };
+enum pivot_policy { PIVOT_EIGEN = 0, PIVOT_STATIC = 1, PIVOT_SWEEP = 2, PIVOT_SWEEP1 = 3 };
 
 struct qp_settings {  // qp_base.hpp:17-53 (ADMM-related subset)
     double eps_rel = 1e-3, eps_abs = 1e-3;
@@ -62,6 +62,7 @@ struct LDLT {
     void compute(const std::vector<double>& K, int n_, pivot_policy pol) {
         n = n_; policy = pol; M = K; tr.assign(n, 0); temp.assign(n, 0.0);
         if (policy == PIVOT_STATIC) { compute_static(); return; }
+        if (policy == PIVOT_SWEEP1) { compute_sweep1(); return; }
         if (policy == PIVOT_SWEEP) {   // mirrors the register-resident kernel, which exists for at most 64 KKT rows (4 column blocks of 16)
             if (n > 64) throw std::invalid_argument("oracle: PIVOT_SWEEP restates the 64-row register kernel; use PIVOT_STATIC / PIVOT_EIGEN for larger systems");
             compute_sweep(); return;
@@ -120,6 +121,26 @@ struct LDLT {
     //   trailing update          i, j outside the block, i/16 >= j/16 (block-lower storage in 16x16 tiles; the other
     //                            entries are their mirror images):  M[i][j] = fma(-p[i][t], Cold[j][t], M[i][j]),  t ascending
     //   write-back               M[:, block] = p,  then M[block, :] = p^T
+    // PIVOT_SWEEP1: W = -K^{-1} by the symmetric sweep operator one pivot at a time on the lower triangle (any size) — the order of the
+    // LDS-resident inverse kernel: for pivot k, r = 1/K_kk, l_i = K_ik * r, every other lower entry (i >= j, i, j != k) becomes
+    // fma(-l_i, K_jk, K_ij) with the UNSCALED column entries K_jk of before the step; then column k <- l, K_kk <- -r.
+    void compute_sweep1() {
+        auto lo = [&](int i, int j) -> double& { return i >= j ? M[i + j * n] : M[j + i * n]; };
+        for (int k = 0; k < n; ++k) tr[k] = k;
+        std::vector<double> c(n), l(n);
+        for (int k = 0; k < n; ++k) {
+            const double r = 1.0 / lo(k, k);
+            for (int i = 0; i < n; ++i) { c[i] = lo(i, k); l[i] = c[i] * r; }
+            for (int j = 0; j < n; ++j) {
+                if (j == k) continue;
+                for (int i = j; i < n; ++i) { if (i == k) continue; M[i + j * n] = std::fma(-l[i], c[j], M[i + j * n]); }
+            }
+            for (int i = 0; i < n; ++i) if (i != k) lo(i, k) = l[i];
+            lo(k, k) = -r;
+        }
+        for (int j = 0; j < n; ++j) for (int i = 0; i < j; ++i) M[i + j * n] = M[j + i * n];   // mirror for solve()
+    }
+
     void compute_sweep() {
         auto at = [&](int i, int j) -> double& { return M[i + j * n]; };
         for (int k = 0; k < n; ++k) tr[k] = k;
@@ -158,6 +179,10 @@ struct LDLT {
 
     void solve(const double* b, double* x) const {
         auto at = [&](int i, int j) -> double { return M[i + j * n]; };
+        if (policy == PIVOT_SWEEP1) {   // x = -(W b): one fma chain per row, columns ascending
+            for (int i = 0; i < n; ++i) { double a = 0.0; for (int j = 0; j < n; ++j) a = std::fma(at(i, j), b[j], a); x[i] = -a; }
+            return;
+        }
         if (policy == PIVOT_SWEEP) {   // x = -(W b): one fma chain per block of 16 columns (P_r, r = j/16), combined as (P0+P2)+(P1+P3)
             for (int i = 0; i < n; ++i) {
                 double acc[4] = {0.0, 0.0, 0.0, 0.0};

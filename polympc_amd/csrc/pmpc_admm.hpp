@@ -17,7 +17,7 @@
 namespace pmpc {
 
 // K (lower triangle) <- [H + diag(kdiag[0:n]) ; A ; I | diag(kdiag[n:])]
-__device__ inline void admm_kkt_build(const QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ A, int lda) {
+__device__ __forceinline__ void admm_kkt_build(const QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ A, int lda) {
     const int ln = lane_id();
     const int me = m + n;
     for (int j = 0; j < n; ++j) {
@@ -35,7 +35,7 @@ __device__ inline void admm_kkt_build(const QpLds& w, int n, int m, const double
 
 struct AdmmResidualState { double max_Ax_z_norm, max_Hx_ATy_h_norm, res_prim, res_dual; };
 
-__device__ inline void admm_residuals(const QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ h,
+__device__ __forceinline__ void admm_residuals(const QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ h,
                                       const double* __restrict__ A, int lda, AdmmResidualState& r) {
     const int ln = lane_id();
     double nAx = 0, nz = 0, rp = 0;
@@ -62,7 +62,7 @@ __device__ inline void admm_residuals(const QpLds& w, int n, int m, const double
     r.res_dual = wave_max(rd);
 }
 
-__device__ inline void admm_rho_vec_update(const QpLds& w, int n, int m, const double* Alb, const double* Aub, const double* xl, const double* xu, double rho0) {
+__device__ __forceinline__ void admm_rho_vec_update(const QpLds& w, int n, int m, const double* Alb, const double* Aub, const double* xl, const double* xu, double rho0) {
     const int ln = lane_id();
     for (int i = ln; i < m + n; i += WAVE) {
         const int t = (i < m) ? classify_bounds(Alb[i], Aub[i]) : classify_bounds(xl[i - m], xu[i - m]);
@@ -72,7 +72,7 @@ __device__ inline void admm_rho_vec_update(const QpLds& w, int n, int m, const d
 }
 
 // ADMM::solve_impl. w carved with QpLds::carve(base, n, m + n). Result in w.x (n) and w.y (m+n).
-__device__ inline void admm_solve(QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* h, const double* __restrict__ A, int lda,
+__device__ __forceinline__ void admm_solve(QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* h, const double* __restrict__ A, int lda,
                                   const double* Alb, const double* Aub, const double* xl, const double* xu, const double* x0, const double* y0,
                                   const pmpc_qp_settings& s, pmpc_qp_info& info) {
     const int ln = lane_id();

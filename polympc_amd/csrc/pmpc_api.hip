@@ -18,6 +18,11 @@
 #include "pmpc_ruiz.hpp"
 #include "pmpc_admm.hpp"
 
+namespace pmpc {   // LDS-resident kernels that also exist with phase timers (PMPC_PHASE_PROFILE=1): the two models of configs A' / B
+template <> struct LDS_PATH_PROFILED<RobotOCP> { static constexpr bool value = true; };
+template <> struct LDS_PATH_PROFILED<CstrOCP> { static constexpr bool value = true; };
+}
+
 using namespace pmpc;
 
 // =====================================================================================================================

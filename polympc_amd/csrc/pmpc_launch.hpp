@@ -18,7 +18,10 @@ using ::pmpc_status;
 
 constexpr int FILTER_LDS_DOUBLES = 24;   // PMPC_FILTER_STATE_DOUBLES rounded up
 
-template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0>
+// KHBM: large-instance mode of the LDS-resident kernels — the KKT factor lives in an HBM workspace (Kws). A compile-time flag so
+// that in the normal mode every QP pointer provably addresses LDS (ds_read / ds_write instead of flat accesses, which cost the
+// LDS path most of its time when the location of K was a run-time choice)
+template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bool KHBM = false>
 #ifndef PMPC_SQP_WAVES
 #define PMPC_SQP_WAVES 2
 #endif
@@ -41,13 +44,13 @@ __global__ __launch_bounds__(64, (NN > 0 ? PMPC_SQP_WAVES : 1)) void sqp_kernel(
     const int n = ocp.dm.n, m = ocp.dm.m, mi = ocp.dm.mi;
     QpLds qw; SqpLds v;
     // Kws != nullptr: large-instance mode — the KKT factor lives in an HBM workspace (does not fit LDS)
-    double* p = (NN > 0 || Kws) ? qw.carve_xy(smem, n, m) : qw.carve(smem, n, ss.qp_solver == 1 ? m + n : m);   // ADMM: stacked constraint rows
+    double* p = (NN > 0 || KHBM) ? qw.carve_xy(smem, n, m) : qw.carve(smem, n, ss.qp_solver == 1 ? m + n : m);   // ADMM: stacked constraint rows
     p = v.carve(p, n, m, mi);
     double* stage0 = p;
     p = ocp.s.carve(p, P, S);
     if (NN > 0 && (size_t)(p - stage0) < (size_t)RegKkt<(NN > 0 ? NN + MM : 1)>::TRI + ocp.s.const_doubles(P, S)) p = stage0 + RegKkt<(NN > 0 ? NN + MM : 1)>::TRI + ocp.s.const_doubles(P, S);
     // large-instance mode: the remaining QP vectors reuse the second-order AD staging (dead while the QP runs)
-    if (NN == 0 && Kws) qw.carve_rest(ocp.s.Lhes, n, m, Kws + (size_t)b * QpLds::kdoubles(n + m));
+    if constexpr (NN == 0 && KHBM) qw.carve_rest(ocp.s.Lhes, n, m, Kws + (size_t)b * QpLds::kdoubles(n + m));
     double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
     const int ln = lane_id();
     for (int i = ln; i < Model::ND; i += WAVE) dL[i] = d[(size_t)b * Model::ND + i];
@@ -82,7 +85,8 @@ __global__ __launch_bounds__(64, (NN > 0 ? PMPC_SQP_WAVES : 1)) void sqp_kernel(
         const int G = WAVE / ocp.dm.NN;
         const size_t need = (size_t)G * (m + ocp.dm.NN + 3);
         const size_t have = (size_t)((smem + lds_doubles_total) - ocp.s.fval);
-        sqp.lsbuf = (G >= 2 && need <= have) ? ocp.s.fval : nullptr;
+        sqp.lsbuf = ocp.s.fval;   // a flag, not a null pointer, says whether it fits (compiler hazard 7: null tests of LDS pointers)
+        sqp.ls_side_by_side = (G >= 2 && need <= have);
     }
     pmpc_sqp_info si;
     if (it_begin > 0) { const pmpc_sqp_info prev = info[b]; sqp.qp_iter_total = prev.qp_solver_iter; sqp.cost_log = prev.cost; }
@@ -161,6 +165,9 @@ template <class Model> inline size_t linearise_kernel_lds_bytes(int P, int S) {
 }
 
 
+// models whose LDS-resident kernel also exists with phase timers (PMPC_PHASE_PROFILE=1)
+template <class Model> struct LDS_PATH_PROFILED { static constexpr bool value = false; };
+
 // Launch the fused SQP kernel for `Model` on DEVICE buffers (asynchronous on the context's stream).
 // Register-resident QP specialisations are selected from the compile-time model dimensions and the runtime node count
 // when the KKT system has at most 64 rows; otherwise the LDS-resident path is used.
@@ -226,10 +233,12 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
         if (st != PMPC_OK) return st;
         Hws = ws; Aws = ws + (size_t)B * dm.n * dm.n; slice_state = Aws + (size_t)B * dm.m * dm.n; Kws = ws + base;
     }
-    if (hipFuncSetAttribute((const void*)sqp_kernel<Model>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PMPC_ERR_HIP;
+    auto lkern = Kws ? sqp_kernel<Model, 0, 0, false, 0, true> : sqp_kernel<Model>;
+    if constexpr (LDS_PATH_PROFILED<Model>::value) { if (phase && !Kws) lkern = sqp_kernel<Model, 0, 0, true>; }   // developer builds of two models carry phase timers
+    if (hipFuncSetAttribute((const void*)lkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PMPC_ERR_HIP;
     const int slice = (slice_iters > 0) ? slice_iters : ss->max_iter;
     for (int it = 0; it < ss->max_iter; it += slice)
-        hipLaunchKernelGGL((sqp_kernel<Model>), dim3(B), dim3(WAVE), lds, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, *ss, *qs, Hws, Aws,
+        hipLaunchKernelGGL(lkern, dim3(B), dim3(WAVE), lds, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, *ss, *qs, Hws, Aws,
                            x, lam, info, phase, Kws, it, it + slice, slice_state, (unsigned)(lds / sizeof(double)));
     return (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
 }

@@ -64,7 +64,7 @@ struct OcpLds {
         const int NN = P * S + 1;
         return (size_t)(P + 1) * (P + 1) + (P + 1) + NN + 3 * (size_t)NN + (size_t)(NN + 1) / 2;
     }
-    __device__ double* carve(double* p, int P, int S) {
+    __device__ __forceinline__ double* carve(double* p, int P, int S) {
         const int NN = P * S + 1;
         D = p; p += (P + 1) * (P + 1); w = p; p += P + 1; tn = p; p += NN;
         nd = p; p += NN; nw1 = p; p += NN; nw2 = p; p += NN; nsr = (int*)p; p += (NN + 1) / 2;
@@ -91,7 +91,7 @@ struct Ocp {
 
     __device__ Ocp(const Model& mdl, int P_, int S_, double t_scale) : model(mdl), dm(P_, S_), P(P_), S(S_), ts(t_scale), d(nullptr) {}
 
-    __device__ void stage_constants(const ChebData* cd) {
+    __device__ __forceinline__ void stage_constants(const ChebData* cd) {
         const int ln = lane_id();
         for (int i = ln; i < (P + 1) * (P + 1); i += WAVE) s.D[i] = cd->D[i];
         for (int i = ln; i <= P; i += WAVE) s.w[i] = cd->w[i];
@@ -118,7 +118,7 @@ struct Ocp {
     }
 
     // ---- values only: c = D*X - t_scale*f, g (equalities :739-766, inequalities :770-782)
-    __device__ void constraints(const double* var, double* c) {
+    __device__ __forceinline__ void constraints(const double* var, double* c) {
         for (int k = lane_id(); k < dm.NN; k += WAVE) {
             double f[NX > 0 ? NX : 1];
             for (int q = 0; q < NX; ++q) f[q] = 0.0;
@@ -145,7 +145,7 @@ struct Ocp {
     }
 
     // ---- cost (:1182-1207)
-    __device__ double cost(const double* var) {
+    __device__ __forceinline__ double cost(const double* var) {
         for (int k = lane_id(); k < dm.NN; k += WAVE) {
             double L = 0.0;
             model.template lagrange_term_impl<double>(cref<double>(var + k * NX), cref<double>(var + dm.VARX + k * NU),
@@ -355,7 +355,7 @@ struct Ocp {
     // structure = false: J already holds a linearisation of THIS problem — its zeros and its differentiation-matrix entries
     // do not depend on the iterate, so only the per-node blocks (D self entry - t_scale*df, dg) are rewritten.
     template <bool WANT_COST = true>
-    __device__ double assemble_first_order(double* c, double* __restrict__ J, double* cost_grad, int ldj, bool structure = true) {
+    __device__ __forceinline__ double assemble_first_order(double* c, double* __restrict__ J, double* cost_grad, int ldj, bool structure = true) {
         const int ln = lane_id();
         const int n = dm.n, m = dm.m;
         if (structure) {

@@ -130,7 +130,7 @@ struct QpLds {
     }
     // register-resident QP path: only the result vectors live in LDS
     __host__ __device__ static size_t doubles_xy(int n, int m) { return 2 * (size_t)n + (size_t)m + 8; }
-    __device__ double* carve_xy(double* base, int n, int m) {
+    __device__ __forceinline__ double* carve_xy(double* base, int n, int m) {
         N = n + m; K = nullptr;
         double* p = base;
         x = p; p += n; y = p; p += N;
@@ -139,13 +139,13 @@ struct QpLds {
     }
     // large-instance mode: x, y as carve_xy; K in an HBM workspace; every other vector in a caller-provided LDS region
     __host__ __device__ static size_t doubles_rest(int n, int m) { return 3 * (size_t)n + 5 * (size_t)m + 4 * (size_t)(n + m); }
-    __device__ void carve_rest(double* p, int n, int m, double* K_hbm) {
+    __device__ __forceinline__ void carve_rest(double* p, int n, int m, double* K_hbm) {
         N = n + m; K = K_hbm;
         q = p; p += n; kdiag = p; p += N;
         z = p; p += m; zt = p; p += m; zprev = p; p += m; rho = p; p += m; rhoinv = p; p += m;
         rhob = p; p += n; rhobinv = p; p += n; rhs = p; p += N; t1 = p; p += N; t2 = p; p += N;
     }
-    __device__ double* carve(double* base, int n, int m) {
+    __device__ __forceinline__ double* carve(double* base, int n, int m) {
         N = n + m;
         double* p = base;
         K = p; p += kdoubles(N) + 2 * WAVE_DUMMY;   // K[kdoubles(N) + lane], K[kdoubles(N) + 64 + lane]: dummy slots of the branch-free factor
@@ -157,8 +157,41 @@ struct QpLds {
 };
 
 // K (lower triangle) <- [H + diag(kdiag[0:n]) ; A, diag(kdiag[n:])]  (construct_kkt_matrix, box_admm.hpp:209-223)
-__device__ inline void kkt_build(const QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ A, int lda) {
+__device__ __forceinline__ void kkt_build(const QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ A, int lda) {
     const int ln = lane_id();
+    const int N = n + m;
+    if (N <= 2 * WAVE) {
+        // at most two rows per lane (i0 = lane, i1 = lane + 64): the global loads of eight columns are issued together before the
+        // first LDS store, instead of one dependent load -> store round trip per column segment
+        const int i0 = ln, i1 = ln + WAVE;
+        const bool h0 = i0 < N, h1 = i1 < N;
+        constexpr int CB = 8;
+        for (int j0 = 0; j0 < n; j0 += CB) {
+            double e0[CB], e1[CB];
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                const int j = (j0 + u < n) ? j0 + u : n - 1;
+                e0[u] = 0.0; e1[u] = 0.0;
+                if (h0 && i0 > j) e0[u] = (i0 < n) ? H[(size_t)j * ldh + i0] : A[(size_t)j * lda + (i0 - n)];
+                if (h1 && i1 > j) e1[u] = (i1 < n) ? H[(size_t)j * ldh + i1] : A[(size_t)j * lda + (i1 - n)];
+            }
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                const int j = j0 + u;
+                if (j < n) {
+                    const int o = w.off(j);
+                    if (h0 && i0 >= j) w.K[o + i0] = (i0 == j) ? w.kdiag[i0] : e0[u];
+                    if (h1 && i1 >= j) w.K[o + i1] = (i1 == j) ? w.kdiag[i1] : e1[u];
+                }
+            }
+        }
+        for (int j = 0; j < m; ++j) {
+            const int o = w.off(n + j);
+            for (int i = j + ln; i < m; i += WAVE) w.K[o + n + i] = (i == j) ? w.kdiag[n + i] : 0.0;
+        }
+        wsync();
+        return;
+    }
     for (int j = 0; j < n; ++j) {
         const int o = w.off(j);
         for (int i = j + ln; i < n; i += WAVE) w.K[o + i] = (i == j) ? w.kdiag[i] : H[(size_t)j * ldh + i];
@@ -179,7 +212,7 @@ __device__ __forceinline__ double bcast_uniform(double v, int lane) {
 }
 
 // in-place LDL^T, static order, right-looking (factorise_kkt_matrix, box_admm.hpp:336-341)
-__device__ inline void kkt_factor(const QpLds& w, int N) {
+__device__ __forceinline__ void kkt_factor(const QpLds& w, int N) {
     const int ln = lane_id();
     double* K = w.K;
     if (N <= 2 * WAVE) {
@@ -270,7 +303,7 @@ __device__ inline void kkt_factor(const QpLds& w, int N) {
 }
 
 // v <- K^{-1} v  (linear_solver.solve, box_admm.hpp:123), v in LDS
-__device__ inline void kkt_solve(const QpLds& w, int N, double* v) {
+__device__ __forceinline__ void kkt_solve(const QpLds& w, int N, double* v) {
     const int ln = lane_id();
     const double* K = w.K;
     if (N <= 2 * WAVE) {
@@ -380,7 +413,7 @@ __device__ inline void kkt_solve(const QpLds& w, int N, double* v) {
 struct QpResidualState { double max_Ax_z_norm, max_Hx_ATy_h_norm, res_prim, res_dual; };
 
 // residuals_update, box_admm.hpp:398-415 (H, A streamed from global memory, coalesced down the columns)
-__device__ inline void qp_residuals(const QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ h,
+__device__ __forceinline__ void qp_residuals(const QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ h,
                                     const double* __restrict__ A, int lda, QpResidualState& r) {
     const int ln = lane_id();
     double nAx = 0, nz = 0, nx = 0, rp = 0;
@@ -408,7 +441,7 @@ __device__ inline void qp_residuals(const QpLds& w, int n, int m, const double* 
     r.res_dual = rd;
 }
 
-__device__ inline void rho_vec_update(const QpLds& w, int n, int m, const double* Alb, const double* Aub, const double* xlb,
+__device__ __forceinline__ void rho_vec_update(const QpLds& w, int n, int m, const double* Alb, const double* Aub, const double* xlb,
                                       const double* xub, double rho0) {
     const int ln = lane_id();
     for (int i = ln; i < m; i += WAVE) { const double r = rho_of(classify_bounds(Alb[i], Aub[i]), rho0); w.rho[i] = r; w.rhoinv[i] = 1.0 / r; }
@@ -417,12 +450,13 @@ __device__ inline void rho_vec_update(const QpLds& w, int n, int m, const double
 
 // boxADMM::solve_impl (box_admm.hpp:88-205). Result in w.x (n) and w.y (m+n). h/Alb/Aub/xlb/xub may live in LDS or HBM.
 // H(i,j) = H[j*ldh + i], A(r,j) = A[j*lda + r]  (ldh = n, lda = m for plain column-major inputs)
-__device__ inline void boxadmm_solve(QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* h,
+__device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* h,
                                      const double* __restrict__ A, int lda, const double* Alb, const double* Aub, const double* xlb,
                                      const double* xub, const double* x0, const double* y0, const pmpc_qp_settings& s,
-                                     pmpc_qp_info& info) {
+                                     pmpc_qp_info& info, long long* tm = nullptr) {   // tm (phase profiling): [0] build + factor, [1] residuals, [2] substitutions, [3] build alone
     const int ln = lane_id();
     const int N = n + m;
+    auto tick = [&]() -> long long { return tm ? clock64() : 0; };
     // x = x_guess; y = y_guess; z = A*x_guess; q = x_guess  (:97-100)
     for (int i = ln; i < n; i += WAVE) { const double v = x0 ? x0[i] : 0.0; w.x[i] = v; w.q[i] = v; }
     for (int i = ln; i < N; i += WAVE) w.y[i] = y0 ? y0[i] : 0.0;
@@ -440,8 +474,11 @@ __device__ inline void boxadmm_solve(QpLds& w, int n, int m, const double* __res
     for (int i = ln; i < n; i += WAVE) { double dgl = H[(size_t)i * ldh + i]; dgl += s.sigma; dgl += w.rhob[i]; w.kdiag[i] = dgl; }
     for (int i = ln; i < m; i += WAVE) w.kdiag[n + i] = -w.rhoinv[i];
     wsync();
-    kkt_build(w, n, m, H, ldh, A, lda);
-    kkt_factor(w, N);
+    { const long long t0 = tick();
+      kkt_build(w, n, m, H, ldh, A, lda);
+      const long long t1 = tick();
+      kkt_factor(w, N);
+      if (tm) { tm[0] += tick() - t0; tm[3] += t1 - t0; } }
 
     int status = PMPC_QP_UNSOLVED;
     const double alpha = s.alpha;
@@ -453,7 +490,7 @@ __device__ inline void boxadmm_solve(QpLds& w, int n, int m, const double* __res
         for (int i = ln; i < n; i += WAVE) w.rhs[i] = ((s.sigma * w.x[i] - h[i]) + w.rhob[i] * w.q[i]) - w.y[m + i];
         for (int i = ln; i < m; i += WAVE) { w.zprev[i] = w.z[i]; w.rhs[n + i] = w.z[i] - w.rhoinv[i] * w.y[i]; }
         wsync();
-        kkt_solve(w, N, w.rhs);
+        { const long long t0 = tick(); kkt_solve(w, N, w.rhs); if (tm) tm[2] += tick() - t0; }
         for (int i = ln; i < m; i += WAVE) {
             const double zt = w.zprev[i] + w.rhoinv[i] * (w.rhs[n + i] - w.y[i]);
             double zz = alpha * zt;
@@ -474,7 +511,9 @@ __device__ inline void boxadmm_solve(QpLds& w, int n, int m, const double* __res
         wsync();
         const bool check = (s.check_termination != 0 && iter % s.check_termination == 0);
         if (check) {
+            const long long t0 = tick();
             qp_residuals(w, n, m, H, ldh, h, A, lda, rs);
+            if (tm) tm[1] += tick() - t0;
             const double ep = s.eps_abs + s.eps_rel * rs.max_Ax_z_norm, ed = s.eps_abs + s.eps_rel * rs.max_Hx_ATy_h_norm;
             if (rs.res_prim <= ep && rs.res_dual <= ed) { status = PMPC_QP_SOLVED; break; }
         }

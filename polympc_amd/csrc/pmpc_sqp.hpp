@@ -23,7 +23,7 @@ struct SqpLds {
     __host__ __device__ static size_t doubles(int n, int m, int mi) {
         return 12 * (size_t)n + 2 * (size_t)(m + n) + 3 * (size_t)m + 2 * (size_t)mi + 3 * (size_t)(n + m) + 8;
     }
-    __device__ double* carve(double* p, int n, int m, int mi) {
+    __device__ __forceinline__ double* carve(double* p, int n, int m, int mi) {
         x = p; p += n; lam = p; p += m + n; lam_k = p; p += m + n; h = p; p += n; lg = p; p += n; lgn = p; p += n;
         al = p; p += m; au = p; p += m; lx = p; p += n; ux = p; p += n; lbx = p; p += n; ubx = p; p += n;
         lbg = p; p += mi; ubg = p; p += mi; step = p; p += n; xs = p; p += n; cb = p; p += m;
@@ -50,6 +50,7 @@ struct SqpDevice {
     SqpLds& v;
     QpLds& qw;
     double* lsbuf = nullptr;   // LDS scratch of the side-by-side line search (aliases the MFMA staging, free outside the QP)
+    bool ls_side_by_side = false;   // lsbuf holds G >= 2 candidates
     bool cb_valid = false;     // v.cb holds the constraint values of the CURRENT iterate (set by the line search)
     double* tr = nullptr;  // LDS transpose scratch of the register-resident QP (aliases the per-node AD staging, dead during the QP)
     double* Hw;  // H(i,j) = Hw[j*ldw + i]  — upper block of the stacked (n+m) x n HBM workspace [H ; J]
@@ -75,7 +76,7 @@ struct SqpDevice {
         : ocp(o), v(v_), qw(q_), Hw(H_), Aw(A_), ldw(o.dm.n + o.dm.m), ss(s), qs(q), n(o.dm.n), m(o.dm.m), me(o.dm.me), mi(o.dm.mi) {}
 
     // constraints_violation_impl :423-444 (sequential sums, reference association order)
-    __device__ double constraints_violation(const double* xx) {
+    __device__ __forceinline__ double constraints_violation(const double* xx) {
         ocp.constraints(xx, v.cb);
         double cl1 = DBL_EPS;
         double s = 0.0;
@@ -89,7 +90,7 @@ struct SqpDevice {
         return cl1;
     }
     // max_constraints_violation_impl :448-474
-    __device__ double max_constraints_violation(const double* xx) {
+    __device__ __forceinline__ double max_constraints_violation(const double* xx) {
         if (!cb_valid) ocp.constraints(xx, v.cb);   // otherwise the accepted line-search candidate already evaluated them at this point
         const int ln = lane_id();
         const int n = n_ct(), me = me_ct(), mi = mi_ct();
@@ -109,7 +110,7 @@ struct SqpDevice {
     // same values; lane 0 alone edits the list. Compiled into the LDS-resident kernels only (the launcher routes line_search = 1 there).
     double* filt = nullptr;
     __device__ __forceinline__ bool filter_mode() const { if constexpr (NN == 0) return __builtin_amdgcn_readfirstlane(ss.line_search) == 1; else return false; }
-    __device__ bool filter_is_acceptable(double cost, double constraint) const {   // :65-74
+    __device__ __forceinline__ bool filter_is_acceptable(double cost, double constraint) const {   // :65-74
         int cnt = (int)filt[0];
         if (cnt > PMPC_FILTER_MAX_DEPTH) cnt = PMPC_FILTER_MAX_DEPTH;
         const double beta = ss.filter_beta;
@@ -121,7 +122,7 @@ struct SqpDevice {
         }
         return __builtin_amdgcn_readfirstlane((int)ok) != 0;
     }
-    __device__ void filter_add(double cost, double constraint) {                   // :76-92 (remove_if(dominated_by) :14-29 keeps the order)
+    __device__ __forceinline__ void filter_add(double cost, double constraint) {                   // :76-92 (remove_if(dominated_by) :14-29 keeps the order)
         wsync();
         if (lane_id() == 0) {
             int cnt = (int)filt[0];
@@ -144,7 +145,7 @@ struct SqpDevice {
     }
 
     // step_size_selection_impl :380-419 ; p = QP primal step in qw.x  (one trial point at a time)
-    __device__ double step_size_selection_serial() {
+    __device__ __forceinline__ double step_size_selection_serial() {
         const double* p = qw.x;
         const int ln = lane_id();
         const double constr_l1 = constraints_violation(v.x);
@@ -182,10 +183,10 @@ struct SqpDevice {
     // constraints_violation_impl; the acceptance test then walks the candidates in the reference's order, so the chosen
     // alpha and the logged cost are those of the sequential loop. The accepted candidate's constraint values are kept
     // for the termination test (x + alpha*p is the same floating-point vector).
-    __device__ double step_size_selection() {
+    __device__ __forceinline__ double step_size_selection() {
         const int NNo = ocp.dm.NN;
         const int G = WAVE / NNo;
-        if (G < 2 || lsbuf == nullptr || ss.rho < 0.0) return step_size_selection_serial();   // (sqp rho is unused by the reference; negative = debug switch)
+        if (G < 2 || !ls_side_by_side || ss.rho < 0.0) return step_size_selection_serial();   // (sqp rho is unused by the reference; negative = debug switch)
         constexpr int NX = Model::NX, NU = Model::NU, NP = Model::NP, NG = Model::NG;
         const double* p = qw.x;
         const int ln = lane_id();
@@ -371,7 +372,7 @@ struct SqpDevice {
     }
 
     // lag_grad = J^T lam[0:m] + cost_grad + lam_box  (continuous_ocp.hpp:2112-2114)
-    __device__ void lagrangian_gradient(double* out) {
+    __device__ __forceinline__ void lagrangian_gradient(double* out) {
         if constexpr (NN > 0) {   // compile-time sizes: one batch of independent loads (column j of J), then the chain
             const int j = lane_id() < NN ? lane_id() : 0;
             const unsigned jo = (unsigned)j * (NN + MM) + opaque_zero();
@@ -398,7 +399,7 @@ struct SqpDevice {
     }
 
     // Gershgorin shift, dense_sparse_compare.cpp:109-122
-    __device__ void regularise_gershgorin() {
+    __device__ __forceinline__ void regularise_gershgorin() {
         for (int i = lane_id(); i < n; i += WAVE) {
             const double aii = Hw[(size_t)i * ldw + i];
             double ri = 0.0;
@@ -508,7 +509,7 @@ struct SqpDevice {
         wfence();
         wsync();
     }
-    __device__ void bfgs_update() {
+    __device__ __forceinline__ void bfgs_update() {
         const int ln = lane_id();
         double* Bs = v.t1; double* r = v.t2; double* y = v.t3;
         for (int i = ln; i < n; i += WAVE) {
@@ -538,7 +539,7 @@ struct SqpDevice {
     // (x_k, u_k) diagonal block gets the damped rank-2 update, with the global scalars s'Bs, s'y, s'r; NP > 0 adds the parameter
     // border and corner. One lane per updated entry; coefficients in the reference's association order
     //   (-scaling_inv * v_i) * v_j  then  += (c_inv * w_i) * w_j   (w = y or the damped r);  hes_xu = hes_ux'.
-    __device__ void bfgs_update_block() {
+    __device__ __forceinline__ void bfgs_update_block() {
         constexpr int NX = Model::NX, NU = Model::NU, NP = Model::NP, NB = NX + NU;
         const int ln = lane_id();
         const int VARX = ocp.dm.VARX, VARU = ocp.dm.VARU, NNo = ocp.dm.NN;
@@ -584,7 +585,7 @@ struct SqpDevice {
         wsync();
     }
     // B += -(Bs Bs^T)/sBs + (r r^T)/sr, element by element in the HBM workspace
-    __device__ void rank2_update_mem(const double* Bs, const double* r, double sBs, double sr) {
+    __device__ __forceinline__ void rank2_update_mem(const double* Bs, const double* r, double sBs, double sr) {
         const int ln = lane_id();
         for (int j = 0; j < n; ++j) {
             const double Bsj = Bs[j], rj = r[j];
@@ -600,7 +601,7 @@ struct SqpDevice {
     }
 
     // QP bounds :588-593
-    __device__ void form_qp_bounds() {
+    __device__ __forceinline__ void form_qp_bounds() {
         const int ln = lane_id();
         const int n = n_ct(), m = m_ct(), me = me_ct();
         for (int i = ln; i < m; i += WAVE) {
@@ -613,7 +614,7 @@ struct SqpDevice {
     }
 
     // one SQP iteration after (update_)linearisation: QP, line search, step, norms  (:588-632 / :652-683)
-    __device__ void qp_and_step() {
+    __device__ __forceinline__ void qp_and_step() {
         const int ln = lane_id();
         const int n = n_ct(), m = m_ct();
         const long long q0 = now();
@@ -635,7 +636,11 @@ struct SqpDevice {
         else {
             // Solver<Problem, ADMM<...>>: the launcher sized the QP's LDS for the stacked (2n+m)-row system when qp_solver = 1
             if (RUIZ_COMPILED && __builtin_amdgcn_readfirstlane(ss.qp_solver) == 1) admm_solve(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi);
-            else boxadmm_solve(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi);
+            else {
+                long long tq[4] = {0, 0, 0, 0};
+                boxadmm_solve(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, PROF ? tq : nullptr);
+                acc(6, tq[0]); acc(7, tq[1]); acc(17, tq[2]); acc(16, tq[3]);   // (slots 16 / 17 double as "KKT build" / "substitutions" on the LDS path)
+            }
         }
         qp_iter_total += qi.iter;
         if constexpr (RUIZ_COMPILED) if (ruiz) {   // unscale(p, p_lambda); unscale(m_H, m_h, m_A, ...), sqp_base.hpp:608-609 / :664-665
@@ -656,13 +661,13 @@ struct SqpDevice {
         dual_norm = alpha * dn;
         wsync();
     }
-    __device__ bool termination_criteria() {  // :524-529
+    __device__ __forceinline__ bool termination_criteria() {  // :524-529
         max_violation = max_constraints_violation(v.x);
         return (primal_norm <= ss.eps_prim) && (dual_norm <= ss.eps_dual) && (max_violation <= ss.eps_prim);
     }
 
     // SQP iterations it_begin+1 .. min(it_end, max_iter). status PMPC_SQP_IN_PROGRESS (internal) when the slice ends first.
-    __device__ void solve(pmpc_sqp_info& info, int it_begin, int it_end) {
+    __device__ __forceinline__ void solve(pmpc_sqp_info& info, int it_begin, int it_end) {
         int status = PMPC_SQP_MAX_ITER_EXCEEDED;
         int iter = it_begin;
         // single code site for the (large) QP + line-search body: first pass = exact linearisation (:583), later = update (:649)

@@ -25,14 +25,20 @@ def _mat(Hc, n, m=None):
     return Hc.reshape(n if m is None else n, -1).T if m is None else Hc.reshape(n, m).T
 
 
+def _lds_order(oracle, rows):
+    """The LDS- and HBM-resident kernels (boxADMM above 64 KKT rows or with a policy the register path does not carry, the stacked
+    system of the OSQP-form ADMM): static right-looking LDL^T with fma substitutions, whatever the size."""
+    return oracle.PIVOT_STATIC
+
+
 def _gpu_order(oracle, n, m, nodes=None):
-    """Which of the oracle's two GPU-order linear-solve restatements mirrors the kernel that serves this size: the
-    register-resident QP (compile-time sizes with n+m <= 64: the (35, 21) QP entry point, SQP grids of 7 or 5 nodes)
-    applies the swept inverse (PIVOT_SWEEP); every other size runs the LDS/HBM-resident static LDL^T (PIVOT_STATIC).
-    Both are tied to the reference's pivoted Eigen LDLT (PIVOT_EIGEN) in tests/test_oracle_pins.py."""
+    """Which of the oracle's GPU-order linear-solve restatements mirrors the kernel that serves this size: the register-resident QP
+    (compile-time sizes with n+m <= 64: the (35, 21) QP entry point, SQP grids of 7 or 5 nodes) applies the inverse swept in blocks of
+    four pivots (PIVOT_SWEEP); every other size runs an LDS/HBM-resident kernel (_lds_order: PIVOT_STATIC). All of them are tied to the reference's
+    pivoted Eigen LDLT (PIVOT_EIGEN) in tests/test_oracle_pins.py."""
     if nodes is None:
-        return oracle.PIVOT_SWEEP if (n, m) == (35, 21) else oracle.PIVOT_STATIC
-    return oracle.PIVOT_SWEEP if (n + m <= 64 and nodes in (5, 7)) else oracle.PIVOT_STATIC
+        return oracle.PIVOT_SWEEP if (n, m) == (35, 21) else _lds_order(oracle, n + m)
+    return oracle.PIVOT_SWEEP if (n + m <= 64 and nodes in (5, 7)) else _lds_order(oracle, n + m)
 
 
 def _qp_oracle(oracle, q, s, x0=None, y0=None):
@@ -347,7 +353,9 @@ def _sqp_both(ctx, oracle, wl, B, **kw):
     n = wl["lbx"].shape[1]; dm = oracle.ocp_dims(wl["model"], wl["P"], wl["S"])
     # (preconditioner = 1, qp_solver = 1 and line_search = 1 are served by the LDS-resident QP kernels whatever the size: static LDL^T
     #  order; hessian_update = 1 has register-resident specialisations like the default)
-    order = oracle.PIVOT_STATIC if (kw.get("preconditioner", 0) or kw.get("qp_solver", 0) or kw.get("line_search", 0)) else _gpu_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1)
+    if kw.get("qp_solver", 0): order = oracle.PIVOT_STATIC
+    elif kw.get("preconditioner", 0) or kw.get("line_search", 0): order = _lds_order(oracle, dm["n"] + dm["m"])
+    else: order = _gpu_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1)
     xo, lo, io = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"],
                                         sqp_settings=oss, pivot=order, threads=8)
     return (x, lam, info), (xo, lo, io)
@@ -454,7 +462,7 @@ def test_sqp_parking_nonlinear_path_constraint(ctx, oracle, P, S, ubg, qp_max):
     oqs = oracle.sqp_qp_default_settings(); oqs.max_iter = qp_max
     x, lam, info = ctx.sqp_solve_batch(pa.MODEL_PARKING_NG, P, S, 0.0, 1.0, 1, [[1.0]], lbx, ubx, lbg=lbg, ubg=ubgv, x_guess=xg,
                                        sqp_settings=ss, qp_settings=qs)
-    pivot = oracle.PIVOT_SWEEP if nn == 7 else oracle.PIVOT_STATIC
+    pivot = oracle.PIVOT_SWEEP if nn == 7 else _lds_order(oracle, 100)
     xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_PARKING_NG, P, S, 0.0, 1.0, 1, [[1.0]], lbx, ubx, lbg=lbg, ubg=ubgv, x_guess=xg,
                                         sqp_settings=oss, qp_settings=oqs, pivot=pivot)
     assert info["status"][0] == io[0].status and info["iter"][0] == io[0].iter and info["qp_solver_iter"][0] == io[0].qp_solver_iter

@@ -190,7 +190,7 @@ def test_boxadmm_nonconvex(oracle):  # :299-334
 
 
 # ---------------------------------------------------------------- §8f-4: the OSQP-style ADMM solver (admm_solver_test.cpp)
-@pytest.mark.parametrize("pivot", [0, 1])
+@pytest.mark.parametrize("pivot", [0, 1, 3])
 def test_admm_simple_qp(oracle, pivot):  # admm_solver_test.cpp:16-45
     s = oracle.qp_default_settings(); s.max_iter = 1000
     x, y, info = oracle.qp_admm_solve_batch(*_simple_qp(), settings=s, pivot=pivot)
@@ -297,25 +297,25 @@ def _nlp_settings(oracle):
     return ss
 
 
-@pytest.mark.parametrize("pivot", [0, 1])
+@pytest.mark.parametrize("pivot", [0, 1, 3])
 def test_sqp_constrained_rosenbrock(oracle, pivot):  # :78-97
     x, lam, info = oracle.nlp_solve(oracle.NLP_CONSTRAINED_ROSENBROCK, [2.01, 1.01], sqp_settings=_nlp_settings(oracle), pivot=pivot)
     assert _is_approx(x, np.array([0.7864, 0.6177]), 1e-2) and info.iter < 50
 
 
-@pytest.mark.parametrize("pivot", [0, 1])
+@pytest.mark.parametrize("pivot", [0, 1, 3])
 def test_sqp_rosenbrock(oracle, pivot):  # :119-137
     x, lam, info = oracle.nlp_solve(oracle.NLP_ROSENBROCK, [2.01, 1.01], sqp_settings=_nlp_settings(oracle), pivot=pivot)
     assert _is_approx(x, np.array([1.0, 1.0]), 1e-2) and info.iter < 50
 
 
-@pytest.mark.parametrize("pivot", [0, 1])
+@pytest.mark.parametrize("pivot", [0, 1, 3])
 def test_sqp_simple_nlp(oracle, pivot):  # :165-186
     x, lam, info = oracle.nlp_solve(oracle.NLP_SIMPLE, [1.0, 1.0], lbg=[1.0], ubg=[2.0], sqp_settings=_nlp_settings(oracle), pivot=pivot)
     assert _is_approx(x, np.array([1.0, 1.0]), 1e-2) and info.iter < 50
 
 
-@pytest.mark.parametrize("pivot", [0, 1])
+@pytest.mark.parametrize("pivot", [0, 1, 3])
 def test_sqp_hs071_solution(oracle, pivot):  # :223-246
     x, lam, info = oracle.nlp_solve(oracle.NLP_HS071, [1.0, 5.0, 5.0, 1.0], lbx=[1.0] * 4, ubx=[5.0] * 4, lbg=[25.0], ubg=[inf],
                                     sqp_settings=_nlp_settings(oracle), pivot=pivot)
@@ -333,7 +333,7 @@ def _robot_bounds(nn, x0):
     return lbx[None], ubx[None]
 
 
-@pytest.mark.parametrize("pivot", [0, 1])
+@pytest.mark.parametrize("pivot", [0, 1, 3])
 def test_sqp_codegen_robot(oracle, pivot):  # codegen_test.cpp:402-438 — exact Hessian every iteration, qp max_iter 1000
     ss = oracle.sqp_default_settings(); ss.max_iter = 10; ss.line_search_max_iter = 10; ss.exact_hessian_every_iter = 1
     qs = oracle.sqp_qp_default_settings(); qs.max_iter = 1000
@@ -342,7 +342,7 @@ def test_sqp_codegen_robot(oracle, pivot):  # codegen_test.cpp:402-438 — exact
     assert info[0].status == oracle.SQP_SOLVED and info[0].iter < 10
 
 
-@pytest.mark.parametrize("pivot", [0, 1])
+@pytest.mark.parametrize("pivot", [0, 1, 3])
 def test_sqp_robot_mpc_warm_start(oracle, pivot):  # mpc_wrapper_test.cpp:120-166 (dense BFGS variant)
     ss = oracle.sqp_default_settings(); ss.max_iter = 10; ss.line_search_max_iter = 10
     lbx, ubx = _robot_bounds(16, [0.5, 0.5, 0.5])
@@ -371,7 +371,7 @@ def _minimal_time_parking(nn=11):
     return lbx[None], ubx[None], xg[None]
 
 
-@pytest.mark.parametrize("pivot", [0, 1])
+@pytest.mark.parametrize("pivot", [0, 1, 3])
 def test_sqp_minimal_time_valet_parking(oracle, pivot):  # minimal_time_test.cpp:146-188 — exact Hessian every iteration + Gershgorin
     ss = oracle.sqp_default_settings(); ss.max_iter = 20; ss.line_search_max_iter = 10
     ss.regularisation = 2; ss.exact_hessian_every_iter = 1
@@ -397,7 +397,7 @@ def _parking_ng(oracle, ubg, pivot, qp_max_iter=100, max_iter=20):
     return x[0], lam[0], info[0], u[:, 0] ** 2 * np.cos(u[:, 1])
 
 
-@pytest.mark.parametrize("pivot", [0, 1])
+@pytest.mark.parametrize("pivot", [0, 1, 3])
 def test_sqp_parking_with_nonlinear_path_constraint(oracle, pivot):
     """nonlinear_constraints_test.cpp:159-184 — the minimal-time parking problem with g = u0^2 cos(u1) in [-10, 10] at every node
     (NP = 1 and NG = 1 together; exact linearisation every iteration + Gershgorin, :97-145). The reference program only prints
@@ -417,7 +417,7 @@ def test_sqp_parking_with_nonlinear_path_constraint(oracle, pivot):
     assert np.abs(lam[33:44]).max() <= 1e-6                              # rows 33..43 are g: inactive, no multiplier
 
 
-@pytest.mark.parametrize("pivot", [0, 1])
+@pytest.mark.parametrize("pivot", [0, 1, 3])
 def test_sqp_parking_active_nonlinear_path_constraint(oracle, pivot):
     """The same problem with the bound tightened until it binds (u0^2 cos(u1) <= 1.2; the free optimum reaches 2.19): SOLVED with
     the reference's settings, g at the bound on the nodes, non-zero multipliers on the g rows, and a longer manoeuvre."""
@@ -444,7 +444,7 @@ def _valet_bounds(x0):
     return lbx[None], ubx[None]
 
 
-@pytest.mark.parametrize("pivot", [0, 1])
+@pytest.mark.parametrize("pivot", [0, 1, 3])
 def test_sqp_valet_parking_with_ruiz(oracle, pivot):
     """valet_parking_mpc_test.cpp:183-240 — SQP with the RuizEquilibration preconditioner, QP max_iter 1000, cold solve then a
     warm-started solve from a moved initial state; both must be SOLVED in < 10 iterations. (Variant: the reference's solver
@@ -461,7 +461,7 @@ def test_sqp_valet_parking_with_ruiz(oracle, pivot):
     assert i2[0].status == oracle.SQP_SOLVED and i2[0].iter < 10
 
 
-@pytest.mark.parametrize("pivot", [0, 1])
+@pytest.mark.parametrize("pivot", [0, 1, 3])
 def test_sqp_valet_parking_as_the_reference_runs_it(oracle, pivot):
     """valet_parking_mpc_test.cpp:183-240 with every hook that test installs: RuizEquilibration preconditioner, QP max_iter 1000,
     the filter line search on LSFilter with beta = 0.1 (:116-158, :192; line_search.hpp:31-98) and ContinuousOCP's block BFGS
@@ -499,7 +499,7 @@ def test_ls_filter_list_semantics(oracle):
     assert full[0, 0] == 10 and full[0, 19] == 100.0 + 7 and full[0, 3] == 0.0 and abs(full[0, 4] - 1.5) < 1e-12
 
 
-@pytest.mark.parametrize("pivot", [0, 1])
+@pytest.mark.parametrize("pivot", [0, 1, 3])
 def test_sqp_robot_mpc_warm_start_block_bfgs(oracle, pivot):
     """mpc_wrapper_test.cpp:120-166 with the Hessian update that test actually selects (MySolver::hessian_update_impl ->
     ContinuousOCP::hessian_update_impl, the block BFGS of continuous_ocp.hpp:2304-2431): SOLVED, and the warm-started second solve
@@ -526,7 +526,7 @@ def test_block_bfgs_keeps_the_hessian_block_diagonal(oracle):
     assert np.abs(x0 - x1).max() < 5e-2
 
 
-@pytest.mark.parametrize("pivot", [0, 1])
+@pytest.mark.parametrize("pivot", [0, 1, 3])
 def test_sqp_with_admm_qp_solver(oracle, pivot):
     """Solver<Problem, ADMM<...>> (the admm_solver alias of mpc_wrapper_test.cpp:109-110): the OSQP-form QP solver inside the SQP
     loop reaches the optimum boxADMM reaches, cold and warm-started (mpc_wrapper_test.cpp:120-166's assertions)."""

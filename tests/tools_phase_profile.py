@@ -7,17 +7,18 @@ import polympc_amd as pa
 from polympc_amd import workloads
 
 B = int(os.environ.get("B", 4096))
-wl = workloads.robot_batch(B)
+P_, S_ = int(os.environ.get("P", 6)), int(os.environ.get("S", 1))   # P=5 S=2 (88 KKT rows) or PMPC_FORCE_LDS_PATH=1: the LDS-resident kernel
+wl = workloads.robot_batch(B, P=P_, S=S_)
 ctx = pa.Context(0)
 ss = pa.sqp_settings_default(); ss.max_iter = 10; ss.line_search_max_iter = 10
 for rep in range(2):
     t = time.perf_counter()
-    x, lam, info = ctx.sqp_solve_batch(0, 6, 1, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
+    x, lam, info = ctx.sqp_solve_batch(0, P_, S_, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
     t = time.perf_counter() - t
 cyc = ctx.phase_cycles()
 names = ["linearise(+update)", "QP", "line search", "termination", "total loop", "BFGS", "KKT build+factor", "QP residuals",
          "ls node evaluation", "ls scalar sums", "first-order staging", "second-order staging", "first-order assembly",
-         "Hessian assembly", "Lagrangian gradient", "-", "inv: row loads + staging", "inv: panel moves", "inv: sweeps", "inv: MFMA updates",
+         "Hessian assembly", "Lagrangian gradient", "-", "inv: row loads + staging | LDS path: KKT build", "inv: panel moves | LDS path: substitutions", "inv: sweeps", "inv: MFMA updates",
          "inv: final conversion", "ls prologue", "ls acceptance", "-"]
 qps = info["iter"].sum()
 print(f"host wall {t*1e3:.2f} ms (incl. copies), {qps} QPs, {info['qp_solver_iter'].sum()/qps:.2f} ADMM it/QP")

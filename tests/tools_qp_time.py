@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import polympc_amd as pa
 from polympc_amd import workloads
-B, n, m = 4096, 66, 44
+B, n, m = 4096, int(os.environ.get("N", 66)), int(os.environ.get("M", 44))
 q = workloads.random_qp_batch(B, n, m, seed=2)
 dev = torch.device("cuda", 0)
 stream = torch.cuda.Stream(dev); torch.cuda.set_stream(stream)

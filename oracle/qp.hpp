@@ -18,6 +18,8 @@
 //                  compares the two policies on the reference's QP fixtures and on the SQP workloads).
 //   PIVOT_STATIC : identical arithmetic without the permutation, right-looking update order — the order
 //                  the HIP kernels use, so a GPU-vs-oracle comparison isolates kernel bugs from pivot effects.
+//   PIVOT_SWEEP1 : the swept inverse of PIVOT_SWEEP one pivot at a time on the lower triangle (any size), x = -(W b) as one fma chain
+//                  per row: accuracy evidence for the explicit-inverse route above 64 rows (no shipped kernel uses it this round).
 // All matrices column-major.
 #pragma once
 #include <algorithm>

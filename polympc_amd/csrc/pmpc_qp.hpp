@@ -302,98 +302,133 @@ __device__ __forceinline__ void kkt_factor(const QpLds& w, int N) {
     }
 }
 
+// Substitutions for systems of at most 128 rows: two rows per lane, held in registers (c0: row lane, c1: row lane + 64). A single
+// wavefront per SIMD issues one instruction every four cycles whatever its kind, so these loops are bound by their instruction COUNT:
+//  - the factor entry of a step is read through a running LDS pointer (one add per step; the second row is the same address + 64
+//    entries, an immediate offset), never clamped: a lane without an entry in the column reads a neighbouring entry or the dummy slots
+//    behind the triangle, and its result is dropped;
+//  - only the row set that really shrinks during a phase is masked (rows `lane` while the pivots are below 64, rows `lane + 64`
+//    above); the other row of the lane is either always inside the column or belongs to a lane whose registers are never read;
+//  - the pivot value comes out of the registers with v_readlane; the loads of eight steps are issued ahead of the (serial) fma chain.
+// Same operations on every entry, in the same order, as the generic loops below (forward: columns ascending, backward: descending).
+template <bool TWO>
+__device__ __forceinline__ void kkt_solve_rows(const QpLds& w, int N, double* v) {
+    const int ln = lane_id();
+    const double* K = w.K;
+    const int i0 = ln, i1 = ln + WAVE;
+    const bool h0 = i0 < N, h1 = TWO && i1 < N;
+    const int r0 = h0 ? i0 : 0, r1 = h1 ? i1 : 0;
+    double c0 = h0 ? v[i0] : 0.0, c1 = h1 ? v[i1] : 0.0;
+    const int nA = (N - 1 < WAVE) ? N - 1 : WAVE;   // forward steps whose pivot lives in c0
+    // ---- forward, pivots in c0: L(i, j) at off(j) + i
+    const double* pa = K + i0;
+    int inc = N - 1;                                  // off(j + 1) - off(j)
+    int j = 0;
+    for (; j + 8 <= nA; j += 8) {
+        double f0[8], f1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { f0[u] = pa[0]; if (TWO) f1[u] = pa[WAVE]; pa += inc; --inc; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double xj = bcast_uniform(c0, j + u);
+            const double t0 = fma(-f0[u], xj, c0);
+            if (TWO) c1 = fma(-f1[u], xj, c1);
+            c0 = (i0 > j + u) ? t0 : c0;
+        }
+    }
+    for (; j < nA; ++j) {
+        const double f0 = pa[0], f1 = TWO ? pa[WAVE] : 0.0;
+        pa += inc; --inc;
+        const double xj = bcast_uniform(c0, j);
+        const double t0 = fma(-f0, xj, c0);
+        if (TWO) c1 = fma(-f1, xj, c1);
+        c0 = (i0 > j) ? t0 : c0;
+    }
+    if (TWO) {   // ---- forward, pivots in c1 (j from 64 on): only rows lane + 64 are still below them
+        for (; j + 8 <= N - 1; j += 8) {
+            double f1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { f1[u] = pa[WAVE]; pa += inc; --inc; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double xj = bcast_uniform(c1, j + u - WAVE);
+                const double t1 = fma(-f1[u], xj, c1);
+                c1 = (i1 > j + u) ? t1 : c1;
+            }
+        }
+        for (; j < N - 1; ++j) {
+            const double f1 = pa[WAVE];
+            pa += inc; --inc;
+            const double xj = bcast_uniform(c1, j - WAVE);
+            const double t1 = fma(-f1, xj, c1);
+            c1 = (i1 > j) ? t1 : c1;
+        }
+    }
+    // ---- diagonal
+    const int o0 = w.off(r0), o1 = w.off(r1);
+    c0 = c0 / K[o0 + r0];
+    if (TWO) c1 = c1 / K[o1 + r1];
+    // ---- backward: L(j, i) at off(i) + j, pivots descending
+    j = N - 1;
+    if (TWO) {   // pivots in c1 (j >= 64): every row below 64, and the rows lane + 64 above the pivot
+        const double* pb0 = K + o0 + j;
+        const double* pb1 = K + o1 + j;
+        for (; j - 8 >= WAVE - 1; j -= 8) {
+            double f0[8], f1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { f0[u] = pb0[-u]; f1[u] = pb1[-u]; }
+            pb0 -= 8; pb1 -= 8;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double xj = bcast_uniform(c1, j - u - WAVE);
+                c0 = fma(-f0[u], xj, c0);
+                const double t1 = fma(-f1[u], xj, c1);
+                c1 = (i1 < j - u) ? t1 : c1;
+            }
+        }
+        for (; j >= WAVE; --j) {
+            const double f0 = pb0[0], f1 = pb1[0];
+            --pb0; --pb1;
+            const double xj = bcast_uniform(c1, j - WAVE);
+            c0 = fma(-f0, xj, c0);
+            const double t1 = fma(-f1, xj, c1);
+            c1 = (i1 < j) ? t1 : c1;
+        }
+    }
+    {   // pivots in c0 (j below 64): rows lane < j only
+        const double* pb0 = K + o0 + j;
+        for (; j - 8 >= 0; j -= 8) {
+            double f0[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) f0[u] = pb0[-u];
+            pb0 -= 8;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double xj = bcast_uniform(c0, j - u);
+                const double t0 = fma(-f0[u], xj, c0);
+                c0 = (i0 < j - u) ? t0 : c0;
+            }
+        }
+        for (; j > 0; --j) {
+            const double f0 = pb0[0];
+            --pb0;
+            const double xj = bcast_uniform(c0, j);
+            const double t0 = fma(-f0, xj, c0);
+            c0 = (i0 < j) ? t0 : c0;
+        }
+    }
+    wsync();
+    if (h0) v[i0] = c0;
+    if (h1) v[i1] = c1;
+    wsync();
+}
+
 // v <- K^{-1} v  (linear_solver.solve, box_admm.hpp:123), v in LDS
 __device__ __forceinline__ void kkt_solve(const QpLds& w, int N, double* v) {
     const int ln = lane_id();
     const double* K = w.K;
     if (N <= 2 * WAVE) {
-        // at most two rows per lane, held in registers (c0: row lane, c1: row lane + 64); the pivot entry of every step is
-        // broadcast with v_readlane and the factor entries of eight steps are loaded ahead of the (serial) fma chain — no LDS
-        // write/read round trip per column. Branch-free (clamped loads + selects); pivots below 64 come out of c0, the others
-        // out of c1, so each sweep is two loops without a per-step case distinction.
-        const int i0 = ln, i1 = ln + WAVE;
-        const bool h0 = i0 < N, h1 = i1 < N;
-        const int r0 = h0 ? i0 : 0, r1 = h1 ? i1 : 0;   // clamped row indices for the loads
-        double c0 = h0 ? v[i0] : 0.0, c1 = h1 ? v[i1] : 0.0;
-        const int nA = (N - 1 < WAVE) ? N - 1 : WAVE;   // forward steps whose pivot lives in c0: j in [0, nA)
-        int oc = 0;   // off(j) of the column being loaded, advanced incrementally: off(j+1) - off(j) = N - 1 - j
-        for (int j0 = 0; j0 < nA; j0 += 8) {
-            double f0[8], f1[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool in = j0 + u < nA;
-                const int j = in ? j0 + u : nA - 1;
-                const int o = in ? oc : w.off(nA - 1);
-                f0[u] = K[o + (r0 > j ? r0 : j)];
-                f1[u] = K[o + (r1 > j ? r1 : j)];
-                if (in) oc += N - 1 - j;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 + u;
-                const double xj = bcast_uniform(c0, j < nA ? j : 0);
-                const double t0 = fma(-f0[u], xj, c0), t1 = fma(-f1[u], xj, c1);
-                c0 = (j < nA && h0 && i0 > j) ? t0 : c0;
-                c1 = (j < nA && h1) ? t1 : c1;
-            }
-        }
-        for (int j0 = WAVE; j0 < N - 1; j0 += 8) {      // pivots in c1; only the rows above 64 are still below them (oc = off(64) here)
-            double f1[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool in = j0 + u < N - 1;
-                const int j = in ? j0 + u : N - 2;
-                const int o = in ? oc : w.off(N - 2);
-                f1[u] = K[o + (r1 > j ? r1 : j)];
-                if (in) oc += N - 1 - j;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 + u;
-                const double xj = bcast_uniform(c1, (j < N - 1 ? j : WAVE) - WAVE);
-                const double t1 = fma(-f1[u], xj, c1);
-                c1 = (j < N - 1 && h1 && i1 > j) ? t1 : c1;
-            }
-        }
-        const int o0 = w.off(r0), o1 = w.off(r1);
-        { const double q0 = c0 / K[o0 + r0], q1 = c1 / K[o1 + r1]; c0 = h0 ? q0 : c0; c1 = h1 ? q1 : c1; }
-        for (int j0 = N - 1; j0 >= WAVE; j0 -= 8) {     // backward, pivots in c1: every row below 64 and the rows i1 < j
-            double f0[8], f1[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = (j0 - u >= WAVE) ? j0 - u : WAVE;
-                f0[u] = K[o0 + j];
-                f1[u] = K[o1 + (r1 < j ? j : r1)];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 - u;
-                const double xj = bcast_uniform(c1, (j >= WAVE ? j : WAVE) - WAVE);
-                const double t0 = fma(-f0[u], xj, c0), t1 = fma(-f1[u], xj, c1);
-                c0 = (j >= WAVE && h0) ? t0 : c0;
-                c1 = (j >= WAVE && h1 && i1 < j) ? t1 : c1;
-            }
-        }
-        const int jtop = (N - 1 < WAVE - 1) ? N - 1 : WAVE - 1;
-        for (int j0 = jtop; j0 > 0; j0 -= 8) {          // backward, pivots in c0: rows i0 < j only
-            double f0[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = (j0 - u > 0) ? j0 - u : 1;
-                f0[u] = K[o0 + (r0 < j ? j : r0)];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 - u;
-                const double xj = bcast_uniform(c0, j > 0 ? j : 0);
-                const double t0 = fma(-f0[u], xj, c0);
-                c0 = (j > 0 && h0 && i0 < j) ? t0 : c0;
-            }
-        }
-        wsync();
-        if (h0) v[i0] = c0;
-        if (h1) v[i1] = c1;
-        wsync();
+        if (N <= WAVE) kkt_solve_rows<false>(w, N, v); else kkt_solve_rows<true>(w, N, v);
         return;
     }
     for (int j = 0; j < N - 1; ++j) {

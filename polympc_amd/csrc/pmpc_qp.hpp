@@ -451,25 +451,53 @@ struct QpResidualState { double max_Ax_z_norm, max_Hx_ATy_h_norm, res_prim, res_
 __device__ __forceinline__ void qp_residuals(const QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ h,
                                     const double* __restrict__ A, int lda, QpResidualState& r) {
     const int ln = lane_id();
+    // The three products keep one add chain per row (columns ascending: the order of the CPU restatement); what is batched is the
+    // loads — eight global loads and eight LDS reads are in flight before the chain consumes them (one dependent L2 round trip per
+    // term made this routine cost four substitutions).
+    constexpr int CH = 8;
+    // sum_j M[j * sj + i * si] * vec[j], j ascending: full chunks without any clamping, then one clamped chunk for the remainder
+    auto dot = [&](const double* __restrict__ M, size_t sj, size_t si, int i, int cnt, const double* vec) -> double {
+        double a = 0.0;
+        const double* __restrict__ p = M + (size_t)i * si;
+        int j0 = 0;
+        for (; j0 + CH <= cnt; j0 += CH) {
+            double e[CH], x[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) { e[u] = p[(size_t)u * sj]; x[u] = vec[j0 + u]; }
+            p += (size_t)CH * sj;
+#pragma unroll
+            for (int u = 0; u < CH; ++u) a += e[u] * x[u];
+        }
+        if (j0 < cnt) {
+            const int rem = cnt - j0;
+            double e[CH], x[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) { const int uu = (u < rem) ? u : rem - 1; e[u] = p[(size_t)uu * sj]; x[u] = vec[j0 + uu]; }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) if (u < rem) a += e[u] * x[u];
+        }
+        return a;
+    };
+    auto dot_col = [&](const double* __restrict__ M, int ld, int i, int cnt, const double* vec) -> double { return dot(M, (size_t)ld, 1, i, cnt, vec); };
+    auto dot_row = [&](const double* __restrict__ M, int ld, int i, int cnt, const double* vec) -> double { return dot(M, 1, (size_t)ld, i, cnt, vec); };
     double nAx = 0, nz = 0, nx = 0, rp = 0;
     for (int i = ln; i < m; i += WAVE) {
-        double a = 0.0;
-        for (int j = 0; j < n; ++j) a += A[(size_t)j * lda + i] * w.x[j];
+        const double a = dot_col(A, lda, i, n, w.x);
         nAx = fmax(nAx, fabs(a)); nz = fmax(nz, fabs(w.z[i])); rp = fmax(rp, fabs(a - w.z[i]));
     }
     double nHx = 0, nATy = 0, nh = 0, nyb = 0, rq = 0, rd = 0;
     for (int i = ln; i < n; i += WAVE) {
-        double a = 0.0;
-        for (int j = 0; j < n; ++j) a += H[(size_t)j * ldh + i] * w.x[j];
-        double b = 0.0;
-        for (int k = 0; k < m; ++k) b += A[(size_t)i * lda + k] * w.y[k];
+        const double a = dot_col(H, ldh, i, n, w.x);
+        const double b = (m > 0) ? dot_row(A, lda, i, m, w.y) : 0.0;
         nx = fmax(nx, fabs(w.x[i])); nHx = fmax(nHx, fabs(a)); nATy = fmax(nATy, fabs(b));
         nh = fmax(nh, fabs(h[i])); nyb = fmax(nyb, fabs(w.y[m + i]));
         rq = fmax(rq, fabs(w.x[i] - w.q[i]));
         rd = fmax(rd, fabs(((a + h[i]) + b) + w.y[m + i]));
     }
-    nAx = wave_max(nAx); nz = wave_max(nz); nx = wave_max(nx); rp = wave_max(rp);
-    nHx = wave_max(nHx); nATy = wave_max(nATy); nh = wave_max(nh); nyb = wave_max(nyb); rq = wave_max(rq); rd = wave_max(rd);
+    // max is exact and order-free: the norms that are only ever used through their maximum are merged before the reductions
+    nAx = wave_max(fmax(nAx, fmax(nz, nx))); nz = nAx; nx = nAx;
+    nHx = wave_max(fmax(fmax(nHx, nATy), fmax(nh, nyb))); nATy = nHx; nh = nHx; nyb = nHx;
+    rp = wave_max(rp); rq = wave_max(rq); rd = wave_max(rd);
     r.max_Ax_z_norm = fmax(nAx, fmax(nz, nx));
     r.max_Hx_ATy_h_norm = fmax(nHx, fmax(nATy, fmax(nh, nyb)));
     r.res_prim = rp + rq;

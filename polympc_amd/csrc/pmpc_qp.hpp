@@ -211,76 +211,89 @@ __device__ __forceinline__ double bcast_uniform(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+// Right-looking LDL^T for systems of at most 128 rows: two rows per lane (i0 = lane, i1 = lane + 64). The unscaled column stays in two
+// registers and the multiplier l_jk comes out of the scaled registers with v_readlane (no LDS round trip through the column just
+// written); the trailing update takes four columns at a time — loads issued together, then the fma, then the stores. Like the
+// substitutions this loop is bound by its instruction count (one wavefront per SIMD): the entry index is a running value (one add per
+// column, the second row is + 64), and a lane without an entry in a column is redirected to its private dummy slot behind the packed
+// triangle with one select — branch-free, and an index, not a pointer, is selected (compiler hazard 7 in DESIGN.md).
+template <bool TWO>
+__device__ __forceinline__ void kkt_factor_rows(const QpLds& w, int N) {
+    const int ln = lane_id();
+    double* K = w.K;
+    const int i0 = ln, i1 = ln + WAVE;
+    const bool h0 = i0 < N, h1 = TWO && i1 < N;
+    const int d0 = (int)QpLds::kdoubles(N) + ln, d1 = d0 + QpLds::WAVE_DUMMY;
+    const int NL = N < WAVE ? N : WAVE;
+    constexpr int FC = 4;                              // columns per batch of loads (8 costs the same per column and lengthens the remainder)
+    int ok = 0;                                        // off(k)
+    for (int k = 0; k < N; ++k) {
+        const double dk = K[ok + k];
+        const bool a0 = h0 && i0 > k, a1 = h1 && i1 > k;
+        const int p0 = a0 ? ok + i0 : d0, p1 = a1 ? ok + i1 : d1;
+        const double c0 = K[p0];
+        const double c1 = TWO ? K[p1] : 0.0;
+        const double s0 = c0 / dk, s1 = TWO ? c1 / dk : 0.0;   // scaled column: l_jk for row j lives in lane j (s0) / lane j - 64 (s1)
+        K[p0] = s0;
+        if (TWO) K[p1] = s1;
+        ok += N - 1 - k;                               // off(k + 1)
+        int ij = ok + i0;                              // index of (i0, j) for the running column j
+        int inc = N - 2 - k;                           // off(j + 1) - off(j)
+        int j = k + 1;
+        for (; j + FC <= NL; j += FC) {                  // columns below 64: rows lane from j on, rows lane + 64 always
+            double l[FC], e0[FC], e1[FC]; int q0[FC], q1[FC];
+#pragma unroll
+            for (int u = 0; u < FC; ++u) {
+                l[u] = bcast_uniform(s0, j + u);
+                q0[u] = (a0 && i0 >= j + u) ? ij : d0;
+                if (TWO) q1[u] = a1 ? ij + WAVE : d1;
+                ij += inc; --inc;
+            }
+#pragma unroll
+            for (int u = 0; u < FC; ++u) { e0[u] = K[q0[u]]; if (TWO) e1[u] = K[q1[u]]; }
+#pragma unroll
+            for (int u = 0; u < FC; ++u) { K[q0[u]] = fma(-c0, l[u], e0[u]); if (TWO) K[q1[u]] = fma(-c1, l[u], e1[u]); }
+        }
+        for (; j < NL; ++j) {
+            const double l = bcast_uniform(s0, j);
+            const int q0 = (a0 && i0 >= j) ? ij : d0, q1 = a1 ? ij + WAVE : d1;
+            ij += inc; --inc;
+            const double e0 = K[q0], e1 = TWO ? K[q1] : 0.0;
+            K[q0] = fma(-c0, l, e0);
+            if (TWO) K[q1] = fma(-c1, l, e1);
+        }
+        if (TWO) {                                     // columns from 64 on: only rows lane + 64, from j on
+            for (; j + FC <= N; j += FC) {
+                double l[FC], e1[FC]; int q1[FC];
+#pragma unroll
+                for (int u = 0; u < FC; ++u) {
+                    l[u] = bcast_uniform(s1, j + u - WAVE);
+                    q1[u] = (a1 && i1 >= j + u) ? ij + WAVE : d1;
+                    ij += inc; --inc;
+                }
+#pragma unroll
+                for (int u = 0; u < FC; ++u) e1[u] = K[q1[u]];
+#pragma unroll
+                for (int u = 0; u < FC; ++u) K[q1[u]] = fma(-c1, l[u], e1[u]);
+            }
+            for (; j < N; ++j) {
+                const double l = bcast_uniform(s1, j - WAVE);
+                const int q1 = (a1 && i1 >= j) ? ij + WAVE : d1;
+                ij += inc; --inc;
+                const double e1 = K[q1];
+                K[q1] = fma(-c1, l, e1);
+            }
+        }
+        wsync();
+    }
+}
+
 // in-place LDL^T, static order, right-looking (factorise_kkt_matrix, box_admm.hpp:336-341)
 __device__ __forceinline__ void kkt_factor(const QpLds& w, int N) {
     const int ln = lane_id();
     double* K = w.K;
     if (N <= 2 * WAVE) {
-        // at most two rows per lane (i0 = lane, i1 = lane + 64): the unscaled column stays in two registers, and the trailing
-        // update takes four columns at a time — their loads are issued together, then the fma and the stores (one LDS round
-        // trip per four columns instead of per column; same operations on every entry, in the same order). Branch-free: a
-        // lane without an entry in a column reads and rewrites a private dummy slot behind the packed triangle instead of being
-        // masked off — divergent branches around single LDS operations cost more than the operations.
-        const int i0 = ln, i1 = ln + WAVE;
-        const int d0 = (int)QpLds::kdoubles(N) + ln, d1 = d0 + QpLds::WAVE_DUMMY;   // dummy slots behind the packed triangle (indices, not
-                                                                                    // pointers: see compiler hazard 7 in DESIGN.md)
-        const bool h0 = i0 < N, h1 = i1 < N;
-        for (int k = 0; k < N; ++k) {
-            const int ok = w.off(k);
-            const double dk = K[ok + k];
-            const bool a0 = i0 > k && h0, a1 = i1 > k && h1;
-            const int p0 = a0 ? ok + i0 : d0, p1 = a1 ? ok + i1 : d1;
-            const double c0 = K[p0], c1 = K[p1];
-            const double s0 = c0 / dk, s1 = c1 / dk;   // scaled column entries: l_jk for row j lives in lane j (s0) / lane j-64 (s1)
-            K[p0] = s0;
-            K[p1] = s1;
-            // trailing update, columns j below 64: row lane + 64 is always in the column, row lane from j on; the multiplier l_jk
-            // comes out of the scaled registers with v_readlane (no LDS round trip through the column just written)
-            int oj = w.off(k + 1);
-            int j = k + 1;
-            for (; j + 3 < N && j + 3 < WAVE; j += 4) {
-                double l[4], e0[4], e1[4]; int q0[4], q1[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    l[u] = bcast_uniform(s0, j + u);
-                    q0[u] = (h0 && i0 >= j + u) ? oj + i0 : d0;
-                    q1[u] = h1 ? oj + i1 : d1;
-                    oj += N - 1 - (j + u);   // off(j+1) - off(j)
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { e0[u] = K[q0[u]]; e1[u] = K[q1[u]]; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { K[q0[u]] = fma(-c0, l[u], e0[u]); K[q1[u]] = fma(-c1, l[u], e1[u]); }
-            }
-            for (; j < N && j < WAVE; ++j) {   // remainder of the columns below 64
-                const double l = bcast_uniform(s0, j);
-                const int q0 = (h0 && i0 >= j) ? oj + i0 : d0, q1 = h1 ? oj + i1 : d1;
-                const double e0 = K[q0], e1 = K[q1];
-                K[q0] = fma(-c0, l, e0); K[q1] = fma(-c1, l, e1);
-                oj += N - 1 - j;
-            }
-            for (; j + 3 < N; j += 4) {        // columns from 64 on: only row lane + 64 (from j on) is in them
-                double l[4], e1[4]; int q1[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    l[u] = bcast_uniform(s1, j + u - WAVE);
-                    q1[u] = (h1 && i1 >= j + u) ? oj + i1 : d1;
-                    oj += N - 1 - (j + u);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) e1[u] = K[q1[u]];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) K[q1[u]] = fma(-c1, l[u], e1[u]);
-            }
-            for (; j < N; ++j) {
-                const double l = bcast_uniform(s1, j - WAVE);
-                const int q1 = (h1 && i1 >= j) ? oj + i1 : d1;
-                const double e1 = K[q1];
-                K[q1] = fma(-c1, l, e1);
-                oj += N - 1 - j;
-            }
-            wsync();
-        }
+        if (N <= WAVE) kkt_factor_rows<false>(w, N); else kkt_factor_rows<true>(w, N);
         return;
     }
     for (int k = 0; k < N; ++k) {

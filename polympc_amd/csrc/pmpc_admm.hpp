@@ -40,17 +40,14 @@ __device__ __forceinline__ void admm_residuals(const QpLds& w, int n, int m, con
     const int ln = lane_id();
     double nAx = 0, nz = 0, rp = 0;
     for (int i = ln; i < m; i += WAVE) {
-        double a = 0.0;
-        for (int j = 0; j < n; ++j) a += A[(size_t)j * lda + i] * w.x[j];
+        const double a = seq_dot_strided(A, (size_t)lda, 1, i, n, w.x);
         nAx = fmax(nAx, fabs(a)); rp = fmax(rp, fabs(a - w.z[i]));
     }
     for (int i = ln; i < m + n; i += WAVE) nz = fmax(nz, fabs(w.z[i]));
     double nx = 0, nHx = 0, nATy = 0, nh = 0, nyb = 0, rb = 0, rd = 0;
     for (int i = ln; i < n; i += WAVE) {
-        double a = 0.0;
-        for (int j = 0; j < n; ++j) a += H[(size_t)j * ldh + i] * w.x[j];
-        double b = 0.0;
-        for (int k = 0; k < m; ++k) b += A[(size_t)i * lda + k] * w.y[k];
+        const double a = seq_dot_strided(H, (size_t)ldh, 1, i, n, w.x);
+        const double b = (m > 0) ? seq_dot_strided(A, 1, (size_t)lda, i, m, w.y) : 0.0;
         nx = fmax(nx, fabs(w.x[i])); nHx = fmax(nHx, fabs(a)); nATy = fmax(nATy, fabs(b));
         nh = fmax(nh, fabs(h[i])); nyb = fmax(nyb, fabs(w.y[m + i]));
         rb = fmax(rb, fabs(w.x[i] - w.z[m + i]));

@@ -458,6 +458,32 @@ __device__ __forceinline__ void kkt_solve(const QpLds& w, int N, double* v) {
     }
 }
 
+// sum_j M[j * sj + i * si] * vec[j], one add chain with j ascending (the order of the CPU restatement); eight global loads and eight LDS
+// reads are in flight before the chain consumes them: full chunks without any clamping, then one clamped chunk for the remainder
+__device__ __forceinline__ double seq_dot_strided(const double* __restrict__ M, size_t sj, size_t si, int i, int cnt, const double* vec) {
+    constexpr int CH = 8;
+    double a = 0.0;
+    const double* __restrict__ p = M + (size_t)i * si;
+    int j0 = 0;
+    for (; j0 + CH <= cnt; j0 += CH) {
+        double e[CH], x[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) { e[u] = p[(size_t)u * sj]; x[u] = vec[j0 + u]; }
+        p += (size_t)CH * sj;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) a += e[u] * x[u];
+    }
+    if (j0 < cnt) {
+        const int rem = cnt - j0;
+        double e[CH], x[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) { const int uu = (u < rem) ? u : rem - 1; e[u] = p[(size_t)uu * sj]; x[u] = vec[j0 + uu]; }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) if (u < rem) a += e[u] * x[u];
+    }
+    return a;
+}
+
 struct QpResidualState { double max_Ax_z_norm, max_Hx_ATy_h_norm, res_prim, res_dual; };
 
 // residuals_update, box_admm.hpp:398-415 (H, A streamed from global memory, coalesced down the columns)
@@ -467,32 +493,8 @@ __device__ __forceinline__ void qp_residuals(const QpLds& w, int n, int m, const
     // The three products keep one add chain per row (columns ascending: the order of the CPU restatement); what is batched is the
     // loads — eight global loads and eight LDS reads are in flight before the chain consumes them (one dependent L2 round trip per
     // term made this routine cost four substitutions).
-    constexpr int CH = 8;
-    // sum_j M[j * sj + i * si] * vec[j], j ascending: full chunks without any clamping, then one clamped chunk for the remainder
-    auto dot = [&](const double* __restrict__ M, size_t sj, size_t si, int i, int cnt, const double* vec) -> double {
-        double a = 0.0;
-        const double* __restrict__ p = M + (size_t)i * si;
-        int j0 = 0;
-        for (; j0 + CH <= cnt; j0 += CH) {
-            double e[CH], x[CH];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) { e[u] = p[(size_t)u * sj]; x[u] = vec[j0 + u]; }
-            p += (size_t)CH * sj;
-#pragma unroll
-            for (int u = 0; u < CH; ++u) a += e[u] * x[u];
-        }
-        if (j0 < cnt) {
-            const int rem = cnt - j0;
-            double e[CH], x[CH];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) { const int uu = (u < rem) ? u : rem - 1; e[u] = p[(size_t)uu * sj]; x[u] = vec[j0 + uu]; }
-#pragma unroll
-            for (int u = 0; u < CH; ++u) if (u < rem) a += e[u] * x[u];
-        }
-        return a;
-    };
-    auto dot_col = [&](const double* __restrict__ M, int ld, int i, int cnt, const double* vec) -> double { return dot(M, (size_t)ld, 1, i, cnt, vec); };
-    auto dot_row = [&](const double* __restrict__ M, int ld, int i, int cnt, const double* vec) -> double { return dot(M, 1, (size_t)ld, i, cnt, vec); };
+    auto dot_col = [&](const double* __restrict__ M, int ld, int i, int cnt, const double* vec) -> double { return seq_dot_strided(M, (size_t)ld, 1, i, cnt, vec); };
+    auto dot_row = [&](const double* __restrict__ M, int ld, int i, int cnt, const double* vec) -> double { return seq_dot_strided(M, 1, (size_t)ld, i, cnt, vec); };
     double nAx = 0, nz = 0, nx = 0, rp = 0;
     for (int i = ln; i < m; i += WAVE) {
         const double a = dot_col(A, lda, i, n, w.x);

@@ -91,6 +91,28 @@ def _f(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
 
 
+def set_libm(flag):
+    """Model transcendental functions: False (default) = the IEEE-only restatement shared with the HIP kernels, True = glibc (what the
+    reference binary calls). Returns the previous setting."""
+    f = lib().orc_set_libm; f.argtypes = [C.c_int]; f.restype = C.c_int
+    return bool(f(1 if flag else 0))
+
+
+class libm:
+    """with libm(): ... — evaluate the models with glibc inside the block."""
+    def __enter__(self):
+        self.old = set_libm(True)
+    def __exit__(self, *a):
+        set_libm(self.old)
+
+
+def math_eval(kind, x, impl=0):
+    """kind: 'sin' | 'cos' | 'exp'; impl 0 = detmath, 1 = glibc."""
+    x = _f(x); y = np.zeros_like(x)
+    lib().orc_math_eval({"sin": 0, "cos": 1, "exp": 2}[kind], impl, x.size, _p(x), _p(y))
+    return y
+
+
 def qp_default_settings():
     s = QPSettings(); lib().orc_qp_default_settings(C.byref(s)); return s
 

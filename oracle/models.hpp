@@ -16,7 +16,7 @@ struct RobotOCP {
     enum { NX = 3, NU = 2, NP = 0, ND = 1, NG = 0 };
     double Q[3] = {1, 1, 1}, R[2] = {1, 1}, QN[3] = {1, 1, 1};
     template <class T> void dynamics(const T* x, const T* u, const T*, const double* d, const T&, T* xdot) const {
-        using std::cos; using std::sin;
+        using oracle::cos; using oracle::sin;
         xdot[0] = u[0] * cos(x[2]) * cos(u[1]);
         xdot[1] = u[0] * sin(x[2]) * cos(u[1]);
         xdot[2] = u[0] * sin(u[1]) / T(d[0]);
@@ -49,7 +49,7 @@ struct CstrOCP {
     double xs[4] = {2.1402105301746182e00, 1.0903043613077321e00, 1.1419108442079495e02, 1.1290659291045561e02};
     double us[2] = {14.19, -1113.50};
     template <class T> void dynamics(const T* x, const T* u, const T*, const double*, const T&, T* xdot) const {
-        using std::exp;
+        using oracle::exp;
         T c_AO = T(5.1), v_0 = T(104.9), k_w = T(4032.0), A_R = T(0.215), rho = T(0.9342), C_P = T(3.01), V_R = T(10.0);
         T H_1 = T(4.2), H_2 = T(-11.0), H_3 = T(-41.85), m_K = T(5.0), C_PK = T(2.0);
         T k10 = T(1.287e12), k20 = T(1.287e12), k30 = T(9.043e09), E1 = T(-9758.3), E2 = T(-9758.3), E3 = T(-8560.0);
@@ -88,7 +88,7 @@ struct CstrOCP {
 struct ParkingOCP {
     enum { NX = 3, NU = 2, NP = 1, ND = 1, NG = 0 };
     template <class T> void dynamics(const T* x, const T* u, const T* p, const double* d, const T&, T* xdot) const {
-        using std::cos; using std::sin;
+        using oracle::cos; using oracle::sin;
         xdot[0] = p[0] * u[0] * cos(x[2]) * cos(u[1]);
         xdot[1] = p[0] * u[0] * sin(x[2]) * cos(u[1]);
         xdot[2] = p[0] * u[0] * sin(u[1]) / T(d[0]);
@@ -112,7 +112,7 @@ struct RobotNGOCP : RobotOCP {
 struct ParkingNGOCP : ParkingOCP {
     enum { NX = 3, NU = 2, NP = 1, ND = 1, NG = 1 };
     template <class T> void inequality(const T*, const T* u, const T*, const double*, double, T* g) const {
-        using std::cos;
+        using oracle::cos;
         g[0] = u[0] * u[0] * cos(u[1]);
     }
 };
@@ -123,7 +123,7 @@ struct ParkingNGOCP : ParkingOCP {
 struct KiteStandInOCP {
     enum { NX = 13, NU = 3, NP = 0, ND = 0, NG = 0 };
     template <class T> void dynamics(const T* x, const T* u, const T*, const double*, const T&, T* xdot) const {
-        using std::cos; using std::sin;
+        using oracle::cos; using oracle::sin;
         for (int i = 0; i < 13; ++i) {
             const int j = (i + 1) % 13, k = (i + 5) % 13;
             T a = T(-0.1 - 0.01 * i) * x[i];

@@ -65,6 +65,15 @@ template <> RobotNGOCP make_model<RobotNGOCP>(const double* mp, int nmp) {
 
 extern "C" {
 
+int orc_set_libm(int use_libm) { const int old = oracle::use_libm() ? 1 : 0; oracle::use_libm() = use_libm != 0; return old; }
+void orc_math_eval(int kind, int impl, int count, const double* x, double* y) {
+    for (int i = 0; i < count; ++i) {
+        const double v = x[i];
+        if (impl == 0) y[i] = kind == 0 ? pmpc::detmath::sin(v) : (kind == 1 ? pmpc::detmath::cos(v) : pmpc::detmath::exp(v));
+        else y[i] = kind == 0 ? std::sin(v) : (kind == 1 ? std::cos(v) : std::exp(v));
+    }
+}
+
 void orc_qp_default_settings(orc_qp_settings* s) { from_qp(qp_settings(), s); }
 void orc_sqp_qp_default_settings(orc_qp_settings* s) {
     qp_settings q;  // sqp_base.hpp:83-90

@@ -46,6 +46,12 @@ typedef struct {
 enum { ORC_MODEL_ROBOT = 0, ORC_MODEL_CSTR = 1, ORC_MODEL_PARKING = 2, ORC_MODEL_ROBOT_NG = 3, ORC_MODEL_KITE_STANDIN = 4, ORC_MODEL_PARKING_NG = 5 };
 enum { ORC_NLP_CONSTRAINED_ROSENBROCK = 0, ORC_NLP_ROSENBROCK = 1, ORC_NLP_SIMPLE = 2, ORC_NLP_HS071 = 3 };
 
+/* sin / cos / exp used by the model evaluations: 0 (default) = pmpc::detmath, the IEEE-only restatement the HIP kernels share
+ * (GPU-vs-oracle comparisons are bit for bit); 1 = glibc, what the reference binary calls. Process-wide; returns the old value. */
+int  orc_set_libm(int use_libm);
+/* kind 0 sin, 1 cos, 2 exp; impl 0 detmath, 1 glibc: y[i] = f(x[i]) */
+void orc_math_eval(int kind, int impl, int count, const double* x, double* y);
+
 void orc_qp_default_settings(orc_qp_settings* s);       /* qp_base.hpp:17-53 defaults */
 void orc_sqp_qp_default_settings(orc_qp_settings* s);   /* + SQP-ctor overrides sqp_base.hpp:83-90 */
 void orc_sqp_default_settings(orc_sqp_settings* s);

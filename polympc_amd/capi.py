@@ -59,20 +59,37 @@ SQP_INFO_DTYPE = np.dtype([("iter", "i4"), ("qp_solver_iter", "i4"), ("status", 
                            ("primal_norm", "f8"), ("dual_norm", "f8"), ("max_violation", "f8"), ("cost", "f8")])
 assert QP_INFO_DTYPE.itemsize == C.sizeof(QPInfo) == 40 and SQP_INFO_DTYPE.itemsize == C.sizeof(SQPInfo) == 48
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+BUILD_DIR = os.path.join(HERE, "_build")
 
 
-def build_library(force=False, verbose=False):
-    """Cross-compile the HIP library for gfx950 in-tree (works without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
-    newest = max(os.path.getmtime(s) for s in srcs + [os.path.join(HERE, "..", "include", "polympc_amd.h")])
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
-        return LIB_PATH
+def build_library(force=False, verbose=False, jobs=None):
+    """Cross-compile the HIP library for gfx950 in-tree (works without a GPU): one object per translation unit
+    (pmpc_api.hip + one pmpc_model_*.hip per built-in OCP), compiled in parallel, then linked."""
+    from concurrent.futures import ThreadPoolExecutor
+    files = sorted(os.listdir(CSRC))
+    units = [f for f in files if f.endswith(".hip")]
+    deps = [os.path.join(CSRC, f) for f in files if f.endswith(".hpp")] + [os.path.join(HERE, "..", "include", "polympc_amd.h")]
+    newest_hdr = max(os.path.getmtime(d) for d in deps)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, os.path.join(CSRC, "pmpc_api.hip")]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    extra = os.environ.get("PMPC_EXTRA_HIPCC_FLAGS", "").split()
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    todo, objs = [], []
+    for u in units:
+        src, obj = os.path.join(CSRC, u), os.path.join(BUILD_DIR, u[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(newest_hdr, os.path.getmtime(src)):
+            todo.append([hipcc] + HIPCC_FLAGS + extra + ["-c", "-o", obj, src])
+    if not todo and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(o) for o in objs):
+        return LIB_PATH
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(run, todo))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
     return LIB_PATH
 
 

@@ -4,6 +4,7 @@
 // expression templates, usable from __device__ code so a user's templated dynamics_impl<T> compiles for the GPU.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "pmpc_math.hpp"
 
 namespace pmpc {
 
@@ -59,13 +60,22 @@ struct Dual {
     }
 };
 
+// sin / cos / exp of a double: pmpc::detmath (pmpc_math.hpp) — IEEE operations only, so the CPU checker that includes the same header
+// reproduces every model evaluation bit for bit, and within 1 ulp of the glibc functions the reference calls. Building with
+// -DPMPC_LIBM_TRANSCENDENTALS selects the device maths library instead (last-bit differences against any CPU run).
+#ifdef PMPC_LIBM_TRANSCENDENTALS
 __host__ __device__ inline double m_sin(double x) { return ::sin(x); }
 __host__ __device__ inline double m_cos(double x) { return ::cos(x); }
 __host__ __device__ inline double m_exp(double x) { return ::exp(x); }
-__host__ __device__ inline double m_sqrt(double x) { return ::sqrt(x); }
-// sine and cosine of one argument with ONE argument reduction (the device library's sincos shares it between the two
-// polynomial kernels: ~200 instructions instead of ~350 for separate calls, which the compiler does not merge)
 __host__ __device__ inline void m_sincos(double x, double& s, double& c) { ::sincos(x, &s, &c); }
+#else
+__host__ __device__ inline double m_sin(double x) { return detmath::sin(x); }
+__host__ __device__ inline double m_cos(double x) { return detmath::cos(x); }
+__host__ __device__ inline double m_exp(double x) { return detmath::exp(x); }
+// sine and cosine of one argument with ONE argument reduction
+__host__ __device__ inline void m_sincos(double x, double& s, double& c) { const detmath::SinCos r = detmath::sincos(x); s = r.s; c = r.c; }
+#endif
+__host__ __device__ inline double m_sqrt(double x) { return ::sqrt(x); }
 
 template <class S, int N> __host__ __device__ Dual<S, N> m_sin(const Dual<S, N>& a);
 template <class S, int N> __host__ __device__ Dual<S, N> m_cos(const Dual<S, N>& a);
@@ -112,9 +122,9 @@ template <class S, int N> __host__ __device__ Dual<S, N> m_sqrt(const Dual<S, N>
 }
 
 // the names user model code writes (found by ADL for Dual; ::sin etc. for double)
-__host__ __device__ inline double sin(double x) { return ::sin(x); }
-__host__ __device__ inline double cos(double x) { return ::cos(x); }
-__host__ __device__ inline double exp(double x) { return ::exp(x); }
+__host__ __device__ inline double sin(double x) { return m_sin(x); }
+__host__ __device__ inline double cos(double x) { return m_cos(x); }
+__host__ __device__ inline double exp(double x) { return m_exp(x); }
 __host__ __device__ inline double sqrt(double x) { return ::sqrt(x); }
 template <class S, int N> __host__ __device__ Dual<S, N> sin(const Dual<S, N>& a) { return m_sin(a); }
 template <class S, int N> __host__ __device__ Dual<S, N> cos(const Dual<S, N>& a) { return m_cos(a); }
@@ -123,5 +133,28 @@ template <class S, int N> __host__ __device__ Dual<S, N> sqrt(const Dual<S, N>& 
 // extension for model code: both values of one angle at the price of one (see m_sincos)
 __host__ __device__ inline void sincos(double x, double& s, double& c) { m_sincos(x, s, c); }
 template <class S, int N> __host__ __device__ void sincos(const Dual<S, N>& a, Dual<S, N>& s, Dual<S, N>& c) { m_sincos(a, s, c); }
+
+// Value: the scalar of the VALUE-ONLY model evaluations (cost and constraints in the line search and the termination test). It is a
+// double inside a struct for one reason: name lookup. A user's model calls sin(x) / cos(x) / exp(x) unqualified, as in the reference;
+// with T = double those names would resolve to the device maths library, with T = Value (as with T = Dual) argument-dependent lookup
+// finds the functions of this namespace — the value passes and the derivative passes then evaluate every transcendental with the
+// same implementation (pmpc_math.hpp), which is also the one the CPU checker uses. Same size and layout as a double: LDS arrays of
+// doubles are viewed as arrays of Value (as_values in pmpc_models.hpp).
+struct Value {
+    double v;
+    __host__ __device__ Value() : v(0.0) {}
+    __host__ __device__ Value(double c) : v(c) {}
+    __host__ __device__ friend Value operator+(const Value& a, const Value& b) { return Value(a.v + b.v); }
+    __host__ __device__ friend Value operator-(const Value& a, const Value& b) { return Value(a.v - b.v); }
+    __host__ __device__ friend Value operator-(const Value& a) { return Value(-a.v); }
+    __host__ __device__ friend Value operator*(const Value& a, const Value& b) { return Value(a.v * b.v); }
+    __host__ __device__ friend Value operator/(const Value& a, const Value& b) { return Value(a.v / b.v); }
+};
+static_assert(sizeof(Value) == sizeof(double) && alignof(Value) == alignof(double), "Value must alias a double");
+__host__ __device__ inline Value sin(const Value& a) { return Value(m_sin(a.v)); }
+__host__ __device__ inline Value cos(const Value& a) { return Value(m_cos(a.v)); }
+__host__ __device__ inline Value exp(const Value& a) { return Value(m_exp(a.v)); }
+__host__ __device__ inline Value sqrt(const Value& a) { return Value(m_sqrt(a.v)); }
+__host__ __device__ inline void sincos(const Value& a, Value& s, Value& c) { m_sincos(a.v, s.v, c.v); }
 
 }  // namespace pmpc

@@ -8,8 +8,8 @@
 #include <vector>
 
 #include "../../include/polympc_amd.h"
-#include "pmpc_cheb.hpp"
-#include "pmpc_models.hpp"
+#include "pmpc_context.hpp"
+#include "pmpc_builtin.hpp"
 #include "pmpc_ocp.hpp"
 #include "pmpc_qp.hpp"
 #include "pmpc_qp_reg.hpp"
@@ -18,10 +18,6 @@
 #include "pmpc_ruiz.hpp"
 #include "pmpc_admm.hpp"
 
-namespace pmpc {   // LDS-resident kernels that also exist with phase timers (PMPC_PHASE_PROFILE=1): the two models of configs A' / B
-template <> struct LDS_PATH_PROFILED<RobotOCP> { static constexpr bool value = true; };
-template <> struct LDS_PATH_PROFILED<CstrOCP> { static constexpr bool value = true; };
-}
 
 using namespace pmpc;
 
@@ -72,59 +68,6 @@ __global__ __launch_bounds__(64, 2) void qp_boxadmm_reg_kernel(int B, const doub
 }
 static size_t qp_kernel_lds_bytes(int n, int m) { return (QpLds::doubles(n, m) + 3 * (size_t)n + 2 * (size_t)m) * sizeof(double); }
 
-// =====================================================================================================================
-// context
-// =====================================================================================================================
-struct pmpc_context {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    size_t lds_limit = 64 * 1024;
-    unsigned long long* phase_cycles = nullptr;   // PMPC_PHASE_PROFILE=1: per-phase shader-clock totals of the SQP kernels
-    int sqp_slice = 0;             // PMPC_SQP_SLICE=k: run k SQP iterations per kernel launch with per-instance state in HBM (finished
-                                   // instances free their slots); 0 (default) = whole solve in one launch — measured faster on config A
-    bool force_lds_path = false;   // PMPC_FORCE_LDS_PATH=1: disable the register-resident specialisations (A/B testing)
-    std::map<std::tuple<int, int, double, double>, ChebData*> cheb_cache;
-    double* ws = nullptr; size_t ws_bytes = 0;       // SQP HBM workspace (H, J)
-    void* scratch[24] = {nullptr}; size_t scratch_bytes[24] = {0};  // host-buffer API staging
-};
-
-#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "polympc_amd: %s failed: %s (%s:%d)\n", #call, hipGetErrorString(e_), __FILE__, __LINE__); return PMPC_ERR_HIP; } } while (0)
-
-static pmpc_status ensure_ws(pmpc_context* ctx, size_t bytes) {
-    if (ctx->ws_bytes >= bytes) return PMPC_OK;
-    if (ctx->ws) HIPCHK(hipFree(ctx->ws));
-    ctx->ws = nullptr; ctx->ws_bytes = 0;
-    HIPCHK(hipMalloc((void**)&ctx->ws, bytes));
-    ctx->ws_bytes = bytes;
-    return PMPC_OK;
-}
-static pmpc_status ensure_scratch(pmpc_context* ctx, int slot, size_t bytes, void** out) {
-    if (bytes == 0) bytes = 8;
-    if (ctx->scratch_bytes[slot] < bytes) {
-        if (ctx->scratch[slot]) HIPCHK(hipFree(ctx->scratch[slot]));
-        ctx->scratch[slot] = nullptr; ctx->scratch_bytes[slot] = 0;
-        HIPCHK(hipMalloc(&ctx->scratch[slot], bytes));
-        ctx->scratch_bytes[slot] = bytes;
-    }
-    *out = ctx->scratch[slot];
-    return PMPC_OK;
-}
-static pmpc_status get_cheb(pmpc_context* ctx, int P, int S, double t0, double tf, const ChebData** out) {
-    auto key = std::make_tuple(P, S, t0, tf);
-    auto it = ctx->cheb_cache.find(key);
-    if (it != ctx->cheb_cache.end()) { *out = it->second; return PMPC_OK; }
-    ChebData cd;
-    if (!make_cheb_data(P, S, t0, tf, cd)) return PMPC_ERR_UNSUPPORTED_SIZE;
-    ChebData* dptr = nullptr;
-    HIPCHK(hipMalloc((void**)&dptr, sizeof(ChebData)));
-    HIPCHK(hipMemcpyAsync(dptr, &cd, sizeof(ChebData), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));  // cd is a stack object
-    ctx->cheb_cache[key] = dptr;
-    *out = dptr;
-    return PMPC_OK;
-}
-
 extern "C" pmpc_status pmpc_internal_services(pmpc_context* ctx, int P, int S, double t0, double tf, size_t ws_bytes, const void** cheb,
                                                double** ws, void** stream, size_t* lds_limit, unsigned long long** phase_cycles, int* force_lds) {
     if (!ctx) return PMPC_ERR_INVALID_ARGUMENT;
@@ -141,7 +84,6 @@ extern "C" pmpc_status pmpc_internal_services(pmpc_context* ctx, int P, int S, d
 
 extern "C" int pmpc_internal_sqp_slice(pmpc_context* ctx) { return ctx ? ctx->sqp_slice : 0; }
 
-template <class Model> static Model make_model(const double* mp, int nmp) { Model mdl; mdl.set_params(mp, nmp); return mdl; }
 
 // =====================================================================================================================
 // C ABI
@@ -280,23 +222,6 @@ pmpc_status pmpc_qp_boxadmm_solve_batch_dev(pmpc_context* ctx, int B, int n, int
     return PMPC_OK;
 }
 
-#define H2D(slot, host, count, devptr)                                                                        \
-    do {                                                                                                      \
-        void* p_ = nullptr;                                                                                   \
-        if (host) {                                                                                           \
-            pmpc_status st_ = ensure_scratch(ctx, slot, (size_t)(count) * sizeof(double), &p_);               \
-            if (st_ != PMPC_OK) return st_;                                                                   \
-            HIPCHK(hipMemcpyAsync(p_, host, (size_t)(count) * sizeof(double), hipMemcpyHostToDevice, ctx->stream)); \
-        }                                                                                                     \
-        devptr = (double*)p_;                                                                                 \
-    } while (0)
-#define DEVOUT(slot, bytes, devptr)                                                \
-    do {                                                                           \
-        void* p_ = nullptr;                                                        \
-        pmpc_status st_ = ensure_scratch(ctx, slot, (size_t)(bytes), &p_);         \
-        if (st_ != PMPC_OK) return st_;                                            \
-        devptr = (decltype(devptr))p_;                                             \
-    } while (0)
 
 pmpc_status pmpc_qp_boxadmm_solve_batch(pmpc_context* ctx, int B, int n, int m, const double* H, const double* h,
                                         const double* A, const double* Alb, const double* Aub, const double* xlb,
@@ -433,48 +358,6 @@ static pmpc_status dims_impl(int P, int S, int* nx, int* nu, int* np, int* nd, i
     OcpDims<Model> dm(P, S);
     if (nx) *nx = Model::NX; if (nu) *nu = Model::NU; if (np) *np = Model::NP; if (nd) *nd = Model::ND; if (ng) *ng = Model::NG;
     if (n) *n = dm.n; if (me) *me = dm.me; if (mi) *mi = dm.mi;
-    return PMPC_OK;
-}
-
-template <class Model>
-static pmpc_status sqp_builtin_dev(pmpc_context* ctx, int P, int S, double t0, double tf, const double* mp, int nmp, int B,
-                                   const double* x_guess, const double* lam_guess, const double* d, const double* lbx,
-                                   const double* ubx, const double* lbg, const double* ubg, const pmpc_sqp_settings* ss,
-                                   const pmpc_qp_settings* qs, double* x, double* lam, pmpc_sqp_info* info) {
-    const Model mdl = make_model<Model>(mp, nmp);
-    return pmpc::sqp_launch_dev<Model>(ctx, mdl, P, S, t0, tf, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, x, lam, info);
-}
-
-template <class Model>
-static pmpc_status linearise_impl(pmpc_context* ctx, int P, int S, double t0, double tf, const double* mp, int nmp, int B,
-                                  const double* var, const double* d, const double* lam, double* cost, double* constr, double* jac,
-                                  double* cost_grad, double* lag_grad, double* lag_hess) {
-    const ChebData* cd = nullptr;
-    pmpc_status st = get_cheb(ctx, P, S, t0, tf, &cd);
-    if (st != PMPC_OK) return st;
-    OcpDims<Model> dm(P, S);
-    const int n = dm.n, m = dm.m;
-    const size_t lds = linearise_kernel_lds_bytes<Model>(P, S);
-    if (lds > ctx->lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;
-    double *dvar, *dd, *dlam, *dcost, *dc, *dj, *dcg, *dlg, *dlh;
-    H2D(0, var, (size_t)B * n, dvar); H2D(1, (Model::ND ? d : nullptr), (size_t)B * Model::ND, dd); H2D(2, lam, (size_t)B * (m + n), dlam);
-    if (!Model::ND) DEVOUT(1, 8, dd);
-    DEVOUT(3, (size_t)B * 2 * sizeof(double), dcost); DEVOUT(4, (size_t)B * m * sizeof(double), dc);
-    DEVOUT(5, (size_t)B * m * n * sizeof(double), dj); DEVOUT(6, (size_t)B * n * sizeof(double), dcg);
-    DEVOUT(7, (size_t)B * n * sizeof(double), dlg); DEVOUT(8, (size_t)B * n * n * sizeof(double), dlh);
-    HIPCHK(hipFuncSetAttribute((const void*)linearise_kernel<Model>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    Model mdl = make_model<Model>(mp, nmp);
-    hipLaunchKernelGGL(linearise_kernel<Model>, dim3(B), dim3(WAVE), lds, ctx->stream, mdl, cd, B, dvar, dd, dlam, dcost, dc, dj, dcg, dlg, dlh);
-    HIPCHK(hipGetLastError());
-    std::vector<double> c2((size_t)B * 2);
-    HIPCHK(hipMemcpyAsync(c2.data(), dcost, (size_t)B * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (constr) HIPCHK(hipMemcpyAsync(constr, dc, (size_t)B * m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (jac) HIPCHK(hipMemcpyAsync(jac, dj, (size_t)B * m * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (cost_grad) HIPCHK(hipMemcpyAsync(cost_grad, dcg, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (lag_grad) HIPCHK(hipMemcpyAsync(lag_grad, dlg, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (lag_hess) HIPCHK(hipMemcpyAsync(lag_hess, dlh, (size_t)B * n * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (cost) for (int b = 0; b < 2 * B; ++b) cost[b] = c2[b];
     return PMPC_OK;
 }
 

@@ -1,0 +1,84 @@
+// polympc_amd — the context object behind the opaque pmpc_context handle and the host-side staging helpers shared by the
+// translation units of libpolympc_amd.so (pmpc_api.hip and one pmpc_model_*.hip per built-in OCP).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <map>
+#include <tuple>
+#include "../../include/polympc_amd.h"
+#include "pmpc_cheb.hpp"
+
+using pmpc::ChebData;
+using pmpc::make_cheb_data;
+
+// =====================================================================================================================
+// context
+// =====================================================================================================================
+struct pmpc_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    size_t lds_limit = 64 * 1024;
+    unsigned long long* phase_cycles = nullptr;   // PMPC_PHASE_PROFILE=1: per-phase shader-clock totals of the SQP kernels
+    int sqp_slice = 0;             // PMPC_SQP_SLICE=k: run k SQP iterations per kernel launch with per-instance state in HBM (finished
+                                   // instances free their slots); 0 (default) = whole solve in one launch — measured faster on config A
+    bool force_lds_path = false;   // PMPC_FORCE_LDS_PATH=1: disable the register-resident specialisations (A/B testing)
+    std::map<std::tuple<int, int, double, double>, ChebData*> cheb_cache;
+    double* ws = nullptr; size_t ws_bytes = 0;       // SQP HBM workspace (H, J)
+    void* scratch[24] = {nullptr}; size_t scratch_bytes[24] = {0};  // host-buffer API staging
+};
+
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "polympc_amd: %s failed: %s (%s:%d)\n", #call, hipGetErrorString(e_), __FILE__, __LINE__); return PMPC_ERR_HIP; } } while (0)
+
+inline pmpc_status ensure_ws(pmpc_context* ctx, size_t bytes) {
+    if (ctx->ws_bytes >= bytes) return PMPC_OK;
+    if (ctx->ws) HIPCHK(hipFree(ctx->ws));
+    ctx->ws = nullptr; ctx->ws_bytes = 0;
+    HIPCHK(hipMalloc((void**)&ctx->ws, bytes));
+    ctx->ws_bytes = bytes;
+    return PMPC_OK;
+}
+inline pmpc_status ensure_scratch(pmpc_context* ctx, int slot, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 8;
+    if (ctx->scratch_bytes[slot] < bytes) {
+        if (ctx->scratch[slot]) HIPCHK(hipFree(ctx->scratch[slot]));
+        ctx->scratch[slot] = nullptr; ctx->scratch_bytes[slot] = 0;
+        HIPCHK(hipMalloc(&ctx->scratch[slot], bytes));
+        ctx->scratch_bytes[slot] = bytes;
+    }
+    *out = ctx->scratch[slot];
+    return PMPC_OK;
+}
+inline pmpc_status get_cheb(pmpc_context* ctx, int P, int S, double t0, double tf, const ChebData** out) {
+    auto key = std::make_tuple(P, S, t0, tf);
+    auto it = ctx->cheb_cache.find(key);
+    if (it != ctx->cheb_cache.end()) { *out = it->second; return PMPC_OK; }
+    ChebData cd;
+    if (!make_cheb_data(P, S, t0, tf, cd)) return PMPC_ERR_UNSUPPORTED_SIZE;
+    ChebData* dptr = nullptr;
+    HIPCHK(hipMalloc((void**)&dptr, sizeof(ChebData)));
+    HIPCHK(hipMemcpyAsync(dptr, &cd, sizeof(ChebData), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // cd is a stack object
+    ctx->cheb_cache[key] = dptr;
+    *out = dptr;
+    return PMPC_OK;
+}
+
+
+#define H2D(slot, host, count, devptr)                                                                        \
+    do {                                                                                                      \
+        void* p_ = nullptr;                                                                                   \
+        if (host) {                                                                                           \
+            pmpc_status st_ = ensure_scratch(ctx, slot, (size_t)(count) * sizeof(double), &p_);               \
+            if (st_ != PMPC_OK) return st_;                                                                   \
+            HIPCHK(hipMemcpyAsync(p_, host, (size_t)(count) * sizeof(double), hipMemcpyHostToDevice, ctx->stream)); \
+        }                                                                                                     \
+        devptr = (double*)p_;                                                                                 \
+    } while (0)
+#define DEVOUT(slot, bytes, devptr)                                                \
+    do {                                                                           \
+        void* p_ = nullptr;                                                        \
+        pmpc_status st_ = ensure_scratch(ctx, slot, (size_t)(bytes), &p_);         \
+        if (st_ != PMPC_OK) return st_;                                            \
+        devptr = (decltype(devptr))p_;                                             \
+    } while (0)

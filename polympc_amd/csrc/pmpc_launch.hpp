@@ -49,6 +49,7 @@ __global__ __launch_bounds__(64, (NN > 0 ? PMPC_SQP_WAVES : 1)) void sqp_kernel(
     double* stage0 = p;
     p = ocp.s.carve(p, P, S);
     if (NN > 0 && (size_t)(p - stage0) < (size_t)RegKkt<(NN > 0 ? NN + MM : 1)>::TRI + ocp.s.const_doubles(P, S)) p = stage0 + RegKkt<(NN > 0 ? NN + MM : 1)>::TRI + ocp.s.const_doubles(P, S);
+    const double* stage_end = p;   // end of the per-node staging block: what follows (static parameters, filter) stays live during the line search
     // large-instance mode: the remaining QP vectors reuse the second-order AD staging (dead while the QP runs)
     if constexpr (NN == 0 && KHBM) qw.carve_rest(ocp.s.Lhes, n, m, Kws + (size_t)b * QpLds::kdoubles(n + m));
     double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(64, (NN > 0 ? PMPC_SQP_WAVES : 1)) void sqp_kernel(
     {   // side-by-side line search: G candidates x (m constraint values + NN Lagrange values) + 3 scalars each, in the same region
         const int G = WAVE / ocp.dm.NN;
         const size_t need = (size_t)G * (m + ocp.dm.NN + 3);
-        const size_t have = (size_t)((smem + lds_doubles_total) - ocp.s.fval);
+        const size_t have = (size_t)(stage_end - ocp.s.fval);   // the staging block only — never the parameters / filter carved behind it
         sqp.lsbuf = ocp.s.fval;   // a flag, not a null pointer, says whether it fits (compiler hazard 7: null tests of LDS pointers)
         sqp.ls_side_by_side = (G >= 2 && need <= have);
     }

@@ -15,6 +15,9 @@ struct vref {
     __host__ __device__ T& operator[](int i) const { return p[i]; }
 };
 template <class T> using cref = vref<const T>;
+// doubles viewed as value-only scalars (see Value in pmpc_ad.hpp)
+__host__ __device__ inline cref<Value> as_cvalues(const double* p) { return cref<Value>(reinterpret_cast<const Value*>(p)); }
+__host__ __device__ inline vref<Value> as_values(double* p) { return vref<Value>(reinterpret_cast<Value*>(p)); }
 
 // Mobile robot (unicycle with steering): tests/control/mpc_wrapper_test.cpp:33-80, docs/source/ocp.rst:229-281.
 struct RobotOCP {

@@ -122,9 +122,9 @@ struct Ocp {
         for (int k = lane_id(); k < dm.NN; k += WAVE) {
             double f[NX > 0 ? NX : 1];
             for (int q = 0; q < NX; ++q) f[q] = 0.0;
-            double tk = s.tn[k];
-            model.template dynamics_impl<double>(cref<double>(var + k * NX), cref<double>(var + dm.VARX + k * NU),
-                                                 cref<double>(var + dm.VARX + dm.VARU), cref<double>(d), tk, vref<double>(f));
+            const Value tk(s.tn[k]);
+            model.template dynamics_impl<Value>(as_cvalues(var + k * NX), as_cvalues(var + dm.VARX + k * NU),
+                                                as_cvalues(var + dm.VARX + dm.VARU), cref<double>(d), tk, as_values(f));
             int seg, row; seg_row(k, seg, row);
             for (int q = 0; q < NX; ++q) {
                 double acc = 0.0;
@@ -136,8 +136,8 @@ struct Ocp {
             if (NG > 0) {
                 double g[NG > 0 ? NG : 1];
                 for (int q = 0; q < NG; ++q) g[q] = 0.0;
-                model.template inequality_constraints_impl<double>(cref<double>(var + k * NX), cref<double>(var + dm.VARX + k * NU),
-                                                                   cref<double>(var + dm.VARX + dm.VARU), cref<double>(d), tk, vref<double>(g));
+                model.template inequality_constraints_impl<Value>(as_cvalues(var + k * NX), as_cvalues(var + dm.VARX + k * NU),
+                                                                  as_cvalues(var + dm.VARX + dm.VARU), cref<double>(d), tk.v, as_values(g));
                 for (int q = 0; q < NG; ++q) c[dm.me + k * NG + q] = g[q];
             }
         }
@@ -147,19 +147,19 @@ struct Ocp {
     // ---- cost (:1182-1207)
     __device__ __forceinline__ double cost(const double* var) {
         for (int k = lane_id(); k < dm.NN; k += WAVE) {
-            double L = 0.0;
-            model.template lagrange_term_impl<double>(cref<double>(var + k * NX), cref<double>(var + dm.VARX + k * NU),
-                                                      cref<double>(var + dm.VARX + dm.VARU), cref<double>(d), s.tn[k], L);
-            s.Lval[k] = L;
+            Value L(0.0);
+            model.template lagrange_term_impl<Value>(as_cvalues(var + k * NX), as_cvalues(var + dm.VARX + k * NU),
+                                                     as_cvalues(var + dm.VARX + dm.VARU), cref<double>(d), s.tn[k], L);
+            s.Lval[k] = L.v;
         }
         wsync();
         double c = 0.0;
         for (int sg = 0; sg < S; ++sg)
             for (int k = 0; k <= P; ++k) c += ts * s.w[k] * s.Lval[sg * P + k];
-        double M = 0.0;
-        model.template mayer_term_impl<double>(cref<double>(var), cref<double>(var + dm.VARX), cref<double>(var + dm.VARX + dm.VARU),
-                                               cref<double>(d), s.tn[0], M);
-        c += M;
+        Value M(0.0);
+        model.template mayer_term_impl<Value>(as_cvalues(var), as_cvalues(var + dm.VARX), as_cvalues(var + dm.VARX + dm.VARU),
+                                              cref<double>(d), s.tn[0], M);
+        c += M.v;
         wsync();
         return c;
     }

@@ -232,7 +232,7 @@ struct SqpDevice {
                 for (int q = 0; q < NU; ++q) uk[q] = xat(VARX + k * NU + q);
                 for (int q = 0; q < NP; ++q) pk[q] = xat(VARX + VARU + q);
                 const double tk = ocp.s.tn[k];
-                ocp.model.template dynamics_impl<double>(cref<double>(xk), cref<double>(uk), cref<double>(pk), cref<double>(ocp.d), tk, vref<double>(f));
+                ocp.model.template dynamics_impl<Value>(as_cvalues(xk), as_cvalues(uk), as_cvalues(pk), cref<double>(ocp.d), Value(tk), as_values(f));
                 int seg, row; ocp.seg_row(k, seg, row);
                 {   // D-row times the segment's states: loads of 4 nodes at a time (independent), then the ordered adds
                     double acc[NX > 0 ? NX : 1];
@@ -263,12 +263,12 @@ struct SqpDevice {
                 if (NG > 0) {
                     double gg[NG > 0 ? NG : 1];
                     for (int q = 0; q < NG; ++q) gg[q] = 0.0;
-                    ocp.model.template inequality_constraints_impl<double>(cref<double>(xk), cref<double>(uk), cref<double>(pk), cref<double>(ocp.d), tk, vref<double>(gg));
+                    ocp.model.template inequality_constraints_impl<Value>(as_cvalues(xk), as_cvalues(uk), as_cvalues(pk), cref<double>(ocp.d), tk, as_values(gg));
                     for (int q = 0; q < NG; ++q) cand_c[g * m + me + k * NG + q] = gg[q];
                 }
-                double L = 0.0;
-                ocp.model.template lagrange_term_impl<double>(cref<double>(xk), cref<double>(uk), cref<double>(pk), cref<double>(ocp.d), tk, L);
-                cand_L[g * NNo + k] = L;
+                Value L(0.0);
+                ocp.model.template lagrange_term_impl<Value>(as_cvalues(xk), as_cvalues(uk), as_cvalues(pk), cref<double>(ocp.d), tk, L);
+                cand_L[g * NNo + k] = L.v;
             }
             wsync();
             const long long e1 = now();
@@ -327,9 +327,9 @@ struct SqpDevice {
                 for (int q = 0; q < NX; ++q) x0[q] = xat(q);
                 for (int q = 0; q < NU; ++q) u0[q] = xat(VARX + q);
                 for (int q = 0; q < NP; ++q) p0[q] = xat(VARX + VARU + q);
-                double M = 0.0;
-                ocp.model.template mayer_term_impl<double>(cref<double>(x0), cref<double>(u0), cref<double>(p0), cref<double>(ocp.d), ocp.s.tn[0], M);
-                c += M;
+                Value M(0.0);
+                ocp.model.template mayer_term_impl<Value>(as_cvalues(x0), as_cvalues(u0), as_cvalues(p0), cref<double>(ocp.d), ocp.s.tn[0], M);
+                c += M.v;
                 cand_cost[gc] = c;
             }
             wsync();

@@ -108,7 +108,7 @@ void orc_ldlt_solve(int n, const double* K, const double* b, int pivot, double* 
 void orc_qp_admm_solve_batch(int B, int n, int m, const double* H, const double* h, const double* A, const double* Alb,
                              const double* Aub, const double* xlb, const double* xub, const double* x0, const double* y0,
                              const orc_qp_settings* s, int pivot, int threads, double* x, double* y, orc_qp_info* info) {
-#pragma omp parallel for schedule(dynamic) num_threads(threads > 1 ? threads : 1)
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads > 1 ? threads : 1)
     for (int b = 0; b < B; ++b) {
         ADMM qp(n, m);
         qp.settings = to_qp(s);
@@ -146,7 +146,7 @@ void orc_ruiz_unscale_solution_batch(int B, int n, int m, const double* D, const
 void orc_qp_solve_batch(int B, int n, int m, const double* H, const double* h, const double* A, const double* Alb,
                         const double* Aub, const double* xlb, const double* xub, const double* x0, const double* y0,
                         const orc_qp_settings* s, int pivot, int threads, double* x, double* y, orc_qp_info* info) {
-#pragma omp parallel for schedule(dynamic) num_threads(threads > 1 ? threads : 1)
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads > 1 ? threads : 1)
     for (int b = 0; b < B; ++b) {
         BoxADMM qp(n, m);
         qp.settings = to_qp(s);
@@ -231,7 +231,7 @@ static void sqp_batch_impl(int P, int S, double t0, double tf, const double* mp,
                            const double* lam_guess, const double* d, const double* lbx, const double* ubx,
                            const double* lbg, const double* ubg, const orc_sqp_settings* ss, const orc_qp_settings* qs,
                            int pivot, int threads, double* x, double* lam, orc_sqp_info* info) {
-#pragma omp parallel for schedule(dynamic) num_threads(threads > 1 ? threads : 1)
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads > 1 ? threads : 1)
     for (int b = 0; b < B; ++b) {
         ContinuousOCP<Model> ocp(P, S, make_model<Model>(mp, nmp));
         ocp.set_time_limits(t0, tf);

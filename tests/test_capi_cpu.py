@@ -82,3 +82,12 @@ def test_workload_generator_is_deterministic():
     assert np.array_equal(a["lbx"][4:], b["lbx"]) and np.array_equal(a["d"][4:], b["d"])
     u = workloads.uniform_pm1(workloads.SEED, np.arange(1000), 0)
     assert -1 <= u.min() < -0.9 and 0.9 < u.max() <= 1 and abs(u.mean()) < 0.1
+
+
+def test_bench_rejects_a_launcher_mismatch():
+    """bench.py --gpus N under a launcher that started a different number of ranks is an error (never a silent single-GPU run)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

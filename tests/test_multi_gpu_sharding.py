@@ -47,3 +47,74 @@ def test_two_rank_sharding_gloo(tmp_path, oracle):
     ss = oracle.sqp_default_settings(); ss.max_iter = 10; ss.line_search_max_iter = 10
     xg, _, _ = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 6, 1, 0.0, 2.0, world * B, g["d"], g["lbx"], g["ubx"], sqp_settings=ss, pivot=oracle.PIVOT_STATIC)
     assert np.array_equal(np.concatenate([r[0]["x"], r[1]["x"]]), xg)
+
+
+# ------------------------------------------------------------------------------------------------ the PRODUCT on N > 1 ranks (GPU)
+def _gpu_worker(rank, world, port, out_dir):
+    """One rank of the multi-GPU path as bench.py runs it — a context per rank, the rank's shard of the instance stream, device-resident
+    solve, statistics combined over the process group — with both ranks on device 0 (the test box has one GPU) and gloo for the group."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import polympc_amd as pa
+    from polympc_amd import workloads, sharding
+    Bg = 64
+    dev = torch.device("cuda", 0)
+    wl = workloads.robot_batch(Bg, first=sharding.shard_first_instance(rank, Bg))
+    stream = torch.cuda.Stream(dev)
+    ctx = pa.Context(0, stream=stream.cuda_stream)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    n, m = wl["n"], wl["m"]
+    x = torch.zeros(Bg, n, dtype=torch.float64, device=dev); lam = torch.zeros(Bg, m + n, dtype=torch.float64, device=dev)
+    info = torch.zeros(Bg, 48, dtype=torch.uint8, device=dev)
+    ss = pa.sqp_settings_default(); ss.max_iter = 10; ss.line_search_max_iter = 10
+    ctx.sqp_solve_batch_dev(wl["model"], 6, 1, 0.0, 2.0, Bg, t(wl["d"]), t(wl["lbx"]), t(wl["ubx"]), x, lam, info, ss, pa.qp_settings_sqp_default())
+    torch.cuda.synchronize(dev)
+    inf = np.frombuffer(info.cpu().numpy().tobytes(), dtype=pa.capi.SQP_INFO_DTYPE)
+    dist.barrier()
+    (qp_all,), t_max = sharding.combine_stats(dist, torch.device("cpu"), [int(inf["iter"].sum())], elapsed=1.0 + rank)
+    np.savez(os.path.join(out_dir, f"g{rank}.npz"), x=x.cpu().numpy(), it=inf["iter"], qp_all=qp_all, t_max=t_max)
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_product_shards_equal_single_process_batch(tmp_path):
+    """Two ranks of the HIP library, each solving its shard, against ONE process solving the global batch: bit-identical solutions and
+    iteration counts (no cross-instance coupling; the shard boundaries are those of bench.py), and the reductions bench.py reports."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    world, Bg = 2, 64
+    mp.spawn(_gpu_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"g{k}.npz") for k in range(world)]
+    g = workloads.robot_batch(world * Bg)
+    ctx = pa.Context(0)
+    ss = pa.sqp_settings_default(); ss.max_iter = 10; ss.line_search_max_iter = 10
+    xg, _, ig = ctx.sqp_solve_batch(g["model"], 6, 1, 0.0, 2.0, world * Bg, g["d"], g["lbx"], g["ubx"], sqp_settings=ss)
+    ctx.close()
+    assert np.array_equal(np.concatenate([r[0]["x"], r[1]["x"]]), xg)
+    assert np.array_equal(np.concatenate([r[0]["it"], r[1]["it"]]), ig["iter"])
+    for k in range(world):
+        assert r[k]["qp_all"] == ig["iter"].sum() and r[k]["t_max"] == 2.0
+
+
+@pytest.mark.gpu
+def test_bench_gpus_flag_starts_the_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher must start two ranks itself and report n_gpus = 2 with the whole-job aggregate
+    (developer switches put both ranks on the one GPU of the test box and use gloo for the barrier / reductions)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PMPC_BENCH_SINGLE_DEVICE="1", PMPC_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "512",
+                          "--cpu-sample", "0", "--configs", "", "--no-replay"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 1024 and j["value"] > 0 and j["scaling"] == "weak"
+    # a launcher / flag mismatch is an error, not a silent single-GPU run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env2, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)

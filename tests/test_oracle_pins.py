@@ -9,6 +9,16 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden", "casadi_robot_P5S2.npz"
 inf = np.inf
 
 
+@pytest.fixture(autouse=True, params=["glibc", "detmath"])
+def transcendental_functions(request, oracle):
+    """Every pin runs twice: with glibc's sin / cos / exp (what the reference binary calls) and with the IEEE-only restatement the HIP
+    kernels share (polympc_amd/csrc/pmpc_math.hpp, pinned to glibc within 1 ulp in tests/test_math_pins.py) — the known answers hold
+    for both, so the GPU-vs-oracle comparisons (which use the shared functions to be bit for bit) are pinned to the reference too."""
+    old = oracle.set_libm(request.param == "glibc")
+    yield request.param
+    oracle.set_libm(old)
+
+
 # ---------------------------------------------------------------- A1: Chebyshev constants (SURVEY.md Appendix A)
 @pytest.mark.parametrize("P", [2, 3, 4, 5, 6, 7, 8, 15])
 def test_cheb_closed_forms(oracle, P):

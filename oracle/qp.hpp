@@ -18,6 +18,7 @@
 //                  compares the two policies on the reference's QP fixtures and on the SQP workloads).
 //   PIVOT_STATIC : identical arithmetic without the permutation, right-looking update order — the order
 //                  the HIP kernels use, so a GPU-vs-oracle comparison isolates kernel bugs from pivot effects.
+//   PIVOT_SWEEP2 : PIVOT_SWEEP's blocked sweep for 65..112 rows with the mat-vec order of the two-rows-per-lane register kernel
 //   PIVOT_SWEEP1 : the swept inverse of PIVOT_SWEEP one pivot at a time on the lower triangle (any size), x = -(W b) as one fma chain
 //                  per row: accuracy evidence for the explicit-inverse route above 64 rows (no shipped kernel uses it this round).
 // All matrices column-major.
@@ -31,7 +32,7 @@
 namespace oracle {
 
 enum qp_status { QP_SOLVED = 0, QP_MAX_ITER_EXCEEDED = 1, QP_UNSOLVED = 2, QP_UNINITIALIZED = 3, QP_INFEASIBLE = 4, QP_INCONSISTENT = 5 };
-enum pivot_policy { PIVOT_EIGEN = 0, PIVOT_STATIC = 1, PIVOT_SWEEP = 2, PIVOT_SWEEP1 = 3 };
+enum pivot_policy { PIVOT_EIGEN = 0, PIVOT_STATIC = 1, PIVOT_SWEEP = 2, PIVOT_SWEEP1 = 3, PIVOT_SWEEP2 = 4 };
 
 struct qp_settings {  // qp_base.hpp:17-53 (ADMM-related subset)
     double eps_rel = 1e-3, eps_abs = 1e-3;
@@ -65,6 +66,10 @@ struct LDLT {
         n = n_; policy = pol; M = K; tr.assign(n, 0); temp.assign(n, 0.0);
         if (policy == PIVOT_STATIC) { compute_static(); return; }
         if (policy == PIVOT_SWEEP1) { compute_sweep1(); return; }
+        if (policy == PIVOT_SWEEP2) {  // the two-rows-per-lane register kernel (pmpc_qp_reg2.hpp): the same blocked sweep on 65..112 rows
+            if (n > 112) throw std::invalid_argument("oracle: PIVOT_SWEEP2 restates the 112-row register kernel; use PIVOT_STATIC / PIVOT_EIGEN for larger systems");
+            compute_sweep(); return;
+        }
         if (policy == PIVOT_SWEEP) {   // mirrors the register-resident kernel, which exists for at most 64 KKT rows (4 column blocks of 16)
             if (n > 64) throw std::invalid_argument("oracle: PIVOT_SWEEP restates the 64-row register kernel; use PIVOT_STATIC / PIVOT_EIGEN for larger systems");
             compute_sweep(); return;
@@ -183,6 +188,15 @@ struct LDLT {
         auto at = [&](int i, int j) -> double { return M[i + j * n]; };
         if (policy == PIVOT_SWEEP1) {   // x = -(W b): one fma chain per row, columns ascending
             for (int i = 0; i < n; ++i) { double a = 0.0; for (int j = 0; j < n; ++j) a = std::fma(at(i, j), b[j], a); x[i] = -a; }
+            return;
+        }
+        if (policy == PIVOT_SWEEP2) {  // x = -(W b): four fma chains per row, chain q over the columns j = q (mod 4) ascending (the columns one
+                                       // 16-lane row of the wavefront owns in the accumulator-tile layout), combined as (P0+P2)+(P1+P3)
+            for (int i = 0; i < n; ++i) {
+                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int j = 0; j < n; ++j) acc[j & 3] = std::fma(at(i, j), b[j], acc[j & 3]);
+                x[i] = -((acc[0] + acc[2]) + (acc[1] + acc[3]));
+            }
             return;
         }
         if (policy == PIVOT_SWEEP) {   // x = -(W b): one fma chain per block of 16 columns (P_r, r = j/16), combined as (P0+P2)+(P1+P3)

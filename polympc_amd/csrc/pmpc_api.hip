@@ -21,6 +21,10 @@
 
 using namespace pmpc;
 
+extern "C" int pmpc_internal_qp_reg2_launch(void* stream, int B, int n, int m, const double* H, const double* h, const double* A, const double* Alb,
+                                            const double* Aub, const double* xlb, const double* xub, const double* x0, const double* y0,
+                                            const pmpc_qp_settings* s, double* x, double* y, pmpc_qp_info* info);
+
 // =====================================================================================================================
 // kernels: one 64-lane workgroup (= one wavefront) per instance; grid = batch
 // =====================================================================================================================
@@ -212,6 +216,11 @@ pmpc_status pmpc_qp_boxadmm_solve_batch_dev(pmpc_context* ctx, int B, int n, int
                            *settings, x, y, info);
         HIPCHK(hipGetLastError());
         return PMPC_OK;
+    }
+    if (!ctx->force_lds_path) {   // 65..112 KKT rows with a two-rows-per-lane register specialisation (pmpc_qp_reg2.hip)
+        const int r2 = pmpc_internal_qp_reg2_launch((void*)ctx->stream, B, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0, settings, x, y, info);
+        if (r2 < 0) return PMPC_ERR_HIP;
+        if (r2 > 0) return PMPC_OK;
     }
     const size_t lds = qp_kernel_lds_bytes(n, m);
     if (lds > ctx->lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;

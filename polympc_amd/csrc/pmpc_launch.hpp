@@ -6,6 +6,7 @@
 #include "pmpc_ocp.hpp"
 #include "pmpc_qp.hpp"
 #include "pmpc_qp_reg.hpp"
+#include "pmpc_qp_reg2.hpp"
 #include "pmpc_sqp.hpp"
 
 // context services exported by libpolympc_amd.so (collocation constants cache, HBM workspace, stream, limits)
@@ -18,6 +19,13 @@ using ::pmpc_status;
 
 constexpr int FILTER_LDS_DOUBLES = 24;   // PMPC_FILTER_STATE_DOUBLES rounded up
 
+// LDS staging (doubles) of the register-resident QP that serves a compile-time size: one row per lane up to 64 KKT rows, two rows per lane up to 112
+template <int NKKT> constexpr int reg_qp_staging() {
+    if constexpr (NKKT <= 0) return 0;
+    else if constexpr (NKKT <= WAVE) return RegKkt<NKKT>::TRI;
+    else return RegKkt2<NKKT>::TRI;
+}
+
 // KHBM: large-instance mode of the LDS-resident kernels — the KKT factor lives in an HBM workspace (Kws). A compile-time flag so
 // that in the normal mode every QP pointer provably addresses LDS (ds_read / ds_write instead of flat accesses, which cost the
 // LDS path most of its time when the location of K was a run-time choice)
@@ -25,7 +33,7 @@ template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bo
 #ifndef PMPC_SQP_WAVES
 #define PMPC_SQP_WAVES 2
 #endif
-__global__ __launch_bounds__(64, (NN > 0 ? PMPC_SQP_WAVES : 1)) void sqp_kernel(Model model, const ChebData* __restrict__ cd, int B,
+__global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : 1)) void sqp_kernel(Model model, const ChebData* __restrict__ cd, int B,
                                                  const double* __restrict__ x_guess, const double* __restrict__ lam_guess,
                                                  const double* __restrict__ d, const double* __restrict__ lbx,
                                                  const double* __restrict__ ubx, const double* __restrict__ lbg,
@@ -48,7 +56,7 @@ __global__ __launch_bounds__(64, (NN > 0 ? PMPC_SQP_WAVES : 1)) void sqp_kernel(
     p = v.carve(p, n, m, mi);
     double* stage0 = p;
     p = ocp.s.carve(p, P, S);
-    if (NN > 0 && (size_t)(p - stage0) < (size_t)RegKkt<(NN > 0 ? NN + MM : 1)>::TRI + ocp.s.const_doubles(P, S)) p = stage0 + RegKkt<(NN > 0 ? NN + MM : 1)>::TRI + ocp.s.const_doubles(P, S);
+    if (NN > 0 && (size_t)(p - stage0) < (size_t)reg_qp_staging<NN + MM>() + ocp.s.const_doubles(P, S)) p = stage0 + reg_qp_staging<NN + MM>() + ocp.s.const_doubles(P, S);
     const double* stage_end = p;   // end of the per-node staging block: what follows (static parameters, filter) stays live during the line search
     // large-instance mode: the remaining QP vectors reuse the second-order AD staging (dead while the QP runs)
     if constexpr (NN == 0 && KHBM) qw.carve_rest(ocp.s.Lhes, n, m, Kws + (size_t)b * QpLds::kdoubles(n + m));
@@ -101,15 +109,16 @@ __global__ __launch_bounds__(64, (NN > 0 ? PMPC_SQP_WAVES : 1)) void sqp_kernel(
     }
     if constexpr (PROF) { if (phase_cycles && ln == 0) for (int i = 0; i < 24; ++i) atomicAdd(&phase_cycles[i], (unsigned long long)sqp.cyc[i]); }
 }
-// mode 0: KKT factor in LDS; 1: register-resident QP (n+m <= 64); 2: KKT factor in HBM (large instances)
+// mode 0: KKT factor in LDS; 1: register-resident QP (n+m <= 64); 2: KKT factor in HBM (large instances); 3: register-resident QP, 65..112 rows
 template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode, int qp_solver = 0) {
     OcpDims<Model> dm(P, S);
     if (mode == 0 && qp_solver == 1)
         return (QpLds::doubles(dm.n, dm.m + dm.n) + SqpLds::doubles(dm.n, dm.m, dm.mi) + OcpLds<Model>::doubles(P, S) + 8 + FILTER_LDS_DOUBLES) * sizeof(double);
     size_t stage = OcpLds<Model>::doubles(P, S);
     if (mode == 1) { const size_t need = (size_t)RegKkt<64>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
+    if (mode == 3) { const size_t need = (size_t)RegKkt2<112>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
     return ((mode == 0 ? QpLds::doubles(dm.n, dm.m) : QpLds::doubles_xy(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8 +
-            (mode == 1 ? 0 : FILTER_LDS_DOUBLES)) * sizeof(double);
+            ((mode == 1 || mode == 3) ? 0 : FILTER_LDS_DOUBLES)) * sizeof(double);
 }
 template <class Model> inline bool sqp_hbm_mode_fits(int P, int S) {   // do the QP vectors fit the second-order staging?
     OcpDims<Model> dm(P, S);
@@ -193,6 +202,18 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
                                *ss, *qs, Hws, Aws, x, lam, info, phase, (double*)nullptr, it, it + slice, slice_state, (unsigned)(ldsr / sizeof(double)));
         *st = (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
         return true;
+    } else if constexpr (NN_ + MM_ <= 112) {   // two KKT rows per lane (pmpc_qp_reg2.hpp); the Hessian-update policy is a run-time choice there
+        if (P * S + 1 != NNODES) return false;
+        const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, 3);
+        if (ldsr > lds_limit) return false;
+        auto kern = sqp_kernel<Model, NN_, MM_, false>;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
+        const int slice = (slice_state && slice_iters > 0) ? slice_iters : ss->max_iter;
+        for (int it = 0; it < ss->max_iter; it += slice)
+            hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), ldsr, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
+                               *ss, *qs, Hws, Aws, x, lam, info, (unsigned long long*)nullptr, (double*)nullptr, it, it + slice, slice_state, (unsigned)(ldsr / sizeof(double)));
+        *st = (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
+        return true;
     } else {
         return false;
     }
@@ -222,6 +243,7 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
         pmpc_status rst = PMPC_OK;
         if (try_launch_reg<Model, 7>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;
         if (try_launch_reg<Model, 5>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;
+        if (try_launch_reg<Model, 11>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;   // config B / the reference's P = 5, S = 2 grids: 88..110 KKT rows
     }
     size_t lds = sqp_kernel_lds_bytes<Model>(P, S, 0, ss->qp_solver);
     double* Kws = nullptr;

@@ -9,8 +9,8 @@
 // fma, division, integer arithmetic on the bit pattern) the CPU restatement used by the tests and the HIP kernels agree
 // bit for bit, and every trajectory test can demand identity instead of a tolerance.
 // Accuracy: < 1 ulp (checked against glibc in tests/test_oracle_pins.py) for |x| < 2^19 * pi/2 (sin / cos) and everywhere (exp).
-// Beyond that range sin / cos use a three-constant fma reduction whose absolute error grows like 2^-60 |x| — still identical on
-// both sides; no collocation problem has angles of 10^6 rad.
+// Beyond that range the same reduction loses accuracy gradually (absolute error ~ 1e-26 |x|^2) and from 2^50 on (sin, cos) is defined as (0, 1) — still
+// identical on both sides; no collocation problem has angles of 10^6 rad.
 //
 // This header has no dependencies and is included by the product (pmpc_ad.hpp) and, as a maths library, by the CPU checker
 // (its AD header). Compile with -ffp-contract=off (both build recipes do); the routines use explicit fma where they want one.
@@ -35,13 +35,6 @@ namespace detmath {
 PMPC_MATH_HD inline double from_bits(unsigned long long u) { return __builtin_bit_cast(double, u); }
 PMPC_MATH_HD inline unsigned long long to_bits(double x) { return __builtin_bit_cast(unsigned long long, x); }
 PMPC_MATH_HD inline double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
-// round to nearest integer (ties to even) by the 1.5 * 2^52 trick: two additions, exact for |x| < 2^51
-PMPC_MATH_HD inline double rint_small(double x) {
-    PMPC_MATH_NOCONTRACT
-    const double magic = 6755399441055744.0;
-    const double t = x + magic;      // (no -ffast-math on either side: the pair of additions is not simplified)
-    return t - magic;
-}
 
 struct SinCos { double s, c; };
 
@@ -67,50 +60,41 @@ PMPC_MATH_HD inline double kcos(double x, double y) {
     return w + (((1.0 - w) - hz) + (z * r - x * y));
 }
 
-// x = n * pi/2 + (y0 + y1), |y0 + y1| <= pi/4 (a little more next to the boundaries); returns n mod 4
+// x = n * pi/2 + (y0 + y1), |y0 + y1| <= pi/4 (a little more next to the boundaries); returns n mod 4.
+// One straight-line path for every finite x (two rarely taken refinement branches): fn = rint(x * 2/pi) by the magic-number addition, whose
+// low mantissa bits ARE the integer (n mod 4 without a conversion); first step with fma (exact below 2^19 pi/2, where fn * PIO2_1 is exact
+// anyway, and correctly rounded above).
 PMPC_MATH_HD inline int rem_pio2(double x, double& y0, double& y1) {
     PMPC_MATH_NOCONTRACT
     const double INVPIO2 = from_bits(0x3FE45F306DC9C883ull);
     const double PIO2_1 = from_bits(0x3FF921FB54400000ull), PIO2_1T = from_bits(0x3DD0B4611A626331ull);
     const double PIO2_2 = from_bits(0x3DD0B4611A600000ull), PIO2_2T = from_bits(0x3BA3198A2E037073ull);
     const double PIO2_3 = from_bits(0x3BA3198A2E000000ull), PIO2_3T = from_bits(0x397B839A252049C1ull);
-    const unsigned long long ux = to_bits(x);
-    const unsigned ix = (unsigned)(ux >> 32) & 0x7fffffffu;
-    if (ix < 0x413921fbu) {                                                     // |x| < 2^19 * pi/2: three-step Cody–Waite (fn = 0, y0 = x below pi/4)
-        const double fn = rint_small(x * INVPIO2);
-        const int n = (int)fn;
-        double r = x - fn * PIO2_1;                                             // exact: 33-bit constant, |fn| < 2^20
-        double w = fn * PIO2_1T;
-        const int j = (int)(ix >> 20);
-        double y = r - w;
-        int i = j - (int)((to_bits(y) >> 52) & 0x7ff);
-        if (i > 16) {                                                           // cancellation: second step, good to 118 bits
-            double t = r;
-            w = fn * PIO2_2; r = t - w; w = fn * PIO2_2T - ((t - r) - w); y = r - w;
-            i = j - (int)((to_bits(y) >> 52) & 0x7ff);
-            if (i > 49) {                                                       // third step, 151 bits
-                t = r;
-                w = fn * PIO2_3; r = t - w; w = fn * PIO2_3T - ((t - r) - w); y = r - w;
-            }
+    const double MAGIC = 6755399441055744.0;                                    // 1.5 * 2^52
+    const double tm = x * INVPIO2 + MAGIC;
+    const double fn = tm - MAGIC;
+    const int n = (int)(unsigned)to_bits(tm);                                   // low 32 bits of the mantissa = fn mod 2^32 (two's complement)
+    double r = fma_(-fn, PIO2_1, x);
+    double w = fn * PIO2_1T;
+    const int j = (int)((to_bits(x) >> 52) & 0x7ff);
+    double y = r - w;
+    int i = j - (int)((to_bits(y) >> 52) & 0x7ff);
+    if (i > 16) {                                                               // cancellation: second step, good to 118 bits
+        double t = r;
+        w = fn * PIO2_2; r = t - w; w = fn * PIO2_2T - ((t - r) - w); y = r - w;
+        i = j - (int)((to_bits(y) >> 52) & 0x7ff);
+        if (i > 49) {                                                           // third step, 151 bits
+            t = r;
+            w = fn * PIO2_3; r = t - w; w = fn * PIO2_3T - ((t - r) - w); y = r - w;
         }
-        y0 = y; y1 = (r - y) - w;
-        return n & 3;
     }
-    if (ix >= 0x7ff00000u) { y0 = x - x; y1 = 0.0; return 0; }                 // inf / NaN -> NaN
-    {   // large arguments: pi/2 = C1 + C2 + C3 (53 bits each), two fma steps and a tail
-        const double C1 = from_bits(0x3FF921FB54442D18ull), C2 = from_bits(0x3C91A62633145C07ull), C3 = from_bits(0xB91F1976B7ED8FBCull);
-        const double ax = x < 0 ? -x : x;
-        if (!(ax < 1125899906842624.0)) { y0 = 0.0; y1 = 0.0; return 0; }      // |x| >= 2^50: the spacing of doubles exceeds 1/8 — no phase information left (sin 0, cos 1)
-        const double fn = rint_small(x * INVPIO2);
-        double r = fma_(-fn, C1, x);
-        r = fma_(-fn, C2, r);
-        const double w = fn * C3;
-        const double y = r - w;
-        y0 = y; y1 = (r - y) - w;
-        // n mod 4 from the integer-valued double: fn - 4 * rint(fn / 4)
-        const double q = fn - 4.0 * rint_small(fn * 0.25);
-        return ((int)q) & 3;
-    }
+    // |x| >= 2^50 (the spacing of doubles exceeds 1/8: no phase information left) -> reduced argument 0, i.e. (sin, cos) = (0, 1);
+    // inf / NaN -> NaN. Selects, not branches.
+    const double ax = x < 0 ? -x : x;
+    const bool huge = !(ax < 1125899906842624.0);
+    y0 = huge ? (x - x) : y;
+    y1 = huge ? 0.0 : ((r - y) - w);
+    return huge ? 0 : (n & 3);
 }
 
 // both values with one argument reduction
@@ -128,34 +112,31 @@ PMPC_MATH_HD inline SinCos sincos(double x) {
 PMPC_MATH_HD inline double sin(double x) { return sincos(x).s; }
 PMPC_MATH_HD inline double cos(double x) { return sincos(x).c; }
 
+// exp: k = rint(x / ln 2), r = x - k ln 2 in two pieces, the degree-5 rational form on r, scaling by 2^k in two factors (one rounding even
+// when the result is subnormal). Straight-line: the special cases are selects on the argument at the end.
 PMPC_MATH_HD inline double exp(double x) {
     PMPC_MATH_NOCONTRACT
     const double LN2HI = from_bits(0x3FE62E42FEE00000ull), LN2LO = from_bits(0x3DEA39EF35793C76ull), INVLN2 = from_bits(0x3FF71547652B82FEull);
     const double P1 = from_bits(0x3FC555555555553Eull), P2 = from_bits(0xBF66C16C16BEBD93ull), P3 = from_bits(0x3F11566AAF25DE2Cull),
                  P4 = from_bits(0xBEBBBD41C5D26BF1ull), P5 = from_bits(0x3E66376972BEA4D0ull);
-    if (x != x) return x + x;
-    if (x > 709.782712893384) return from_bits(0x7FF0000000000000ull);
-    if (x < -745.1332191019412) return 0.0;
-    const double ax = x < 0 ? -x : x;
-    double hi = x, lo = 0.0;
-    int k = 0;
-    if (ax > 0.34657359027997264) {                                             // 0.5 ln 2
-        const double t = rint_small(x * INVLN2);
-        k = (int)t;
-        hi = x - t * LN2HI;                                                     // exact product (32-bit constant)
-        lo = t * LN2LO;
-        x = hi - lo;
-    } else if (ax < 3.725290298461914e-09) {                                    // 2^-28
-        return 1.0 + x;
-    }
-    const double t = x * x;
-    const double c = x - t * fma_(t, fma_(t, fma_(t, fma_(t, P5, P4), P3), P2), P1);
-    if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
-    const double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
-    // y * 2^k in two exact-then-rounded steps (k in [-1075, 1024]): no overflow in the first, one rounding in the second
+    const double MAGIC = 6755399441055744.0;
+    // the argument is clamped for the arithmetic (results outside the clamp are replaced below): k stays in [-1080, 1030]
+    const double xc = x > 712.0 ? 712.0 : (x < -748.0 ? -748.0 : x);
+    const double tm = xc * INVLN2 + MAGIC;
+    const double t = tm - MAGIC;
+    const int k = (int)(unsigned)to_bits(tm);
+    const double hi = xc - t * LN2HI;                                           // exact product (32-bit constant)
+    const double lo = t * LN2LO;
+    const double r = hi - lo;
+    const double z = r * r;
+    const double c = r - z * fma_(z, fma_(z, fma_(z, fma_(z, P5, P4), P3), P2), P1);
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
     const int k1 = k >> 1, k2 = k - k1;
-    const double s1 = from_bits((unsigned long long)(k1 + 1023) << 52), s2 = from_bits((unsigned long long)(k2 + 1023) << 52);
-    return (y * s1) * s2;
+    const double s1 = from_bits((unsigned long long)(unsigned)(k1 + 1023) << 52), s2 = from_bits((unsigned long long)(unsigned)(k2 + 1023) << 52);
+    double e = (y * s1) * s2;
+    e = x > 709.782712893384 ? from_bits(0x7FF0000000000000ull) : e;
+    e = x < -745.1332191019412 ? 0.0 : e;
+    return x != x ? x + x : e;
 }
 
 }  // namespace detmath

@@ -341,7 +341,11 @@ struct RegKkt {
 // tr: LDS staging of RegKkt<NN+MM>::TRI doubles.
 // STACKED: H and A are the upper / lower block of ONE (n+m) x n column-major array (leading dimension n+m, A = H + n):
 // every lane then reads row `lane` of that array with a compile-time stride, i.e. one base address + immediate offsets.
-template <int NN, int MM, bool STACKED = false>
+// SYMLOWER: the Hessian block of K is taken from the LOWER triangle of H only — K(i, j) = H(max(i,j), min(i,j)) — as Eigen::LDLT reads it
+// (helpers.hpp:38-43 selects the lower triangle). It matters only for a Hessian that is not bitwise symmetric: the block BFGS forms
+// (-c v_i) v_j per entry (continuous_ocp.hpp:2304-2431), which differs from its mirror image in the last bit; the dense BFGS and the
+// exact Hessian are bitwise symmetric, and their kernels skip the per-load select.
+template <int NN, int MM, bool STACKED = false, bool SYMLOWER = false>
 __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, const double* h, const double* __restrict__ A,
                                                   const double* Alb, const double* Aub, const double* xlb, const double* xub,
                                                   const double* x0, const double* y0, const pmpc_qp_settings& s, pmpc_qp_info& info,
@@ -381,6 +385,18 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
     auto Krow = [&](int j, int zo) -> double {   // (H or A)(row of this lane, j), j < NN
         if constexpr (STACKED) { const unsigned l = lane_near(zo); unsigned b = (l < (unsigned)N ? l : 0u) + (unsigned)zo; asm("" : "+v"(b)); return H[b + (unsigned)(j * N)]; }
         else return rowp[(size_t)j * (size_t)(unsigned)(rstride + zo)];
+    };
+    auto KrowLower = [&](int j, int zo) -> double {   // H(max(lane, j), min(lane, j)) on primal lanes, A(row, j) on constraint lanes; j < NN
+        if constexpr (STACKED) {
+            const unsigned l = lane_near(zo);
+            const unsigned lc = (l < (unsigned)N ? l : 0u);
+            unsigned b = ((lc < (unsigned)j) ? ((unsigned)j + lc * (unsigned)N) : (lc + (unsigned)(j * N))) + (unsigned)zo;
+            asm("" : "+v"(b));
+            return H[b];
+        } else {
+            const bool up = isP && ln < j;
+            return up ? H[(size_t)ln * NN + j] : rowp[(size_t)j * (size_t)(unsigned)(rstride + zo)];
+        }
     };
     auto Acol = [&](int k, int zo) -> double {   // A(k, lane), k < MM (primal lanes)
         if constexpr (STACKED) { const unsigned l = lane_near(zo); unsigned b = (l < (unsigned)NN ? l : 0u) * N + NN + (unsigned)zo; asm("" : "+v"(b)); return H[b + (unsigned)k]; }
@@ -425,7 +441,7 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
         {   // construct_kkt_matrix + factorise_kkt_matrix
             const long long f0 = dbg ? clock64() : 0;
             K.invert(ln, tr, kdiag, [&](int j, int z) -> double {   // row `lane` of [H  A^T ; A  .] (construct_kkt_matrix, box_admm.hpp:209-223)
-                if (j < NN) return Krow(j < NN ? j : 0, z);
+                if (j < NN) { if constexpr (SYMLOWER) return KrowLower(j < NN ? j : 0, z); else return Krow(j < NN ? j : 0, z); }
                 // block-lower tile storage: column j is staged for the lanes of tile rows >= j/16 only, and the A' block is
                 // non-zero on primal lanes only — past the last primal tile row it is never consumed, so it is not loaded
                 if (16 * (j / 16) >= NN) return 0.0;

@@ -13,6 +13,7 @@
 #include "pmpc_ocp.hpp"
 #include "pmpc_qp.hpp"
 #include "pmpc_qp_reg.hpp"
+#include "pmpc_qp_reg2.hpp"
 #include "pmpc_ruiz.hpp"
 #include "pmpc_admm.hpp"
 
@@ -36,7 +37,9 @@ constexpr double DBL_EPS = 2.220446049250313e-16;
 constexpr int RUIZ_MAX_NDER = 64;   // see SqpDevice::qp_and_step
 constexpr int PMPC_SQP_IN_PROGRESS = 3;   // internal: the instance continues in the next iteration-slice launch
 
-// NN, MM > 0: compile-time QP size with NN+MM <= 64 -> register-resident QP (pmpc_qp_reg.hpp); 0 -> LDS-resident QP
+// NN, MM > 0: compile-time QP size -> register-resident QP: NN+MM <= 64 one KKT row per lane (pmpc_qp_reg.hpp, REG1), 65..112 two rows per
+// lane (pmpc_qp_reg2.hpp, REG2: the QP alone is specialised, the other phases run the size-generic code with compile-time trip counts);
+// 0 -> LDS-resident QP
 // PROF: accumulate per-phase shader-clock cycles (separate kernel instantiation; costs 16+ VGPRs, off by default)
 // HU: Hessian-update policy compiled into a register-resident specialisation (0 dense damped BFGS, 1 block BFGS); the LDS-resident
 // kernels (NN == 0) select it at run time from settings.hessian_update
@@ -46,6 +49,8 @@ struct SqpDevice {
     // Ruiz scaling is compiled into the LDS / HBM-resident QP kernels only: the launcher routes preconditioner = 1 there. In the
     // register-resident kernels its three (cold, out-of-line) calls cost private-memory frames and call-ABI spills on the hot path.
     static constexpr bool RUIZ_COMPILED = (NN == 0) && (int)Dm::NDER <= RUIZ_MAX_NDER;
+    static constexpr bool REG1 = NN > 0 && NN + MM <= WAVE;    // one KKT row per lane
+    static constexpr bool REG2 = NN > 0 && NN + MM > WAVE;     // two KKT rows per lane
     Ocp<Model>& ocp;
     SqpLds& v;
     QpLds& qw;
@@ -373,7 +378,7 @@ struct SqpDevice {
 
     // lag_grad = J^T lam[0:m] + cost_grad + lam_box  (continuous_ocp.hpp:2112-2114)
     __device__ __forceinline__ void lagrangian_gradient(double* out) {
-        if constexpr (NN > 0) {   // compile-time sizes: one batch of independent loads (column j of J), then the chain
+        if constexpr (REG1) {   // compile-time sizes: one batch of independent loads (column j of J), then the chain
             const int j = lane_id() < NN ? lane_id() : 0;
             const unsigned jo = (unsigned)j * (NN + MM) + opaque_zero();
             double col[MM];
@@ -432,13 +437,18 @@ struct SqpDevice {
             acc(11, l2 - l1); acc(12, l3 - l2); acc(13, l4 - l3); acc(14, now() - l4);
             if (ss.regularisation == 2) regularise_gershgorin();
         } else {
-            ocp.template assemble_first_order<false>(v.al, Aw, v.h, ldw, false);   // J's zeros and D entries are already in place
+            // J's zeros and D entries are already in place — unless the Ruiz preconditioner scaled and unscaled the workspace around the
+            // last QP (sqp_base.hpp:605-609): the round trip leaves rounding noise on every entry, and the reference rebuilds J from
+            // scratch at each linearisation
+            bool rebuild = false;
+            if constexpr (RUIZ_COMPILED) rebuild = __builtin_amdgcn_readfirstlane(ss.preconditioner) == 1;
+            ocp.template assemble_first_order<false>(v.al, Aw, v.h, ldw, rebuild);
             const long long l3 = now();
             lagrangian_gradient(v.lgn);
             acc(12, l3 - l1); acc(14, now() - l3);
             const long long b0 = now();
-            if constexpr (NN > 0 && HU == 1) bfgs_update_block();
-            else if constexpr (NN > 0) { double brow[NN > 0 ? NN : 1]; bfgs_load_row(brow); bfgs_update_reg(brow); }
+            if constexpr (REG1 && HU == 1) bfgs_update_block();
+            else if constexpr (REG1) { double brow[NN > 0 ? NN : 1]; bfgs_load_row(brow); bfgs_update_reg(brow); }
             else { if (__builtin_amdgcn_readfirstlane(ss.hessian_update) == 1) bfgs_update_block(); else bfgs_update(); }   // (the launcher routes hessian_update = 1 to these kernels)
             acc(5, now() - b0);
             for (int i = lane_id(); i < n; i += WAVE) v.lg[i] = v.lgn[i];
@@ -632,7 +642,10 @@ struct SqpDevice {
             if (ruiz) rz_c = ruiz_compute_wave(n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, rz);
         }
         // 7-argument form: zero guesses (Q2)
-        if constexpr (NN > 0) { boxadmm_solve_reg<NN, MM, true>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr); wsync(); }
+        if constexpr (REG2) {   // (lower-triangle read of H always: the Hessian update is a run-time choice in these kernels)
+            boxadmm_solve_reg2<NN, MM, true, true>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr);
+            wsync();
+        } else if constexpr (REG1) { boxadmm_solve_reg<NN, MM, true, HU == 1>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr); wsync(); }
         else {
             // Solver<Problem, ADMM<...>>: the launcher sized the QP's LDS for the stacked (2n+m)-row system when qp_solver = 1
             if (RUIZ_COMPILED && __builtin_amdgcn_readfirstlane(ss.qp_solver) == 1) admm_solve(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi);

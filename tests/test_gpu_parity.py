@@ -31,14 +31,24 @@ def _lds_order(oracle, rows):
     return oracle.PIVOT_STATIC
 
 
+REG2_QP_SHAPES = ((66, 44), (55, 33))   # QP entry point: two-rows-per-lane register specialisations (pmpc_qp_reg2.hip)
+
+
 def _gpu_order(oracle, n, m, nodes=None):
     """Which of the oracle's GPU-order linear-solve restatements mirrors the kernel that serves this size: the register-resident QP
     (compile-time sizes with n+m <= 64: the (35, 21) QP entry point, SQP grids of 7 or 5 nodes) applies the inverse swept in blocks of
-    four pivots (PIVOT_SWEEP); every other size runs an LDS/HBM-resident kernel (_lds_order: PIVOT_STATIC). All of them are tied to the reference's
-    pivoted Eigen LDLT (PIVOT_EIGEN) in tests/test_oracle_pins.py."""
+    four pivots (PIVOT_SWEEP); the two-rows-per-lane register path (65..112 rows: the (66, 44) and (55, 33) QP entry points) the same sweep with
+    its own mat-vec order (PIVOT_SWEEP2); every other size runs an LDS/HBM-resident kernel (_lds_order: PIVOT_STATIC). All of them are tied to the
+    reference's pivoted Eigen LDLT (PIVOT_EIGEN) in tests/test_oracle_pins.py."""
     if nodes is None:
+        if (n, m) in REG2_QP_SHAPES:
+            return oracle.PIVOT_SWEEP2
         return oracle.PIVOT_SWEEP if (n, m) == (35, 21) else _lds_order(oracle, n + m)
-    return oracle.PIVOT_SWEEP if (n + m <= 64 and nodes in (5, 7)) else _lds_order(oracle, n + m)
+    if n + m <= 64 and nodes in (5, 7):
+        return oracle.PIVOT_SWEEP
+    if 64 < n + m <= 112 and nodes == 11:      # SQP grids of 11 nodes (P = 5, S = 2): two-rows-per-lane register path
+        return oracle.PIVOT_SWEEP2
+    return _lds_order(oracle, n + m)
 
 
 def _qp_oracle(oracle, q, s, x0=None, y0=None):
@@ -48,6 +58,30 @@ def _qp_oracle(oracle, q, s, x0=None, y0=None):
     n, m = q["h"].shape[1], q["Alb"].shape[1]
     return oracle.qp_solve_batch(q["H"], q["h"], q["A"], q["Alb"], q["Aub"], q["xlb"], q["xub"], settings=os_,
                                  pivot=_gpu_order(oracle, n, m), x0=x0, y0=y0)
+
+
+
+def _assert_same_solve(info, io, x, xo, lam=None, lo=None, bit=True, tol=1e-8):
+    """GPU vs CPU restatement on EVERY instance (no mask): identical SQP iteration counts, statuses and total ADMM iterations; with
+    bit=True (the kernels and the restatement evaluate the models with the same IEEE-only sin / cos / exp — pmpc_math.hpp — and the same
+    order of linear algebra) the primal / dual solutions and the reported KKT quantities must be BIT-IDENTICAL; bit=False: within `tol`
+    (1e-8 = north_star's fp64 tolerance) for the two policies whose device code is not yet operation-for-operation the restatement."""
+    assert np.array_equal(info["iter"], np.array([i.iter for i in io])), "SQP iteration counts differ"
+    assert np.array_equal(info["status"], np.array([i.status for i in io])), "statuses differ"
+    assert np.array_equal(info["qp_solver_iter"], np.array([i.qp_solver_iter for i in io])), "total ADMM iterations differ"
+    q = {f: np.array([getattr(i, f) for i in io]) for f in ("primal_norm", "dual_norm", "max_violation", "cost")}
+    if bit:
+        assert np.array_equal(x, xo), f"x not bit-identical: max |dx| = {np.abs(x - xo).max():.3e}"
+        if lam is not None:
+            assert np.array_equal(lam, lo), f"lam not bit-identical: max |dlam| = {np.abs(lam - lo).max():.3e}"
+        for f, v in q.items():
+            assert np.array_equal(info[f], v), f
+    else:
+        assert np.abs(x - xo).max() <= tol * max(1.0, np.abs(xo).max())
+        if lam is not None:
+            assert np.abs(lam - lo).max() <= tol * max(1.0, np.abs(lo).max())
+        for f, v in q.items():
+            assert np.abs(info[f] - v).max() <= tol * max(1.0, np.abs(v).max()), f
 
 
 # -------------------------------------------------------------------------------------------- A16-A18: box-ADMM QP
@@ -272,10 +306,7 @@ def test_sqp_with_ruiz_preconditioner_vs_oracle(ctx, oracle):
     from polympc_amd import workloads
     for P, S, B in ((6, 1, 48), (5, 2, 8)):
         (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, workloads.robot_batch(B, P=P, S=S), B, preconditioner=1)
-        same = (info["iter"] == np.array([i.iter for i in io])) & (info["status"] == np.array([i.status for i in io]))
-        assert same.mean() >= 0.95, (P, S, same.mean())
-        assert np.abs(x - xo)[same].max() <= 1e-8
-        assert np.abs(info["max_violation"] - [i.max_violation for i in io])[same].max() <= 1e-8
+        _assert_same_solve(info, io, x, xo, lam, lo, bit=False)   # identical trajectories on every instance; values within 1e-8 (measured 1e-10)
 
 
 # -------------------------------------------------------------------------------------------- §8f-1: batched MPC step
@@ -283,9 +314,8 @@ def test_mpc_receding_horizon_device_resident(ctx, oracle):
     """Closed loop of 16 robots for 5 steps: pmpc_mpc_step_batch_dev (x0 pinned on the device, warm start from the previous
     solution held in HBM, first control extracted on the device, Euler plant in torch on the same stream — no host
     synchronisation inside the loop). Every step is re-solved by the CPU restatement from the SAME inputs (state, warm-start
-    primal / dual; mpc_wrapper.hpp:89-93 / :298 / sqp_base.hpp:368-374): identical SQP iteration counts on >= 80 % of the
-    instances at every step (a warm-started solve sits next to the termination threshold, where last-bit differences of
-    sin / cos decide one iteration more or less), x within 1e-6 on those; the cold step matches on all. Warm-started steps
+    primal / dual; mpc_wrapper.hpp:89-93 / :298 / sqp_base.hpp:368-374): identical SQP iteration counts and BIT-IDENTICAL solutions on
+    every instance at every step (cold and warm-started). Warm-started steps
     need fewer iterations than the cold one (mpc_wrapper_test.cpp:159) and the loop drives the robots towards the origin."""
     import torch
     import polympc_amd as pa
@@ -329,9 +359,8 @@ def test_mpc_receding_horizon_device_resident(ctx, oracle):
         lbx[:, 3 * nn - 3:3 * nn] = st_k; ubx[:, 3 * nn - 3:3 * nn] = st_k
         xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 6, 1, 0.0, 2.0, B, wl["d"], lbx, ubx, x_guess=xg, lam_guess=lg,
                                             sqp_settings=oss, pivot=oracle.PIVOT_SWEEP)
-        same = it_gpu == np.array([i.iter for i in io])
-        assert same.mean() >= (1.0 if k == 0 else 0.8), (k, it_gpu, [i.iter for i in io])
-        assert np.abs(xk - xo)[same].max() <= 1e-6
+        assert np.array_equal(it_gpu, np.array([i.iter for i in io])), (k, it_gpu, [i.iter for i in io])
+        assert np.array_equal(xk, xo), (k, np.abs(xk - xo).max())
         assert np.array_equal(u0k, xk[:, 3 * nn + 2 * (nn - 1):3 * nn + 2 * nn])      # u(t_start) = last node of the u block
         assert np.abs(xk[:, 3 * nn - 3:3 * nn] - st_k).max() <= 1e-3                  # the pinned initial state is honoured (eps_prim)
         mean_iters.append(it_gpu.mean())
@@ -362,29 +391,19 @@ def _sqp_both(ctx, oracle, wl, B, **kw):
 
 
 def test_sqp_config_A_vs_oracle(ctx, oracle):
-    """256 config-A instances: identical SQP iteration counts, statuses and total ADMM iterations; x within 1e-8 and
-    the reported KKT quantities (primal/dual step norms, constraint violation) within 1e-8 of the oracle."""
+    """1024 config-A instances: identical SQP iteration counts, statuses and total ADMM iterations on EVERY instance, and bit-identical
+    x, lam and reported KKT quantities (primal / dual step norms, constraint violation, cost)."""
     from polympc_amd import workloads
-    B = 256
+    B = 1024
     (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, workloads.robot_batch(B), B)
-    it = np.array([i.iter for i in io]); st = np.array([i.status for i in io]); qi = np.array([i.qp_solver_iter for i in io])
-    same = (info["iter"] == it) & (info["status"] == st) & (info["qp_solver_iter"] == qi)
-    assert same.mean() >= 0.99, f"trajectory mismatch on {np.sum(~same)} of {B} instances"
-    dx = np.abs(x - xo).max(axis=1)
-    assert dx[same].max() <= 1e-8
-    assert np.abs(lam - lo)[same].max() <= 1e-6
-    assert np.abs(info["max_violation"] - [i.max_violation for i in io])[same].max() <= 1e-8
-    assert np.abs(info["primal_norm"] - [i.primal_norm for i in io])[same].max() <= 1e-8
-    assert np.abs(info["dual_norm"] - [i.dual_norm for i in io])[same].max() <= 1e-6
-    assert np.abs(info["cost"] - [i.cost for i in io])[same].max() <= 1e-8
+    _assert_same_solve(info, io, x, xo, lam, lo)
 
 
 def test_sqp_config_D_perturbed_params(ctx, oracle):
     from polympc_amd import workloads
     B = 64
     (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, workloads.robot_batch(B, perturb_d=True, first=5000), B)
-    same = info["iter"] == np.array([i.iter for i in io])
-    assert same.mean() >= 0.98 and np.abs(x - xo)[same].max() <= 1e-8
+    _assert_same_solve(info, io, x, xo, lam, lo)
 
 
 def test_sqp_reference_robot_fixture_sizes(ctx, oracle):
@@ -393,9 +412,7 @@ def test_sqp_reference_robot_fixture_sizes(ctx, oracle):
     for P, S in ((5, 2), (5, 3)):
         B = 8
         (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, workloads.robot_batch(B, P=P, S=S), B)
-        assert list(info["iter"]) == [i.iter for i in io]
-        assert list(info["status"]) == [i.status for i in io]
-        assert np.abs(x - xo).max() <= 1e-8
+        _assert_same_solve(info, io, x, xo, lam, lo)
 
 
 def test_sqp_five_node_register_path(ctx, oracle):
@@ -405,9 +422,7 @@ def test_sqp_five_node_register_path(ctx, oracle):
     for P, S in ((4, 1), (2, 2)):
         B = 32
         (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, workloads.robot_batch(B, P=P, S=S), B)
-        assert list(info["iter"]) == [i.iter for i in io]
-        assert list(info["qp_solver_iter"]) == [i.qp_solver_iter for i in io]
-        assert np.abs(x - xo).max() <= 1e-8
+        _assert_same_solve(info, io, x, xo, lam, lo)
 
 
 def test_sqp_codegen_robot_exact_hessian(ctx, oracle):
@@ -430,7 +445,7 @@ def test_sqp_codegen_robot_exact_hessian(ctx, oracle):
 def test_sqp_minimal_time_valet_parking(ctx, oracle):
     """minimal_time_test.cpp:146-188 through the GPU path (NP = 1 border blocks, exact Hessian every iteration, Gershgorin shift,
     parameter / final-state bounds, primal guess): SOLVED in < 20 iterations like the reference asserts, same iteration count
-    as the CPU restatement, x within 1e-7."""
+    as the CPU restatement, bit-identical solution."""
     import polympc_amd as pa
     from test_oracle_pins import _minimal_time_parking
     lbx, ubx, xg = _minimal_time_parking()
@@ -439,7 +454,7 @@ def test_sqp_minimal_time_valet_parking(ctx, oracle):
     oss = oracle.sqp_default_settings(); oss.max_iter = 20; oss.line_search_max_iter = 10; oss.regularisation = 2; oss.exact_hessian_every_iter = 1
     xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_PARKING, 5, 2, 0.0, 1.0, 1, [[1.0]], lbx, ubx, x_guess=xg, sqp_settings=oss, pivot=oracle.PIVOT_STATIC)
     assert info["status"][0] == pa.SQP_SOLVED and info["iter"][0] < 20
-    assert info["iter"][0] == io[0].iter and np.abs(x - xo).max() <= 1e-7
+    _assert_same_solve(info, io, x, xo, lam, lo)
 
 
 @pytest.mark.parametrize("P,S,ubg,qp_max", [(5, 2, 10.0, 100), (5, 2, 10.0, 300), (5, 2, 1.2, 100), (6, 1, 10.0, 300), (6, 1, 1.2, 100)])
@@ -447,7 +462,7 @@ def test_sqp_parking_nonlinear_path_constraint(ctx, oracle, P, S, ubg, qp_max):
     """nonlinear_constraints_test.cpp:159-184 through the GPU path (NP = 1 and NG = 1 together, exact linearisation every iteration
     + Gershgorin): the reference's grid (P=5, S=2: 100 KKT rows, LDS path, static-order CPU restatement) with the reference's bound
     (inactive) and a binding one, and a 7-node grid whose KKT system has exactly 64 rows — the largest the register-resident path
-    takes (CPU restatement in the kernel's sweep order). Same outcome, same SQP and QP iteration counts, minimal time within 1e-8, x within 1e-5
+    takes (CPU restatement in the kernel's sweep order). Same outcome, same SQP and QP iteration counts, bit-identical x and lam
     (the steering-angle profile of this minimal-time problem is nearly flat in the cost and most QPs stop at their iteration cap, so
     last-bit sin/cos differences are carried un-damped through up to 20 iterations; observed up to 1.8e-6)."""
     import polympc_amd as pa
@@ -465,9 +480,7 @@ def test_sqp_parking_nonlinear_path_constraint(ctx, oracle, P, S, ubg, qp_max):
     pivot = oracle.PIVOT_SWEEP if nn == 7 else _lds_order(oracle, 100)
     xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_PARKING_NG, P, S, 0.0, 1.0, 1, [[1.0]], lbx, ubx, lbg=lbg, ubg=ubgv, x_guess=xg,
                                         sqp_settings=oss, qp_settings=oqs, pivot=pivot)
-    assert info["status"][0] == io[0].status and info["iter"][0] == io[0].iter and info["qp_solver_iter"][0] == io[0].qp_solver_iter
-    assert abs(x[0, 5 * nn] - xo[0, 5 * nn]) <= 1e-8 and np.abs(x - xo).max() <= 1e-5
-    assert np.abs(lam - lo).max() <= 1e-4 * max(1.0, np.abs(lo).max())
+    _assert_same_solve(info, io, x, xo, lam, lo)
     if not (ubg == 10.0 and qp_max == 100):
         assert info["status"][0] == pa.SQP_SOLVED
     u = x[0, 3 * nn:5 * nn].reshape(nn, 2)
@@ -492,7 +505,7 @@ def test_sqp_valet_parking_with_ruiz(ctx, oracle):
         xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 2.0, 1, [[2.0]], lbx, ubx, x_guess=xo, lam_guess=lo, sqp_settings=oss,
                                             qp_settings=oqs, pivot=oracle.PIVOT_STATIC, mparams=[1.0])
         assert info["status"][0] == pa.SQP_SOLVED and info["iter"][0] < 10
-        assert info["iter"][0] == io[0].iter and np.abs(xg - xo).max() <= 1e-7
+        _assert_same_solve(info, io, xg, xo, lg, lo, bit=False)   # (Ruiz-preconditioned: identical trajectory, values within 1e-8)
 
 
 def test_sqp_valet_parking_as_the_reference_runs_it(ctx, oracle):
@@ -518,8 +531,7 @@ def test_sqp_valet_parking_as_the_reference_runs_it(ctx, oracle):
             xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 2.0, 1, [[2.0]], lbx, ubx, x_guess=xo, lam_guess=lo, sqp_settings=oss,
                                                 qp_settings=oqs, pivot=oracle.PIVOT_STATIC, mparams=[1.0])
             assert info["status"][0] == pa.SQP_SOLVED and info["iter"][0] < 10
-            assert info["iter"][0] == io[0].iter and info["qp_solver_iter"][0] == io[0].qp_solver_iter
-            assert np.abs(xg - xo).max() <= 1e-7
+            _assert_same_solve(info, io, xg, xo, lg, lo, bit=False)   # (Ruiz + block BFGS: identical trajectory, values within 1e-8)
             filt = ctx.filter_state_download(1, handle)
             assert filt[0, 0] == ofilt[0, 0] >= 1 and np.abs(filt - ofilt).max() <= 1e-9
         ctx.filter_state_clear(1, handle)
@@ -530,7 +542,7 @@ def test_sqp_valet_parking_as_the_reference_runs_it(ctx, oracle):
 
 def test_sqp_filter_line_search_batch_vs_oracle(ctx, oracle):
     """line_search = 1 on batches of randomised robot OCPs (P=5 S=3 and config A's grid, both on the LDS-resident path), with and
-    without a carried filter: identical iteration counts and filter lengths, x and filter entries within 1e-7 of the CPU restatement; a second solve from the
+    without a carried filter: identical iteration counts, bit-identical x, lam and filter contents; a second solve from the
     first one's solution with the carried filter must again agree (the filter then holds the first solve's history)."""
     import polympc_amd as pa
     from polympc_amd import workloads
@@ -547,11 +559,9 @@ def test_sqp_filter_line_search_batch_vs_oracle(ctx, oracle):
                 xg, lg, info = ctx.sqp_solve_batch(pa.MODEL_ROBOT, P, S, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], x_guess=xg, lam_guess=lg, sqp_settings=ss)
                 xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, P, S, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], x_guess=xo, lam_guess=lo,
                                                     sqp_settings=oss, pivot=oracle.PIVOT_STATIC)
-                same = info["iter"] == np.array([i.iter for i in io])
-                assert same.mean() >= 0.95, (P, S, rep, same.mean())
-                assert np.abs(xg - xo)[same].max() <= 1e-7
+                _assert_same_solve(info, io, xg, xo, lg, lo)
                 filt = ctx.filter_state_download(B, handle)
-                assert np.array_equal(filt[same, 0], ofilt[same, 0]) and np.abs(filt - ofilt)[same].max() <= 1e-7
+                assert np.array_equal(filt, ofilt)
                 xo, lo = xg.copy(), lg.copy()   # continue both sides from the same point
                 ofilt[:] = filt
         finally:
@@ -562,7 +572,7 @@ def test_sqp_filter_line_search_batch_vs_oracle(ctx, oracle):
     oss = oracle.sqp_default_settings(); oss.max_iter = 10; oss.line_search_max_iter = 10; oss.line_search = 1
     x, lam, info = ctx.sqp_solve_batch(pa.MODEL_ROBOT, 5, 2, 0.0, 2.0, 8, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
     xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 2.0, 8, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, pivot=oracle.PIVOT_STATIC)
-    assert list(info["iter"]) == [i.iter for i in io] and np.abs(x - xo).max() <= 1e-7
+    _assert_same_solve(info, io, x, xo, lam, lo)
 
 
 def test_filter_settings_are_validated(ctx):
@@ -583,8 +593,7 @@ def test_sqp_block_bfgs_vs_oracle(ctx, oracle):
     import polympc_amd as pa
     for P, S, B in ((5, 3, 6), (6, 1, 256), (4, 1, 64)):   # LDS path; register-resident specialisations for 7 and 5 nodes (sweep order)
         (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, workloads.robot_batch(B, P=P, S=S), B, hessian_update=1)
-        same = (info["iter"] == np.array([i.iter for i in io])) & (info["qp_solver_iter"] == np.array([i.qp_solver_iter for i in io]))
-        assert same.mean() >= 0.98 and np.abs(x - xo)[same].max() <= 1e-8
+        _assert_same_solve(info, io, x, xo, lam, lo, bit=False)   # identical trajectories on every instance; values within 1e-8 (measured 5e-11)
     from test_oracle_pins import _minimal_time_parking
     lbx, ubx, xg = _minimal_time_parking()
     # three iterations only: quasi-Newton updates are not what this minimal-time problem is solved with (the reference switches it
@@ -603,20 +612,15 @@ def test_sqp_admm_qp_solver_vs_oracle(ctx, oracle):
     from polympc_amd import workloads
     for P, S, B in ((6, 1, 24), (5, 2, 6)):
         (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, workloads.robot_batch(B, P=P, S=S), B, qp_solver=1)
-        same = (info["iter"] == np.array([i.iter for i in io])) & (info["qp_solver_iter"] == np.array([i.qp_solver_iter for i in io]))
-        assert same.mean() >= 0.95, (P, S, same.mean())
-        assert np.abs(x - xo)[same].max() <= 1e-8
+        _assert_same_solve(info, io, x, xo, lam, lo)
 
 
 def test_sqp_cstr_config_B(ctx, oracle):
-    """Config B (CSTR, 110 KKT rows, exp-heavy dynamics, badly scaled): trajectory parity on a small batch."""
+    """Config B (CSTR, 110 KKT rows, exp-heavy dynamics, badly scaled): identical trajectories and bit-identical solutions on every instance."""
     from polympc_amd import workloads
-    B = 16
+    B = 128
     (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, workloads.cstr_batch(B), B)
-    same = (info["iter"] == np.array([i.iter for i in io])) & (info["status"] == np.array([i.status for i in io]))
-    assert same.mean() >= 0.9
-    scale = np.maximum(1.0, np.abs(xo))
-    assert (np.abs(x - xo) / scale)[same].max() <= 1e-7
+    _assert_same_solve(info, io, x, xo, lam, lo)
 
 
 def test_sqp_kite_standin_config_C(ctx, oracle):
@@ -658,9 +662,9 @@ def test_sqp_warm_start_and_gershgorin(ctx, oracle):
     oss = oracle.sqp_default_settings(); oss.max_iter = 10; oss.line_search_max_iter = 10; oss.regularisation = 2
     xo1, lo1, io1 = oracle.sqp_solve_batch(0, 5, 3, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, pivot=1, mparams=mp)
     xo2, lo2, io2 = oracle.sqp_solve_batch(0, 5, 3, 0.0, 2.0, B, wl["d"], lbx2, ubx2, x_guess=xo1, lam_guess=lo1, sqp_settings=oss, pivot=1, mparams=mp)
-    assert list(i1["iter"]) == [i.iter for i in io1] and np.abs(x1 - xo1).max() <= 1e-8
-    assert list(i2["iter"]) == [i.iter for i in io2] and np.abs(x2 - xo2).max() <= 1e-7
-    assert list(i2["status"]) == [i.status for i in io2] and np.mean(i2["status"] == pa.SQP_SOLVED) >= 0.75
+    _assert_same_solve(i1, io1, x1, xo1, l1, lo1)
+    _assert_same_solve(i2, io2, x2, xo2, l2, lo2)
+    assert np.mean(i2["status"] == pa.SQP_SOLVED) >= 0.75
 
 
 def test_sqp_full_size_properties(ctx):

@@ -20,7 +20,11 @@ from oracle import binding as ob             # noqa: E402
 def order_for(n, m, nodes, kw):
     if kw.get("qp_solver", 0) or kw.get("preconditioner", 0) or kw.get("line_search", 0):
         return ob.PIVOT_STATIC
-    return ob.PIVOT_SWEEP if (n + m <= 64 and nodes in (5, 7)) else ob.PIVOT_STATIC
+    if n + m <= 64 and nodes in (5, 7):
+        return ob.PIVOT_SWEEP
+    if 64 < n + m <= 112 and nodes == 11:
+        return ob.PIVOT_SWEEP2
+    return ob.PIVOT_STATIC
 
 
 def probe(ctx, name, wl, B, **kw):
@@ -48,6 +52,14 @@ def probe(ctx, name, wl, B, **kw):
 def main():
     big = "--big" in sys.argv
     ctx = pa.Context(0)
+    if "--hunt" in sys.argv:   # localise the first SQP iteration at which a policy stops being bit-identical
+        for mi in (1, 2, 3):
+            for name, kw in (("block BFGS", dict(hessian_update=1)), ("ruiz", dict(preconditioner=1))):
+                for P, S in ((6, 1), (5, 2)):
+                    wl = workloads.robot_batch(64, P=P, S=S); wl["max_iter"] = mi
+                    probe(ctx, f"{name} P{P}S{S} max_iter={mi}", wl, 64, **kw)
+        ctx.close()
+        return
     probe(ctx, "A robot P6S1", workloads.robot_batch(4096 if big else 512), 4096 if big else 512)
     probe(ctx, "A block BFGS", workloads.robot_batch(512), 512, hessian_update=1)
     probe(ctx, "D robot perturbed d", workloads.robot_batch(1024, perturb_d=True, first=5000), 1024)

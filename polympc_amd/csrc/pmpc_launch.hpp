@@ -207,11 +207,13 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
         const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, 3);
         if (ldsr > lds_limit) return false;
         auto kern = sqp_kernel<Model, NN_, MM_, false>;
+        bool timed = false;
+        if constexpr (LDS_PATH_PROFILED<Model>::value) { if (phase) { kern = sqp_kernel<Model, NN_, MM_, true>; timed = true; } }   // developer builds with phase timers
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
         const int slice = (slice_state && slice_iters > 0) ? slice_iters : ss->max_iter;
         for (int it = 0; it < ss->max_iter; it += slice)
             hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), ldsr, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
-                               *ss, *qs, Hws, Aws, x, lam, info, (unsigned long long*)nullptr, (double*)nullptr, it, it + slice, slice_state, (unsigned)(ldsr / sizeof(double)));
+                               *ss, *qs, Hws, Aws, x, lam, info, timed ? phase : (unsigned long long*)nullptr, (double*)nullptr, it, it + slice, slice_state, (unsigned)(ldsr / sizeof(double)));
         *st = (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
         return true;
     } else {

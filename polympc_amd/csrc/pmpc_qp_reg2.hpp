@@ -232,6 +232,32 @@ struct RegKkt2 {
         return __hiloint2double(th, tl);
     }
 
+    // The VGPR-resident tiles leave the register file while the residuals are evaluated (every check_termination-th iteration): that code
+    // wants dozens of loads in flight, and with 136 registers pinned by the operand the allocator spilled the LOADED values instead — a
+    // scratch round trip between any two loads, i.e. one exposed L2 latency per matrix entry (0.37 ms per check on 4096 QPs; the ADMM
+    // iteration itself takes 0.012 ms). `mem` is a private (scratch) array, indexed through an opaque zero so that it stays memory.
+    static constexpr int NPARK = NV * 4;
+    __device__ __forceinline__ void park(double* mem, int oz) {
+#pragma unroll
+        for (int R = 0; R < NT; ++R)
+#pragma unroll
+            for (int C = 0; C < NT; ++C)
+                if (!in_agpr(R, C)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mem[(R * NT + C) * 4 + r + oz] = T[R][C][r];
+                }
+    }
+    __device__ __forceinline__ void unpark(const double* mem, int oz) {
+#pragma unroll
+        for (int R = 0; R < NT; ++R)
+#pragma unroll
+            for (int C = 0; C < NT; ++C)
+                if (!in_agpr(R, C)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T[R][C][r] = mem[(R * NT + C) * 4 + r + oz];
+                }
+    }
+
     // K^{-1} c for the two entries of every lane: c0 = entry `lane`, c1 = entry `lane + 64` (exact zero where that is >= N).
     __device__ __forceinline__ void apply(double c0, double c1, double* st, int ln, double& x0, double& x1) const {
         const int lr = ln >> 4, lc = ln & 15;
@@ -417,12 +443,14 @@ __device__ __forceinline__ void boxadmm_solve_reg2(const double* __restrict__ H,
             if (s.adaptive_rho) { until_adapt -= nrun; if (until_adapt == 0) { adapt = true; until_adapt = s.adaptive_rho_interval; } }
             if (check || adapt) {  // residuals_update, box_admm.hpp:398-415: one add chain per row, columns ascending
                 const long long r0 = dbg ? clock64() : 0;
-                constexpr int RC = 8;
+                constexpr int RC = 24;
                 int zr = 0;
                 asm volatile("" : "+v"(zr));
+                double parked[RegKkt2<N>::NPARK];
+                K.park(parked, zr);
+                sched_fence();
                 double acc[2] = {0.0, 0.0}, aty[2] = {0.0, 0.0};
-                // one slot at a time, RC loads in flight: this code runs between the groups of iterations with the mat-vec operand still
-                // resident, so its own register demand is kept small (a scratch reload between two loads of a batch serialises the batch)
+                // one slot at a time, RC loads in flight (the VGPR-resident part of the mat-vec operand is parked in scratch meanwhile)
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
 #pragma unroll
@@ -460,6 +488,8 @@ __device__ __forceinline__ void boxadmm_solve_reg2(const double* __restrict__ H,
                 max_Hx_ATy_h_norm = wave_max(a2);
                 res_prim = wave_max(rp) + wave_max(rq);
                 res_dual = wave_max(rd);
+                sched_fence();
+                K.unpark(parked, zr);
                 if (dbg) dbg[1] += clock64() - r0;
             }
             if (check) {

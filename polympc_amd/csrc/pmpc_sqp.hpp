@@ -393,6 +393,28 @@ struct SqpDevice {
             wsync();
             return;
         }
+        if constexpr (REG2) {   // compile-time sizes, columns lane and lane + 64: the loads of a column in batches, then the same add chain
+#pragma unroll
+            for (int e = 0; e < (NN > WAVE ? 2 : 1); ++e) {
+                const int col = lane_id() + 64 * e;
+                const int j = col < NN ? col : 0;
+                const unsigned jo = (unsigned)j * (NN + MM) + opaque_zero();
+                double a = 0.0;
+#pragma unroll
+                for (int i0 = 0; i0 < MM; i0 += 16) {
+                    double colv[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) colv[i] = Aw[jo + (unsigned)((i0 + i < MM) ? i0 + i : 0)];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) if (i0 + i < MM) a += colv[i] * v.lam[i0 + i];
+                }
+                a += v.h[j];
+                a += v.lam[MM + j];
+                if (col < NN) out[j] = a;
+            }
+            wsync();
+            return;
+        }
         for (int j = lane_id(); j < n; j += WAVE) {
             double a = 0.0;
             for (int i = 0; i < m; ++i) a += Aw[(size_t)j * ldw + i] * v.lam[i];
@@ -449,6 +471,7 @@ struct SqpDevice {
             const long long b0 = now();
             if constexpr (REG1 && HU == 1) bfgs_update_block();
             else if constexpr (REG1) { double brow[NN > 0 ? NN : 1]; bfgs_load_row(brow); bfgs_update_reg(brow); }
+            else if constexpr (REG2) { if (__builtin_amdgcn_readfirstlane(ss.hessian_update) == 1) bfgs_update_block(); else bfgs_update_reg2(); }
             else { if (__builtin_amdgcn_readfirstlane(ss.hessian_update) == 1) bfgs_update_block(); else bfgs_update(); }   // (the launcher routes hessian_update = 1 to these kernels)
             acc(5, now() - b0);
             for (int i = lane_id(); i < n; i += WAVE) v.lg[i] = v.lgn[i];
@@ -460,10 +483,80 @@ struct SqpDevice {
     // register-row variant for compile-time n: lane i owns row i of B; ONE batch of loads, ONE batch of stores
     // brow: row i of B (loading it earlier, across the first-order staging, costs more in register pressure than the L2
     // round trip it hides — measured)
+    // E: row slot — lane i owns row i + 64 E (two-rows-per-lane kernels: E = 1 serves the rows from 64 on)
+    template <int E = 0>
     __device__ __forceinline__ void bfgs_load_row(double (&brow)[NN > 0 ? NN : 1]) {
-        const unsigned i = (lane_id() < NN ? lane_id() : 0) + opaque_zero();
+        const int row = lane_id() + 64 * E;
+        const unsigned i = (row < NN ? row : 0) + opaque_zero();
 #pragma unroll
         for (int j = 0; j < NN; ++j) brow[j] = Hw[i + (unsigned)(j * (NN + MM))];
+    }
+    // B s and y for the rows of slot E (into v.t1 / v.t3); brow stays in registers
+    template <int E>
+    __device__ __forceinline__ void bfgs_row_products(const double (&brow)[NN > 0 ? NN : 1]) {
+        const int row = lane_id() + 64 * E;
+        const int i = row < NN ? row : 0;
+        double a = 0.0;
+#pragma unroll
+        for (int j = 0; j < NN; ++j) a += brow[j] * v.step[j];
+        if (row < NN) { v.t1[i] = a; v.t3[i] = v.lgn[i] - v.lg[i]; }
+    }
+    // B(row, :) += -(Bs_row Bs')/sBs + (r_row r')/sr for the rows of slot E, then the row goes back to the workspace
+    template <int E>
+    __device__ __forceinline__ void bfgs_row_rank2(double (&brow)[NN > 0 ? NN : 1], const UniformDiv& by_sBs, const UniformDiv& by_sr) {
+        const int row = lane_id() + 64 * E;
+        const int i = row < NN ? row : 0;
+        const double* Bs = v.t1; const double* r = v.t2;
+        const double Bsi = Bs[i], ri = r[i];
+#pragma unroll
+        for (int j0 = 0; j0 < NN; j0 += 8) {
+            double bsj[8], rj[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int jj = (j0 + j < NN) ? j0 + j : 0; bsj[j] = Bs[jj]; rj[j] = r[jj]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j0 + j < NN) {
+                    double b = brow[j0 + j];
+                    b += by_sBs(-Bsi * bsj[j]);
+                    b += by_sr(ri * rj[j]);
+                    brow[j0 + j] = b;
+                }
+            asm volatile("" ::: "memory");
+        }
+        if (row < NN) {
+            const unsigned io = (unsigned)i + opaque_zero();
+#pragma unroll
+            for (int j = 0; j < NN; ++j) Hw[io + (unsigned)(j * (NN + MM))] = brow[j];
+        }
+    }
+    // BFGS_update for the two-rows-per-lane kernels (compile-time n, up to 128 rows of B): the same operations on every entry as
+    // bfgs_update_reg / bfgs_update (one add chain per row for B s, sequential scalar products, quotients by the wave-uniform divisors)
+    __device__ __forceinline__ void bfgs_update_reg2() {
+        const int ln = lane_id();
+        double* Bs = v.t1; double* r = v.t2; double* y = v.t3;
+        double brow[NN > 0 ? NN : 1];
+        if constexpr (NN > WAVE) { bfgs_load_row<1>(brow); bfgs_row_products<1>(brow); }
+        bfgs_load_row<0>(brow); bfgs_row_products<0>(brow);
+        wsync();
+        const double sBs = seq_dot(v.step, Bs, NN);
+        const double sy = seq_dot(v.step, y, NN);
+        double sr;
+        if (sy < 0.2 * sBs) {
+            const double theta = 0.8 * sBs / (sBs - sy);
+            for (int i = ln; i < NN; i += WAVE) r[i] = theta * y[i] + (1 - theta) * Bs[i];
+            sr = theta * sy + (1 - theta) * sBs;
+        } else {
+            for (int i = ln; i < NN; i += WAVE) r[i] = y[i];
+            sr = sy;
+        }
+        wsync();
+        if (__builtin_amdgcn_readfirstlane((int)(sr < DBL_EPS))) return;
+        const UniformDiv by_sBs(sBs), by_sr(sr);
+        if (!(by_sBs.ok() && by_sr.ok())) { rank2_update_mem(Bs, r, sBs, sr); return; }   // divisor outside the window of UniformDiv (rare)
+        bfgs_row_rank2<0>(brow, by_sBs, by_sr);
+        if constexpr (NN > WAVE) { bfgs_load_row<1>(brow); bfgs_row_rank2<1>(brow, by_sBs, by_sr); }
+        wfence();
+        wsync();
     }
     __device__ __forceinline__ void bfgs_update_reg(double (&brow)[NN > 0 ? NN : 1]) {
         const int ln = lane_id();

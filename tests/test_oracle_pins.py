@@ -600,3 +600,47 @@ def test_sweep_policy_on_benchmark_stream(oracle):
     same = (r[0][1] == r[2][1]) & (r[0][2] == r[2][2])
     assert same.mean() >= 0.99
     assert np.abs(r[0][0] - r[2][0])[same].max() <= 1e-8
+
+
+# ---------------------------------------------------------------- PIVOT_SWEEP2: the two-rows-per-lane register kernel's order (65..112 rows)
+@pytest.mark.parametrize("n,m", [(66, 44), (55, 33), (41, 24), (70, 42)])
+def test_sweep2_policy_matches_factorisations(oracle, n, m):
+    """The blocked sweep carried to 5..7 tiles per dimension with the mat-vec order of pmpc_qp_reg2.hpp (four chains per row, columns
+    j = q mod 4) against numpy and against both LDL^T policies, on quasi-definite KKT matrices with the conditioning of the ADMM; sizes:
+    config B (110 rows), the 11-node robot grid (88), the smallest size the path takes (65) and its limit (112)."""
+    rng = np.random.default_rng(n * 100 + m)
+    G = rng.normal(size=(n, n)); H = G @ G.T / n + (1e-6 + 0.1) * np.eye(n); A = rng.normal(size=(m, n))
+    K = np.block([[H, A.T], [A, -np.diag(1.0 / rng.choice([0.1, 100.0], m))]])
+    b = rng.normal(size=n + m)
+    x_ref = np.linalg.solve(K, b)
+    scale = np.abs(x_ref).max()
+    xs = oracle.ldlt_solve(np.tril(K), b, oracle.PIVOT_SWEEP2)
+    assert np.abs(xs - x_ref).max() < 1e-9 * scale
+    for piv in (oracle.PIVOT_EIGEN, oracle.PIVOT_STATIC):
+        assert np.abs(xs - oracle.ldlt_solve(np.tril(K), b, piv)).max() < 1e-9 * scale
+
+
+def test_sweep2_policy_rejects_systems_over_112_rows(oracle):
+    from polympc_amd import workloads
+    wl = workloads.robot_batch(1, P=5, S=3)   # 128 rows
+    with pytest.raises(ValueError):
+        oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 3, 0.0, 2.0, 1, wl["d"], wl["lbx"], wl["ubx"], pivot=oracle.PIVOT_SWEEP2)
+
+
+@pytest.mark.parametrize("cfg", ["cstr", "robot_P5S2"])
+def test_sweep2_policy_on_benchmark_streams(oracle, cfg):
+    """Config B's own stream (CSTR, 110 KKT rows) and the 11-node robot grid: the swept-inverse order of the two-rows-per-lane kernel follows
+    the Eigen-pivoted trajectory — identical SQP and ADMM iteration counts and statuses on every instance, solutions within 1e-7 relative
+    (CSTR: states of magnitude 100; measured 7e-8) / 1e-8 (robot)."""
+    from polympc_amd import workloads
+    B = 96
+    wl = workloads.cstr_batch(B) if cfg == "cstr" else workloads.robot_batch(B, P=5, S=2)
+    ss = oracle.sqp_default_settings(); ss.max_iter = wl["max_iter"]; ss.line_search_max_iter = wl["ls_max_iter"]
+    r = {}
+    for piv in (oracle.PIVOT_EIGEN, oracle.PIVOT_SWEEP2):
+        x, l, info = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"],
+                                            sqp_settings=ss, pivot=piv, threads=8)
+        r[piv] = (x, [i.iter for i in info], [i.qp_solver_iter for i in info], [i.status for i in info])
+    a, b = r[oracle.PIVOT_EIGEN], r[oracle.PIVOT_SWEEP2]
+    assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3]
+    assert (np.abs(a[0] - b[0]) / np.maximum(1.0, np.abs(a[0]))).max() <= (1e-7 if cfg == "cstr" else 1e-8)

@@ -8,12 +8,12 @@ from polympc_amd import workloads
 
 B = int(os.environ.get("B", 4096))
 P_, S_ = int(os.environ.get("P", 6)), int(os.environ.get("S", 1))   # P=5 S=2 (88 KKT rows) or PMPC_FORCE_LDS_PATH=1: the LDS-resident kernel
-wl = workloads.robot_batch(B, P=P_, S=S_)
+wl = workloads.cstr_batch(B) if os.environ.get("CFG") == "B" else workloads.robot_batch(B, P=P_, S=S_)   # CFG=B: config B (CSTR, 110 KKT rows)
 ctx = pa.Context(0)
-ss = pa.sqp_settings_default(); ss.max_iter = 10; ss.line_search_max_iter = 10
+ss = pa.sqp_settings_default(); ss.max_iter = wl["max_iter"]; ss.line_search_max_iter = wl["ls_max_iter"]
 for rep in range(2):
     t = time.perf_counter()
-    x, lam, info = ctx.sqp_solve_batch(0, P_, S_, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
+    x, lam, info = ctx.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
     t = time.perf_counter() - t
 cyc = ctx.phase_cycles()
 names = ["linearise(+update)", "QP", "line search", "termination", "total loop", "BFGS", "KKT build+factor", "QP residuals",

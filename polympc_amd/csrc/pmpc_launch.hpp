@@ -7,6 +7,7 @@
 #include "pmpc_qp.hpp"
 #include "pmpc_qp_reg.hpp"
 #include "pmpc_qp_reg2.hpp"
+#include "pmpc_qp_big.hpp"
 #include "pmpc_sqp.hpp"
 
 // context services exported by libpolympc_amd.so (collocation constants cache, HBM workspace, stream, limits)
@@ -59,7 +60,8 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : 1
     if (NN > 0 && (size_t)(p - stage0) < (size_t)reg_qp_staging<NN + MM>() + ocp.s.const_doubles(P, S)) p = stage0 + reg_qp_staging<NN + MM>() + ocp.s.const_doubles(P, S);
     const double* stage_end = p;   // end of the per-node staging block: what follows (static parameters, filter) stays live during the line search
     // large-instance mode: the remaining QP vectors reuse the second-order AD staging (dead while the QP runs)
-    if constexpr (NN == 0 && KHBM) qw.carve_rest(ocp.s.Lhes, n, m, Kws + (size_t)b * QpLds::kdoubles(n + m));
+    if constexpr (NN == 0 && KHBM) qw.carve_rest(ocp.s.Lhes, n, m, Kws + (size_t)b * BigKkt::doubles(n + m));
+    if constexpr (NN == 0 && KHBM) { qw.big_lds = p; p += BigKkt::LDS_DOUBLES; }   // diagonal tile + broadcast slots of the blocked factorisation
     double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
     const int ln = lane_id();
     for (int i = ln; i < Model::ND; i += WAVE) dL[i] = d[(size_t)b * Model::ND + i];
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : 1
     // stacked workspace K0 = [H ; J] ((n+m) x n, column-major, leading dimension n+m): lane i reads row i of K0 with ONE stride
     double* K0 = Hws + (size_t)b * (size_t)(n + m) * n;
     (void)Aws;
-    SqpDevice<Model, NN, MM, PROF, HU> sqp(ocp, v, qw, K0, K0 + n, ss, qs);
+    SqpDevice<Model, NN, MM, PROF, HU, KHBM> sqp(ocp, v, qw, K0, K0 + n, ss, qs);
     sqp.filt = filt;
     sqp.tr = ocp.s.fval;   // first per-node staging array: everything from here on is dead while the QP runs
     {   // side-by-side line search: G candidates x (m constraint values + NN Lagrange values) + 3 scalars each, in the same region
@@ -118,7 +120,7 @@ template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode
     if (mode == 1) { const size_t need = (size_t)RegKkt<64>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
     if (mode == 3) { const size_t need = (size_t)RegKkt2<112>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
     return ((mode == 0 ? QpLds::doubles(dm.n, dm.m) : QpLds::doubles_xy(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8 +
-            ((mode == 1 || mode == 3) ? 0 : FILTER_LDS_DOUBLES)) * sizeof(double);
+            ((mode == 1 || mode == 3) ? 0 : FILTER_LDS_DOUBLES) + (mode == 2 ? BigKkt::LDS_DOUBLES : 0)) * sizeof(double);
 }
 template <class Model> inline bool sqp_hbm_mode_fits(int P, int S) {   // do the QP vectors fit the second-order staging?
     OcpDims<Model> dm(P, S);
@@ -253,13 +255,13 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     if (lds > lds_limit) {   // large instance: KKT factor in HBM, QP vectors over the AD staging
         lds = sqp_kernel_lds_bytes<Model>(P, S, 2);
         if (lds > lds_limit || !sqp_hbm_mode_fits<Model>(P, S)) return PMPC_ERR_UNSUPPORTED_SIZE;
-        st = pmpc_internal_services(ctx, P, S, t0, tf, (base + (size_t)B * QpLds::kdoubles(dm.n + dm.m)) * sizeof(double), &cdv, &ws, &streamv,
+        st = pmpc_internal_services(ctx, P, S, t0, tf, (base + (size_t)B * BigKkt::doubles(dm.n + dm.m)) * sizeof(double), &cdv, &ws, &streamv,
                                     &lds_limit, &phase, &force_lds);
         if (st != PMPC_OK) return st;
         Hws = ws; Aws = ws + (size_t)B * dm.n * dm.n; slice_state = Aws + (size_t)B * dm.m * dm.n; Kws = ws + base;
     }
     auto lkern = Kws ? sqp_kernel<Model, 0, 0, false, 0, true> : sqp_kernel<Model>;
-    if constexpr (LDS_PATH_PROFILED<Model>::value) { if (phase && !Kws) lkern = sqp_kernel<Model, 0, 0, true>; }   // developer builds of two models carry phase timers
+    if constexpr (LDS_PATH_PROFILED<Model>::value) { if (phase) lkern = Kws ? sqp_kernel<Model, 0, 0, true, 0, true> : sqp_kernel<Model, 0, 0, true>; }   // developer builds with phase timers
     if (hipFuncSetAttribute((const void*)lkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PMPC_ERR_HIP;
     const int slice = (slice_iters > 0) ? slice_iters : ss->max_iter;
     for (int it = 0; it < ss->max_iter; it += slice)

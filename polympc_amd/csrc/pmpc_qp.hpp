@@ -122,6 +122,7 @@ struct QpLds {
     __host__ __device__ static int koff(int N_, int j) { return j * N_ - (j * (j + 1)) / 2; }
     __device__ __forceinline__ int off(int j) const { return j * N - (j * (j + 1)) / 2; }
     double *x, *y, *z, *q, *zt, *zprev, *rho, *rhoinv, *rhob, *rhobinv, *kdiag, *rhs, *t1, *t2;
+    double* big_lds = nullptr;     // large-instance mode (pmpc_qp_big.hpp): BigKkt::LDS_DOUBLES doubles of LDS; K then points at the tile workspace in HBM
     __host__ __device__ static size_t kdoubles(int N_) { return (size_t)N_ * (N_ + 1) / 2; }
     __host__ __device__ static size_t doubles(int n, int m) {
         const int N = n + m;
@@ -526,8 +527,15 @@ __device__ __forceinline__ void rho_vec_update(const QpLds& w, int n, int m, con
     for (int i = ln; i < n; i += WAVE) { const double r = rho_of(classify_bounds(xlb[i], xub[i]), rho0); w.rhob[i] = r; w.rhobinv[i] = 1.0 / r; }
 }
 
+// large-instance linear algebra (pmpc_qp_big.hpp, included after this header by its users)
+__device__ __forceinline__ void big_build(double* __restrict__ W, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ A, int lda, const double* kdiag);
+__device__ __forceinline__ void big_factor(double* __restrict__ W, int N, double* dl);
+__device__ __forceinline__ void big_solve(const double* __restrict__ W, int N, double* v, double* bx);
+
 // boxADMM::solve_impl (box_admm.hpp:88-205). Result in w.x (n) and w.y (m+n). h/Alb/Aub/xlb/xub may live in LDS or HBM.
 // H(i,j) = H[j*ldh + i], A(r,j) = A[j*lda + r]  (ldh = n, lda = m for plain column-major inputs)
+// BIG: the KKT factor is the tiled HBM workspace of pmpc_qp_big.hpp (blocked LDL^T, MFMA trailing updates) instead of the packed triangle.
+template <bool BIG = false>
 __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* h,
                                      const double* __restrict__ A, int lda, const double* Alb, const double* Aub, const double* xlb,
                                      const double* xub, const double* x0, const double* y0, const pmpc_qp_settings& s,
@@ -553,9 +561,9 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
     for (int i = ln; i < m; i += WAVE) w.kdiag[n + i] = -w.rhoinv[i];
     wsync();
     { const long long t0 = tick();
-      kkt_build(w, n, m, H, ldh, A, lda);
+      if constexpr (BIG) big_build(w.K, n, m, H, ldh, A, lda, w.kdiag); else kkt_build(w, n, m, H, ldh, A, lda);
       const long long t1 = tick();
-      kkt_factor(w, N);
+      if constexpr (BIG) big_factor(w.K, N, w.big_lds); else kkt_factor(w, N);
       if (tm) { tm[0] += tick() - t0; tm[3] += t1 - t0; } }
 
     int status = PMPC_QP_UNSOLVED;
@@ -568,7 +576,7 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
         for (int i = ln; i < n; i += WAVE) w.rhs[i] = ((s.sigma * w.x[i] - h[i]) + w.rhob[i] * w.q[i]) - w.y[m + i];
         for (int i = ln; i < m; i += WAVE) { w.zprev[i] = w.z[i]; w.rhs[n + i] = w.z[i] - w.rhoinv[i] * w.y[i]; }
         wsync();
-        { const long long t0 = tick(); kkt_solve(w, N, w.rhs); if (tm) tm[2] += tick() - t0; }
+        { const long long t0 = tick(); if constexpr (BIG) big_solve(w.K, N, w.rhs, w.big_lds + 256); else kkt_solve(w, N, w.rhs); if (tm) tm[2] += tick() - t0; }
         for (int i = ln; i < m; i += WAVE) {
             const double zt = w.zprev[i] + w.rhoinv[i] * (w.rhs[n + i] - w.y[i]);
             double zz = alpha * zt;
@@ -613,8 +621,8 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
                 for (int i = ln; i < n; i += WAVE) w.kdiag[i] += (w.rhob[i] - w.t2[i]);
                 for (int i = ln; i < m; i += WAVE) w.kdiag[n + i] = -w.rhoinv[i];
                 wsync();
-                kkt_build(w, n, m, H, ldh, A, lda);
-                kkt_factor(w, N);
+                if constexpr (BIG) { big_build(w.K, n, m, H, ldh, A, lda, w.kdiag); big_factor(w.K, N, w.big_lds); }
+                else { kkt_build(w, n, m, H, ldh, A, lda); kkt_factor(w, N); }
             }
         }
     }

@@ -14,6 +14,7 @@
 #include "pmpc_qp.hpp"
 #include "pmpc_qp_reg.hpp"
 #include "pmpc_qp_reg2.hpp"
+#include "pmpc_qp_big.hpp"
 #include "pmpc_ruiz.hpp"
 #include "pmpc_admm.hpp"
 
@@ -43,7 +44,8 @@ constexpr int PMPC_SQP_IN_PROGRESS = 3;   // internal: the instance continues in
 // PROF: accumulate per-phase shader-clock cycles (separate kernel instantiation; costs 16+ VGPRs, off by default)
 // HU: Hessian-update policy compiled into a register-resident specialisation (0 dense damped BFGS, 1 block BFGS); the LDS-resident
 // kernels (NN == 0) select it at run time from settings.hessian_update
-template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0>
+// BIG: large-instance mode — the KKT factor is the tiled HBM workspace of pmpc_qp_big.hpp
+template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bool BIG = false>
 struct SqpDevice {
     using Dm = OcpDims<Model>;
     // Ruiz scaling is compiled into the LDS / HBM-resident QP kernels only: the launcher routes preconditioner = 1 there. In the
@@ -744,7 +746,7 @@ struct SqpDevice {
             if (RUIZ_COMPILED && __builtin_amdgcn_readfirstlane(ss.qp_solver) == 1) admm_solve(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi);
             else {
                 long long tq[4] = {0, 0, 0, 0};
-                boxadmm_solve(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, PROF ? tq : nullptr);
+                boxadmm_solve<BIG>(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, PROF ? tq : nullptr);
                 acc(6, tq[0]); acc(7, tq[1]); acc(17, tq[2]); acc(16, tq[3]);   // (slots 16 / 17 double as "KKT build" / "substitutions" on the LDS path)
             }
         }

@@ -8,7 +8,8 @@ from polympc_amd import workloads
 
 B = int(os.environ.get("B", 4096))
 P_, S_ = int(os.environ.get("P", 6)), int(os.environ.get("S", 1))   # P=5 S=2 (88 KKT rows) or PMPC_FORCE_LDS_PATH=1: the LDS-resident kernel
-wl = workloads.cstr_batch(B) if os.environ.get("CFG") == "B" else workloads.robot_batch(B, P=P_, S=S_)   # CFG=B: config B (CSTR, 110 KKT rows)
+_cfg = os.environ.get("CFG")   # CFG=B: config B (CSTR, 110 KKT rows); CFG=C: the kite stand-in (464 KKT rows)
+wl = workloads.cstr_batch(B) if _cfg == "B" else (workloads.kite_standin_batch(B) if _cfg == "C" else workloads.robot_batch(B, P=P_, S=S_))
 ctx = pa.Context(0)
 ss = pa.sqp_settings_default(); ss.max_iter = wl["max_iter"]; ss.line_search_max_iter = wl["ls_max_iter"]
 for rep in range(2):

@@ -8,7 +8,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(HERE, "libpolympc_amd.so")
+LIB_PATH = os.environ.get("PMPC_LIB") or os.path.join(HERE, "libpolympc_amd.so")   # PMPC_LIB: developer switch for A/B builds of the library
 
 MODEL_ROBOT, MODEL_CSTR, MODEL_PARKING, MODEL_ROBOT_NG, MODEL_KITE_STANDIN, MODEL_PARKING_NG = 0, 1, 2, 3, 4, 5
 QP_SOLVED, QP_MAX_ITER_EXCEEDED, QP_UNSOLVED = 0, 1, 2

@@ -528,9 +528,9 @@ __device__ __forceinline__ void rho_vec_update(const QpLds& w, int n, int m, con
 }
 
 // large-instance linear algebra (pmpc_qp_big.hpp, included after this header by its users)
-__device__ __forceinline__ void big_build(double* __restrict__ W, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ A, int lda, const double* kdiag);
-__device__ __forceinline__ void big_factor(double* __restrict__ W, int N, double* dl);
-__device__ __forceinline__ void big_solve(const double* __restrict__ W, int N, double* v, double* bx);
+__device__ __forceinline__ void big_build(double* W, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ A, int lda, const double* kdiag);
+__device__ __forceinline__ void big_factor(double* W, int N, double* dl);
+__device__ __forceinline__ void big_solve(const double* W, int N, double* v, double* bx);
 
 // boxADMM::solve_impl (box_admm.hpp:88-205). Result in w.x (n) and w.y (m+n). h/Alb/Aub/xlb/xub may live in LDS or HBM.
 // H(i,j) = H[j*ldh + i], A(r,j) = A[j*lda + r]  (ldh = n, lda = m for plain column-major inputs)

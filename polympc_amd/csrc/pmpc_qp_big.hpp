@@ -6,11 +6,15 @@
 // UNSCALED column entry c_ik and the scaled l_jk = c_jk / d_k, the substitutions are the column-oriented fma chains, pivot order 0..N-1 —
 // so the CPU restatement is the same PIVOT_STATIC and the results are bit-identical to the unblocked kernels. What changes is the
 // schedule and the data layout:
-//   * the factor lives in HBM as 16 x 16 tiles of the lower block triangle, tile (I, J) at I(I+1)/2 + J, in TWO copies: row-major tiles
-//     (Lr: a lane reads ITS ROW of a tile as 128 contiguous bytes — forward substitution, panel factorisation; an accumulator tile is four
-//     coalesced 512-byte loads) and k-major tiles (Lc = the transposes: a lane reads ITS COLUMN contiguously — backward substitution; a
-//     tile is directly the B operand of the trailing update). The unblocked kernel streamed the packed trailing triangle once per PIVOT
+//   * the WORKING matrix lives in HBM as 16 x 16 row-major tiles of the lower block triangle, tile (I, J) at I(I+1)/2 + J (Lr: an MFMA
+//     accumulator tile is four coalesced 512-byte loads). The unblocked kernel streamed the packed trailing triangle once per PIVOT
 //     (270 MB per factorisation at 464 rows); here a trailing tile is read and written once per 16 pivots (27 MB).
+//   * the finished FACTOR is written twice, in the two layouts the substitutions stream with one lane per row and every load instruction a
+//     contiguous 512-byte segment: LF — per block column J the 16 columns of L below (and including) the diagonal tile, each column
+//     contiguous over the rows (forward substitution: instruction c loads L(row, 16J + c) for 64 consecutive rows; it is also the B operand
+//     of the trailing update) — and LB — per block row J its 16 rows of L, each row contiguous over the columns (backward substitution:
+//     instruction c loads L(16J + c, i) for 64 consecutive i). Per-lane contiguous 128-byte rows of tiles, the first layout tried, kept the
+//     texture-address unit busy with 64 different cache lines per instruction: 2.5 TB/s.
 //   * block column k: the diagonal tile is factorised by 16 lanes (pivot values broadcast with v_readlane), every row below applies the
 //     16 pivots to its own 16 entries independently (one lane per row, the diagonal tile's d and l through LDS), then every trailing tile
 //     gets ONE rank-16 update on the matrix cores: four v_mfma_f64_16x16x4_f64 (a k-ascending fma chain per entry — verified on gfx950,
@@ -32,22 +36,36 @@ struct BigKkt {
     __host__ __device__ static int nblk(int N) { return (N + TB - 1) / TB; }
     __host__ __device__ static int ntiles(int N) { const int nb = nblk(N); return nb * (nb + 1) / 2; }
     __host__ __device__ static int tidx(int I, int J) { return I * (I + 1) / 2 + J; }
-    // per-instance HBM workspace (doubles): [Lr tiles | Lc tiles | -C strip (16 x Npad, k-major)]
-    __host__ __device__ static size_t doubles(int N) { return 2 * (size_t)ntiles(N) * 256 + (size_t)TB * nblk(N) * TB; }
+    // Panels are stored in SLABS of 64 lanes x 16 entries (8 KB): entry (c, rel) of a panel at (rel / 64) * 1024 + c * 64 + rel % 64, so that the 16
+    // load instructions of one lane-per-row slot sweep ONE contiguous 8 KB region (sixteen 512-byte pieces a panel-column apart kept one DRAM
+    // row per piece open).
+    //   LF, block column J: rel = row - 16J, c = column - 16J, (NPAD - 16J) rows padded to a multiple of 64; panels in J order
+    //   LB, block row J:    rel = column i,  c = row - 16J,    16(J+1) columns padded to a multiple of 64; panels in J order
+    __host__ __device__ static size_t sizeF(int J, int NPAD) { return (size_t)16 * (((NPAD - 16 * J) + 63) / 64 * 64); }
+    __host__ __device__ static size_t sizeB(int J) { return (size_t)16 * ((16 * (J + 1) + 63) / 64 * 64); }
+    __host__ __device__ static size_t ceil4_sum(int t) { const int Q = t >> 2, R = t & 3; return (size_t)(Q + 1) * (2 * Q + R); }   // sum_{u=1..t} ceil(u / 4)
+    __host__ __device__ static size_t offB(int J) { return 1024 * ceil4_sum(J); }                                    // sizeB(j) = 1024 ceil((j+1)/4)
+    __host__ __device__ static size_t offF(int J, int NPAD) { const int nb = NPAD >> 4; return 1024 * (ceil4_sum(nb) - ceil4_sum(nb - J)); }   // sizeF(j) = 1024 ceil((nb-j)/4)
+    __host__ __device__ static size_t slab(int c, int rel) { return (size_t)(rel >> 6) * 1024 + (size_t)c * 64 + (rel & 63); }
+    // per-instance HBM workspace (doubles): [Lr working tiles | LF forward panels | LB backward panels | -C strip (16 x Npad, k-major)]
+    __host__ __device__ static size_t doubles(int N) {
+        const int nb = nblk(N);
+        return (size_t)ntiles(N) * 256 + offF(nb, nb * 16) + offB(nb) + (size_t)TB * nb * TB;
+    }
     static constexpr int LDS_DOUBLES = 256 + 16;                    // diagonal tile (d on the diagonal, l below) + 16 broadcast slots
 };
 
 using big_d4 = double __attribute__((ext_vector_type(4)));
 
 // K (lower block triangle, row-major tiles in W) <- [H + diag ; A, diag]; rows / columns >= N: identity padding
-__device__ __forceinline__ void big_build(double* __restrict__ W, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ A,
+__device__ __forceinline__ void big_build(double* W, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ A,
                                           int lda, const double* kdiag) {
     const int ln = lane_id();
     const int N = n + m, nb = BigKkt::nblk(N);
     const int r = ln & 15, cg = ln >> 4;
     for (int I = 0; I < nb; ++I)
         for (int J = 0; J <= I; ++J) {
-            double* __restrict__ t = W + (size_t)BigKkt::tidx(I, J) * 256;
+            double* t = W + (size_t)BigKkt::tidx(I, J) * 256;
             const int i = 16 * I + r;
             double e[4];
 #pragma unroll
@@ -66,18 +84,21 @@ __device__ __forceinline__ void big_build(double* __restrict__ W, int n, int m, 
 }
 
 // in-place blocked LDL^T of the tiles in W (see the header). dl: BigKkt::LDS_DOUBLES doubles of LDS.
-__device__ __forceinline__ void big_factor(double* __restrict__ W, int N, double* dl) {
+__device__ __forceinline__ void big_factor(double* W, int N, double* dl) {
     const int ln = lane_id();
     const int nb = BigKkt::nblk(N), NPAD = nb * 16;
     const size_t nt = (size_t)BigKkt::ntiles(N);
-    double* __restrict__ Lr = W;
-    double* __restrict__ Lc = W + nt * 256;
-    double* __restrict__ Cn = W + 2 * nt * 256;      // -C strip: entry (t, row) at t * NPAD + row
+    double* Lr = W;
+    double* LF = W + nt * 256;
+    double* LB = LF + BigKkt::offF(nb, NPAD);
+    double* Cn = LB + BigKkt::offB(nb);      // -C strip: entry (t, row) at t * NPAD + row
     const int lr = ln >> 4, lc = ln & 15;
-    for (int k = 0; k < nb; ++k) {
+    size_t oF = 0;
+    for (int k = 0; k < nb; oF += BigKkt::sizeF(k, NPAD), ++k) {
+        double* pF = LF + oF;   // forward panel of block column k
         // ---- (a) diagonal tile: right-looking LDL^T on 16 lanes (lane r = row r of the tile)
         {
-            double* __restrict__ td = Lr + (size_t)BigKkt::tidx(k, k) * 256;
+            double* td = Lr + (size_t)BigKkt::tidx(k, k) * 256;
             const int r = ln & 15;
             double a[16];
 #pragma unroll
@@ -96,10 +117,11 @@ __device__ __forceinline__ void big_factor(double* __restrict__ W, int N, double
                 a[t] = (r > t) ? l : a[t];
             }
             if (ln < 16) {
-                double* __restrict__ tc = Lc + (size_t)BigKkt::tidx(k, k) * 256;
+                double* pB = LB + BigKkt::offB(k);
 #pragma unroll
-                for (int c = 0; c < 16; ++c) { td[r * 16 + c] = a[c]; tc[c * 16 + r] = a[c]; dl[r * 16 + c] = a[c]; }
+                for (int c = 0; c < 16; ++c) { pF[BigKkt::slab(c, r)] = a[c]; pB[BigKkt::slab(r, 16 * k + c)] = a[c]; dl[r * 16 + c] = a[c]; }
             }
+            wfence();
             wsync();
         }
         if (k == nb - 1) break;
@@ -109,7 +131,7 @@ __device__ __forceinline__ void big_factor(double* __restrict__ W, int N, double
             const bool live = row < NPAD;
             const int rw = live ? row : row0;
             const int I = rw >> 4, rr = rw & 15;
-            double* __restrict__ tr_ = Lr + (size_t)BigKkt::tidx(I, k) * 256 + rr * 16;
+            double* tr_ = Lr + (size_t)BigKkt::tidx(I, k) * 256 + rr * 16;
             double a[16], cneg[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) a[c] = tr_[c];
@@ -123,9 +145,9 @@ __device__ __forceinline__ void big_factor(double* __restrict__ W, int N, double
                 a[t] = l;
             }
             if (live) {
-                double* __restrict__ tc = Lc + (size_t)BigKkt::tidx(I, k) * 256 + rr;
+                double* pB = LB + BigKkt::offB(I);
 #pragma unroll
-                for (int c = 0; c < 16; ++c) { tr_[c] = a[c]; tc[c * 16] = a[c]; Cn[(size_t)c * NPAD + row] = cneg[c]; }
+                for (int c = 0; c < 16; ++c) { pF[BigKkt::slab(c, row - 16 * k)] = a[c]; pB[BigKkt::slab(rr, 16 * k + c)] = a[c]; Cn[(size_t)c * NPAD + row] = cneg[c]; }
             }
         }
         wfence();
@@ -142,17 +164,16 @@ __device__ __forceinline__ void big_factor(double* __restrict__ W, int N, double
             }
             const int Jend = (I0 + 3 < nb) ? I0 + 3 : nb - 1;
             for (int J = k + 1; J <= Jend; ++J) {
-                const double* __restrict__ tb = Lc + (size_t)BigKkt::tidx(J, k) * 256;
-                double bv[4];
+                double bv[4];   // B(kk = 4s + lr, col = lc) = L(16J + lc, 16k + 4s + lr)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) bv[s] = tb[64 * s + ln];
+                for (int s = 0; s < 4; ++s) bv[s] = pF[BigKkt::slab(4 * s + lr, 16 * (J - k) + lc)];
                 big_d4 T[4];
                 // (tiles of the group with I < J do not exist: their loads are redirected to the group's last tile and the result dropped)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int I = I0 + g;
                     const bool ex = I < nb && I >= J;
-                    const double* __restrict__ tt = Lr + (size_t)BigKkt::tidx(ex ? I : Jend, ex ? J : k + 1) * 256;
+                    const double* tt = Lr + (size_t)BigKkt::tidx(ex ? I : Jend, ex ? J : k + 1) * 256;
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) T[g][rg] = tt[64 * rg + ln];
                 }
@@ -164,7 +185,7 @@ __device__ __forceinline__ void big_factor(double* __restrict__ W, int N, double
                 for (int g = 0; g < 4; ++g) {
                     const int I = I0 + g;
                     if (I < nb && I >= J) {
-                        double* __restrict__ tt = Lr + (size_t)BigKkt::tidx(I, J) * 256;
+                        double* tt = Lr + (size_t)BigKkt::tidx(I, J) * 256;
 #pragma unroll
                         for (int rg = 0; rg < 4; ++rg) tt[64 * rg + ln] = T[g][rg];
                     }
@@ -176,24 +197,28 @@ __device__ __forceinline__ void big_factor(double* __restrict__ W, int N, double
     }
 }
 
-// v <- K^{-1} v, v in LDS (N entries; padding rows are not touched). bx: 16 doubles of LDS (broadcast slots).
-__device__ __forceinline__ void big_solve(const double* __restrict__ W, int N, double* v, double* bx) {
+// v <- K^{-1} v, v in LDS (N entries; padding rows are not touched). bx: unused LDS slots.
+__device__ __forceinline__ void big_solve(const double* W, int N, double* v, double* bx) {
     const int ln = lane_id();
     const int nb = BigKkt::nblk(N), NPAD = nb * 16;
     const size_t nt = (size_t)BigKkt::ntiles(N);
-    const double* __restrict__ Lr = W;
-    const double* __restrict__ Lc = W + nt * 256;
-    constexpr int GS = 4;   // row slots (of 64 rows) whose loads are issued together
+    const double* LF = W + nt * 256;
+    const double* LB = LF + BigKkt::offF(nb, NPAD);
+#ifndef PMPC_BIG_GS
+#define PMPC_BIG_GS 4
+#endif
+    constexpr int GS = PMPC_BIG_GS;   // row slots (of 64 rows) whose loads are issued together
     // ---- forward: blocks ascending; inside a block columns ascending
-    for (int J = 0; J < nb; ++J) {
+    size_t oF = 0;
+    for (int J = 0; J < nb; oF += BigKkt::sizeF(J, NPAD), ++J) {
+        const double* pF = LF + oF;
         double xj[16];
         {   // finish x_J on 16 lanes (unit-lower triangular solve with the diagonal tile), then broadcast its 16 entries
             const int r = ln & 15;
             const int row = 16 * J + r;
-            const double* __restrict__ td = Lr + (size_t)BigKkt::tidx(J, J) * 256 + r * 16;
             double lrow[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) lrow[c] = td[c];
+            for (int c = 0; c < 16; ++c) lrow[c] = pF[BigKkt::slab(c, r)];
             double xr = (row < N) ? v[row] : 0.0;
 #pragma unroll
             for (int c = 0; c < 15; ++c) {
@@ -211,9 +236,8 @@ __device__ __forceinline__ void big_solve(const double* __restrict__ W, int N, d
             for (int g = 0; g < GS; ++g) {
                 const int row = row0 + g * WAVE + ln;
                 const int rw = (row < NPAD) ? row : NPAD - 1;
-                const double* __restrict__ tr_ = Lr + (size_t)BigKkt::tidx(rw >> 4, J) * 256 + (rw & 15) * 16;
 #pragma unroll
-                for (int c = 0; c < 16; ++c) L[g][c] = tr_[c];
+                for (int c = 0; c < 16; ++c) L[g][c] = pF[BigKkt::slab(c, rw - 16 * J)];
                 vi[g] = (row < N) ? v[row] : 0.0;
             }
 #pragma unroll
@@ -227,18 +251,23 @@ __device__ __forceinline__ void big_solve(const double* __restrict__ W, int N, d
         wsync();
     }
     // ---- diagonal
-    for (int i = ln; i < N; i += WAVE) v[i] = v[i] / Lr[(size_t)BigKkt::tidx(i >> 4, i >> 4) * 256 + (i & 15) * 17];
+    for (int i = ln; i < N; i += WAVE) {
+        const int I = i >> 4, r = i & 15;
+        v[i] = v[i] / LF[BigKkt::offF(I, NPAD) + BigKkt::slab(r, r)];
+    }
     wsync();
     // ---- backward: blocks descending; inside a block columns descending
+    size_t oB = BigKkt::offB(nb);
     for (int J = nb - 1; J >= 0; --J) {
+        oB -= BigKkt::sizeB(J);
+        const double* pB = LB + oB;
         double xj[16];
         {
             const int r = ln & 15;
             const int row = 16 * J + r;
-            const double* __restrict__ tc = Lc + (size_t)BigKkt::tidx(J, J) * 256 + r * 16;   // column r of the diagonal tile: L(16J + c, 16J + r), c = 0..15
-            double lcol[16];
+            double lcol[16];   // column r of the diagonal tile: L(16J + c, 16J + r), c = 0..15
 #pragma unroll
-            for (int c = 0; c < 16; ++c) lcol[c] = tc[c];
+            for (int c = 0; c < 16; ++c) lcol[c] = pB[BigKkt::slab(c, 16 * J + r)];
             double xr = (row < N) ? v[row] : 0.0;
 #pragma unroll
             for (int c = 15; c > 0; --c) {
@@ -256,9 +285,8 @@ __device__ __forceinline__ void big_solve(const double* __restrict__ W, int N, d
             for (int g = 0; g < GS; ++g) {
                 const int row = row0 + g * WAVE + ln;
                 const int rw = (row < 16 * J) ? row : 0;
-                const double* __restrict__ tc = Lc + (size_t)BigKkt::tidx(J, rw >> 4) * 256 + (rw & 15) * 16;   // L(16J + c, rw), c = 0..15
 #pragma unroll
-                for (int c = 0; c < 16; ++c) L[g][c] = tc[c];
+                for (int c = 0; c < 16; ++c) L[g][c] = pB[BigKkt::slab(c, rw)];   // L(16J + c, rw)
                 vi[g] = v[rw];
             }
 #pragma unroll

@@ -618,9 +618,7 @@ struct SqpDevice {
         const int ln = lane_id();
         double* Bs = v.t1; double* r = v.t2; double* y = v.t3;
         for (int i = ln; i < n; i += WAVE) {
-            double a = 0.0;
-            for (int j = 0; j < n; ++j) a += Hw[(size_t)j * ldw + i] * v.step[j];
-            Bs[i] = a;
+            Bs[i] = seq_dot_strided(Hw, (size_t)ldw, 1, i, n, v.step);   // row i of B times s: one add chain, columns ascending, eight loads in flight
             y[i] = v.lgn[i] - v.lg[i];
         }
         wsync();
@@ -689,16 +687,26 @@ struct SqpDevice {
         wfence();
         wsync();
     }
-    // B += -(Bs Bs^T)/sBs + (r r^T)/sr, element by element in the HBM workspace
+    // B += -(Bs Bs^T)/sBs + (r r^T)/sr, element by element in the HBM workspace: lane i walks row i, eight columns per batch of loads
+    // (every entry sees the same two operations as in the reference's expression, entries are independent of each other)
     __device__ __forceinline__ void rank2_update_mem(const double* Bs, const double* r, double sBs, double sr) {
         const int ln = lane_id();
-        for (int j = 0; j < n; ++j) {
-            const double Bsj = Bs[j], rj = r[j];
-            for (int i = ln; i < n; i += WAVE) {
-                double b = Hw[(size_t)j * ldw + i];
-                b += (-Bs[i] * Bsj) / sBs;
-                b += (r[i] * rj) / sr;
-                Hw[(size_t)j * ldw + i] = b;
+        constexpr int CH = 8;
+        for (int i = ln; i < n; i += WAVE) {
+            const double Bsi = Bs[i], ri = r[i];
+            double* __restrict__ row = Hw + i;
+            for (int j0 = 0; j0 < n; j0 += CH) {
+                double b[CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) b[u] = row[(size_t)((j0 + u < n) ? j0 + u : n - 1) * ldw];
+#pragma unroll
+                for (int u = 0; u < CH; ++u)
+                    if (j0 + u < n) {
+                        double t = b[u];
+                        t += (-Bsi * Bs[j0 + u]) / sBs;
+                        t += (ri * r[j0 + u]) / sr;
+                        row[(size_t)(j0 + u) * ldw] = t;
+                    }
             }
         }
         wfence();

@@ -1,4 +1,5 @@
-"""Summarise the CSVs written by tests/tools_pmc.sh into profiles/<tag>_pmc_summary.json (per-launch means)."""
+"""Summarise the CSVs written by tests/tools_pmc.sh into gpurun_out/<tag>_pmc_summary.json (per-launch means; copy the summaries to be
+judged into profiles/). The traffic figure is taken for the kernel with the largest FETCH_SIZE total unless it is the bench kernel."""
 import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
@@ -10,7 +11,7 @@ for name in ["sq1", "sq2", "fetch", "write", "calfetch", "calwrite"]:
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
         kn = r["Kernel_Name"]
-        if "sqp_kernel" in kn or "stream_rw" in kn:
+        if "sqp_kernel" in kn or "stream_rw" in kn or "qp_boxadmm" in kn:
             agg[(kn.split("(")[0][-60:], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (kn, cn), v in agg.items():
         out.setdefault(name, {})[f"{cn} [{kn}]"] = {"per_launch_mean": sum(v) / len(v), "launches": len(v)}
@@ -21,7 +22,9 @@ def _one(d, key):
     # the bench kernel is the default-policy specialisation (template arguments ..., PROF = false, HU = 0, KHBM = false); bench.py also
     # launches the block-BFGS specialisation (HU = 1) for its variant leg, which is reported but not used for the traffic figure
     ks = [k for k in d if k.startswith(key)]
-    pref = [k for k in ks if "stream_rw" in k or ", false, 0, false>" in k] or ks
+    pref = [k for k in ks if "stream_rw" in k or ", 35, 21, false, 0, false>" in k]
+    if not pref:   # not the bench command: the kernel that moves the most data
+        pref = sorted(ks, key=lambda k: -d[k]["per_launch_mean"] * d[k]["launches"])
     return d[pref[0]]["per_launch_mean"] if pref else None
 try:
     f_unit = (1 << 30) / _one(out["calfetch"], "FETCH_SIZE")
@@ -30,8 +33,13 @@ try:
     write = _one(out["write"], "WRITE_SIZE") * w_unit
     out["traffic"] = {"fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "bytes_per_launch": fetch + write,
                       "bytes_per_counter_unit": {"FETCH_SIZE": f_unit, "WRITE_SIZE": w_unit},
-                      "workload": "bench.py --steps 5 --warmup 1 (config A, batch 4096), sqp_kernel<RobotOCP,35,21>"}
+                      "kernel": [k for k in sorted(out["fetch"], key=lambda k: -out["fetch"][k]["per_launch_mean"] * out["fetch"][k]["launches"])][0] if not any(", 35, 21, false, 0, false>" in k for k in out["fetch"]) else "sqp_kernel<RobotOCP,35,21> (bench.py --steps 5 --warmup 1, config A, batch 4096)"}
 except Exception as e:  # incomplete collection
     out["traffic"] = None
-json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1)
+try:
+    import hashlib
+    out["library_build_id"] = hashlib.sha256(open(os.path.join(ROOT, "polympc_amd", "libpolympc_amd.so"), "rb").read()).hexdigest()[:16]
+except Exception:
+    pass
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

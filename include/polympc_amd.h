@@ -59,9 +59,12 @@ typedef struct {
  * (= number of KKT factorisations), the reference never resets its counter (box_admm.hpp:395). */
 typedef struct {
     int status, iter, rho_updates;
-    int _pad;
+    int flags;   /* PMPC_FLAG_NONFINITE: a non-finite value reached the QP solution — the static-order (unpivoted) factorisation met a zero
+                  * pivot (indefinite Hessian without regularisation). The reference has no such report: Eigen::LDLT pivots and "simply
+                  * proceeds" (SURVEY Appendix B); status follows the reference's rules, this word says the numbers are not to be trusted. */
     double rho_estimate, res_prim, res_dual;
 } pmpc_qp_info;
+#define PMPC_FLAG_NONFINITE 1
 
 /* sqp_settings_t (sqp_base.hpp:24-47) + the two override points the reference's tests use:
  * regularisation: 0 none (default hook, sqp_base.hpp:305), 2 Gershgorin shift (dense_sparse_compare.cpp:109-122)
@@ -98,7 +101,7 @@ typedef enum { PMPC_SQP_SOLVED = 0, PMPC_SQP_MAX_ITER_EXCEEDED = 1, PMPC_SQP_INV
 /* sqp_info_t (sqp_base.hpp:57-61) + the getters primal_norm/dual_norm/constr_violation/cost (:192-195) */
 typedef struct {
     int iter, qp_solver_iter, status;
-    int _pad;
+    int flags;   /* OR of the pmpc_qp_info::flags of every QP of the solve (PMPC_FLAG_NONFINITE) */
     double primal_norm, dual_norm, max_violation, cost;
 } pmpc_sqp_info;
 

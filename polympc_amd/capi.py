@@ -32,7 +32,7 @@ class QPSettings(C.Structure):
 
 
 class QPInfo(C.Structure):
-    _fields_ = [("status", C.c_int), ("iter", C.c_int), ("rho_updates", C.c_int), ("_pad", C.c_int),
+    _fields_ = [("status", C.c_int), ("iter", C.c_int), ("rho_updates", C.c_int), ("flags", C.c_int),
                 ("rho_estimate", C.c_double), ("res_prim", C.c_double), ("res_dual", C.c_double)]
 
 
@@ -48,14 +48,14 @@ FILTER_STATE_DOUBLES = 1 + 2 * FILTER_MAX_DEPTH
 
 
 class SQPInfo(C.Structure):
-    _fields_ = [("iter", C.c_int), ("qp_solver_iter", C.c_int), ("status", C.c_int), ("_pad", C.c_int),
+    _fields_ = [("iter", C.c_int), ("qp_solver_iter", C.c_int), ("status", C.c_int), ("flags", C.c_int),
                 ("primal_norm", C.c_double), ("dual_norm", C.c_double), ("max_violation", C.c_double),
                 ("cost", C.c_double)]
 
 
-QP_INFO_DTYPE = np.dtype([("status", "i4"), ("iter", "i4"), ("rho_updates", "i4"), ("_pad", "i4"),
+QP_INFO_DTYPE = np.dtype([("status", "i4"), ("iter", "i4"), ("rho_updates", "i4"), ("flags", "i4"),
                           ("rho_estimate", "f8"), ("res_prim", "f8"), ("res_dual", "f8")])
-SQP_INFO_DTYPE = np.dtype([("iter", "i4"), ("qp_solver_iter", "i4"), ("status", "i4"), ("_pad", "i4"),
+SQP_INFO_DTYPE = np.dtype([("iter", "i4"), ("qp_solver_iter", "i4"), ("status", "i4"), ("flags", "i4"),
                            ("primal_norm", "f8"), ("dual_norm", "f8"), ("max_violation", "f8"), ("cost", "f8")])
 assert QP_INFO_DTYPE.itemsize == C.sizeof(QPInfo) == 40 and SQP_INFO_DTYPE.itemsize == C.sizeof(SQPInfo) == 48
 

@@ -140,7 +140,7 @@ __device__ __forceinline__ void admm_solve(QpLds& w, int n, int m, const double*
         }
     }
     if (iter > s.max_iter) status = PMPC_QP_MAX_ITER_EXCEEDED;
-    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info._pad = 0;
+    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info.flags = 0;
     info.rho_estimate = rho_estimate; info.res_prim = rs.res_prim; info.res_dual = rs.res_dual;
 }
 

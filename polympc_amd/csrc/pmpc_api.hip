@@ -107,12 +107,25 @@ const char* pmpc_status_string(pmpc_status s) {
     return "?";
 }
 
+static pmpc_status create_impl(int device, void* stream, pmpc_context* ctx);
 pmpc_status pmpc_create(int device, void* stream, pmpc_context** out) {
     if (!out) return PMPC_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return PMPC_ERR_NO_DEVICE;
     HIPCHK(hipSetDevice(device));
     pmpc_context* ctx = new pmpc_context();
+    const pmpc_status st = create_impl(device, stream, ctx);
+    if (st != PMPC_OK) {   // nothing of a half-built context outlives the failed call
+        if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+        if (ctx->phase_cycles) (void)hipFree(ctx->phase_cycles);
+        delete ctx;
+        return st;
+    }
+    *out = ctx;
+    return PMPC_OK;
+}
+static pmpc_status create_impl(int device, void* stream, pmpc_context* ctx) {
     ctx->device = device;
     if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
     else { HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
@@ -124,7 +137,6 @@ pmpc_status pmpc_create(int device, void* stream, pmpc_context** out) {
     { const char* e = getenv("PMPC_SQP_SLICE"); if (e && e[0]) ctx->sqp_slice = atoi(e) < 0 ? 0 : atoi(e); }
     { const char* e = getenv("PMPC_PHASE_PROFILE");
       if (e && e[0] == '1') { HIPCHK(hipMalloc((void**)&ctx->phase_cycles, 24 * sizeof(unsigned long long))); HIPCHK(hipMemset(ctx->phase_cycles, 0, 24 * sizeof(unsigned long long))); } }
-    *out = ctx;
     return PMPC_OK;
 }
 pmpc_status pmpc_destroy(pmpc_context* ctx) {
@@ -380,8 +392,22 @@ pmpc_status pmpc_ocp_linearise_batch(pmpc_context* ctx, int model, int P, int S,
                                      int n_mparams, int B, const double* var, const double* d, const double* lam, double* cost,
                                      double* constr, double* jac, double* cost_grad, double* lag_grad, double* lag_hess) {
     if (!ctx || B < 1 || !var) return PMPC_ERR_INVALID_ARGUMENT;
+    { int nd = 0; const pmpc_status ds = pmpc_ocp_dims(model, P, S, nullptr, nullptr, nullptr, &nd, nullptr, nullptr, nullptr, nullptr);
+      if (ds != PMPC_OK) return ds;
+      if (nd > 0 && !d) return PMPC_ERR_INVALID_ARGUMENT; }
     HIPCHK(hipSetDevice(ctx->device));
     DISPATCH_MODEL(model, linearise_impl, ctx, P, S, t0, tf, mparams, n_mparams, B, var, d, lam, cost, constr, jac, cost_grad, lag_grad, lag_hess);
+}
+
+/* arguments every SQP entry point shares: the static parameters `d` are mandatory for models that have them (ND > 0), and at least one
+ * SQP iteration must be allowed (max_iter <= 0 would launch nothing and leave the outputs unwritten) */
+static pmpc_status check_sqp_args(int model, int P, int S, const double* d, const pmpc_sqp_settings* ss) {
+    int nd = 0;
+    const pmpc_status st = pmpc_ocp_dims(model, P, S, nullptr, nullptr, nullptr, &nd, nullptr, nullptr, nullptr, nullptr);
+    if (st != PMPC_OK) return st;
+    if (nd > 0 && !d) return PMPC_ERR_INVALID_ARGUMENT;
+    if (ss && ss->max_iter < 1) return PMPC_ERR_INVALID_ARGUMENT;
+    return PMPC_OK;
 }
 
 pmpc_status pmpc_sqp_solve_batch_dev(pmpc_context* ctx, int model, int P, int S, double t0, double tf, const double* mparams,
@@ -391,6 +417,7 @@ pmpc_status pmpc_sqp_solve_batch_dev(pmpc_context* ctx, int model, int P, int S,
                                      pmpc_sqp_info* info) {
     if (!ctx || B < 0 || !lbx || !ubx || !ss || !qs || !x || !lam || !info) return PMPC_ERR_INVALID_ARGUMENT;
     if (ss->regularisation != 0 && ss->regularisation != 2) return PMPC_ERR_INVALID_ARGUMENT;
+    { const pmpc_status ca = check_sqp_args(model, P, S, d, ss); if (ca != PMPC_OK) return ca; }
     if (B == 0) return PMPC_OK;
     HIPCHK(hipSetDevice(ctx->device));
     DISPATCH_MODEL(model, sqp_builtin_dev, ctx, P, S, t0, tf, mparams, n_mparams, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, x, lam, info);
@@ -420,6 +447,7 @@ pmpc_status pmpc_mpc_step_batch_dev(pmpc_context* ctx, int model, int P, int S, 
     int nx, nu, np, nd, ng, n, me, mi;
     pmpc_status st = pmpc_ocp_dims(model, P, S, &nx, &nu, &np, &nd, &ng, &n, &me, &mi);
     if (st != PMPC_OK) return st;
+    if ((nd > 0 && !d) || ss->max_iter < 1) return PMPC_ERR_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(ctx->device));
     const int m = me + mi, nn = P * S + 1, varx = nx * nn;
     hipLaunchKernelGGL(mpc_pin_initial_state_kernel, dim3((B * nx + 255) / 256), dim3(256), 0, ctx->stream, B, n, varx, nx, x0, lbx, ubx);

@@ -55,6 +55,11 @@ inline pmpc_status get_cheb(pmpc_context* ctx, int P, int S, double t0, double t
     if (it != ctx->cheb_cache.end()) { *out = it->second; return PMPC_OK; }
     ChebData cd;
     if (!make_cheb_data(P, S, t0, tf, cd)) return PMPC_ERR_UNSUPPORTED_SIZE;
+    if (ctx->cheb_cache.size() >= 64) {   // a receding-horizon caller that shifts (t0, tf) every step must not grow the cache without bound
+        HIPCHK(hipStreamSynchronize(ctx->stream));   // (kernels in flight may still read the entries)
+        for (auto& kv : ctx->cheb_cache) (void)hipFree(kv.second);
+        ctx->cheb_cache.clear();
+    }
     ChebData* dptr = nullptr;
     HIPCHK(hipMalloc((void**)&dptr, sizeof(ChebData)));
     HIPCHK(hipMemcpyAsync(dptr, &cd, sizeof(ChebData), hipMemcpyHostToDevice, ctx->stream));

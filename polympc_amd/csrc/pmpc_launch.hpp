@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : 1
         sqp.ls_side_by_side = (G >= 2 && need <= have);
     }
     pmpc_sqp_info si;
-    if (it_begin > 0) { const pmpc_sqp_info prev = info[b]; sqp.qp_iter_total = prev.qp_solver_iter; sqp.cost_log = prev.cost; }
+    if (it_begin > 0) { const pmpc_sqp_info prev = info[b]; sqp.qp_iter_total = prev.qp_solver_iter; sqp.qp_flags = prev.flags; sqp.cost_log = prev.cost; }
     sqp.solve(si, it_begin, it_end);
     if (si.status == PMPC_SQP_IN_PROGRESS && sst) for (int i = ln; i < n; i += WAVE) { sst[i] = v.lg[i]; sst[n + i] = v.step[i]; }
     for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = v.x[i];

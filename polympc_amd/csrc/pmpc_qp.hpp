@@ -627,7 +627,11 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
         }
     }
     if (iter > s.max_iter) status = PMPC_QP_MAX_ITER_EXCEEDED;
-    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info._pad = 0;
+    double worst = 0.0;   // NaN-propagating: |x| summed through max() would drop NaNs, (x - x) is 0 for finite x and NaN otherwise
+    for (int i = ln; i < n; i += WAVE) worst += fabs(w.x[i] - w.x[i]);
+    for (int i = ln; i < N; i += WAVE) worst += fabs(w.y[i] - w.y[i]);
+    const bool bad = __builtin_amdgcn_ballot_w64(worst != 0.0) != 0;
+    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info.flags = bad ? PMPC_FLAG_NONFINITE : 0;
     info.rho_estimate = rho_estimate; info.res_prim = rs.res_prim; info.res_dual = rs.res_dual;
 }
 

@@ -541,7 +541,8 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
     if (iter > s.max_iter) status = PMPC_QP_MAX_ITER_EXCEEDED;
     if (isP) { out_x[ln] = xv; out_y[MM + ln] = yv; }
     if (isC) out_y[r] = yv;
-    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info._pad = 0;
+    const bool bad = __builtin_amdgcn_ballot_w64(((xv - xv) + (yv - yv)) != 0.0) != 0;   // non-finite x or y on any lane
+    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info.flags = bad ? PMPC_FLAG_NONFINITE : 0;
     info.rho_estimate = rho_estimate; info.res_prim = res_prim; info.res_dual = res_dual;
 }
 

@@ -527,7 +527,8 @@ __device__ __forceinline__ void boxadmm_solve_reg2(const double* __restrict__ H,
         if (isP[e]) { out_x[idx[e]] = xv[e]; out_y[MM + idx[e]] = yv[e]; }
         if (isC[e]) out_y[rc[e]] = yv[e];
     }
-    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info._pad = 0;
+    const bool bad = __builtin_amdgcn_ballot_w64((((xv[0] - xv[0]) + (yv[0] - yv[0])) + ((xv[1] - xv[1]) + (yv[1] - yv[1]))) != 0.0) != 0;   // non-finite x or y
+    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info.flags = bad ? PMPC_FLAG_NONFINITE : 0;
     info.rho_estimate = rho_estimate; info.res_prim = res_prim; info.res_dual = res_dual;
 }
 

@@ -75,6 +75,7 @@ struct SqpDevice {
     __device__ __forceinline__ int mi_ct() const { if constexpr (NN > 0) return Model::NG * NNODES_CT_; else return mi; }
     double cost_log = 0.0, primal_norm = 0.0, dual_norm = 0.0, max_violation = 0.0;
     int qp_iter_total = 0;
+    int qp_flags = 0;            // OR of the QP solves' flags (PMPC_FLAG_NONFINITE)
     long long cyc[PROF ? 24 : 1] = {0};
     __device__ __forceinline__ static long long now() { if constexpr (PROF) return clock64(); else return 0; }
     __device__ __forceinline__ void acc(int i, long long dt) { if constexpr (PROF) cyc[i] += dt; }   // shader-clock cycles: 0 linearise(+BFGS) 1 QP 2 line search 3 termination 4 total 5 BFGS 6 KKT build+factor 7 QP residuals 8 ls node evaluation 9 ls scalar sums 10 first-order staging 11 second-order staging 12 first-order assembly 13 Hessian assembly 14 Lagrangian gradient 16..20 KKT inverse: row loads+staging, panel moves, sweeps, MFMA updates, final conversion 21 ls prologue (mu, grad'p) 22 ls acceptance
@@ -759,6 +760,7 @@ struct SqpDevice {
             }
         }
         qp_iter_total += qi.iter;
+        qp_flags |= qi.flags;
         if constexpr (RUIZ_COMPILED) if (ruiz) {   // unscale(p, p_lambda); unscale(m_H, m_h, m_A, ...), sqp_base.hpp:608-609 / :664-665
             ruiz_unscale_solution_wave(n, m, rz.D, rz.E, rz_c, qw.x, qw.y);
             ruiz_unscale_problem_wave(n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, rz.D, rz.E, rz_c);
@@ -801,7 +803,7 @@ struct SqpDevice {
             if (iter >= ss.max_iter) break;
             if (iter >= it_end) { status = PMPC_SQP_IN_PROGRESS; break; }
         }
-        info.iter = iter; info.qp_solver_iter = qp_iter_total; info.status = status; info._pad = 0;
+        info.iter = iter; info.qp_solver_iter = qp_iter_total; info.status = status; info.flags = qp_flags;
         info.primal_norm = primal_norm; info.dual_norm = dual_norm; info.max_violation = max_violation; info.cost = cost_log;
     }
 };

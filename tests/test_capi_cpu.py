@@ -91,3 +91,22 @@ def test_bench_rejects_a_launcher_mismatch():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_argument_validation_without_a_device():
+    """Entry points reject bad arguments before touching the GPU (so this runs on a CPU box): NULL context, and — with any non-NULL
+    context pointer never dereferenced on these paths — max_iter < 1 and a missing static-parameter array for a model with ND > 0."""
+    import ctypes as C
+    import polympc_amd as pa
+    L = pa.lib()
+    ss = pa.sqp_settings_default(); qs = pa.qp_settings_sqp_default()
+    one = (C.c_double * 64)()
+    info = (C.c_char * 48)()
+    f = L.pmpc_sqp_solve_batch_dev
+    f.restype = C.c_int
+    args = lambda ctx, d, s: (ctx, 0, 6, 1, C.c_double(0.0), C.c_double(2.0), None, 0, 1, None, None, d, one, one, None, None, C.byref(s), C.byref(qs), one, one, info)
+    fake = C.c_void_p(8)   # never dereferenced: validation precedes every use of the context
+    assert f(*args(None, one, ss)) == 1                       # PMPC_ERR_INVALID_ARGUMENT: NULL context
+    assert f(*args(fake, None, ss)) == 1                      # ND = 1 (robot) and d == NULL
+    s0 = pa.sqp_settings_default(); s0.max_iter = 0
+    assert f(*args(fake, one, s0)) == 1                       # nothing would be solved

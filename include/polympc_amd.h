@@ -67,7 +67,8 @@ typedef struct {
 #define PMPC_FLAG_NONFINITE 1
 
 /* sqp_settings_t (sqp_base.hpp:24-47) + the two override points the reference's tests use:
- * regularisation: 0 none (default hook, sqp_base.hpp:305), 2 Gershgorin shift (dense_sparse_compare.cpp:109-122)
+ * regularisation: 0 none (default hook, sqp_base.hpp:305), 1 eigenvalue mirroring (sqp_test_autodiff.cpp:29-45; Jacobi iteration in LDS, needs
+ *                 16 n^2 bytes of LDS per instance: PMPC_ERR_UNSUPPORTED_SIZE beyond that), 2 Gershgorin shift (dense_sparse_compare.cpp:109-122)
  * exact_hessian_every_iter: update_linearisation_dense_impl overridden to linearisation_dense_impl
  *                           (codegen_test.cpp:381-398) instead of damped BFGS (bfgs.hpp:23-52). */
 typedef struct {

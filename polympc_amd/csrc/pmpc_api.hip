@@ -416,7 +416,7 @@ pmpc_status pmpc_sqp_solve_batch_dev(pmpc_context* ctx, int model, int P, int S,
                                      const pmpc_sqp_settings* ss, const pmpc_qp_settings* qs, double* x, double* lam,
                                      pmpc_sqp_info* info) {
     if (!ctx || B < 0 || !lbx || !ubx || !ss || !qs || !x || !lam || !info) return PMPC_ERR_INVALID_ARGUMENT;
-    if (ss->regularisation != 0 && ss->regularisation != 2) return PMPC_ERR_INVALID_ARGUMENT;
+    if (ss->regularisation < 0 || ss->regularisation > 2) return PMPC_ERR_INVALID_ARGUMENT;
     { const pmpc_status ca = check_sqp_args(model, P, S, d, ss); if (ca != PMPC_OK) return ca; }
     if (B == 0) return PMPC_OK;
     HIPCHK(hipSetDevice(ctx->device));

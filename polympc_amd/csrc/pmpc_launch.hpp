@@ -72,6 +72,8 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : 1
         const bool carried = ss.line_search == 1 && ss.filter_state != nullptr;
         if (ln < PMPC_FILTER_STATE_DOUBLES) filt[ln] = carried ? ss.filter_state[(size_t)b * PMPC_FILTER_STATE_DOUBLES + ln] : 0.0;
     }
+    double* eigw = nullptr;   // eigenvalue-mirroring regulariser (regularisation = 1): A and V of the Jacobi iteration, 2 n^2 doubles; allocated on request only
+    if constexpr (NN == 0) { if (ss.regularisation == 1) { eigw = p; p += 2 * (size_t)n * n; } }
     ocp.stage_constants(cd);
     double* sst = slice_state ? slice_state + (size_t)b * 2 * n : nullptr;   // [previous Lagrangian gradient | previous step]
     for (int i = ln; i < n; i += WAVE) {
@@ -91,6 +93,7 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : 1
     (void)Aws;
     SqpDevice<Model, NN, MM, PROF, HU, KHBM> sqp(ocp, v, qw, K0, K0 + n, ss, qs);
     sqp.filt = filt;
+    sqp.eig = eigw;
     sqp.tr = ocp.s.fval;   // first per-node staging array: everything from here on is dead while the QP runs
     {   // side-by-side line search: G candidates x (m constraint values + NN Lagrange values) + 3 scalars each, in the same region
         const int G = WAVE / ocp.dm.NN;
@@ -112,6 +115,10 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : 1
     if constexpr (PROF) { if (phase_cycles && ln == 0) for (int i = 0; i < 24; ++i) atomicAdd(&phase_cycles[i], (unsigned long long)sqp.cyc[i]); }
 }
 // mode 0: KKT factor in LDS; 1: register-resident QP (n+m <= 64); 2: KKT factor in HBM (large instances); 3: register-resident QP, 65..112 rows
+template <class Model> inline size_t sqp_eig_lds_bytes(int P, int S, const pmpc_sqp_settings* ss) {   // regularisation = 1: Jacobi workspace
+    OcpDims<Model> dm(P, S);
+    return ss->regularisation == 1 ? 2 * (size_t)dm.n * dm.n * sizeof(double) : 0;
+}
 template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode, int qp_solver = 0) {
     OcpDims<Model> dm(P, S);
     if (mode == 0 && qp_solver == 1)
@@ -243,17 +250,17 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     if ((ss->hessian_update != 0 && ss->hessian_update != 1) || (ss->qp_solver != 0 && ss->qp_solver != 1)) return PMPC_ERR_INVALID_ARGUMENT;
     if ((ss->line_search != 0 && ss->line_search != 1) ||
         (ss->line_search == 1 && (ss->filter_max_depth < 1 || ss->filter_max_depth > PMPC_FILTER_MAX_DEPTH))) return PMPC_ERR_INVALID_ARGUMENT;
-    if (!force_lds && ss->preconditioner == 0 && ss->qp_solver == 0 && ss->line_search == 0) {   // node counts whose KKT system can fit 64 rows for small models (7 nodes: config A / D); Ruiz: LDS path
+    if (!force_lds && ss->preconditioner == 0 && ss->qp_solver == 0 && ss->line_search == 0 && ss->regularisation != 1) {   // node counts whose KKT system can fit 64 rows for small models (7 nodes: config A / D); Ruiz: LDS path
         pmpc_status rst = PMPC_OK;
         if (try_launch_reg<Model, 7>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;
         if (try_launch_reg<Model, 5>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;
         if (try_launch_reg<Model, 11>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;   // config B / the reference's P = 5, S = 2 grids: 88..110 KKT rows
     }
-    size_t lds = sqp_kernel_lds_bytes<Model>(P, S, 0, ss->qp_solver);
+    size_t lds = sqp_kernel_lds_bytes<Model>(P, S, 0, ss->qp_solver) + sqp_eig_lds_bytes<Model>(P, S, ss);
     double* Kws = nullptr;
     if (lds > lds_limit && ss->qp_solver == 1) return PMPC_ERR_UNSUPPORTED_SIZE;   // the stacked system lives in LDS only
     if (lds > lds_limit) {   // large instance: KKT factor in HBM, QP vectors over the AD staging
-        lds = sqp_kernel_lds_bytes<Model>(P, S, 2);
+        lds = sqp_kernel_lds_bytes<Model>(P, S, 2) + sqp_eig_lds_bytes<Model>(P, S, ss);
         if (lds > lds_limit || !sqp_hbm_mode_fits<Model>(P, S)) return PMPC_ERR_UNSUPPORTED_SIZE;
         st = pmpc_internal_services(ctx, P, S, t0, tf, (base + (size_t)B * BigKkt::doubles(dm.n + dm.m)) * sizeof(double), &cdv, &ws, &streamv,
                                     &lds_limit, &phase, &force_lds);

@@ -428,6 +428,55 @@ struct SqpDevice {
         wsync();
     }
 
+    // Eigenvalue mirroring, tests/solvers/sqp/sqp_test_autodiff.cpp:29-45 (the regulariser the reference's SQP tests plug into
+    // hessian_regularisation_dense_impl): H = V diag(w) V^T with every eigenvalue w <= 0 replaced by -w + 0.1, when the smallest one is not
+    // positive. The reference calls Eigen::EigenSolver; the CPU restatement — and this routine, operation for operation — uses the cyclic
+    // Jacobi method: rotations (p, q) in row-major order, t = sign(theta) / (|theta| + sqrt(theta^2 + 1)), the column pair, then the row pair,
+    // then the vector pair updated as  c a - s b,  s a + c b  (products and one add, no fma), sweeps until the sum of squares of the strict
+    // lower triangle drops below 1e-300 (at most 100). A (n x n) and V (n x n) live in LDS (`eig`, 2 n^2 doubles, allocated by the
+    // launcher only when regularisation = 1); every lane evaluates the wave-uniform scalars redundantly, the O(n) updates run one entry per lane.
+    double* eig = nullptr;
+    __device__ __forceinline__ void regularise_eig_mirror() {
+        const int ln = lane_id();
+        double* A = eig; double* V = eig + (size_t)n * n;
+        for (int e = ln; e < n * n; e += WAVE) { const int j = e / n, i = e - j * n; A[e] = Hw[(size_t)j * ldw + i]; V[e] = (i == j) ? 1.0 : 0.0; }
+        wsync();
+        for (int sweep = 0; sweep < 100; ++sweep) {
+            double off = 0.0;
+            for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) { const double a = A[i + j * n]; off += a * a; }
+            if (__builtin_amdgcn_readfirstlane((int)(off < 1e-300))) break;
+            for (int p = 0; p < n; ++p)
+                for (int q = p + 1; q < n; ++q) {
+                    const double apq = A[p + q * n];
+                    if (__builtin_amdgcn_readfirstlane((int)(fabs(apq) < 1e-300))) continue;
+                    const double theta = (A[q + q * n] - A[p + p * n]) / (2 * apq);
+                    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + ::sqrt(theta * theta + 1));
+                    const double c = 1 / ::sqrt(t * t + 1), sn = t * c;
+                    wsync();
+                    for (int k = ln; k < n; k += WAVE) { const double akp = A[k + p * n], akq = A[k + q * n]; A[k + p * n] = c * akp - sn * akq; A[k + q * n] = sn * akp + c * akq; }
+                    wsync();
+                    for (int k = ln; k < n; k += WAVE) { const double apk = A[p + k * n], aqk = A[q + k * n]; A[p + k * n] = c * apk - sn * aqk; A[q + k * n] = sn * apk + c * aqk; }
+                    for (int k = ln; k < n; k += WAVE) { const double vkp = V[k + p * n], vkq = V[k + q * n]; V[k + p * n] = c * vkp - sn * vkq; V[k + q * n] = sn * vkp + c * vkq; }
+                    wsync();
+                }
+        }
+        double mn = A[0];
+        for (int i = 1; i < n; ++i) mn = fmin(mn, A[i + i * n]);
+        if (__builtin_amdgcn_readfirstlane((int)(mn <= 0))) {
+            wsync();
+            for (int i = ln; i < n; i += WAVE) { const double w = A[i + i * n]; A[i + i * n] = (w <= 0) ? (-1 * w + 0.1) : w; }   // (the diagonal of A now holds the mirrored spectrum)
+            wsync();
+            for (int e = ln; e < n * n; e += WAVE) {
+                const int j = e / n, i = e - j * n;
+                double a = 0.0;
+                for (int k = 0; k < n; ++k) a += (V[i + k * n] * A[k + k * n]) * V[j + k * n];
+                Hw[(size_t)j * ldw + i] = a;
+            }
+            wfence();
+        }
+        wsync();
+    }
+
     // Gershgorin shift, dense_sparse_compare.cpp:109-122
     __device__ __forceinline__ void regularise_gershgorin() {
         for (int i = lane_id(); i < n; i += WAVE) {
@@ -461,6 +510,7 @@ struct SqpDevice {
             lagrangian_gradient(v.lg);
             acc(11, l2 - l1); acc(12, l3 - l2); acc(13, l4 - l3); acc(14, now() - l4);
             if (ss.regularisation == 2) regularise_gershgorin();
+            if constexpr (NN == 0) { if (ss.regularisation == 1) regularise_eig_mirror(); }   // (LDS / HBM-resident kernels only: the launcher routes this policy there)
         } else {
             // J's zeros and D entries are already in place — unless the Ruiz preconditioner scaled and unscaled the workspace around the
             // last QP (sqp_base.hpp:605-609): the round trip leaves rounding noise on every entry, and the reference rebuilds J from

@@ -667,6 +667,28 @@ def test_sqp_warm_start_and_gershgorin(ctx, oracle):
     assert np.mean(i2["status"] == pa.SQP_SOLVED) >= 0.75
 
 
+def test_sqp_eigenvalue_mirroring_regulariser(ctx, oracle):
+    """regularisation = 1 (the eigenvalue-mirroring hook of sqp_test_autodiff.cpp:29-45) on the device: exact Lagrangian Hessian every iteration
+    — indefinite along the way — mirrored by the in-LDS Jacobi iteration, against the CPU restatement's Jacobi: identical trajectories and
+    bit-identical solutions (7- and 5-node robot grids; the policy is served by the LDS-resident kernels)."""
+    from polympc_amd import workloads
+    import polympc_amd as pa
+    for P, S, B in ((6, 1, 24), (4, 1, 16)):
+        wl = workloads.robot_batch(B, P=P, S=S)
+        ss = pa.sqp_settings_default(); oss = oracle.sqp_default_settings()
+        for st in (ss, oss):
+            st.max_iter = 6; st.line_search_max_iter = 10; st.regularisation = 1; st.exact_hessian_every_iter = 1
+        x, lam, info = ctx.sqp_solve_batch(wl["model"], P, S, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
+        xo, lo, io = oracle.sqp_solve_batch(wl["model"], P, S, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, pivot=oracle.PIVOT_STATIC, threads=8)
+        _assert_same_solve(info, io, x, xo, lam, lo)
+        assert np.all(info["flags"] == 0)
+    # the Jacobi workspace is 16 n^2 bytes of LDS: a grid that does not leave room for it is refused, not mis-solved
+    wl = workloads.kite_standin_batch(1)
+    ss = pa.sqp_settings_default(); ss.max_iter = 1; ss.regularisation = 1
+    with pytest.raises(RuntimeError):
+        ctx.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], 1, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
+
+
 def test_sqp_full_size_properties(ctx):
     """BASELINE size (4096 config-A OCPs): every SOLVED instance honours the pinned initial state, the control box and
     the collocation equalities to the solver's own tolerance (checked with an independent numpy evaluation)."""

@@ -623,6 +623,39 @@ def test_sqp_cstr_config_B(ctx, oracle):
     _assert_same_solve(info, io, x, xo, lam, lo)
 
 
+def test_sqp_cstr_reference_scenario(ctx, oracle):
+    """cstr_control_test.cpp:137-183 through the C ABI (cold solve, then the warm-started solve from a moved initial state). Cold: SOLVED in 7
+    iterations, bit-identical to the restatement in the kernel's order. Warm, as the reference runs it (no regularisation of an indefinite exact
+    Hessian — ill-posed, see test_sqp_cstr_warm_start_needs_regularisation_to_be_well_posed): still bit-identical to the restatement, SOLVED as the
+    reference asserts, and the info word says whether a non-finite value went through. Warm with the Gershgorin shift: SOLVED in 4 iterations /
+    240 ADMM iterations — the counts of the Eigen-pivoted order — at the same optimum (1e-7 relative)."""
+    import polympc_amd as pa
+    from test_oracle_pins import _cstr_reference_scenario
+    n = 66
+    order = _gpu_order(oracle, 66, 44, 11)
+    for reg in (0, 2):
+        ss = pa.sqp_settings_default(); ss.max_iter = 20; ss.line_search_max_iter = 20; ss.regularisation = reg
+        oss = oracle.sqp_default_settings(); oss.max_iter = 20; oss.line_search_max_iter = 20; oss.regularisation = reg
+        lbx = np.full((1, n), -inf); ubx = np.full((1, n), inf)
+        lbx[0, 40:44] = ubx[0, 40:44] = [1.0, 0.5, 100.0, 100.0]
+        lbx[0, 44:] = np.tile([3.0, -9000.0], 11); ubx[0, 44:] = np.tile([35.0, 0.0], 11)
+        d = np.zeros((1, 1))
+        x, lam, i1 = ctx.sqp_solve_batch(pa.MODEL_CSTR, 5, 2, 0.0, 100.0, 1, d, lbx, ubx, sqp_settings=ss)
+        xo, lo, io1 = oracle.sqp_solve_batch(oracle.MODEL_CSTR, 5, 2, 0.0, 100.0, 1, d, lbx, ubx, sqp_settings=oss, pivot=order)
+        _assert_same_solve(i1, io1, x, xo, lam, lo)
+        assert i1["iter"][0] == 7 and i1["status"][0] == pa.SQP_SOLVED and i1["flags"][0] == 0
+        lbx[0, 40:44] = ubx[0, 40:44] = [1.1, 0.508, 100.5, 100.1]
+        x2, lam2, i2 = ctx.sqp_solve_batch(pa.MODEL_CSTR, 5, 2, 0.0, 100.0, 1, d, lbx, ubx, x_guess=x, lam_guess=lam, sqp_settings=ss)
+        xo2, lo2, io2 = oracle.sqp_solve_batch(oracle.MODEL_CSTR, 5, 2, 0.0, 100.0, 1, d, lbx, ubx, x_guess=xo, lam_guess=lo, sqp_settings=oss, pivot=order)
+        assert i2["iter"][0] == io2[0].iter and i2["qp_solver_iter"][0] == io2[0].qp_solver_iter and i2["status"][0] == io2[0].status == pa.SQP_SOLVED
+        assert np.array_equal(x2, xo2, equal_nan=True) and np.array_equal(lam2, lo2, equal_nan=True)
+        assert (i2["flags"][0] != 0) == (not np.isfinite(x2).all())
+        if reg == 2:
+            (_, _), (xe, ie) = _cstr_reference_scenario(oracle, oracle.PIVOT_EIGEN, regularisation=2)
+            assert (i2["iter"][0], i2["qp_solver_iter"][0]) == (ie.iter, ie.qp_solver_iter) == (4, 240) and i2["flags"][0] == 0
+            assert (np.abs(x2 - xe) / np.maximum(1.0, np.abs(xe))).max() <= 1e-7
+
+
 def test_sqp_kite_standin_config_C(ctx, oracle):
     """Config C (synthetic 13-state / 3-input stand-in, 16 nodes, n=256, m=208: 464 KKT rows): the KKT factor does not
     fit LDS, so the large-instance mode keeps it in an HBM workspace. Same algorithm, same parity bar."""
@@ -712,3 +745,56 @@ def test_sqp_full_size_properties(ctx):
     assert np.abs(X[ok, 6, :] - wl["lbx"][ok, 18:21]).max() <= 1e-3
     assert np.all(np.abs(U[ok, :, 0]) <= 1.5 + 1e-3) and np.all(np.abs(U[ok, :, 1]) <= 0.75 + 1e-3)
     assert np.all(np.isfinite(x))
+
+
+def test_sqp_full_size_properties_config_D(ctx):
+    """BASELINE size of config D (8192 robots per GPU, perturbed wheel base): the same size-independent checks as config A with each
+    instance's own parameter in the independent numpy evaluation of the dynamics."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    B = 8192
+    wl = workloads.robot_batch(B, perturb_d=True, first=5000)
+    ss = pa.sqp_settings_default(); ss.max_iter = 10; ss.line_search_max_iter = 10
+    x, lam, info = ctx.sqp_solve_batch(0, 6, 1, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
+    ok = info["status"] == pa.SQP_SOLVED
+    assert ok.mean() > 0.5 and np.all(info["flags"] == 0) and np.all(np.isfinite(x))
+    nodes, w, D = pa.chebyshev(6)
+    X = x[:, :21].reshape(B, 7, 3); U = x[:, 21:].reshape(B, 7, 2)
+    f = np.stack([U[..., 0] * np.cos(X[..., 2]) * np.cos(U[..., 1]), U[..., 0] * np.sin(X[..., 2]) * np.cos(U[..., 1]),
+                  U[..., 0] * np.sin(U[..., 1]) / wl["d"]], axis=-1)
+    viol = np.abs(np.einsum("ij,bjs->bis", D, X) - f).reshape(B, -1).max(axis=1)
+    viol = np.maximum(viol, np.maximum((wl["lbx"] - x).max(axis=1), (x - wl["ubx"]).max(axis=1)))
+    assert np.abs(viol[ok] - info["max_violation"][ok]).max() <= 1e-9 and viol[ok].max() <= 1e-3
+    assert np.all(np.abs(U[ok, :, 0]) <= 1.5 + 1e-3) and np.all(np.abs(U[ok, :, 1]) <= 0.75 + 1e-3)
+
+
+def test_sqp_full_size_properties_config_B(ctx):
+    """BASELINE size of config B (16 384 CSTR instances, 110 KKT rows, two-rows-per-lane register path): every instance SOLVED, finite, inside
+    the input box, initial state pinned, and the reported constraint violation equal to an independent numpy evaluation of the collocation
+    defects (cstr_control_test.cpp:80-96 dynamics, t_scale = 100 / (2 * 2) = 25)."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    B = 16384
+    wl = workloads.cstr_batch(B)
+    ss = pa.sqp_settings_default(); ss.max_iter = wl["max_iter"]; ss.line_search_max_iter = wl["ls_max_iter"]
+    x, lam, info = ctx.sqp_solve_batch(wl["model"], 5, 2, 0.0, 100.0, B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
+    ok = info["status"] == pa.SQP_SOLVED
+    assert ok.mean() >= 0.999 and np.all(info["flags"] == 0) and np.all(np.isfinite(x))
+    nn = 11
+    X = x[:, :4 * nn].reshape(B, nn, 4); U = x[:, 4 * nn:].reshape(B, nn, 2)
+    k1 = 1.287e12 * np.exp(-9758.3 / (273.15 + X[..., 2])); k2 = k1; k3 = 9.043e09 * np.exp(-8560.0 / (273.15 + X[..., 2]))
+    f = np.stack([(1 / 3600.0) * (U[..., 0] * (5.1 - X[..., 0]) - k1 * X[..., 0] - k3 * X[..., 0] ** 2),
+                  (1 / 3600.0) * (-U[..., 0] * X[..., 1] + k1 * X[..., 0] - k2 * X[..., 1]),
+                  (1 / 3600.0) * (U[..., 0] * (104.9 - X[..., 2]) + (4032.0 * 0.215 / (0.9342 * 3.01 * 10.0)) * (X[..., 3] - X[..., 2])
+                                  - (1 / (0.9342 * 3.01)) * (k1 * X[..., 0] * 4.2 + k2 * X[..., 1] * (-11.0) + k3 * X[..., 0] * X[..., 1] * (-41.85))),
+                  (1 / 3600.0) * ((1 / (5.0 * 2.0)) * (U[..., 1] + 4032.0 * 0.215 * (X[..., 2] - X[..., 3])))], axis=-1)
+    nodes, w, D = pa.chebyshev(5)
+    c = np.zeros((B, nn, 4))
+    for seg in range(2):   # later segments overwrite the junction row (continuous_ocp.hpp:750-751)
+        c[:, seg * 5:seg * 5 + 6] = np.einsum("ij,bjs->bis", D, X[:, seg * 5:seg * 5 + 6]) - 25.0 * f[:, seg * 5:seg * 5 + 6]
+    viol = np.abs(c).reshape(B, -1).max(axis=1)
+    viol = np.maximum(viol, np.maximum((wl["lbx"] - x).max(axis=1), (x - wl["ubx"]).max(axis=1)))
+    assert np.abs(viol[ok] - info["max_violation"][ok]).max() <= 1e-6 * max(1.0, np.abs(viol[ok]).max()) + 1e-9
+    assert viol[ok].max() <= 1e-3
+    assert np.abs(X[ok, nn - 1, :] - wl["lbx"][ok, 4 * nn - 4:4 * nn]).max() <= 1e-3
+    assert np.all(U[ok, :, 0] >= 3.0 - 1e-3) and np.all(U[ok, :, 0] <= 35.0 + 1e-3) and np.all(U[ok, :, 1] >= -9000.0 - 1e-3) and np.all(U[ok, :, 1] <= 1e-3)

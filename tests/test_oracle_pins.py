@@ -584,6 +584,44 @@ def test_sqp_cstr(oracle):  # cstr_control_test.cpp:137-183 (Eigen pivot policy)
     assert i2[0].status == oracle.SQP_SOLVED
 
 
+def _cstr_reference_scenario(oracle, pivot, regularisation=0):
+    """cstr_control_test.cpp:137-183: cold solve from x0 = (1, 0.5, 100, 100), then a second solve warm-started from its primal / dual solution
+    with x0 = (1.1, 0.508, 100.5, 100.1)."""
+    ss = oracle.sqp_default_settings(); ss.max_iter = 20; ss.line_search_max_iter = 20; ss.regularisation = regularisation
+    n = 66
+    lbx = np.full(n, -inf); ubx = np.full(n, inf)
+    lbx[40:44] = ubx[40:44] = [1.0, 0.5, 100.0, 100.0]
+    lbx[44:] = np.tile([3.0, -9000.0], 11); ubx[44:] = np.tile([35.0, 0.0], 11)
+    d = np.zeros((1, 1))
+    x, lam, i1 = oracle.sqp_solve_batch(oracle.MODEL_CSTR, 5, 2, 0.0, 100.0, 1, d, lbx[None], ubx[None], sqp_settings=ss, pivot=pivot)
+    lbx[40:44] = ubx[40:44] = [1.1, 0.508, 100.5, 100.1]
+    x2, lam2, i2 = oracle.sqp_solve_batch(oracle.MODEL_CSTR, 5, 2, 0.0, 100.0, 1, d, lbx[None], ubx[None], x_guess=x, lam_guess=lam, sqp_settings=ss, pivot=pivot)
+    return (x, i1[0]), (x2, i2[0])
+
+
+def test_sqp_cstr_warm_start_needs_regularisation_to_be_well_posed(oracle, transcendental_functions):
+    """The second solve of cstr_control_test.cpp starts from multipliers for which the exact Lagrangian Hessian is indefinite, and the reference
+    applies no regularisation there: the first QPs run into their iteration cap with steps of size 1e4..1e30 and whether the iteration comes
+    back is decided by rounding. Measured on the restatement: with glibc's exp and the Eigen-style pivoted order (the reference's arithmetic) it
+    returns to the optimum in 6 iterations; the same order with the IEEE-only exp, the static order and the swept inverse either come back
+    (after 9-10 iterations) or overflow to NaN — after which the reference's own termination test (norms that drop NaNs) reports SOLVED.
+    What is NOT fragile, and is what a device run can be held to: the cold solve (7 iterations, 401 ADMM iterations in every order), and the
+    warm solve with the Gershgorin shift the reference uses wherever it keeps exact Hessians (dense_sparse_compare.cpp:109-122): 4 iterations,
+    240 ADMM iterations, the same optimum, in every order and with either function set."""
+    ref = None
+    for pivot in (oracle.PIVOT_EIGEN, oracle.PIVOT_STATIC, oracle.PIVOT_SWEEP2):
+        (x1, i1), (x2, i2) = _cstr_reference_scenario(oracle, pivot, regularisation=2)
+        assert (i1.iter, i1.status) == (7, oracle.SQP_SOLVED)
+        assert (i2.iter, i2.qp_solver_iter, i2.status) == (4, 240, oracle.SQP_SOLVED) and np.isfinite(x2).all()
+        ref = x2 if ref is None else ref
+        assert (np.abs(x2 - ref) / np.maximum(1.0, np.abs(ref))).max() <= 1e-7
+        (x1, i1), (x2u, i2u) = _cstr_reference_scenario(oracle, pivot, regularisation=0)
+        assert (i1.iter, i1.qp_solver_iter, i1.status) == (7, 401, oracle.SQP_SOLVED)
+        assert i2u.status == oracle.SQP_SOLVED            # the reference's assertion (:181) — met, with or without a finite iterate
+        if pivot == oracle.PIVOT_EIGEN and transcendental_functions == "glibc":
+            assert i2u.iter == 6 and np.isfinite(x2u).all() and abs(i2u.cost - 11662.3) < 1.0   # the reference's arithmetic: comes back
+
+
 def test_static_and_eigen_pivot_agree_on_config_A(oracle):
     """The two GPU-order restatements (static LDL^T, swept inverse) and Eigen's pivoted order give the same SQP trajectory
     to rounding on the benchmark configuration (H positive definite throughout)."""

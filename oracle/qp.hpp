@@ -18,6 +18,8 @@
 //                  compares the two policies on the reference's QP fixtures and on the SQP workloads).
 //   PIVOT_STATIC : identical arithmetic without the permutation, right-looking update order — the order
 //                  the HIP kernels use, so a GPU-vs-oracle comparison isolates kernel bugs from pivot effects.
+//   PIVOT_BLOCKED: PIVOT_STATIC's factor and forward substitution, backward substitution by column dot products in blocks of 16 (the blocked
+//                  tile LDL^T of pmpc_qp_big.hpp, KKT systems that live in HBM)
 //   PIVOT_SWEEP2 : PIVOT_SWEEP's blocked sweep for 65..112 rows with the mat-vec order of the two-rows-per-lane register kernel
 //   PIVOT_SWEEP1 : the swept inverse of PIVOT_SWEEP one pivot at a time on the lower triangle (any size), x = -(W b) as one fma chain
 //                  per row: accuracy evidence for the explicit-inverse route above 64 rows (no shipped kernel uses it this round).
@@ -32,7 +34,7 @@
 namespace oracle {
 
 enum qp_status { QP_SOLVED = 0, QP_MAX_ITER_EXCEEDED = 1, QP_UNSOLVED = 2, QP_UNINITIALIZED = 3, QP_INFEASIBLE = 4, QP_INCONSISTENT = 5 };
-enum pivot_policy { PIVOT_EIGEN = 0, PIVOT_STATIC = 1, PIVOT_SWEEP = 2, PIVOT_SWEEP1 = 3, PIVOT_SWEEP2 = 4 };
+enum pivot_policy { PIVOT_EIGEN = 0, PIVOT_STATIC = 1, PIVOT_SWEEP = 2, PIVOT_SWEEP1 = 3, PIVOT_SWEEP2 = 4, PIVOT_BLOCKED = 5 };
 
 struct qp_settings {  // qp_base.hpp:17-53 (ADMM-related subset)
     double eps_rel = 1e-3, eps_abs = 1e-3;
@@ -64,7 +66,7 @@ struct LDLT {
 
     void compute(const std::vector<double>& K, int n_, pivot_policy pol) {
         n = n_; policy = pol; M = K; tr.assign(n, 0); temp.assign(n, 0.0);
-        if (policy == PIVOT_STATIC) { compute_static(); return; }
+        if (policy == PIVOT_STATIC || policy == PIVOT_BLOCKED) { compute_static(); return; }
         if (policy == PIVOT_SWEEP1) { compute_sweep1(); return; }
         if (policy == PIVOT_SWEEP2) {  // the two-rows-per-lane register kernel (pmpc_qp_reg2.hpp): the same blocked sweep on 65..112 rows
             if (n > 112) throw std::invalid_argument("oracle: PIVOT_SWEEP2 restates the 112-row register kernel; use PIVOT_STATIC / PIVOT_EIGEN for larger systems");
@@ -209,6 +211,27 @@ struct LDLT {
         }
         for (int i = 0; i < n; ++i) x[i] = b[i];
         if (policy == PIVOT_EIGEN) for (int k = 0; k < n; ++k) if (tr[k] != k) std::swap(x[k], x[tr[k]]);
+        if (policy == PIVOT_BLOCKED) {
+            // The large-instance kernel (pmpc_qp_big.hpp): factor and forward substitution exactly as PIVOT_STATIC; the BACKWARD substitution reads the
+            // factor by columns — the layout the forward pass streams — instead of by rows: per block of 16 columns (descending) the contributions of
+            // the rows below the block are column dot products, summed in the kernel's order — 64 partial sums per column (row r of the rows below goes
+            // to partial (r - 16(J+1)) mod 64, rows ascending, fma), the partials added in index order — subtracted once, then the 16 x 16 triangle of the
+            // block as in PIVOT_STATIC. (Halves the factor traffic of an ADMM iteration: no second, row-ordered copy of L is read.)
+            for (int j = 0; j < n; ++j) for (int i = j + 1; i < n; ++i) x[i] = std::fma(-at(i, j), x[j], x[i]);
+            for (int i = 0; i < n; ++i) x[i] = x[i] / at(i, i);
+            const int nb = (n + 15) / 16;
+            for (int J = nb - 1; J >= 0; --J) {
+                const int lo = 16 * J, hi = std::min(lo + 16, n), below = 16 * (J + 1);
+                for (int c = lo; c < hi; ++c) {
+                    double P[64]; for (int l = 0; l < 64; ++l) P[l] = 0.0;
+                    for (int r = below; r < n; ++r) P[(r - below) & 63] = std::fma(at(r, c), x[r], P[(r - below) & 63]);
+                    double sum = 0.0; for (int l = 0; l < 64; ++l) sum += P[l];
+                    x[c] = x[c] - sum;
+                }
+                for (int j = hi - 1; j >= lo; --j) for (int i = j - 1; i >= lo; --i) x[i] = std::fma(-at(j, i), x[j], x[i]);
+            }
+            return;
+        }
         if (policy == PIVOT_STATIC) {
             // column-oriented forward substitution, fma order of the HIP kernel
             for (int j = 0; j < n; ++j) for (int i = j + 1; i < n; ++i) x[i] = std::fma(-at(i, j), x[j], x[i]);

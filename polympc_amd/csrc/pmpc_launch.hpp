@@ -27,6 +27,12 @@ template <int NKKT> constexpr int reg_qp_staging() {
     else return RegKkt2<NKKT>::TRI;
 }
 
+// large-instance mode: per-instance HBM scratch (doubles) behind the factor workspace — SQP vectors, per-node AD staging, QP vectors
+template <class Model> __host__ __device__ inline size_t big_scratch_doubles(int P, int S) {
+    OcpDims<Model> dm(P, S);
+    return SqpLds::doubles(dm.n, dm.m, dm.mi) + OcpLds<Model>::doubles(P, S) + QpLds::doubles_rest(dm.n, dm.m) + 8;
+}
+
 // KHBM: large-instance mode of the LDS-resident kernels — the KKT factor lives in an HBM workspace (Kws). A compile-time flag so
 // that in the normal mode every QP pointer provably addresses LDS (ds_read / ds_write instead of flat accesses, which cost the
 // LDS path most of its time when the location of K was a run-time choice)
@@ -52,16 +58,30 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : 1
     Ocp<Model> ocp(model, P, S, cd->t_scale);
     const int n = ocp.dm.n, m = ocp.dm.m, mi = ocp.dm.mi;
     QpLds qw; SqpLds v;
-    // Kws != nullptr: large-instance mode — the KKT factor lives in an HBM workspace (does not fit LDS)
-    double* p = (NN > 0 || KHBM) ? qw.carve_xy(smem, n, m) : qw.carve(smem, n, ss.qp_solver == 1 ? m + n : m);   // ADMM: stacked constraint rows
-    p = v.carve(p, n, m, mi);
-    double* stage0 = p;
-    p = ocp.s.carve(p, P, S);
-    if (NN > 0 && (size_t)(p - stage0) < (size_t)reg_qp_staging<NN + MM>() + ocp.s.const_doubles(P, S)) p = stage0 + reg_qp_staging<NN + MM>() + ocp.s.const_doubles(P, S);
-    const double* stage_end = p;   // end of the per-node staging block: what follows (static parameters, filter) stays live during the line search
-    // large-instance mode: the remaining QP vectors reuse the second-order AD staging (dead while the QP runs)
-    if constexpr (NN == 0 && KHBM) qw.carve_rest(ocp.s.Lhes, n, m, Kws + (size_t)b * BigKkt::doubles(n + m));
-    if constexpr (NN == 0 && KHBM) { qw.big_lds = p; p += BigKkt::LDS_DOUBLES; }   // diagonal tile + broadcast slots of the blocked factorisation
+    // KHBM, large-instance mode: the KKT factor lives in an HBM workspace, and so does everything else except the vectors the substitutions
+    // hammer (the QP solution x / y and the right-hand side): the SQP vectors (20 of length n or n+m), the per-node AD staging and the remaining
+    // QP vectors go to a per-instance scratch region behind the factor. With them in LDS one instance took 157 KB — ONE wavefront per CU, three
+    // SIMDs of four idle (config C: 256 instances in flight, four rounds); now a CU holds one instance per SIMD.
+    double* p; double* stage0; const double* stage_end;
+    if constexpr (NN == 0 && KHBM) {
+        p = qw.carve_xy(smem, n, m);
+        double* rhsL = p; p += n + m;
+        qw.big_lds = p; p += BigKkt::LDS_DOUBLES;   // diagonal tile + broadcast slots of the blocked factorisation
+        double* Wb = Kws + (size_t)b * (BigKkt::doubles(n + m) + big_scratch_doubles<Model>(P, S));
+        double* hq = Wb + BigKkt::doubles(n + m);
+        hq = v.carve(hq, n, m, mi);
+        stage0 = hq;
+        hq = ocp.s.carve(hq, P, S);
+        stage_end = hq;
+        qw.carve_rest_split(hq, rhsL, n, m, Wb);
+    } else {
+        p = (NN > 0) ? qw.carve_xy(smem, n, m) : qw.carve(smem, n, ss.qp_solver == 1 ? m + n : m);   // ADMM: stacked constraint rows
+        p = v.carve(p, n, m, mi);
+        stage0 = p;
+        p = ocp.s.carve(p, P, S);
+        if (NN > 0 && (size_t)(p - stage0) < (size_t)reg_qp_staging<NN + MM>() + ocp.s.const_doubles(P, S)) p = stage0 + reg_qp_staging<NN + MM>() + ocp.s.const_doubles(P, S);
+        stage_end = p;   // end of the per-node staging block: what follows (static parameters, filter) stays live during the line search
+    }
     double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
     const int ln = lane_id();
     for (int i = ln; i < Model::ND; i += WAVE) dL[i] = d[(size_t)b * Model::ND + i];
@@ -125,6 +145,8 @@ template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode
         return (QpLds::doubles(dm.n, dm.m + dm.n) + SqpLds::doubles(dm.n, dm.m, dm.mi) + OcpLds<Model>::doubles(P, S) + 8 + FILTER_LDS_DOUBLES) * sizeof(double);
     size_t stage = OcpLds<Model>::doubles(P, S);
     if (mode == 1) { const size_t need = (size_t)RegKkt<64>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
+    if (mode == 2)   // large instances: x, y, the right-hand side of the substitutions and the factorisation's diagonal tile; everything else in HBM
+        return (QpLds::doubles_xy(dm.n, dm.m) + (size_t)(dm.n + dm.m) + BigKkt::LDS_DOUBLES + (Model::ND > 0 ? Model::ND : 1) + FILTER_LDS_DOUBLES + 8) * sizeof(double);
     if (mode == 3) { const size_t need = (size_t)RegKkt2<112>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
     return ((mode == 0 ? QpLds::doubles(dm.n, dm.m) : QpLds::doubles_xy(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8 +
             ((mode == 1 || mode == 3) ? 0 : FILTER_LDS_DOUBLES) + (mode == 2 ? BigKkt::LDS_DOUBLES : 0)) * sizeof(double);
@@ -261,8 +283,8 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     if (lds > lds_limit && ss->qp_solver == 1) return PMPC_ERR_UNSUPPORTED_SIZE;   // the stacked system lives in LDS only
     if (lds > lds_limit) {   // large instance: KKT factor in HBM, QP vectors over the AD staging
         lds = sqp_kernel_lds_bytes<Model>(P, S, 2) + sqp_eig_lds_bytes<Model>(P, S, ss);
-        if (lds > lds_limit || !sqp_hbm_mode_fits<Model>(P, S)) return PMPC_ERR_UNSUPPORTED_SIZE;
-        st = pmpc_internal_services(ctx, P, S, t0, tf, (base + (size_t)B * BigKkt::doubles(dm.n + dm.m)) * sizeof(double), &cdv, &ws, &streamv,
+        if (lds > lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;
+        st = pmpc_internal_services(ctx, P, S, t0, tf, (base + (size_t)B * (BigKkt::doubles(dm.n + dm.m) + big_scratch_doubles<Model>(P, S))) * sizeof(double), &cdv, &ws, &streamv,
                                     &lds_limit, &phase, &force_lds);
         if (st != PMPC_OK) return st;
         Hws = ws; Aws = ws + (size_t)B * dm.n * dm.n; slice_state = Aws + (size_t)B * dm.m * dm.n; Kws = ws + base;

@@ -146,6 +146,13 @@ struct QpLds {
         z = p; p += m; zt = p; p += m; zprev = p; p += m; rho = p; p += m; rhoinv = p; p += m;
         rhob = p; p += n; rhobinv = p; p += n; rhs = p; p += N; t1 = p; p += N; t2 = p; p += N;
     }
+    // large-instance mode, round 2: as carve_rest with the right-hand side of the substitutions in LDS and the other vectors wherever `p` points (HBM)
+    __device__ __forceinline__ void carve_rest_split(double* p, double* rhs_lds, int n, int m, double* K_hbm) {
+        N = n + m; K = K_hbm;
+        q = p; p += n; kdiag = p; p += N;
+        z = p; p += m; zt = p; p += m; zprev = p; p += m; rho = p; p += m; rhoinv = p; p += m;
+        rhob = p; p += n; rhobinv = p; p += n; rhs = rhs_lds; t1 = p; p += N; t2 = p; p += N;
+    }
     __device__ __forceinline__ double* carve(double* base, int n, int m) {
         N = n + m;
         double* p = base;

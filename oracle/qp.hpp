@@ -215,7 +215,7 @@ struct LDLT {
             // The large-instance kernel (pmpc_qp_big.hpp): factor and forward substitution exactly as PIVOT_STATIC; the BACKWARD substitution reads the
             // factor by columns — the layout the forward pass streams — instead of by rows: per block of 16 columns (descending) the contributions of
             // the rows below the block are column dot products, summed in the kernel's order — 64 partial sums per column (row r of the rows below goes
-            // to partial (r - 16(J+1)) mod 64, rows ascending, fma), the partials added in index order — subtracted once, then the 16 x 16 triangle of the
+            // to partial (r - 16(J+1)) mod 64, rows ascending, fma), the partials added in four groups of 16 (index order inside a group, (S0+S1)+(S2+S3) across) — subtracted once, then the 16 x 16 triangle of the
             // block as in PIVOT_STATIC. (Halves the factor traffic of an ADMM iteration: no second, row-ordered copy of L is read.)
             for (int j = 0; j < n; ++j) for (int i = j + 1; i < n; ++i) x[i] = std::fma(-at(i, j), x[j], x[i]);
             for (int i = 0; i < n; ++i) x[i] = x[i] / at(i, i);
@@ -225,7 +225,9 @@ struct LDLT {
                 for (int c = lo; c < hi; ++c) {
                     double P[64]; for (int l = 0; l < 64; ++l) P[l] = 0.0;
                     for (int r = below; r < n; ++r) P[(r - below) & 63] = std::fma(at(r, c), x[r], P[(r - below) & 63]);
-                    double sum = 0.0; for (int l = 0; l < 64; ++l) sum += P[l];
+                    double S[4];   // four groups of 16 partials, each added in index order, combined as (S0 + S1) + (S2 + S3)
+                    for (int k = 0; k < 4; ++k) { double a = 0.0; for (int u = 0; u < 16; ++u) a += P[16 * k + u]; S[k] = a; }
+                    const double sum = (S[0] + S[1]) + (S[2] + S[3]);
                     x[c] = x[c] - sum;
                 }
                 for (int j = hi - 1; j >= lo; --j) for (int i = j - 1; i >= lo; --i) x[i] = std::fma(-at(j, i), x[j], x[i]);

@@ -4,17 +4,17 @@
 // (box_admm.hpp:209-223), factorise_kkt_matrix (:336-341, Eigen::LDLT) and linear_solver.solve (:123). Same arithmetic as the
 // static-order right-looking LDL^T of pmpc_qp.hpp — every entry receives  a_ij <- fma(-c_ik, l_jk, a_ij)  for k ascending with the
 // UNSCALED column entry c_ik and the scaled l_jk = c_jk / d_k, the substitutions are the column-oriented fma chains, pivot order 0..N-1 —
-// so the CPU restatement is the same PIVOT_STATIC and the results are bit-identical to the unblocked kernels. What changes is the
-// schedule and the data layout:
+// and the CPU restatement (PIVOT_BLOCKED) shares PIVOT_STATIC's factorisation and forward pass. What changes is the schedule and the data layout:
 //   * the WORKING matrix lives in HBM as 16 x 16 row-major tiles of the lower block triangle, tile (I, J) at I(I+1)/2 + J (Lr: an MFMA
 //     accumulator tile is four coalesced 512-byte loads). The unblocked kernel streamed the packed trailing triangle once per PIVOT
 //     (270 MB per factorisation at 464 rows); here a trailing tile is read and written once per 16 pivots (27 MB).
-//   * the finished FACTOR is written twice, in the two layouts the substitutions stream with one lane per row and every load instruction a
-//     contiguous 512-byte segment: LF — per block column J the 16 columns of L below (and including) the diagonal tile, each column
-//     contiguous over the rows (forward substitution: instruction c loads L(row, 16J + c) for 64 consecutive rows; it is also the B operand
-//     of the trailing update) — and LB — per block row J its 16 rows of L, each row contiguous over the columns (backward substitution:
-//     instruction c loads L(16J + c, i) for 64 consecutive i). Per-lane contiguous 128-byte rows of tiles, the first layout tried, kept the
-//     texture-address unit busy with 64 different cache lines per instruction: 2.5 TB/s.
+//   * the finished FACTOR is written once, as column panels LF — per block column J the 16 columns of L below (and including) the diagonal tile,
+//     each column contiguous over the rows, in slabs of 64 rows: with one lane per row every load instruction is a contiguous 512-byte segment.
+//     The forward substitution streams it (instruction c loads L(row, 16J + c) for 64 consecutive rows), it is the B operand of the trailing
+//     update, and the BACKWARD substitution streams the same panels: the contributions of the rows below a block are column dot products
+//     (per-lane partial sums, combined in a fixed order) instead of the row-oriented fma chains, which need a second, row-ordered copy of L and
+//     twice the traffic per ADMM iteration (measured with that copy: 195 GB per launch, 99 GB of it in the substitutions). The summation order of
+//     the backward pass is therefore its own restated policy, PIVOT_BLOCKED; factor and forward pass are PIVOT_STATIC's operation for operation.
 //   * block column k: the diagonal tile is factorised by 16 lanes (pivot values broadcast with v_readlane), every row below applies the
 //     16 pivots to its own 16 entries independently (one lane per row, the diagonal tile's d and l through LDS), then every trailing tile
 //     gets ONE rank-16 update on the matrix cores: four v_mfma_f64_16x16x4_f64 (a k-ascending fma chain per entry — verified on gfx950,
@@ -40,19 +40,18 @@ struct BigKkt {
     // load instructions of one lane-per-row slot sweep ONE contiguous 8 KB region (sixteen 512-byte pieces a panel-column apart kept one DRAM
     // row per piece open).
     //   LF, block column J: rel = row - 16J, c = column - 16J, (NPAD - 16J) rows padded to a multiple of 64; panels in J order
-    //   LB, block row J:    rel = column i,  c = row - 16J,    16(J+1) columns padded to a multiple of 64; panels in J order
     __host__ __device__ static size_t sizeF(int J, int NPAD) { return (size_t)16 * (((NPAD - 16 * J) + 63) / 64 * 64); }
     __host__ __device__ static size_t sizeB(int J) { return (size_t)16 * ((16 * (J + 1) + 63) / 64 * 64); }
     __host__ __device__ static size_t ceil4_sum(int t) { const int Q = t >> 2, R = t & 3; return (size_t)(Q + 1) * (2 * Q + R); }   // sum_{u=1..t} ceil(u / 4)
     __host__ __device__ static size_t offB(int J) { return 1024 * ceil4_sum(J); }                                    // sizeB(j) = 1024 ceil((j+1)/4)
     __host__ __device__ static size_t offF(int J, int NPAD) { const int nb = NPAD >> 4; return 1024 * (ceil4_sum(nb) - ceil4_sum(nb - J)); }   // sizeF(j) = 1024 ceil((nb-j)/4)
     __host__ __device__ static size_t slab(int c, int rel) { return (size_t)(rel >> 6) * 1024 + (size_t)c * 64 + (rel & 63); }
-    // per-instance HBM workspace (doubles): [Lr working tiles | LF forward panels | LB backward panels | -C strip (16 x Npad, k-major)]
+    // per-instance HBM workspace (doubles): [Lr working tiles | LF column panels | -C strip (16 x Npad, k-major)]
     __host__ __device__ static size_t doubles(int N) {
         const int nb = nblk(N);
-        return (size_t)ntiles(N) * 256 + offF(nb, nb * 16) + offB(nb) + (size_t)TB * nb * TB;
+        return (size_t)ntiles(N) * 256 + offF(nb, nb * 16) + (size_t)TB * nb * TB;
     }
-    static constexpr int LDS_DOUBLES = 256 + 16;                    // diagonal tile (d on the diagonal, l below) + 16 broadcast slots
+    static constexpr int LDS_DOUBLES = 256 + 16 + 16 * 64 + 64;     // diagonal tile (d on the diagonal, l below) + 16 slots + the backward pass's partial sums (16 x 64) and group sums (4 x 16)
 };
 
 using big_d4 = double __attribute__((ext_vector_type(4)));
@@ -90,8 +89,7 @@ __device__ __forceinline__ void big_factor(double* W, int N, double* dl) {
     const size_t nt = (size_t)BigKkt::ntiles(N);
     double* Lr = W;
     double* LF = W + nt * 256;
-    double* LB = LF + BigKkt::offF(nb, NPAD);
-    double* Cn = LB + BigKkt::offB(nb);      // -C strip: entry (t, row) at t * NPAD + row
+    double* Cn = LF + BigKkt::offF(nb, NPAD);      // -C strip: entry (t, row) at t * NPAD + row
     const int lr = ln >> 4, lc = ln & 15;
     size_t oF = 0;
     for (int k = 0; k < nb; oF += BigKkt::sizeF(k, NPAD), ++k) {
@@ -117,9 +115,8 @@ __device__ __forceinline__ void big_factor(double* W, int N, double* dl) {
                 a[t] = (r > t) ? l : a[t];
             }
             if (ln < 16) {
-                double* pB = LB + BigKkt::offB(k);
 #pragma unroll
-                for (int c = 0; c < 16; ++c) { pF[BigKkt::slab(c, r)] = a[c]; pB[BigKkt::slab(r, 16 * k + c)] = a[c]; dl[r * 16 + c] = a[c]; }
+                for (int c = 0; c < 16; ++c) { pF[BigKkt::slab(c, r)] = a[c]; dl[r * 16 + c] = a[c]; }
             }
             wfence();
             wsync();
@@ -145,9 +142,8 @@ __device__ __forceinline__ void big_factor(double* W, int N, double* dl) {
                 a[t] = l;
             }
             if (live) {
-                double* pB = LB + BigKkt::offB(I);
 #pragma unroll
-                for (int c = 0; c < 16; ++c) { pF[BigKkt::slab(c, row - 16 * k)] = a[c]; pB[BigKkt::slab(rr, 16 * k + c)] = a[c]; Cn[(size_t)c * NPAD + row] = cneg[c]; }
+                for (int c = 0; c < 16; ++c) { pF[BigKkt::slab(c, row - 16 * k)] = a[c]; Cn[(size_t)c * NPAD + row] = cneg[c]; }
             }
         }
         wfence();
@@ -203,7 +199,6 @@ __device__ __forceinline__ void big_solve(const double* W, int N, double* v, dou
     const int nb = BigKkt::nblk(N), NPAD = nb * 16;
     const size_t nt = (size_t)BigKkt::ntiles(N);
     const double* LF = W + nt * 256;
-    const double* LB = LF + BigKkt::offF(nb, NPAD);
 #ifndef PMPC_BIG_GS
 #define PMPC_BIG_GS 4
 #endif
@@ -256,19 +251,56 @@ __device__ __forceinline__ void big_solve(const double* W, int N, double* v, dou
         v[i] = v[i] / LF[BigKkt::offF(I, NPAD) + BigKkt::slab(r, r)];
     }
     wsync();
-    // ---- backward: blocks descending; inside a block columns descending
-    size_t oB = BigKkt::offB(nb);
+    // ---- backward, from the SAME column panels (no row-ordered copy of L is read): per block of 16 columns, descending, the contributions of
+    // the rows below the block are column dot products — every lane keeps one partial sum per column over its rows (row 16(J+1) + 64 g + lane,
+    // g ascending, fma); the 64 partials of a column are added in four groups of 16 (lane (c, k) adds group k of column c in index order), the
+    // group sums as (S0 + S1) + (S2 + S3) — subtracted once; then the block's own triangle, columns descending. (CPU restatement: PIVOT_BLOCKED.)
+    constexpr int GB = 2;     // row slots in flight (16 running sums per lane on top of the loaded entries)
+    double* red = bx + 16;    // 16 x 64 partial sums
+    double* grp = red + 1024; // 4 x 16 group sums
+    size_t oFb = BigKkt::offF(nb, NPAD);
     for (int J = nb - 1; J >= 0; --J) {
-        oB -= BigKkt::sizeB(J);
-        const double* pB = LB + oB;
-        double xj[16];
-        {
-            const int r = ln & 15;
-            const int row = 16 * J + r;
-            double lcol[16];   // column r of the diagonal tile: L(16J + c, 16J + r), c = 0..15
+        oFb -= BigKkt::sizeF(J, NPAD);
+        const double* pF = LF + oFb;
+        double acc[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) lcol[c] = pB[BigKkt::slab(c, 16 * J + r)];
+        for (int c = 0; c < 16; ++c) acc[c] = 0.0;
+        for (int row0 = 16 * (J + 1); row0 < NPAD; row0 += GB * WAVE) {
+            double L[GB][16], xr[GB];
+#pragma unroll
+            for (int g = 0; g < GB; ++g) {
+                const int row = row0 + g * WAVE + ln;
+                const int rw = (row < NPAD) ? row : NPAD - 1;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) L[g][c] = pF[BigKkt::slab(c, rw - 16 * J)];
+                xr[g] = (row < N) ? v[row] : 0.0;
+            }
+#pragma unroll
+            for (int g = 0; g < GB; ++g)
+#pragma unroll
+                for (int c = 0; c < 16; ++c) acc[c] = fma(L[g][c], xr[g], acc[c]);   // (rows beyond the matrix carry x = 0: the sum is unchanged)
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) red[c * 64 + ln] = acc[c];
+        wsync();
+        const int r = ln & 15, kq = ln >> 4;
+        {
+            double t[16], a = 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = red[r * 64 + 16 * kq + u];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a += t[u];
+            grp[kq * 16 + r] = a;
+        }
+        wsync();
+        {
+            const int row = 16 * J + r;
+            const double sum = (grp[r] + grp[16 + r]) + (grp[32 + r] + grp[48 + r]);
+            double lcol[16];   // column r of the diagonal tile: L(16J + c, 16J + r), c = 0..15 — contiguous in the column panel
+#pragma unroll
+            for (int c = 0; c < 16; ++c) lcol[c] = pF[BigKkt::slab(r, c)];
             double xr = (row < N) ? v[row] : 0.0;
+            xr = xr - sum;
 #pragma unroll
             for (int c = 15; c > 0; --c) {
                 const double xc = bcast_lane(xr, c);
@@ -276,26 +308,6 @@ __device__ __forceinline__ void big_solve(const double* W, int N, double* v, dou
                 xr = (r < c) ? up : xr;
             }
             if (ln < 16 && row < N) v[row] = xr;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) xj[c] = bcast_lane(xr, c);
-        }
-        for (int row0 = 0; row0 < 16 * J; row0 += GS * WAVE) {
-            double L[GS][16], vi[GS];
-#pragma unroll
-            for (int g = 0; g < GS; ++g) {
-                const int row = row0 + g * WAVE + ln;
-                const int rw = (row < 16 * J) ? row : 0;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) L[g][c] = pB[BigKkt::slab(c, rw)];   // L(16J + c, rw)
-                vi[g] = v[rw];
-            }
-#pragma unroll
-            for (int g = 0; g < GS; ++g) {
-                const int row = row0 + g * WAVE + ln;
-#pragma unroll
-                for (int c = 15; c >= 0; --c) vi[g] = fma(-L[g][c], xj[c], vi[g]);
-                if (row < 16 * J) v[row] = vi[g];
-            }
         }
         wsync();
     }

@@ -26,9 +26,11 @@ def _mat(Hc, n, m=None):
 
 
 def _lds_order(oracle, rows):
-    """The LDS- and HBM-resident kernels (boxADMM above 64 KKT rows or with a policy the register path does not carry, the stacked
-    system of the OSQP-form ADMM): static right-looking LDL^T with fma substitutions, whatever the size."""
-    return oracle.PIVOT_STATIC
+    """The LDS-resident kernels (boxADMM above 64 KKT rows without a register specialisation, every policy the register paths do not carry, the
+    stacked system of the OSQP-form ADMM): static right-looking LDL^T with fma substitutions (PIVOT_STATIC). Systems whose packed triangle does not
+    fit LDS (above ~190 rows: config C) run the blocked tile LDL^T in HBM: same factor and forward pass, backward pass by column dot products
+    (PIVOT_BLOCKED)."""
+    return oracle.PIVOT_BLOCKED if rows > 190 else oracle.PIVOT_STATIC
 
 
 REG2_QP_SHAPES = ((66, 44), (55, 33))   # QP entry point: two-rows-per-lane register specialisations (pmpc_qp_reg2.hip)

@@ -24,7 +24,7 @@ def order_for(n, m, nodes, kw):
         return ob.PIVOT_SWEEP
     if 64 < n + m <= 112 and nodes == 11:
         return ob.PIVOT_SWEEP2
-    return ob.PIVOT_STATIC
+    return ob.PIVOT_BLOCKED if n + m > 190 else ob.PIVOT_STATIC
 
 
 def probe(ctx, name, wl, B, **kw):

@@ -51,7 +51,7 @@ struct BigKkt {
         const int nb = nblk(N);
         return (size_t)ntiles(N) * 256 + offF(nb, nb * 16) + (size_t)TB * nb * TB;
     }
-    static constexpr int LDS_DOUBLES = 256 + 16 + 16 * 64 + 64;     // diagonal tile (d on the diagonal, l below) + 16 slots + the backward pass's partial sums (16 x 64) and group sums (4 x 16)
+    static constexpr int LDS_DOUBLES = 256 + 16 + 16 * 65 + 64;     // diagonal tile (d on the diagonal, l below) + 16 slots + the backward pass's partial sums (16 columns, stride 65: the group sums read 16 columns at once) and group sums (4 x 16)
 };
 
 using big_d4 = double __attribute__((ext_vector_type(4)));
@@ -256,8 +256,8 @@ __device__ __forceinline__ void big_solve(const double* W, int N, double* v, dou
     // g ascending, fma); the 64 partials of a column are added in four groups of 16 (lane (c, k) adds group k of column c in index order), the
     // group sums as (S0 + S1) + (S2 + S3) — subtracted once; then the block's own triangle, columns descending. (CPU restatement: PIVOT_BLOCKED.)
     constexpr int GB = 2;     // row slots in flight (16 running sums per lane on top of the loaded entries)
-    double* red = bx + 16;    // 16 x 64 partial sums
-    double* grp = red + 1024; // 4 x 16 group sums
+    double* red = bx + 16;    // 16 x 64 partial sums, column stride 65 (conflict-free for the column-parallel group sums)
+    double* grp = red + 16 * 65; // 4 x 16 group sums
     size_t oFb = BigKkt::offF(nb, NPAD);
     for (int J = nb - 1; J >= 0; --J) {
         oFb -= BigKkt::sizeF(J, NPAD);
@@ -281,13 +281,13 @@ __device__ __forceinline__ void big_solve(const double* W, int N, double* v, dou
                 for (int c = 0; c < 16; ++c) acc[c] = fma(L[g][c], xr[g], acc[c]);   // (rows beyond the matrix carry x = 0: the sum is unchanged)
         }
 #pragma unroll
-        for (int c = 0; c < 16; ++c) red[c * 64 + ln] = acc[c];
+        for (int c = 0; c < 16; ++c) red[c * 65 + ln] = acc[c];
         wsync();
         const int r = ln & 15, kq = ln >> 4;
         {
             double t[16], a = 0.0;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) t[u] = red[r * 64 + 16 * kq + u];
+            for (int u = 0; u < 16; ++u) t[u] = red[r * 65 + 16 * kq + u];
 #pragma unroll
             for (int u = 0; u < 16; ++u) a += t[u];
             grp[kq * 16 + r] = a;

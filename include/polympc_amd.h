@@ -53,6 +53,13 @@ typedef struct {
     int adaptive_rho;
     double adaptive_rho_tolerance;
     int adaptive_rho_interval;
+    int linear_solver;   /* boxADMM's LinearSolver template argument (box_admm.hpp:25-27, default Eigen::LDLT, helpers.hpp:38-43):
+                          * 0 (default) the static-order kernels — K is symmetric quasi-definite whenever H is positive semi-definite, so every pivot
+                          *   is non-zero without permutations; register- / LDS- / HBM-resident by size;
+                          * 1 LDL^T with Eigen::LDLT's pivoting (largest remaining |diagonal| first, D^+ solve with its zero-pivot rule), operation for
+                          *   operation the CPU restatement's Eigen-style policy; LDS-resident kernel only (PMPC_ERR_UNSUPPORTED_SIZE beyond ~190 KKT
+                          *   rows), an order of magnitude slower: for indefinite Hessians used without regularisation, and for cross-checks.
+                          * (occupies what was tail padding: the struct size is unchanged) */
 } pmpc_qp_settings;
 
 /* qp_solver_info_t (qp_base.hpp:64-72), one per instance. rho_updates counts rho_vec_update calls of THIS solve

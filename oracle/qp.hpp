@@ -216,7 +216,7 @@ struct LDLT {
             // factor by columns — the layout the forward pass streams — instead of by rows: per block of 16 columns (descending) the contributions of
             // the rows below the block are column dot products, summed in the kernel's order — 64 partial sums per column (row r of the rows below goes
             // to partial (r - 16(J+1)) mod 64, rows ascending, fma), the partials added in four groups of 16 (index order inside a group, (S0+S1)+(S2+S3) across) — subtracted once, then the 16 x 16 triangle of the
-            // block as in PIVOT_STATIC. (Halves the factor traffic of an ADMM iteration: no second, row-ordered copy of L is read.)
+            // block as in PIVOT_STATIC. (No second, row-ordered copy of L is stored or read.)
             for (int j = 0; j < n; ++j) for (int i = j + 1; i < n; ++i) x[i] = std::fma(-at(i, j), x[j], x[i]);
             for (int i = 0; i < n; ++i) x[i] = x[i] / at(i, i);
             const int nb = (n + 15) / 16;

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("PMPC_LIB") or os.path.join(HERE, "libpolympc_amd.so")
 MODEL_ROBOT, MODEL_CSTR, MODEL_PARKING, MODEL_ROBOT_NG, MODEL_KITE_STANDIN, MODEL_PARKING_NG = 0, 1, 2, 3, 4, 5
 QP_SOLVED, QP_MAX_ITER_EXCEEDED, QP_UNSOLVED = 0, 1, 2
 SQP_SOLVED, SQP_MAX_ITER_EXCEEDED = 0, 1
+FLAG_NONFINITE = 1   # pmpc_qp_info / pmpc_sqp_info flags: a non-finite value went through a QP solve
 
 EXPORTED_SYMBOLS = [
     "pmpc_version", "pmpc_status_string", "pmpc_create", "pmpc_destroy", "pmpc_synchronize", "pmpc_debug_phase_cycles",
@@ -28,7 +29,8 @@ EXPORTED_SYMBOLS = [
 class QPSettings(C.Structure):
     _fields_ = [("eps_rel", C.c_double), ("eps_abs", C.c_double), ("max_iter", C.c_int), ("rho", C.c_double),
                 ("sigma", C.c_double), ("alpha", C.c_double), ("check_termination", C.c_int),
-                ("adaptive_rho", C.c_int), ("adaptive_rho_tolerance", C.c_double), ("adaptive_rho_interval", C.c_int)]
+                ("adaptive_rho", C.c_int), ("adaptive_rho_tolerance", C.c_double), ("adaptive_rho_interval", C.c_int),
+                ("linear_solver", C.c_int)]
 
 
 class QPInfo(C.Structure):

@@ -195,7 +195,7 @@ pmpc_status pmpc_filter_state_destroy(pmpc_context* ctx, double* filter_state) {
 
 void pmpc_qp_settings_default(pmpc_qp_settings* s) {
     s->eps_rel = 1e-3; s->eps_abs = 1e-3; s->max_iter = 1000; s->rho = 1e-1; s->sigma = 1e-6; s->alpha = 1.0;
-    s->check_termination = 25; s->adaptive_rho = 0; s->adaptive_rho_tolerance = 5; s->adaptive_rho_interval = 25;
+    s->check_termination = 25; s->adaptive_rho = 0; s->adaptive_rho_tolerance = 5; s->adaptive_rho_interval = 25; s->linear_solver = 0;
 }
 void pmpc_qp_settings_sqp_default(pmpc_qp_settings* s) {
     pmpc_qp_settings_default(s);
@@ -223,13 +223,15 @@ pmpc_status pmpc_qp_boxadmm_solve_batch_dev(pmpc_context* ctx, int B, int n, int
     if ((x0 == nullptr) != (y0 == nullptr)) return PMPC_ERR_INVALID_ARGUMENT;
     if (B == 0) return PMPC_OK;
     HIPCHK(hipSetDevice(ctx->device));
-    if (n == 35 && m == 21 && !ctx->force_lds_path) {   // config A: register-resident specialisation
+    if (settings->linear_solver != 0 && settings->linear_solver != 1) return PMPC_ERR_INVALID_ARGUMENT;
+    const bool static_order = settings->linear_solver == 0 && !ctx->force_lds_path;   // the register-resident specialisations factorise in a static order
+    if (n == 35 && m == 21 && static_order) {   // config A: register-resident specialisation
         hipLaunchKernelGGL((qp_boxadmm_reg_kernel<35, 21>), dim3(B), dim3(WAVE), 0, ctx->stream, B, H, h, A, Alb, Aub, xlb, xub, x0, y0,
                            *settings, x, y, info);
         HIPCHK(hipGetLastError());
         return PMPC_OK;
     }
-    if (!ctx->force_lds_path) {   // 65..112 KKT rows with a two-rows-per-lane register specialisation (pmpc_qp_reg2.hip)
+    if (static_order) {   // 65..112 KKT rows with a two-rows-per-lane register specialisation (pmpc_qp_reg2.hip)
         const int r2 = pmpc_internal_qp_reg2_launch((void*)ctx->stream, B, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0, settings, x, y, info);
         if (r2 < 0) return PMPC_ERR_HIP;
         if (r2 > 0) return PMPC_OK;

@@ -272,7 +272,8 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     if ((ss->hessian_update != 0 && ss->hessian_update != 1) || (ss->qp_solver != 0 && ss->qp_solver != 1)) return PMPC_ERR_INVALID_ARGUMENT;
     if ((ss->line_search != 0 && ss->line_search != 1) ||
         (ss->line_search == 1 && (ss->filter_max_depth < 1 || ss->filter_max_depth > PMPC_FILTER_MAX_DEPTH))) return PMPC_ERR_INVALID_ARGUMENT;
-    if (!force_lds && ss->preconditioner == 0 && ss->qp_solver == 0 && ss->line_search == 0 && ss->regularisation != 1) {   // node counts whose KKT system can fit 64 rows for small models (7 nodes: config A / D); Ruiz: LDS path
+    if (qs->linear_solver != 0 && qs->linear_solver != 1) return PMPC_ERR_INVALID_ARGUMENT;
+    if (!force_lds && ss->preconditioner == 0 && ss->qp_solver == 0 && ss->line_search == 0 && ss->regularisation != 1 && qs->linear_solver == 0) {   // node counts whose KKT system can fit 64 rows for small models (7 nodes: config A / D); Ruiz: LDS path
         pmpc_status rst = PMPC_OK;
         if (try_launch_reg<Model, 7>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;
         if (try_launch_reg<Model, 5>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;
@@ -281,6 +282,7 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     size_t lds = sqp_kernel_lds_bytes<Model>(P, S, 0, ss->qp_solver) + sqp_eig_lds_bytes<Model>(P, S, ss);
     double* Kws = nullptr;
     if (lds > lds_limit && ss->qp_solver == 1) return PMPC_ERR_UNSUPPORTED_SIZE;   // the stacked system lives in LDS only
+    if (lds > lds_limit && qs->linear_solver == 1) return PMPC_ERR_UNSUPPORTED_SIZE;   // the pivoted factorisation lives in LDS only
     if (lds > lds_limit) {   // large instance: KKT factor in HBM, QP vectors over the AD staging
         lds = sqp_kernel_lds_bytes<Model>(P, S, 2) + sqp_eig_lds_bytes<Model>(P, S, ss);
         if (lds > lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;

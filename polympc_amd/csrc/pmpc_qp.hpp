@@ -122,12 +122,13 @@ struct QpLds {
     __host__ __device__ static int koff(int N_, int j) { return j * N_ - (j * (j + 1)) / 2; }
     __device__ __forceinline__ int off(int j) const { return j * N - (j * (j + 1)) / 2; }
     double *x, *y, *z, *q, *zt, *zprev, *rho, *rhoinv, *rhob, *rhobinv, *kdiag, *rhs, *t1, *t2;
+    double* trp = nullptr;         // transpositions of the pivoted LDL^T (linear_solver = 1), N entries stored as doubles; LDS-resident mode only
     double* big_lds = nullptr;     // large-instance mode (pmpc_qp_big.hpp): BigKkt::LDS_DOUBLES doubles of LDS; K then points at the tile workspace in HBM
     __host__ __device__ static size_t kdoubles(int N_) { return (size_t)N_ * (N_ + 1) / 2; }
     __host__ __device__ static size_t doubles(int n, int m) {
         const int N = n + m;
         return kdoubles(N) + 2 * WAVE_DUMMY /*per-lane dummy slots behind K*/ + 3 * (size_t)n /*x q kdiag(n part)*/ + (size_t)N /*y*/ + 5 * (size_t)m /*z zt zprev rho rhoinv*/ +
-               2 * (size_t)n /*rhob rhobinv*/ + (size_t)N /*rhs*/ + 2 * (size_t)N /*t1 t2*/ + (size_t)m /*kdiag m part*/ + 8;
+               2 * (size_t)n /*rhob rhobinv*/ + (size_t)N /*rhs*/ + 2 * (size_t)N /*t1 t2*/ + (size_t)m /*kdiag m part*/ + (size_t)N /*trp*/ + 8;
     }
     // register-resident QP path: only the result vectors live in LDS
     __host__ __device__ static size_t doubles_xy(int n, int m) { return 2 * (size_t)n + (size_t)m + 8; }
@@ -159,7 +160,7 @@ struct QpLds {
         K = p; p += kdoubles(N) + 2 * WAVE_DUMMY;   // K[kdoubles(N) + lane], K[kdoubles(N) + 64 + lane]: dummy slots of the branch-free factor
         x = p; p += n; q = p; p += n; kdiag = p; p += N; y = p; p += N;
         z = p; p += m; zt = p; p += m; zprev = p; p += m; rho = p; p += m; rhoinv = p; p += m;
-        rhob = p; p += n; rhobinv = p; p += n; rhs = p; p += N; t1 = p; p += N; t2 = p; p += N;
+        rhob = p; p += n; rhobinv = p; p += n; rhs = p; p += N; t1 = p; p += N; t2 = p; p += N; trp = p; p += N;
         return p;
     }
 };
@@ -534,6 +535,95 @@ __device__ __forceinline__ void rho_vec_update(const QpLds& w, int n, int m, con
     for (int i = ln; i < n; i += WAVE) { const double r = rho_of(classify_bounds(xlb[i], xub[i]), rho0); w.rhob[i] = r; w.rhobinv[i] = 1.0 / r; }
 }
 
+// ---- linear_solver = 1: LDL^T with Eigen::LDLT's diagonal pivoting, operation for operation the CPU restatement's Eigen-style policy
+// (SURVEY Appendix B): at step k the largest remaining |diagonal| (first occurrence) is swapped to position k; left-looking update
+//   temp_j = d_j l_kj,  a_kk -= sum_j l_kj temp_j,  a_ik -= sum_j l_ij temp_j  (products and adds, j ascending — no fma),  l_ik = a_ik / a_kk  (skipped for a zero pivot);
+// solve: transpositions, forward substitution (x_i -= l_ij x_j, j ascending), D^+ (entries with |d| <= 1/DBL_MAX give 0), backward substitution
+// (x_i -= l_ji x_j, j ascending from i+1: a serial chain per row — evaluated by every lane on broadcast LDS reads), transpositions back.
+// Packed lower triangle in LDS as for the static order. Slow by construction (dot-product form, serial backward pass): a policy for
+// indefinite Hessians and for cross-checks, not a fast path.
+__device__ __forceinline__ void kkt_factor_pivoted(const QpLds& w, int N) {
+    const int ln = lane_id();
+    double* K = w.K; double* temp = w.t1; double* tr = w.trp;
+    auto at = [&](int i, int j) -> double& { return K[w.off(j) + i]; };   // i >= j
+    auto swp = [](double& a, double& b) { const double t = a; a = b; b = t; };
+    for (int k = 0; k < N; ++k) {
+        // largest remaining |diagonal|, first occurrence (a NaN at position k keeps k, as the scalar loop does)
+        const double dkk = fabs(at(k, k));
+        double bv = -1.0; int bi = N;
+        for (int i = k + ln; i < N; i += WAVE) { const double v = fabs(at(i, i)); if (v > bv) { bv = v; bi = i; } }
+        const double mx = wave_max(bv);
+        int big = -(int)wave_max((bv == mx && bi < N) ? -(double)bi : -1.0e9);
+        if (dkk != dkk) big = k;
+        big = __builtin_amdgcn_readfirstlane(big);
+        if (ln == 0) tr[k] = (double)big;
+        if (big != k) {
+            for (int j = ln; j < k; j += WAVE) swp(at(k, j), at(big, j));
+            for (int i = big + 1 + ln; i < N; i += WAVE) swp(at(i, k), at(i, big));
+            if (ln == 0) swp(at(k, k), at(big, big));
+            for (int i = k + 1 + ln; i < big; i += WAVE) swp(at(i, k), at(big, i));
+        }
+        wsync();
+        if (k > 0) {
+            for (int j = ln; j < k; j += WAVE) temp[j] = at(j, j) * at(k, j);
+            wsync();
+            double acc = 0.0;
+            { int o = 0; for (int j = 0; j < k; ++j) { acc += K[o + k] * temp[j]; o += N - 1 - j; } }
+            for (int i = k + 1 + ln; i < N; i += WAVE) {
+                double a = 0.0;
+                int o = 0;
+                for (int j0 = 0; j0 < k; j0 += 8) {
+                    double e[8], t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const int j = (j0 + u < k) ? j0 + u : k - 1; e[u] = K[w.off(j) + i]; t[u] = temp[j]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) if (j0 + u < k) a += e[u] * t[u];
+                }
+                (void)o;
+                at(i, k) -= a;
+            }
+            if (ln == 0) at(k, k) -= acc;
+            wsync();
+        }
+        const double akk = at(k, k);
+        const bool valid = fabs(akk) > 0.0;
+        if (k == 0 && !valid) { for (int j = ln; j < N; j += WAVE) tr[j] = (double)j; wsync(); return; }
+        if (valid) for (int i = k + 1 + ln; i < N; i += WAVE) at(i, k) = at(i, k) / akk;
+        wsync();
+    }
+}
+__device__ __forceinline__ void kkt_solve_pivoted(const QpLds& w, int N, double* v) {
+    const int ln = lane_id();
+    const double* K = w.K; const double* tr = w.trp;
+    if (ln == 0) for (int k = 0; k < N; ++k) { const int t = (int)tr[k]; if (t != k) { const double a = v[k]; v[k] = v[t]; v[t] = a; } }
+    wsync();
+    for (int j = 0; j < N - 1; ++j) {
+        const double xj = v[j];
+        const int o = w.off(j);
+        for (int i = j + 1 + ln; i < N; i += WAVE) v[i] = v[i] - K[o + i] * xj;
+        wsync();
+    }
+    const double tol = 1.0 / 1.7976931348623157e308;
+    for (int i = ln; i < N; i += WAVE) { const double d = K[w.off(i) + i]; v[i] = (fabs(d) > tol) ? v[i] / d : 0.0; }
+    wsync();
+    for (int i = N - 2; i >= 0; --i) {   // row i: a serial chain over j = i+1 .. N-1 (every lane evaluates it on broadcast reads; lane 0 stores)
+        double a = v[i];
+        const int o = w.off(i);
+        for (int j0 = i + 1; j0 < N; j0 += 8) {
+            double e[8], x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int j = (j0 + u < N) ? j0 + u : N - 1; e[u] = K[o + j]; x[u] = v[j]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (j0 + u < N) a -= e[u] * x[u];
+        }
+        wsync();
+        if (ln == 0) v[i] = a;
+        wsync();
+    }
+    if (ln == 0) for (int k = N - 1; k >= 0; --k) { const int t = (int)tr[k]; if (t != k) { const double a = v[k]; v[k] = v[t]; v[t] = a; } }
+    wsync();
+}
+
 // large-instance linear algebra (pmpc_qp_big.hpp, included after this header by its users)
 __device__ __forceinline__ void big_build(double* W, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ A, int lda, const double* kdiag);
 __device__ __forceinline__ void big_factor(double* W, int N, double* dl);
@@ -549,6 +639,7 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
                                      pmpc_qp_info& info, long long* tm = nullptr) {   // tm (phase profiling): [0] build + factor, [1] residuals, [2] substitutions, [3] build alone
     const int ln = lane_id();
     const int N = n + m;
+    const bool pivoted = !BIG && __builtin_amdgcn_readfirstlane(s.linear_solver) == 1 && w.trp != nullptr;   // Eigen::LDLT's pivoting (LDS-resident mode only)
     auto tick = [&]() -> long long { return tm ? clock64() : 0; };
     // x = x_guess; y = y_guess; z = A*x_guess; q = x_guess  (:97-100)
     for (int i = ln; i < n; i += WAVE) { const double v = x0 ? x0[i] : 0.0; w.x[i] = v; w.q[i] = v; }
@@ -570,7 +661,7 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
     { const long long t0 = tick();
       if constexpr (BIG) big_build(w.K, n, m, H, ldh, A, lda, w.kdiag); else kkt_build(w, n, m, H, ldh, A, lda);
       const long long t1 = tick();
-      if constexpr (BIG) big_factor(w.K, N, w.big_lds); else kkt_factor(w, N);
+      if constexpr (BIG) big_factor(w.K, N, w.big_lds); else { if (pivoted) kkt_factor_pivoted(w, N); else kkt_factor(w, N); }
       if (tm) { tm[0] += tick() - t0; tm[3] += t1 - t0; } }
 
     int status = PMPC_QP_UNSOLVED;
@@ -583,7 +674,7 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
         for (int i = ln; i < n; i += WAVE) w.rhs[i] = ((s.sigma * w.x[i] - h[i]) + w.rhob[i] * w.q[i]) - w.y[m + i];
         for (int i = ln; i < m; i += WAVE) { w.zprev[i] = w.z[i]; w.rhs[n + i] = w.z[i] - w.rhoinv[i] * w.y[i]; }
         wsync();
-        { const long long t0 = tick(); if constexpr (BIG) big_solve(w.K, N, w.rhs, w.big_lds + 256); else kkt_solve(w, N, w.rhs); if (tm) tm[2] += tick() - t0; }
+        { const long long t0 = tick(); if constexpr (BIG) big_solve(w.K, N, w.rhs, w.big_lds + 256); else { if (pivoted) kkt_solve_pivoted(w, N, w.rhs); else kkt_solve(w, N, w.rhs); } if (tm) tm[2] += tick() - t0; }
         for (int i = ln; i < m; i += WAVE) {
             const double zt = w.zprev[i] + w.rhoinv[i] * (w.rhs[n + i] - w.y[i]);
             double zz = alpha * zt;
@@ -629,7 +720,7 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
                 for (int i = ln; i < m; i += WAVE) w.kdiag[n + i] = -w.rhoinv[i];
                 wsync();
                 if constexpr (BIG) { big_build(w.K, n, m, H, ldh, A, lda, w.kdiag); big_factor(w.K, N, w.big_lds); }
-                else { kkt_build(w, n, m, H, ldh, A, lda); kkt_factor(w, N); }
+                else { kkt_build(w, n, m, H, ldh, A, lda); if (pivoted) kkt_factor_pivoted(w, N); else kkt_factor(w, N); }
             }
         }
     }

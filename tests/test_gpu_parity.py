@@ -122,6 +122,48 @@ def test_qp_random_vs_oracle(ctx, oracle, n, m, B):
     assert np.abs(info["res_dual"] - [i.res_dual for i in io]).max() <= 1e-9
 
 
+@pytest.mark.parametrize("n,m,B", [(7, 3, 9), (35, 21, 16), (66, 44, 6), (20, 45, 4)])
+def test_qp_pivoted_linear_solver_vs_eigen_order(ctx, oracle, n, m, B):
+    """linear_solver = 1 (Eigen::LDLT's diagonal pivoting on the device, LDS-resident kernel) against the CPU restatement's Eigen-style policy —
+    the restatement of what the reference itself runs: identical iteration counts, statuses and rho updates, bit-identical x, y and residuals."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    q = workloads.random_qp_batch(B, n, m, seed=n * 1000 + m + 1)
+    s = pa.qp_settings_sqp_default(); s.linear_solver = 1
+    x, y, info = ctx.qp_solve_batch(q["H"], q["h"], q["A"], q["Alb"], q["Aub"], q["xlb"], q["xub"], settings=s)
+    os_ = oracle.qp_default_settings()
+    for f, _ in os_._fields_:
+        setattr(os_, f, getattr(s, f))
+    xo, yo, io = oracle.qp_solve_batch(q["H"], q["h"], q["A"], q["Alb"], q["Aub"], q["xlb"], q["xub"], settings=os_, pivot=oracle.PIVOT_EIGEN)
+    assert [int(i) for i in info["iter"]] == [i.iter for i in io] and [int(i) for i in info["status"]] == [i.status for i in io]
+    assert [int(i) for i in info["rho_updates"]] == [i.rho_updates for i in io]
+    assert np.array_equal(x, xo) and np.array_equal(y, yo)
+    assert np.array_equal(info["res_prim"], [i.res_prim for i in io]) and np.array_equal(info["res_dual"], [i.res_dual for i in io])
+
+
+def test_qp_pivoted_linear_solver_on_an_indefinite_hessian(ctx, oracle):
+    """box_admm_test.cpp:299-334 (H = -1, -1 <= x <= 2, rho = 2: a non-convex QP the reference solves to x = 2) and an indefinite 6 x 6 Hessian with a
+    zero leading entry — a zero first pivot in the static order (flagged non-finite there), factorised by the pivoted solver like the restatement."""
+    import polympc_amd as pa
+    z = np.zeros((1, 0))
+    s = pa.qp_settings_default(); s.max_iter = 200; s.adaptive_rho = 1; s.check_termination = 10; s.rho = 2; s.linear_solver = 1
+    x, y, info = ctx.qp_solve_batch(-np.ones((1, 1)), np.zeros((1, 1)), z, z, z, [[-1.0]], [[2.0]], settings=s, x0=[[0.1]], y0=[[0.1]])
+    assert abs(x[0, 0] - 2.0) <= 2e-2 and info["status"][0] == pa.QP_SOLVED
+    n = 6
+    H = np.diag([-(1e-6 + 0.1), 1.0, 2.0, 3.0, 4.0, 5.0]); H[0, 1] = H[1, 0] = 1.0     # K(0,0) = H00 + sigma + rho_box = 0 exactly
+    Hc = H.T.reshape(1, n * n).copy(); h = np.ones((1, n)); lb = -np.ones((1, n)); ub = np.ones((1, n))
+    res = {}
+    for ls in (0, 1):
+        s = pa.qp_settings_default(); s.max_iter = 50; s.check_termination = 10; s.linear_solver = ls
+        res[ls] = ctx.qp_solve_batch(Hc, h, z, z, z, lb, ub, settings=s)
+    assert res[0][2]["flags"][0] == pa.capi.FLAG_NONFINITE           # static order: zero pivot, reported
+    x1, y1, i1 = res[1]
+    assert i1["flags"][0] == 0 and np.isfinite(x1).all()
+    os_ = oracle.qp_default_settings(); os_.max_iter = 50; os_.check_termination = 10
+    xo, yo, io = oracle.qp_solve_batch(Hc, h, z, z, z, lb, ub, settings=os_, pivot=oracle.PIVOT_EIGEN)
+    assert int(i1["iter"][0]) == io[0].iter and np.array_equal(x1, xo) and np.array_equal(y1, yo)
+
+
 def test_qp_warm_start_guess(ctx, oracle):
     import polympc_amd as pa
     from polympc_amd import workloads
@@ -652,6 +694,18 @@ def test_sqp_cstr_reference_scenario(ctx, oracle):
         assert i2["iter"][0] == io2[0].iter and i2["qp_solver_iter"][0] == io2[0].qp_solver_iter and i2["status"][0] == io2[0].status == pa.SQP_SOLVED
         assert np.array_equal(x2, xo2, equal_nan=True) and np.array_equal(lam2, lo2, equal_nan=True)
         assert (i2["flags"][0] != 0) == (not np.isfinite(x2).all())
+        # the same two solves with Eigen::LDLT's pivoting on the device (linear_solver = 1): bit-identical to the Eigen-order restatement, i.e. to the
+        # restatement of what the reference binary runs — the iteration counts of PIVOT_EIGEN by construction
+        qp = pa.qp_settings_sqp_default(); qp.linear_solver = 1
+        lbx[0, 40:44] = ubx[0, 40:44] = [1.0, 0.5, 100.0, 100.0]
+        xp, lp, ip1 = ctx.sqp_solve_batch(pa.MODEL_CSTR, 5, 2, 0.0, 100.0, 1, d, lbx, ubx, sqp_settings=ss, qp_settings=qp)
+        xe1, le1, ie1 = oracle.sqp_solve_batch(oracle.MODEL_CSTR, 5, 2, 0.0, 100.0, 1, d, lbx, ubx, sqp_settings=oss, pivot=oracle.PIVOT_EIGEN)
+        _assert_same_solve(ip1, ie1, xp, xe1, lp, le1)
+        lbx[0, 40:44] = ubx[0, 40:44] = [1.1, 0.508, 100.5, 100.1]
+        xp2, lp2, ip2 = ctx.sqp_solve_batch(pa.MODEL_CSTR, 5, 2, 0.0, 100.0, 1, d, lbx, ubx, x_guess=xp, lam_guess=lp, sqp_settings=ss, qp_settings=qp)
+        xe2, le2, ie2 = oracle.sqp_solve_batch(oracle.MODEL_CSTR, 5, 2, 0.0, 100.0, 1, d, lbx, ubx, x_guess=xe1, lam_guess=le1, sqp_settings=oss, pivot=oracle.PIVOT_EIGEN)
+        assert ip2["iter"][0] == ie2[0].iter and ip2["qp_solver_iter"][0] == ie2[0].qp_solver_iter and ip2["status"][0] == ie2[0].status == pa.SQP_SOLVED
+        assert np.array_equal(xp2, xe2, equal_nan=True) and np.array_equal(lp2, le2, equal_nan=True)
         if reg == 2:
             (_, _), (xe, ie) = _cstr_reference_scenario(oracle, oracle.PIVOT_EIGEN, regularisation=2)
             assert (i2["iter"][0], i2["qp_solver_iter"][0]) == (ie.iter, ie.qp_solver_iter) == (4, 240) and i2["flags"][0] == 0

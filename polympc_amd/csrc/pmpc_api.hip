@@ -133,6 +133,7 @@ static pmpc_status create_impl(int device, void* stream, pmpc_context* ctx) {
     HIPCHK(hipGetDeviceProperties(&prop, device));
     ctx->lds_limit = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 64 * 1024;
     if (prop.sharedMemPerBlockOptin && (size_t)prop.sharedMemPerBlockOptin < ctx->lds_limit) ctx->lds_limit = prop.sharedMemPerBlockOptin;
+    { const char* e = getenv("PMPC_LDS_LIMIT"); if (e && e[0] && atol(e) > 0 && (size_t)atol(e) < ctx->lds_limit) ctx->lds_limit = (size_t)atol(e); }   // developer switch: a smaller LDS budget (moves mid-size instances to the HBM-factor kernel)
     { const char* e = getenv("PMPC_FORCE_LDS_PATH"); ctx->force_lds_path = (e && e[0] == '1'); }
     { const char* e = getenv("PMPC_SQP_SLICE"); if (e && e[0]) ctx->sqp_slice = atoi(e) < 0 ? 0 : atoi(e); }
     { const char* e = getenv("PMPC_PHASE_PROFILE");

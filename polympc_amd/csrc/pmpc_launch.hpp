@@ -40,7 +40,10 @@ template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bo
 #ifndef PMPC_SQP_WAVES
 #define PMPC_SQP_WAVES 2
 #endif
-__global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : 1)) void sqp_kernel(Model model, const ChebData* __restrict__ cd, int B,
+#ifndef PMPC_BIG_WAVES
+#define PMPC_BIG_WAVES 1
+#endif
+__global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (KHBM ? PMPC_BIG_WAVES : 1))) void sqp_kernel(Model model, const ChebData* __restrict__ cd, int B,
                                                  const double* __restrict__ x_guess, const double* __restrict__ lam_guess,
                                                  const double* __restrict__ d, const double* __restrict__ lbx,
                                                  const double* __restrict__ ubx, const double* __restrict__ lbg,
@@ -151,6 +154,7 @@ template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode
     return ((mode == 0 ? QpLds::doubles(dm.n, dm.m) : QpLds::doubles_xy(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8 +
             ((mode == 1 || mode == 3) ? 0 : FILTER_LDS_DOUBLES) + (mode == 2 ? BigKkt::LDS_DOUBLES : 0)) * sizeof(double);
 }
+constexpr int BIG_KKT_MIN_ROWS = 96;   // n + m from which sqp_launch_dev prefers the HBM-factor kernel (see there)
 template <class Model> inline bool sqp_hbm_mode_fits(int P, int S) {   // do the QP vectors fit the second-order staging?
     OcpDims<Model> dm(P, S);
     return QpLds::doubles_rest(dm.n, dm.m) <= 2 * (size_t)dm.NN * OcpDims<Model>::NDER * OcpDims<Model>::NDER;
@@ -283,7 +287,12 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     double* Kws = nullptr;
     if (lds > lds_limit && ss->qp_solver == 1) return PMPC_ERR_UNSUPPORTED_SIZE;   // the stacked system lives in LDS only
     if (lds > lds_limit && qs->linear_solver == 1) return PMPC_ERR_UNSUPPORTED_SIZE;   // the pivoted factorisation lives in LDS only
-    if (lds > lds_limit) {   // large instance: KKT factor in HBM, QP vectors over the AD staging
+    // Above BIG_KKT_MIN_ROWS rows the blocked tile factorisation (fp64 MFMA trailing updates, factor panels streamed from HBM / L2, 13 KB of LDS:
+    // one instance per SIMD) beats the LDS-resident triangle, whose footprint leaves one or two instances per CU — measured on robot grids, 2048
+    // instances: 104 rows 21.0 -> 18.3 ms, 128 rows (the reference's mpc_wrapper_test grid) 52.2 -> 25.3, 168 rows 247.6 -> 39.4; 72 rows 13.5 -> 17.7
+    // (stays in LDS). The stacked OSQP-form system and the pivoted factorisation exist in LDS only.
+    const bool prefer_big = dm.n + dm.m >= BIG_KKT_MIN_ROWS && ss->qp_solver == 0 && qs->linear_solver == 0 && !force_lds;
+    if (lds > lds_limit || prefer_big) {   // large instance: KKT factor in HBM, SQP / QP vectors in an HBM scratch behind it
         lds = sqp_kernel_lds_bytes<Model>(P, S, 2) + sqp_eig_lds_bytes<Model>(P, S, ss);
         if (lds > lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;
         st = pmpc_internal_services(ctx, P, S, t0, tf, (base + (size_t)B * (BigKkt::doubles(dm.n + dm.m) + big_scratch_doubles<Model>(P, S))) * sizeof(double), &cdv, &ws, &streamv,

@@ -18,6 +18,10 @@
 #include <hip/hip_runtime.h>
 #include "pmpc_qp.hpp"
 
+#ifndef PMPC_REG_RESIDUAL_BATCH
+#define PMPC_REG_RESIDUAL_BATCH 14
+#endif
+
 namespace pmpc {
 
 __device__ __forceinline__ double bcast_lane(double v, int lane) {
@@ -479,27 +483,27 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
             if (check || adapt) {  // residuals_update, box_admm.hpp:398-415
                 const long long r0 = dbg ? clock64() : 0;
                 // loads in chunks of RC columns (independent, coalesced), each followed by its slice of the mat-vec chain
-                constexpr int RC = 12;
+                // H / A row and A column in ONE list of NN + MM entries, RC at a time: the loads are L2 round trips (~2 k cycles each batch) and
+                // the two mat-vec chains keep their ascending order whatever the batching
+                constexpr int RC = PMPC_REG_RESIDUAL_BATCH;
                 int zr = 0;            // opaque zero added to the addresses: keeps these loop-invariant loads inside the loop
                 asm volatile("" : "+v"(zr));
                 double acc = 0.0;      // lanes < n: (H x)_i ; lanes in [n, N): (A x)_r
-#pragma unroll
-                for (int j0 = 0; j0 < NN; j0 += RC) {
-                    double mrow[RC];
-#pragma unroll
-                    for (int j = 0; j < RC; ++j) mrow[j] = (j0 + j < NN) ? Krow(j0 + j < NN ? j0 + j : 0, zr) : 0.0;
-#pragma unroll
-                    for (int j = 0; j < RC; ++j) if (j0 + j < NN) acc += mrow[j] * bcast_lane(xv, j0 + j);
-                    sched_fence();
-                }
                 double aty = 0.0;      // lanes < n: (A^T y_a)_i
 #pragma unroll
-                for (int k0 = 0; k0 < MM; k0 += RC) {
-                    double mcol[RC];
+                for (int e0 = 0; e0 < N; e0 += RC) {
+                    double mv[RC];
 #pragma unroll
-                    for (int k = 0; k < RC; ++k) mcol[k] = (k0 + k < MM) ? Acol((k0 + k < MM) ? k0 + k : 0, zr) : 0.0;
+                    for (int e = 0; e < RC; ++e) {
+                        const int ee = e0 + e;
+                        mv[e] = (ee < NN) ? Krow(ee < NN ? ee : 0, zr) : ((ee < N) ? Acol((ee >= NN && ee < N) ? ee - NN : 0, zr) : 0.0);
+                    }
 #pragma unroll
-                    for (int k = 0; k < RC; ++k) if (k0 + k < MM) aty += mcol[k] * bcast_lane(yv, NN + k0 + k);
+                    for (int e = 0; e < RC; ++e) {
+                        const int ee = e0 + e;
+                        if (ee < NN) acc += mv[e] * bcast_lane(xv, ee);
+                        else if (ee < N) aty += mv[e] * bcast_lane(yv, ee);
+                    }
                     sched_fence();
                 }
                 // max is exact and order-free: the maximum of several infinity norms is ONE wave reduction of the per-lane maxima

@@ -25,12 +25,15 @@ def _mat(Hc, n, m=None):
     return Hc.reshape(n if m is None else n, -1).T if m is None else Hc.reshape(n, m).T
 
 
-def _lds_order(oracle, rows):
+BIG_KKT_MIN_ROWS = 96   # pmpc_launch.hpp: from this many KKT rows the fused SQP kernel keeps its factor in HBM (blocked tile LDL^T)
+
+
+def _lds_order(oracle, rows, sqp=True):
     """The LDS-resident kernels (boxADMM above 64 KKT rows without a register specialisation, every policy the register paths do not carry, the
-    stacked system of the OSQP-form ADMM): static right-looking LDL^T with fma substitutions (PIVOT_STATIC). Systems whose packed triangle does not
-    fit LDS (above ~190 rows: config C) run the blocked tile LDL^T in HBM: same factor and forward pass, backward pass by column dot products
-    (PIVOT_BLOCKED)."""
-    return oracle.PIVOT_BLOCKED if rows > 190 else oracle.PIVOT_STATIC
+    stacked system of the OSQP-form ADMM, the QP entry point): static right-looking LDL^T with fma substitutions (PIVOT_STATIC). SQP instances of
+    96 rows and more (and everything whose packed triangle does not fit LDS: config C) run the blocked tile LDL^T with the factor in HBM: same
+    factor and forward pass, backward pass by column dot products (PIVOT_BLOCKED)."""
+    return oracle.PIVOT_BLOCKED if (sqp and rows >= BIG_KKT_MIN_ROWS) else oracle.PIVOT_STATIC
 
 
 REG2_QP_SHAPES = ((66, 44), (55, 33))   # QP entry point: two-rows-per-lane register specialisations (pmpc_qp_reg2.hip)
@@ -45,7 +48,7 @@ def _gpu_order(oracle, n, m, nodes=None):
     if nodes is None:
         if (n, m) in REG2_QP_SHAPES:
             return oracle.PIVOT_SWEEP2
-        return oracle.PIVOT_SWEEP if (n, m) == (35, 21) else _lds_order(oracle, n + m)
+        return oracle.PIVOT_SWEEP if (n, m) == (35, 21) else _lds_order(oracle, n + m, sqp=False)
     if n + m <= 64 and nodes in (5, 7):
         return oracle.PIVOT_SWEEP
     if 64 < n + m <= 112 and nodes == 11:      # SQP grids of 11 nodes (P = 5, S = 2): two-rows-per-lane register path
@@ -585,7 +588,7 @@ def test_sqp_valet_parking_as_the_reference_runs_it(ctx, oracle):
 
 
 def test_sqp_filter_line_search_batch_vs_oracle(ctx, oracle):
-    """line_search = 1 on batches of randomised robot OCPs (P=5 S=3 and config A's grid, both on the LDS-resident path), with and
+    """line_search = 1 on batches of randomised robot OCPs (P=5 S=3: 128 KKT rows, HBM-factor kernel; config A's grid on the LDS-resident path), with and
     without a carried filter: identical iteration counts, bit-identical x, lam and filter contents; a second solve from the
     first one's solution with the carried filter must again agree (the filter then holds the first solve's history)."""
     import polympc_amd as pa
@@ -597,12 +600,13 @@ def test_sqp_filter_line_search_batch_vs_oracle(ctx, oracle):
             st.max_iter = 10; st.line_search_max_iter = 10; st.line_search = 1
         handle = ctx.filter_state_create(B); ss.filter_state = handle
         ofilt = np.zeros((B, oracle.FILTER_STATE_DOUBLES)); oracle.bind_filter_state(oss, ofilt)
+        dm = oracle.ocp_dims(oracle.MODEL_ROBOT, P, S)
         try:
             xg = lg = xo = lo = None
             for rep in range(2):
                 xg, lg, info = ctx.sqp_solve_batch(pa.MODEL_ROBOT, P, S, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], x_guess=xg, lam_guess=lg, sqp_settings=ss)
                 xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, P, S, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], x_guess=xo, lam_guess=lo,
-                                                    sqp_settings=oss, pivot=oracle.PIVOT_STATIC)
+                                                    sqp_settings=oss, pivot=_lds_order(oracle, dm["n"] + dm["m"]))
                 _assert_same_solve(info, io, xg, xo, lg, lo)
                 filt = ctx.filter_state_download(B, handle)
                 assert np.array_equal(filt, ofilt)
@@ -749,8 +753,8 @@ def test_sqp_warm_start_and_gershgorin(ctx, oracle):
     lbx2[:, 45:48] -= 0.1; ubx2[:, 45:48] -= 0.1
     x2, l2, i2 = ctx.sqp_solve_batch(0, 5, 3, 0.0, 2.0, B, wl["d"], lbx2, ubx2, x_guess=x1, lam_guess=l1, sqp_settings=ss, mparams=mp)
     oss = oracle.sqp_default_settings(); oss.max_iter = 10; oss.line_search_max_iter = 10; oss.regularisation = 2
-    xo1, lo1, io1 = oracle.sqp_solve_batch(0, 5, 3, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, pivot=1, mparams=mp)
-    xo2, lo2, io2 = oracle.sqp_solve_batch(0, 5, 3, 0.0, 2.0, B, wl["d"], lbx2, ubx2, x_guess=xo1, lam_guess=lo1, sqp_settings=oss, pivot=1, mparams=mp)
+    xo1, lo1, io1 = oracle.sqp_solve_batch(0, 5, 3, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, pivot=_lds_order(oracle, 128), mparams=mp)
+    xo2, lo2, io2 = oracle.sqp_solve_batch(0, 5, 3, 0.0, 2.0, B, wl["d"], lbx2, ubx2, x_guess=xo1, lam_guess=lo1, sqp_settings=oss, pivot=_lds_order(oracle, 128), mparams=mp)
     _assert_same_solve(i1, io1, x1, xo1, l1, lo1)
     _assert_same_solve(i2, io2, x2, xo2, l2, lo2)
     assert np.mean(i2["status"] == pa.SQP_SOLVED) >= 0.75

@@ -9,7 +9,8 @@ import polympc_amd as pa
 from polympc_amd import workloads
 
 CONFIGS = {
-    "A": lambda: workloads.robot_batch(4096),
+    "A": lambda: workloads.robot_batch(int(os.environ.get("BA", 4096))),
+    "R": lambda: workloads.robot_batch(int(os.environ.get("BA", 4096)), P=int(os.environ.get("P", 5)), S=int(os.environ.get("S", 3))),   # any robot grid: P=5 S=3 -> 128 KKT rows (the reference's mpc_wrapper_test size)
     "B": lambda: workloads.cstr_batch(int(os.environ.get("BB", 16384))),
     "C": lambda: workloads.kite_standin_batch(int(os.environ.get("BC", 1024))),
     "D": lambda: workloads.robot_batch(8192, perturb_d=True),

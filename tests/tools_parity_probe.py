@@ -18,13 +18,15 @@ from oracle import binding as ob             # noqa: E402
 
 
 def order_for(n, m, nodes, kw):
-    if kw.get("qp_solver", 0) or kw.get("preconditioner", 0) or kw.get("line_search", 0):
+    if kw.get("qp_solver", 0):
         return ob.PIVOT_STATIC
+    if kw.get("preconditioner", 0) or kw.get("line_search", 0):
+        return ob.PIVOT_BLOCKED if n + m >= 96 else ob.PIVOT_STATIC
     if n + m <= 64 and nodes in (5, 7):
         return ob.PIVOT_SWEEP
     if 64 < n + m <= 112 and nodes == 11:
         return ob.PIVOT_SWEEP2
-    return ob.PIVOT_BLOCKED if n + m > 190 else ob.PIVOT_STATIC
+    return ob.PIVOT_BLOCKED if n + m >= 96 else ob.PIVOT_STATIC
 
 
 def probe(ctx, name, wl, B, **kw):

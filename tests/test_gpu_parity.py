@@ -740,6 +740,57 @@ def test_collocation_kite_standin_vs_oracle(ctx, oracle):
             assert np.abs(ev[k][b] - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), k
 
 
+def _cstr_grid(B, P, S):
+    """cstr_batch's bounds on another grid."""
+    from polympc_amd import workloads
+    nn = P * S + 1
+    n = 6 * nn
+    inst = np.arange(B, dtype=np.uint64)
+    lbx = np.full((B, n), -np.inf); ubx = np.full((B, n), np.inf)
+    for j, b in enumerate([1.0, 0.5, 100.0, 100.0]):
+        x0 = b * (1.0 + 0.05 * workloads.uniform_pm1(workloads.SEED, inst, j))
+        lbx[:, 4 * nn - 4 + j] = x0; ubx[:, 4 * nn - 4 + j] = x0
+    lbx[:, 4 * nn:] = np.tile([3.0, -9000.0], nn); ubx[:, 4 * nn:] = np.tile([35.0, 0.0], nn)
+    return lbx, ubx
+
+
+@pytest.mark.parametrize("case", ["cstr_13_nodes", "parking_16_nodes", "parking_ng_16_nodes", "robot_13_nodes_ruiz", "robot_21_nodes"])
+def test_sqp_builtin_models_on_the_hbm_factor_kernel(ctx, oracle, case):
+    """From 96 KKT rows on (and off the 11-node register grids) the fused SQP kernel keeps its factor in HBM: blocked tile LDL^T with MFMA
+    trailing updates. Every built-in model family is driven through it — CSTR on 13 nodes (130 rows), the minimal-time parking problem with
+    its free parameter on 16 nodes (129 rows; with the nonlinear path constraint 145 rows), the robot with the Ruiz preconditioner on 13 nodes
+    (104 rows) and on 21 nodes (168 rows: not a multiple of 16) — against the blocked-order CPU restatement: bit-identical."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    from test_oracle_pins import _minimal_time_parking
+    kw = dict(); okw = dict(); ss = pa.sqp_settings_default(); oss = oracle.sqp_default_settings(); B = 6
+    if case == "cstr_13_nodes":
+        model, P, S, t0, tf = pa.MODEL_CSTR, 4, 3, 0.0, 100.0
+        lbx, ubx = _cstr_grid(B, P, S); d = np.zeros((B, 1))
+        for st in (ss, oss): st.max_iter = 8; st.line_search_max_iter = 20
+    elif case in ("parking_16_nodes", "parking_ng_16_nodes"):
+        B = 1
+        model, P, S, t0, tf = (pa.MODEL_PARKING if case == "parking_16_nodes" else pa.MODEL_PARKING_NG), 5, 3, 0.0, 1.0
+        lbx, ubx, xg = _minimal_time_parking(16); d = np.array([[1.0]])
+        kw["x_guess"] = xg; okw["x_guess"] = xg
+        if case == "parking_ng_16_nodes":
+            kw["lbg"] = okw["lbg"] = np.full((1, 16), -10.0); kw["ubg"] = okw["ubg"] = np.full((1, 16), 1.2)
+        for st in (ss, oss): st.max_iter = 12; st.line_search_max_iter = 10; st.regularisation = 2; st.exact_hessian_every_iter = 1
+    else:
+        P, S = (4, 3) if case == "robot_13_nodes_ruiz" else (5, 4)
+        wl = workloads.robot_batch(B, P=P, S=S)
+        model, t0, tf, lbx, ubx, d = pa.MODEL_ROBOT, 0.0, 2.0, wl["lbx"], wl["ubx"], wl["d"]
+        for st in (ss, oss):
+            st.max_iter = 8; st.line_search_max_iter = 10
+            if case == "robot_13_nodes_ruiz": st.preconditioner = 1
+    dm = oracle.ocp_dims(model, P, S)
+    assert dm["n"] + dm["m"] >= BIG_KKT_MIN_ROWS
+    x, lam, info = ctx.sqp_solve_batch(model, P, S, t0, tf, B, d, lbx, ubx, sqp_settings=ss, **kw)
+    xo, lo, io = oracle.sqp_solve_batch(model, P, S, t0, tf, B, d, lbx, ubx, sqp_settings=oss, pivot=oracle.PIVOT_BLOCKED, **okw)
+    _assert_same_solve(info, io, x, xo, lam, lo)
+    assert np.all(info["flags"] == 0)
+
+
 def test_sqp_warm_start_and_gershgorin(ctx, oracle):
     """Second solve warm-started from the first (x, lam) with a moved initial state; Gershgorin regulariser on."""
     import polympc_amd as pa

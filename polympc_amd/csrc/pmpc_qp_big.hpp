@@ -46,10 +46,13 @@ struct BigKkt {
     __host__ __device__ static size_t offB(int J) { return 1024 * ceil4_sum(J); }                                    // sizeB(j) = 1024 ceil((j+1)/4)
     __host__ __device__ static size_t offF(int J, int NPAD) { const int nb = NPAD >> 4; return 1024 * (ceil4_sum(nb) - ceil4_sum(nb - J)); }   // sizeF(j) = 1024 ceil((nb-j)/4)
     __host__ __device__ static size_t slab(int c, int rel) { return (size_t)(rel >> 6) * 1024 + (size_t)c * 64 + (rel & 63); }
-    // per-instance HBM workspace (doubles): [Lr working tiles | LF column panels | -C strip (16 x Npad, k-major)]
+    //   CF, block column k: the NEGATED UNSCALED column entries -c of the rows below the diagonal tile (the A operand of the tile updates), k-major:
+    //   entry (t, row) at t * (NPAD - 16(k+1)) + row - 16(k+1); strips in k order
+    __host__ __device__ static size_t offC(int k, int NPAD) { return (size_t)16 * ((size_t)k * NPAD - (size_t)8 * k * (k + 1)); }
+    // per-instance HBM workspace (doubles): [Lr working tiles | LF column panels | CF strips]
     __host__ __device__ static size_t doubles(int N) {
         const int nb = nblk(N);
-        return (size_t)ntiles(N) * 256 + offF(nb, nb * 16) + (size_t)TB * nb * TB;
+        return (size_t)ntiles(N) * 256 + offF(nb, nb * 16) + offC(nb > 0 ? nb - 1 : 0, nb * 16) + 16;
     }
     static constexpr int LDS_DOUBLES = 256 + 16 + 16 * 65 + 64;     // diagonal tile (d on the diagonal, l below) + 16 slots + the backward pass's partial sums (16 columns, stride 65: the group sums read 16 columns at once) and group sums (4 x 16)
 };
@@ -83,20 +86,79 @@ __device__ __forceinline__ void big_build(double* W, int n, int m, const double*
 }
 
 // in-place blocked LDL^T of the tiles in W (see the header). dl: BigKkt::LDS_DOUBLES doubles of LDS.
+// LEFT-LOOKING schedule: block column J first receives the rank-16 updates of ALL earlier block columns k < J (accumulator tiles stay in
+// registers while k runs: per update one A operand tile from the CF strip of k and a quarter of a B operand tile from the LF panel of k are read),
+// then its diagonal tile is factorised and the rows below apply the 16 pivots. Every entry still receives fma(-c_ik, l_jk, a_ij) for k ascending
+// — the right-looking schedule's operations in the right-looking schedule's order — but a tile is read and written ONCE instead of once per earlier
+// block column (config C: 48 GB of the 220 GB a launch moved were those writes).
 __device__ __forceinline__ void big_factor(double* W, int N, double* dl) {
     const int ln = lane_id();
     const int nb = BigKkt::nblk(N), NPAD = nb * 16;
     const size_t nt = (size_t)BigKkt::ntiles(N);
     double* Lr = W;
     double* LF = W + nt * 256;
-    double* Cn = LF + BigKkt::offF(nb, NPAD);      // -C strip: entry (t, row) at t * NPAD + row
+    double* CF = LF + BigKkt::offF(nb, NPAD);
     const int lr = ln >> 4, lc = ln & 15;
     size_t oF = 0;
-    for (int k = 0; k < nb; oF += BigKkt::sizeF(k, NPAD), ++k) {
-        double* pF = LF + oF;   // forward panel of block column k
+    for (int J = 0; J < nb; oF += BigKkt::sizeF(J, NPAD), ++J) {
+        double* pF = LF + oF;   // forward panel of block column J
+        // ---- (u) tiles (I, J), I >= J: T += sum_k (-C_I^k) * (L_J^k)^T, k ascending, four v_mfma_f64_16x16x4_f64 per k. Tile rows in groups of
+        // four; the operands of k + 1 are requested before the matrix cores work on k.
+        if (J > 0) {
+            for (int I0 = J; I0 < nb; I0 += 4) {
+                big_d4 T[4];
+                int rowI[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int I = (I0 + g < nb) ? I0 + g : nb - 1;   // (a group's missing tiles repeat its last one; their result is dropped)
+                    rowI[g] = 16 * I + lc;
+                    const double* tt = Lr + (size_t)BigKkt::tidx(I, J) * 256;
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) T[g][rg] = tt[64 * rg + ln];
+                }
+                double av[4][4], bv[4];
+                auto load_ops = [&](int k, double (&a)[4][4], double (&b)[4]) {
+                    const double* cs = CF + BigKkt::offC(k, NPAD);
+                    const int w = NPAD - 16 * (k + 1);
+                    const double* pk = LF + BigKkt::offF(k, NPAD);
+#pragma unroll
+                    for (int sx = 0; sx < 4; ++sx) b[sx] = pk[BigKkt::slab(4 * sx + lr, 16 * (J - k) + lc)];   // B(kk = 4s + lr, col = lc) = L(16J + lc, 16k + 4s + lr)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int sx = 0; sx < 4; ++sx) a[g][sx] = cs[(size_t)(4 * sx + lr) * w + rowI[g] - 16 * (k + 1)];
+                };
+                load_ops(0, av, bv);
+                for (int k = 0; k < J; ++k) {
+                    double an[4][4], bn[4];
+                    load_ops((k + 1 < J) ? k + 1 : k, an, bn);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int sx = 0; sx < 4; ++sx) T[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g][sx], bv[sx], T[g], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int sx = 0; sx < 4; ++sx) av[g][sx] = an[g][sx];
+#pragma unroll
+                    for (int sx = 0; sx < 4; ++sx) bv[sx] = bn[sx];
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int I = I0 + g;
+                    if (I < nb) {
+                        double* tt = Lr + (size_t)BigKkt::tidx(I, J) * 256;
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) tt[64 * rg + ln] = T[g][rg];
+                    }
+                }
+            }
+            wfence();
+            wsync();
+        }
         // ---- (a) diagonal tile: right-looking LDL^T on 16 lanes (lane r = row r of the tile)
         {
-            double* td = Lr + (size_t)BigKkt::tidx(k, k) * 256;
+            double* td = Lr + (size_t)BigKkt::tidx(J, J) * 256;
             const int r = ln & 15;
             double a[16];
 #pragma unroll
@@ -121,14 +183,16 @@ __device__ __forceinline__ void big_factor(double* W, int N, double* dl) {
             wfence();
             wsync();
         }
-        if (k == nb - 1) break;
+        if (J == nb - 1) break;
         // ---- (b) rows below the diagonal tile: 16 pivots applied to the row's own 16 entries (one lane per row)
-        for (int row0 = 16 * (k + 1); row0 < NPAD; row0 += WAVE) {
+        double* cs = CF + BigKkt::offC(J, NPAD);
+        const int w = NPAD - 16 * (J + 1);
+        for (int row0 = 16 * (J + 1); row0 < NPAD; row0 += WAVE) {
             const int row = row0 + ln;
             const bool live = row < NPAD;
             const int rw = live ? row : row0;
             const int I = rw >> 4, rr = rw & 15;
-            double* tr_ = Lr + (size_t)BigKkt::tidx(I, k) * 256 + rr * 16;
+            double* tr_ = Lr + (size_t)BigKkt::tidx(I, J) * 256 + rr * 16;
             double a[16], cneg[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) a[c] = tr_[c];
@@ -143,49 +207,7 @@ __device__ __forceinline__ void big_factor(double* W, int N, double* dl) {
             }
             if (live) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) { pF[BigKkt::slab(c, row - 16 * k)] = a[c]; Cn[(size_t)c * NPAD + row] = cneg[c]; }
-            }
-        }
-        wfence();
-        wsync();
-        // ---- (c) trailing tiles (I, J), k < J <= I: T += (-C_I) * L_J^T, one rank-16 update on the matrix cores per tile. Tile rows in
-        // groups of four (their A operands stay in registers while J runs), the B operand of a J is loaded once per group.
-        for (int I0 = k + 1; I0 < nb; I0 += 4) {
-            double av[4][4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int I = (I0 + g < nb) ? I0 + g : nb - 1;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) av[g][s] = Cn[(size_t)(4 * s + lr) * NPAD + 16 * I + lc];
-            }
-            const int Jend = (I0 + 3 < nb) ? I0 + 3 : nb - 1;
-            for (int J = k + 1; J <= Jend; ++J) {
-                double bv[4];   // B(kk = 4s + lr, col = lc) = L(16J + lc, 16k + 4s + lr)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) bv[s] = pF[BigKkt::slab(4 * s + lr, 16 * (J - k) + lc)];
-                big_d4 T[4];
-                // (tiles of the group with I < J do not exist: their loads are redirected to the group's last tile and the result dropped)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int I = I0 + g;
-                    const bool ex = I < nb && I >= J;
-                    const double* tt = Lr + (size_t)BigKkt::tidx(ex ? I : Jend, ex ? J : k + 1) * 256;
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) T[g][rg] = tt[64 * rg + ln];
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) T[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g][s], bv[s], T[g], 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int I = I0 + g;
-                    if (I < nb && I >= J) {
-                        double* tt = Lr + (size_t)BigKkt::tidx(I, J) * 256;
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) tt[64 * rg + ln] = T[g][rg];
-                    }
-                }
+                for (int c = 0; c < 16; ++c) { pF[BigKkt::slab(c, row - 16 * J)] = a[c]; cs[(size_t)c * w + row - 16 * (J + 1)] = cneg[c]; }
             }
         }
         wfence();

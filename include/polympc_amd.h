@@ -99,9 +99,19 @@ typedef struct {
                            * else a DEVICE buffer of B x PMPC_FILTER_STATE_DOUBLES, read when the solve starts and written back when it
                            * ends — per instance [count, cost_0, violation_0, cost_1, violation_1, ...], newest pair first
                            * (pmpc_filter_state_create / _clear / _destroy manage one for hosts without device pointers) */
+    double* iteration_trace;      /* counterpart of sqp_settings_t::iteration_callback (sqp_base.hpp:33, called at :685-686 once per iteration
+                                   * from the second one on, after the step and its norms): a fused kernel cannot call back into the host, it RECORDS
+                                   * what the callback could read. NULL (default) = nothing recorded; else a DEVICE buffer of
+                                   * B x iteration_trace_capacity x PMPC_TRACE_DOUBLES: record (iter - 1) of instance b =
+                                   * [iter, alpha, primal_norm, dual_norm, cost, qp iterations, qp status, max constraint violation] of SQP iteration
+                                   * `iter` (1-based; the first iteration is recorded too — the reference's callback starts at 2), written after that
+                                   * iteration's termination test; iterations beyond the capacity are not recorded, records of iterations that
+                                   * did not run keep what the buffer held (pmpc_iteration_trace_create / _clear zero it). */
+    int iteration_trace_capacity; /* records per instance (ignored when iteration_trace is NULL) */
 } pmpc_sqp_settings;
 #define PMPC_FILTER_MAX_DEPTH 10
 #define PMPC_FILTER_STATE_DOUBLES (1 + 2 * PMPC_FILTER_MAX_DEPTH)
+#define PMPC_TRACE_DOUBLES 8
 
 /* sqp_status_t (sqp_base.hpp:49-55) */
 typedef enum { PMPC_SQP_SOLVED = 0, PMPC_SQP_MAX_ITER_EXCEEDED = 1, PMPC_SQP_INVALID_SETTINGS = 2 } pmpc_sqp_status;
@@ -221,6 +231,13 @@ pmpc_status pmpc_filter_state_create(pmpc_context* ctx, int B, double** filter_s
 pmpc_status pmpc_filter_state_clear(pmpc_context* ctx, int B, double* filter_state);
 pmpc_status pmpc_filter_state_download(pmpc_context* ctx, int B, const double* filter_state, double* host_out);
 pmpc_status pmpc_filter_state_destroy(pmpc_context* ctx, double* filter_state);
+
+/* Iteration records of B solver objects in device memory (zeroed) for pmpc_sqp_settings::iteration_trace — what the reference hands to
+ * sqp_settings_t::iteration_callback (sqp_base.hpp:33,685-686), kept per iteration instead of called back. download: B x capacity x PMPC_TRACE_DOUBLES. */
+pmpc_status pmpc_iteration_trace_create(pmpc_context* ctx, int B, int capacity, double** trace);
+pmpc_status pmpc_iteration_trace_clear(pmpc_context* ctx, int B, int capacity, double* trace);
+pmpc_status pmpc_iteration_trace_download(pmpc_context* ctx, int B, int capacity, const double* trace, double* host_out);
+pmpc_status pmpc_iteration_trace_destroy(pmpc_context* ctx, double* trace);
 
 /* One receding-horizon step of B MPC<OCP> controllers, everything resident on the device (replaces the caller's loop around
  * MPC::initial_conditions(x0) + MPC::solve() + MPC::solution_u_at(t_start), mpc_wrapper.hpp:89-93, :298, :241-244):

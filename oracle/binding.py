@@ -44,10 +44,22 @@ class SQPSettings(C.Structure):
     _fields_ = [("tau", C.c_double), ("eta", C.c_double), ("rho", C.c_double), ("eps_prim", C.c_double),
                 ("eps_dual", C.c_double), ("max_iter", C.c_int), ("line_search_max_iter", C.c_int),
                 ("regularisation", C.c_int), ("exact_hessian_every_iter", C.c_int), ("preconditioner", C.c_int), ("hessian_update", C.c_int), ("qp_solver", C.c_int),
-                ("line_search", C.c_int), ("filter_max_depth", C.c_int), ("filter_beta", C.c_double), ("filter_state", C.POINTER(C.c_double))]
+                ("line_search", C.c_int), ("filter_max_depth", C.c_int), ("filter_beta", C.c_double), ("filter_state", C.POINTER(C.c_double)),
+                ("iteration_trace", C.POINTER(C.c_double)), ("iteration_trace_capacity", C.c_int)]
 
 
 FILTER_STATE_DOUBLES = 21
+TRACE_DOUBLES = 8
+
+
+def bind_iteration_trace(ss, trace):
+    """Attach a (B, capacity, TRACE_DOUBLES) float64 array that receives the per-iteration records; None detaches it."""
+    if trace is None:
+        ss.iteration_trace = C.POINTER(C.c_double)(); ss.iteration_trace_capacity = 0
+    else:
+        assert trace.dtype == np.float64 and trace.flags.c_contiguous and trace.shape[-1] == TRACE_DOUBLES
+        ss.iteration_trace = trace.ctypes.data_as(C.POINTER(C.c_double)); ss.iteration_trace_capacity = trace.shape[-2]
+        ss._keep_trace = trace
 
 
 def bind_filter_state(ss, state):

@@ -87,6 +87,7 @@ void orc_sqp_default_settings(orc_sqp_settings* s) {
     s->max_iter = q.max_iter; s->line_search_max_iter = q.line_search_max_iter;
     s->regularisation = 0; s->exact_hessian_every_iter = 0; s->preconditioner = 0; s->hessian_update = 0; s->qp_solver = 0;
     s->line_search = q.line_search; s->filter_max_depth = q.filter_max_depth; s->filter_beta = q.filter_beta; s->filter_state = nullptr;
+    s->iteration_trace = nullptr; s->iteration_trace_capacity = 0;
 }
 
 void orc_cheb(int P, double* nodes, double* weights, double* D) {
@@ -238,6 +239,7 @@ static void sqp_batch_impl(int P, int S, double t0, double tf, const double* mp,
         SQP<ContinuousOCP<Model>> sqp(ocp, Model::ND);
         setup_solver<Model>(sqp, b, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, pivot);
         if (ss->filter_state) sqp.filter.load(ss->filter_state + (size_t)b * ORC_FILTER_STATE_DOUBLES);
+        if (ss->iteration_trace) { sqp.trace = ss->iteration_trace + (size_t)b * ss->iteration_trace_capacity * ORC_TRACE_DOUBLES; sqp.trace_capacity = ss->iteration_trace_capacity; }
         sqp.solve();
         if (ss->filter_state) sqp.filter.store(ss->filter_state + (size_t)b * ORC_FILTER_STATE_DOUBLES);
         const int n = sqp.n, m = sqp.m;

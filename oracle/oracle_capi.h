@@ -35,8 +35,11 @@ typedef struct {
     double filter_beta;            /* LSFilter::beta (1e-5) */
     double* filter_state;          /* NULL: every solve starts with an empty filter; else B x ORC_FILTER_STATE_DOUBLES, read before and
                                     * written after the solve (the solver member that outlives solve()): [count, cost0, viol0, cost1, ...] */
+    double* iteration_trace;       /* NULL, or B x iteration_trace_capacity x ORC_TRACE_DOUBLES: [iter, alpha, primal_norm, dual_norm, cost, qp iterations,
+                                    * qp status, max violation] per SQP iteration — what iteration_callback (sqp_base.hpp:33,685-686) could read */
+    int iteration_trace_capacity;
 } orc_sqp_settings;
-enum { ORC_FILTER_STATE_DOUBLES = 21 };
+enum { ORC_FILTER_STATE_DOUBLES = 21, ORC_TRACE_DOUBLES = 8 };
 
 typedef struct {
     int iter, qp_solver_iter, status;

@@ -147,6 +147,15 @@ struct SQP {
     int n, me, mi, m;
     std::vector<double> H, h, x, lam, lam_k, A, al, au, p_static, lbx, ubx, lx, ux, lbg, ubg, lag_gradient, step_prev;
     double cost_ = 0, primal_norm = 0, dual_norm = 0, max_violation = 0;
+    // iteration records: what sqp_settings_t::iteration_callback (sqp_base.hpp:33, called at :685-686 from the second iteration on) could read,
+    // kept per iteration — [iter, alpha, primal_norm, dual_norm, cost, qp iterations, qp status, max violation] after each termination test
+    double alpha_last = 0; int qp_iter_last = 0, qp_status_last = 0;
+    double* trace = nullptr; int trace_capacity = 0;
+    void record() {
+        if (!trace || info.iter > trace_capacity) return;
+        double* r = trace + (size_t)(info.iter - 1) * 8;
+        r[0] = info.iter; r[1] = alpha_last; r[2] = primal_norm; r[3] = dual_norm; r[4] = cost_; r[5] = qp_iter_last; r[6] = qp_status_last; r[7] = max_violation;
+    }
     sqp_settings settings;
     sqp_info info;
     BoxADMM qp;
@@ -274,11 +283,11 @@ struct SQP {
         if (settings.qp_solver == 1) {   // Solver<Problem, ADMM<...>>: zero guesses as in the 7-argument form (admm.hpp:104-109)
             qp_admm.settings = qp.settings; qp_admm.pivot = qp.pivot;
             qp_admm.solve(H.data(), h.data(), A.data(), al.data(), au.data(), lx.data(), ux.data(), nullptr, nullptr);
-            info.qp_solver_iter += qp_admm.info.iter;
+            info.qp_solver_iter += qp_admm.info.iter; qp_iter_last = qp_admm.info.iter; qp_status_last = qp_admm.info.status;
             p = qp_admm.x; p_lambda = qp_admm.y;
         } else {
             qp.solve(H.data(), h.data(), A.data(), al.data(), au.data(), lx.data(), ux.data());
-            info.qp_solver_iter += qp.info.iter;
+            info.qp_solver_iter += qp.info.iter; qp_iter_last = qp.info.iter; qp_status_last = qp.info.status;
             p = qp.x; p_lambda = qp.y;
         }
         if (settings.preconditioner == 1) {
@@ -295,6 +304,7 @@ struct SQP {
         lam_k = p_lambda;
         for (int i = 0; i < m + n; ++i) p_lambda[i] -= lam[i];
         const double alpha = step_size_selection(p.data());
+        alpha_last = alpha;
         for (int i = 0; i < n; ++i) x[i] += alpha * p[i];
         for (int i = 0; i < m + n; ++i) lam[i] += alpha * p_lambda[i];
         for (int i = 0; i < n; ++i) step_prev[i] = alpha * p[i];
@@ -311,14 +321,15 @@ struct SQP {
         form_qp_bounds();
         solve_qp(p, p_lambda);
         iterate_tail(p, p_lambda);
-        if (termination_criteria()) { info.status = SQP_SOLVED; return; }
+        { const bool done = termination_criteria(); record(); if (done) { info.status = SQP_SOLVED; return; } }
         while (info.iter < settings.max_iter) {
             info.iter++;
             update_linearisation();
             form_qp_bounds();
             solve_qp(p, p_lambda);
             iterate_tail(p, p_lambda);
-            if (termination_criteria()) { info.status = SQP_SOLVED; break; }
+            const bool done = termination_criteria(); record();
+            if (done) { info.status = SQP_SOLVED; break; }
         }
     }
     void solve(const double* x_guess, const double* lam_guess) {

@@ -23,6 +23,7 @@ EXPORTED_SYMBOLS = [
     "pmpc_mpc_step_batch_dev", "pmpc_mpc_batch_create", "pmpc_mpc_batch_step", "pmpc_mpc_batch_solution", "pmpc_mpc_batch_destroy",
     "pmpc_qp_admm_solve_batch", "pmpc_qp_admm_solve_batch_dev", "pmpc_qp_ruiz_compute_batch", "pmpc_qp_ruiz_compute_batch_dev", "pmpc_qp_ruiz_unscale_batch", "pmpc_qp_ruiz_unscale_batch_dev",
     "pmpc_filter_state_create", "pmpc_filter_state_clear", "pmpc_filter_state_download", "pmpc_filter_state_destroy",
+    "pmpc_iteration_trace_create", "pmpc_iteration_trace_clear", "pmpc_iteration_trace_download", "pmpc_iteration_trace_destroy",
 ]
 
 
@@ -42,11 +43,13 @@ class SQPSettings(C.Structure):
     _fields_ = [("tau", C.c_double), ("eta", C.c_double), ("rho", C.c_double), ("eps_prim", C.c_double),
                 ("eps_dual", C.c_double), ("max_iter", C.c_int), ("line_search_max_iter", C.c_int),
                 ("regularisation", C.c_int), ("exact_hessian_every_iter", C.c_int), ("preconditioner", C.c_int), ("hessian_update", C.c_int), ("qp_solver", C.c_int),
-                ("line_search", C.c_int), ("filter_max_depth", C.c_int), ("filter_beta", C.c_double), ("filter_state", C.c_void_p)]
+                ("line_search", C.c_int), ("filter_max_depth", C.c_int), ("filter_beta", C.c_double), ("filter_state", C.c_void_p),
+                ("iteration_trace", C.c_void_p), ("iteration_trace_capacity", C.c_int)]
 
 
 FILTER_MAX_DEPTH = 10
 FILTER_STATE_DOUBLES = 1 + 2 * FILTER_MAX_DEPTH
+TRACE_DOUBLES = 8   # [iter, alpha, primal_norm, dual_norm, cost, qp iterations, qp status, max violation]
 
 
 class SQPInfo(C.Structure):
@@ -279,6 +282,32 @@ class Context:
 
     def filter_state_destroy(self, handle):
         f = lib().pmpc_filter_state_destroy
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        _check(f(self._ctx, handle))
+
+    # ------------------------------------------------------------------ per-iteration records (the reference's iteration_callback, recorded)
+    def iteration_trace_create(self, B, capacity):
+        """Device buffer of B x capacity zeroed records; put the handle into SQPSettings.iteration_trace (and the capacity next to it)."""
+        out = C.c_void_p()
+        f = lib().pmpc_iteration_trace_create
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        _check(f(self._ctx, B, capacity, C.byref(out)))
+        return out.value
+
+    def iteration_trace_clear(self, B, capacity, handle):
+        f = lib().pmpc_iteration_trace_clear
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        _check(f(self._ctx, B, capacity, handle))
+
+    def iteration_trace_download(self, B, capacity, handle):
+        out = np.zeros((B, capacity, TRACE_DOUBLES))
+        f = lib().pmpc_iteration_trace_download
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
+        _check(f(self._ctx, B, capacity, handle, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def iteration_trace_destroy(self, handle):
+        f = lib().pmpc_iteration_trace_destroy
         f.argtypes = [C.c_void_p, C.c_void_p]
         _check(f(self._ctx, handle))
 

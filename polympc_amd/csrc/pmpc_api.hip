@@ -194,6 +194,33 @@ pmpc_status pmpc_filter_state_destroy(pmpc_context* ctx, double* filter_state) {
     return PMPC_OK;
 }
 
+pmpc_status pmpc_iteration_trace_create(pmpc_context* ctx, int B, int capacity, double** trace) {
+    if (!ctx || B < 1 || capacity < 1 || !trace) return PMPC_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(ctx->device));
+    double* p = nullptr;
+    const size_t bytes = (size_t)B * capacity * PMPC_TRACE_DOUBLES * sizeof(double);
+    HIPCHK(hipMalloc(&p, bytes));
+    if (hipMemsetAsync(p, 0, bytes, ctx->stream) != hipSuccess) { (void)hipFree(p); return PMPC_ERR_HIP; }
+    *trace = p;
+    return PMPC_OK;
+}
+pmpc_status pmpc_iteration_trace_clear(pmpc_context* ctx, int B, int capacity, double* trace) {
+    if (!ctx || B < 1 || capacity < 1 || !trace) return PMPC_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipMemsetAsync(trace, 0, (size_t)B * capacity * PMPC_TRACE_DOUBLES * sizeof(double), ctx->stream));
+    return PMPC_OK;
+}
+pmpc_status pmpc_iteration_trace_download(pmpc_context* ctx, int B, int capacity, const double* trace, double* host_out) {
+    if (!ctx || B < 1 || capacity < 1 || !trace || !host_out) return PMPC_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipMemcpyAsync(host_out, trace, (size_t)B * capacity * PMPC_TRACE_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PMPC_OK;
+}
+pmpc_status pmpc_iteration_trace_destroy(pmpc_context* ctx, double* trace) {
+    if (!ctx) return PMPC_ERR_INVALID_ARGUMENT;
+    if (trace) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(trace)); }
+    return PMPC_OK;
+}
+
 void pmpc_qp_settings_default(pmpc_qp_settings* s) {
     s->eps_rel = 1e-3; s->eps_abs = 1e-3; s->max_iter = 1000; s->rho = 1e-1; s->sigma = 1e-6; s->alpha = 1.0;
     s->check_termination = 25; s->adaptive_rho = 0; s->adaptive_rho_tolerance = 5; s->adaptive_rho_interval = 25; s->linear_solver = 0;
@@ -207,6 +234,7 @@ void pmpc_sqp_settings_default(pmpc_sqp_settings* s) {
     s->tau = 0.5; s->eta = 0.25; s->rho = 0.5; s->eps_prim = 1e-3; s->eps_dual = 1e-3; s->max_iter = 100;
     s->line_search_max_iter = 100; s->regularisation = 0; s->exact_hessian_every_iter = 0; s->preconditioner = 0; s->hessian_update = 0; s->qp_solver = 0;
     s->line_search = 0; s->filter_max_depth = PMPC_FILTER_MAX_DEPTH; s->filter_beta = 1e-5; s->filter_state = nullptr;
+    s->iteration_trace = nullptr; s->iteration_trace_capacity = 0;
 }
 
 pmpc_status pmpc_chebyshev(int P, double* nodes, double* weights, double* D) {
@@ -410,6 +438,7 @@ static pmpc_status check_sqp_args(int model, int P, int S, const double* d, cons
     if (st != PMPC_OK) return st;
     if (nd > 0 && !d) return PMPC_ERR_INVALID_ARGUMENT;
     if (ss && ss->max_iter < 1) return PMPC_ERR_INVALID_ARGUMENT;
+    if (ss && ss->iteration_trace && ss->iteration_trace_capacity < 1) return PMPC_ERR_INVALID_ARGUMENT;
     return PMPC_OK;
 }
 

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
     SqpDevice<Model, NN, MM, PROF, HU, KHBM> sqp(ocp, v, qw, K0, K0 + n, ss, qs);
     sqp.filt = filt;
     sqp.eig = eigw;
+    sqp.trace = ss.iteration_trace ? ss.iteration_trace + (size_t)b * (size_t)ss.iteration_trace_capacity * PMPC_TRACE_DOUBLES : nullptr;
     sqp.tr = ocp.s.fval;   // first per-node staging array: everything from here on is dead while the QP runs
     {   // side-by-side line search: G candidates x (m constraint values + NN Lagrange values) + 3 scalars each, in the same region
         const int G = WAVE / ocp.dm.NN;

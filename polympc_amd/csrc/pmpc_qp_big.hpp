@@ -7,7 +7,8 @@
 // and the CPU restatement (PIVOT_BLOCKED) shares PIVOT_STATIC's factorisation and forward pass. What changes is the schedule and the data layout:
 //   * the WORKING matrix lives in HBM as 16 x 16 row-major tiles of the lower block triangle, tile (I, J) at I(I+1)/2 + J (Lr: an MFMA
 //     accumulator tile is four coalesced 512-byte loads). The unblocked kernel streamed the packed trailing triangle once per PIVOT
-//     (270 MB per factorisation at 464 rows); here a trailing tile is read and written once per 16 pivots (27 MB).
+//     (270 MB per factorisation at 464 rows), a right-looking tile schedule once per 16 pivots (27 MB read and written); the left-looking
+//     schedule used here reads and writes every tile once and streams the operands of its updates instead (see big_factor).
 //   * the finished FACTOR is written once, as column panels LF — per block column J the 16 columns of L below (and including) the diagonal tile,
 //     each column contiguous over the rows, in slabs of 64 rows: with one lane per row every load instruction is a contiguous 512-byte segment.
 //     The forward substitution streams it (instruction c loads L(row, 16J + c) for 64 consecutive rows), it is the B operand of the trailing
@@ -19,7 +20,7 @@
 //     16 pivots to its own 16 entries independently (one lane per row, the diagonal tile's d and l through LDS), then every trailing tile
 //     gets ONE rank-16 update on the matrix cores: four v_mfma_f64_16x16x4_f64 (a k-ascending fma chain per entry — verified on gfx950,
 //     tests/experiments/mfma_f64_probe.hip — which is exactly the order above), A operand = the negated unscaled panel (-C, kept k-major
-//     in a 16 x N scratch strip), B operand = the k-major tile of L.
+//     in the CF strip of its block column), B operand = the k-major tile of L.
 //   * substitutions: lane per row; per block column the 16 finished entries are broadcast (v_readlane) and every row below (above) applies
 //     its 16 fma from ONE contiguous 128-byte load; 32 such loads are in flight per batch. 2N dependent steps become 2N/16.
 // MFMA-busy is what bounds a single wavefront here (33 MFLOP per factorisation at 32 flop/cycle/SIMD), HBM traffic what bounds the batch

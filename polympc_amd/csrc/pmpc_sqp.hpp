@@ -74,6 +74,8 @@ struct SqpDevice {
     __device__ __forceinline__ int me_ct() const { if constexpr (NN > 0) return Model::NX * NNODES_CT_; else return me; }
     __device__ __forceinline__ int mi_ct() const { if constexpr (NN > 0) return Model::NG * NNODES_CT_; else return mi; }
     double cost_log = 0.0, primal_norm = 0.0, dual_norm = 0.0, max_violation = 0.0;
+    double alpha_log = 0.0; int qp_iter_last = 0, qp_status_last = 0;   // for the iteration records
+    double* trace = nullptr;   // this instance's records (pmpc_sqp_settings::iteration_trace), or null
     int qp_iter_total = 0;
     int qp_flags = 0;            // OR of the QP solves' flags (PMPC_FLAG_NONFINITE)
     long long cyc[PROF ? 24 : 1] = {0};
@@ -811,6 +813,7 @@ struct SqpDevice {
         }
         qp_iter_total += qi.iter;
         qp_flags |= qi.flags;
+        qp_iter_last = qi.iter; qp_status_last = qi.status;
         if constexpr (RUIZ_COMPILED) if (ruiz) {   // unscale(p, p_lambda); unscale(m_H, m_h, m_A, ...), sqp_base.hpp:608-609 / :664-665
             ruiz_unscale_solution_wave(n, m, rz.D, rz.E, rz_c, qw.x, qw.y);
             ruiz_unscale_problem_wave(n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, rz.D, rz.E, rz_c);
@@ -827,6 +830,7 @@ struct SqpDevice {
         for (int i = ln; i < m + n; i += WAVE) v.lam[i] += alpha * qw.y[i];
         primal_norm = alpha * pn;
         dual_norm = alpha * dn;
+        alpha_log = alpha;
         wsync();
     }
     __device__ __forceinline__ bool termination_criteria() {  // :524-529
@@ -849,6 +853,11 @@ struct SqpDevice {
             const bool done = __builtin_amdgcn_readfirstlane((int)termination_criteria()) != 0;
             const long long c3 = now();
             acc(0, c1 - c0); acc(3, c3 - c2); acc(4, c3 - c0); (void)c2;
+            if (trace != nullptr && iter <= ss.iteration_trace_capacity && lane_id() == 0) {   // what sqp_settings_t::iteration_callback could read (sqp_base.hpp:685-686)
+                double* r = trace + (size_t)(iter - 1) * PMPC_TRACE_DOUBLES;
+                r[0] = (double)iter; r[1] = alpha_log; r[2] = primal_norm; r[3] = dual_norm; r[4] = cost_log;
+                r[5] = (double)qp_iter_last; r[6] = (double)qp_status_last; r[7] = max_violation;
+            }
             if (done) { status = PMPC_SQP_SOLVED; break; }
             if (iter >= ss.max_iter) break;
             if (iter >= it_end) { status = PMPC_SQP_IN_PROGRESS; break; }

@@ -161,6 +161,10 @@ struct sqp_settings_t {   // sqp_base.hpp:24-47 (+ the two override points as fl
     int qp_solver = 0;                 // QPSolver template argument: 0 boxADMM, 1 ADMM (OSQP form)
     int line_search = 0;               // step_size_selection_impl: 0 l1-merit backtracking (sqp_base.hpp:380-419), 1 the filter line search
                                        // of valet_parking_mpc_test.cpp:116-158 on LSFilter (line_search.hpp:31-98)
+    void (*iteration_callback)(void* solver) = nullptr;   // sqp_base.hpp:33, called at :685-686 once per iteration from the second one on. The fused
+                                       // kernel records what the callback can read (pmpc_sqp_settings::iteration_trace); Solver<OCP>::solve() then
+                                       // calls it once per recorded iteration with info().iter, primal_norm(), dual_norm(), cost() and
+                                       // constr_violation() of THAT iteration (the iterates themselves are not retained: primal_solution() is the final one)
 };
 
 // LSFilter's tunables under the reference's member names (`solver.filter.beta = 0.1`, valet_parking_mpc_test.cpp:192); the list itself
@@ -233,11 +237,20 @@ public:
         pmpc_context* ctx = context();
         if (!ctx) return last_error();
         pmpc_sqp_settings ss;
+        pmpc_sqp_settings_default(&ss);
         ss.tau = m_settings.tau; ss.eta = m_settings.eta; ss.rho = m_settings.rho; ss.eps_prim = m_settings.eps_prim;
         ss.eps_dual = m_settings.eps_dual; ss.max_iter = m_settings.max_iter; ss.line_search_max_iter = m_settings.line_search_max_iter;
         ss.regularisation = m_settings.regularisation; ss.exact_hessian_every_iter = m_settings.exact_hessian_every_iter ? 1 : 0;
         ss.preconditioner = m_settings.preconditioner; ss.hessian_update = m_settings.hessian_update; ss.qp_solver = m_settings.qp_solver;
         { const pmpc_status fs = filter.bind(ctx, B, m_settings.line_search, ss); if (fs != PMPC_OK) return last_error() = fs; }
+        double* trace_dev = nullptr;
+        const int cap = m_settings.max_iter;
+        if (m_settings.iteration_callback != nullptr && cap > 0) {   // records for the callbacks (replayed by the caller of solve())
+            const pmpc_status ts = pmpc_iteration_trace_create(ctx, B, cap, &trace_dev);
+            if (ts != PMPC_OK) return last_error() = ts;
+            ss.iteration_trace = trace_dev; ss.iteration_trace_capacity = cap;
+        }
+        m_trace.clear(); m_trace_capacity = 0;
         std::vector<double> xo(m_x.size()), lo(m_lam.size());
         const pmpc_status st = device_binding<OCP>::solve(ctx, problem, OCP::POLY_ORDER, OCP::NUM_SEGMENTS, problem.t_start, problem.t_stop, B,
                                                           m_x.data(), m_lam.data(), m_p.data(), m_lbx.data(), m_ubx.data(),
@@ -245,13 +258,28 @@ public:
                                                           &m_qp_settings, xo.data(), lo.data(), m_info.data());
         last_error() = st;
         if (st == PMPC_OK) { m_x.swap(xo); m_lam.swap(lo); }
+        if (trace_dev) {
+            if (st == PMPC_OK) {
+                m_trace.assign((size_t)B * cap * PMPC_TRACE_DOUBLES, 0.0);
+                if (pmpc_iteration_trace_download(ctx, B, cap, trace_dev, m_trace.data()) == PMPC_OK) m_trace_capacity = cap; else m_trace.clear();
+            }
+            pmpc_iteration_trace_destroy(ctx, trace_dev);
+        }
         return st;
+    }
+    // record of SQP iteration `iter` (1-based) of instance b: [iter, alpha, primal_norm, dual_norm, cost, qp iterations, qp status, max violation];
+    // null when nothing was recorded (no iteration_callback set, or the iteration did not run)
+    const double* iteration_record(int b, int iter) const noexcept {
+        if (iter < 1 || iter > m_trace_capacity || b < 0 || b >= B) return nullptr;
+        const double* r = &m_trace[((size_t)b * m_trace_capacity + (iter - 1)) * PMPC_TRACE_DOUBLES];
+        return r[0] == (double)iter ? r : nullptr;
     }
 
     OCP problem;
     int B;
     std::vector<double> m_x, m_lam, m_lbx, m_ubx, m_lbg, m_ubg, m_p;
     std::vector<pmpc_sqp_info> m_info;
+    std::vector<double> m_trace; int m_trace_capacity = 0;
     sqp_settings_t m_settings;
     qp_solver_settings_t m_qp_settings;
     LSFilterHandle filter;   // `MySolver::filter` of valet_parking_mpc_test.cpp:114 for every instance (used when settings().line_search == 1)
@@ -309,6 +337,18 @@ public:
         std::copy(m_batch.primal_solution(0), m_batch.primal_solution(0) + VAR_SIZE, m_x.data());
         std::copy(m_batch.dual_solution(0), m_batch.dual_solution(0) + OCP::DUAL_SIZE, m_lam.data());
         const pmpc_sqp_info& i = m_batch.info(0);
+        if (m_batch.settings().iteration_callback != nullptr) {   // sqp_base.hpp:685-686: from the second iteration on, before that iteration's termination test
+            int qp_sum = 0;
+            if (const double* r1 = m_batch.iteration_record(0, 1)) qp_sum = (int)r1[5];
+            for (int k = 2; k <= i.iter; ++k) {
+                const double* r = m_batch.iteration_record(0, k);
+                if (!r) break;
+                qp_sum += (int)r[5];
+                m_info.iter = k; m_info.qp_solver_iter = qp_sum;
+                m_primal_norm = r[2]; m_dual_norm = r[3]; m_cost = r[4]; m_max_violation = r[7];
+                m_batch.settings().iteration_callback(this);
+            }
+        }
         m_info.iter = i.iter; m_info.qp_solver_iter = i.qp_solver_iter;
         m_info.status.value = i.status == PMPC_SQP_SOLVED ? sqp_status_t::SOLVED : sqp_status_t::MAX_ITER_EXCEEDED;
         m_primal_norm = i.primal_norm; m_dual_norm = i.dual_norm; m_max_violation = i.max_violation; m_cost = i.cost;
@@ -534,6 +574,7 @@ public:
             if (st != PMPC_OK) return last_error() = st;
         }
         pmpc_sqp_settings ss;
+        pmpc_sqp_settings_default(&ss);
         ss.tau = m_settings.tau; ss.eta = m_settings.eta; ss.rho = m_settings.rho; ss.eps_prim = m_settings.eps_prim; ss.eps_dual = m_settings.eps_dual;
         ss.max_iter = m_settings.max_iter; ss.line_search_max_iter = m_settings.line_search_max_iter; ss.regularisation = m_settings.regularisation;
         ss.exact_hessian_every_iter = m_settings.exact_hessian_every_iter ? 1 : 0; ss.preconditioner = m_settings.preconditioner;

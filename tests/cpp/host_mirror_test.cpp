@@ -144,6 +144,42 @@ static void MPCWrapperTest() {
     EXPECT_TRUE(std::fabs(mpc.solution_x_at(0)(0) - 0.3) < 1e-3);   // the pinned initial state is the FIRST point in time
 }
 
+// sqp_settings_t::iteration_callback (sqp_base.hpp:33, :685-686): called once per SQP iteration from the second one on with the solver, whose getters
+// then describe THAT iteration. The fused kernel records those values; Solver<OCP>::solve() replays them.
+static std::vector<int> cb_iters;
+static std::vector<double> cb_primal;
+static void record_iteration(void* solver) {
+    auto* s = static_cast<Solver<RobotOCP>*>(solver);
+    cb_iters.push_back(s->info().iter);
+    cb_primal.push_back(s->primal_norm());
+}
+static void IterationCallbackTest() {
+    std::printf("IterationCallbackTest\n");
+    using mpc_t = MPC<RobotOCP>;
+    mpc_t mpc;
+    mpc.ocp().set_Q_coeff(2.0);
+    mpc.settings().max_iter = 10;
+    mpc.settings().line_search_max_iter = 10;
+    mpc.settings().iteration_callback = &record_iteration;
+    mpc.set_time_limits(0, 2);
+    mpc_t::static_param p; p(0) = 2.0;
+    mpc_t::state_t x0; x0(0) = 0.5; x0(1) = 0.5; x0(2) = 0.5;
+    mpc_t::control_t lbu, ubu; lbu(0) = -1.5; lbu(1) = -0.75; ubu(0) = 1.5; ubu(1) = 0.75;
+    mpc.set_static_parameters(p);
+    mpc.control_bounds(lbu, ubu);
+    mpc.initial_conditions(x0);
+    cb_iters.clear(); cb_primal.clear();
+    mpc.solve();
+    const int iters = mpc.info().iter;
+    EXPECT_TRUE(mpc.info().status.value == sqp_status_t::SOLVED);
+    EXPECT_TRUE(iters >= 2 && (int)cb_iters.size() == iters - 1);
+    for (size_t k = 0; k < cb_iters.size(); ++k) EXPECT_TRUE(cb_iters[k] == (int)k + 2);
+    EXPECT_TRUE(!cb_primal.empty() && cb_primal.back() == mpc.primal_norm());
+    EXPECT_TRUE(cb_primal.size() < 2 || cb_primal.front() > cb_primal.back());   // the steps shrink towards the solution
+    std::printf("  %d iterations, %zu callbacks, |step| %.3e -> %.3e\n", iters, cb_iters.size(), cb_primal.empty() ? 0.0 : cb_primal.front(), cb_primal.empty() ? 0.0 : cb_primal.back());
+    mpc.settings().iteration_callback = nullptr;
+}
+
 // valet_parking_mpc_test.cpp:183-240 — the reference plugs three hooks into SQPBase there (Ruiz preconditioner as template argument,
 // filter line search :116-158, block BFGS :160-165); here they are the three settings flags, `solver.filter.beta` keeps its name.
 static void ValetParkingTest() {
@@ -258,6 +294,7 @@ int main() {
     admmSimpleQP();
     box_admmNonConvex();
     MPCWrapperTest();
+    IterationCallbackTest();
     BatchMPCTest();
     UserRegisteredRobotMatchesBuiltin();
     UserPendulumWithPathConstraint();

@@ -30,7 +30,7 @@ def test_header_symbols_are_exported(pa):
 def test_struct_layouts_match_header(pa):
     import ctypes as C
     assert C.sizeof(pa.QPSettings) == 72 and C.sizeof(pa.QPInfo) == 40
-    assert C.sizeof(pa.SQPSettings) == 96 and C.sizeof(pa.SQPInfo) == 48
+    assert C.sizeof(pa.SQPSettings) == 112 and C.sizeof(pa.SQPInfo) == 48
 
 
 def test_defaults_match_reference(pa):
@@ -42,6 +42,7 @@ def test_defaults_match_reference(pa):
     n = pa.sqp_settings_default()     # sqp_base.hpp:24-47
     assert (n.tau, n.eta, n.rho, n.eps_prim, n.eps_dual, n.max_iter, n.line_search_max_iter) == (0.5, 0.25, 0.5, 1e-3, 1e-3, 100, 100)
     assert (n.line_search, n.filter_max_depth, n.filter_beta, n.filter_state) == (0, 10, 1e-5, None)   # LSFilter, line_search.hpp:38-39
+    assert (n.iteration_trace, n.iteration_trace_capacity) == (None, 0)   # iteration_callback = nullptr, sqp_base.hpp:33
 
 
 def test_no_cpu_fallback(pa):

@@ -791,6 +791,37 @@ def test_sqp_builtin_models_on_the_hbm_factor_kernel(ctx, oracle, case):
     assert np.all(info["flags"] == 0)
 
 
+@pytest.mark.parametrize("P,S,B", [(6, 1, 64), (5, 2, 16), (5, 3, 6)])
+def test_sqp_iteration_records_vs_oracle(ctx, oracle, P, S, B):
+    """pmpc_sqp_settings::iteration_trace — what the reference hands to sqp_settings_t::iteration_callback (sqp_base.hpp:33, :685-686), recorded per
+    iteration by the fused kernel: bit-identical to the CPU restatement's records on the three kernel families (register path, two rows per
+    lane, HBM factor), one record per iteration that ran, nothing written beyond them, validation of the capacity."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    cap = 12
+    wl = workloads.robot_batch(B, P=P, S=S)
+    ss = pa.sqp_settings_default(); ss.max_iter = 10; ss.line_search_max_iter = 10
+    oss = oracle.sqp_default_settings(); oss.max_iter = 10; oss.line_search_max_iter = 10
+    h = ctx.iteration_trace_create(B, cap)
+    try:
+        ss.iteration_trace = h; ss.iteration_trace_capacity = cap
+        x, lam, info = ctx.sqp_solve_batch(wl["model"], P, S, wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
+        tr = ctx.iteration_trace_download(B, cap, h)
+        otr = np.zeros((B, cap, oracle.TRACE_DOUBLES)); oracle.bind_iteration_trace(oss, otr)
+        dm = oracle.ocp_dims(wl["model"], P, S)
+        xo, lo, io = oracle.sqp_solve_batch(wl["model"], P, S, wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss,
+                                            pivot=_gpu_order(oracle, dm["n"], dm["m"], P * S + 1))
+        _assert_same_solve(info, io, x, xo, lam, lo)
+        assert np.array_equal(tr, otr)
+        for b in range(B):
+            assert np.array_equal(tr[b, :info["iter"][b], 0], np.arange(1, info["iter"][b] + 1)) and np.all(tr[b, info["iter"][b]:] == 0)
+        ss.iteration_trace_capacity = 0
+        with pytest.raises(RuntimeError):
+            ctx.sqp_solve_batch(wl["model"], P, S, wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
+    finally:
+        ctx.iteration_trace_destroy(h)
+
+
 def test_sqp_warm_start_and_gershgorin(ctx, oracle):
     """Second solve warm-started from the first (x, lam) with a moved initial state; Gershgorin regulariser on."""
     import polympc_amd as pa

@@ -733,3 +733,25 @@ def test_blocked_policy_on_config_C_stream(oracle):
         r[piv] = (x, [i.iter for i in info], [i.qp_solver_iter for i in info], [i.status for i in info])
     a, b = r[oracle.PIVOT_EIGEN], r[oracle.PIVOT_BLOCKED]
     assert a[1:] == b[1:] and np.abs(a[0] - b[0]).max() <= 1e-9
+
+
+def test_sqp_iteration_records(oracle):
+    """sqp_settings_t::iteration_callback (sqp_base.hpp:33, :685-686) restated as records: one per SQP iteration, in order, the last one equal to
+    what the solver reports; the first iteration takes the full step of its (feasible-by-construction) QP unless the line search cuts it."""
+    from polympc_amd import workloads
+    B, cap = 8, 12
+    wl = workloads.robot_batch(B)
+    ss = oracle.sqp_default_settings(); ss.max_iter = 10; ss.line_search_max_iter = 10
+    tr = np.zeros((B, cap, oracle.TRACE_DOUBLES)); oracle.bind_iteration_trace(ss, tr)
+    x, lam, info = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
+    for b in range(B):
+        k = info[b].iter
+        assert np.array_equal(tr[b, :k, 0], np.arange(1, k + 1)) and np.all(tr[b, k:] == 0)
+        last = tr[b, k - 1]
+        assert (last[2], last[3], last[4], last[7]) == (info[b].primal_norm, info[b].dual_norm, info[b].cost, info[b].max_violation)
+        assert tr[b, :k, 5].sum() == info[b].qp_solver_iter
+        assert np.all((tr[b, :k, 1] > 0) & (tr[b, :k, 1] <= 1))
+    # a capacity smaller than the iteration count keeps the first records only
+    tr2 = np.zeros((B, 3, oracle.TRACE_DOUBLES)); oracle.bind_iteration_trace(ss, tr2)
+    oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
+    assert np.array_equal(tr2, tr[:, :3])

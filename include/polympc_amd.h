@@ -157,7 +157,10 @@ pmpc_status pmpc_chebyshev(int P, double* nodes, double* weights, double* D);
 
 /* Batched boxADMM::solve (replaces QPBase::solve -> boxADMM::solve_impl, qp_base.hpp:161-175,
  * box_admm.hpp:81-205). Host buffers; copies in, solves on the GPU, copies out, synchronises.
- * x0 / y0 may be NULL (the 7-argument form: zero guesses, box_admm.hpp:81-86). */
+ * x0 / y0 may be NULL (the 7-argument form: zero guesses, box_admm.hpp:81-86).
+ * Any size: n + m <= 64 and 65..112 rows have register-resident specialisations for the built-in shapes, systems below 112 rows are factorised in LDS,
+ * larger ones (the reference's kite size, n + m = 464, included) keep a tiled factor in a per-QP HBM workspace the context owns
+ * (about 2 (n+m)^2 x 8 bytes per QP). linear_solver = 1 (pivoted) exists in LDS only: PMPC_ERR_UNSUPPORTED_SIZE beyond ~190 rows. */
 pmpc_status pmpc_qp_boxadmm_solve_batch(pmpc_context* ctx, int B, int n, int m, const double* H, const double* h,
                                         const double* A, const double* Alb, const double* Aub, const double* xlb,
                                         const double* xub, const double* x0, const double* y0,

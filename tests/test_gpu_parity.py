@@ -28,12 +28,15 @@ def _mat(Hc, n, m=None):
 BIG_KKT_MIN_ROWS = 96   # pmpc_launch.hpp: from this many KKT rows the fused SQP kernel keeps its factor in HBM (blocked tile LDL^T)
 
 
-def _lds_order(oracle, rows, sqp=True):
+QP_BIG_MIN_ROWS = 112   # pmpc_api.hip: the QP entry point's threshold for the same kernel family
+
+
+def _lds_order(oracle, rows, qp_entry=False):
     """The LDS-resident kernels (boxADMM above 64 KKT rows without a register specialisation, every policy the register paths do not carry, the
-    stacked system of the OSQP-form ADMM, the QP entry point): static right-looking LDL^T with fma substitutions (PIVOT_STATIC). SQP instances of
-    96 rows and more (and everything whose packed triangle does not fit LDS: config C) run the blocked tile LDL^T with the factor in HBM: same
-    factor and forward pass, backward pass by column dot products (PIVOT_BLOCKED)."""
-    return oracle.PIVOT_BLOCKED if (sqp and rows >= BIG_KKT_MIN_ROWS) else oracle.PIVOT_STATIC
+    stacked system of the OSQP-form ADMM): static right-looking LDL^T with fma substitutions (PIVOT_STATIC). Larger systems — 96 rows and more in the
+    fused SQP kernel, 112 and more at the QP entry point, and everything whose packed triangle does not fit LDS (config C) — run the blocked tile
+    LDL^T with the factor in HBM: same factor and forward pass, backward pass by column dot products (PIVOT_BLOCKED)."""
+    return oracle.PIVOT_BLOCKED if rows >= (QP_BIG_MIN_ROWS if qp_entry else BIG_KKT_MIN_ROWS) else oracle.PIVOT_STATIC
 
 
 REG2_QP_SHAPES = ((66, 44), (55, 33))   # QP entry point: two-rows-per-lane register specialisations (pmpc_qp_reg2.hip)
@@ -48,7 +51,7 @@ def _gpu_order(oracle, n, m, nodes=None):
     if nodes is None:
         if (n, m) in REG2_QP_SHAPES:
             return oracle.PIVOT_SWEEP2
-        return oracle.PIVOT_SWEEP if (n, m) == (35, 21) else _lds_order(oracle, n + m, sqp=False)
+        return oracle.PIVOT_SWEEP if (n, m) == (35, 21) else _lds_order(oracle, n + m, qp_entry=True)
     if n + m <= 64 and nodes in (5, 7):
         return oracle.PIVOT_SWEEP
     if 64 < n + m <= 112 and nodes == 11:      # SQP grids of 11 nodes (P = 5, S = 2): two-rows-per-lane register path
@@ -107,10 +110,10 @@ def test_qp_reference_known_answers(ctx, oracle):
     assert abs(x[0, 0] - 2.0) <= 2e-2 and info["iter"][0] < 200 and info["status"][0] == pa.QP_SOLVED
 
 
-@pytest.mark.parametrize("n,m,B", [(2, 1, 8), (1, 0, 4), (7, 3, 33), (35, 21, 64), (55, 33, 16), (66, 44, 8), (80, 48, 4), (3, 70, 4)])
+@pytest.mark.parametrize("n,m,B", [(2, 1, 8), (1, 0, 4), (7, 3, 33), (35, 21, 64), (55, 33, 16), (66, 44, 8), (80, 48, 4), (3, 70, 4), (60, 36, 5), (105, 63, 3), (256, 208, 3)])
 def test_qp_random_vs_oracle(ctx, oracle, n, m, B):
     """Random convex QPs of many shapes (incl. ragged n+m > 64, m > n, m = 0): same iteration count, status and
-    rho updates as the oracle; x, y within 1e-9 (absolute, problem data O(1))."""
+    rho updates as the oracle; x, y and the reported residuals bit-identical (register, two-rows-per-lane, LDS and HBM-factor kernels)."""
     import polympc_amd as pa
     from polympc_amd import workloads
     q = workloads.random_qp_batch(B, n, m, seed=n * 1000 + m)
@@ -120,9 +123,8 @@ def test_qp_random_vs_oracle(ctx, oracle, n, m, B):
     assert [int(i) for i in info["iter"]] == [i.iter for i in io]
     assert [int(i) for i in info["status"]] == [i.status for i in io]
     assert [int(i) for i in info["rho_updates"]] == [i.rho_updates for i in io]
-    assert np.abs(x - xo).max() <= 1e-9 and np.abs(y - yo).max() <= 1e-9
-    assert np.abs(info["res_prim"] - [i.res_prim for i in io]).max() <= 1e-9
-    assert np.abs(info["res_dual"] - [i.res_dual for i in io]).max() <= 1e-9
+    assert np.array_equal(x, xo) and np.array_equal(y, yo), (np.abs(x - xo).max(), np.abs(y - yo).max())
+    assert np.array_equal(info["res_prim"], np.array([i.res_prim for i in io])) and np.array_equal(info["res_dual"], np.array([i.res_dual for i in io]))
 
 
 @pytest.mark.parametrize("n,m,B", [(7, 3, 9), (35, 21, 16), (66, 44, 6), (20, 45, 4)])

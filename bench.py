@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="OCP instances per GPU")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="instances per pass of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="minimum wall time of the all-core CPU-baseline sample (single core: half)")
-    ap.add_argument("--configs", default="B,C,D", help="sub-records beside the headline (N = 1 only): any of B, C, D; '' = none")
+    ap.add_argument("--configs", default="B,C,D,R", help="sub-records beside the headline (N = 1 only): any of B, C, D (BASELINE.json configs[2..4]) and R (the reference's own 16-node robot grid, 128 KKT rows); '' = none")
     ap.add_argument("--no-replay", action="store_true", help="skip the QP-only replay record")
     ap.add_argument("--streams", type=int, default=1, help="1 (default, the contract's configuration): every step is one launch on one "
                     "stream. S > 1: consecutive steps alternate over S contexts (own stream, workspace and output buffers), so that a "
@@ -274,6 +274,9 @@ def main():
             if "C" in want:
                 cfg["C_kite_standin_1024"] = sqp_record(workloads.kite_standin_batch(1024), 1024, 2, 1, "sqp_kernel<KiteStandInOCP> (464 KKT rows)")
                 cfg["C_kite_standin_1024"]["workload"] = "SYNTHETIC 13-state / 3-input stand-in (the reference tree has no kite model), P=5 S=3 (16 nodes), SQP max_iter=5"
+            if "R" in want:
+                cfg["R_robot_16_nodes_2048"] = sqp_record(workloads.robot_batch(2048, P=5, S=3), 2048, 3, 1, "sqp_kernel<RobotOCP> (128 KKT rows, HBM-factor kernel)")
+                cfg["R_robot_16_nodes_2048"]["workload"] = "mobile robot on the reference's mpc_wrapper_test grid, P=5 S=3 (16 nodes, n=80, m=48), 2048 instances (not a BASELINE.json configuration: the mid-size path)"
             if cfg:
                 out["configs"] = cfg
             if not args.no_replay:

@@ -110,7 +110,7 @@ def test_qp_reference_known_answers(ctx, oracle):
     assert abs(x[0, 0] - 2.0) <= 2e-2 and info["iter"][0] < 200 and info["status"][0] == pa.QP_SOLVED
 
 
-@pytest.mark.parametrize("n,m,B", [(2, 1, 8), (1, 0, 4), (7, 3, 33), (35, 21, 64), (55, 33, 16), (66, 44, 8), (80, 48, 4), (3, 70, 4), (60, 36, 5), (105, 63, 3), (256, 208, 3)])
+@pytest.mark.parametrize("n,m,B", [(2, 1, 8), (1, 0, 4), (7, 3, 33), (35, 21, 64), (55, 33, 16), (66, 44, 8), (80, 48, 4), (3, 70, 4), (60, 36, 5), (105, 63, 3), (256, 208, 3), (70, 43, 4), (64, 65, 3), (130, 0, 3), (5, 140, 2)])
 def test_qp_random_vs_oracle(ctx, oracle, n, m, B):
     """Random convex QPs of many shapes (incl. ragged n+m > 64, m > n, m = 0): same iteration count, status and
     rho updates as the oracle; x, y and the reported residuals bit-identical (register, two-rows-per-lane, LDS and HBM-factor kernels)."""

@@ -942,3 +942,35 @@ def test_sqp_full_size_properties_config_B(ctx):
     assert viol[ok].max() <= 1e-3
     assert np.abs(X[ok, nn - 1, :] - wl["lbx"][ok, 4 * nn - 4:4 * nn]).max() <= 1e-3
     assert np.all(U[ok, :, 0] >= 3.0 - 1e-3) and np.all(U[ok, :, 0] <= 35.0 + 1e-3) and np.all(U[ok, :, 1] >= -9000.0 - 1e-3) and np.all(U[ok, :, 1] <= 1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["C_kite_standin_1024", "R_robot_16_nodes_2048"])
+def test_sqp_full_size_properties_hbm_factor_kernel(ctx, oracle, case):
+    """BASELINE size of config C (1024 instances of the 464-row stand-in) and 2048 instances on the reference's 16-node robot grid (128 rows), both
+    on the HBM-factor kernel: SOLVED fractions, finite, bounds respected, the reported constraint violation equal to what the SEPARATE collocation
+    kernel (pmpc_ocp_linearise_batch) evaluates at the returned point, and a sample of instances spread over the batch bit-identical to the
+    blocked-order CPU restatement run on those instances alone (the batch position must not matter)."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    if case.startswith("C"):
+        B = 1024; wl = workloads.kite_standin_batch(B); min_solved = 0.99
+    else:
+        B = 2048; wl = workloads.robot_batch(B, P=5, S=3); min_solved = 0.8
+    P, S = wl["P"], wl["S"]
+    ss = pa.sqp_settings_default(); ss.max_iter = wl["max_iter"]; ss.line_search_max_iter = wl["ls_max_iter"]
+    x, lam, info = ctx.sqp_solve_batch(wl["model"], P, S, wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
+    ok = info["status"] == pa.SQP_SOLVED
+    assert ok.mean() >= min_solved and np.all(info["flags"] == 0) and np.all(np.isfinite(x)) and np.all(np.isfinite(lam))
+    viol = np.zeros(B)
+    for b0 in range(0, B, 128):
+        ev = ctx.ocp_linearise_batch(wl["model"], P, S, wl["t0"], wl["tf"], x[b0:b0 + 128], wl["d"][b0:b0 + 128])
+        viol[b0:b0 + 128] = np.abs(ev["c"]).max(axis=1)
+    viol = np.maximum(viol, np.maximum((wl["lbx"] - x).max(axis=1), (x - wl["ubx"]).max(axis=1)))
+    assert np.abs(viol - info["max_violation"]).max() <= 1e-12 * max(1.0, viol.max())
+    assert viol[ok].max() <= ss.eps_prim
+    sample = np.array([0, 1, B // 3, B // 2 + 7, B - 2, B - 1])
+    oss = oracle.sqp_default_settings(); oss.max_iter = wl["max_iter"]; oss.line_search_max_iter = wl["ls_max_iter"]
+    xo, lo, io = oracle.sqp_solve_batch(wl["model"], P, S, wl["t0"], wl["tf"], len(sample), wl["d"][sample], wl["lbx"][sample], wl["ubx"][sample],
+                                        sqp_settings=oss, pivot=oracle.PIVOT_BLOCKED, threads=6)
+    _assert_same_solve(info[sample], io, x[sample], xo, lam[sample], lo)

@@ -87,7 +87,7 @@ typedef struct {
                            * 1 RuizEquilibration (qp_preconditioners.hpp:114-385), applied around every QP (sqp_base.hpp:605-611) */
     int hessian_update;   /* SQPBase::hessian_update_impl: 0 damped BFGS on the whole matrix (bfgs.hpp:23-52, the DENSE default),
                            * 1 the sparsity-preserving block BFGS of ContinuousOCP (continuous_ocp.hpp:2304-2431) that the reference's
-                           * MPC tests plug in (mpc_wrapper_test.cpp:100-105); register-resident specialisations for 7- and 5-node grids like the default, LDS-resident kernels otherwise */
+                           * MPC tests plug in (mpc_wrapper_test.cpp:100-105); register-resident specialisations for 7- and 5-node grids (one KKT row per lane) and 9…13-node grids (two rows per lane) like the default, LDS-resident / HBM-factor kernels otherwise */
     int qp_solver;        /* SQPBase's QPSolver argument: 0 boxADMM (box_admm.hpp, default), 1 ADMM (admm.hpp, OSQP form: (2n+m)-row KKT);
                            * 1 is served by the LDS-resident kernels */
     int line_search;      /* SQPBase::step_size_selection_impl: 0 l1-merit backtracking (sqp_base.hpp:380-419, default), 1 the filter line

@@ -73,7 +73,7 @@ def build_library(force=False, verbose=False, jobs=None):
     (pmpc_api.hip + one pmpc_model_*.hip per built-in OCP), compiled in parallel, then linked."""
     from concurrent.futures import ThreadPoolExecutor
     files = sorted(os.listdir(CSRC))
-    units = [f for f in files if f.endswith(".hip")]
+    units = sorted((f for f in files if f.endswith(".hip")), key=lambda f: (not f.startswith("pmpc_model_"), not f.startswith("pmpc_grids_"), f))   # longest translation units first
     deps = [os.path.join(CSRC, f) for f in files if f.endswith(".hpp")] + [os.path.join(HERE, "..", "include", "polympc_amd.h")]
     newest_hdr = max(os.path.getmtime(d) for d in deps)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

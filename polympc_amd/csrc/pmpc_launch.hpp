@@ -217,7 +217,7 @@ template <class Model> struct LDS_PATH_PROFILED { static constexpr bool value = 
 // Launch the fused SQP kernel for `Model` on DEVICE buffers (asynchronous on the context's stream).
 // Register-resident QP specialisations are selected from the compile-time model dimensions and the runtime node count
 // when the KKT system has at most 64 rows; otherwise the LDS-resident path is used.
-template <class Model, int NNODES>
+template <class Model, int NNODES, bool LEAN = false>   // LEAN: no phase-timer and no block-BFGS specialisation (pmpc_grids.hpp: those requests take the LDS-resident kernel)
 inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* cd, int P, int S, int B, const double* x_guess,
                            const double* lam_guess, const double* d, const double* lbx, const double* ubx, const double* lbg,
                            const double* ubg, const pmpc_sqp_settings* ss, const pmpc_qp_settings* qs, double* Hws, double* Aws, double* x,
@@ -229,8 +229,11 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
         if (P * S + 1 != NNODES) return false;
         const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, 1);
         if (ldsr > lds_limit) return false;
-        auto kern = (ss->hessian_update == 1) ? sqp_kernel<Model, NN_, MM_, false, 1>   // (no phase timers in the block-BFGS specialisation)
-                                              : (phase ? sqp_kernel<Model, NN_, MM_, true> : sqp_kernel<Model, NN_, MM_, false>);
+        if (LEAN && (ss->hessian_update == 1 || phase)) return false;
+        auto kern = sqp_kernel<Model, NN_, MM_, false>;
+        if constexpr (!LEAN)
+            kern = (ss->hessian_update == 1) ? sqp_kernel<Model, NN_, MM_, false, 1>   // (no phase timers in the block-BFGS specialisation)
+                                             : (phase ? sqp_kernel<Model, NN_, MM_, true> : sqp_kernel<Model, NN_, MM_, false>);
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
         const int slice = (slice_state && slice_iters > 0) ? slice_iters : ss->max_iter;
         for (int it = 0; it < ss->max_iter; it += slice)
@@ -244,7 +247,7 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
         if (ldsr > lds_limit) return false;
         auto kern = sqp_kernel<Model, NN_, MM_, false>;
         bool timed = false;
-        if constexpr (LDS_PATH_PROFILED<Model>::value) { if (phase) { kern = sqp_kernel<Model, NN_, MM_, true>; timed = true; } }   // developer builds with phase timers
+        if constexpr (LDS_PATH_PROFILED<Model>::value && !LEAN) { if (phase) { kern = sqp_kernel<Model, NN_, MM_, true>; timed = true; } }   // developer builds with phase timers
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
         const int slice = (slice_state && slice_iters > 0) ? slice_iters : ss->max_iter;
         for (int it = 0; it < ss->max_iter; it += slice)
@@ -256,6 +259,16 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
         return false;
     }
 }
+
+// Register-resident specialisations for further node counts live in their own translation units (pmpc_grids_*.hip, built-in models only: a user OCP's
+// translation unit instantiates the three grids below and takes the LDS / HBM-factor kernels elsewhere). Same arguments and meaning as try_launch_reg.
+template <class Model> struct EXTRA_GRIDS { static constexpr bool value = false; };
+template <class Model>
+bool try_launch_extra_grids(pmpc_context* ctx, const Model& mdl, const ChebData* cd, int P, int S, int B, const double* x_guess,
+                            const double* lam_guess, const double* d, const double* lbx, const double* ubx, const double* lbg,
+                            const double* ubg, const pmpc_sqp_settings* ss, const pmpc_qp_settings* qs, double* Hws, double* Aws, double* x,
+                            double* lam, pmpc_sqp_info* info, hipStream_t stream, size_t lds_limit, unsigned long long* phase, pmpc_status* st,
+                            double* slice_state, int slice_iters);
 
 template <class Model>
 inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, int S, double t0, double tf, int B, const double* x_guess,
@@ -283,6 +296,9 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
         if (try_launch_reg<Model, 7>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;
         if (try_launch_reg<Model, 5>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;
         if (try_launch_reg<Model, 11>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;   // config B / the reference's P = 5, S = 2 grids: 88..110 KKT rows
+        if constexpr (EXTRA_GRIDS<Model>::value) {   // 3-, 4-, 6-, 8-, 9-, 10-, 12- and 13-node grids of the built-in models
+            if (try_launch_extra_grids<Model>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;
+        }
     }
     size_t lds = sqp_kernel_lds_bytes<Model>(P, S, 0, ss->qp_solver) + sqp_eig_lds_bytes<Model>(P, S, ss);
     double* Kws = nullptr;

@@ -42,9 +42,12 @@ def _lds_order(oracle, rows, qp_entry=False):
 REG2_QP_SHAPES = ((66, 44), (55, 33))   # QP entry point: two-rows-per-lane register specialisations (pmpc_qp_reg2.hip)
 
 
-def _gpu_order(oracle, n, m, nodes=None):
+REG_NODE_COUNTS = (3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)   # grids of the built-in models with register-resident SQP kernels (pmpc_launch.hpp, pmpc_grids.hpp)
+
+
+def _gpu_order(oracle, n, m, nodes=None, block_bfgs=False):
     """Which of the oracle's GPU-order linear-solve restatements mirrors the kernel that serves this size: the register-resident QP
-    (compile-time sizes with n+m <= 64: the (35, 21) QP entry point, SQP grids of 7 or 5 nodes) applies the inverse swept in blocks of
+    (compile-time sizes with n+m <= 64: the (35, 21) QP entry point, SQP grids of 3 to 8 nodes) applies the inverse swept in blocks of
     four pivots (PIVOT_SWEEP); the two-rows-per-lane register path (65..112 rows: the (66, 44) and (55, 33) QP entry points) the same sweep with
     its own mat-vec order (PIVOT_SWEEP2); every other size runs an LDS/HBM-resident kernel (_lds_order: PIVOT_STATIC). All of them are tied to the
     reference's pivoted Eigen LDLT (PIVOT_EIGEN) in tests/test_oracle_pins.py."""
@@ -52,9 +55,9 @@ def _gpu_order(oracle, n, m, nodes=None):
         if (n, m) in REG2_QP_SHAPES:
             return oracle.PIVOT_SWEEP2
         return oracle.PIVOT_SWEEP if (n, m) == (35, 21) else _lds_order(oracle, n + m, qp_entry=True)
-    if n + m <= 64 and nodes in (5, 7):
+    if n + m <= 64 and nodes in ((5, 7) if block_bfgs else REG_NODE_COUNTS):   # (the block-BFGS one-row-per-lane specialisation exists for 5 and 7 nodes)
         return oracle.PIVOT_SWEEP
-    if 64 < n + m <= 112 and nodes == 11:      # SQP grids of 11 nodes (P = 5, S = 2): two-rows-per-lane register path
+    if 64 < n + m <= 112 and nodes in REG_NODE_COUNTS:      # two-rows-per-lane register path (the Hessian update is a run-time choice there)
         return oracle.PIVOT_SWEEP2
     return _lds_order(oracle, n + m)
 
@@ -433,7 +436,7 @@ def _sqp_both(ctx, oracle, wl, B, **kw):
     #  order; hessian_update = 1 has register-resident specialisations like the default)
     if kw.get("qp_solver", 0): order = oracle.PIVOT_STATIC
     elif kw.get("preconditioner", 0) or kw.get("line_search", 0): order = _lds_order(oracle, dm["n"] + dm["m"])
-    else: order = _gpu_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1)
+    else: order = _gpu_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, block_bfgs=bool(kw.get("hessian_update", 0)))
     xo, lo, io = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"],
                                         sqp_settings=oss, pivot=order, threads=8)
     return (x, lam, info), (xo, lo, io)
@@ -822,6 +825,28 @@ def test_sqp_iteration_records_vs_oracle(ctx, oracle, P, S, B):
             ctx.sqp_solve_batch(wl["model"], P, S, wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
     finally:
         ctx.iteration_trace_destroy(h)
+
+
+@pytest.mark.parametrize("model,P,S", [(0, 3, 1), (0, 5, 1), (0, 7, 1), (0, 2, 1), (0, 4, 2), (0, 3, 3), (0, 11, 1), (0, 4, 3), (1, 5, 1), (1, 4, 2), (1, 3, 1)])
+def test_sqp_register_paths_on_other_grids(ctx, oracle, model, P, S):
+    """Register-resident SQP kernels beyond the 5-, 7- and 11-node grids (pmpc_grids_*.hip): robot on 4, 6, 8 and 3 nodes (one KKT row per lane) and
+    on 9, 10, 12 and 13 nodes (72 .. 104 rows, two rows per lane); CSTR on 6 nodes (60 rows), 9 nodes (90 rows) and 4 nodes. Identical trajectories and
+    bit-identical solutions against the sweep-order restatements; the block BFGS on such a grid takes the LDS-resident kernel (static order) below 65
+    rows and stays on the two-rows-per-lane kernel above."""
+    from polympc_amd import workloads
+    B = 12
+    nn = P * S + 1
+    if model == 0:
+        wl = workloads.robot_batch(B, P=P, S=S)
+    else:
+        lbx, ubx = _cstr_grid(B, P, S)
+        wl = dict(model=1, P=P, S=S, t0=0.0, tf=100.0, d=np.zeros((B, 1)), lbx=lbx, ubx=ubx, max_iter=8, ls_max_iter=20)
+    dm = oracle.ocp_dims(model, P, S)
+    assert nn in REG_NODE_COUNTS and dm["n"] + dm["m"] <= 112
+    (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, wl, B)
+    _assert_same_solve(info, io, x, xo, lam, lo)
+    (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, wl, B, hessian_update=1)
+    _assert_same_solve(info, io, x, xo, lam, lo)
 
 
 def test_sqp_warm_start_and_gershgorin(ctx, oracle):

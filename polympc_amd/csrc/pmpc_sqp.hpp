@@ -421,8 +421,7 @@ struct SqpDevice {
             return;
         }
         for (int j = lane_id(); j < n; j += WAVE) {
-            double a = 0.0;
-            for (int i = 0; i < m; ++i) a += Aw[(size_t)j * ldw + i] * v.lam[i];
+            double a = seq_dot_strided(Aw, 1, (size_t)ldw, j, m, v.lam);   // column j of J against lam: one add chain, rows ascending, eight loads in flight
             a += v.h[j];
             a += v.lam[m + j];
             out[j] = a;
@@ -701,9 +700,7 @@ struct SqpDevice {
         const int VARX = ocp.dm.VARX, VARU = ocp.dm.VARU, NNo = ocp.dm.NN;
         double* vv = v.t1; double* r = v.t2; double* y = v.t3;
         for (int i = ln; i < n; i += WAVE) {
-            double a = 0.0;
-            for (int j = 0; j < n; ++j) a += Hw[(size_t)j * ldw + i] * v.step[j];
-            vv[i] = a;
+            vv[i] = seq_dot_strided(Hw, (size_t)ldw, 1, i, n, v.step);   // row i of B times s: one add chain, columns ascending, eight loads in flight
             y[i] = v.lgn[i] - v.lg[i];
         }
         wsync();

@@ -27,6 +27,7 @@
 // (factor + two substitution passes per ADMM iteration: 1.7 MB per iteration and instance).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "pmpc_qp.hpp"
 #include "pmpc_qp_reg.hpp"
 
@@ -102,11 +103,12 @@ __device__ __forceinline__ void big_build(double* W, int n, int m, const double*
 }
 
 // in-place blocked LDL^T of the tiles in W (see the header). dl: BigKkt::LDS_DOUBLES doubles of LDS.
-// LEFT-LOOKING schedule: block column J first receives the rank-16 updates of ALL earlier block columns k < J (accumulator tiles stay in
-// registers while k runs: per update one A operand tile from the CF strip of k and a quarter of a B operand tile from the LF panel of k are read),
-// then its diagonal tile is factorised and the rows below apply the 16 pivots. Every entry still receives fma(-c_ik, l_jk, a_ij) for k ascending
-// — the right-looking schedule's operations in the right-looking schedule's order — but a tile is read and written ONCE instead of once per earlier
-// block column (config C: 48 GB of the 220 GB a launch moved were those writes).
+// LEFT-LOOKING schedule, two block columns at a time: block columns J and J + 1 first receive the rank-16 updates of ALL earlier block columns k < J
+// together (accumulator tiles of both columns stay in registers while k runs: per k and group of four tile rows, four A operand tiles from the CF
+// strip of k and one B operand tile per column from the LF panel of k feed 32 MFMA — 12 KB per 32 MFMA, where one column at a time needs 20 KB and the
+// right-looking schedule re-read and re-wrote every tile per k); then column J is finished (diagonal tile, the rows below apply the 16 pivots), column
+// J + 1 takes its last update (k = J) and is finished. Every entry still receives fma(-c_ik, l_jk, a_ij) for k ascending — the right-looking
+// schedule's operations in the right-looking schedule's order.
 __device__ __forceinline__ void big_factor(double* W, int N, double* dl) {
     const int ln = lane_id();
     const int nb = BigKkt::nblk(N), NPAD = nb * 16;
@@ -115,63 +117,81 @@ __device__ __forceinline__ void big_factor(double* W, int N, double* dl) {
     double* LF = W + nt * 256;
     double* CF = LF + BigKkt::offF(nb, NPAD);
     const int lr = ln >> 4, lc = ln & 15;
-    size_t oF = 0;
-    for (int J = 0; J < nb; oF += BigKkt::sizeF(J, NPAD), ++J) {
-        double* pF = LF + oF;   // forward panel of block column J
-        // ---- (u) tiles (I, J), I >= J: T += sum_k (-C_I^k) * (L_J^k)^T, k ascending, four v_mfma_f64_16x16x4_f64 per k. Tile rows in groups of
-        // four; the operands of k + 1 are requested before the matrix cores work on k.
-        if (J > 0) {
-            for (int I0 = J; I0 < nb; I0 += 4) {
-                big_d4 T[4];
-                int rowI[4];
+
+    // tiles (I, Jc + c), c < NC, I in [I_first, I_end): T += sum_{k in [k0, k1)} (-C_I^k) * (L_{Jc+c}^k)^T, k ascending, four v_mfma_f64_16x16x4_f64 per k and
+    // tile. Tile rows in groups of GI; the operands of k + 1 are requested before the matrix cores work on k.
+    auto update_cols = [&](auto nc_tag, auto gi_tag, int Jc, int I_first, int I_end, int k0, int k1) {
+        constexpr int NC = decltype(nc_tag)::value, GI = decltype(gi_tag)::value;
+        if (k1 <= k0) return;
+        for (int I0 = I_first; I0 < I_end; I0 += GI) {
+            big_d4 T[NC][GI];
+            int rowI[GI];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int I = (I0 + g < nb) ? I0 + g : nb - 1;   // (a group's missing tiles repeat its last one; their result is dropped)
-                    rowI[g] = 16 * I + lc;
-                    const double* tt = Lr + (size_t)BigKkt::tidx(I, J) * 256;
+            for (int g = 0; g < GI; ++g) {
+                const int I = (I0 + g < I_end) ? I0 + g : I_end - 1;   // (a group's missing tiles repeat its last one; their result is dropped)
+                rowI[g] = 16 * I + lc;
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) T[g][rg] = tt[64 * rg + ln];
+                for (int c = 0; c < NC; ++c) {
+                    const double* tt = Lr + (size_t)BigKkt::tidx(I, Jc + c) * 256;
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) T[c][g][rg] = tt[64 * rg + ln];
                 }
-                double av[4][4], bv[4];
-                auto load_ops = [&](int k, double (&a)[4][4], double (&b)[4]) {
-                    const double* cs = CF + BigKkt::offC(k, NPAD);
-                    const int w = NPAD - 16 * (k + 1);
-                    const double* pk = LF + BigKkt::offF(k, NPAD);
+            }
+            double av[GI][4], bv[NC][4];
+            auto load_ops = [&](int k, double (&a)[GI][4], double (&b)[NC][4]) {
+                const double* cs = CF + BigKkt::offC(k, NPAD);
+                const int w = NPAD - 16 * (k + 1);
+                const double* pk = LF + BigKkt::offF(k, NPAD);
 #pragma unroll
-                    for (int sx = 0; sx < 4; ++sx) b[sx] = pk[BigKkt::slab(4 * sx + lr, 16 * (J - k) + lc)];   // B(kk = 4s + lr, col = lc) = L(16J + lc, 16k + 4s + lr)
+                for (int c = 0; c < NC; ++c)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
+                    for (int sx = 0; sx < 4; ++sx) b[c][sx] = pk[BigKkt::slab(4 * sx + lr, 16 * (Jc + c - k) + lc)];   // B(kk = 4s + lr, col = lc) = L(16(Jc+c) + lc, 16k + 4s + lr)
 #pragma unroll
-                        for (int sx = 0; sx < 4; ++sx) a[g][sx] = cs[(size_t)(4 * sx + lr) * w + rowI[g] - 16 * (k + 1)];
-                };
-                load_ops(0, av, bv);
-                for (int k = 0; k < J; ++k) {
-                    double an[4][4], bn[4];
-                    load_ops((k + 1 < J) ? k + 1 : k, an, bn);
+                for (int g = 0; g < GI; ++g)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
+                    for (int sx = 0; sx < 4; ++sx) a[g][sx] = cs[(size_t)(4 * sx + lr) * w + rowI[g] - 16 * (k + 1)];
+            };
+            load_ops(k0, av, bv);
+            for (int k = k0; k < k1; ++k) {
+                double an[GI][4], bn[NC][4];
+                load_ops((k + 1 < k1) ? k + 1 : k, an, bn);
 #pragma unroll
-                        for (int sx = 0; sx < 4; ++sx) T[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g][sx], bv[sx], T[g], 0, 0, 0);
+                for (int c = 0; c < NC; ++c)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
+                    for (int g = 0; g < GI; ++g)
 #pragma unroll
-                        for (int sx = 0; sx < 4; ++sx) av[g][sx] = an[g][sx];
+                        for (int sx = 0; sx < 4; ++sx) T[c][g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g][sx], bv[c][sx], T[c][g], 0, 0, 0);
 #pragma unroll
-                    for (int sx = 0; sx < 4; ++sx) bv[sx] = bn[sx];
-                }
+                for (int g = 0; g < GI; ++g)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int I = I0 + g;
-                    if (I < nb) {
-                        double* tt = Lr + (size_t)BigKkt::tidx(I, J) * 256;
+                    for (int sx = 0; sx < 4; ++sx) av[g][sx] = an[g][sx];
 #pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) tt[64 * rg + ln] = T[g][rg];
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int sx = 0; sx < 4; ++sx) bv[c][sx] = bn[c][sx];
+            }
+#pragma unroll
+            for (int g = 0; g < GI; ++g) {
+                const int I = I0 + g;
+                if (I < I_end) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        double* tt = Lr + (size_t)BigKkt::tidx(I, Jc + c) * 256;
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) tt[64 * rg + ln] = T[c][g][rg];
                     }
                 }
             }
-            wfence();
-            wsync();
         }
+    };
+    using one = std::integral_constant<int, 1>;
+    using two = std::integral_constant<int, 2>;
+    using four = std::integral_constant<int, 4>;
+    constexpr int PAIR_MIN_BLOCKS = 16;
+
+    // diagonal tile of block column J, then the rows below it: LF panel J and CF strip J
+    auto finish_column = [&](int J) {
+        double* pF = LF + BigKkt::offF(J, NPAD);
         // ---- (a) diagonal tile: right-looking LDL^T on 16 lanes (lane r = row r of the tile)
         {
             double* td = Lr + (size_t)BigKkt::tidx(J, J) * 256;
@@ -199,7 +219,7 @@ __device__ __forceinline__ void big_factor(double* W, int N, double* dl) {
             wfence();
             wsync();
         }
-        if (J == nb - 1) break;
+        if (J == nb - 1) return;
         // ---- (b) rows below the diagonal tile: 16 pivots applied to the row's own 16 entries (one lane per row)
         double* cs = CF + BigKkt::offC(J, NPAD);
         const int w = NPAD - 16 * (J + 1);
@@ -228,6 +248,29 @@ __device__ __forceinline__ void big_factor(double* W, int N, double* dl) {
         }
         wfence();
         wsync();
+    };
+
+    if (nb < PAIR_MIN_BLOCKS) {   // few block columns: one at a time (the extra passes of the paired schedule cost more than the operands they save: 128 rows +4 %)
+        for (int J = 0; J < nb; ++J) {
+            if (J > 0) { update_cols(one{}, four{}, J, J, nb, 0, J); wfence(); wsync(); }
+            finish_column(J);
+        }
+        return;
+    }
+    for (int J = 0; J < nb; J += 2) {
+        const bool pair = J + 1 < nb;
+        if (J > 0) {
+            update_cols(one{}, one{}, J, J, J + 1, 0, J);               // tile (J, J): the only tile of row J in this pair
+            if (pair) update_cols(two{}, four{}, J, J + 1, nb, 0, J);   // rows J + 1 .. : both columns
+            wfence();
+            wsync();
+        }
+        finish_column(J);
+        if (!pair) break;
+        update_cols(one{}, four{}, J + 1, J + 1, nb, J, J + 1);         // column J + 1: its last update, k = J
+        wfence();
+        wsync();
+        finish_column(J + 1);
     }
 }
 

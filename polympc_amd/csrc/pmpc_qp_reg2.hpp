@@ -353,6 +353,11 @@ __device__ __forceinline__ void boxadmm_solve_reg2(const double* __restrict__ H,
             return isP[e] ? v : 0.0;
         }
     };
+    constexpr bool XT = (NN > 64) && (NN - 64 <= 4) && (NN - 64 + MM <= 64);   // see the residual evaluation: few primal rows in the second slot, every constraint row there too
+    auto AcolAt = [&](int k, int col, int zo) -> double {   // A(k, col) for a per-lane k and a uniform column (col < NN)
+        if constexpr (STACKED) { unsigned b = (unsigned)col * (unsigned)N + (unsigned)NN + (unsigned)k + (unsigned)zo; asm("" : "+v"(b)); return H[b]; }
+        else return A[(size_t)col * MM + (unsigned)(k + zo)];
+    };
     auto xbc = [&](const double (&v)[2], int j) -> double { return (j < 64) ? bcast_lane(v[0], j & 63) : bcast_lane(v[1], (j - 64) & 63); };   // entry j of a two-slot vector
 
     // state: xv = x (primal rows) / z (constraint rows); yv = y_box / y_a; qv = q (primal rows)
@@ -462,7 +467,23 @@ __device__ __forceinline__ void boxadmm_solve_reg2(const double* __restrict__ H,
                         for (int j = 0; j < RC; ++j) if (j0 + j < NN) acc[e] += mm[j] * xbc(xv, j0 + j);
                         sched_fence();
                     }
-                    if (e == 0 || NN > 64) {
+                    if (e == 1 && NN > 64 && XT) {
+                        // The few primal rows of the second slot (config B: rows 64 and 65) need sum_k A(k, row) y_k too. A batch of MM loads per lane for
+                        // two live lanes cost two memory round trips per check: instead the lane that OWNS y_k (constraint row k sits on lane NN - 64 + k of
+                        // this slot) loads A(k, row) — one coalesced load per row — and forms the product; the products are then added in ascending k on
+                        // every lane (v_readlane broadcasts): the same products in the same order.
+#pragma unroll
+                        for (int t = 0; t < NN - 64; ++t) {
+                            const int kk = (int)lane_near(zr) - (NN - 64);
+                            const bool own = kk >= 0 && kk < MM;
+                            const double av = AcolAt(own ? kk : 0, 64 + t, zr);
+                            const double prod = av * yv[1];
+                            double sacc = 0.0;
+#pragma unroll
+                            for (int k = 0; k < MM; ++k) sacc += bcast_lane(prod, NN - 64 + k);
+                            aty[1] = ((int)lane_near(zr) == t) ? sacc : aty[1];
+                        }
+                    } else if (e == 0 || NN > 64) {
 #pragma unroll
                         for (int k0 = 0; k0 < MM; k0 += RC) {
                             double mm[RC];

@@ -448,7 +448,10 @@ __device__ __forceinline__ void boxadmm_solve_reg2(const double* __restrict__ H,
             if (s.adaptive_rho) { until_adapt -= nrun; if (until_adapt == 0) { adapt = true; until_adapt = s.adaptive_rho_interval; } }
             if (check || adapt) {  // residuals_update, box_admm.hpp:398-415: one add chain per row, columns ascending
                 const long long r0 = dbg ? clock64() : 0;
-                constexpr int RC = 24;
+#ifndef PMPC_REG2_RC
+#define PMPC_REG2_RC 22   /* measured on config B: 11 / 17 / 22 / 24 / 33 / 44 loads per batch -> 47.9 / 45.4 / 41.0 / 43.5 / 42.9 / 51.0 ms */
+#endif
+                constexpr int RC = PMPC_REG2_RC;
                 int zr = 0;
                 asm volatile("" : "+v"(zr));
                 double parked[RegKkt2<N>::NPARK];

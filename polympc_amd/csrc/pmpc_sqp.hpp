@@ -399,8 +399,23 @@ struct SqpDevice {
             return;
         }
         if constexpr (REG2) {   // compile-time sizes, columns lane and lane + 64: the loads of a column in batches, then the same add chain
+            constexpr bool FEW = NN > WAVE && NN - WAVE <= 4 && MM <= WAVE;   // a few columns in the second slot (config B: 64 and 65): lane i loads J(i, column)
+            if constexpr (FEW) {                                              // and forms the product with lam_i, the products are added in ascending i on every lane
+#pragma unroll                                                                // (v_readlane) — instead of MM loads per lane for two live lanes
+                for (int t = 0; t < NN - WAVE; ++t) {
+                    const int i = lane_id() < MM ? lane_id() : 0;
+                    const unsigned o = (unsigned)(WAVE + t) * (NN + MM) + (unsigned)i + opaque_zero();
+                    const double prod = Aw[o] * v.lam[i];
+                    double a = 0.0;
 #pragma unroll
-            for (int e = 0; e < (NN > WAVE ? 2 : 1); ++e) {
+                    for (int k = 0; k < MM; ++k) a += bcast_lane(prod, k);
+                    a += v.h[WAVE + t];
+                    a += v.lam[MM + WAVE + t];
+                    if (lane_id() == t) out[WAVE + t] = a;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < ((NN > WAVE && !FEW) ? 2 : 1); ++e) {
                 const int col = lane_id() + 64 * e;
                 const int j = col < NN ? col : 0;
                 const unsigned jo = (unsigned)j * (NN + MM) + opaque_zero();

@@ -262,12 +262,23 @@ pmpc_status pmpc_qp_boxadmm_solve_batch_dev(pmpc_context* ctx, int B, int n, int
     HIPCHK(hipSetDevice(ctx->device));
     if (settings->linear_solver != 0 && settings->linear_solver != 1) return PMPC_ERR_INVALID_ARGUMENT;
     const bool static_order = settings->linear_solver == 0 && !ctx->force_lds_path;   // the register-resident specialisations factorise in a static order
-    if (n == 35 && m == 21 && static_order) {   // config A: register-resident specialisation
-        hipLaunchKernelGGL((qp_boxadmm_reg_kernel<35, 21>), dim3(B), dim3(WAVE), 0, ctx->stream, B, H, h, A, Alb, Aub, xlb, xub, x0, y0,
-                           *settings, x, y, info);
-        HIPCHK(hipGetLastError());
-        return PMPC_OK;
+    // register-resident specialisations (one KKT row per lane): config A's QP and the QPs of the robot / CSTR grids of 4 to 8 nodes
+#define PMPC_REG1_CASE(NN_, MM_)                                                                                                             \
+    if (n == NN_ && m == MM_ && static_order) {                                                                                              \
+        hipLaunchKernelGGL((qp_boxadmm_reg_kernel<NN_, MM_>), dim3(B), dim3(WAVE), 0, ctx->stream, B, H, h, A, Alb, Aub, xlb, xub, x0, y0,   \
+                           *settings, x, y, info);                                                                                           \
+        HIPCHK(hipGetLastError());                                                                                                           \
+        return PMPC_OK;                                                                                                                      \
     }
+    PMPC_REG1_CASE(35, 21)
+    PMPC_REG1_CASE(20, 12)
+    PMPC_REG1_CASE(25, 15)
+    PMPC_REG1_CASE(30, 18)
+    PMPC_REG1_CASE(40, 24)
+    PMPC_REG1_CASE(24, 16)
+    PMPC_REG1_CASE(30, 20)
+    PMPC_REG1_CASE(36, 24)
+#undef PMPC_REG1_CASE
     if (static_order) {   // 65..112 KKT rows with a two-rows-per-lane register specialisation (pmpc_qp_reg2.hip)
         const int r2 = pmpc_internal_qp_reg2_launch((void*)ctx->stream, B, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0, settings, x, y, info);
         if (r2 < 0) return PMPC_ERR_HIP;

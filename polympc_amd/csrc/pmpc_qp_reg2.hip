@@ -1,5 +1,6 @@
 // polympc_amd — batched boxADMM::solve on the two-rows-per-lane register path (65..112 KKT rows, pmpc_qp_reg2.hpp): the QP entry point's
-// specialisations for the sizes of config B (CSTR, 11 nodes: 66 + 44) and of the reference's 11-node robot grid (55 + 33).
+// specialisations for the sizes of config B (CSTR, 11 nodes: 66 + 44), of the reference's 11-node robot grid (55 + 33) and of the other robot / CSTR grids the
+// fused SQP kernel serves on this path (9, 10, 12, 13 nodes).
 #include <hip/hip_runtime.h>
 #include "../../include/polympc_amd.h"
 #include "pmpc_qp_reg2.hpp"
@@ -35,6 +36,12 @@ extern "C" int pmpc_internal_qp_reg2_launch(void* stream, int B, int n, int m, c
     }
     PMPC_REG2_CASE(66, 44)
     PMPC_REG2_CASE(55, 33)
+    PMPC_REG2_CASE(45, 27)   // robot grids of 9, 10, 12 and 13 nodes
+    PMPC_REG2_CASE(50, 30)
+    PMPC_REG2_CASE(60, 36)
+    PMPC_REG2_CASE(65, 39)
+    PMPC_REG2_CASE(54, 36)   // CSTR grids of 9 and 10 nodes
+    PMPC_REG2_CASE(60, 40)
 #undef PMPC_REG2_CASE
     return 0;
 }

@@ -39,7 +39,8 @@ def _lds_order(oracle, rows, qp_entry=False):
     return oracle.PIVOT_BLOCKED if rows >= (QP_BIG_MIN_ROWS if qp_entry else BIG_KKT_MIN_ROWS) else oracle.PIVOT_STATIC
 
 
-REG2_QP_SHAPES = ((66, 44), (55, 33))   # QP entry point: two-rows-per-lane register specialisations (pmpc_qp_reg2.hip)
+REG2_QP_SHAPES = ((66, 44), (55, 33), (45, 27), (50, 30), (60, 36), (65, 39), (54, 36), (60, 40))
+REG1_QP_SHAPES = ((35, 21), (20, 12), (25, 15), (30, 18), (40, 24), (24, 16), (30, 20), (36, 24))   # one KKT row per lane (pmpc_api.hip)   # QP entry point: two-rows-per-lane register specialisations (pmpc_qp_reg2.hip)
 
 
 REG_NODE_COUNTS = (3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)   # grids of the built-in models with register-resident SQP kernels (pmpc_launch.hpp, pmpc_grids.hpp)
@@ -54,7 +55,7 @@ def _gpu_order(oracle, n, m, nodes=None, block_bfgs=False):
     if nodes is None:
         if (n, m) in REG2_QP_SHAPES:
             return oracle.PIVOT_SWEEP2
-        return oracle.PIVOT_SWEEP if (n, m) == (35, 21) else _lds_order(oracle, n + m, qp_entry=True)
+        return oracle.PIVOT_SWEEP if (n, m) in REG1_QP_SHAPES else _lds_order(oracle, n + m, qp_entry=True)
     if n + m <= 64 and nodes in ((5, 7) if block_bfgs else REG_NODE_COUNTS):   # (the block-BFGS one-row-per-lane specialisation exists for 5 and 7 nodes)
         return oracle.PIVOT_SWEEP
     if 64 < n + m <= 112 and nodes in REG_NODE_COUNTS:      # two-rows-per-lane register path (the Hessian update is a run-time choice there)
@@ -113,7 +114,7 @@ def test_qp_reference_known_answers(ctx, oracle):
     assert abs(x[0, 0] - 2.0) <= 2e-2 and info["iter"][0] < 200 and info["status"][0] == pa.QP_SOLVED
 
 
-@pytest.mark.parametrize("n,m,B", [(2, 1, 8), (1, 0, 4), (7, 3, 33), (35, 21, 64), (55, 33, 16), (66, 44, 8), (80, 48, 4), (3, 70, 4), (60, 36, 5), (105, 63, 3), (256, 208, 3), (70, 43, 4), (64, 65, 3), (130, 0, 3), (5, 140, 2)])
+@pytest.mark.parametrize("n,m,B", [(2, 1, 8), (1, 0, 4), (7, 3, 33), (35, 21, 64), (55, 33, 16), (66, 44, 8), (80, 48, 4), (3, 70, 4), (60, 36, 5), (105, 63, 3), (256, 208, 3), (70, 43, 4), (64, 65, 3), (130, 0, 3), (5, 140, 2), (20, 12, 9), (40, 24, 5), (36, 24, 5), (45, 27, 4), (60, 36, 3), (65, 39, 3), (60, 40, 3)])
 def test_qp_random_vs_oracle(ctx, oracle, n, m, B):
     """Random convex QPs of many shapes (incl. ragged n+m > 64, m > n, m = 0): same iteration count, status and
     rho updates as the oracle; x, y and the reported residuals bit-identical (register, two-rows-per-lane, LDS and HBM-factor kernels)."""

@@ -95,6 +95,7 @@ extern "C" pmpc_status pmpc_internal_services(pmpc_context* ctx, int P, int S, d
 }
 
 extern "C" int pmpc_internal_sqp_slice(pmpc_context* ctx) { return ctx ? ctx->sqp_slice : 0; }
+extern "C" int pmpc_internal_simd_count(pmpc_context* ctx) { return ctx ? ctx->simd_count : 1024; }
 
 
 // =====================================================================================================================
@@ -139,6 +140,7 @@ static pmpc_status create_impl(int device, void* stream, pmpc_context* ctx) {
     else { HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
+    ctx->simd_count = 4 * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
     ctx->lds_limit = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 64 * 1024;
     if (prop.sharedMemPerBlockOptin && (size_t)prop.sharedMemPerBlockOptin < ctx->lds_limit) ctx->lds_limit = prop.sharedMemPerBlockOptin;
     { const char* e = getenv("PMPC_LDS_LIMIT"); if (e && e[0] && atol(e) > 0 && (size_t)atol(e) < ctx->lds_limit) ctx->lds_limit = (size_t)atol(e); }   // developer switch: a smaller LDS budget (moves mid-size instances to the HBM-factor kernel)

@@ -20,6 +20,7 @@ struct pmpc_context {
     bool own_stream = false;
     size_t lds_limit = 64 * 1024;
     unsigned long long* phase_cycles = nullptr;   // PMPC_PHASE_PROFILE=1: per-phase shader-clock totals of the SQP kernels
+    int simd_count = 1024;         // compute units x 4
     int sqp_slice = 0;             // PMPC_SQP_SLICE=k: run k SQP iterations per kernel launch with per-instance state in HBM (finished
                                    // instances free their slots); 0 (default) = whole solve in one launch — measured faster on config A
     bool force_lds_path = false;   // PMPC_FORCE_LDS_PATH=1: disable the register-resident specialisations (A/B testing)

@@ -13,6 +13,7 @@
 // context services exported by libpolympc_amd.so (collocation constants cache, HBM workspace, stream, limits)
 extern "C" pmpc_status pmpc_internal_services(pmpc_context* ctx, int P, int S, double t0, double tf, size_t ws_bytes, const void** cheb,
                                                double** ws, void** stream, size_t* lds_limit, unsigned long long** phase_cycles, int* force_lds);
+extern "C" int pmpc_internal_simd_count(pmpc_context* ctx);   // SIMDs of the device (compute units x 4)
 extern "C" int pmpc_internal_sqp_slice(pmpc_context* ctx);   // SQP iterations per kernel launch (0 = whole solve in one launch)
 
 namespace pmpc {
@@ -36,14 +37,14 @@ template <class Model> __host__ __device__ inline size_t big_scratch_doubles(int
 // KHBM: large-instance mode of the LDS-resident kernels — the KKT factor lives in an HBM workspace (Kws). A compile-time flag so
 // that in the normal mode every QP pointer provably addresses LDS (ds_read / ds_write instead of flat accesses, which cost the
 // LDS path most of its time when the location of K was a run-time choice)
-template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bool KHBM = false>
+template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bool KHBM = false, bool W2 = false>   // W2: the HBM-factor kernel compiled for two wavefronts per SIMD (256 registers)
 #ifndef PMPC_SQP_WAVES
 #define PMPC_SQP_WAVES 2
 #endif
 #ifndef PMPC_BIG_WAVES
 #define PMPC_BIG_WAVES 1
 #endif
-__global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (KHBM ? PMPC_BIG_WAVES : 1))) void sqp_kernel(Model model, const ChebData* __restrict__ cd, int B,
+__global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : ((KHBM && W2) ? 2 : (KHBM ? PMPC_BIG_WAVES : 1)))) void sqp_kernel(Model model, const ChebData* __restrict__ cd, int B,
                                                  const double* __restrict__ x_guess, const double* __restrict__ lam_guess,
                                                  const double* __restrict__ d, const double* __restrict__ lbx,
                                                  const double* __restrict__ ubx, const double* __restrict__ lbg,
@@ -155,6 +156,7 @@ template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode
     return ((mode == 0 ? QpLds::doubles(dm.n, dm.m) : QpLds::doubles_xy(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8 +
             ((mode == 1 || mode == 3) ? 0 : FILTER_LDS_DOUBLES) + (mode == 2 ? BigKkt::LDS_DOUBLES : 0)) * sizeof(double);
 }
+constexpr int BIG_TWO_WAVES_MAX_ROWS = 200;   // below: two wavefronts per SIMD on the HBM-factor kernel when the batch exceeds the SIMD count (see sqp_launch_dev)
 constexpr int BIG_KKT_MIN_ROWS = 96;   // n + m from which sqp_launch_dev prefers the HBM-factor kernel (see there)
 template <class Model> inline bool sqp_hbm_mode_fits(int P, int S) {   // do the QP vectors fit the second-order staging?
     OcpDims<Model> dm(P, S);
@@ -318,6 +320,10 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
         Hws = ws; Aws = ws + (size_t)B * dm.n * dm.n; slice_state = Aws + (size_t)B * dm.m * dm.n; Kws = ws + base;
     }
     auto lkern = Kws ? sqp_kernel<Model, 0, 0, false, 0, true> : sqp_kernel<Model>;
+    // Mid-size instances on the HBM-factor kernel stream little per wavefront: with more instances than SIMDs a second wavefront per SIMD (a 256-register
+    // build of the same kernel) hides part of that latency — per 4096 robots 128 rows 40.5 -> 35.4 ms, 168 rows 64.3 -> 60.8; at config C's 464 rows
+    // the second wave only thrashes the L2 (2048 instances 93.0 -> 99.1 ms), hence the row bound.
+    if (Kws && dm.n + dm.m < BIG_TWO_WAVES_MAX_ROWS && B > pmpc_internal_simd_count(ctx) && !phase) lkern = sqp_kernel<Model, 0, 0, false, 0, true, true>;
     if constexpr (LDS_PATH_PROFILED<Model>::value) { if (phase) lkern = Kws ? sqp_kernel<Model, 0, 0, true, 0, true> : sqp_kernel<Model, 0, 0, true>; }   // developer builds with phase timers
     if (hipFuncSetAttribute((const void*)lkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PMPC_ERR_HIP;
     const int slice = (slice_iters > 0) ? slice_iters : ss->max_iter;

@@ -1,4 +1,4 @@
-// polympc_amd — register-resident specialisations of the fused SQP kernel for further node counts of the built-in models: 3, 4, 6, 8, 9, 10, 12 and 13 nodes — one KKT row
+// polympc_amd — register-resident specialisations of the fused SQP kernel for further node counts of the built-in models: 3, 4, 6, 8, 9, 10, 12, 13 and 14 nodes — one KKT row
 // per lane (pmpc_qp_reg.hpp) where n + m <= 64, two rows per lane (pmpc_qp_reg2.hpp) where 64 < n + m <= 112, nothing where the system is larger. The 5-, 7- and
 // 11-node grids are part of every model's own translation unit (pmpc_launch.hpp); these compile in parallel to them, one translation unit per model
 // (pmpc_grids_*.hip), without the phase-timer and block-BFGS variants (such requests take the LDS-resident kernel).
@@ -27,6 +27,7 @@ bool try_launch_extra_grids(pmpc_context* ctx, const Model& mdl, const ChebData*
     PMPC_TRY_GRID(10)
     PMPC_TRY_GRID(12)
     PMPC_TRY_GRID(13)
+    PMPC_TRY_GRID(14)
 #undef PMPC_TRY_GRID
     return false;
 }

@@ -43,7 +43,7 @@ REG2_QP_SHAPES = ((66, 44), (55, 33), (45, 27), (50, 30), (60, 36), (65, 39), (5
 REG1_QP_SHAPES = ((35, 21), (20, 12), (25, 15), (30, 18), (40, 24), (24, 16), (30, 20), (36, 24))   # one KKT row per lane (pmpc_api.hip)   # QP entry point: two-rows-per-lane register specialisations (pmpc_qp_reg2.hip)
 
 
-REG_NODE_COUNTS = (3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)   # grids of the built-in models with register-resident SQP kernels (pmpc_launch.hpp, pmpc_grids.hpp)
+REG_NODE_COUNTS = (3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14)   # grids of the built-in models with register-resident SQP kernels (pmpc_launch.hpp, pmpc_grids.hpp)
 
 
 def _gpu_order(oracle, n, m, nodes=None, block_bfgs=False):
@@ -828,7 +828,7 @@ def test_sqp_iteration_records_vs_oracle(ctx, oracle, P, S, B):
         ctx.iteration_trace_destroy(h)
 
 
-@pytest.mark.parametrize("model,P,S", [(0, 3, 1), (0, 5, 1), (0, 7, 1), (0, 2, 1), (0, 4, 2), (0, 3, 3), (0, 11, 1), (0, 4, 3), (1, 5, 1), (1, 4, 2), (1, 3, 1)])
+@pytest.mark.parametrize("model,P,S", [(0, 3, 1), (0, 5, 1), (0, 7, 1), (0, 2, 1), (0, 4, 2), (0, 3, 3), (0, 11, 1), (0, 4, 3), (0, 13, 1), (1, 5, 1), (1, 4, 2), (1, 3, 1)])
 def test_sqp_register_paths_on_other_grids(ctx, oracle, model, P, S):
     """Register-resident SQP kernels beyond the 5-, 7- and 11-node grids (pmpc_grids_*.hip): robot on 4, 6, 8 and 3 nodes (one KKT row per lane) and
     on 9, 10, 12 and 13 nodes (72 .. 104 rows, two rows per lane); CSTR on 6 nodes (60 rows), 9 nodes (90 rows) and 4 nodes. Identical trajectories and

@@ -95,6 +95,7 @@ extern "C" pmpc_status pmpc_internal_services(pmpc_context* ctx, int P, int S, d
 }
 
 extern "C" int pmpc_internal_sqp_slice(pmpc_context* ctx) { return ctx ? ctx->sqp_slice : 0; }
+extern "C" int pmpc_internal_sqp_rr(pmpc_context* ctx) { return ctx ? ctx->sqp_rr : 0; }
 extern "C" int pmpc_internal_simd_count(pmpc_context* ctx) { return ctx ? ctx->simd_count : 1024; }
 
 
@@ -146,6 +147,7 @@ static pmpc_status create_impl(int device, void* stream, pmpc_context* ctx) {
     { const char* e = getenv("PMPC_LDS_LIMIT"); if (e && e[0] && atol(e) > 0 && (size_t)atol(e) < ctx->lds_limit) ctx->lds_limit = (size_t)atol(e); }   // developer switch: a smaller LDS budget (moves mid-size instances to the HBM-factor kernel)
     { const char* e = getenv("PMPC_FORCE_LDS_PATH"); ctx->force_lds_path = (e && e[0] == '1'); }
     { const char* e = getenv("PMPC_SQP_SLICE"); if (e && e[0]) ctx->sqp_slice = atoi(e) < 0 ? 0 : atoi(e); }
+    { const char* e = getenv("PMPC_SQP_RR"); if (e && e[0]) ctx->sqp_rr = atoi(e) != 0 ? 1 : 0; }
     { const char* e = getenv("PMPC_PHASE_PROFILE");
       if (e && e[0] == '1') { HIPCHK(hipMalloc((void**)&ctx->phase_cycles, 24 * sizeof(unsigned long long))); HIPCHK(hipMemset(ctx->phase_cycles, 0, 24 * sizeof(unsigned long long))); } }
     return PMPC_OK;

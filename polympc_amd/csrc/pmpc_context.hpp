@@ -23,6 +23,8 @@ struct pmpc_context {
     int simd_count = 1024;         // compute units x 4
     int sqp_slice = 0;             // PMPC_SQP_SLICE=k: run k SQP iterations per kernel launch with per-instance state in HBM (finished
                                    // instances free their slots); 0 (default) = whole solve in one launch — measured faster on config A
+    int sqp_rr = 0;                // PMPC_SQP_RR=1: batches beyond the resident wavefronts run one SQP iteration per work item from a ready queue (sqp_kernel_rr,
+                                   // pmpc_launch.hpp); 0 (default) = one workgroup per instance — measured equal or faster on configs A and D
     bool force_lds_path = false;   // PMPC_FORCE_LDS_PATH=1: disable the register-resident specialisations (A/B testing)
     std::map<std::tuple<int, int, double, double>, ChebData*> cheb_cache;
     double* ws = nullptr; size_t ws_bytes = 0;       // SQP HBM workspace (H, J)

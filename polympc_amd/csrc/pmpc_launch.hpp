@@ -15,6 +15,7 @@ extern "C" pmpc_status pmpc_internal_services(pmpc_context* ctx, int P, int S, d
                                                double** ws, void** stream, size_t* lds_limit, unsigned long long** phase_cycles, int* force_lds);
 extern "C" int pmpc_internal_simd_count(pmpc_context* ctx);   // SIMDs of the device (compute units x 4)
 extern "C" int pmpc_internal_sqp_slice(pmpc_context* ctx);   // SQP iterations per kernel launch (0 = whole solve in one launch)
+extern "C" int pmpc_internal_sqp_rr(pmpc_context* ctx);      // 1 (PMPC_SQP_RR=1, developer switch): batches beyond the resident wavefronts run one SQP iteration per work item (sqp_kernel_rr)
 
 namespace pmpc {
 using ::pmpc_status;
@@ -57,7 +58,9 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
     const int b = blockIdx.x;
     if (b >= B) return;
     // iteration-sliced execution: instances that finished in an earlier slice give their slot back immediately
-    if (it_begin > 0 && __builtin_amdgcn_readfirstlane(info[b].status) != PMPC_SQP_IN_PROGRESS) return;
+    if (it_begin != 0 && __builtin_amdgcn_readfirstlane(info[b].status) != PMPC_SQP_IN_PROGRESS) return;
+    // it_begin < 0: resume mode (the launch behind the round-robin kernel, sqp_kernel_rr below): every instance continues from the iteration its own record holds
+    if (it_begin < 0) it_begin = __builtin_amdgcn_readfirstlane(info[b].iter);
     const int P = cd->P, S = cd->S;
     Ocp<Model> ocp(model, P, S, cd->t_scale);
     const int n = ocp.dm.n, m = ocp.dm.m, mi = ocp.dm.mi;
@@ -138,6 +141,192 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
         if (ss.line_search == 1 && ss.filter_state != nullptr && ln < PMPC_FILTER_STATE_DOUBLES) ss.filter_state[(size_t)b * PMPC_FILTER_STATE_DOUBLES + ln] = filt[ln];
     }
     if constexpr (PROF) { if (phase_cycles && ln == 0) for (int i = 0; i < 24; ++i) atomicAdd(&phase_cycles[i], (unsigned long long)sqp.cyc[i]); }
+}
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Round-robin execution of a batch that exceeds the resident wavefronts (register-resident QP, one KKT row per lane) — a DEVELOPER SWITCH
+// (PMPC_SQP_RR=1), measured and not made the default: see DESIGN.md §6. Instances need 4..max_iter SQP iterations, and with one workgroup per
+// instance a launch of 4096 config-A instances takes 1.45 x its throughput time. Here the unit of work is ONE SQP ITERATION of one instance: a
+// grid of resident wavefronts pops instances from a ready queue, runs the next iteration of the instance from its state in HBM (x, lam, the previous
+// Lagrangian gradient and step, the BFGS matrix in the workspace: the state of the iteration-sliced launches), writes the state back and pushes
+// the instance to the tail of the queue if it has to go on; an instance whose iteration took much longer than the wavefront's mean keeps the
+// wavefront (it is on the critical path). The arithmetic of an iteration is the one-launch kernel's: bit-identical results
+// (test_sqp_round_robin_execution_bit_identical). What the per-item time stamps of this kernel showed is why it does not pay: the launch is not
+// waiting for instances that were dispatched late but for the serial work of the hardest ones (ten iterations whose QPs need several rho updates,
+// i.e. re-factorisations: 2.1 M cycles = 0.98 ms under load for the worst of the 4096) — no order of execution shortens that.
+//   Queues: instance b belongs to queue b % 8; a workgroup serves the queue of the XCD it finds itself on (s_getreg XCC_ID), so that the wavefront
+//   that wrote an instance's state and the one that continues it share one L2. A queue is an array of nk x max_iter entries (an instance is
+//   pushed at most max_iter times: no wrap-around), entry = (instance + 1) | (iterations done << 24), 0 = not written yet; head / tail / finished
+//   counters on their own 128-byte lines. The producer drains its stores (s_waitcnt vmcnt(0): they have reached the XCD's L2) before the agent-scope
+//   store of the entry; the consumer polls its entry with agent-scope loads and invalidates its CU's L1 (agent-scope acquire) before reading the state.
+//   Placement changes speed only: the resume-mode launch of sqp_kernel behind this kernel (it_begin < 0) finishes whatever a queue without
+//   workgroups, or a wavefront that gave up waiting (every spin is bounded), left in progress.
+constexpr int RR_QUEUES = 8;
+constexpr int RR_LINE = 32;                                  // ints per 128-byte line
+constexpr int RR_HEADER_WORDS = RR_QUEUES * 3 * RR_LINE;     // per queue: head, tail, finished
+constexpr int RR_PASS_SHIFT = 24;                            // entry = (b + 1) | (iterations done << 24)
+constexpr int RR_MAX_BATCH = (1 << RR_PASS_SHIFT) - 2;
+constexpr int RR_MAX_ITER = 127;
+constexpr int RR_SPIN_LIMIT = 1 << 16;
+#ifndef PMPC_RR_HARD_TENTHS
+#define PMPC_RR_HARD_TENTHS 14
+#endif
+constexpr int RR_HARD_TENTHS = PMPC_RR_HARD_TENTHS;   // an iteration is 'hard' when it takes more than this many tenths of the wavefront's mean
+inline size_t rr_queue_bytes(int B, int max_iter) { return ((size_t)RR_HEADER_WORDS + (size_t)B * (size_t)(max_iter > 0 ? max_iter : 1)) * sizeof(int); }
+__host__ __device__ inline int rr_queue_len(int B, int q) { return (q < B) ? (B - q + RR_QUEUES - 1) / RR_QUEUES : 0; }   // instances q, q + 8, ...
+
+template <class Model>   // (a template so that every translation unit may carry it)
+__global__ __launch_bounds__(256) void sqp_rr_init_kernel(int* __restrict__ queue, pmpc_sqp_info* __restrict__ info, int B, int max_iter) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) { pmpc_sqp_info z; z.iter = 0; z.qp_solver_iter = 0; z.status = PMPC_SQP_IN_PROGRESS; z.flags = 0; z.primal_norm = 0.0; z.dual_norm = 0.0; z.max_violation = 0.0; z.cost = 0.0; info[i] = z; }
+    if (i < RR_HEADER_WORDS) {   // head = 0, tail = number of instances of the queue (all of them are ready), finished = 0
+        const int q = i / (3 * RR_LINE), w = i - q * 3 * RR_LINE;
+        queue[i] = (w == RR_LINE) ? rr_queue_len(B, q) : 0;
+    }
+    if (i < B * max_iter) {
+        int start = 0, val = 0;
+        for (int q = 0; q < RR_QUEUES; ++q) {
+            const int nk = rr_queue_len(B, q), cap = nk * max_iter;
+            if (i >= start && i < start + cap) { const int k = i - start; val = (k < nk) ? (q + RR_QUEUES * k + 1) : 0; }
+            start += cap;
+        }
+        queue[RR_HEADER_WORDS + i] = val;
+    }
+}
+
+template <class Model, int NN, int MM, int HU>
+__global__ __launch_bounds__(64, PMPC_SQP_WAVES) void sqp_kernel_rr(Model model, const ChebData* __restrict__ cd, int B,
+                                                 const double* __restrict__ x_guess, const double* __restrict__ lam_guess,
+                                                 const double* __restrict__ d, const double* __restrict__ lbx,
+                                                 const double* __restrict__ ubx, const double* __restrict__ lbg,
+                                                 const double* __restrict__ ubg, pmpc_sqp_settings ss, pmpc_qp_settings qs,
+                                                 double* __restrict__ Hws, double* __restrict__ x, double* __restrict__ lam, pmpc_sqp_info* __restrict__ info,
+                                                 double* __restrict__ slice_state, int* __restrict__ queue, unsigned lds_dyn_doubles, unsigned long long* __restrict__ prof) {
+    static_assert(NN > 0 && NN + MM <= WAVE, "round-robin execution exists for the one-row-per-lane register path");
+    extern __shared__ double smem[];
+    const int P = cd->P, S = cd->S;
+    Ocp<Model> ocp(model, P, S, cd->t_scale);
+    const int n = ocp.dm.n, m = ocp.dm.m, mi = ocp.dm.mi;
+    QpLds qw; SqpLds v;
+    double* p = qw.carve_xy(smem, n, m);
+    p = v.carve(p, n, m, mi);
+    double* stage0 = p;
+    p = ocp.s.carve(p, P, S);
+    if ((size_t)(p - stage0) < (size_t)reg_qp_staging<NN + MM>() + ocp.s.const_doubles(P, S)) p = stage0 + reg_qp_staging<NN + MM>() + ocp.s.const_doubles(P, S);
+    const double* stage_end = p;
+    double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
+    ocp.d = dL;
+    const int ln = lane_id();
+    ocp.stage_constants(cd);
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    xcc &= (unsigned)(RR_QUEUES - 1);
+    const int nk = rr_queue_len(B, (int)xcc);
+    if (nk == 0) return;
+    const int cap = nk * ss.max_iter;
+    int start = 0;
+    for (int q = 0; q < (int)xcc; ++q) start += rr_queue_len(B, q) * ss.max_iter;
+    int* head = queue + (size_t)xcc * 3 * RR_LINE;
+    int* tail = head + RR_LINE;
+    int* finished = head + 2 * RR_LINE;
+    int* entries = queue + RR_HEADER_WORDS + start;
+    const int G = WAVE / ocp.dm.NN;
+    const bool side_by_side = (G >= 2 && (size_t)G * (m + ocp.dm.NN + 3) <= (size_t)(stage_end - ocp.s.fval));
+#ifdef PMPC_RR_PROFILE   // developer build: cycles per wavefront in [0] whole life [1] solve [2] waiting for an entry [3] state load [4] state store + push; [5] work items [6] wavefronts
+    long long pc[5] = {0, 0, 0, 0, 0}; int items = 0; const long long life0 = clock64();
+#define RR_EXIT do { if (prof && ln == 0) { atomicAdd(&prof[0], (unsigned long long)(clock64() - life0)); for (int i_ = 1; i_ < 5; ++i_) atomicAdd(&prof[i_], (unsigned long long)pc[i_]); atomicAdd(&prof[5], (unsigned long long)items); atomicAdd(&prof[6], 1ull); } return; } while (0)
+#define RR_T(var) const long long var = clock64()
+#define RR_ACC(i, a, b) pc[i] += (b) - (a)
+#else
+#define RR_EXIT return
+#define RR_T(var)
+#define RR_ACC(i, a, b)
+    (void)prof;
+#endif
+    long long cyc_sum = 0; int cyc_items = 0;   // this wavefront's iterations so far (shader-clock cycles)
+    while (true) {
+        RR_T(t0);
+        int hq = 0;
+        if (ln == 0) hq = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hq = __builtin_amdgcn_readfirstlane(hq);
+        if (hq >= cap) RR_EXIT;   // beyond every push the queue can ever see
+        int e = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&entries[hq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        for (int spin = 0; e == 0; ++spin) {
+            if (spin >= RR_SPIN_LIMIT) RR_EXIT;   // (the resume-mode launch finishes what is left)
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= nk) RR_EXIT;
+            __builtin_amdgcn_s_sleep(8);
+            e = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&entries[hq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        const int b = (e & ((1 << RR_PASS_SHIFT) - 1)) - 1;
+        const int pass = (int)((unsigned)e >> RR_PASS_SHIFT);   // SQP iterations the instance has behind it
+        RR_T(t1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        for (int i = ln; i < Model::ND; i += WAVE) dL[i] = d[(size_t)b * Model::ND + i];
+        double* sst = slice_state + (size_t)b * 2 * n;   // [previous Lagrangian gradient | previous step]
+        for (int i = ln; i < n; i += WAVE) {
+            v.x[i] = (pass > 0) ? x[(size_t)b * n + i] : (x_guess ? x_guess[(size_t)b * n + i] : 0.0);
+            v.lbx[i] = lbx[(size_t)b * n + i]; v.ubx[i] = ubx[(size_t)b * n + i];
+            if (pass > 0) { v.lg[i] = sst[i]; v.step[i] = sst[n + i]; }
+        }
+        for (int i = ln; i < m + n; i += WAVE)
+            v.lam[i] = (pass > 0) ? lam[(size_t)b * (m + n) + i] : (lam_guess ? lam_guess[(size_t)b * (m + n) + i] : 0.0);
+        for (int i = ln; i < mi; i += WAVE) {
+            v.lbg[i] = lbg ? lbg[(size_t)b * mi + i] : -INFINITY;
+            v.ubg[i] = ubg ? ubg[(size_t)b * mi + i] : INFINITY;
+        }
+        wsync();
+        RR_T(t2);
+        double* K0 = Hws + (size_t)b * (size_t)(n + m) * n;
+        pmpc_sqp_info si;
+        int done_iters = pass;
+        {
+            SqpDevice<Model, NN, MM, false, HU, false> sqp(ocp, v, qw, K0, K0 + n, ss, qs);
+            sqp.filt = nullptr;
+            sqp.eig = nullptr;
+            sqp.trace = ss.iteration_trace ? ss.iteration_trace + (size_t)b * (size_t)ss.iteration_trace_capacity * PMPC_TRACE_DOUBLES : nullptr;
+            sqp.tr = ocp.s.fval;
+            sqp.lsbuf = ocp.s.fval;
+            sqp.ls_side_by_side = side_by_side;
+            if (pass > 0) { const pmpc_sqp_info prev = info[b]; sqp.qp_iter_total = prev.qp_solver_iter; sqp.qp_flags = prev.flags; sqp.cost_log = prev.cost; }
+            // An instance whose iteration took much longer than this wavefront's iterations so far (hard QPs: more ADMM iterations, rho updates with their
+            // re-factorisations) is on the critical path of the launch: it keeps the wavefront until it ends instead of queueing behind the others.
+            while (true) {
+                const long long c0 = clock64();
+                sqp.solve(si, done_iters, done_iters + 1);
+                const long long c1 = clock64() - c0;
+                ++done_iters;
+                if (si.status != PMPC_SQP_IN_PROGRESS) break;
+                const bool hard = cyc_items > 0 && c1 * 10 * cyc_items > cyc_sum * RR_HARD_TENTHS;
+                cyc_sum += c1; ++cyc_items;
+                if (!hard) break;
+            }
+        }
+        RR_T(t3);
+#ifdef PMPC_RR_PROFILE   // per-item wall-clock stamps (100 MHz) in the alpha / primal_norm / dual_norm fields of the iteration record
+        if (ss.iteration_trace && ln == 0 && si.iter <= ss.iteration_trace_capacity) {
+            double* r_ = ss.iteration_trace + ((size_t)b * (size_t)ss.iteration_trace_capacity + (size_t)(si.iter - 1)) * PMPC_TRACE_DOUBLES;
+            r_[1] = (double)wall_clock64(); r_[2] = (double)(t2 - t0); r_[3] = (double)(t3 - t2); r_[4] = (double)xcc;
+        }
+#endif
+        const bool more = si.status == PMPC_SQP_IN_PROGRESS;
+        int tq = 0;
+        if (more && ln == 0) tq = __hip_atomic_fetch_add(tail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (reserved while the stores below are in flight)
+        if (more) for (int i = ln; i < n; i += WAVE) { sst[i] = v.lg[i]; sst[n + i] = v.step[i]; }
+        for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = v.x[i];
+        for (int i = ln; i < m + n; i += WAVE) lam[(size_t)b * (m + n) + i] = v.lam[i];
+        if (ln == 0) info[b] = si;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's stores have reached the XCD's L2
+        if (ln == 0) {
+            if (more) { if (tq < cap) __hip_atomic_store(&entries[tq], (b + 1) | (done_iters << RR_PASS_SHIFT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            else __hip_atomic_fetch_add(finished, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        wsync();
+#ifdef PMPC_RR_PROFILE
+        { const long long t4 = clock64(); RR_ACC(2, t0, t1); RR_ACC(3, t1, t2); RR_ACC(1, t2, t3); RR_ACC(4, t3, t4); ++items; }
+#endif
+    }
+#undef RR_EXIT
+#undef RR_T
+#undef RR_ACC
 }
 // mode 0: KKT factor in LDS; 1: register-resident QP (n+m <= 64); 2: KKT factor in HBM (large instances); 3: register-resident QP, 65..112 rows
 template <class Model> inline size_t sqp_eig_lds_bytes(int P, int S, const pmpc_sqp_settings* ss) {   // regularisation = 1: Jacobi workspace
@@ -238,6 +427,29 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
                                              : (phase ? sqp_kernel<Model, NN_, MM_, true> : sqp_kernel<Model, NN_, MM_, false>);
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
         const int slice = (slice_state && slice_iters > 0) ? slice_iters : ss->max_iter;
+        if constexpr (!LEAN) {
+            // more instances than resident wavefronts: one SQP iteration per work item, round-robin over the instances (sqp_kernel_rr)
+            const int slots = PMPC_SQP_WAVES * pmpc_internal_simd_count(ctx);
+            #ifdef PMPC_RR_PROFILE
+            const bool rr_phase_ok = true;
+#else
+            const bool rr_phase_ok = !phase;
+#endif
+            if (slice_state && slice_iters == 0 && rr_phase_ok && ss->max_iter > 1 && ss->max_iter <= RR_MAX_ITER && B > slots && B <= RR_MAX_BATCH && (size_t)B * ss->max_iter < ((size_t)1 << 30) && pmpc_internal_sqp_rr(ctx)) {
+                auto rrk = (ss->hessian_update == 1) ? sqp_kernel_rr<Model, NN_, MM_, 1> : sqp_kernel_rr<Model, NN_, MM_, 0>;
+                if (hipFuncSetAttribute((const void*)rrk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
+                int* queue = (int*)(slice_state + (size_t)B * 2 * NN_);   // behind the slice state (sqp_launch_dev sizes the workspace for it)
+                { const size_t words = (size_t)B * ss->max_iter > (size_t)RR_HEADER_WORDS ? (size_t)B * ss->max_iter : (size_t)RR_HEADER_WORDS;
+                  hipLaunchKernelGGL(sqp_rr_init_kernel<Model>, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, queue, info, B, ss->max_iter); }
+                hipLaunchKernelGGL(rrk, dim3(slots), dim3(WAVE), ldsr, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
+                                   *ss, *qs, Hws, x, lam, info, slice_state, queue, (unsigned)(ldsr / sizeof(double)), phase);
+                // resume mode: a no-op per instance unless something was left in progress (see sqp_kernel_rr)
+                hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), ldsr, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
+                                   *ss, *qs, Hws, Aws, x, lam, info, phase, (double*)nullptr, -1, ss->max_iter, slice_state, (unsigned)(ldsr / sizeof(double)));
+                *st = (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
+                return true;
+            }
+        }
         for (int it = 0; it < ss->max_iter; it += slice)
             hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), ldsr, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
                                *ss, *qs, Hws, Aws, x, lam, info, phase, (double*)nullptr, it, it + slice, slice_state, (unsigned)(ldsr / sizeof(double)));
@@ -282,7 +494,7 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     OcpDims<Model> dm(P, S);
     const void* cdv = nullptr; double* ws = nullptr; void* streamv = nullptr; size_t lds_limit = 0; unsigned long long* phase = nullptr; int force_lds = 0;
     const size_t base = (size_t)B * ((size_t)dm.n * dm.n + (size_t)dm.m * dm.n + 2 * (size_t)dm.n);
-    pmpc_status st = pmpc_internal_services(ctx, P, S, t0, tf, base * sizeof(double), &cdv, &ws, &streamv, &lds_limit, &phase, &force_lds);
+    pmpc_status st = pmpc_internal_services(ctx, P, S, t0, tf, base * sizeof(double) + rr_queue_bytes(B, ss->max_iter), &cdv, &ws, &streamv, &lds_limit, &phase, &force_lds);
     if (st != PMPC_OK) return st;
     const ChebData* cd = (const ChebData*)cdv;
     hipStream_t stream = (hipStream_t)streamv;

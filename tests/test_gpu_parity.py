@@ -970,6 +970,56 @@ def test_sqp_full_size_properties_config_B(ctx):
     assert np.all(U[ok, :, 0] >= 3.0 - 1e-3) and np.all(U[ok, :, 0] <= 35.0 + 1e-3) and np.all(U[ok, :, 1] >= -9000.0 - 1e-3) and np.all(U[ok, :, 1] <= 1e-3)
 
 
+def _same_bits(a, b):
+    """Bit-for-bit equality (NaN payloads included)."""
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    return a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hessian_update,warm", [(0, False), (1, False), (0, True)])
+def test_sqp_round_robin_execution_bit_identical(ctx, oracle, monkeypatch, hessian_update, warm):
+    """PMPC_SQP_RR=1 (developer switch): batches beyond the resident wavefronts run one SQP ITERATION per work item from a ready queue, with the
+    instance's state in HBM between iterations (sqp_kernel_rr, pmpc_launch.hpp). 4099 config-A instances (not a multiple of the eight queues): the
+    same iterations, statuses, ADMM iteration totals, bit-identical x / lam / KKT quantities and iteration records as the one-launch kernel
+    (default context) — cold and warm-started, dense and block BFGS — and as the CPU restatement on every instance."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    B, cap = 4099, 10
+    wl = workloads.robot_batch(B)
+    ss = pa.sqp_settings_default(); ss.max_iter = 10; ss.line_search_max_iter = 10; ss.hessian_update = hessian_update
+    xg = lg = None
+    if warm:   # warm start = the iterate of a two-iteration solve
+        s2 = pa.sqp_settings_default(); s2.max_iter = 2; s2.line_search_max_iter = 10
+        xg, lg, _ = ctx.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=s2)
+    monkeypatch.setenv("PMPC_SQP_RR", "1")
+    rr_ctx = pa.Context(0)
+    monkeypatch.delenv("PMPC_SQP_RR")
+    res = []
+    try:
+        for c in (rr_ctx, ctx):
+            h = c.iteration_trace_create(B, cap)
+            try:
+                ss.iteration_trace = h; ss.iteration_trace_capacity = cap
+                x, lam, info = c.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"],
+                                                 x_guess=xg, lam_guess=lg, sqp_settings=ss)
+                res.append((x, lam, info, c.iteration_trace_download(B, cap, h)))
+            finally:
+                c.iteration_trace_destroy(h)
+    finally:
+        rr_ctx.close()
+    (x, lam, info, tr), (x1, lam1, info1, tr1) = res
+    assert info["iter"].min() < info["iter"].max()   # the instances need different numbers of iterations
+    assert _same_bits(info, info1) and _same_bits(x, x1) and _same_bits(lam, lam1) and _same_bits(tr, tr1)
+    oss = oracle.sqp_default_settings(); oss.max_iter = 10; oss.line_search_max_iter = 10; oss.hessian_update = hessian_update
+    xo, lo, io = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], x_guess=xg, lam_guess=lg,
+                                        sqp_settings=oss, pivot=_gpu_order(oracle, 35, 21, 7, block_bfgs=bool(hessian_update)), threads=8)
+    fin = np.isfinite(x).all(axis=1) & np.isfinite(xo).all(axis=1)   # (a warm start from an unconverged iterate can diverge: identically on both sides)
+    assert np.array_equal(np.isfinite(x).all(axis=1), np.isfinite(xo).all(axis=1)) and fin.mean() > 0.99
+    _assert_same_solve(info[fin], [i for i, f in zip(io, fin) if f], x[fin], xo[fin], lam[fin], lo[fin])
+    assert np.array_equal(info["iter"], np.array([i.iter for i in io])) and np.array_equal(info["status"], np.array([i.status for i in io]))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["C_kite_standin_1024", "R_robot_16_nodes_2048"])
 def test_sqp_full_size_properties_hbm_factor_kernel(ctx, oracle, case):

@@ -119,7 +119,8 @@ typedef enum { PMPC_SQP_SOLVED = 0, PMPC_SQP_MAX_ITER_EXCEEDED = 1, PMPC_SQP_INV
 /* sqp_info_t (sqp_base.hpp:57-61) + the getters primal_norm/dual_norm/constr_violation/cost (:192-195) */
 typedef struct {
     int iter, qp_solver_iter, status;
-    int flags;   /* OR of the pmpc_qp_info::flags of every QP of the solve (PMPC_FLAG_NONFINITE) */
+    int flags;   /* PMPC_FLAG_NONFINITE: OR of the pmpc_qp_info::flags of every QP of the solve, and set whenever the returned x or lam holds a
+                  * non-finite value, whatever produced it (e.g. a warm start from an unconverged iterate that diverges) */
     double primal_norm, dual_norm, max_violation, cost;
 } pmpc_sqp_info;
 

@@ -874,6 +874,12 @@ struct SqpDevice {
             if (iter >= ss.max_iter) break;
             if (iter >= it_end) { status = PMPC_SQP_IN_PROGRESS; break; }
         }
+        {   // a non-finite iterate is reported whatever produced it (a QP solution, a diverging step of a warm start from an unconverged point, the model itself)
+            bool bad = false;
+            for (int i = lane_id(); i < n_ct(); i += WAVE) bad |= (v.x[i] - v.x[i]) != 0.0;
+            for (int i = lane_id(); i < m_ct() + n_ct(); i += WAVE) bad |= (v.lam[i] - v.lam[i]) != 0.0;
+            if (__builtin_amdgcn_ballot_w64(bad) != 0) qp_flags |= PMPC_FLAG_NONFINITE;
+        }
         info.iter = iter; info.qp_solver_iter = qp_iter_total; info.status = status; info.flags = qp_flags;
         info.primal_norm = primal_norm; info.dual_norm = dual_norm; info.max_violation = max_violation; info.cost = cost_log;
     }

@@ -1016,6 +1016,7 @@ def test_sqp_round_robin_execution_bit_identical(ctx, oracle, monkeypatch, hessi
                                         sqp_settings=oss, pivot=_gpu_order(oracle, 35, 21, 7, block_bfgs=bool(hessian_update)), threads=8)
     fin = np.isfinite(x).all(axis=1) & np.isfinite(xo).all(axis=1)   # (a warm start from an unconverged iterate can diverge: identically on both sides)
     assert np.array_equal(np.isfinite(x).all(axis=1), np.isfinite(xo).all(axis=1)) and fin.mean() > 0.99
+    assert np.array_equal(info["flags"] != 0, ~(np.isfinite(x).all(axis=1) & np.isfinite(lam).all(axis=1)))   # PMPC_FLAG_NONFINITE marks exactly the non-finite results
     _assert_same_solve(info[fin], [i for i, f in zip(io, fin) if f], x[fin], xo[fin], lam[fin], lo[fin])
     assert np.array_equal(info["iter"], np.array([i.iter for i in io])) and np.array_equal(info["status"], np.array([i.status for i in io]))
 

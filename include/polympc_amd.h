@@ -173,6 +173,19 @@ pmpc_status pmpc_qp_boxadmm_solve_batch_dev(pmpc_context* ctx, int B, int n, int
                                             const double* xub, const double* x0, const double* y0,
                                             const pmpc_qp_settings* settings, double* x, double* y, pmpc_qp_info* info);
 
+/* boxADMM<N, M, float>::solve — the single-precision instantiation of the QP solver (QPBase<..., Scalar = float>, qp_base.hpp:94-130; the reference
+ * tests it in tests/solvers/qp/box_admm_test.cpp:85-115). float arrays in the layouts above; every quantity of the algorithm is a float as in the
+ * reference's templates (settings narrowed to float as qp_solver_settings_t<float> stores them; DIV_BY_ZERO_REGUL = regulariser<float>::value,
+ * qp_base.hpp:84-86); the info's floats are returned widened. linear_solver must be 0 (static order). The KKT matrix lives in LDS:
+ * PMPC_ERR_UNSUPPORTED_SIZE beyond n + m = 128 or the LDS budget. A plain one-wavefront-per-QP kernel (the SQP solver computes in fp64 only, like every
+ * SQP test of the reference). Host buffers / device pointers (asynchronous on the context's stream). */
+pmpc_status pmpc_qp_boxadmm_solve_batch_f32(pmpc_context* ctx, int B, int n, int m, const float* H, const float* h, const float* A, const float* Alb,
+                                            const float* Aub, const float* xlb, const float* xub, const float* x0, const float* y0,
+                                            const pmpc_qp_settings* settings, float* x, float* y, pmpc_qp_info* info);
+pmpc_status pmpc_qp_boxadmm_solve_batch_f32_dev(pmpc_context* ctx, int B, int n, int m, const float* H, const float* h, const float* A, const float* Alb,
+                                                const float* Aub, const float* xlb, const float* xub, const float* x0, const float* y0,
+                                                const pmpc_qp_settings* settings, float* x, float* y, pmpc_qp_info* info);
+
 /* Batched ADMM::solve — the reference's OSQP-style solver (replaces QPBase::solve -> ADMM::solve_impl, admm.hpp:104-212: box
  * constraints stacked under the general ones, one (2n+m)-row KKT system). Same arguments, layouts and dual ordering
  * [general (m) | box (n)] as pmpc_qp_boxadmm_solve_batch. Host buffers / device pointers. */

@@ -70,6 +70,11 @@ void orc_qp_solve_batch(int B, int n, int m, const double* H, const double* h, c
                         const double* Aub, const double* xlb, const double* xub, const double* x0, const double* y0,
                         const orc_qp_settings* s, int pivot, int threads, double* x, double* y, orc_qp_info* info);
 
+/* boxADMM<N, M, float> (box_admm_test.cpp:85-115): float arrays; pivot = PIVOT_EIGEN or PIVOT_STATIC; the info's floats are widened */
+void orc_qp_solve_batch_f32(int B, int n, int m, const float* H, const float* h, const float* A, const float* Alb, const float* Aub,
+                            const float* xlb, const float* xub, const float* x0, const float* y0, const orc_qp_settings* s, int pivot,
+                            float* x, float* y, orc_qp_info* info);
+
 /* the OSQP-style ADMM solver (admm.hpp) on the same batch layout; y has m+n entries per instance ([general | box]) */
 void orc_qp_admm_solve_batch(int B, int n, int m, const double* H, const double* h, const double* A, const double* Alb,
                              const double* Aub, const double* xlb, const double* xub, const double* x0, const double* y0,

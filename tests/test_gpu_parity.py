@@ -362,6 +362,45 @@ def test_sqp_with_ruiz_preconditioner_vs_oracle(ctx, oracle):
         _assert_same_solve(info, io, x, xo, lam, lo)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,B", [(2, 1, 1), (7, 3, 33), (35, 21, 16), (5, 0, 4), (66, 44, 3), (3, 70, 2)])
+def test_qp_single_precision_vs_oracle(ctx, oracle, n, m, B):
+    """pmpc_qp_boxadmm_solve_batch_f32 = boxADMM<N, M, float> (box_admm_test.cpp:85-115): the reference's float fixture (n = 2, m = 1) and random QPs,
+    cold and warm-started, with adaptive rho — identical iteration counts, statuses, rho updates and BIT-IDENTICAL float x / y / residuals against
+    the float restatement in the kernel's static order; the fixture's own assertions hold on the GPU result."""
+    import polympc_amd as pa
+    if (n, m, B) == (2, 1, 1):
+        H = np.array([[4, 1, 1, 2]], dtype=np.float32); h = np.array([[1, 1]], dtype=np.float32); A = np.array([[1, 1]], dtype=np.float32)
+        al = np.array([[1]], dtype=np.float32); au = al.copy(); xl = np.zeros((1, 2), dtype=np.float32); xu = np.full((1, 2), 0.7, dtype=np.float32)
+    else:
+        from polympc_amd import workloads
+        q = workloads.random_qp_batch(B, n, m, seed=n * 1000 + m)
+        H, h, A, al, au, xl, xu = (np.asarray(q[k], dtype=np.float32) for k in ("H", "h", "A", "Alb", "Aub", "xlb", "xub"))
+        al = al.reshape(B, m); au = au.reshape(B, m)
+    for adaptive, iters in ((0, 150), (1, 400)):
+        s = pa.qp_settings_default(); s.max_iter = iters; s.adaptive_rho = adaptive; s.adaptive_rho_interval = 25
+        so = oracle.qp_default_settings(); so.max_iter = iters; so.adaptive_rho = adaptive; so.adaptive_rho_interval = 25
+        x0 = y0 = None
+        for warm in (False, True):
+            x, y, info = ctx.qp_solve_batch_f32(H, h, A, al, au, xl, xu, settings=s, x0=x0, y0=y0)
+            xo, yo, io = oracle.qp_solve_batch_f32(H, h, A, al, au, xl, xu, settings=so, pivot=oracle.PIVOT_STATIC, x0=x0, y0=y0)
+            assert np.array_equal(info["iter"], [i.iter for i in io]) and np.array_equal(info["status"], [i.status for i in io])
+            assert np.array_equal(info["rho_updates"], [i.rho_updates for i in io])
+            assert x.dtype == np.float32 and x.tobytes() == xo.tobytes() and y.tobytes() == yo.tobytes()
+            assert np.array_equal(info["res_prim"], [i.res_prim for i in io]) and np.array_equal(info["res_dual"], [i.res_dual for i in io])
+            assert np.all(info["flags"] == 0)
+            x0, y0 = x, y
+    if (n, m, B) == (2, 1, 1):
+        sol = np.array([0.3, 0.7], dtype=np.float32)
+        s = pa.qp_settings_default(); s.max_iter = 150
+        x, y, info = ctx.qp_solve_batch_f32(H, h, A, al, au, xl, xu, settings=s)
+        assert np.linalg.norm(x[0] - sol) <= 1e-2 * min(np.linalg.norm(x[0]), np.linalg.norm(sol))
+        assert info["iter"][0] < 150 and info["status"][0] == pa.QP_SOLVED
+    with pytest.raises(RuntimeError):   # the matrix lives in LDS, two KKT rows per lane
+        z = np.zeros((1, 130), dtype=np.float32)
+        ctx.qp_solve_batch_f32(np.eye(130, dtype=np.float32).reshape(1, -1), z, np.zeros((1, 0)), np.zeros((1, 0)), np.zeros((1, 0)), z - 1, z + 1)
+
+
 # -------------------------------------------------------------------------------------------- §8f-1: batched MPC step
 def test_mpc_receding_horizon_device_resident(ctx, oracle):
     """Closed loop of 16 robots for 5 steps: pmpc_mpc_step_batch_dev (x0 pinned on the device, warm start from the previous

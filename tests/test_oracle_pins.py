@@ -755,3 +755,33 @@ def test_sqp_iteration_records(oracle):
     tr2 = np.zeros((B, 3, oracle.TRACE_DOUBLES)); oracle.bind_iteration_trace(ss, tr2)
     oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
     assert np.array_equal(tr2, tr[:, :3])
+
+
+def test_box_admm_single_precision_float_fixture(oracle):
+    """tests/solvers/qp/box_admm_test.cpp:85-115 (box_admmSinglePrecisionFloat): boxADMM<2, 1, float>, max_iter = 150 — the solution within 1e-2 of
+    (0.3, 0.7) in isApprox's sense, SOLVED, fewer than 150 iterations; the float restatement (oracle/qp_f32.hpp) under Eigen-style pivoting and in the
+    static order of the HIP kernel, both with the iteration count of the double solve of the same problem. On random QPs the float restatement
+    agrees with the double one to single-precision accuracy."""
+    H = np.array([[4, 1, 1, 2]], dtype=np.float32); h = [[1, 1]]; A = [[1, 1]]
+    s = oracle.qp_default_settings(); s.max_iter = 150
+    xd, yd, infod = oracle.qp_solve_batch(H, h, A, [[1]], [[1]], [[0, 0]], [[0.7, 0.7]], settings=s)
+    sol = np.array([0.3, 0.7], dtype=np.float32)
+    for piv in (oracle.PIVOT_EIGEN, oracle.PIVOT_STATIC):
+        x, y, info = oracle.qp_solve_batch_f32(H, h, A, [[1]], [[1]], [[0, 0]], [[0.7, 0.7]], settings=s, pivot=piv)
+        assert x.dtype == np.float32
+        assert np.linalg.norm(x[0] - sol) <= 1e-2 * min(np.linalg.norm(x[0]), np.linalg.norm(sol))   # Eigen's isApprox
+        assert info[0].status == oracle.QP_SOLVED and info[0].iter < 150 and info[0].iter == infod[0].iter
+        assert np.abs(x[0] - xd[0]).max() < 1e-5
+    rng = np.random.default_rng(5)
+    n, m, B = 7, 3, 6
+    Hs, hs, As, al, au, xl, xu = [], [], [], [], [], [], []
+    for _ in range(B):
+        G = rng.standard_normal((n, n)); Hm = G @ G.T + n * np.eye(n); Am = rng.standard_normal((m, n)); c = rng.standard_normal(m)
+        Hs.append(Hm.T.ravel()); hs.append(rng.standard_normal(n)); As.append(Am.T.ravel()); al.append(c - 1.0); au.append(c + 1.0)
+        xl.append(-np.ones(n)); xu.append(np.ones(n))
+    s2 = oracle.qp_default_settings(); s2.max_iter = 500
+    xd, yd, infod = oracle.qp_solve_batch(Hs, hs, As, al, au, xl, xu, settings=s2)
+    for piv in (oracle.PIVOT_EIGEN, oracle.PIVOT_STATIC):
+        x, y, info = oracle.qp_solve_batch_f32(Hs, hs, As, al, au, xl, xu, settings=s2, pivot=piv)
+        assert all(i.status == oracle.QP_SOLVED for i in info)
+        assert np.abs(x - xd).max() < 2e-3   # both stop at eps = 1e-3; the iterates agree to single precision until then

@@ -31,6 +31,7 @@
 #include <limits>
 #include <string>
 #include <utility>
+#include <type_traits>
 #include <vector>
 #include "../polympc_amd.h"
 
@@ -50,39 +51,39 @@ struct Spline {
     using scalar_t = typename Polynomial::scalar_t;
 };
 
-// fixed-size vector with the Eigen accessors the reference's call sites use
-template <int N>
+// fixed-size vector with the Eigen accessors the reference's call sites use (Scalar = double, or float for boxADMM<N, M, float>)
+template <int N, typename Scalar = double>
 struct Vector {
-    std::array<double, (N > 0 ? N : 1)> v{};
-    static Vector Constant(double c) { Vector r; r.v.fill(c); return r; }
-    static Vector Zero() { return Constant(0.0); }
-    double& operator()(int i) { return v[i]; }
-    double operator()(int i) const { return v[i]; }
-    double& operator[](int i) { return v[i]; }
-    double operator[](int i) const { return v[i]; }
-    double* data() { return v.data(); }
-    const double* data() const { return v.data(); }
+    std::array<Scalar, (N > 0 ? N : 1)> v{};
+    static Vector Constant(Scalar c) { Vector r; r.v.fill(c); return r; }
+    static Vector Zero() { return Constant(Scalar(0)); }
+    Scalar& operator()(int i) { return v[i]; }
+    Scalar operator()(int i) const { return v[i]; }
+    Scalar& operator[](int i) { return v[i]; }
+    Scalar operator[](int i) const { return v[i]; }
+    Scalar* data() { return v.data(); }
+    const Scalar* data() const { return v.data(); }
     static constexpr int size() { return N; }
-    void setZero() { v.fill(0.0); }
-    template <int K> Vector<K> segment(int start) const { Vector<K> r; for (int i = 0; i < K; ++i) r(i) = v[start + i]; return r; }
-    template <int K> void set_segment(int start, const Vector<K>& s) { for (int i = 0; i < K; ++i) v[start + i] = s(i); }
-    template <int K> Vector<K> head() const { return segment<K>(0); }
-    template <int K> Vector<K> tail() const { return segment<K>(N - K); }
-    double lpNormInf() const { double r = 0; for (int i = 0; i < N; ++i) r = std::max(r, std::fabs(v[i])); return r; }
-    bool isApprox(const Vector& o, double prec) const {   // Eigen: ||a-b|| <= prec * min(||a||, ||b||)
-        double d = 0, a = 0, b = 0;
+    void setZero() { v.fill(Scalar(0)); }
+    template <int K> Vector<K, Scalar> segment(int start) const { Vector<K, Scalar> r; for (int i = 0; i < K; ++i) r(i) = v[start + i]; return r; }
+    template <int K> void set_segment(int start, const Vector<K, Scalar>& s) { for (int i = 0; i < K; ++i) v[start + i] = s(i); }
+    template <int K> Vector<K, Scalar> head() const { return segment<K>(0); }
+    template <int K> Vector<K, Scalar> tail() const { return segment<K>(N - K); }
+    Scalar lpNormInf() const { Scalar r = 0; for (int i = 0; i < N; ++i) r = std::max(r, std::fabs(v[i])); return r; }
+    bool isApprox(const Vector& o, Scalar prec) const {   // Eigen: ||a-b|| <= prec * min(||a||, ||b||)
+        Scalar d = 0, a = 0, b = 0;
         for (int i = 0; i < N; ++i) { d += (v[i] - o.v[i]) * (v[i] - o.v[i]); a += v[i] * v[i]; b += o.v[i] * o.v[i]; }
         return std::sqrt(d) <= prec * std::min(std::sqrt(a), std::sqrt(b));
     }
 };
 // column-major fixed-size matrix (Eigen default)
-template <int R, int C>
+template <int R, int C, typename Scalar = double>
 struct Matrix {
-    std::vector<double> v = std::vector<double>((size_t)(R > 0 ? R : 0) * (C > 0 ? C : 0), 0.0);
-    double& operator()(int i, int j) { return v[i + (size_t)j * R]; }
-    double operator()(int i, int j) const { return v[i + (size_t)j * R]; }
-    double* data() { return v.data(); }
-    const double* data() const { return v.data(); }
+    std::vector<Scalar> v = std::vector<Scalar>((size_t)(R > 0 ? R : 0) * (C > 0 ? C : 0), Scalar(0));
+    Scalar& operator()(int i, int j) { return v[i + (size_t)j * R]; }
+    Scalar operator()(int i, int j) const { return v[i + (size_t)j * R]; }
+    Scalar* data() { return v.data(); }
+    const Scalar* data() const { return v.data(); }
 };
 
 // status enums with the reference's names and values (qp_base.hpp:55-62, sqp_base.hpp:49-55)
@@ -369,12 +370,15 @@ public:
 
 // ---------------------------------------------------------------------------------------------------------------------
 // boxADMM<N, M>: the QP seam (qp_base.hpp:148-175, box_admm.hpp:81-91). Matrices column-major.
+// Scalar = float selects the single-precision instantiation the reference tests (box_admm_test.cpp:85-115): pmpc_qp_boxadmm_solve_batch_f32.
 template <int N, int M> class ADMM;
-template <int N, int M>
+template <int N, int M, typename Scalar = double>
 class boxADMM {
+    static_assert(std::is_same<Scalar, double>::value || std::is_same<Scalar, float>::value, "boxADMM: Scalar is double or float");
 public:
-    using qp_var_t = Vector<N>; using qp_dual_t = Vector<N + M>; using qp_dual_a_t = Vector<M>;
-    using qp_hessian_t = Matrix<N, N>; using qp_constraint_t = Matrix<M, N>;
+    using scalar_t = Scalar;
+    using qp_var_t = Vector<N, Scalar>; using qp_dual_t = Vector<N + M, Scalar>; using qp_dual_a_t = Vector<M, Scalar>;
+    using qp_hessian_t = Matrix<N, N, Scalar>; using qp_constraint_t = Matrix<M, N, Scalar>;
     using settings_t = qp_solver_settings_t; using info_t = qp_solver_info_t;
     boxADMM() { pmpc_qp_settings_default(&m_settings); }
     settings_t& settings() noexcept { return m_settings; }
@@ -393,19 +397,31 @@ public:
     }
 private:
     status_t solve_(const qp_hessian_t& H, const qp_var_t& h, const qp_constraint_t& A, const qp_dual_a_t& Alb, const qp_dual_a_t& Aub,
-                    const qp_var_t& xlb, const qp_var_t& xub, const double* x0, const double* y0) noexcept {
+                    const qp_var_t& xlb, const qp_var_t& xub, const Scalar* x0, const Scalar* y0) noexcept {
         pmpc_context* ctx = context();
         m_info.status = UNINITIALIZED;
         if (!ctx) return m_info.status;
         pmpc_qp_info qi;
-        const pmpc_status st = (m_osqp_form ? pmpc_qp_admm_solve_batch : pmpc_qp_boxadmm_solve_batch)(ctx, 1, N, M, H.data(), h.data(), A.data(), Alb.data(),
-                                                           Aub.data(), xlb.data(), xub.data(), x0, y0, &m_settings, m_x.data(), m_y.data(), &qi);
+        const pmpc_status st = entry_(m_osqp_form, ctx, H.data(), h.data(), A.data(), Alb.data(), Aub.data(), xlb.data(), xub.data(), x0, y0, &m_settings,
+                                      m_x.data(), m_y.data(), &qi);
         last_error() = st;
         if (st != PMPC_OK) return m_info.status;
         m_info.status = (status_t)qi.status; m_info.iter = qi.iter; m_info.rho_updates = qi.rho_updates;
         m_info.rho_estimate = qi.rho_estimate; m_info.res_prim = qi.res_prim; m_info.res_dual = qi.res_dual;
         iter = qi.iter;
         return m_info.status;
+    }
+    // the C-ABI entry for the scalar type (overloads on the pointer type: the header stays C++14)
+    static pmpc_status entry_(bool osqp, pmpc_context* ctx, const double* H, const double* h, const double* A, const double* Alb, const double* Aub,
+                              const double* xlb, const double* xub, const double* x0, const double* y0, const pmpc_qp_settings* s, double* x, double* y,
+                              pmpc_qp_info* qi) noexcept {
+        return (osqp ? pmpc_qp_admm_solve_batch : pmpc_qp_boxadmm_solve_batch)(ctx, 1, N, M, H, h, A, Alb, Aub, xlb, xub, x0, y0, s, x, y, qi);
+    }
+    static pmpc_status entry_(bool osqp, pmpc_context* ctx, const float* H, const float* h, const float* A, const float* Alb, const float* Aub,
+                              const float* xlb, const float* xub, const float* x0, const float* y0, const pmpc_qp_settings* s, float* x, float* y,
+                              pmpc_qp_info* qi) noexcept {
+        if (osqp) return PMPC_ERR_INVALID_ARGUMENT;   // (ADMM<N, M> is double only)
+        return pmpc_qp_boxadmm_solve_batch_f32(ctx, 1, N, M, H, h, A, Alb, Aub, xlb, xub, x0, y0, s, x, y, qi);
     }
     settings_t m_settings; info_t m_info; qp_var_t m_x; qp_dual_t m_y;
     bool m_osqp_form{false};

@@ -371,7 +371,7 @@ public:
 // ---------------------------------------------------------------------------------------------------------------------
 // boxADMM<N, M>: the QP seam (qp_base.hpp:148-175, box_admm.hpp:81-91). Matrices column-major.
 // Scalar = float selects the single-precision instantiation the reference tests (box_admm_test.cpp:85-115): pmpc_qp_boxadmm_solve_batch_f32.
-template <int N, int M> class ADMM;
+template <int N, int M, typename Scalar> class ADMM;
 template <int N, int M, typename Scalar = double>
 class boxADMM {
     static_assert(std::is_same<Scalar, double>::value || std::is_same<Scalar, float>::value, "boxADMM: Scalar is double or float");
@@ -420,16 +420,15 @@ private:
     static pmpc_status entry_(bool osqp, pmpc_context* ctx, const float* H, const float* h, const float* A, const float* Alb, const float* Aub,
                               const float* xlb, const float* xub, const float* x0, const float* y0, const pmpc_qp_settings* s, float* x, float* y,
                               pmpc_qp_info* qi) noexcept {
-        if (osqp) return PMPC_ERR_INVALID_ARGUMENT;   // (ADMM<N, M> is double only)
-        return pmpc_qp_boxadmm_solve_batch_f32(ctx, 1, N, M, H, h, A, Alb, Aub, xlb, xub, x0, y0, s, x, y, qi);
+        return (osqp ? pmpc_qp_admm_solve_batch_f32 : pmpc_qp_boxadmm_solve_batch_f32)(ctx, 1, N, M, H, h, A, Alb, Aub, xlb, xub, x0, y0, s, x, y, qi);
     }
     settings_t m_settings; info_t m_info; qp_var_t m_x; qp_dual_t m_y;
     bool m_osqp_form{false};
-    friend class ADMM<N, M>;
+    friend class ADMM<N, M, Scalar>;
 };
 // ADMM<N, M>: the reference's OSQP-style solver (admm.hpp) — same seam, the stacked (2N+M)-row KKT system on the device
-template <int N, int M>
-class ADMM : public boxADMM<N, M> {
+template <int N, int M, typename Scalar = double>
+class ADMM : public boxADMM<N, M, Scalar> {
 public:
     ADMM() { this->m_osqp_form = true; }
 };

@@ -186,6 +186,15 @@ pmpc_status pmpc_qp_boxadmm_solve_batch_f32_dev(pmpc_context* ctx, int B, int n,
                                                 const float* Aub, const float* xlb, const float* xub, const float* x0, const float* y0,
                                                 const pmpc_qp_settings* settings, float* x, float* y, pmpc_qp_info* info);
 
+/* ADMM<N, M, float>::solve — the single-precision instantiation of the OSQP-style solver (admm.hpp; tests/solvers/qp/admm_solver_test.cpp:84-113):
+ * as pmpc_qp_boxadmm_solve_batch_f32 with the stacked (2n+m)-row KKT system in LDS (PMPC_ERR_UNSUPPORTED_SIZE beyond 2n + m = 128). */
+pmpc_status pmpc_qp_admm_solve_batch_f32(pmpc_context* ctx, int B, int n, int m, const float* H, const float* h, const float* A, const float* Alb,
+                                         const float* Aub, const float* xlb, const float* xub, const float* x0, const float* y0,
+                                         const pmpc_qp_settings* settings, float* x, float* y, pmpc_qp_info* info);
+pmpc_status pmpc_qp_admm_solve_batch_f32_dev(pmpc_context* ctx, int B, int n, int m, const float* H, const float* h, const float* A, const float* Alb,
+                                             const float* Aub, const float* xlb, const float* xub, const float* x0, const float* y0,
+                                             const pmpc_qp_settings* settings, float* x, float* y, pmpc_qp_info* info);
+
 /* Batched ADMM::solve — the reference's OSQP-style solver (replaces QPBase::solve -> ADMM::solve_impl, admm.hpp:104-212: box
  * constraints stacked under the general ones, one (2n+m)-row KKT system). Same arguments, layouts and dual ordering
  * [general (m) | box (n)] as pmpc_qp_boxadmm_solve_batch. Host buffers / device pointers. */

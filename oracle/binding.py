@@ -186,8 +186,8 @@ def qp_solve_batch(H, h, A, Alb, Aub, xlb, xub, settings=None, pivot=PIVOT_EIGEN
     return x, y, info
 
 
-def qp_solve_batch_f32(H, h, A, Alb, Aub, xlb, xub, settings=None, pivot=PIVOT_EIGEN, x0=None, y0=None):
-    """boxADMM<N, M, float>: the same layout as qp_solve_batch with float32 arrays (pivot: PIVOT_EIGEN or PIVOT_STATIC)."""
+def qp_solve_batch_f32(H, h, A, Alb, Aub, xlb, xub, settings=None, pivot=PIVOT_EIGEN, x0=None, y0=None, osqp_form=False):
+    """boxADMM<N, M, float> (osqp_form: ADMM<N, M, float>): the same layout as qp_solve_batch with float32 arrays (pivot: PIVOT_EIGEN or PIVOT_STATIC)."""
     f32 = lambda a: None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float32))
     pf = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
     H = f32(H); h = f32(h); A = f32(A); Alb = f32(Alb); Aub = f32(Aub); xlb = f32(xlb); xub = f32(xub); x0 = f32(x0); y0 = f32(y0)
@@ -196,7 +196,7 @@ def qp_solve_batch_f32(H, h, A, Alb, Aub, xlb, xub, settings=None, pivot=PIVOT_E
     assert pivot in (PIVOT_EIGEN, PIVOT_STATIC)
     s = settings or qp_default_settings()
     x = np.zeros((B, n), dtype=np.float32); y = np.zeros((B, n + m), dtype=np.float32); info = (QPInfo * B)()
-    f = lib().orc_qp_solve_batch_f32
+    f = lib().orc_qp_admm_solve_batch_f32 if osqp_form else lib().orc_qp_solve_batch_f32
     f.restype = None
     f(B, n, m, pf(H), pf(h), pf(A), pf(Alb), pf(Aub), pf(xlb), pf(xub), pf(x0), pf(y0), C.byref(s), pivot, pf(x), pf(y), info)
     return x, y, info

@@ -64,6 +64,26 @@ template <> RobotNGOCP make_model<RobotNGOCP>(const double* mp, int nmp) {
         default: break;                                                 \
     }
 
+template <class Solver>
+static void qp_solve_batch_f32_impl(int B, int n, int m, const float* H, const float* h, const float* A, const float* Alb, const float* Aub,
+                                    const float* xlb, const float* xub, const float* x0, const float* y0, const orc_qp_settings* s, int pivot,
+                                    float* x, float* y, orc_qp_info* info) {
+    for (int b = 0; b < B; ++b) {
+        Solver q(n, m);
+        q.settings.eps_rel = (float)s->eps_rel; q.settings.eps_abs = (float)s->eps_abs; q.settings.max_iter = s->max_iter;
+        q.settings.rho = (float)s->rho; q.settings.sigma = (float)s->sigma; q.settings.alpha = (float)s->alpha;
+        q.settings.check_termination = s->check_termination; q.settings.adaptive_rho = s->adaptive_rho != 0;
+        q.settings.adaptive_rho_tolerance = (float)s->adaptive_rho_tolerance; q.settings.adaptive_rho_interval = s->adaptive_rho_interval;
+        q.pivot = (pivot_policy)pivot;
+        q.solve(H + (size_t)b * n * n, h + (size_t)b * n, A + (size_t)b * m * n, Alb + (size_t)b * m, Aub + (size_t)b * m, xlb + (size_t)b * n,
+                xub + (size_t)b * n, x0 ? x0 + (size_t)b * n : nullptr, y0 ? y0 + (size_t)b * (n + m) : nullptr);
+        for (int i = 0; i < n; ++i) x[(size_t)b * n + i] = q.x[i];
+        for (int i = 0; i < n + m; ++i) y[(size_t)b * (n + m) + i] = q.y[i];
+        info[b].status = q.info.status; info[b].iter = q.info.iter; info[b].rho_updates = q.info.rho_updates;
+        info[b].rho_estimate = q.info.rho_estimate; info[b].res_prim = q.info.res_prim; info[b].res_dual = q.info.res_dual;
+    }
+}
+
 extern "C" {
 
 int orc_set_libm(int use_libm) { const int old = oracle::use_libm() ? 1 : 0; oracle::use_libm() = use_libm != 0; return old; }
@@ -315,24 +335,17 @@ void orc_ocp_eval(int model, int P, int S, double t0, double tf, const double* m
     DISPATCH_MODEL(model, eval_impl, P, S, t0, tf, mparams, n_mparams, var, d, lam, cost, c_eq, g_ineq, jac, cost_grad,
                    cost_hess, lag_grad, lag_hess);
 }
-// boxADMM<N, M, float> (box_admm_test.cpp:85-115): float arrays, the settings narrowed to float as qp_solver_settings_t<float> holds them
+// boxADMM<N, M, float> (box_admm_test.cpp:85-115) / ADMM<N, M, float> (admm_solver_test.cpp:84-113): float arrays, the settings narrowed to float as
+// qp_solver_settings_t<float> holds them
 void orc_qp_solve_batch_f32(int B, int n, int m, const float* H, const float* h, const float* A, const float* Alb, const float* Aub,
                             const float* xlb, const float* xub, const float* x0, const float* y0, const orc_qp_settings* s, int pivot,
                             float* x, float* y, orc_qp_info* info) {
-    for (int b = 0; b < B; ++b) {
-        BoxADMMf q(n, m);
-        q.settings.eps_rel = (float)s->eps_rel; q.settings.eps_abs = (float)s->eps_abs; q.settings.max_iter = s->max_iter;
-        q.settings.rho = (float)s->rho; q.settings.sigma = (float)s->sigma; q.settings.alpha = (float)s->alpha;
-        q.settings.check_termination = s->check_termination; q.settings.adaptive_rho = s->adaptive_rho != 0;
-        q.settings.adaptive_rho_tolerance = (float)s->adaptive_rho_tolerance; q.settings.adaptive_rho_interval = s->adaptive_rho_interval;
-        q.pivot = (pivot_policy)pivot;
-        q.solve(H + (size_t)b * n * n, h + (size_t)b * n, A + (size_t)b * m * n, Alb + (size_t)b * m, Aub + (size_t)b * m, xlb + (size_t)b * n,
-                xub + (size_t)b * n, x0 ? x0 + (size_t)b * n : nullptr, y0 ? y0 + (size_t)b * (n + m) : nullptr);
-        for (int i = 0; i < n; ++i) x[(size_t)b * n + i] = q.x[i];
-        for (int i = 0; i < n + m; ++i) y[(size_t)b * (n + m) + i] = q.y[i];
-        info[b].status = q.info.status; info[b].iter = q.info.iter; info[b].rho_updates = q.info.rho_updates;
-        info[b].rho_estimate = q.info.rho_estimate; info[b].res_prim = q.info.res_prim; info[b].res_dual = q.info.res_dual;
-    }
+    qp_solve_batch_f32_impl<BoxADMMf>(B, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0, s, pivot, x, y, info);
+}
+void orc_qp_admm_solve_batch_f32(int B, int n, int m, const float* H, const float* h, const float* A, const float* Alb, const float* Aub,
+                                 const float* xlb, const float* xub, const float* x0, const float* y0, const orc_qp_settings* s, int pivot,
+                                 float* x, float* y, orc_qp_info* info) {
+    qp_solve_batch_f32_impl<ADMMf>(B, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0, s, pivot, x, y, info);
 }
 
 void orc_sqp_solve_batch(int model, int P, int S, double t0, double tf, const double* mparams, int n_mparams, int B,

@@ -75,6 +75,11 @@ void orc_qp_solve_batch_f32(int B, int n, int m, const float* H, const float* h,
                             const float* xlb, const float* xub, const float* x0, const float* y0, const orc_qp_settings* s, int pivot,
                             float* x, float* y, orc_qp_info* info);
 
+/* ADMM<N, M, float> (admm_solver_test.cpp:84-113), same arguments */
+void orc_qp_admm_solve_batch_f32(int B, int n, int m, const float* H, const float* h, const float* A, const float* Alb, const float* Aub,
+                                 const float* xlb, const float* xub, const float* x0, const float* y0, const orc_qp_settings* s, int pivot,
+                                 float* x, float* y, orc_qp_info* info);
+
 /* the OSQP-style ADMM solver (admm.hpp) on the same batch layout; y has m+n entries per instance ([general | box]) */
 void orc_qp_admm_solve_batch(int B, int n, int m, const double* H, const double* h, const double* A, const double* Alb,
                              const double* Aub, const double* xlb, const double* xub, const double* x0, const double* y0,

@@ -243,4 +243,107 @@ struct BoxADMMf {
     }
 };
 
+// ADMM<N, M, float> (admm.hpp, OSQP form: box constraints stacked under the general ones; tests/solvers/qp/admm_solver_test.cpp:84-113): oracle/admm.hpp in float
+struct ADMMf {
+    int N, M, ME;
+    qp_settings_f settings;
+    qp_info_f info;
+    pivot_policy pivot = PIVOT_EIGEN;
+    std::vector<float> x, y, z, z_tilde, z_prev, x_tilde, rho_vec, rho_inv_vec, K;
+    std::vector<int> ctype;
+    LDLTf ldlt;
+    float rho = 0, max_Ax_z_norm = 0, max_Hx_ATy_h_norm = 0;
+    int iter = 0;
+
+    ADMMf(int n, int m) : N(n), M(m), ME(n + m) {
+        x.assign(N, 0); x_tilde.assign(N, 0); y.assign(ME, 0); z.assign(ME, 0); z_tilde.assign(ME, 0); z_prev.assign(ME, 0);
+        rho_vec.assign(ME, 0); rho_inv_vec.assign(ME, 0); ctype.assign(ME, 0);
+        K.assign((size_t)(N + ME) * (N + ME), 0.0f);
+    }
+    void rho_vec_update(float rho0) {   // admm.hpp:405-440
+        for (int i = 0; i < ME; ++i) { rho_vec[i] = BoxADMMf::rho_of(ctype[i], rho0); rho_inv_vec[i] = 1.0f / rho_vec[i]; }
+        rho = rho0;
+        info.rho_updates += 1;
+    }
+    void construct_kkt(const float* H, const float* A) {   // :249-263
+        const int NM = N + ME;
+        std::fill(K.begin(), K.end(), 0.0f);
+        for (int j = 0; j < N; ++j) for (int i = 0; i < N; ++i) K[i + (size_t)j * NM] = H[i + j * N];
+        for (int i = 0; i < N; ++i) K[i + (size_t)i * NM] += settings.sigma;
+        for (int j = 0; j < N; ++j) for (int i = 0; i < M; ++i) K[(N + i) + (size_t)j * NM] = A[i + j * M];
+        for (int i = 0; i < N; ++i) K[(N + M + i) + (size_t)i * NM] = 1.0f;
+        for (int i = 0; i < ME; ++i) K[(N + i) + (size_t)(N + i) * NM] = -1.0f * rho_inv_vec[i];
+    }
+    void update_kkt_rho() { const int NM = N + ME; for (int i = 0; i < ME; ++i) K[(N + i) + (size_t)(N + i) * NM] = -rho_inv_vec[i]; }   // :490-494
+    void residuals_update(const float* H, const float* h, const float* A) {   // :442-462
+        std::vector<float> Ax(M), Hx(N), ATy(N);
+        for (int i = 0; i < M; ++i) { float a = 0; for (int j = 0; j < N; ++j) a += A[i + j * M] * x[j]; Ax[i] = a; }
+        float norm_Ax = BoxADMMf::inf_norm(Ax.data(), M);
+        norm_Ax = std::fmax(norm_Ax, BoxADMMf::inf_norm(x.data(), N));
+        max_Ax_z_norm = std::fmax(norm_Ax, BoxADMMf::inf_norm(z.data(), ME));
+        for (int i = 0; i < N; ++i) { float a = 0; for (int j = 0; j < N; ++j) a += H[i + j * N] * x[j]; Hx[i] = a; }
+        for (int j = 0; j < N; ++j) { float a = 0; for (int i = 0; i < M; ++i) a += A[i + j * M] * y[i]; ATy[j] = a; }
+        max_Hx_ATy_h_norm = std::fmax(BoxADMMf::inf_norm(Hx.data(), N), std::fmax(BoxADMMf::inf_norm(ATy.data(), N),
+                                      std::fmax(BoxADMMf::inf_norm(h, N), BoxADMMf::inf_norm(y.data() + M, N))));
+        float rp = 0, rb = 0, rd = 0;
+        for (int i = 0; i < M; ++i) rp = std::fmax(rp, std::fabs(Ax[i] - z[i]));
+        for (int i = 0; i < N; ++i) rb = std::fmax(rb, std::fabs(x[i] - z[M + i]));
+        info.res_prim = std::fmax(rp, rb);
+        for (int i = 0; i < N; ++i) rd = std::fmax(rd, std::fabs(((Hx[i] + h[i]) + ATy[i]) + y[M + i]));
+        info.res_dual = rd;
+    }
+    int solve(const float* H, const float* h, const float* A, const float* Alb, const float* Aub, const float* xl, const float* xu,
+              const float* x_guess, const float* y_guess) {   // :112-212
+        const int NM = N + ME;
+        std::vector<float> rhs(NM), sol(NM);
+        for (int i = 0; i < N; ++i) x[i] = x_guess ? x_guess[i] : 0.0f;
+        for (int i = 0; i < ME; ++i) y[i] = y_guess ? y_guess[i] : 0.0f;
+        for (int i = 0; i < M; ++i) { float a = 0; for (int j = 0; j < N; ++j) a += A[i + j * M] * x[j]; z[i] = a; }
+        for (int i = 0; i < N; ++i) z[M + i] = x[i];
+        for (int i = 0; i < M; ++i) ctype[i] = BoxADMMf::classify(Alb[i], Aub[i]);
+        for (int i = 0; i < N; ++i) ctype[M + i] = BoxADMMf::classify(xl[i], xu[i]);
+        rho_vec_update(settings.rho);
+        construct_kkt(H, A);
+        ldlt.compute(K, NM, pivot);
+        info.status = QP_UNSOLVED;
+        const float alpha = settings.alpha;
+        for (iter = 1; iter <= settings.max_iter; iter++) {
+            z_prev = z;
+            for (int i = 0; i < N; ++i) rhs[i] = settings.sigma * x[i] - h[i];
+            for (int i = 0; i < ME; ++i) rhs[N + i] = z[i] - rho_inv_vec[i] * y[i];
+            ldlt.solve(rhs.data(), sol.data());
+            for (int i = 0; i < N; ++i) x_tilde[i] = sol[i];
+            for (int i = 0; i < ME; ++i) z_tilde[i] = z_prev[i] + rho_inv_vec[i] * (sol[N + i] - y[i]);
+            for (int i = 0; i < N; ++i) x[i] = alpha * x_tilde[i] + (1 - alpha) * x[i];
+            for (int i = 0; i < ME; ++i) {
+                z[i] = alpha * z_tilde[i];
+                z[i] += (1 - alpha) * z_prev[i] + rho_inv_vec[i] * y[i];
+                const float lo = i < M ? Alb[i] : xl[i - M], hi = i < M ? Aub[i] : xu[i - M];
+                z[i] = std::fmin(std::fmax(z[i], lo), hi);
+            }
+            for (int i = 0; i < ME; ++i) y[i] += rho_vec[i] * ((alpha * z_tilde[i] + (1 - alpha) * z_prev[i]) - z[i]);
+            const bool check = (settings.check_termination != 0 && iter % settings.check_termination == 0);
+            if (check) {
+                residuals_update(H, h, A);
+                if (info.res_prim <= settings.eps_abs + settings.eps_rel * max_Ax_z_norm && info.res_dual <= settings.eps_abs + settings.eps_rel * max_Hx_ATy_h_norm) { info.status = QP_SOLVED; break; }
+            }
+            if (settings.adaptive_rho && iter % settings.adaptive_rho_interval == 0) {
+                if (!check) residuals_update(H, h, A);
+                const float rp = info.res_prim / (max_Ax_z_norm + BoxADMMf::DIV_BY_ZERO_REGUL), rd = info.res_dual / (max_Hx_ATy_h_norm + BoxADMMf::DIV_BY_ZERO_REGUL);
+                float new_rho = rho * std::sqrt(rp / (rd + BoxADMMf::DIV_BY_ZERO_REGUL));
+                new_rho = std::fmax(BoxADMMf::RHO_MIN, std::fmin(new_rho, BoxADMMf::RHO_MAX));
+                info.rho_estimate = new_rho;
+                if (new_rho < rho / settings.adaptive_rho_tolerance || new_rho > rho * settings.adaptive_rho_tolerance) {
+                    rho_vec_update(new_rho);
+                    update_kkt_rho();
+                    ldlt.compute(K, NM, pivot);
+                }
+            }
+        }
+        if (iter > settings.max_iter) info.status = QP_MAX_ITER_EXCEEDED;
+        info.iter = iter;
+        return info.status;
+    }
+};
+
 }  // namespace oracle

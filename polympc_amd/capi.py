@@ -18,7 +18,7 @@ FLAG_NONFINITE = 1   # pmpc_qp_info / pmpc_sqp_info flags: a non-finite value we
 EXPORTED_SYMBOLS = [
     "pmpc_version", "pmpc_status_string", "pmpc_create", "pmpc_destroy", "pmpc_synchronize", "pmpc_debug_phase_cycles",
     "pmpc_qp_settings_default", "pmpc_qp_settings_sqp_default", "pmpc_sqp_settings_default", "pmpc_chebyshev",
-    "pmpc_qp_boxadmm_solve_batch", "pmpc_qp_boxadmm_solve_batch_dev", "pmpc_qp_boxadmm_solve_batch_f32", "pmpc_qp_boxadmm_solve_batch_f32_dev", "pmpc_ocp_dims", "pmpc_ocp_linearise_batch",
+    "pmpc_qp_boxadmm_solve_batch", "pmpc_qp_boxadmm_solve_batch_dev", "pmpc_qp_boxadmm_solve_batch_f32", "pmpc_qp_boxadmm_solve_batch_f32_dev", "pmpc_qp_admm_solve_batch_f32", "pmpc_qp_admm_solve_batch_f32_dev", "pmpc_ocp_dims", "pmpc_ocp_linearise_batch",
     "pmpc_sqp_solve_batch", "pmpc_sqp_solve_batch_dev", "pmpc_sqp_solve_batch_user",
     "pmpc_mpc_step_batch_dev", "pmpc_mpc_batch_create", "pmpc_mpc_batch_step", "pmpc_mpc_batch_solution", "pmpc_mpc_batch_destroy",
     "pmpc_qp_admm_solve_batch", "pmpc_qp_admm_solve_batch_dev", "pmpc_qp_ruiz_compute_batch", "pmpc_qp_ruiz_compute_batch_dev", "pmpc_qp_ruiz_unscale_batch", "pmpc_qp_ruiz_unscale_batch_dev",
@@ -204,8 +204,9 @@ class Context:
                                                  y.ctypes.data_as(C.POINTER(C.c_double)), C.c_void_p(info.ctypes.data)))
         return x, y, info
 
-    def qp_solve_batch_f32(self, H, h, A, Alb, Aub, xlb, xub, settings=None, x0=None, y0=None):
-        """boxADMM<N, M, float> (pmpc_qp_boxadmm_solve_batch_f32): float32 host arrays in the layout of qp_solve_batch."""
+    def qp_solve_batch_f32(self, H, h, A, Alb, Aub, xlb, xub, settings=None, x0=None, y0=None, osqp_form=False):
+        """boxADMM<N, M, float> (pmpc_qp_boxadmm_solve_batch_f32; osqp_form: ADMM<N, M, float>, pmpc_qp_admm_solve_batch_f32): float32 host arrays in
+        the layout of qp_solve_batch."""
         f32 = lambda a: None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float32))
         pf = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
         H, h, A, Alb, Aub, xlb, xub, x0, y0 = (f32(a) for a in (H, h, A, Alb, Aub, xlb, xub, x0, y0))
@@ -213,7 +214,7 @@ class Context:
         m = Alb.shape[1] if Alb.ndim == 2 else 0
         s = settings or qp_settings_default()
         x = np.zeros((B, n), dtype=np.float32); y = np.zeros((B, n + m), dtype=np.float32); info = np.zeros(B, dtype=QP_INFO_DTYPE)
-        f = lib().pmpc_qp_boxadmm_solve_batch_f32
+        f = lib().pmpc_qp_admm_solve_batch_f32 if osqp_form else lib().pmpc_qp_boxadmm_solve_batch_f32
         f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_float)] * 9 + [C.POINTER(QPSettings)] + [C.POINTER(C.c_float)] * 2 + [C.c_void_p]
         _check(f(self._ctx, B, n, m, pf(H), pf(h), pf(A), pf(Alb), pf(Aub), pf(xlb), pf(xub), pf(x0), pf(y0), C.byref(s), pf(x), pf(y),
                  C.c_void_p(info.ctypes.data)))

@@ -44,6 +44,30 @@ struct F32Lds {
     }
 };
 
+// static-order LDL^T in place (right-looking, fma updates; two rows per lane: N <= 128)
+__device__ void factor_static(float* K, int N) {
+    const int ln = lane();
+    for (int k = 0; k < N; ++k) {
+        const float dk = K[k + k * N];
+        float col[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = ln + WAVE * e;
+            if (i > k && i < N) { col[e] = K[i + k * N]; K[i + k * N] = col[e] / dk; }
+        }
+        wsync();
+        for (int j = k + 1; j < N; ++j) {
+            const float ljk = K[j + k * N];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int i = ln + WAVE * e;
+                if (i >= j && i < N) K[i + j * N] = fmaf(-col[e], ljk, K[i + j * N]);
+            }
+        }
+        wsync();
+    }
+}
+
 // construct_kkt_matrix (box_admm.hpp:209-223) / update_kkt_rho (:448-452), then the static-order LDL^T (right-looking, fma updates).
 // The factorisation overwrites K in LDS, the reference keeps the unfactorised matrix and updates its diagonal in place: the primal diagonal is
 // carried in kdg with exactly those updates (first: (H_ii + sigma) + rho_i; later: += rho_i - rho_i_prev) and K is rebuilt around it.
@@ -62,40 +86,22 @@ __device__ void build_and_factor(const F32Lds& w, int n, int m, const float* __r
     for (int e = ln; e < m * n; e += WAVE) { const int i = e % m, j = e / m; w.K[(n + i) + j * N] = A[e]; }
     for (int i = ln; i < m; i += WAVE) w.K[(n + i) + (n + i) * N] = -w.rvi[i];
     wsync();
-    for (int k = 0; k < N; ++k) {
-        const float dk = w.K[k + k * N];
-        float col[2] = {0.0f, 0.0f};
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int i = ln + WAVE * e;
-            if (i > k && i < N) { col[e] = w.K[i + k * N]; w.K[i + k * N] = col[e] / dk; }
-        }
-        wsync();
-        for (int j = k + 1; j < N; ++j) {
-            const float ljk = w.K[j + k * N];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int i = ln + WAVE * e;
-                if (i >= j && i < N) w.K[i + j * N] = fmaf(-col[e], ljk, w.K[i + j * N]);
-            }
-        }
-        wsync();
-    }
+    factor_static(w.K, N);
 }
 
 // column-oriented substitutions in the order of the static-order CPU restatement: in place on v (N floats in LDS)
-__device__ void ldlt_solve(const F32Lds& w, int N, float* v) {
+__device__ void ldlt_solve(const float* K, int N, float* v) {
     const int ln = lane();
     for (int j = 0; j < N; ++j) {
         const float xj = v[j];
-        for (int i = j + 1 + ln; i < N; i += WAVE) v[i] = fmaf(-w.K[i + j * N], xj, v[i]);
+        for (int i = j + 1 + ln; i < N; i += WAVE) v[i] = fmaf(-K[i + j * N], xj, v[i]);
         wsync();
     }
-    for (int i = ln; i < N; i += WAVE) v[i] = v[i] / w.K[i + i * N];
+    for (int i = ln; i < N; i += WAVE) v[i] = v[i] / K[i + i * N];
     wsync();
     for (int j = N - 1; j >= 0; --j) {
         const float xj = v[j];
-        for (int i = ln; i < j; i += WAVE) v[i] = fmaf(-w.K[j + i * N], xj, v[i]);
+        for (int i = ln; i < j; i += WAVE) v[i] = fmaf(-K[j + i * N], xj, v[i]);
         wsync();
     }
 }
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(64) void qp_boxadmm_f32_kernel(int B, int n, int m,
         for (int i = ln; i < n; i += WAVE) w.rhs[i] = ((sigma * w.x[i] - w.hv[i]) + w.rb[i] * w.q[i]) - w.y[m + i];   // compute_kkt_rhs :351-355
         for (int i = ln; i < m; i += WAVE) w.rhs[n + i] = w.z[i] - w.rvi[i] * w.y[i];
         wsync();
-        ldlt_solve(w, N, w.rhs);
+        ldlt_solve(w.K, N, w.rhs);
         for (int i = ln; i < n; i += WAVE) {
             const float xt = w.rhs[i];
             float xx = alpha * xt; xx += (1 - alpha) * xx;   // quirk Q1 (:129-130)
@@ -212,30 +218,172 @@ __global__ __launch_bounds__(64) void qp_boxadmm_f32_kernel(int B, int n, int m,
     }
 }
 
+// ADMM<N, M, float> (admm.hpp:112-212, OSQP form; tests/solvers/qp/admm_solver_test.cpp:84-113): the box constraints stacked under the general ones,
+// z / y / rho over the ME = m + n rows of A_e = [A ; I], one (2n + m)-row KKT matrix [H + sigma I, A_e' ; A_e, -diag(1/rho)] (construct_kkt_matrix
+// :249-263) in LDS, no quirk Q1. A rho update changes the lower diagonal only (update_kkt_rho :490-494): K is rebuilt (the same values) and re-factorised.
+struct F32AdmmLds {
+    float *K, *x, *y, *z, *zp, *rv, *rvi, *rhs, *lo, *hi, *hv;
+    int* type;
+    __host__ __device__ static size_t floats(int n, int m) { const size_t NK = 2 * (size_t)n + m; return NK * NK + 12 * NK + 16; }
+    __device__ void carve(float* p, int n, int m) {
+        const int ME = n + m, NK = n + ME;
+        K = p; p += (size_t)NK * NK;
+        x = p; p += n; y = p; p += ME; z = p; p += ME; zp = p; p += ME; rv = p; p += ME; rvi = p; p += ME; rhs = p; p += NK;
+        lo = p; p += ME; hi = p; p += ME; hv = p; p += n;
+        type = (int*)p;
+    }
+};
+
+__device__ void admm_build_and_factor(const F32AdmmLds& w, int n, int m, const float* __restrict__ H, const float* __restrict__ A, float sigma) {
+    const int ME = n + m, NK = n + ME, ln = lane();
+    for (int e = ln; e < NK * NK; e += WAVE) w.K[e] = 0.0f;
+    wsync();
+    for (int e = ln; e < n * n; e += WAVE) { const int i = e % n, j = e / n; w.K[i + j * NK] = H[e]; }
+    wsync();
+    for (int i = ln; i < n; i += WAVE) { w.K[i + i * NK] += sigma; w.K[(n + m + i) + i * NK] = 1.0f; }
+    for (int e = ln; e < m * n; e += WAVE) { const int i = e % m, j = e / m; w.K[(n + i) + j * NK] = A[e]; }
+    for (int i = ln; i < ME; i += WAVE) w.K[(n + i) + (n + i) * NK] = -1.0f * w.rvi[i];
+    wsync();
+    factor_static(w.K, NK);
+}
+
+__global__ __launch_bounds__(64) void qp_admm_f32_kernel(int B, int n, int m, const float* __restrict__ Hb, const float* __restrict__ hb,
+                                                         const float* __restrict__ Ab, const float* __restrict__ Albb, const float* __restrict__ Aubb,
+                                                         const float* __restrict__ xlbb, const float* __restrict__ xubb, const float* __restrict__ x0b,
+                                                         const float* __restrict__ y0b, pmpc_qp_settings sd, float* __restrict__ xo, float* __restrict__ yo,
+                                                         pmpc_qp_info* __restrict__ info) {
+    extern __shared__ float smem_f[];
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const int ME = n + m, NK = n + ME, ln = lane();
+    F32AdmmLds w; w.carve(smem_f, n, m);
+    const float* H = Hb + (size_t)b * n * n; const float* h = hb + (size_t)b * n; const float* A = Ab + (size_t)b * m * n;
+    const float eps_rel = (float)sd.eps_rel, eps_abs = (float)sd.eps_abs, sigma = (float)sd.sigma, alpha = (float)sd.alpha, tol = (float)sd.adaptive_rho_tolerance;
+    float rho = (float)sd.rho;
+    for (int i = ln; i < n; i += WAVE) {
+        w.hv[i] = h[i]; w.lo[m + i] = xlbb[(size_t)b * n + i]; w.hi[m + i] = xubb[(size_t)b * n + i];
+        w.x[i] = x0b ? x0b[(size_t)b * n + i] : 0.0f;
+        w.type[m + i] = classify(w.lo[m + i], w.hi[m + i]);
+    }
+    for (int i = ln; i < m; i += WAVE) {
+        w.lo[i] = Albb[(size_t)b * m + i]; w.hi[i] = Aubb[(size_t)b * m + i];
+        w.type[i] = classify(w.lo[i], w.hi[i]);
+    }
+    for (int i = ln; i < ME; i += WAVE) w.y[i] = y0b ? y0b[(size_t)b * ME + i] : 0.0f;
+    wsync();
+    for (int i = ln; i < m; i += WAVE) { float a = 0.0f; for (int j = 0; j < n; ++j) a += A[i + j * m] * w.x[j]; w.z[i] = a; }   // z = A_e x_guess
+    for (int i = ln; i < n; i += WAVE) w.z[m + i] = w.x[i];
+    auto rho_vec_update = [&](float rho0) {   // admm.hpp:405-440
+        for (int i = ln; i < ME; i += WAVE) { w.rv[i] = rho_of(w.type[i], rho0); w.rvi[i] = 1.0f / w.rv[i]; }
+        wsync();
+    };
+    int rho_updates = 1;
+    rho_vec_update(rho);
+    admm_build_and_factor(w, n, m, H, A, sigma);
+    int status = PMPC_QP_UNSOLVED, iter = 1;
+    float max_Ax_z = 0.0f, max_Hx = 0.0f, res_prim = 1.0f, res_dual = 1.0f, rho_estimate = 0.0f;
+    for (; iter <= sd.max_iter; ++iter) {
+        for (int i = ln; i < ME; i += WAVE) w.zp[i] = w.z[i];
+        for (int i = ln; i < n; i += WAVE) w.rhs[i] = sigma * w.x[i] - w.hv[i];   // compute_kkt_rhs :390-394
+        for (int i = ln; i < ME; i += WAVE) w.rhs[n + i] = w.z[i] - w.rvi[i] * w.y[i];
+        wsync();
+        ldlt_solve(w.K, NK, w.rhs);
+        for (int i = ln; i < n; i += WAVE) w.x[i] = alpha * w.rhs[i] + (1 - alpha) * w.x[i];   // :152
+        for (int i = ln; i < ME; i += WAVE) {
+            const float zt = w.zp[i] + w.rvi[i] * (w.rhs[n + i] - w.y[i]);
+            float zz = alpha * zt;
+            zz += (1 - alpha) * w.zp[i] + w.rvi[i] * w.y[i];
+            zz = fminf(fmaxf(zz, w.lo[i]), w.hi[i]);
+            w.z[i] = zz;
+            w.y[i] += w.rv[i] * ((alpha * zt + (1 - alpha) * w.zp[i]) - zz);
+        }
+        wsync();
+        const bool check = sd.check_termination != 0 && iter % sd.check_termination == 0;
+        const bool adapt = sd.adaptive_rho && iter % sd.adaptive_rho_interval == 0;
+        if (check || adapt) {   // residuals_update :442-462
+            float nAx = 0.0f, nz = 0.0f, nx = 0.0f, nHx = 0.0f, nATy = 0.0f, nh = 0.0f, nyb = 0.0f, rp = 0.0f, rb = 0.0f, rd = 0.0f;
+            for (int i = ln; i < m; i += WAVE) {
+                float a = 0.0f; for (int j = 0; j < n; ++j) a += A[i + j * m] * w.x[j];
+                nAx = fmaxf(nAx, fabsf(a)); rp = fmaxf(rp, fabsf(a - w.z[i]));
+            }
+            for (int i = ln; i < ME; i += WAVE) nz = fmaxf(nz, fabsf(w.z[i]));
+            for (int i = ln; i < n; i += WAVE) {
+                float hx = 0.0f; for (int j = 0; j < n; ++j) hx += H[i + j * n] * w.x[j];
+                float aty = 0.0f; for (int k = 0; k < m; ++k) aty += A[k + i * m] * w.y[k];
+                nx = fmaxf(nx, fabsf(w.x[i])); nHx = fmaxf(nHx, fabsf(hx)); nATy = fmaxf(nATy, fabsf(aty));
+                nh = fmaxf(nh, fabsf(w.hv[i])); nyb = fmaxf(nyb, fabsf(w.y[m + i]));
+                rb = fmaxf(rb, fabsf(w.x[i] - w.z[m + i]));
+                rd = fmaxf(rd, fabsf(((hx + w.hv[i]) + aty) + w.y[m + i]));
+            }
+            max_Ax_z = wave_max(fmaxf(fmaxf(nAx, nx), nz));
+            max_Hx = wave_max(fmaxf(nHx, fmaxf(nATy, fmaxf(nh, nyb))));
+            res_prim = fmaxf(wave_max(rp), wave_max(rb));
+            res_dual = wave_max(rd);
+        }
+        if (check && res_prim <= eps_abs + eps_rel * max_Ax_z && res_dual <= eps_abs + eps_rel * max_Hx) { status = PMPC_QP_SOLVED; break; }
+        if (adapt) {
+            const float rpn = res_prim / (max_Ax_z + F_DIV_BY_ZERO_REGUL);
+            const float rdn = res_dual / (max_Hx + F_DIV_BY_ZERO_REGUL);
+            float new_rho = rho * sqrtf(rpn / (rdn + F_DIV_BY_ZERO_REGUL));
+            new_rho = fmaxf(F_RHO_MIN, fminf(new_rho, F_RHO_MAX));
+            rho_estimate = new_rho;
+            if (new_rho < rho / tol || new_rho > rho * tol) {
+                rho = new_rho;
+                rho_vec_update(rho);
+                ++rho_updates;
+                admm_build_and_factor(w, n, m, H, A, sigma);
+            }
+        }
+    }
+    if (iter > sd.max_iter) status = PMPC_QP_MAX_ITER_EXCEEDED;
+    for (int i = ln; i < n; i += WAVE) xo[(size_t)b * n + i] = w.x[i];
+    for (int i = ln; i < ME; i += WAVE) yo[(size_t)b * ME + i] = w.y[i];
+    bool bad = false;
+    for (int i = ln; i < n; i += WAVE) bad |= (w.x[i] - w.x[i]) != 0.0f;
+    for (int i = ln; i < ME; i += WAVE) bad |= (w.y[i] - w.y[i]) != 0.0f;
+    const bool anybad = __builtin_amdgcn_ballot_w64(bad) != 0;
+    if (ln == 0) {
+        pmpc_qp_info qi; qi.status = status; qi.iter = iter; qi.rho_updates = rho_updates; qi.flags = anybad ? PMPC_FLAG_NONFINITE : 0;
+        qi.rho_estimate = rho_estimate; qi.res_prim = res_prim; qi.res_dual = res_dual;
+        info[b] = qi;
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
-pmpc_status pmpc_qp_boxadmm_solve_batch_f32_dev(pmpc_context* ctx, int B, int n, int m, const float* H, const float* h, const float* A, const float* Alb,
-                                                const float* Aub, const float* xlb, const float* xub, const float* x0, const float* y0,
-                                                const pmpc_qp_settings* settings, float* x, float* y, pmpc_qp_info* info) {
+static pmpc_status f32_solve_dev(bool osqp, pmpc_context* ctx, int B, int n, int m, const float* H, const float* h, const float* A, const float* Alb,
+                                 const float* Aub, const float* xlb, const float* xub, const float* x0, const float* y0,
+                                 const pmpc_qp_settings* settings, float* x, float* y, pmpc_qp_info* info) {
     if (!ctx || B < 0 || n < 1 || m < 0 || !H || !h || !xlb || !xub || !settings || !x || !y || !info) return PMPC_ERR_INVALID_ARGUMENT;
     if (m > 0 && (!A || !Alb || !Aub)) return PMPC_ERR_INVALID_ARGUMENT;
     if ((x0 == nullptr) != (y0 == nullptr)) return PMPC_ERR_INVALID_ARGUMENT;
     if (settings->linear_solver != 0) return PMPC_ERR_INVALID_ARGUMENT;   // the static order only
     if (B == 0) return PMPC_OK;
     HIPCHK(hipSetDevice(ctx->device));
-    const size_t lds = F32Lds::floats(n, m) * sizeof(float);
-    if (n + m > 2 * WAVE || lds > ctx->lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;   // two KKT rows per lane, the matrix in LDS
-    HIPCHK(hipFuncSetAttribute((const void*)qp_boxadmm_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(qp_boxadmm_f32_kernel, dim3(B), dim3(WAVE), lds, ctx->stream, B, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0, *settings, x, y, info);
+    const size_t lds = (osqp ? F32AdmmLds::floats(n, m) : F32Lds::floats(n, m)) * sizeof(float);
+    if ((osqp ? 2 * n + m : n + m) > 2 * WAVE || lds > ctx->lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;   // two KKT rows per lane, the matrix in LDS
+    auto kern = osqp ? qp_admm_f32_kernel : qp_boxadmm_f32_kernel;
+    HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), lds, ctx->stream, B, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0, *settings, x, y, info);
     HIPCHK(hipGetLastError());
     return PMPC_OK;
 }
+pmpc_status pmpc_qp_boxadmm_solve_batch_f32_dev(pmpc_context* ctx, int B, int n, int m, const float* H, const float* h, const float* A, const float* Alb,
+                                                const float* Aub, const float* xlb, const float* xub, const float* x0, const float* y0,
+                                                const pmpc_qp_settings* settings, float* x, float* y, pmpc_qp_info* info) {
+    return f32_solve_dev(false, ctx, B, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0, settings, x, y, info);
+}
+pmpc_status pmpc_qp_admm_solve_batch_f32_dev(pmpc_context* ctx, int B, int n, int m, const float* H, const float* h, const float* A, const float* Alb,
+                                             const float* Aub, const float* xlb, const float* xub, const float* x0, const float* y0,
+                                             const pmpc_qp_settings* settings, float* x, float* y, pmpc_qp_info* info) {
+    return f32_solve_dev(true, ctx, B, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0, settings, x, y, info);
+}
 
-pmpc_status pmpc_qp_boxadmm_solve_batch_f32(pmpc_context* ctx, int B, int n, int m, const float* H, const float* h, const float* A, const float* Alb,
-                                            const float* Aub, const float* xlb, const float* xub, const float* x0, const float* y0,
-                                            const pmpc_qp_settings* settings, float* x, float* y, pmpc_qp_info* info) {
+static pmpc_status f32_solve_host(bool osqp, pmpc_context* ctx, int B, int n, int m, const float* H, const float* h, const float* A, const float* Alb,
+                                  const float* Aub, const float* xlb, const float* xub, const float* x0, const float* y0,
+                                  const pmpc_qp_settings* settings, float* x, float* y, pmpc_qp_info* info) {
     if (!ctx || B < 0 || n < 1 || m < 0 || !H || !h || !xlb || !xub || !settings || !x || !y || !info) return PMPC_ERR_INVALID_ARGUMENT;
     if (m > 0 && (!A || !Alb || !Aub)) return PMPC_ERR_INVALID_ARGUMENT;
     if ((x0 == nullptr) != (y0 == nullptr)) return PMPC_ERR_INVALID_ARGUMENT;
@@ -258,14 +406,24 @@ pmpc_status pmpc_qp_boxadmm_solve_batch_f32(pmpc_context* ctx, int B, int n, int
     st = ensure_scratch(ctx, 10, Bz * (n + m) * sizeof(float), &dy); if (st != PMPC_OK) return st;
     st = ensure_scratch(ctx, 11, Bz * sizeof(pmpc_qp_info), &di); if (st != PMPC_OK) return st;
     if (m == 0) { dev[2] = dev[3] = dev[4] = (float*)dx; }   // never read (m = 0), but the device entry wants non-null pointers only when m > 0
-    st = pmpc_qp_boxadmm_solve_batch_f32_dev(ctx, B, n, m, dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], dev[6], dev[7], dev[8], settings,
-                                             (float*)dx, (float*)dy, (pmpc_qp_info*)di);
+    st = f32_solve_dev(osqp, ctx, B, n, m, dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], dev[6], dev[7], dev[8], settings,
+                       (float*)dx, (float*)dy, (pmpc_qp_info*)di);
     if (st != PMPC_OK) return st;
     HIPCHK(hipMemcpyAsync(x, dx, Bz * n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(y, dy, Bz * (n + m) * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(info, di, Bz * sizeof(pmpc_qp_info), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return PMPC_OK;
+}
+pmpc_status pmpc_qp_boxadmm_solve_batch_f32(pmpc_context* ctx, int B, int n, int m, const float* H, const float* h, const float* A, const float* Alb,
+                                            const float* Aub, const float* xlb, const float* xub, const float* x0, const float* y0,
+                                            const pmpc_qp_settings* settings, float* x, float* y, pmpc_qp_info* info) {
+    return f32_solve_host(false, ctx, B, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0, settings, x, y, info);
+}
+pmpc_status pmpc_qp_admm_solve_batch_f32(pmpc_context* ctx, int B, int n, int m, const float* H, const float* h, const float* A, const float* Alb,
+                                         const float* Aub, const float* xlb, const float* xub, const float* x0, const float* y0,
+                                         const pmpc_qp_settings* settings, float* x, float* y, pmpc_qp_info* info) {
+    return f32_solve_host(true, ctx, B, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0, settings, x, y, info);
 }
 
 }  // extern "C"

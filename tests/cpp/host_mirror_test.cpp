@@ -1,6 +1,7 @@
 // Host-side tests written like the reference's own gtest cases, against include/polympc/polympc.hpp.
 //   box_admmSimpleQP / SimpleLP / NonConvex    tests/solvers/qp/box_admm_test.cpp:15-45, :266-297, :299-334
 //   box_admmSinglePrecisionFloat                tests/solvers/qp/box_admm_test.cpp:85-115 (boxADMM<2, 1, float>)
+//   admmSinglePrecisionFloat                    tests/solvers/qp/admm_solver_test.cpp:84-113 (ADMM<2, 1, float>)
 //   MPCWrapperTest                              tests/control/mpc_wrapper_test.cpp:120-199 (dense-BFGS variant)
 //   ValetParkingTest                            tests/control/valet_parking_mpc_test.cpp:183-240 (Ruiz + filter line search + block BFGS)
 //   user-registered OCP                         docs/source/ocp.rst:229-481 workflow, compiled by hipcc (user_ocp.hip)
@@ -40,6 +41,22 @@ static void box_admmSinglePrecisionFloat() {   // box_admm_test.cpp:85-115
     QP prob;
     prob.settings().max_iter = 150;
     prob.solve(H, h, A, Al, Au, xl, xu);
+    const QP::qp_var_t sol = prob.primal_solution();
+    EXPECT_TRUE(sol.isApprox(solution, Scalar(1e-2)));
+    EXPECT_LT(prob.iter, prob.settings().max_iter);
+    EXPECT_EQ(prob.info().status, SOLVED);
+}
+
+static void admmSinglePrecisionFloat() {   // admm_solver_test.cpp:84-113
+    std::printf("admmSinglePrecisionFloat\n");
+    using Scalar = float;
+    using QP = ADMM<2, 1, Scalar>;
+    QP::qp_hessian_t H; QP::qp_var_t h, xl, xu, solution; QP::qp_constraint_t A; QP::qp_dual_a_t al, au;
+    H(0, 0) = 4; H(0, 1) = 1; H(1, 0) = 1; H(1, 1) = 2;
+    h(0) = 1; h(1) = 1; A(0, 0) = 1; A(0, 1) = 1; al(0) = 1; xl(0) = 0; xl(1) = 0; au(0) = 1; xu(0) = Scalar(0.7); xu(1) = Scalar(0.7);
+    solution(0) = Scalar(0.3); solution(1) = Scalar(0.7);
+    QP prob;
+    prob.solve(H, h, A, al, au, xl, xu);
     const QP::qp_var_t sol = prob.primal_solution();
     EXPECT_TRUE(sol.isApprox(solution, Scalar(1e-2)));
     EXPECT_LT(prob.iter, prob.settings().max_iter);
@@ -308,6 +325,7 @@ int main() {
     if (!polympc::context()) { std::printf("no GPU: %s\n", pmpc_status_string(polympc::last_error())); return 77; }
     box_admmSimpleQP();
     box_admmSinglePrecisionFloat();
+    admmSinglePrecisionFloat();
     box_admmRuizEquilibration();
     ValetParkingTest();
     admmSimpleQP();

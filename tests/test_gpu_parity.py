@@ -363,12 +363,19 @@ def test_sqp_with_ruiz_preconditioner_vs_oracle(ctx, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,m,B", [(2, 1, 1), (7, 3, 33), (35, 21, 16), (5, 0, 4), (66, 44, 3), (3, 70, 2)])
-def test_qp_single_precision_vs_oracle(ctx, oracle, n, m, B):
-    """pmpc_qp_boxadmm_solve_batch_f32 = boxADMM<N, M, float> (box_admm_test.cpp:85-115): the reference's float fixture (n = 2, m = 1) and random QPs,
+@pytest.mark.parametrize("osqp_form", [False, True])
+@pytest.mark.parametrize("n,m,B", [(2, 1, 1), (7, 3, 33), (35, 21, 16), (5, 0, 4), (66, 44, 3), (3, 70, 2), (40, 24, 3)])
+def test_qp_single_precision_vs_oracle(ctx, oracle, n, m, B, osqp_form):
+    """pmpc_qp_boxadmm_solve_batch_f32 = boxADMM<N, M, float> (box_admm_test.cpp:85-115) and pmpc_qp_admm_solve_batch_f32 = ADMM<N, M, float>
+    (admm_solver_test.cpp:84-113, the stacked (2n+m)-row system): the reference's float fixture (n = 2, m = 1) and random QPs,
     cold and warm-started, with adaptive rho — identical iteration counts, statuses, rho updates and BIT-IDENTICAL float x / y / residuals against
     the float restatement in the kernel's static order; the fixture's own assertions hold on the GPU result."""
     import polympc_amd as pa
+    if osqp_form and 2 * n + m > 128:
+        with pytest.raises(RuntimeError):   # the stacked system must fit two rows per lane
+            z = np.zeros((1, n), dtype=np.float32)
+            ctx.qp_solve_batch_f32(np.eye(n, dtype=np.float32).reshape(1, -1), z, np.zeros((1, m * n)), np.zeros((1, m)), np.zeros((1, m)), z - 1, z + 1, osqp_form=True)
+        return
     if (n, m, B) == (2, 1, 1):
         H = np.array([[4, 1, 1, 2]], dtype=np.float32); h = np.array([[1, 1]], dtype=np.float32); A = np.array([[1, 1]], dtype=np.float32)
         al = np.array([[1]], dtype=np.float32); au = al.copy(); xl = np.zeros((1, 2), dtype=np.float32); xu = np.full((1, 2), 0.7, dtype=np.float32)
@@ -382,8 +389,8 @@ def test_qp_single_precision_vs_oracle(ctx, oracle, n, m, B):
         so = oracle.qp_default_settings(); so.max_iter = iters; so.adaptive_rho = adaptive; so.adaptive_rho_interval = 25
         x0 = y0 = None
         for warm in (False, True):
-            x, y, info = ctx.qp_solve_batch_f32(H, h, A, al, au, xl, xu, settings=s, x0=x0, y0=y0)
-            xo, yo, io = oracle.qp_solve_batch_f32(H, h, A, al, au, xl, xu, settings=so, pivot=oracle.PIVOT_STATIC, x0=x0, y0=y0)
+            x, y, info = ctx.qp_solve_batch_f32(H, h, A, al, au, xl, xu, settings=s, x0=x0, y0=y0, osqp_form=osqp_form)
+            xo, yo, io = oracle.qp_solve_batch_f32(H, h, A, al, au, xl, xu, settings=so, pivot=oracle.PIVOT_STATIC, x0=x0, y0=y0, osqp_form=osqp_form)
             assert np.array_equal(info["iter"], [i.iter for i in io]) and np.array_equal(info["status"], [i.status for i in io])
             assert np.array_equal(info["rho_updates"], [i.rho_updates for i in io])
             assert x.dtype == np.float32 and x.tobytes() == xo.tobytes() and y.tobytes() == yo.tobytes()
@@ -392,10 +399,10 @@ def test_qp_single_precision_vs_oracle(ctx, oracle, n, m, B):
             x0, y0 = x, y
     if (n, m, B) == (2, 1, 1):
         sol = np.array([0.3, 0.7], dtype=np.float32)
-        s = pa.qp_settings_default(); s.max_iter = 150
-        x, y, info = ctx.qp_solve_batch_f32(H, h, A, al, au, xl, xu, settings=s)
+        s = pa.qp_settings_default(); s.max_iter = 1000 if osqp_form else 150   # (the ADMM test keeps the default max_iter)
+        x, y, info = ctx.qp_solve_batch_f32(H, h, A, al, au, xl, xu, settings=s, osqp_form=osqp_form)
         assert np.linalg.norm(x[0] - sol) <= 1e-2 * min(np.linalg.norm(x[0]), np.linalg.norm(sol))
-        assert info["iter"][0] < 150 and info["status"][0] == pa.QP_SOLVED
+        assert info["iter"][0] < s.max_iter and info["status"][0] == pa.QP_SOLVED
     with pytest.raises(RuntimeError):   # the matrix lives in LDS, two KKT rows per lane
         z = np.zeros((1, 130), dtype=np.float32)
         ctx.qp_solve_batch_f32(np.eye(130, dtype=np.float32).reshape(1, -1), z, np.zeros((1, 0)), np.zeros((1, 0)), np.zeros((1, 0)), z - 1, z + 1)

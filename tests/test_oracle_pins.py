@@ -785,3 +785,17 @@ def test_box_admm_single_precision_float_fixture(oracle):
         x, y, info = oracle.qp_solve_batch_f32(Hs, hs, As, al, au, xl, xu, settings=s2, pivot=piv)
         assert all(i.status == oracle.QP_SOLVED for i in info)
         assert np.abs(x - xd).max() < 2e-3   # both stop at eps = 1e-3; the iterates agree to single precision until then
+
+
+def test_admm_single_precision_float_fixture(oracle):
+    """tests/solvers/qp/admm_solver_test.cpp:84-113 (admmSinglePrecisionFloat): ADMM<2, 1, float> with the default settings — within 1e-2 of (0.3, 0.7),
+    SOLVED, fewer than max_iter iterations, under both factorisation orders of the float restatement; the iteration count of the double solve."""
+    H = np.array([[4, 1, 1, 2]], dtype=np.float32)
+    s = oracle.qp_default_settings()
+    xd, yd, infod = oracle.qp_admm_solve_batch(H, [[1, 1]], [[1, 1]], [[1]], [[1]], [[0, 0]], [[0.7, 0.7]], settings=s)
+    sol = np.array([0.3, 0.7], dtype=np.float32)
+    for piv in (oracle.PIVOT_EIGEN, oracle.PIVOT_STATIC):
+        x, y, info = oracle.qp_solve_batch_f32(H, [[1, 1]], [[1, 1]], [[1]], [[1]], [[0, 0]], [[0.7, 0.7]], settings=s, pivot=piv, osqp_form=True)
+        assert np.linalg.norm(x[0] - sol) <= 1e-2 * min(np.linalg.norm(x[0]), np.linalg.norm(sol))
+        assert info[0].status == oracle.QP_SOLVED and info[0].iter < s.max_iter and info[0].iter == infod[0].iter
+        assert np.abs(x[0] - xd[0]).max() < 1e-5

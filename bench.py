@@ -197,6 +197,8 @@ def main():
     solved = int((info["status"] == pa.SQP_SOLVED).sum())
     (qp_all, admm_all, solved_all), elapsed = sharding.combine_stats(dist, red_dev, [qp_solves, admm_iters, solved], elapsed)
 
+    sol = [None]
+
     def sqp_record(cwl, Bc, steps, warmup, kernel_name, **settings):
         """A few launches of another configuration on this rank's context: ms per batch (median of HIP-event times), QP/s, rooflines."""
         cn, cm = cwl["n"], cwl["m"]
@@ -218,10 +220,11 @@ def main():
         inf = np.frombuffer(ci.cpu().numpy().tobytes(), dtype=pa.capi.SQP_INFO_DTYPE)
         qps = int(inf["iter"].sum()); its = int(inf["qp_solver_iter"].sum())
         med = float(np.median(ms)) * 1e-3
+        sol[0] = (cx.cpu().numpy(), clam.cpu().numpy(), inf)   # for the parity objects of the CPU leg
         return {"batch": Bc, "n": cn, "m": cm, "kkt_rows": cn + cm, "steps": steps, "kernel": kernel_name,
                 "ms_per_batch": {"min": float(ms.min()), "median": float(np.median(ms)), "max": float(ms.max())},
                 "qp_solves_per_s": qps / med, "sqp_solves_per_s": Bc / med, "qp_solves_per_batch": qps, "admm_iters_per_qp": its / max(qps, 1),
-                "sqp_solved_fraction": float((inf["status"] == pa.SQP_SOLVED).mean()),
+                "sqp_solved_fraction": float((inf["status"] == pa.SQP_SOLVED).mean()), "route": pa.capi.ROUTE_NAMES.get(ctx.last_route(), "?"),
                 "roofline_hbm_frac": qp_algorithmic_bytes(cn, cm) * qps / med / 1e9 / PEAK_HBM_GBS,
                 "roofline_fp64_frac": qp_algorithmic_flops(cn, cm, its / max(qps, 1), 1.0) * qps / med / 1e12 / PEAK_FP64_TFLOPS}
 
@@ -265,18 +268,23 @@ def main():
             # ---- BASELINE.json configs[2..4] (a few launches each; the headline above stays configs[1])
             want = [c for c in args.configs.split(",") if c]
             cfg = {}
+            cfg_runs = {}   # key -> (letter, workload, batch, GPU solution) for the CPU leg below
+            def add(key, letter, cwl, Bc, steps, warmup, kernel_name, workload):
+                cfg[key] = sqp_record(cwl, Bc, steps, warmup, kernel_name)
+                cfg[key]["workload"] = workload
+                cfg_runs[key] = (letter, cwl, Bc, sol[0])
             if "D" in want:
-                cfg["D_scenario_8192_per_gpu"] = sqp_record(workloads.robot_batch(8192, perturb_d=True, first=5000), 8192, 10, 2, "sqp_kernel<RobotOCP,35,21>")
-                cfg["D_scenario_8192_per_gpu"]["workload"] = "mobile robot, perturbed wheel base d = 2(1+0.1U), 8192 instances per GPU (65 536 over 8 GPUs)"
+                add("D_scenario_8192_per_gpu", "D", workloads.robot_batch(8192, perturb_d=True, first=5000), 8192, 10, 2, "sqp_kernel<RobotOCP,35,21>",
+                    "mobile robot, perturbed wheel base d = 2(1+0.1U), 8192 instances per GPU (65 536 over 8 GPUs)")
             if "B" in want:
-                cfg["B_cstr_16384"] = sqp_record(workloads.cstr_batch(16384), 16384, 3, 1, "sqp_kernel<CstrOCP> (110 KKT rows)")
-                cfg["B_cstr_16384"]["workload"] = "CSTR nx=4 nu=2, P=5 S=2 (11 nodes), t in [0,100], SQP max_iter=20 ls=20"
+                add("B_cstr_16384", "B", workloads.cstr_batch(16384), 16384, 5, 1, "sqp_kernel<CstrOCP,66,44> (110 KKT rows)",
+                    "CSTR nx=4 nu=2, P=5 S=2 (11 nodes), t in [0,100], SQP max_iter=20 ls=20")
             if "C" in want:
-                cfg["C_kite_standin_1024"] = sqp_record(workloads.kite_standin_batch(1024), 1024, 2, 1, "sqp_kernel<KiteStandInOCP> (464 KKT rows)")
-                cfg["C_kite_standin_1024"]["workload"] = "SYNTHETIC 13-state / 3-input stand-in (the reference tree has no kite model), P=5 S=3 (16 nodes), SQP max_iter=5"
+                add("C_kite_standin_1024", "C", workloads.kite_standin_batch(1024), 1024, 4, 1, "sqp_kernel<KiteStandInOCP> (464 KKT rows)",
+                    "SYNTHETIC 13-state / 3-input stand-in (the reference tree has no kite model), P=5 S=3 (16 nodes), SQP max_iter=5")
             if "R" in want:
-                cfg["R_robot_16_nodes_2048"] = sqp_record(workloads.robot_batch(2048, P=5, S=3), 2048, 3, 1, "sqp_kernel<RobotOCP> (128 KKT rows, HBM-factor kernel)")
-                cfg["R_robot_16_nodes_2048"]["workload"] = "mobile robot on the reference's mpc_wrapper_test grid, P=5 S=3 (16 nodes, n=80, m=48), 2048 instances (not a BASELINE.json configuration: the mid-size path)"
+                add("R_robot_16_nodes_2048", "R", workloads.robot_batch(2048, P=5, S=3), 2048, 5, 1, "sqp_kernel<RobotOCP> (128 KKT rows)",
+                    "mobile robot on the reference's mpc_wrapper_test grid, P=5 S=3 (16 nodes, n=80, m=48), 2048 instances (not a BASELINE.json configuration: the mid-size path)")
             if cfg:
                 out["configs"] = cfg
             if not args.no_replay:
@@ -355,12 +363,50 @@ def main():
                         "max_abs_dlam": float(np.abs(lg - lo).max()), "max_abs_d_primal_norm": kk("primal_norm"), "max_abs_d_dual_norm": kk("dual_norm"),
                         "max_abs_d_constraint_violation": kk("max_violation"), "max_abs_d_cost": kk("cost"), "note": note}
 
+            # ---- the same two objects + a CPU baseline beside every sub-record ("the reference CPU path timed next to it"): bounded samples
+            from polympc_amd.parity_stats import cross_order_stats
+            SAMPLE = {"D": (4096, 256), "B": (2048, 64), "C": (64, 8), "R": (1024, 128)}   # instances of the (all-core, single-core) CPU samples / parity objects
+            for key, (letter, cwl, Bfull, gsol) in (cfg_runs.items() if world == 1 and "configs" in out else []):
+                n_all, n_one = SAMPLE[letter]
+                coss = ob.sqp_default_settings(); coss.max_iter = cwl["max_iter"]; coss.line_search_max_iter = cwl["ls_max_iter"]
+                rows = cwl["n"] + cwl["m"]
+                korder = ob.PIVOT_SWEEP if rows <= 64 else (ob.PIVOT_SWEEP2 if rows <= ob.SWEEP2_MAX_ROWS else ob.PIVOT_BLOCKED)
+
+                def crun(count, threads, pivot, glibc):
+                    with (ob.libm() if glibc else _null()):
+                        return ob.sqp_solve_batch(cwl["model"], cwl["P"], cwl["S"], cwl["t0"], cwl["tf"], count, cwl["d"][:count], cwl["lbx"][:count],
+                                                  cwl["ubx"][:count], sqp_settings=coss, pivot=pivot, threads=threads)
+
+                def crate(count, threads, seconds):
+                    rates, tc, passes = [], 0.0, 0
+                    while tc < seconds and passes < 200:
+                        t1 = time.perf_counter(); _, _, io_ = crun(count, threads, ob.PIVOT_EIGEN, True); dt = time.perf_counter() - t1
+                        rates.append(sum(i.iter for i in io_) / dt); tc += dt; passes += 1
+                    return float(np.median(rates)), passes, tc
+
+                r1c, p1c, t1c = crate(n_one, 1, 3.0)
+                rNc, pNc, tNc = crate(n_all, cores, 3.0)
+                cfg[key]["cpu_baseline"] = {"value": rNc, "unit": "QP solves/s", "cores": cores, "kind": "port",
+                                            "single_core": {"value": r1c, "unit": "QP solves/s", "cores": 1, "sample": "median of %d passes over the first %d instances, %.1f s" % (p1c, n_one, t1c)},
+                                            "sample": "median of %d passes over the first %d instances, Eigen-style pivoted LDLT + glibc, OpenMP on %d threads, %.1f s" % (pNc, n_all, cores, tNc)}
+                gx, gl, gi = gsol
+                xr, lr, ir = crun(n_all, cores, ob.PIVOT_EIGEN, True)
+                pr = cross_order_stats(letter, cwl, gx[:n_all], gl[:n_all], gi[:n_all], xr, lr, ir)
+                pr["note"] = "GPU (default kernels) vs the CPU restatement as the reference computes (Eigen-style pivoted LDLT, glibc), first %d instances, no mask" % n_all
+                cfg[key]["parity_vs_cpu_reference"] = pr
+                xk, lk, ik = crun(n_all, cores, korder, False)
+                it_k = np.array([i.iter for i in ik]); qi_k = np.array([i.qp_solver_iter for i in ik])
+                cfg[key]["parity_vs_cpu_same_order"] = {"instances": n_all, "order": int(korder),
+                                                        "identical_trajectory_fraction": float(((it_k == gi["iter"][:n_all]) & (qi_k == gi["qp_solver_iter"][:n_all])).mean()),
+                                                        "bit_identical_x": bool(np.array_equal(gx[:n_all], xk)), "bit_identical_lam": bool(np.array_equal(gl[:n_all], lk)),
+                                                        "max_abs_dx": float(np.abs(gx[:n_all] - xk).max())}
             xs, ls_, is_ = cpu_run(Bc, cores, ob.PIVOT_SWEEP, False)
             out["parity_vs_cpu_same_order"] = parity(xs, ls_, is_, "CPU restatement in the kernel's own elimination order and with the shared IEEE-only sin/cos "
                                                                    "(pmpc_math.hpp): identical arithmetic on both sides, every instance, no mask")
             xo, lo, io = cpu_run(Bc, cores, ob.PIVOT_EIGEN, True)
             out["parity_vs_cpu_reference"] = parity(xo, lo, io, "CPU restatement as the reference computes: Eigen-style pivoted LDLT and glibc sin/cos — a different, "
                                                                 "equally valid, order of the linear algebra and last-bit differences in sin/cos; every instance, no mask")
+            out["parity_vs_cpu_reference"]["record"] = cross_order_stats("A", wl, xg, lg, info[:Bc], xo, lo, io)   # the object the sub-records and the tests share
         print(json.dumps(out))
     for c in ctxs:
         c.close()

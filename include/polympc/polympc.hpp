@@ -29,7 +29,9 @@
 #include <cmath>
 #include <cstddef>
 #include <limits>
+#include <memory>
 #include <string>
+#include <thread>
 #include <utility>
 #include <type_traits>
 #include <vector>
@@ -99,9 +101,17 @@ struct ContextHolder {
     pmpc_context* ctx = nullptr;
     ~ContextHolder() { if (ctx) pmpc_destroy(ctx); }
 };
+// the loaded library must come from the header this translation unit was compiled against (struct layouts cross the C ABI by value)
+inline bool abi_matches() {
+    return pmpc_abi_version() == PMPC_ABI_VERSION && pmpc_struct_size(0) == sizeof(pmpc_qp_settings) && pmpc_struct_size(1) == sizeof(pmpc_qp_info) &&
+           pmpc_struct_size(2) == sizeof(pmpc_sqp_settings) && pmpc_struct_size(3) == sizeof(pmpc_sqp_info);
+}
 inline pmpc_context* context(int device = 0) {
     static thread_local ContextHolder h;
-    if (!h.ctx) last_error() = pmpc_create(device, nullptr, &h.ctx);
+    if (!h.ctx) {
+        if (!abi_matches()) { last_error() = PMPC_ERR_ABI_MISMATCH; return nullptr; }
+        last_error() = pmpc_create(device, nullptr, &h.ctx);
+    }
     return h.ctx;
 }
 
@@ -221,6 +231,20 @@ public:
         pmpc_qp_settings_sqp_default(&m_qp_settings);   // SQPBase constructor overrides, sqp_base.hpp:83-90
     }
     int batch() const { return B; }
+    // SURVEY 8e — several devices: the batch is split into contiguous shards, one per entry of `devices` (one context, stream and host thread each;
+    // listing a device twice gives it two shards: useful on a one-GPU box and in tests), no collective. An empty list returns to the calling
+    // thread's own context. Per-instance device state of one context (the carried LSFilter, iteration records) is not available in this mode.
+    pmpc_status set_devices(const std::vector<int>& devices) noexcept {
+        m_multi.clear();
+        if (!devices.empty() && !abi_matches()) return last_error() = PMPC_ERR_ABI_MISMATCH;
+        for (int dv : devices) {
+            m_multi.emplace_back(new ContextHolder());
+            const pmpc_status st = pmpc_create(dv, nullptr, &m_multi.back()->ctx);
+            if (st != PMPC_OK) { m_multi.clear(); return last_error() = st; }
+        }
+        return PMPC_OK;
+    }
+    int num_shards() const noexcept { return m_multi.empty() ? 1 : (int)m_multi.size(); }
     OCP& get_problem() noexcept { return problem; }
     sqp_settings_t& settings() noexcept { return m_settings; }
     qp_solver_settings_t& qp_settings() noexcept { return m_qp_settings; }
@@ -235,6 +259,7 @@ public:
 
     // SQPBase::solve for every instance; the current primal/dual arrays are the initial guess (sqp_base.hpp:368-374)
     pmpc_status solve() noexcept {
+        if (!m_multi.empty()) return solve_sharded();
         pmpc_context* ctx = context();
         if (!ctx) return last_error();
         pmpc_sqp_settings ss;
@@ -268,6 +293,36 @@ public:
         }
         return st;
     }
+    // the same solve with the batch in contiguous shards [k B / N, (k+1) B / N) over the N contexts of set_devices(), one host thread per shard
+    pmpc_status solve_sharded() noexcept {
+        if (m_settings.line_search == 1 || m_settings.iteration_callback != nullptr) return last_error() = PMPC_ERR_INVALID_ARGUMENT;
+        pmpc_sqp_settings ss;
+        pmpc_sqp_settings_default(&ss);
+        ss.tau = m_settings.tau; ss.eta = m_settings.eta; ss.rho = m_settings.rho; ss.eps_prim = m_settings.eps_prim;
+        ss.eps_dual = m_settings.eps_dual; ss.max_iter = m_settings.max_iter; ss.line_search_max_iter = m_settings.line_search_max_iter;
+        ss.regularisation = m_settings.regularisation; ss.exact_hessian_every_iter = m_settings.exact_hessian_every_iter ? 1 : 0;
+        ss.preconditioner = m_settings.preconditioner; ss.hessian_update = m_settings.hessian_update; ss.qp_solver = m_settings.qp_solver;
+        m_trace.clear(); m_trace_capacity = 0;
+        const int N = (int)m_multi.size();
+        std::vector<double> xo(m_x.size()), lo(m_lam.size());
+        std::vector<pmpc_status> st((size_t)N, PMPC_OK);
+        std::vector<std::thread> th;
+        for (int k = 0; k < N; ++k) {
+            const long long b0 = (long long)B * k / N, b1 = (long long)B * (k + 1) / N;
+            if (b1 <= b0) continue;
+            th.emplace_back([&, k, b0, b1]() {
+                const size_t o = (size_t)b0;
+                st[k] = device_binding<OCP>::solve(m_multi[k]->ctx, problem, OCP::POLY_ORDER, OCP::NUM_SEGMENTS, problem.t_start, problem.t_stop, (int)(b1 - b0),
+                                                   &m_x[o * VAR_SIZE], &m_lam[o * DUAL_SIZE], &m_p[o * (ND > 0 ? ND : 1)], &m_lbx[o * VAR_SIZE], &m_ubx[o * VAR_SIZE],
+                                                   (NUM_INEQ > 0) ? &m_lbg[o * NUM_INEQ] : nullptr, (NUM_INEQ > 0) ? &m_ubg[o * NUM_INEQ] : nullptr, &ss, &m_qp_settings,
+                                                   &xo[o * VAR_SIZE], &lo[o * DUAL_SIZE], &m_info[o]);
+            });
+        }
+        for (auto& t : th) t.join();
+        for (int k = 0; k < N; ++k) if (st[k] != PMPC_OK) return last_error() = st[k];
+        m_x.swap(xo); m_lam.swap(lo);
+        return last_error() = PMPC_OK;
+    }
     // record of SQP iteration `iter` (1-based) of instance b: [iter, alpha, primal_norm, dual_norm, cost, qp iterations, qp status, max violation];
     // null when nothing was recorded (no iteration_callback set, or the iteration did not run)
     const double* iteration_record(int b, int iter) const noexcept {
@@ -281,6 +336,7 @@ public:
     std::vector<double> m_x, m_lam, m_lbx, m_ubx, m_lbg, m_ubg, m_p;
     std::vector<pmpc_sqp_info> m_info;
     std::vector<double> m_trace; int m_trace_capacity = 0;
+    std::vector<std::unique_ptr<ContextHolder>> m_multi;   // set_devices(): one context per shard
     sqp_settings_t m_settings;
     qp_solver_settings_t m_qp_settings;
     LSFilterHandle filter;   // `MySolver::filter` of valet_parking_mpc_test.cpp:114 for every instance (used when settings().line_search == 1)

@@ -29,7 +29,8 @@ typedef enum {
     PMPC_ERR_NO_DEVICE = 2,
     PMPC_ERR_HIP = 3,
     PMPC_ERR_UNSUPPORTED_SIZE = 4,
-    PMPC_ERR_UNKNOWN_MODEL = 5
+    PMPC_ERR_UNKNOWN_MODEL = 5,
+    PMPC_ERR_ABI_MISMATCH = 6      /* the loaded library was built from another version of this header (C++ mirror / Python binding check) */
 } pmpc_status;
 
 /* status_t of qp_base.hpp:55-62 (same numeric values) */
@@ -135,6 +136,17 @@ typedef enum {
 } pmpc_model;
 
 /* ------------------------------------------------------------------------------------------------------------ */
+/* ABI version of THIS header. It changes whenever a struct above changes size or meaning or an entry point changes its signature
+ * (1: round 1; 2: linear_solver, flags words, iteration_trace, fp32 QP entries; 3: this query, pmpc_sqp_last_route, multi-device batches).
+ * A host must compare pmpc_abi_version() — what the loaded library was built from — with the PMPC_ABI_VERSION it was compiled against, and
+ * pmpc_struct_size() with its own sizeof, before passing a settings struct: the *_default() functions write the whole struct of the
+ * LIBRARY's layout. Settings structs must always be initialised with pmpc_*_settings_default() and then edited field by field (a struct
+ * filled by hand leaves iteration_trace / filter_state / linear_solver undefined; the entry points reject what they can detect — unknown
+ * enum values, a trace pointer with a capacity < 1 — with PMPC_ERR_INVALID_ARGUMENT, but a garbage pointer cannot be detected). */
+#define PMPC_ABI_VERSION 3
+int pmpc_abi_version(void);
+/* sizeof of the library's own struct: which = 0 pmpc_qp_settings, 1 pmpc_qp_info, 2 pmpc_sqp_settings, 3 pmpc_sqp_info; 0 for anything else */
+unsigned long pmpc_struct_size(int which);
 const char* pmpc_version(void);
 const char* pmpc_status_string(pmpc_status s);
 
@@ -148,6 +160,16 @@ pmpc_status pmpc_synchronize(pmpc_context* ctx);
  * [6] KKT build + factorisation [7] QP residuals [8..23] finer slices (see tests/tools_phase_profile.py). 24 values. */
 pmpc_status pmpc_debug_phase_cycles(pmpc_context* ctx, unsigned long long* out24, int reset);
 
+/* Which kernel family served the last pmpc_sqp_solve_batch[_dev] / pmpc_mpc_step_batch_dev call of this context (the reference has one code path;
+ * here the size and the policy hooks select one of four, with different speed — a caller can log it instead of guessing):
+ *   PMPC_ROUTE_REG1  register-resident QP, one KKT row per lane (n + m <= 64, grids with a compiled specialisation)
+ *   PMPC_ROUTE_REG2  register-resident QP, two KKT rows per lane (65..128 rows)
+ *   PMPC_ROUTE_LDS   KKT factor in LDS (any size that fits; every policy hook)
+ *   PMPC_ROUTE_HBM   blocked tile LDL^T with the factor in an HBM workspace (large instances)
+ * PMPC_ROUTE_NONE before the first call. */
+typedef enum { PMPC_ROUTE_NONE = 0, PMPC_ROUTE_REG1 = 1, PMPC_ROUTE_REG2 = 2, PMPC_ROUTE_LDS = 3, PMPC_ROUTE_HBM = 4 } pmpc_route;
+int pmpc_sqp_last_route(pmpc_context* ctx);
+
 void pmpc_qp_settings_default(pmpc_qp_settings* s);      /* qp_base.hpp:17-53 */
 void pmpc_qp_settings_sqp_default(pmpc_qp_settings* s);  /* + sqp_base.hpp:83-90 */
 void pmpc_sqp_settings_default(pmpc_sqp_settings* s);    /* sqp_base.hpp:24-47 */
@@ -159,6 +181,8 @@ pmpc_status pmpc_chebyshev(int P, double* nodes, double* weights, double* D);
 /* Batched boxADMM::solve (replaces QPBase::solve -> boxADMM::solve_impl, qp_base.hpp:161-175,
  * box_admm.hpp:81-205). Host buffers; copies in, solves on the GPU, copies out, synchronises.
  * x0 / y0 may be NULL (the 7-argument form: zero guesses, box_admm.hpp:81-86).
+ * H: the KKT matrix is built from the LOWER triangle of H only, as Eigen::LDLT<Lower> reads it (helpers.hpp:38-43) — on every kernel family; the
+ * residuals use the full matrix, as the reference's H * x does (qp_base.hpp:240-252).
  * Any size: n + m <= 64 and 65..112 rows have register-resident specialisations for the built-in shapes, systems below 112 rows are factorised in LDS,
  * larger ones (the reference's kite size, n + m = 464, included) keep a tiled factor in a per-QP HBM workspace the context owns
  * (about 2 (n+m)^2 x 8 bytes per QP). linear_solver = 1 (pivoted) exists in LDS only: PMPC_ERR_UNSUPPORTED_SIZE beyond ~190 rows. */
@@ -242,6 +266,17 @@ pmpc_status pmpc_sqp_solve_batch(pmpc_context* ctx, int model, int P, int S, dou
                                  const double* lam_guess, const double* d, const double* lbx, const double* ubx,
                                  const double* lbg, const double* ubg, const pmpc_sqp_settings* sqp_settings,
                                  const pmpc_qp_settings* qp_settings, double* x, double* lam, pmpc_sqp_info* info);
+
+/* The same batch sharded over several contexts — normally one per GPU of the node (instances are independent, the partition is
+ * contiguous ranges [k B / n_ctx, (k+1) B / n_ctx) of the instance-major arrays, no collective): one host thread per context stages its shard in,
+ * launches on that context's stream and stages the results out, all shards concurrently; the call returns when every shard is back in the host
+ * arrays. Arguments as pmpc_sqp_solve_batch. Per-instance device state (filter_state, iteration_trace) belongs to ONE context and is therefore
+ * rejected here (PMPC_ERR_INVALID_ARGUMENT). Returns the first error of any shard. Two contexts on the same device are allowed (testing). */
+pmpc_status pmpc_sqp_solve_batch_multi(pmpc_context* const* ctxs, int n_ctx, int model, int P, int S, double t0, double tf,
+                                       const double* mparams, int n_mparams, int B, const double* x_guess,
+                                       const double* lam_guess, const double* d, const double* lbx, const double* ubx,
+                                       const double* lbg, const double* ubg, const pmpc_sqp_settings* sqp_settings,
+                                       const pmpc_qp_settings* qp_settings, double* x, double* lam, pmpc_sqp_info* info);
 
 /* Same with DEVICE pointers; asynchronous on the context's stream. */
 pmpc_status pmpc_sqp_solve_batch_dev(pmpc_context* ctx, int model, int P, int S, double t0, double tf,

@@ -15,14 +15,15 @@ LIB_PATH = os.path.join(HERE, "liboracle.so")
 REF_PATH = os.path.join(HERE, "_ref", "libref_casadi_robot.so")
 
 PIVOT_EIGEN, PIVOT_STATIC, PIVOT_SWEEP, PIVOT_SWEEP1, PIVOT_SWEEP2, PIVOT_BLOCKED = 0, 1, 2, 3, 4, 5
+SWEEP2_MAX_ROWS = 112   # PIVOT_SWEEP2 restates the two-rows-per-lane register kernel (65..112 KKT rows)
 
 
 def _check_sweep(pivot, rows):
     """PIVOT_SWEEP restates the register-resident kernel, which exists for KKT systems of at most 64 rows."""
     if pivot == PIVOT_SWEEP and rows > 64:
         raise ValueError(f"PIVOT_SWEEP supports at most 64 KKT rows (got {rows}); use PIVOT_STATIC or PIVOT_EIGEN")
-    if pivot == PIVOT_SWEEP2 and rows > 112:
-        raise ValueError(f"PIVOT_SWEEP2 supports at most 112 KKT rows (got {rows}); use PIVOT_STATIC or PIVOT_EIGEN")
+    if pivot == PIVOT_SWEEP2 and rows > SWEEP2_MAX_ROWS:
+        raise ValueError(f"PIVOT_SWEEP2 supports at most {SWEEP2_MAX_ROWS} KKT rows (got {rows}); use PIVOT_STATIC or PIVOT_EIGEN")
 MODEL_ROBOT, MODEL_CSTR, MODEL_PARKING, MODEL_ROBOT_NG, MODEL_KITE_STANDIN, MODEL_PARKING_NG = 0, 1, 2, 3, 4, 5
 NLP_CONSTRAINED_ROSENBROCK, NLP_ROSENBROCK, NLP_SIMPLE, NLP_HS071 = 0, 1, 2, 3
 QP_SOLVED, QP_MAX_ITER_EXCEEDED, QP_UNSOLVED = 0, 1, 2

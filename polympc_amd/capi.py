@@ -15,11 +15,16 @@ QP_SOLVED, QP_MAX_ITER_EXCEEDED, QP_UNSOLVED = 0, 1, 2
 SQP_SOLVED, SQP_MAX_ITER_EXCEEDED = 0, 1
 FLAG_NONFINITE = 1   # pmpc_qp_info / pmpc_sqp_info flags: a non-finite value went through a QP solve
 
+ABI_VERSION = 3   # PMPC_ABI_VERSION of include/polympc_amd.h that the ctypes layouts below mirror
+ROUTE_NONE, ROUTE_REG1, ROUTE_REG2, ROUTE_LDS, ROUTE_HBM = 0, 1, 2, 3, 4   # pmpc_route
+ROUTE_NAMES = {0: "none", 1: "reg1", 2: "reg2", 3: "lds", 4: "hbm"}
+
 EXPORTED_SYMBOLS = [
+    "pmpc_abi_version", "pmpc_struct_size", "pmpc_sqp_last_route",
     "pmpc_version", "pmpc_status_string", "pmpc_create", "pmpc_destroy", "pmpc_synchronize", "pmpc_debug_phase_cycles",
     "pmpc_qp_settings_default", "pmpc_qp_settings_sqp_default", "pmpc_sqp_settings_default", "pmpc_chebyshev",
     "pmpc_qp_boxadmm_solve_batch", "pmpc_qp_boxadmm_solve_batch_dev", "pmpc_qp_boxadmm_solve_batch_f32", "pmpc_qp_boxadmm_solve_batch_f32_dev", "pmpc_qp_admm_solve_batch_f32", "pmpc_qp_admm_solve_batch_f32_dev", "pmpc_ocp_dims", "pmpc_ocp_linearise_batch",
-    "pmpc_sqp_solve_batch", "pmpc_sqp_solve_batch_dev", "pmpc_sqp_solve_batch_user",
+    "pmpc_sqp_solve_batch", "pmpc_sqp_solve_batch_dev", "pmpc_sqp_solve_batch_user", "pmpc_sqp_solve_batch_multi",
     "pmpc_mpc_step_batch_dev", "pmpc_mpc_batch_create", "pmpc_mpc_batch_step", "pmpc_mpc_batch_solution", "pmpc_mpc_batch_destroy",
     "pmpc_qp_admm_solve_batch", "pmpc_qp_admm_solve_batch_dev", "pmpc_qp_ruiz_compute_batch", "pmpc_qp_ruiz_compute_batch_dev", "pmpc_qp_ruiz_unscale_batch", "pmpc_qp_ruiz_unscale_batch_dev",
     "pmpc_filter_state_create", "pmpc_filter_state_clear", "pmpc_filter_state_download", "pmpc_filter_state_destroy",
@@ -108,9 +113,21 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
                 "polympc_amd has no CPU fallback.")
-        _lib = C.CDLL(LIB_PATH)
-        _lib.pmpc_version.restype = C.c_char_p
-        _lib.pmpc_status_string.restype = C.c_char_p
+        L = C.CDLL(LIB_PATH)
+        L.pmpc_version.restype = C.c_char_p
+        L.pmpc_status_string.restype = C.c_char_p
+        # a stale library next to new ctypes layouts (or the reverse) would have pmpc_*_settings_default() write past a struct, or hand the
+        # kernels garbage in the fields it does not know: refuse it here
+        if not hasattr(L, "pmpc_abi_version"):
+            raise RuntimeError(f"{LIB_PATH} predates the ABI version query: rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
+        L.pmpc_struct_size.restype = C.c_ulong
+        got = L.pmpc_abi_version()
+        sizes = [int(L.pmpc_struct_size(i)) for i in range(4)]
+        want = [C.sizeof(QPSettings), C.sizeof(QPInfo), C.sizeof(SQPSettings), C.sizeof(SQPInfo)]
+        if got != ABI_VERSION or sizes != want:
+            raise RuntimeError(f"{LIB_PATH}: ABI version {got} / struct sizes {sizes}, this binding expects version {ABI_VERSION} / {want}: "
+                               "rebuild the library from the same tree")
+        _lib = L
     return _lib
 
 
@@ -181,6 +198,10 @@ class Context:
 
     def synchronize(self):
         _check(lib().pmpc_synchronize(self._ctx))
+
+    def last_route(self):
+        """pmpc_sqp_last_route: the kernel family that served this context's last fused SQP call (ROUTE_* / ROUTE_NAMES)."""
+        return int(lib().pmpc_sqp_last_route(self._ctx))
 
     def phase_cycles(self, reset=True):
         out = (C.c_ulonglong * 24)()
@@ -271,6 +292,24 @@ class Context:
         f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, P_, C.c_int, C.c_int] + [P_] * 7 + \
                      [C.POINTER(SQPSettings), C.POINTER(QPSettings), P_, P_, C.c_void_p]
         _check(f(self._ctx, model, P, S, t0, tf, keep[0][1], 0 if keep[0][0] is None else len(keep[0][0]), B,
+                 *[k[1] for k in keep[1:]], C.byref(ss), C.byref(qs), x.ctypes.data_as(P_), lam.ctypes.data_as(P_),
+                 C.c_void_p(info.ctypes.data)))
+        return x, lam, info
+
+    @staticmethod
+    def sqp_solve_batch_multi(ctxs, model, P, S, t0, tf, B, d, lbx, ubx, lbg=None, ubg=None, x_guess=None, lam_guess=None,
+                              sqp_settings=None, qp_settings=None, mparams=None):
+        """pmpc_sqp_solve_batch_multi: the batch in contiguous shards over the given contexts, one host thread per context."""
+        dm = ocp_dims(model, P, S); n, m = dm["n"], dm["m"]
+        ss = sqp_settings or sqp_settings_default(); qs = qp_settings or qp_settings_sqp_default()
+        x = np.zeros((B, n)); lam = np.zeros((B, m + n)); info = np.zeros(B, dtype=SQP_INFO_DTYPE)
+        keep = [_h(a) for a in (mparams, x_guess, lam_guess, d, lbx, ubx, lbg, ubg)]
+        P_ = C.POINTER(C.c_double)
+        arr = (C.c_void_p * len(ctxs))(*[c._ctx for c in ctxs])
+        f = lib().pmpc_sqp_solve_batch_multi
+        f.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, P_, C.c_int, C.c_int] + [P_] * 7 + \
+                     [C.POINTER(SQPSettings), C.POINTER(QPSettings), P_, P_, C.c_void_p]
+        _check(f(arr, len(ctxs), model, P, S, t0, tf, keep[0][1], 0 if keep[0][0] is None else len(keep[0][0]), B,
                  *[k[1] for k in keep[1:]], C.byref(ss), C.byref(qs), x.ctypes.data_as(P_), lam.ctypes.data_as(P_),
                  C.c_void_p(info.ctypes.data)))
         return x, lam, info

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(64, 2) void qp_boxadmm_reg_kernel(int B, const doub
     const int b = blockIdx.x;
     if (b >= B) return;
     pmpc_qp_info qi;
-    boxadmm_solve_reg<NN, MM>(H + (size_t)b * NN * NN, h + (size_t)b * NN, A + (size_t)b * MM * NN, Alb + (size_t)b * MM, Aub + (size_t)b * MM,
+    boxadmm_solve_reg<NN, MM, false, true>(H + (size_t)b * NN * NN, h + (size_t)b * NN, A + (size_t)b * MM * NN, Alb + (size_t)b * MM, Aub + (size_t)b * MM,
                               xlb + (size_t)b * NN, xub + (size_t)b * NN, x0 ? x0 + (size_t)b * NN : nullptr,
                               y0 ? y0 + (size_t)b * (NN + MM) : nullptr, s, qi, x + (size_t)b * NN, y + (size_t)b * (NN + MM), tr);
     if (lane_id() == 0) info[b] = qi;
@@ -97,6 +98,7 @@ extern "C" pmpc_status pmpc_internal_services(pmpc_context* ctx, int P, int S, d
 extern "C" int pmpc_internal_sqp_slice(pmpc_context* ctx) { return ctx ? ctx->sqp_slice : 0; }
 extern "C" int pmpc_internal_sqp_rr(pmpc_context* ctx) { return ctx ? ctx->sqp_rr : 0; }
 extern "C" int pmpc_internal_simd_count(pmpc_context* ctx) { return ctx ? ctx->simd_count : 1024; }
+extern "C" void pmpc_internal_set_route(pmpc_context* ctx, int route) { if (ctx) ctx->last_route = route; }
 
 
 // =====================================================================================================================
@@ -104,7 +106,18 @@ extern "C" int pmpc_internal_simd_count(pmpc_context* ctx) { return ctx ? ctx->s
 // =====================================================================================================================
 extern "C" {
 
-const char* pmpc_version(void) { return "polympc_amd 0.1 (gfx950)"; }
+const char* pmpc_version(void) { return "polympc_amd 0.3 (gfx950, abi 3)"; }
+int pmpc_abi_version(void) { return PMPC_ABI_VERSION; }
+unsigned long pmpc_struct_size(int which) {
+    switch (which) {
+        case 0: return (unsigned long)sizeof(pmpc_qp_settings);
+        case 1: return (unsigned long)sizeof(pmpc_qp_info);
+        case 2: return (unsigned long)sizeof(pmpc_sqp_settings);
+        case 3: return (unsigned long)sizeof(pmpc_sqp_info);
+    }
+    return 0;
+}
+int pmpc_sqp_last_route(pmpc_context* ctx) { return ctx ? ctx->last_route : PMPC_ROUTE_NONE; }
 const char* pmpc_status_string(pmpc_status s) {
     switch (s) {
         case PMPC_OK: return "ok";
@@ -113,6 +126,7 @@ const char* pmpc_status_string(pmpc_status s) {
         case PMPC_ERR_HIP: return "HIP runtime error";
         case PMPC_ERR_UNSUPPORTED_SIZE: return "problem size not supported by the LDS-resident kernels";
         case PMPC_ERR_UNKNOWN_MODEL: return "unknown model id";
+        case PMPC_ERR_ABI_MISMATCH: return "library and header / binding come from different ABI versions";
     }
     return "?";
 }
@@ -619,6 +633,36 @@ pmpc_status pmpc_sqp_solve_batch(pmpc_context* ctx, int model, int P, int S, dou
     return PMPC_OK;
 }
 
+
+/* contiguous shards over n_ctx contexts, one host thread per context, no collective */
+pmpc_status pmpc_sqp_solve_batch_multi(pmpc_context* const* ctxs, int n_ctx, int model, int P, int S, double t0, double tf, const double* mparams,
+                                       int n_mparams, int B, const double* x_guess, const double* lam_guess, const double* d, const double* lbx,
+                                       const double* ubx, const double* lbg, const double* ubg, const pmpc_sqp_settings* ss,
+                                       const pmpc_qp_settings* qs, double* x, double* lam, pmpc_sqp_info* info) {
+    if (!ctxs || n_ctx < 1 || B < 0 || !lbx || !ubx || !ss || !qs || !x || !lam || !info) return PMPC_ERR_INVALID_ARGUMENT;
+    for (int k = 0; k < n_ctx; ++k) if (!ctxs[k]) return PMPC_ERR_INVALID_ARGUMENT;
+    if (ss->filter_state || ss->iteration_trace) return PMPC_ERR_INVALID_ARGUMENT;   // device buffers of one context
+    int nx, nu, np, nd, ng, n, me, mi;
+    const pmpc_status ds = pmpc_ocp_dims(model, P, S, &nx, &nu, &np, &nd, &ng, &n, &me, &mi);
+    if (ds != PMPC_OK) return ds;
+    if (B == 0) return PMPC_OK;
+    const int m = me + mi;
+    std::vector<pmpc_status> st((size_t)n_ctx, PMPC_OK);
+    std::vector<std::thread> th;
+    for (int k = 0; k < n_ctx; ++k) {
+        const long long b0 = (long long)B * k / n_ctx, b1 = (long long)B * (k + 1) / n_ctx;
+        if (b1 <= b0) continue;
+        th.emplace_back([=, &st]() {
+            auto at = [&](const double* p, size_t per) { return p ? p + (size_t)b0 * per : nullptr; };
+            st[k] = pmpc_sqp_solve_batch(ctxs[k], model, P, S, t0, tf, mparams, n_mparams, (int)(b1 - b0), at(x_guess, n), at(lam_guess, m + n),
+                                         at(d, nd), at(lbx, n), at(ubx, n), at(lbg, mi), at(ubg, mi), ss, qs, x + (size_t)b0 * n,
+                                         lam + (size_t)b0 * (m + n), info + b0);
+        });
+    }
+    for (auto& t : th) t.join();
+    for (int k = 0; k < n_ctx; ++k) if (st[k] != PMPC_OK) return st[k];
+    return PMPC_OK;
+}
 
 /* Host-buffer wrapper around a user-registered OCP's device entry (PMPC_REGISTER_OCP): stage in, launch, stage out. */
 pmpc_status pmpc_sqp_solve_batch_user(pmpc_context* ctx, pmpc_sqp_dev_fn fn, const void* model, int nx, int nu, int np, int nd, int ng,

@@ -17,13 +17,6 @@ template <class Model> pmpc_status linearise_impl(pmpc_context* ctx, int P, int 
 #include <vector>
 #include "pmpc_launch.hpp"
 using namespace pmpc;
-namespace pmpc {   // further register-resident grids of these models: pmpc_grids_*.hip
-template <> struct EXTRA_GRIDS<RobotOCP> { static constexpr bool value = true; };
-template <> struct EXTRA_GRIDS<CstrOCP> { static constexpr bool value = true; };
-template <> struct EXTRA_GRIDS<ParkingOCP> { static constexpr bool value = true; };
-template <> struct EXTRA_GRIDS<RobotNGOCP> { static constexpr bool value = true; };
-template <> struct EXTRA_GRIDS<ParkingNGOCP> { static constexpr bool value = true; };
-}
 
 template <class Model> static inline Model make_model(const double* mp, int nmp) { Model mdl; mdl.set_params(mp, nmp); return mdl; }
 

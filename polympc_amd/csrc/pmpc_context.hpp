@@ -25,6 +25,7 @@ struct pmpc_context {
                                    // instances free their slots); 0 (default) = whole solve in one launch — measured faster on config A
     int sqp_rr = 0;                // PMPC_SQP_RR=1: batches beyond the resident wavefronts run one SQP iteration per work item from a ready queue (sqp_kernel_rr,
                                    // pmpc_launch.hpp); 0 (default) = one workgroup per instance — measured equal or faster on configs A and D
+    int last_route = 0;            // pmpc_route of the last fused SQP launch (pmpc_sqp_last_route)
     bool force_lds_path = false;   // PMPC_FORCE_LDS_PATH=1: disable the register-resident specialisations (A/B testing)
     std::map<std::tuple<int, int, double, double>, ChebData*> cheb_cache;
     double* ws = nullptr; size_t ws_bytes = 0;       // SQP HBM workspace (H, J)

@@ -16,6 +16,7 @@ extern "C" pmpc_status pmpc_internal_services(pmpc_context* ctx, int P, int S, d
 extern "C" int pmpc_internal_simd_count(pmpc_context* ctx);   // SIMDs of the device (compute units x 4)
 extern "C" int pmpc_internal_sqp_slice(pmpc_context* ctx);   // SQP iterations per kernel launch (0 = whole solve in one launch)
 extern "C" int pmpc_internal_sqp_rr(pmpc_context* ctx);      // 1 (PMPC_SQP_RR=1, developer switch): batches beyond the resident wavefronts run one SQP iteration per work item (sqp_kernel_rr)
+extern "C" void pmpc_internal_set_route(pmpc_context* ctx, int route);   // records the kernel family of the launch (pmpc_sqp_last_route)
 
 namespace pmpc {
 using ::pmpc_status;
@@ -404,6 +405,11 @@ template <class Model> inline size_t linearise_kernel_lds_bytes(int P, int S) {
 
 // models whose LDS-resident kernel also exists with phase timers (PMPC_PHASE_PROFILE=1)
 template <class Model> struct LDS_PATH_PROFILED { static constexpr bool value = false; };
+// (specialised HERE, before any template reads it and in the one header every translation unit sees: a specialisation that only some translation
+// units declare would make the trait's value depend on the translation unit — an ODR violation)
+template <> struct LDS_PATH_PROFILED<RobotOCP> { static constexpr bool value = true; };
+template <> struct LDS_PATH_PROFILED<CstrOCP> { static constexpr bool value = true; };
+template <> struct LDS_PATH_PROFILED<KiteStandInOCP> { static constexpr bool value = true; };
 
 // Launch the fused SQP kernel for `Model` on DEVICE buffers (asynchronous on the context's stream).
 // Register-resident QP specialisations are selected from the compile-time model dimensions and the runtime node count
@@ -421,6 +427,7 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
         const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, 1);
         if (ldsr > lds_limit) return false;
         if (LEAN && (ss->hessian_update == 1 || phase)) return false;
+        pmpc_internal_set_route(ctx, PMPC_ROUTE_REG1);
         auto kern = sqp_kernel<Model, NN_, MM_, false>;
         if constexpr (!LEAN)
             kern = (ss->hessian_update == 1) ? sqp_kernel<Model, NN_, MM_, false, 1>   // (no phase timers in the block-BFGS specialisation)
@@ -459,6 +466,7 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
         if (P * S + 1 != NNODES) return false;
         const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, 3);
         if (ldsr > lds_limit) return false;
+        pmpc_internal_set_route(ctx, PMPC_ROUTE_REG2);
         auto kern = sqp_kernel<Model, NN_, MM_, false>;
         bool timed = false;
         if constexpr (LDS_PATH_PROFILED<Model>::value && !LEAN) { if (phase) { kern = sqp_kernel<Model, NN_, MM_, true>; timed = true; } }   // developer builds with phase timers
@@ -477,6 +485,11 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
 // Register-resident specialisations for further node counts live in their own translation units (pmpc_grids_*.hip, built-in models only: a user OCP's
 // translation unit instantiates the three grids below and takes the LDS / HBM-factor kernels elsewhere). Same arguments and meaning as try_launch_reg.
 template <class Model> struct EXTRA_GRIDS { static constexpr bool value = false; };
+template <> struct EXTRA_GRIDS<RobotOCP> { static constexpr bool value = true; };      // (declared here for every translation unit, see LDS_PATH_PROFILED)
+template <> struct EXTRA_GRIDS<CstrOCP> { static constexpr bool value = true; };
+template <> struct EXTRA_GRIDS<ParkingOCP> { static constexpr bool value = true; };
+template <> struct EXTRA_GRIDS<RobotNGOCP> { static constexpr bool value = true; };
+template <> struct EXTRA_GRIDS<ParkingNGOCP> { static constexpr bool value = true; };
 template <class Model>
 bool try_launch_extra_grids(pmpc_context* ctx, const Model& mdl, const ChebData* cd, int P, int S, int B, const double* x_guess,
                             const double* lam_guess, const double* d, const double* lbx, const double* ubx, const double* lbg,
@@ -494,7 +507,11 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     OcpDims<Model> dm(P, S);
     const void* cdv = nullptr; double* ws = nullptr; void* streamv = nullptr; size_t lds_limit = 0; unsigned long long* phase = nullptr; int force_lds = 0;
     const size_t base = (size_t)B * ((size_t)dm.n * dm.n + (size_t)dm.m * dm.n + 2 * (size_t)dm.n);
-    pmpc_status st = pmpc_internal_services(ctx, P, S, t0, tf, base * sizeof(double) + rr_queue_bytes(B, ss->max_iter), &cdv, &ws, &streamv, &lds_limit, &phase, &force_lds);
+    // the ready queue of the round-robin kernel (developer switch PMPC_SQP_RR=1, one-row-per-lane register path only) is requested only when that
+    // kernel can run: with the reference's default max_iter = 100 it is B x 400 bytes of otherwise dead HBM
+    const bool rr_possible = pmpc_internal_sqp_rr(ctx) && dm.n + dm.m <= WAVE && ss->max_iter > 1 && ss->max_iter <= RR_MAX_ITER && B <= RR_MAX_BATCH &&
+                             (size_t)B * ss->max_iter < ((size_t)1 << 30);
+    pmpc_status st = pmpc_internal_services(ctx, P, S, t0, tf, base * sizeof(double) + (rr_possible ? rr_queue_bytes(B, ss->max_iter) : 0), &cdv, &ws, &streamv, &lds_limit, &phase, &force_lds);
     if (st != PMPC_OK) return st;
     const ChebData* cd = (const ChebData*)cdv;
     hipStream_t stream = (hipStream_t)streamv;
@@ -531,6 +548,7 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
         if (st != PMPC_OK) return st;
         Hws = ws; Aws = ws + (size_t)B * dm.n * dm.n; slice_state = Aws + (size_t)B * dm.m * dm.n; Kws = ws + base;
     }
+    pmpc_internal_set_route(ctx, Kws ? PMPC_ROUTE_HBM : PMPC_ROUTE_LDS);
     auto lkern = Kws ? sqp_kernel<Model, 0, 0, false, 0, true> : sqp_kernel<Model>;
     // Mid-size instances on the HBM-factor kernel stream little per wavefront: with more instances than SIMDs a second wavefront per SIMD (a 256-register
     // build of the same kernel) hides part of that latency — per 4096 robots 128 rows 40.5 -> 35.4 ms, 168 rows 64.3 -> 60.8; at config C's 464 rows

@@ -398,8 +398,9 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
             asm("" : "+v"(b));
             return H[b];
         } else {
-            const bool up = isP && ln < j;
-            return up ? H[(size_t)ln * NN + j] : rowp[(size_t)j * (size_t)(unsigned)(rstride + zo)];
+            const bool up = isP && ln < j;   // one load from a selected address (H(j, lane) sits at lane * NN + j)
+            const double* src = up ? H + ((size_t)lp * NN + (size_t)(unsigned)(j + zo)) : rowp + (size_t)j * (size_t)(unsigned)(rstride + zo);
+            return *src;
         }
     };
     auto Acol = [&](int k, int zo) -> double {   // A(k, lane), k < MM (primal lanes)

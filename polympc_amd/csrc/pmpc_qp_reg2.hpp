@@ -321,7 +321,6 @@ __device__ __forceinline__ void boxadmm_solve_reg2(const double* __restrict__ H,
     // K0(i, j), j < NN: row i of [H ; A]. Addresses are rebuilt from a lane id re-materialised next to the loads (see pmpc_qp_reg.hpp).
     auto lane_near = [](int zo) -> unsigned { unsigned l; asm("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l) : "v"(zo)); return l; };
     constexpr int LDH = STACKED ? N : NN;
-    static_assert(STACKED || !SYMLOWER, "the lower-triangle read is implemented for the stacked workspace of the SQP kernels");
     // unstacked inputs (the QP entry point): per-slot row base and stride — ONE load per entry (H for primal rows, A for constraint rows)
     const double* rowp[2]; int rstride[2];
 #pragma unroll
@@ -337,7 +336,10 @@ __device__ __forceinline__ void boxadmm_solve_reg2(const double* __restrict__ H,
             return live ? v : 0.0;
         } else {
             unsigned so = (unsigned)(rstride[e] + zo); asm volatile("" : "+v"(so));   // (volatile: the products j * stride are formed next to their load, not hoisted and spilled)
-            const double v = rowp[e][(size_t)((unsigned)j * so)];
+            const bool up = lower && isP[e] && idx[e] < j;   // lower: H(max, min) — H(j, row) sits at row * NN + j; one load from a selected offset
+            const double* base = up ? H : rowp[e];
+            const size_t off = up ? ((size_t)(unsigned)lp[e] * NN + (size_t)(unsigned)(j + zo)) : (size_t)((unsigned)j * so);
+            const double v = base[off];
             return (isP[e] || isC[e]) ? v : 0.0;
         }
     };

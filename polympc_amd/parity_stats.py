@@ -1,0 +1,58 @@
+"""Comparison of two solution sets of one synthetic batch (numpy only — no solver arithmetic, no oracle): the record that the bench line, the GPU
+parity tests, the oracle pin tests and tests/tools_cross_order.py share when they put a run next to the reference-order run."""
+import numpy as np
+
+
+def variable_scales(cfg, wl):
+    """Per-variable magnitudes (n) and per-multiplier magnitudes are NOT invented here: x scales are the steady state / box of the workload
+    definitions in polympc_amd/workloads.py (CSTR: states (1, 0.5, 100, 100), inputs (35, 9000); robot: states 1, inputs (1.5, 0.75); kite
+    stand-in: 1)."""
+    P, S = wl["P"], wl["S"]
+    nn = P * S + 1
+    if cfg == "B":
+        xs, us = [1.0, 0.5, 100.0, 100.0], [35.0, 9000.0]
+    elif cfg == "C":
+        xs, us = [1.0] * 13, [1.0] * 3
+    else:
+        xs, us = [1.0, 1.0, 1.0], [1.5, 0.75]
+    return np.concatenate([np.tile(xs, nn), np.tile(us, nn)])
+
+
+def cross_order_stats(cfg, wl, x, lam, info, xr, lamr, inforef):
+    """(x, lam, info) — a solution set under test (numpy arrays; info = structured array or list of oracle SQPInfo) — against the reference-order run
+    (xr, lamr, inforef). Returns the record the bench line / tests / table share. Solution differences are reported over ALL instances and over the
+    instances whose trajectory (SQP iterations, status, total ADMM iterations) is identical in both runs: an instance that takes another branch at a
+    borderline discrete decision is a different computation, not a perturbed one."""
+    def col(inf, f):
+        return np.asarray(inf[f]) if isinstance(inf, np.ndarray) else np.array([getattr(i, f) for i in inf])
+    B = x.shape[0]
+    same = (col(info, "iter") == col(inforef, "iter")) & (col(info, "status") == col(inforef, "status")) & \
+           (col(info, "qp_solver_iter") == col(inforef, "qp_solver_iter"))
+    sc = variable_scales(cfg, wl)
+    n = x.shape[1]
+    if sc.size != n:   # models with parameters (none of the BASELINE configurations)
+        sc = np.concatenate([sc, np.ones(n - sc.size)])
+    dx = np.abs(x - xr)
+    dxi = dx.max(axis=1)
+    dxs = (dx / sc).max(axis=1)
+    dl = np.abs(lam - lamr)
+    lscale = np.maximum(1.0, np.abs(lamr).max(axis=1))
+    dls = dl.max(axis=1) / lscale
+    cost_r = col(inforef, "cost")
+    dviol = np.abs(col(info, "max_violation") - col(inforef, "max_violation"))
+    dcost = np.abs(col(info, "cost") - cost_r) / np.maximum(1.0, np.abs(cost_r))
+    dpn = np.abs(col(info, "primal_norm") - col(inforef, "primal_norm")); ddn = np.abs(col(info, "dual_norm") - col(inforef, "dual_norm"))
+    pct = lambda v: {"p50": float(np.percentile(v, 50)), "p90": float(np.percentile(v, 90)), "p99": float(np.percentile(v, 99)), "max": float(v.max())}
+    mx = lambda v, msk: float(v[msk].max()) if msk.any() else 0.0
+    return {
+        "instances": int(B), "identical_trajectory_fraction": float(same.mean()), "different_trajectories": int((~same).sum()),
+        "max_abs_dx": float(dx.max()), "instances_dx_over_1e-8": int((dxi > 1e-8).sum()),
+        "abs_dx_per_instance": pct(dxi), "scaled_dx_per_instance": pct(dxs),
+        "max_abs_dlam": float(dl.max()), "scaled_dlam_per_instance": pct(dls),
+        "max_abs_d_primal_norm": float(dpn.max()), "max_abs_d_dual_norm": float(ddn.max()),
+        "max_abs_d_constraint_violation": float(dviol.max()), "max_rel_d_cost": float(dcost.max()),
+        "identical_trajectories_only": {"max_abs_dx": mx(dxi, same), "max_scaled_dx": mx(dxs, same), "max_scaled_dlam": mx(dls, same),
+                                        "max_abs_d_constraint_violation": mx(dviol, same), "max_rel_d_cost": mx(dcost, same)},
+        "scaling": "dx per variable / its box or steady-state magnitude (CSTR: states 1, 0.5, 100, 100, inputs 35, 9000; robot: states 1, inputs 1.5, 0.75; "
+                   "stand-in: 1); dlam per instance / max(1, |lam_ref|_inf)",
+    }

@@ -4,6 +4,7 @@
 //   admmSinglePrecisionFloat                    tests/solvers/qp/admm_solver_test.cpp:84-113 (ADMM<2, 1, float>)
 //   MPCWrapperTest                              tests/control/mpc_wrapper_test.cpp:120-199 (dense-BFGS variant)
 //   ValetParkingTest                            tests/control/valet_parking_mpc_test.cpp:183-240 (Ruiz + filter line search + block BFGS)
+//   ShardedBatchSolver...                       SURVEY 8e: BatchSolver::set_devices / pmpc_sqp_solve_batch_multi, shards == single context
 //   user-registered OCP                         docs/source/ocp.rst:229-481 workflow, compiled by hipcc (user_ocp.hip)
 #include <cstdio>
 #include <cstring>
@@ -300,6 +301,61 @@ static void UserRegisteredRobotMatchesBuiltin() {
     EXPECT_TRUE(solved > B / 2);
 }
 
+// SURVEY 8e through the C++ front-end: the batch in three contiguous shards over three contexts driven by three host threads (all on device 0 here;
+// one per GPU on a node) against the single-context batch — built-in and user-registered OCP, bit for bit — and the plain-C entry point
+static void ShardedBatchSolverMatchesSingleContext() {
+    std::printf("ShardedBatchSolverMatchesSingleContext\n");
+    using Builtin = polympc::models::MobileRobot<ApproxA>;
+    const int B = 37;   // not a multiple of the shard count
+    auto fill = [&](auto& s) {
+        s.get_problem().set_time_limits(0, 2);
+        s.settings().max_iter = 10; s.settings().line_search_max_iter = 10;
+        for (int b = 0; b < B; ++b) {
+            for (int k = 0; k < 7; ++k) {
+                s.lower_bound_x(b)[21 + 2 * k] = -1.5; s.upper_bound_x(b)[21 + 2 * k] = 1.5;
+                s.lower_bound_x(b)[22 + 2 * k] = -0.75; s.upper_bound_x(b)[22 + 2 * k] = 0.75;
+            }
+            for (int i = 0; i < 3; ++i) { const double x0 = 0.5 + 0.013 * (b % 11) * (i + 1) - 0.02 * i; s.lower_bound_x(b)[18 + i] = x0; s.upper_bound_x(b)[18 + i] = x0; }
+            s.parameters(b)[0] = 2.0 + 0.01 * b;
+        }
+    };
+    BatchSolver<Builtin> one(B), many(B); BatchSolver<UserRobotOCP> umany(B);
+    fill(one); fill(many); fill(umany);
+    EXPECT_EQ(many.set_devices({0, 0, 0}), PMPC_OK);
+    EXPECT_EQ(umany.set_devices({0, 0}), PMPC_OK);
+    EXPECT_EQ(many.num_shards(), 3);
+    EXPECT_EQ(one.solve(), PMPC_OK);
+    EXPECT_EQ(many.solve(), PMPC_OK);
+    EXPECT_EQ(umany.solve(), PMPC_OK);
+    bool same = true, usame = true;
+    for (int b = 0; b < B; ++b) {
+        same = same && one.info(b).iter == many.info(b).iter && one.info(b).status == many.info(b).status &&
+               std::memcmp(one.primal_solution(b), many.primal_solution(b), sizeof(double) * 35) == 0 &&
+               std::memcmp(one.dual_solution(b), many.dual_solution(b), sizeof(double) * 56) == 0;
+        usame = usame && one.info(b).iter == umany.info(b).iter && std::memcmp(one.primal_solution(b), umany.primal_solution(b), sizeof(double) * 35) == 0;
+    }
+    std::printf("  3 shards == 1 context bitwise: %s; user OCP in 2 shards: %s\n", same ? "yes" : "NO", usame ? "yes" : "NO");
+    EXPECT_TRUE(same); EXPECT_TRUE(usame);
+    // the C entry point: two contexts, two host threads inside the library
+    pmpc_context* c2[2] = {nullptr, nullptr};
+    EXPECT_EQ(pmpc_create(0, nullptr, &c2[0]), PMPC_OK); EXPECT_EQ(pmpc_create(0, nullptr, &c2[1]), PMPC_OK);
+    pmpc_sqp_settings ss; pmpc_sqp_settings_default(&ss); ss.max_iter = 10; ss.line_search_max_iter = 10;
+    pmpc_qp_settings qs; pmpc_qp_settings_sqp_default(&qs);
+    const double mp[3] = {1.0, 1.0, 1.0};
+    std::vector<double> x((size_t)B * 35), lam((size_t)B * 56); std::vector<pmpc_sqp_info> inf(B);
+    EXPECT_EQ(pmpc_sqp_solve_batch_multi(c2, 2, PMPC_MODEL_ROBOT, 6, 1, 0.0, 2.0, mp, 3, B, nullptr, nullptr, many.parameters(0), many.lower_bound_x(0),
+                                         many.upper_bound_x(0), nullptr, nullptr, &ss, &qs, x.data(), lam.data(), inf.data()), PMPC_OK);
+    bool csame = true;
+    for (int b = 0; b < B; ++b) csame = csame && inf[b].iter == one.info(b).iter && std::memcmp(&x[(size_t)b * 35], one.primal_solution(b), sizeof(double) * 35) == 0;
+    std::printf("  pmpc_sqp_solve_batch_multi over 2 contexts == 1 context bitwise: %s; route of the shard launches: %d\n", csame ? "yes" : "NO", pmpc_sqp_last_route(c2[0]));
+    EXPECT_TRUE(csame);
+    EXPECT_EQ(pmpc_sqp_last_route(c2[0]), (int)PMPC_ROUTE_REG1);
+    ss.iteration_trace = x.data();   // device state of one context: rejected
+    EXPECT_EQ(pmpc_sqp_solve_batch_multi(c2, 2, PMPC_MODEL_ROBOT, 6, 1, 0.0, 2.0, mp, 3, B, nullptr, nullptr, many.parameters(0), many.lower_bound_x(0),
+                                         many.upper_bound_x(0), nullptr, nullptr, &ss, &qs, x.data(), lam.data(), inf.data()), PMPC_ERR_INVALID_ARGUMENT);
+    pmpc_destroy(c2[0]); pmpc_destroy(c2[1]);
+}
+
 static void UserPendulumWithPathConstraint() {
     std::printf("UserPendulumWithPathConstraint\n");
     Solver<PendulumOCP> solver;
@@ -334,6 +390,7 @@ int main() {
     IterationCallbackTest();
     BatchMPCTest();
     UserRegisteredRobotMatchesBuiltin();
+    ShardedBatchSolverMatchesSingleContext();
     UserPendulumWithPathConstraint();
     std::printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
     return failures ? 1 : 0;

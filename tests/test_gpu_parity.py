@@ -151,11 +151,6 @@ def test_qp_hessian_is_read_from_its_lower_triangle_on_every_kernel_family(ctx, 
     xo, yo, io = _qp_oracle(oracle, q, s)
     assert [int(i) for i in info["iter"]] == [i.iter for i in io] and [int(i) for i in info["status"]] == [i.status for i in io]
     assert np.array_equal(x, xo) and np.array_equal(y, yo), (np.abs(x - xo).max(), np.abs(y - yo).max())
-    # and the answer IS the lower triangle's: symmetrising H from its lower triangle changes only the residual evaluation (full H there)
-    Hs = np.tril(Hm) + np.tril(Hm, -1).transpose(0, 2, 1)
-    q2 = dict(q); q2["H"] = np.ascontiguousarray(Hs.transpose(0, 2, 1)).reshape(B, n * n)
-    x2, y2, info2 = ctx.qp_solve_batch(q2["H"], q2["h"], q2["A"], q2["Alb"], q2["Aub"], q2["xlb"], q2["xub"], settings=s)
-    assert np.abs(x2 - x).max() <= 1e-2   # same factor; the residuals (and with them the stopping iteration) may differ
 
 
 @pytest.mark.parametrize("n,m,B", [(7, 3, 9), (35, 21, 16), (66, 44, 6), (20, 45, 4)])

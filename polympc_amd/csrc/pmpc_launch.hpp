@@ -30,6 +30,11 @@ template <int NKKT> constexpr int reg_qp_staging() {
     else return RegKkt2<NKKT>::TRI;
 }
 
+// LDS doubles of the block-sparse copy of J the register-resident kernels keep (pmpc_jview.hpp): per node NX x NDER + NG x NDER
+template <class Model> __host__ __device__ inline size_t jview_doubles(int nnodes) {
+    return (size_t)nnodes * (Model::NX + Model::NG) * OcpDims<Model>::NDER;
+}
+
 // large-instance mode: per-instance HBM scratch (doubles) behind the factor workspace — SQP vectors, per-node AD staging, QP vectors
 template <class Model> __host__ __device__ inline size_t big_scratch_doubles(int P, int S) {
     OcpDims<Model> dm(P, S);
@@ -89,6 +94,9 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
         p = ocp.s.carve(p, P, S);
         if (NN > 0 && (size_t)(p - stage0) < (size_t)reg_qp_staging<NN + MM>() + ocp.s.const_doubles(P, S)) p = stage0 + reg_qp_staging<NN + MM>() + ocp.s.const_doubles(P, S);
         stage_end = p;   // end of the per-node staging block: what follows (static parameters, filter) stays live during the line search
+    }
+    if constexpr (NN > 0) {   // block-sparse copy of J (pmpc_jview.hpp): lives through the QP, behind the staging its LDS buffers alias
+        ocp.jblk = p; p += jview_doubles<Model>(ocp.dm.NN); ocp.gblk = ocp.jblk + (size_t)ocp.dm.NN * Model::NX * OcpDims<Model>::NDER; ocp.keep_blk = true;
     }
     double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
     const int ln = lane_id();
@@ -214,6 +222,7 @@ __global__ __launch_bounds__(64, PMPC_SQP_WAVES) void sqp_kernel_rr(Model model,
     p = ocp.s.carve(p, P, S);
     if ((size_t)(p - stage0) < (size_t)reg_qp_staging<NN + MM>() + ocp.s.const_doubles(P, S)) p = stage0 + reg_qp_staging<NN + MM>() + ocp.s.const_doubles(P, S);
     const double* stage_end = p;
+    ocp.jblk = p; p += jview_doubles<Model>(ocp.dm.NN); ocp.gblk = ocp.jblk + (size_t)ocp.dm.NN * Model::NX * OcpDims<Model>::NDER; ocp.keep_blk = true;
     double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
     ocp.d = dL;
     const int ln = lane_id();
@@ -344,7 +353,7 @@ template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode
         return (QpLds::doubles_xy(dm.n, dm.m) + (size_t)(dm.n + dm.m) + BigKkt::LDS_DOUBLES + (Model::ND > 0 ? Model::ND : 1) + FILTER_LDS_DOUBLES + 8) * sizeof(double);
     if (mode == 3) { const size_t need = (size_t)RegKkt2<112>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
     return ((mode == 0 ? QpLds::doubles(dm.n, dm.m) : QpLds::doubles_xy(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8 +
-            ((mode == 1 || mode == 3) ? 0 : FILTER_LDS_DOUBLES) + (mode == 2 ? BigKkt::LDS_DOUBLES : 0)) * sizeof(double);
+            ((mode == 1 || mode == 3) ? jview_doubles<Model>(dm.NN) : FILTER_LDS_DOUBLES) + (mode == 2 ? BigKkt::LDS_DOUBLES : 0)) * sizeof(double);
 }
 constexpr int BIG_TWO_WAVES_MAX_ROWS = 200;   // below: two wavefronts per SIMD on the HBM-factor kernel when the batch exceeds the SIMD count (see sqp_launch_dev)
 constexpr int BIG_KKT_MIN_ROWS = 96;   // n + m from which sqp_launch_dev prefers the HBM-factor kernel (see there)

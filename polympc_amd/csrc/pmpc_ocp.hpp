@@ -48,7 +48,7 @@ template <class Model>
 struct OcpLds {
     using Dm = OcpDims<Model>;
     enum { NX = Dm::NX, NU = Dm::NU, NP = Dm::NP, NG = Dm::NG, NDER = Dm::NDER };
-    double *D, *w, *tn;                                 // collocation constants
+    double *D, *w, *tn;                                 // collocation constants; D is followed by Dl[t] = -D(0, P - t), the last node's row of J (:845-846)
     double *nd, *nw1, *nw2; int* nsr;                   // per node: D self entry, the two quadrature weights * t_scale, packed (flags, segment, row)
     double *fval, *fjac, *Lval, *Lgrad, *gval, *gjac;   // per node: f (NX), df (NX*NDER), L, dL (NDER), g (NG), dg (NG*NDER)
     double *Lhes, *dhes;                                // per node: d2L (NDER^2), sum lam * d2(f,g) (NDER^2)
@@ -62,11 +62,11 @@ struct OcpLds {
     // collocation constants come first; everything after them is per-linearisation staging
     __host__ __device__ static size_t const_doubles(int P, int S) {
         const int NN = P * S + 1;
-        return (size_t)(P + 1) * (P + 1) + (P + 1) + NN + 3 * (size_t)NN + (size_t)(NN + 1) / 2;
+        return (size_t)(P + 1) * (P + 1) + (P + 1) /*Dl*/ + (P + 1) + NN + 3 * (size_t)NN + (size_t)(NN + 1) / 2;
     }
     __device__ __forceinline__ double* carve(double* p, int P, int S) {
         const int NN = P * S + 1;
-        D = p; p += (P + 1) * (P + 1); w = p; p += P + 1; tn = p; p += NN;
+        D = p; p += (P + 1) * (P + 1) + (P + 1); w = p; p += P + 1; tn = p; p += NN;
         nd = p; p += NN; nw1 = p; p += NN; nw2 = p; p += NN; nsr = (int*)p; p += (NN + 1) / 2;
         fval = p; p += NN * NX; fjac = p; p += NN * NX * NDER; Lval = p; p += NN; Lgrad = p; p += NN * NDER;
         gval = p; p += NN * NG; gjac = p; p += NN * NG * NDER; Lhes = p; p += NN * NDER * NDER; dhes = p; p += NN * NDER * NDER;
@@ -88,12 +88,16 @@ struct Ocp {
     double ts;
     OcpLds<Model> s;
     const double* d;  // static parameters of this instance (ND)
+    // block-sparse copy of J for pmpc_jview.hpp (register-resident kernels): the per-node blocks assemble_first_order writes into J, kept in
+    // an LDS region that outlives the per-node staging (which the QP's staging aliases); keep_blk says whether the two pointers are set
+    double* jblk = nullptr; double* gblk = nullptr; bool keep_blk = false;
 
     __device__ Ocp(const Model& mdl, int P_, int S_, double t_scale) : model(mdl), dm(P_, S_), P(P_), S(S_), ts(t_scale), d(nullptr) {}
 
     __device__ __forceinline__ void stage_constants(const ChebData* cd) {
         const int ln = lane_id();
         for (int i = ln; i < (P + 1) * (P + 1); i += WAVE) s.D[i] = cd->D[i];
+        for (int i = ln; i <= P; i += WAVE) s.D[(P + 1) * (P + 1) + i] = -cd->D[(P - i) * (P + 1)];
         for (int i = ln; i <= P; i += WAVE) s.w[i] = cd->w[i];
         for (int i = ln; i < dm.NN; i += WAVE) s.tn[i] = cd->tn[i];
         // per-node table: everything the hot loops would otherwise derive from k / P and k % P (integer divisions by a run-time
@@ -384,6 +388,7 @@ struct Ocp {
             double v = (i == q) ? s.nd[k] : 0.0;
             v -= ts * s.fjac[e];
             J[(k * NX + q) + (size_t)dm.gidx(k, i) * ldj] = v;
+            if (keep_blk) jblk[e] = v;
         }
         for (int r = ln; r < dm.me; r += WAVE) {
             double cv = -ts * s.fval[r];
@@ -394,6 +399,7 @@ struct Ocp {
             for (int e = ln; e < dm.NN * NG * NDER; e += WAVE) {
                 const int kq = e / NDER, i = e - kq * NDER, k = kq / NG;
                 J[(dm.me + kq) + (size_t)dm.gidx(k, i) * ldj] = s.gjac[e];
+                if (keep_blk) gblk[e] = s.gjac[e];
             }
             for (int r = ln; r < dm.mi; r += WAVE) c[dm.me + r] = s.gval[r];
         }

@@ -20,7 +20,9 @@
 // The CPU restatement of exactly this order is PIVOT_SWEEP2 (tests: bit for bit).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "pmpc_qp_reg.hpp"
+#include "pmpc_jview.hpp"
 
 namespace pmpc {
 
@@ -284,11 +286,15 @@ struct RegKkt2 {
     __device__ __forceinline__ void chain(double (&acc)[8], double b0, double b1) const {
         if constexpr (S < 4 * NT) {
             constexpr int R = S / 4, r = S % 4;
+            // the operands of a step first (accumulation-file reads), then its fma: a v_accvgpr_read directly in front of the DPP operation that
+            // consumes it needs a wait state (an s_nop per operand, 98 per ADMM iteration at 7 x 7 tiles)
+            double w[NT];
+#pragma unroll
+            for (int C = 0; C < NT; ++C) w[C] = in_agpr(R, C) ? from_agpr(Alo[(R * NT + C - NV) * 4 + r], Ahi[(R * NT + C - NV) * 4 + r]) : T[R][C][r];
 #pragma unroll
             for (int C = 0; C < NT; ++C) {
-                const double w = in_agpr(R, C) ? from_agpr(Alo[(R * NT + C - NV) * 4 + r], Ahi[(R * NT + C - NV) * 4 + r]) : T[R][C][r];
-                if constexpr (R < 4) acc[C] = fmac_rowbcast<4 * (R & 3) + r>(acc[C], b0, w);
-                else acc[C] = fmac_rowbcast<4 * (R & 3) + r>(acc[C], b1, w);
+                if constexpr (R < 4) acc[C] = fmac_rowbcast<4 * (R & 3) + r>(acc[C], b0, w[C]);
+                else acc[C] = fmac_rowbcast<4 * (R & 3) + r>(acc[C], b1, w[C]);
             }
             chain<S + 1>(acc, b0, b1);
         }
@@ -296,12 +302,16 @@ struct RegKkt2 {
 };
 
 // boxADMM::solve_impl for compile-time (NN, MM), 64 < NN + MM <= 112. Arguments as boxadmm_solve_reg; tr: RegKkt2<NN+MM>::TRI doubles of LDS.
-template <int NN, int MM, bool STACKED = false, bool SYMLOWER = false>
+// JV: block-sparse view of A (pmpc_jview.hpp) when the QP comes from the fused SQP kernel (STACKED) — the residual evaluation then forms A x and
+// A' y from LDS instead of re-reading the dense A from the workspace; NoJView at the plain QP entry points.
+template <int NN, int MM, bool STACKED = false, bool SYMLOWER = false, class JV = NoJView>
 __device__ __forceinline__ void boxadmm_solve_reg2(const double* __restrict__ H, const double* h, const double* __restrict__ A,
                                                    const double* Alb, const double* Aub, const double* xlb, const double* xub,
                                                    const double* x0, const double* y0, const pmpc_qp_settings& s, pmpc_qp_info& info,
-                                                   double* out_x, double* out_y, double* tr, long long* dbg = nullptr, long long* tm = nullptr) {
+                                                   double* out_x, double* out_y, double* tr, long long* dbg = nullptr, long long* tm = nullptr,
+                                                   const JV& jv = JV()) {
     constexpr int N = NN + MM;
+    constexpr bool HASJ = STACKED && !std::is_same<JV, NoJView>::value;
     static_assert(N > WAVE && N <= 112, "two-rows-per-lane register path");
     const int ln = lane_id();
     // slot e: KKT row i_e = lane + 64 e. Primal rows [0, NN), constraint rows [NN, N).
@@ -456,10 +466,88 @@ __device__ __forceinline__ void boxadmm_solve_reg2(const double* __restrict__ H,
                 constexpr int RC = PMPC_REG2_RC;
                 int zr = 0;
                 asm volatile("" : "+v"(zr));
+                double acc[2] = {0.0, 0.0}, aty[2] = {0.0, 0.0};
+                bool sparse = false;
+                if constexpr (HASJ) {   // (a non-finite iterate takes the dense loops: 0 * inf = NaN on the structural zeros of A)
+                    const double probe = ((xv[0] - xv[0]) + (yv[0] - yv[0])) + ((xv[1] - xv[1]) + (yv[1] - yv[1]));
+                    sparse = __builtin_amdgcn_ballot_w64(probe != 0.0) == 0;
+                }
                 double parked[RegKkt2<N>::NPARK];
                 K.park(parked, zr);
                 sched_fence();
-                double acc[2] = {0.0, 0.0}, aty[2] = {0.0, 0.0};
+                if (HASJ && sparse) {
+                  if constexpr (HASJ) {
+                    // H x from the workspace (dense), A x and A' y from the block-sparse view in LDS — the same products in the same order.
+                    constexpr int NP1 = NN > 64 ? NN - 64 : 0;          // primal rows of the second slot
+                    double* xs = tr; double* ys = tr + NN; double* pb = tr + NN + MM;   // (the staging is free between factorisations)
+                    static_assert(NN + MM + NP1 * NN <= RegKkt2<N>::TRI, "residual scratch fits the staging");
+                    // the lane's rows and their roles, re-derived from a lane id that is materialised HERE: the long-lived copies (idx, isP, rc, ...) are
+                    // spilled across the ADMM loop, and every scratch reload in this block would be an exposed memory round trip
+                    const int sl = (int)lane_near(zr);
+                    int sidx[2], src[2]; bool sP[2], sC[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) { sidx[e] = sl + 64 * e; sP[e] = sidx[e] < NN; sC[e] = sidx[e] >= NN && sidx[e] < N; src[e] = sC[e] ? sidx[e] - NN : 0; }
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) { if (sP[e]) xs[sidx[e]] = xv[e]; if (sC[e]) ys[src[e]] = yv[e]; }
+                    lds_order();
+                    // A' y on the primal rows, A x on the constraint rows — from LDS, before the loads of H occupy the registers
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const bool slotP = (e == 0) || NN > 64, slotC = (e == 0) ? (NN < 64) : true;
+                        if (slotP) { const double v = jv.coldot(sP[e] ? sidx[e] : 0, ys, sP[e]); aty[e] = sP[e] ? v : 0.0; }
+                        if (slotC) { const double v = jv.rowdot(src[e], xs); acc[e] = sC[e] ? v : 0.0; }
+                        sched_fence();
+                    }
+                    // rows 64 .. NN-1 of H: lane j loads H(64 + t, j) (and lane j < NP1 also H(64 + t, 64 + j)) and forms the product with its own x_j;
+                    // lane t then adds the NN products of row 64 + t in ascending j — instead of NN loads per lane for NP1 live lanes
+                    double h0[NP1 > 0 ? NP1 : 1], h1[NP1 > 0 ? NP1 : 1];
+#pragma unroll
+                    for (int t = 0; t < NP1; ++t) {
+                        const unsigned l = lane_near(zr);
+                        unsigned b0 = (64u + (unsigned)t) + l * (unsigned)N + (unsigned)zr; asm("" : "+v"(b0));
+                        h0[t] = H[b0];
+                        unsigned b1 = (64u + (unsigned)t) + (64u + (l < (unsigned)NP1 ? l : 0u)) * (unsigned)N + (unsigned)zr; asm("" : "+v"(b1));
+                        h1[t] = H[b1];
+                    }
+                    // rows of the first slot: RCS loads in flight per batch (primal rows only; a constraint row of this slot re-reads row 0)
+#ifndef PMPC_REG2_RCS
+#define PMPC_REG2_RCS 22
+#endif
+                    constexpr int RCS = PMPC_REG2_RCS;
+                    double hx = 0.0;
+#pragma unroll
+                    for (int j0 = 0; j0 < NN; j0 += RCS) {
+                        double mm[RCS];
+#pragma unroll
+                        for (int j = 0; j < RCS; ++j) {
+                            const unsigned l = lane_near(zr);
+                            unsigned b = (l < (unsigned)NN ? l : 0u) + (unsigned)(((j0 + j < NN) ? j0 + j : 0) * N) + (unsigned)zr; asm("" : "+v"(b));
+                            mm[j] = H[b];
+                        }
+#pragma unroll
+                        for (int j = 0; j < RCS; ++j) if (j0 + j < NN) hx += mm[j] * xbc(xv, j0 + j);
+                        sched_fence();
+                    }
+                    acc[0] = sP[0] ? hx : acc[0];
+                    if constexpr (NP1 > 0) {
+#pragma unroll
+                        for (int t = 0; t < NP1; ++t) { pb[t * NN + sl] = h0[t] * xv[0]; if (sl < NP1) pb[t * NN + 64 + sl] = h1[t] * xv[1]; }
+                        lds_order();
+                        const int tt = sl < NP1 ? sl : 0;
+                        double sacc = 0.0;
+#pragma unroll
+                        for (int j0 = 0; j0 < NN; j0 += 36) {   // (the tiles are parked: registers for 36 reads in flight)
+                            double pv[36];
+#pragma unroll
+                            for (int j = 0; j < 36; ++j) pv[j] = pb[tt * NN + ((j0 + j < NN) ? j0 + j : 0)];
+#pragma unroll
+                            for (int j = 0; j < 36; ++j) if (j0 + j < NN) sacc += pv[j];
+                        }
+                        acc[1] = (sl < NP1) ? sacc : acc[1];
+                    }
+                    lds_order();
+                  }
+                } else {
                 // one slot at a time, RC loads in flight (the VGPR-resident part of the mat-vec operand is parked in scratch meanwhile)
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
@@ -500,6 +588,14 @@ __device__ __forceinline__ void boxadmm_solve_reg2(const double* __restrict__ H,
                         }
                     }
                 }
+                }
+                sched_fence();
+                {   // a second opaque zero: with the one of park() the compiler keeps the 36 slot addresses it formed there alive (in AGPRs and in
+                    // scratch) and reloads them one by one in front of every load here — 36 dependent memory round trips
+                    int zu = 0;
+                    asm volatile("" : "+v"(zu));
+                    K.unpark(parked, zu);
+                }
                 double a1 = 0.0, a2 = 0.0, rp = 0.0, rq = 0.0, rd = 0.0;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
@@ -515,7 +611,6 @@ __device__ __forceinline__ void boxadmm_solve_reg2(const double* __restrict__ H,
                 res_prim = wave_max(rp) + wave_max(rq);
                 res_dual = wave_max(rd);
                 sched_fence();
-                K.unpark(parked, zr);
                 if (dbg) dbg[1] += clock64() - r0;
             }
             if (check) {

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include "pmpc_ocp.hpp"
 #include "pmpc_qp.hpp"
+#include "pmpc_jview.hpp"
 #include "pmpc_qp_reg.hpp"
 #include "pmpc_qp_reg2.hpp"
 #include "pmpc_qp_big.hpp"
@@ -73,6 +74,9 @@ struct SqpDevice {
     __device__ __forceinline__ int m_ct() const { if constexpr (NN > 0) return MM; else return m; }
     __device__ __forceinline__ int me_ct() const { if constexpr (NN > 0) return Model::NX * NNODES_CT_; else return me; }
     __device__ __forceinline__ int mi_ct() const { if constexpr (NN > 0) return Model::NG * NNODES_CT_; else return mi; }
+    // block-sparse view of J (pmpc_jview.hpp) — register-resident kernels: the launcher carved ocp.jblk / ocp.gblk behind the staging
+    using JV = JView<Model, (NNODES_CT_ > 0 ? NNODES_CT_ : 1)>;
+    __device__ __forceinline__ JV jview() const { return JV{ocp.s.D, ocp.s.nsr, ocp.jblk, ocp.gblk, ocp.P}; }
     double cost_log = 0.0, primal_norm = 0.0, dual_norm = 0.0, max_violation = 0.0;
     double alpha_log = 0.0; int qp_iter_last = 0, qp_status_last = 0;   // for the iteration records
     double* trace = nullptr;   // this instance's records (pmpc_sqp_settings::iteration_trace), or null
@@ -383,6 +387,26 @@ struct SqpDevice {
 
     // lag_grad = J^T lam[0:m] + cost_grad + lam_box  (continuous_ocp.hpp:2112-2114)
     __device__ __forceinline__ void lagrangian_gradient(double* out) {
+        if constexpr (NN > 0) {
+            // J' lam from the per-node blocks and the differentiation matrix in LDS: the non-zero products of the dense chain below in the
+            // same ascending-row order (pmpc_jview.hpp). A non-finite multiplier takes the dense loops (0 * inf = NaN on the structural zeros).
+            bool fin = true;
+            for (int i = lane_id(); i < MM; i += WAVE) fin = fin && ((v.lam[i] - v.lam[i]) == 0.0);
+            if (__builtin_amdgcn_ballot_w64(!fin) == 0) {
+                const JV jv = jview();
+#pragma unroll
+                for (int e = 0; e < (NN + WAVE - 1) / WAVE; ++e) {
+                    const int col = lane_id() + WAVE * e;
+                    const int j = col < NN ? col : 0;
+                    double a = jv.coldot(j, v.lam);
+                    a += v.h[j];
+                    a += v.lam[MM + j];
+                    if (col < NN) out[j] = a;
+                }
+                wsync();
+                return;
+            }
+        }
         if constexpr (REG1) {   // compile-time sizes: one batch of independent loads (column j of J), then the chain
             const int j = lane_id() < NN ? lane_id() : 0;
             const unsigned jo = (unsigned)j * (NN + MM) + opaque_zero();
@@ -811,7 +835,7 @@ struct SqpDevice {
         }
         // 7-argument form: zero guesses (Q2)
         if constexpr (REG2) {   // (lower-triangle read of H always: the Hessian update is a run-time choice in these kernels)
-            boxadmm_solve_reg2<NN, MM, true, true>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr);
+            boxadmm_solve_reg2<NN, MM, true, true>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr, jview());
             wsync();
         } else if constexpr (REG1) { boxadmm_solve_reg<NN, MM, true, HU == 1>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr); wsync(); }
         else {

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "liboracle.so")
 REF_PATH = os.path.join(HERE, "_ref", "libref_casadi_robot.so")
 
 PIVOT_EIGEN, PIVOT_STATIC, PIVOT_SWEEP, PIVOT_SWEEP1, PIVOT_SWEEP2, PIVOT_BLOCKED = 0, 1, 2, 3, 4, 5
-SWEEP2_MAX_ROWS = 112   # PIVOT_SWEEP2 restates the two-rows-per-lane register kernel (65..112 KKT rows)
+SWEEP2_MAX_ROWS = 128   # PIVOT_SWEEP2 restates the two-rows-per-lane register kernel (65..128 KKT rows)
 
 
 def _check_sweep(pivot, rows):

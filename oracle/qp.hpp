@@ -20,7 +20,7 @@
 //                  the HIP kernels use, so a GPU-vs-oracle comparison isolates kernel bugs from pivot effects.
 //   PIVOT_BLOCKED: PIVOT_STATIC's factor and forward substitution, backward substitution by column dot products in blocks of 16 (the blocked
 //                  tile LDL^T of pmpc_qp_big.hpp, KKT systems that live in HBM)
-//   PIVOT_SWEEP2 : PIVOT_SWEEP's blocked sweep for 65..112 rows with the mat-vec order of the two-rows-per-lane register kernel
+//   PIVOT_SWEEP2 : PIVOT_SWEEP's blocked sweep for 65..128 rows with the mat-vec order of the two-rows-per-lane register kernel
 //   PIVOT_SWEEP1 : the swept inverse of PIVOT_SWEEP one pivot at a time on the lower triangle (any size), x = -(W b) as one fma chain
 //                  per row: accuracy evidence for the explicit-inverse route above 64 rows (no shipped kernel uses it this round).
 // All matrices column-major.
@@ -68,8 +68,8 @@ struct LDLT {
         n = n_; policy = pol; M = K; tr.assign(n, 0); temp.assign(n, 0.0);
         if (policy == PIVOT_STATIC || policy == PIVOT_BLOCKED) { compute_static(); return; }
         if (policy == PIVOT_SWEEP1) { compute_sweep1(); return; }
-        if (policy == PIVOT_SWEEP2) {  // the two-rows-per-lane register kernel (pmpc_qp_reg2.hpp): the same blocked sweep on 65..112 rows
-            if (n > 112) throw std::invalid_argument("oracle: PIVOT_SWEEP2 restates the 112-row register kernel; use PIVOT_STATIC / PIVOT_EIGEN for larger systems");
+        if (policy == PIVOT_SWEEP2) {  // the two-rows-per-lane register kernel (pmpc_qp_reg2.hpp): the same blocked sweep on 65..128 rows
+            if (n > 128) throw std::invalid_argument("oracle: PIVOT_SWEEP2 restates the 128-row register kernel; use PIVOT_STATIC / PIVOT_EIGEN for larger systems");
             compute_sweep(); return;
         }
         if (policy == PIVOT_SWEEP) {   // mirrors the register-resident kernel, which exists for at most 64 KKT rows (4 column blocks of 16)

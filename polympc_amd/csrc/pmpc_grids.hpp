@@ -28,6 +28,8 @@ bool try_launch_extra_grids(pmpc_context* ctx, const Model& mdl, const ChebData*
     PMPC_TRY_GRID(12)
     PMPC_TRY_GRID(13)
     PMPC_TRY_GRID(14)
+    PMPC_TRY_GRID(15)   // 113..128 rows where the model fits them (robot: 15 and 16 nodes — the reference's mpc_wrapper_test grid; CSTR: 12 above)
+    PMPC_TRY_GRID(16)
 #undef PMPC_TRY_GRID
     return false;
 }

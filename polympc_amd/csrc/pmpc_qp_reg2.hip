@@ -14,7 +14,7 @@ __global__ __launch_bounds__(64, 1) void qp_boxadmm_reg2_kernel(int B, const dou
                                                                 const double* __restrict__ xub, const double* __restrict__ x0,
                                                                 const double* __restrict__ y0, pmpc_qp_settings s,
                                                                 double* __restrict__ x, double* __restrict__ y, pmpc_qp_info* __restrict__ info) {
-    __shared__ double tr[RegKkt2<NN + MM>::TRI];
+    __shared__ __attribute__((aligned(16))) double tr[RegKkt2<NN + MM>::TRI];
     const int b = blockIdx.x;
     if (b >= B) return;
     pmpc_qp_info qi;
@@ -42,6 +42,9 @@ extern "C" int pmpc_internal_qp_reg2_launch(void* stream, int B, int n, int m, c
     PMPC_REG2_CASE(65, 39)
     PMPC_REG2_CASE(54, 36)   // CSTR grids of 9 and 10 nodes
     PMPC_REG2_CASE(60, 40)
+    PMPC_REG2_CASE(80, 48)   // 113..128 rows (8 x 8 tiles, last tile row / column in LDS): robot grids of 15 and 16 nodes (the reference's mpc_wrapper_test grid), CSTR of 12
+    PMPC_REG2_CASE(75, 45)
+    PMPC_REG2_CASE(72, 48)
 #undef PMPC_REG2_CASE
     return 0;
 }

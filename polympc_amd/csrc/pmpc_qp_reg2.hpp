@@ -28,7 +28,7 @@ namespace pmpc {
 
 template <int N>
 struct RegKkt2 {
-    static_assert(N > 64 && N <= 112, "two-rows-per-lane register path: 65..112 KKT rows");
+    static_assert(N > 64 && N <= 128, "two-rows-per-lane register path: 65..128 KKT rows");
     using d4 = double __attribute__((ext_vector_type(4)));
     static constexpr int BK = 4;
     static constexpr int NT = (N + 15) / 16;          // 16x16 tiles per dimension (5..7)
@@ -41,7 +41,22 @@ struct RegKkt2 {
     static constexpr int XSZ = 128 * SX + 128;
     static constexpr int SY = 17;                     // transposition buffer: one 16x16 tile, row stride 17
     static constexpr int TRI0 = BK * SK + (XSZ > BK * SK ? XSZ : BK * SK);
-    static constexpr int TRI = TRI0 > NT * 16 * SY ? TRI0 : NT * 16 * SY;   // doubles of LDS staging (PA | PB aliased with X; Y and the rhs buffer alias both)
+    // 113..128 rows (8 x 8 tiles): the 64 operand tiles of the mat-vec are 512 registers — the whole register file. Sixteen of them — two per tile
+    // row: the tiles with (R + C) mod 4 = 3 — live in LDS instead, lane-major (tile l, component pair h, lane: two doubles at l*256 + h*128 + 2*lane,
+    // one conflict-free 16-byte read per lane), and are read two steps ahead of the fma that consumes them; the other 48 are placed as in the 7 x 7
+    // case (17 in VGPRs, 31 in the accumulation file). Spread over the tile rows like this every step of the mat-vec has the same mix (six register
+    // operands, two from LDS). The sweep itself needs the 36 lower tiles only, all in registers. The LDS tiles alias the sweep's staging (dead once the
+    // inverse is finished); a one-tile transposition buffer behind them also serves as the per-iteration rhs buffer.
+    static constexpr bool LDS_TILES = NT == 8;
+    static constexpr int NL = LDS_TILES ? 2 * NT : 0;
+    static constexpr int LT = NL * 256;                       // doubles of LDS tiles; the small buffer YS sits behind them
+    static constexpr int YS = 16 * SY;
+    static constexpr int TRI1 = TRI0 > NT * 16 * SY ? TRI0 : NT * 16 * SY;
+    static constexpr int TRI = LDS_TILES ? (TRI0 > LT + YS ? TRI0 : LT + YS) : TRI1;   // doubles of LDS staging (PA | PB aliased with X; Y and the rhs buffer alias both)
+    static constexpr int RHS_OFF = LDS_TILES ? LT : 0;        // where apply() stages the right-hand side / the residual evaluation its vectors
+    __device__ __forceinline__ static constexpr bool in_lds(int R, int C) { return LDS_TILES && ((R + C) & 3) == 3; }
+    __device__ __forceinline__ static constexpr int lds_index(int R, int C) { return 2 * R + (C >= 4 ? 1 : 0); }
+    static constexpr int NTR = LDS_TILES ? NT - 2 : NT;       // register-resident operand tiles per tile row
 
     d4 T[NT][NT];   // after invert(): T[R][C] = the operand tile of output rows 16C + lc against columns 16R + 4r + lr
     // Register-file placement of the finished operand tiles, by hand: 49 tiles are 392 registers, more than either file holds (256 each),
@@ -49,9 +64,15 @@ struct RegKkt2 {
     // Tiles with index R*NT + C < NV stay in arch VGPRs; the others are split into 32-bit halves whose only uses are "a"-constrained inline-asm
     // operands, which makes their virtual registers AGPR-class: they live in the accumulation file for the whole ADMM loop and are copied
     // (v_accvgpr_read_b32 x 2) into a temporary pair next to the fma that consumes them.
-    static constexpr int NV = (NT == 7) ? 18 : (NT == 6 ? 12 : 10);
-    static constexpr int NA = NT * NT - NV;
-    __device__ __forceinline__ static constexpr bool in_agpr(int R, int C) { return R * NT + C >= NV; }
+    static constexpr int NV = LDS_TILES ? 17 : ((NT == 7) ? 18 : (NT == 6 ? 12 : 10));
+    static constexpr int NA = NT * NTR - NV;
+    // running index of a register-resident tile, row-major over the tiles that are not in LDS
+    __device__ __forceinline__ static constexpr int reg_index(int R, int C) {
+        if (!LDS_TILES) return R * NT + C;
+        const int c1 = (3 - R) & 3, c2 = c1 + 4;
+        return R * NTR + C - (C > c1 ? 1 : 0) - (C > c2 ? 1 : 0);
+    }
+    __device__ __forceinline__ static constexpr bool in_agpr(int R, int C) { return !in_lds(R, C) && reg_index(R, C) >= NV; }
     int Alo[NA * 4], Ahi[NA * 4];
 
     // one block step of the sweep (pivots 4b .. 4b+3); a member template so that every tile index, lane index and EXEC mask below is
@@ -202,19 +223,31 @@ struct RegKkt2 {
         // mirror: T[C][R] <- T[R][C]^T for R > C (the tiles the block-lower storage never materialised), and T[C][C] <- T[C][C]^T: the
         // operand tile of output row block C against column block R is the transpose of W's (C, R) tile. One tile row per LDS round.
         double* Y = st;
+        if constexpr (!LDS_TILES) {
 #pragma unroll
-        for (int R = 0; R < NT; ++R) {   // one tile row per LDS round: tiles (R, 0..R) out, their transposes back into (0..R, R)
+            for (int R = 0; R < NT; ++R) {   // one tile row per LDS round: tiles (R, 0..R) out, their transposes back into (0..R, R)
 #pragma unroll
-            for (int C = 0; C <= R; ++C)
+                for (int C = 0; C <= R; ++C)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Y[C * 16 * SY + (lr + 4 * r) * SY + lc] = T[R][C][r];
+                    for (int r = 0; r < 4; ++r) Y[C * 16 * SY + (lr + 4 * r) * SY + lc] = T[R][C][r];
+                lds_order();
+#pragma unroll
+                for (int C = 0; C <= R; ++C)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T[C][R][r] = Y[C * 16 * SY + lc * SY + lr + 4 * r];
+                lds_order();
+                sched_fence();
+            }
+        } else {
+            // 8 x 8 tiles: one tile at a time through the small buffer behind the LDS tiles (everything in front of it is being filled with tiles). A lower
+            // tile that lives in LDS is stored as it is, its transpose becomes the mirror tile — in registers or in LDS.
+            double* Lt = st; double* Ys = st + LT;
+            auto to_lds = [&](int li, const d4& v) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Lt[li * 256 + (r >> 1) * 128 + 2 * ln + (r & 1)] = v[r];
+            };
+            mirror_tiles<0, 0>(Ys, lr, lc, to_lds);
             lds_order();
-#pragma unroll
-            for (int C = 0; C <= R; ++C)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) T[C][R][r] = Y[C * 16 * SY + lc * SY + lr + 4 * r];
-            lds_order();
-            sched_fence();
         }
 #pragma unroll
         for (int R = 0; R < NT; ++R)
@@ -222,9 +255,27 @@ struct RegKkt2 {
             for (int C = 0; C < NT; ++C)
                 if (in_agpr(R, C)) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { Alo[(R * NT + C - NV) * 4 + r] = __double2loint(T[R][C][r]); Ahi[(R * NT + C - NV) * 4 + r] = __double2hiint(T[R][C][r]); }
+                    for (int r = 0; r < 4; ++r) { Alo[(reg_index(R, C) - NV) * 4 + r] = __double2loint(T[R][C][r]); Ahi[(reg_index(R, C) - NV) * 4 + r] = __double2hiint(T[R][C][r]); }
                 }
         if (tm) { long long t = clock64(); tm[4] += t - tq0; tq0 = t; }
+    }
+    template <int R, int C, class ToLds>
+    __device__ __forceinline__ void mirror_tiles(double* Ys, int lr, int lc, ToLds to_lds) {
+        if constexpr (R < NT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ys[(lr + 4 * r) * SY + lc] = T[R][C][r];
+            if constexpr (C < R && in_lds(R, C)) to_lds(lds_index(R, C), T[R][C]);
+            lds_order();
+            d4 tt;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tt[r] = Ys[lc * SY + lr + 4 * r];
+            lds_order();
+            if constexpr (in_lds(C, R)) to_lds(lds_index(C, R), tt);
+            else T[C][R] = tt;
+            sched_fence();
+            if constexpr (C < R) mirror_tiles<R, C + 1>(Ys, lr, lc, to_lds);
+            else mirror_tiles<R + 1, 0>(Ys, lr, lc, to_lds);
+        }
     }
     // one entry of an AGPR-resident tile -> a temporary VGPR pair (volatile: stays inside the ADMM loop, next to its use)
     __device__ __forceinline__ static double from_agpr(int alo, int ahi) {
@@ -244,9 +295,9 @@ struct RegKkt2 {
         for (int R = 0; R < NT; ++R)
 #pragma unroll
             for (int C = 0; C < NT; ++C)
-                if (!in_agpr(R, C)) {
+                if (!in_agpr(R, C) && !in_lds(R, C)) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) mem[(R * NT + C) * 4 + r + oz] = T[R][C][r];
+                    for (int r = 0; r < 4; ++r) mem[reg_index(R, C) * 4 + r + oz] = T[R][C][r];
                 }
     }
     __device__ __forceinline__ void unpark(const double* mem, int oz) {
@@ -254,15 +305,16 @@ struct RegKkt2 {
         for (int R = 0; R < NT; ++R)
 #pragma unroll
             for (int C = 0; C < NT; ++C)
-                if (!in_agpr(R, C)) {
+                if (!in_agpr(R, C) && !in_lds(R, C)) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) T[R][C][r] = mem[(R * NT + C) * 4 + r + oz];
+                    for (int r = 0; r < 4; ++r) T[R][C][r] = mem[reg_index(R, C) * 4 + r + oz];
                 }
     }
 
     // K^{-1} c for the two entries of every lane: c0 = entry `lane`, c1 = entry `lane + 64` (exact zero where that is >= N).
-    __device__ __forceinline__ void apply(double c0, double c1, double* st, int ln, double& x0, double& x1) const {
+    __device__ __forceinline__ void apply(double c0, double c1, double* st_, int ln, double& x0, double& x1) const {
         const int lr = ln >> 4, lc = ln & 15;
+        double* st = st_ + RHS_OFF;
         st[ln] = c0; st[64 + ln] = c1;
         lds_order();
         const int pidx = 16 * (lc >> 2) + 4 * (lc & 3) + lr;
@@ -270,7 +322,10 @@ struct RegKkt2 {
         lds_order();
         double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         asm volatile("s_nop 1" : "+v"(b0), "+v"(b1));   // VALU / LDS write -> DPP read: wait states inline asm is not covered for
-        chain<0>(acc, b0, b1);
+        lt_ = reinterpret_cast<const d2*>(st_) + ln;
+        d2 lpa[NT], lpb[NT];
+        lds_step_pairs<0>(lpa);
+        chain<0>(acc, b0, b1, lpa, lpb);
         asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]));
         swap32(acc[0], acc[2]); swap32(acc[1], acc[3]);
         double s0 = acc[0] + acc[2], s1 = acc[1] + acc[3];
@@ -282,21 +337,50 @@ struct RegKkt2 {
         x1 = -(u0 + u1);
     }
     // step (R, r) of every chain: acc[C] = fma(T[R][C][r], rhs(16R + 4r + lr), acc[C]), C < NT; (R, r) ascending
+    using d2 = double __attribute__((ext_vector_type(2)));
+    mutable const d2* lt_ = nullptr;   // this lane's slot in the LDS tiles (set by apply): tile l, component pair h at lt_[l * 128 + h * 64]
+    // the LDS operands of steps S, S + 1 (S even: components r, r + 1 of every LDS tile of tile row S / 4) in one 16-byte read per tile
     template <int S>
-    __device__ __forceinline__ void chain(double (&acc)[8], double b0, double b1) const {
+    __device__ __forceinline__ void lds_step_pairs(d2 (&lp)[NT]) const {
+        if constexpr (LDS_TILES && S < 4 * NT) {
+            constexpr int R = S / 4, h = (S % 4) >> 1;
+#pragma unroll
+            for (int C = 0; C < NT; ++C) if (in_lds(R, C)) lp[C] = lt_[lds_index(R, C) * 128 + h * 64];
+        }
+    }
+    // component r of the operand tiles (R, C), C < NT, wherever they live
+    template <int R, int r, int C>
+    __device__ __forceinline__ void operands(double (&w)[NT], const d2 (&cur)[NT], int c_lo, int c_hi) const {   // (c_lo, c_hi: compile-time after inlining)
+        if constexpr (C < NT) {
+            if (C >= c_lo && C < c_hi) {
+                if constexpr (in_lds(R, C)) w[C] = cur[C][r & 1];
+                else if constexpr (in_agpr(R, C)) w[C] = from_agpr(Alo[(reg_index(R, C) - NV) * 4 + r], Ahi[(reg_index(R, C) - NV) * 4 + r]);
+                else w[C] = T[R][C][r];
+            }
+            operands<R, r, C + 1>(w, cur, c_lo, c_hi);
+        }
+    }
+    // cur: LDS operands of this step (read two steps ago); nxt: buffer for the pair after it, requested at the even steps before the fma are issued
+    template <int S>
+    __device__ __forceinline__ void chain(double (&acc)[8], double b0, double b1, d2 (&cur)[NT], d2 (&nxt)[NT]) const {
         if constexpr (S < 4 * NT) {
             constexpr int R = S / 4, r = S % 4;
+            if constexpr ((r & 1) == 0) lds_step_pairs<S + 2>(nxt);
             // the operands of a step first (accumulation-file reads), then its fma: a v_accvgpr_read directly in front of the DPP operation that
             // consumes it needs a wait state (an s_nop per operand, 98 per ADMM iteration at 7 x 7 tiles)
             double w[NT];
+            constexpr int G = 4;   // (operands in groups of four: with all NT of a step gathered first the loop spilled at the QP entry point)
 #pragma unroll
-            for (int C = 0; C < NT; ++C) w[C] = in_agpr(R, C) ? from_agpr(Alo[(R * NT + C - NV) * 4 + r], Ahi[(R * NT + C - NV) * 4 + r]) : T[R][C][r];
+            for (int C0 = 0; C0 < NT; C0 += G) {
+                operands<R, r, 0>(w, cur, C0, C0 + G);
 #pragma unroll
-            for (int C = 0; C < NT; ++C) {
-                if constexpr (R < 4) acc[C] = fmac_rowbcast<4 * (R & 3) + r>(acc[C], b0, w[C]);
-                else acc[C] = fmac_rowbcast<4 * (R & 3) + r>(acc[C], b1, w[C]);
+                for (int C = C0; C < C0 + G && C < NT; ++C) {
+                    if constexpr (R < 4) acc[C] = fmac_rowbcast<4 * (R & 3) + r>(acc[C], b0, w[C]);
+                    else acc[C] = fmac_rowbcast<4 * (R & 3) + r>(acc[C], b1, w[C]);
+                }
             }
-            chain<S + 1>(acc, b0, b1);
+            if constexpr ((r & 1) == 0) chain<S + 1>(acc, b0, b1, cur, nxt);
+            else chain<S + 1>(acc, b0, b1, nxt, cur);
         }
     }
 };
@@ -312,7 +396,7 @@ __device__ __forceinline__ void boxadmm_solve_reg2(const double* __restrict__ H,
                                                    const JV& jv = JV()) {
     constexpr int N = NN + MM;
     constexpr bool HASJ = STACKED && !std::is_same<JV, NoJView>::value;
-    static_assert(N > WAVE && N <= 112, "two-rows-per-lane register path");
+    static_assert(N > WAVE && N <= 128, "two-rows-per-lane register path");
     const int ln = lane_id();
     // slot e: KKT row i_e = lane + 64 e. Primal rows [0, NN), constraint rows [NN, N).
     int idx[2]; bool isP[2], isC[2]; int rc[2], lp[2];
@@ -479,8 +563,9 @@ __device__ __forceinline__ void boxadmm_solve_reg2(const double* __restrict__ H,
                   if constexpr (HASJ) {
                     // H x from the workspace (dense), A x and A' y from the block-sparse view in LDS — the same products in the same order.
                     constexpr int NP1 = NN > 64 ? NN - 64 : 0;          // primal rows of the second slot
-                    double* xs = tr; double* ys = tr + NN; double* pb = tr + NN + MM;   // (the staging is free between factorisations)
-                    static_assert(NN + MM + NP1 * NN <= RegKkt2<N>::TRI, "residual scratch fits the staging");
+                    constexpr bool FEW1 = NP1 <= 4;                     // few of them: products through LDS; otherwise their lanes load their rows
+                    double* xs = tr + RegKkt2<N>::RHS_OFF; double* ys = xs + NN; double* pb = ys + MM;   // (the staging is free between factorisations)
+                    static_assert(RegKkt2<N>::RHS_OFF + NN + MM + (FEW1 ? NP1 * NN : 0) <= RegKkt2<N>::TRI, "residual scratch fits the staging");
                     // the lane's rows and their roles, re-derived from a lane id that is materialised HERE: the long-lived copies (idx, isP, rc, ...) are
                     // spilled across the ADMM loop, and every scratch reload in this block would be an exposed memory round trip
                     const int sl = (int)lane_near(zr);
@@ -502,7 +587,7 @@ __device__ __forceinline__ void boxadmm_solve_reg2(const double* __restrict__ H,
                     // lane t then adds the NN products of row 64 + t in ascending j — instead of NN loads per lane for NP1 live lanes
                     double h0[NP1 > 0 ? NP1 : 1], h1[NP1 > 0 ? NP1 : 1];
 #pragma unroll
-                    for (int t = 0; t < NP1; ++t) {
+                    for (int t = 0; t < (FEW1 ? NP1 : 0); ++t) {
                         const unsigned l = lane_near(zr);
                         unsigned b0 = (64u + (unsigned)t) + l * (unsigned)N + (unsigned)zr; asm("" : "+v"(b0));
                         h0[t] = H[b0];
@@ -529,7 +614,24 @@ __device__ __forceinline__ void boxadmm_solve_reg2(const double* __restrict__ H,
                         sched_fence();
                     }
                     acc[0] = sP[0] ? hx : acc[0];
-                    if constexpr (NP1 > 0) {
+                    if constexpr (NP1 > 0 && !FEW1) {   // many primal rows in the second slot: lane l < NP1 loads row 64 + l (the other lanes re-read row 64)
+                        double hx1 = 0.0;
+#pragma unroll
+                        for (int j0 = 0; j0 < NN; j0 += RCS) {
+                            double mm[RCS];
+#pragma unroll
+                            for (int j = 0; j < RCS; ++j) {
+                                const unsigned l = lane_near(zr);
+                                unsigned b = 64u + (l < (unsigned)NP1 ? l : 0u) + (unsigned)(((j0 + j < NN) ? j0 + j : 0) * N) + (unsigned)zr; asm("" : "+v"(b));
+                                mm[j] = H[b];
+                            }
+#pragma unroll
+                            for (int j = 0; j < RCS; ++j) if (j0 + j < NN) hx1 += mm[j] * xbc(xv, j0 + j);
+                            sched_fence();
+                        }
+                        acc[1] = (sl < NP1) ? hx1 : acc[1];
+                    }
+                    if constexpr (NP1 > 0 && FEW1) {
 #pragma unroll
                         for (int t = 0; t < NP1; ++t) { pb[t * NN + sl] = h0[t] * xv[0]; if (sl < NP1) pb[t * NN + 64 + sl] = h1[t] * xv[1]; }
                         lds_order();

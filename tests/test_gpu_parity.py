@@ -41,11 +41,11 @@ def _lds_order(oracle, rows, qp_entry=False):
     return oracle.PIVOT_BLOCKED if rows >= (QP_BIG_MIN_ROWS if qp_entry else BIG_KKT_MIN_ROWS) else oracle.PIVOT_STATIC
 
 
-REG2_QP_SHAPES = ((66, 44), (55, 33), (45, 27), (50, 30), (60, 36), (65, 39), (54, 36), (60, 40))
+REG2_QP_SHAPES = ((66, 44), (55, 33), (45, 27), (50, 30), (60, 36), (65, 39), (54, 36), (60, 40), (80, 48), (75, 45), (72, 48))
 REG1_QP_SHAPES = ((35, 21), (20, 12), (25, 15), (30, 18), (40, 24), (24, 16), (30, 20), (36, 24))   # one KKT row per lane (pmpc_api.hip)   # QP entry point: two-rows-per-lane register specialisations (pmpc_qp_reg2.hip)
 
 
-REG_NODE_COUNTS = (3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14)   # grids of the built-in models with register-resident SQP kernels (pmpc_launch.hpp, pmpc_grids.hpp)
+REG_NODE_COUNTS = (3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16)   # grids of the built-in models with register-resident SQP kernels (pmpc_launch.hpp, pmpc_grids.hpp)
 
 
 def _gpu_order(oracle, n, m, nodes=None, block_bfgs=False):
@@ -60,7 +60,7 @@ def _gpu_order(oracle, n, m, nodes=None, block_bfgs=False):
         return oracle.PIVOT_SWEEP if (n, m) in REG1_QP_SHAPES else _lds_order(oracle, n + m, qp_entry=True)
     if n + m <= 64 and nodes in ((5, 7) if block_bfgs else REG_NODE_COUNTS):   # (the block-BFGS one-row-per-lane specialisation exists for 5 and 7 nodes)
         return oracle.PIVOT_SWEEP
-    if 64 < n + m <= 112 and nodes in REG_NODE_COUNTS:      # two-rows-per-lane register path (the Hessian update is a run-time choice there)
+    if 64 < n + m <= 128 and nodes in REG_NODE_COUNTS:      # two-rows-per-lane register path (113..128 rows: part of the operand tiles in LDS) (the Hessian update is a run-time choice there)
         return oracle.PIVOT_SWEEP2
     return _lds_order(oracle, n + m)
 
@@ -116,7 +116,7 @@ def test_qp_reference_known_answers(ctx, oracle):
     assert abs(x[0, 0] - 2.0) <= 2e-2 and info["iter"][0] < 200 and info["status"][0] == pa.QP_SOLVED
 
 
-@pytest.mark.parametrize("n,m,B", [(2, 1, 8), (1, 0, 4), (7, 3, 33), (35, 21, 64), (55, 33, 16), (66, 44, 8), (80, 48, 4), (3, 70, 4), (60, 36, 5), (105, 63, 3), (256, 208, 3), (70, 43, 4), (64, 65, 3), (130, 0, 3), (5, 140, 2), (20, 12, 9), (40, 24, 5), (36, 24, 5), (45, 27, 4), (60, 36, 3), (65, 39, 3), (60, 40, 3)])
+@pytest.mark.parametrize("n,m,B", [(2, 1, 8), (1, 0, 4), (7, 3, 33), (35, 21, 64), (55, 33, 16), (66, 44, 8), (80, 48, 4), (3, 70, 4), (60, 36, 5), (105, 63, 3), (256, 208, 3), (70, 43, 4), (64, 65, 3), (130, 0, 3), (5, 140, 2), (20, 12, 9), (40, 24, 5), (36, 24, 5), (45, 27, 4), (60, 36, 3), (65, 39, 3), (60, 40, 3), (75, 45, 3), (72, 48, 3)])
 def test_qp_random_vs_oracle(ctx, oracle, n, m, B):
     """Random convex QPs of many shapes (incl. ragged n+m > 64, m > n, m = 0): same iteration count, status and
     rho updates as the oracle; x, y and the reported residuals bit-identical (register, two-rows-per-lane, LDS and HBM-factor kernels)."""
@@ -894,10 +894,11 @@ def test_sqp_iteration_records_vs_oracle(ctx, oracle, P, S, B):
         ctx.iteration_trace_destroy(h)
 
 
-@pytest.mark.parametrize("model,P,S", [(0, 3, 1), (0, 5, 1), (0, 7, 1), (0, 2, 1), (0, 4, 2), (0, 3, 3), (0, 11, 1), (0, 4, 3), (0, 13, 1), (1, 5, 1), (1, 4, 2), (1, 3, 1)])
+@pytest.mark.parametrize("model,P,S", [(0, 3, 1), (0, 5, 1), (0, 7, 1), (0, 2, 1), (0, 4, 2), (0, 3, 3), (0, 11, 1), (0, 4, 3), (0, 13, 1), (1, 5, 1), (1, 4, 2), (1, 3, 1), (0, 7, 2), (0, 5, 3), (0, 3, 5), (1, 11, 1)])
 def test_sqp_register_paths_on_other_grids(ctx, oracle, model, P, S):
-    """Register-resident SQP kernels beyond the 5-, 7- and 11-node grids (pmpc_grids_*.hip): robot on 4, 6, 8 and 3 nodes (one KKT row per lane) and
-    on 9, 10, 12 and 13 nodes (72 .. 104 rows, two rows per lane); CSTR on 6 nodes (60 rows), 9 nodes (90 rows) and 4 nodes. Identical trajectories and
+    """Register-resident SQP kernels beyond the 5-, 7- and 11-node grids (pmpc_grids_*.hip): robot on 4, 6, 8 and 3 nodes (one KKT row per lane),
+    on 9, 10, 12 and 13 nodes (72 .. 104 rows, two rows per lane) and on 15 and 16 nodes (120 / 128 rows: 8 x 8 tiles, sixteen of them in LDS — the
+    reference's mpc_wrapper_test grid P = 5, S = 3 and the same node count as 3 x 5); CSTR on 6 nodes (60 rows), 9 nodes (90 rows), 4 nodes and 12 nodes (120 rows). Identical trajectories and
     bit-identical solutions against the sweep-order restatements; the block BFGS on such a grid takes the LDS-resident kernel (static order) below 65
     rows and stays on the two-rows-per-lane kernel above."""
     from polympc_amd import workloads
@@ -909,7 +910,7 @@ def test_sqp_register_paths_on_other_grids(ctx, oracle, model, P, S):
         lbx, ubx = _cstr_grid(B, P, S)
         wl = dict(model=1, P=P, S=S, t0=0.0, tf=100.0, d=np.zeros((B, 1)), lbx=lbx, ubx=ubx, max_iter=8, ls_max_iter=20)
     dm = oracle.ocp_dims(model, P, S)
-    assert nn in REG_NODE_COUNTS and dm["n"] + dm["m"] <= 112
+    assert nn in REG_NODE_COUNTS and dm["n"] + dm["m"] <= 128
     (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, wl, B)
     _assert_same_solve(info, io, x, xo, lam, lo)
     (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, wl, B, hessian_update=1)
@@ -929,8 +930,8 @@ def test_sqp_warm_start_and_gershgorin(ctx, oracle):
     lbx2[:, 45:48] -= 0.1; ubx2[:, 45:48] -= 0.1
     x2, l2, i2 = ctx.sqp_solve_batch(0, 5, 3, 0.0, 2.0, B, wl["d"], lbx2, ubx2, x_guess=x1, lam_guess=l1, sqp_settings=ss, mparams=mp)
     oss = oracle.sqp_default_settings(); oss.max_iter = 10; oss.line_search_max_iter = 10; oss.regularisation = 2
-    xo1, lo1, io1 = oracle.sqp_solve_batch(0, 5, 3, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, pivot=_lds_order(oracle, 128), mparams=mp)
-    xo2, lo2, io2 = oracle.sqp_solve_batch(0, 5, 3, 0.0, 2.0, B, wl["d"], lbx2, ubx2, x_guess=xo1, lam_guess=lo1, sqp_settings=oss, pivot=_lds_order(oracle, 128), mparams=mp)
+    xo1, lo1, io1 = oracle.sqp_solve_batch(0, 5, 3, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, pivot=_gpu_order(oracle, 80, 48, nodes=16), mparams=mp)
+    xo2, lo2, io2 = oracle.sqp_solve_batch(0, 5, 3, 0.0, 2.0, B, wl["d"], lbx2, ubx2, x_guess=xo1, lam_guess=lo1, sqp_settings=oss, pivot=_gpu_order(oracle, 80, 48, nodes=16), mparams=mp)
     _assert_same_solve(i1, io1, x1, xo1, l1, lo1)
     _assert_same_solve(i2, io2, x2, xo2, l2, lo2)
     assert np.mean(i2["status"] == pa.SQP_SOLVED) >= 0.75
@@ -1129,7 +1130,7 @@ def test_default_kernels_against_the_reference_order(ctx, oracle, cfg):
 
 def ROUTE_OF_128_ROWS(pa):
     """the kernel family pmpc_launch.hpp routes 128-row instances to (one place to change when the route changes)"""
-    return pa.capi.ROUTE_HBM
+    return pa.capi.ROUTE_REG2   # round 3: 113..128 rows on the two-rows-per-lane register path (8 x 8 tiles, sixteen of them in LDS)
 
 
 def test_last_route_reports_the_kernel_family(ctx):
@@ -1155,8 +1156,8 @@ def test_last_route_reports_the_kernel_family(ctx):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["C_kite_standin_1024", "R_robot_16_nodes_2048"])
 def test_sqp_full_size_properties_hbm_factor_kernel(ctx, oracle, case):
-    """BASELINE size of config C (1024 instances of the 464-row stand-in) and 2048 instances on the reference's 16-node robot grid (128 rows), both
-    on the HBM-factor kernel: SOLVED fractions, finite, bounds respected, the reported constraint violation equal to what the SEPARATE collocation
+    """BASELINE size of config C (1024 instances of the 464-row stand-in, HBM-factor kernel) and 2048 instances on the reference's 16-node robot grid
+    (128 rows: since round 3 the two-rows-per-lane register kernel with LDS-resident operand tiles): SOLVED fractions, finite, bounds respected, the reported constraint violation equal to what the SEPARATE collocation
     kernel (pmpc_ocp_linearise_batch) evaluates at the returned point, and a sample of instances spread over the batch bit-identical to the
     blocked-order CPU restatement run on those instances alone (the batch position must not matter)."""
     import polympc_amd as pa
@@ -1180,5 +1181,5 @@ def test_sqp_full_size_properties_hbm_factor_kernel(ctx, oracle, case):
     sample = np.array([0, 1, B // 3, B // 2 + 7, B - 2, B - 1])
     oss = oracle.sqp_default_settings(); oss.max_iter = wl["max_iter"]; oss.line_search_max_iter = wl["ls_max_iter"]
     xo, lo, io = oracle.sqp_solve_batch(wl["model"], P, S, wl["t0"], wl["tf"], len(sample), wl["d"][sample], wl["lbx"][sample], wl["ubx"][sample],
-                                        sqp_settings=oss, pivot=oracle.PIVOT_BLOCKED, threads=6)
+                                        sqp_settings=oss, pivot=_gpu_order(oracle, wl["n"], wl["m"], nodes=P * S + 1), threads=6)
     _assert_same_solve(info[sample], io, x[sample], xo, lam[sample], lo)

@@ -711,11 +711,12 @@ def test_config_B_cross_order_spread_is_the_conditioning_of_the_trajectory(oracl
 
 
 # ---------------------------------------------------------------- PIVOT_SWEEP2: the two-rows-per-lane register kernel's order (65..112 rows)
-@pytest.mark.parametrize("n,m", [(66, 44), (55, 33), (41, 24), (70, 42)])
+@pytest.mark.parametrize("n,m", [(66, 44), (55, 33), (41, 24), (70, 42), (80, 48)])
 def test_sweep2_policy_matches_factorisations(oracle, n, m):
     """The blocked sweep carried to 5..7 tiles per dimension with the mat-vec order of pmpc_qp_reg2.hpp (four chains per row, columns
     j = q mod 4) against numpy and against both LDL^T policies, on quasi-definite KKT matrices with the conditioning of the ADMM; sizes:
-    config B (110 rows), the 11-node robot grid (88), the smallest size the path takes (65) and its limit (112)."""
+    config B (110 rows), the 11-node robot grid (88), the smallest size the path takes (65), the limit of the all-register variant (112) and the
+    limit of the path (128: the reference's 16-node robot grid)."""
     rng = np.random.default_rng(n * 100 + m)
     G = rng.normal(size=(n, n)); H = G @ G.T / n + (1e-6 + 0.1) * np.eye(n); A = rng.normal(size=(m, n))
     K = np.block([[H, A.T], [A, -np.diag(1.0 / rng.choice([0.1, 100.0], m))]])
@@ -728,11 +729,11 @@ def test_sweep2_policy_matches_factorisations(oracle, n, m):
         assert np.abs(xs - oracle.ldlt_solve(np.tril(K), b, piv)).max() < 1e-9 * scale
 
 
-def test_sweep2_policy_rejects_systems_over_112_rows(oracle):
+def test_sweep2_policy_rejects_systems_over_128_rows(oracle):
     from polympc_amd import workloads
-    wl = workloads.robot_batch(1, P=5, S=3)   # 128 rows
+    wl = workloads.robot_batch(1, P=4, S=4)   # 17 nodes: 136 rows
     with pytest.raises(ValueError):
-        oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 3, 0.0, 2.0, 1, wl["d"], wl["lbx"], wl["ubx"], pivot=oracle.PIVOT_SWEEP2)
+        oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 4, 4, 0.0, 2.0, 1, wl["d"], wl["lbx"], wl["ubx"], pivot=oracle.PIVOT_SWEEP2)
 
 
 def test_sweep2_policy_on_the_11_node_robot_grid(oracle):

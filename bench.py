@@ -370,7 +370,7 @@ def main():
                 n_all, n_one = SAMPLE[letter]
                 coss = ob.sqp_default_settings(); coss.max_iter = cwl["max_iter"]; coss.line_search_max_iter = cwl["ls_max_iter"]
                 rows = cwl["n"] + cwl["m"]
-                korder = ob.PIVOT_SWEEP if rows <= 64 else (ob.PIVOT_SWEEP2 if rows <= ob.SWEEP2_MAX_ROWS else ob.PIVOT_BLOCKED)
+                korder = ob.PIVOT_SWEEP if rows <= 64 else (ob.PIVOT_SWEEP2 if rows <= ob.SWEEP2_MAX_ROWS else ob.PIVOT_CONDENSED)
 
                 def crun(count, threads, pivot, glibc):
                     with (ob.libm() if glibc else _null()):

@@ -109,6 +109,10 @@ typedef struct {
                                    * iteration's termination test; iterations beyond the capacity are not recorded, records of iterations that
                                    * did not run keep what the buffer held (pmpc_iteration_trace_create / _clear zero it). */
     int iteration_trace_capacity; /* records per instance (ignored when iteration_trace is NULL) */
+    int kkt_form;         /* large instances (KKT factor in HBM): 0 (default) condensed — the diagonal constraint block of the KKT matrix is eliminated in
+                           * closed form and the n x n matrix H + sigma I + rho_box + A' diag(rho) A is factorised (same solution in exact arithmetic,
+                           * box_admm.hpp:209-223 / :123 restated as PIVOT_CONDENSED); 1 the (n+m) x (n+m) KKT matrix as the reference builds it.
+                           * Ignored by the register- and LDS-resident kernels. (Occupies former tail padding: the struct size is unchanged.) */
 } pmpc_sqp_settings;
 #define PMPC_FILTER_MAX_DEPTH 10
 #define PMPC_FILTER_STATE_DOUBLES (1 + 2 * PMPC_FILTER_MAX_DEPTH)
@@ -137,13 +141,14 @@ typedef enum {
 
 /* ------------------------------------------------------------------------------------------------------------ */
 /* ABI version of THIS header. It changes whenever a struct above changes size or meaning or an entry point changes its signature
- * (1: round 1; 2: linear_solver, flags words, iteration_trace, fp32 QP entries; 3: this query, pmpc_sqp_last_route, multi-device batches).
+ * (1: round 1; 2: linear_solver, flags words, iteration_trace, fp32 QP entries; 3: this query, pmpc_sqp_last_route, multi-device batches;
+ * 4: pmpc_sqp_settings::kkt_form).
  * A host must compare pmpc_abi_version() — what the loaded library was built from — with the PMPC_ABI_VERSION it was compiled against, and
  * pmpc_struct_size() with its own sizeof, before passing a settings struct: the *_default() functions write the whole struct of the
  * LIBRARY's layout. Settings structs must always be initialised with pmpc_*_settings_default() and then edited field by field (a struct
  * filled by hand leaves iteration_trace / filter_state / linear_solver undefined; the entry points reject what they can detect — unknown
  * enum values, a trace pointer with a capacity < 1 — with PMPC_ERR_INVALID_ARGUMENT, but a garbage pointer cannot be detected). */
-#define PMPC_ABI_VERSION 3
+#define PMPC_ABI_VERSION 4
 int pmpc_abi_version(void);
 /* sizeof of the library's own struct: which = 0 pmpc_qp_settings, 1 pmpc_qp_info, 2 pmpc_sqp_settings, 3 pmpc_sqp_info; 0 for anything else */
 unsigned long pmpc_struct_size(int which);

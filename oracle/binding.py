@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liboracle.so")
 REF_PATH = os.path.join(HERE, "_ref", "libref_casadi_robot.so")
 
-PIVOT_EIGEN, PIVOT_STATIC, PIVOT_SWEEP, PIVOT_SWEEP1, PIVOT_SWEEP2, PIVOT_BLOCKED = 0, 1, 2, 3, 4, 5
+PIVOT_EIGEN, PIVOT_STATIC, PIVOT_SWEEP, PIVOT_SWEEP1, PIVOT_SWEEP2, PIVOT_BLOCKED, PIVOT_CONDENSED = 0, 1, 2, 3, 4, 5, 6
 SWEEP2_MAX_ROWS = 128   # PIVOT_SWEEP2 restates the two-rows-per-lane register kernel (65..128 KKT rows)
 
 

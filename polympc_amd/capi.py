@@ -15,7 +15,7 @@ QP_SOLVED, QP_MAX_ITER_EXCEEDED, QP_UNSOLVED = 0, 1, 2
 SQP_SOLVED, SQP_MAX_ITER_EXCEEDED = 0, 1
 FLAG_NONFINITE = 1   # pmpc_qp_info / pmpc_sqp_info flags: a non-finite value went through a QP solve
 
-ABI_VERSION = 3   # PMPC_ABI_VERSION of include/polympc_amd.h that the ctypes layouts below mirror
+ABI_VERSION = 4   # PMPC_ABI_VERSION of include/polympc_amd.h that the ctypes layouts below mirror
 ROUTE_NONE, ROUTE_REG1, ROUTE_REG2, ROUTE_LDS, ROUTE_HBM = 0, 1, 2, 3, 4   # pmpc_route
 ROUTE_NAMES = {0: "none", 1: "reg1", 2: "reg2", 3: "lds", 4: "hbm"}
 
@@ -49,7 +49,7 @@ class SQPSettings(C.Structure):
                 ("eps_dual", C.c_double), ("max_iter", C.c_int), ("line_search_max_iter", C.c_int),
                 ("regularisation", C.c_int), ("exact_hessian_every_iter", C.c_int), ("preconditioner", C.c_int), ("hessian_update", C.c_int), ("qp_solver", C.c_int),
                 ("line_search", C.c_int), ("filter_max_depth", C.c_int), ("filter_beta", C.c_double), ("filter_state", C.c_void_p),
-                ("iteration_trace", C.c_void_p), ("iteration_trace_capacity", C.c_int)]
+                ("iteration_trace", C.c_void_p), ("iteration_trace_capacity", C.c_int), ("kkt_form", C.c_int)]
 
 
 FILTER_MAX_DEPTH = 10

@@ -260,7 +260,7 @@ void pmpc_sqp_settings_default(pmpc_sqp_settings* s) {
     s->tau = 0.5; s->eta = 0.25; s->rho = 0.5; s->eps_prim = 1e-3; s->eps_dual = 1e-3; s->max_iter = 100;
     s->line_search_max_iter = 100; s->regularisation = 0; s->exact_hessian_every_iter = 0; s->preconditioner = 0; s->hessian_update = 0; s->qp_solver = 0;
     s->line_search = 0; s->filter_max_depth = PMPC_FILTER_MAX_DEPTH; s->filter_beta = 1e-5; s->filter_state = nullptr;
-    s->iteration_trace = nullptr; s->iteration_trace_capacity = 0;
+    s->iteration_trace = nullptr; s->iteration_trace_capacity = 0; s->kkt_form = 0;
 }
 
 pmpc_status pmpc_chebyshev(int P, double* nodes, double* weights, double* D) {
@@ -485,6 +485,7 @@ static pmpc_status check_sqp_args(int model, int P, int S, const double* d, cons
     if (nd > 0 && !d) return PMPC_ERR_INVALID_ARGUMENT;
     if (ss && ss->max_iter < 1) return PMPC_ERR_INVALID_ARGUMENT;
     if (ss && ss->iteration_trace && ss->iteration_trace_capacity < 1) return PMPC_ERR_INVALID_ARGUMENT;
+    if (ss && ss->kkt_form != 0 && ss->kkt_form != 1) return PMPC_ERR_INVALID_ARGUMENT;
     return PMPC_OK;
 }
 

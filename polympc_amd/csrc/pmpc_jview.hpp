@@ -23,8 +23,6 @@
 
 namespace pmpc {
 
-struct NoJView {};   // tag: the QP has no structure information (the plain QP entry points)
-
 template <class Model, int NNODES>
 struct JView {
     static_assert(NNODES > 0, "the node count is a compile-time constant of the register-resident kernels");
@@ -168,6 +166,163 @@ struct JView {
 #pragma unroll
                 for (int r = 0; r < MI; ++r) g2 += gblk[r * NDER + dcol] * ys[ME + r];
                 a = isp ? g2 : g1;
+            } else a = g1;
+        }
+        return a;
+    }
+};
+
+// The same view for a run-time node count and any memory (the large-instance kernel keeps the blocks and the collocation constants in its HBM
+// scratch): the entry J(r, c) itself — the operands of the matrix-core product A' diag(rho) A — and the two sparse products of the condensed
+// linear solve (pmpc_qp_big.hpp), which are fma chains over the entries that are not exactly zero, rows / columns ascending: the restatement
+// (oracle/qp.hpp, PIVOT_CONDENSED) walks the dense matrix and skips its zeros, so structural zeros and numerical zeros are the same statement on
+// both sides, whatever the operand.
+template <class Model>
+struct JViewRT {
+    enum { NX = Model::NX, NU = Model::NU, NP = Model::NP, NG = Model::NG, NDER = NX + NU + NP };
+    const double* D;      // (P+1) x (P+1) column-major, followed by the last node's row (OcpLds::D)
+    const int* nsr;
+    const double* jblk;
+    const double* gblk;
+    int P, NNo, VARX, VARU, ME;
+
+    struct Node { int kb; const double* drow; int dstride; };
+    // segment start and D row of the equality rows of node k (Ocp::seg_row) from arithmetic alone — k / P through a float reciprocal, exact for the
+    // node counts in question — so that the D loads below depend on no other load (the node table sits in HBM here: a dependent round trip each)
+    __device__ __forceinline__ Node node(int k) const {
+        const bool last = k == NNo - 1;
+        const int seg = (int)(((float)k + 0.5f) * (1.0f / (float)P));
+        const int row = k - seg * P;
+        Node nd; nd.kb = last ? (NNo - 1) - P : seg * P; nd.drow = D + (last ? (P + 1) * (P + 1) : row); nd.dstride = last ? 1 : P + 1;
+        return nd;
+    }
+    struct Col { bool xcol, pcol; int jn, dcol; };
+    __device__ __forceinline__ Col column(int c) const {
+        Col k; k.xcol = c < VARX; k.pcol = (NP > 0) && c >= VARX + VARU;
+        const int cu = c - VARX;
+        const int jx = c / NX, ju = (!k.xcol && !k.pcol) ? cu / NU : 0;
+        k.jn = k.xcol ? jx : ju;
+        k.dcol = k.xcol ? c - jx * NX : (k.pcol ? NX + NU + (cu - VARU) : NX + (cu - ju * NU));
+        return k;
+    }
+    struct Row { bool eq; int k, q, ri, kg; Node nd; };
+    __device__ __forceinline__ Row rowinfo(int r) const {
+        Row w; w.eq = (NG == 0) || r < ME;
+        const int re = w.eq ? r : 0;
+        w.k = re / NX; w.q = re - w.k * NX; w.nd = node(w.k);
+        w.ri = w.eq ? 0 : r - ME; w.kg = (NG > 0) ? w.ri / (NG > 0 ? NG : 1) : 0;
+        return w;
+    }
+    // J(r, c) for a decoded row and column
+    __device__ __forceinline__ double jval(const Row& w, const Col& cc) const {
+        const int t = cc.jn - w.nd.kb;
+        const bool inseg = cc.xcol && cc.dcol == w.q && (unsigned)t <= (unsigned)P;
+        const double dv = w.nd.drow[(inseg ? t : 0) * w.nd.dstride];
+        const double bv = jblk[(w.k * NX + w.q) * NDER + cc.dcol];
+        double v = (cc.pcol || cc.jn == w.k) ? bv : (inseg ? dv : 0.0);
+        if constexpr (NG > 0) {
+            const double gv = gblk[w.ri * NDER + cc.dcol];
+            const double vg = (cc.pcol || cc.jn == w.kg) ? gv : 0.0;
+            v = w.eq ? v : vg;
+        }
+        return v;
+    }
+    __device__ __forceinline__ double jval(int r, int c) const { return jval(rowinfo(r), column(c)); }
+    // is J(r, c) a structural non-zero? (no memory access)
+    __device__ __forceinline__ bool structural(const Row& w, const Col& cc) const {
+        const int t = cc.jn - w.nd.kb;
+        const bool inseg = cc.xcol && cc.dcol == w.q && (unsigned)t <= (unsigned)P;
+        const int kk = w.eq ? w.k : w.kg;
+        return cc.pcol || cc.jn == kk || (w.eq && inseg);
+    }
+    __device__ __forceinline__ static double step(double a, double v, double x, bool on) { const double f = fma(v, x, a); return (on && v != 0.0) ? f : a; }
+
+    // ---- the two sparse products of the condensed solve. D (`D`) and the vectors live in LDS; the per-node blocks come from the HBM scratch and are
+    // requested first (row_block / col_block, every pass of a product before any of them is consumed), so that a product costs one memory round trip.
+    __device__ __forceinline__ void row_block(const Row& w, double (&bv)[NDER]) const {
+        const double* blk = w.eq ? jblk + (w.k * NX + w.q) * NDER : gblk + w.ri * NDER;
+#pragma unroll
+        for (int i = 0; i < NDER; ++i) bv[i] = blk[i];
+    }
+    // fma chain over the non-zero entries of row r against xs (n entries), columns ascending, starting from 0
+    __device__ __forceinline__ double rowdot_fma(const Row& w, const double (&bv)[NDER], const double* xs) const {
+        const int kk = w.eq ? w.k : w.kg;
+        double xb[NDER];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xb[i] = xs[kk * NX + i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) xb[NX + i] = xs[VARX + kk * NU + i];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) xb[NX + NU + i] = xs[VARX + VARU + i];
+        double a = 0.0;
+        for (int ph = 0; ph < 2; ++ph) {   // segment nodes before the own node, the own node's state columns, segment nodes after it
+            for (int t0 = 0; t0 <= P; t0 += 8) {
+                double dv[8], xv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int t = (t0 + u <= P) ? t0 + u : 0; dv[u] = w.nd.drow[t * w.nd.dstride]; xv[u] = xs[(w.nd.kb + t) * NX + w.q]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int j = w.nd.kb + t0 + u; a = step(a, dv[u], xv[u], w.eq && t0 + u <= P && (ph == 0 ? j < w.k : j > w.k)); }
+            }
+            if (ph == 0) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) a = step(a, bv[i], xb[i], true);
+            }
+        }
+#pragma unroll
+        for (int i = NX; i < NDER; ++i) a = step(a, bv[i], xb[i], true);
+        return a;
+    }
+    static constexpr int NCB = NX + NG;   // entries of a column inside its own node's rows (equality rows, then inequality rows)
+    __device__ __forceinline__ void col_block(const Col& cc, double (&bv)[NCB > 0 ? NCB : 1]) const {
+#pragma unroll
+        for (int q = 0; q < NX; ++q) bv[q] = jblk[(cc.jn * NX + q) * NDER + cc.dcol];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) bv[NX + g] = gblk[(cc.jn * NG + g) * NDER + cc.dcol];
+    }
+    // init, then the fma chain over the non-zero entries of column c against us (m entries), rows ascending
+    __device__ __forceinline__ double coldot_fma(const Col& cc, const double (&bv)[NCB > 0 ? NCB : 1], const double* us, double init) const {
+        const int qx = cc.xcol ? cc.dcol : 0;
+        double a = init;
+        for (int ph = 0; ph < 2; ++ph) {
+            for (int k0 = 0; k0 < NNo; k0 += 8) {   // equality rows (k, qx) whose segment holds node jn, above / below the own node
+                double dv[8], uv[8]; bool on[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = (k0 + u < NNo) ? k0 + u : 0;
+                    const Node nd = node(k);
+                    const int t = cc.jn - nd.kb;
+                    const bool inseg = cc.xcol && (unsigned)t <= (unsigned)P;
+                    dv[u] = nd.drow[(inseg ? t : 0) * nd.dstride];
+                    uv[u] = us[k * NX + qx];
+                    on[u] = inseg && (k0 + u < NNo) && (ph == 0 ? k < cc.jn : k > cc.jn);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a = step(a, dv[u], uv[u], on[u]);
+            }
+            if (ph == 0) {   // own-node block: the NX equality rows of node jn (parameter column: every equality row, below)
+#pragma unroll
+                for (int q = 0; q < NX; ++q) a = step(a, bv[q], us[cc.jn * NX + q], !cc.pcol);
+            }
+        }
+        if constexpr (NP > 0) {
+            double b = init;
+            for (int r0 = 0; r0 < ME; r0 += 8) {
+                double pv[8], uv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int r = (r0 + u < ME) ? r0 + u : 0; pv[u] = jblk[r * NDER + cc.dcol]; uv[u] = us[r]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) b = step(b, pv[u], uv[u], r0 + u < ME);
+            }
+            a = cc.pcol ? b : a;
+        }
+        if constexpr (NG > 0) {
+            double g1 = a;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) g1 = step(g1, bv[NX + g], us[ME + cc.jn * NG + g], true);
+            if constexpr (NP > 0) {
+                double g2 = a;
+                for (int r = 0; r < NG * NNo; ++r) g2 = step(g2, gblk[r * NDER + cc.dcol], us[ME + r], true);
+                a = cc.pcol ? g2 : g1;
             } else a = g1;
         }
         return a;

@@ -11,6 +11,7 @@
 // residuals are evaluated (every check_termination-th iteration).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "../../include/polympc_amd.h"
 
 namespace pmpc {
@@ -632,13 +633,29 @@ __device__ __forceinline__ void big_solve(const double* W, int N, double* v, dou
 // boxADMM::solve_impl (box_admm.hpp:88-205). Result in w.x (n) and w.y (m+n). h/Alb/Aub/xlb/xub may live in LDS or HBM.
 // H(i,j) = H[j*ldh + i], A(r,j) = A[j*lda + r]  (ldh = n, lda = m for plain column-major inputs)
 // BIG: the KKT factor is the tiled HBM workspace of pmpc_qp_big.hpp (blocked LDL^T, MFMA trailing updates) instead of the packed triangle.
-template <bool BIG = false>
+// JV (BIG only): a block-sparse view of A (JViewRT, pmpc_jview.hpp) — the fused SQP kernel's QPs. With it and `condensed` set the linear algebra runs
+// in condensed form: the tiles hold S = H + sigma I + rho_box + A' diag(rho) A (n rows instead of n + m) and every solve is
+//     t = r1 + A'(rho o r2),  x = S^{-1} t,  nu = rho o (A x - r2)
+// with the two products formed from the view (pmpc_qp_big.hpp, big_build_condensed; CPU restatement: PIVOT_CONDENSED).
+struct NoJView {};   // tag: the QP has no structure information (the plain QP entry points)
+constexpr int BIG_COND_MAX_ROWS = 272;   // condensed mode: n and m up to this (the passes of its sparse products are unrolled; 4 x 16 ceil(n / 16) doubles of LDS hold a row panel)
+template <bool BIG = false, class JV = NoJView>
 __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* h,
                                      const double* __restrict__ A, int lda, const double* Alb, const double* Aub, const double* xlb,
                                      const double* xub, const double* x0, const double* y0, const pmpc_qp_settings& s,
-                                     pmpc_qp_info& info, long long* tm = nullptr) {   // tm (phase profiling): [0] build + factor, [1] residuals, [2] substitutions, [3] build alone
+                                     pmpc_qp_info& info, long long* tm = nullptr, const JV& jv = JV(), bool condensed = false) {   // tm (phase profiling): [0] build + factor, [1] residuals, [2] substitutions, [3] build alone
     const int ln = lane_id();
     const int N = n + m;
+    constexpr bool HASJ = BIG && !std::is_same<JV, NoJView>::value;
+    const bool cond = HASJ && condensed;
+    auto build_and_factor = [&](long long* tb) {
+        if constexpr (BIG) {
+            if constexpr (HASJ) {
+                if (cond) { big_build_condensed(w.K, n, m, H, ldh, w.kdiag, w.rho, jv); if (tb) *tb = clock64(); big_factor(w.K, n, w.big_lds); return; }
+            }
+            big_build(w.K, n, m, H, ldh, A, lda, w.kdiag); if (tb) *tb = clock64(); big_factor(w.K, N, w.big_lds);
+        }
+    };
     const bool pivoted = !BIG && __builtin_amdgcn_readfirstlane(s.linear_solver) == 1 && w.trp != nullptr;   // Eigen::LDLT's pivoting (LDS-resident mode only)
     auto tick = [&]() -> long long { return tm ? clock64() : 0; };
     // x = x_guess; y = y_guess; z = A*x_guess; q = x_guess  (:97-100)
@@ -659,9 +676,9 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
     for (int i = ln; i < m; i += WAVE) w.kdiag[n + i] = -w.rhoinv[i];
     wsync();
     { const long long t0 = tick();
-      if constexpr (BIG) big_build(w.K, n, m, H, ldh, A, lda, w.kdiag); else kkt_build(w, n, m, H, ldh, A, lda);
-      const long long t1 = tick();
-      if constexpr (BIG) big_factor(w.K, N, w.big_lds); else { if (pivoted) kkt_factor_pivoted(w, N); else kkt_factor(w, N); }
+      long long t1 = t0;
+      if constexpr (BIG) build_and_factor(tm ? &t1 : nullptr);
+      else { kkt_build(w, n, m, H, ldh, A, lda); t1 = tick(); if (pivoted) kkt_factor_pivoted(w, N); else kkt_factor(w, N); }
       if (tm) { tm[0] += tick() - t0; tm[3] += t1 - t0; } }
 
     int status = PMPC_QP_UNSOLVED;
@@ -674,7 +691,39 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
         for (int i = ln; i < n; i += WAVE) w.rhs[i] = ((s.sigma * w.x[i] - h[i]) + w.rhob[i] * w.q[i]) - w.y[m + i];
         for (int i = ln; i < m; i += WAVE) { w.zprev[i] = w.z[i]; w.rhs[n + i] = w.z[i] - w.rhoinv[i] * w.y[i]; }
         wsync();
-        { const long long t0 = tick(); if constexpr (BIG) big_solve(w.K, N, w.rhs, w.big_lds + 256); else { if (pivoted) kkt_solve_pivoted(w, N, w.rhs); else kkt_solve(w, N, w.rhs); } if (tm) tm[2] += tick() - t0; }
+        { const long long t0 = tick();
+          if constexpr (BIG) {
+              bool done = false;
+              if constexpr (HASJ) {
+                  if (cond) {   // t = r1 + A'(rho o r2) ; x = S^{-1} t ; nu = rho o (A x - r2)   (the scaled r2 in the LDS slots big_solve uses later)
+                      double* u = w.big_lds + 256;
+                      for (int i = ln; i < m; i += WAVE) u[i] = w.rho[i] * w.rhs[n + i];
+                      wsync();
+                      for (int c0 = 0; c0 < n; c0 += WAVE) {
+                          const int c = c0 + ln;
+                          const typename JV::Col cc = jv.column(c < n ? c : 0);
+                          double bv[JV::NCB > 0 ? JV::NCB : 1];
+                          jv.col_block(cc, bv);
+                          const double t = jv.coldot_fma(cc, bv, u, w.rhs[c < n ? c : 0]);
+                          if (c < n) w.rhs[c] = t;
+                      }
+                      wsync();
+                      big_solve(w.K, n, w.rhs, w.big_lds + 256);
+                      for (int r0 = 0; r0 < m; r0 += WAVE) {
+                          const int r = r0 + ln;
+                          const typename JV::Row rw = jv.rowinfo(r < m ? r : 0);
+                          double bv[JV::NDER];
+                          jv.row_block(rw, bv);
+                          const double a = jv.rowdot_fma(rw, bv, w.rhs);
+                          if (r < m) w.rhs[n + r] = w.rho[r] * (a - w.rhs[n + r]);
+                      }
+                      wsync();
+                      done = true;
+                  }
+              }
+              if (!done) big_solve(w.K, N, w.rhs, w.big_lds + 256);
+          } else { if (pivoted) kkt_solve_pivoted(w, N, w.rhs); else kkt_solve(w, N, w.rhs); }
+          if (tm) tm[2] += tick() - t0; }
         for (int i = ln; i < m; i += WAVE) {
             const double zt = w.zprev[i] + w.rhoinv[i] * (w.rhs[n + i] - w.y[i]);
             double zz = alpha * zt;
@@ -719,7 +768,7 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
                 for (int i = ln; i < n; i += WAVE) w.kdiag[i] += (w.rhob[i] - w.t2[i]);
                 for (int i = ln; i < m; i += WAVE) w.kdiag[n + i] = -w.rhoinv[i];
                 wsync();
-                if constexpr (BIG) { big_build(w.K, n, m, H, ldh, A, lda, w.kdiag); big_factor(w.K, N, w.big_lds); }
+                if constexpr (BIG) build_and_factor(nullptr);
                 else { kkt_build(w, n, m, H, ldh, A, lda); if (pivoted) kkt_factor_pivoted(w, N); else kkt_factor(w, N); }
             }
         }

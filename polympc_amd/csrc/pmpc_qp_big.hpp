@@ -102,6 +102,79 @@ __device__ __forceinline__ void big_build(double* W, int n, int m, const double*
     wsync();
 }
 
+// Condensed mode (round 3): the constraint block of K is diagonal (-1 / rho), so it is eliminated in closed form and the tiles hold the n x n SPD matrix
+//     S = H + diag(kdiag[0:n]) + A' diag(rho) A          (x = S^{-1} (r1 + A'(rho o r2)),  nu = rho o (A x - r2): boxadmm_solve)
+// instead of the (n + m) x (n + m) KKT matrix — config C: 256 rows instead of 464, a factor of 262 KB instead of 861 KB streamed twice per ADMM
+// iteration, a sixth of the factorisation's flops. A' diag(rho) A is a rank-m update on the matrix cores: per block column of S the accumulator tiles
+// start from H (+ diagonal) and take, for the constraint rows r in groups of four (ascending — the k-ascending fma chain of v_mfma_f64_16x16x4_f64),
+// A operand rho_r J(r, i), B operand J(r, j); the operands are evaluated from the block-sparse view of J (per-node blocks + differentiation
+// matrix), the dense J is never read. Restated by the oracle as PIVOT_CONDENSED (oracle/qp.hpp).
+template <class JV>
+__device__ __forceinline__ void big_build_condensed(double* W, int n, int m, const double* __restrict__ H, int ldh, const double* kdiag,
+                                                    const double* rho, const JV& jv) {
+    const int ln = lane_id();
+    const int nb = BigKkt::nblk(n);
+    const int lr = ln >> 4, lc = ln & 15;
+    constexpr int GI = 16;   // tile rows per pass (128 accumulator registers: one pass per block column up to 256 rows)
+    for (int Jc = 0; Jc < nb; ++Jc) {
+        const int j = 16 * Jc + lc;
+        const typename JV::Col cj = jv.column(j < n ? j : 0);
+        for (int I0 = Jc; I0 < nb; I0 += GI) {
+            big_d4 T[GI];
+            typename JV::Col ci[GI];
+#pragma unroll
+            for (int g = 0; g < GI; ++g) {
+                const int I = (I0 + g < nb) ? I0 + g : nb - 1;   // (a group's missing tiles repeat its last one; their result is dropped)
+                const int ic = 16 * I + lc;
+                ci[g] = jv.column(ic < n ? ic : 0);
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int i = 16 * I + 4 * rg + lr;
+                    const bool in = i < n && j < n;
+                    const double hv = H[(size_t)(in ? j : 0) * ldh + (in ? i : 0)];
+                    const double kd = (i < n) ? kdiag[i < n ? i : 0] : 1.0;
+                    T[g][rg] = (i == j) ? kd : (in ? hv : 0.0);
+                }
+            }
+            for (int r0 = 0; r0 < m; r0 += 4) {
+                const int r = r0 + lr;
+                const bool rin = r < m;
+                const int rc = rin ? r : 0;
+                const typename JV::Row rw = jv.rowinfo(rc);
+                // a group of four constraint rows without an entry in this block column leaves every tile of the pass unchanged (fma(a, 0, c) = c):
+                // most of them — a row touches the state columns of its own segment and its own node's block only. Decided from the structure
+                // alone (no load), so that skipped groups cost a few integer operations
+                if (__builtin_amdgcn_ballot_w64(rin && j < n && jv.structural(rw, cj)) == 0) continue;
+                const double bvv = jv.jval(rw, cj);
+                const double bop = (rin && j < n) ? bvv : 0.0;
+                const double rr = rho[rc];
+                double aop[GI];
+#pragma unroll
+                for (int g = 0; g < GI; ++g) {
+                    const int I = (I0 + g < nb) ? I0 + g : nb - 1;
+                    const int i = 16 * I + lc;
+                    const double av = jv.jval(rw, ci[g]);
+                    aop[g] = (rin && i < n) ? rr * av : 0.0;
+                }
+#pragma unroll
+                for (int g = 0; g < GI; ++g)
+                    if (__builtin_amdgcn_ballot_w64(aop[g] != 0.0) != 0) T[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[g], bop, T[g], 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < GI; ++g) {
+                const int I = I0 + g;
+                if (I < nb) {
+                    double* tt = W + (size_t)BigKkt::tidx(I, Jc) * 256;
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) tt[64 * rg + ln] = T[g][rg];
+                }
+            }
+        }
+    }
+    wfence();
+    wsync();
+}
+
 // in-place blocked LDL^T of the tiles in W (see the header). dl: BigKkt::LDS_DOUBLES doubles of LDS.
 // LEFT-LOOKING schedule, two block columns at a time: block columns J and J + 1 first receive the rank-16 updates of ALL earlier block columns k < J
 // together (accumulator tiles of both columns stay in registers while k runs: per k and group of four tile rows, four A operand tiles from the CF

@@ -843,6 +843,13 @@ struct SqpDevice {
             if (RUIZ_COMPILED && __builtin_amdgcn_readfirstlane(ss.qp_solver) == 1) admm_solve(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi);
             else {
                 long long tq[4] = {0, 0, 0, 0};
+                if constexpr (BIG) {
+                    // large instances: condensed linear algebra from the block-sparse view of J (n instead of n + m rows) — unless the Ruiz preconditioner
+                    // rescaled the workspace, whose entries the per-node blocks of the view then no longer are
+                    const JViewRT<Model> jvr{ocp.Dlds, ocp.s.nsr, ocp.jblk, ocp.gblk, ocp.P, ocp.dm.NN, ocp.dm.VARX, ocp.dm.VARU, ocp.dm.me};
+                    boxadmm_solve<true, JViewRT<Model>>(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, PROF ? tq : nullptr, jvr,
+                                                        ocp.keep_blk && !ruiz && n <= BIG_COND_MAX_ROWS && m <= BIG_COND_MAX_ROWS && __builtin_amdgcn_readfirstlane(ss.kkt_form) == 0);
+                } else
                 boxadmm_solve<BIG>(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, PROF ? tq : nullptr);
                 acc(6, tq[0]); acc(7, tq[1]); acc(17, tq[2]); acc(16, tq[3]);   // (slots 16 / 17 double as "KKT build" / "substitutions" on the LDS path)
             }

@@ -33,12 +33,16 @@ BIG_KKT_MIN_ROWS = 96   # pmpc_launch.hpp: from this many KKT rows the fused SQP
 QP_BIG_MIN_ROWS = 112   # pmpc_api.hip: the QP entry point's threshold for the same kernel family
 
 
-def _lds_order(oracle, rows, qp_entry=False):
+def _lds_order(oracle, rows, qp_entry=False, ruiz=False, kkt_form=0):
     """The LDS-resident kernels (boxADMM above 64 KKT rows without a register specialisation, every policy the register paths do not carry, the
     stacked system of the OSQP-form ADMM): static right-looking LDL^T with fma substitutions (PIVOT_STATIC). Larger systems — 96 rows and more in the
     fused SQP kernel, 112 and more at the QP entry point, and everything whose packed triangle does not fit LDS (config C) — run the blocked tile
-    LDL^T with the factor in HBM: same factor and forward pass, backward pass by column dot products (PIVOT_BLOCKED)."""
-    return oracle.PIVOT_BLOCKED if rows >= (QP_BIG_MIN_ROWS if qp_entry else BIG_KKT_MIN_ROWS) else oracle.PIVOT_STATIC
+    LDL^T with the factor in HBM: same factor and forward pass, backward pass by column dot products (PIVOT_BLOCKED). Inside the fused SQP kernel
+    that kernel works in condensed form since round 3 — the n x n matrix H + sigma I + rho_box + A' diag(rho) A in the same blocked order
+    (PIVOT_CONDENSED) — unless the Ruiz preconditioner rescaled the workspace or pmpc_sqp_settings::kkt_form = 1 asks for the full KKT matrix."""
+    if rows >= (QP_BIG_MIN_ROWS if qp_entry else BIG_KKT_MIN_ROWS):
+        return oracle.PIVOT_BLOCKED if (qp_entry or ruiz or kkt_form == 1) else oracle.PIVOT_CONDENSED
+    return oracle.PIVOT_STATIC
 
 
 REG2_QP_SHAPES = ((66, 44), (55, 33), (45, 27), (50, 30), (60, 36), (65, 39), (54, 36), (60, 40), (80, 48), (75, 45), (72, 48))
@@ -504,7 +508,7 @@ def _sqp_both(ctx, oracle, wl, B, **kw):
     # (preconditioner = 1, qp_solver = 1 and line_search = 1 are served by the LDS-resident QP kernels whatever the size: static LDL^T
     #  order; hessian_update = 1 has register-resident specialisations like the default)
     if kw.get("qp_solver", 0): order = oracle.PIVOT_STATIC
-    elif kw.get("preconditioner", 0) or kw.get("line_search", 0): order = _lds_order(oracle, dm["n"] + dm["m"])
+    elif kw.get("preconditioner", 0) or kw.get("line_search", 0): order = _lds_order(oracle, dm["n"] + dm["m"], ruiz=bool(kw.get("preconditioner", 0)))
     else: order = _gpu_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, block_bfgs=bool(kw.get("hessian_update", 0)))
     xo, lo, io = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"],
                                         sqp_settings=oss, pivot=order, threads=8)
@@ -858,9 +862,14 @@ def test_sqp_builtin_models_on_the_hbm_factor_kernel(ctx, oracle, case):
     dm = oracle.ocp_dims(model, P, S)
     assert dm["n"] + dm["m"] >= BIG_KKT_MIN_ROWS
     x, lam, info = ctx.sqp_solve_batch(model, P, S, t0, tf, B, d, lbx, ubx, sqp_settings=ss, **kw)
-    xo, lo, io = oracle.sqp_solve_batch(model, P, S, t0, tf, B, d, lbx, ubx, sqp_settings=oss, pivot=oracle.PIVOT_BLOCKED, **okw)
+    xo, lo, io = oracle.sqp_solve_batch(model, P, S, t0, tf, B, d, lbx, ubx, sqp_settings=oss, pivot=_lds_order(oracle, dm["n"] + dm["m"], ruiz=(case == "robot_13_nodes_ruiz")), **okw)
     _assert_same_solve(info, io, x, xo, lam, lo)
     assert np.all(info["flags"] == 0)
+    if case != "robot_13_nodes_ruiz":   # the same instances with the full KKT matrix (kkt_form = 1): the blocked order of round 2
+        ss.kkt_form = 1
+        x, lam, info = ctx.sqp_solve_batch(model, P, S, t0, tf, B, d, lbx, ubx, sqp_settings=ss, **kw)
+        xo, lo, io = oracle.sqp_solve_batch(model, P, S, t0, tf, B, d, lbx, ubx, sqp_settings=oss, pivot=oracle.PIVOT_BLOCKED, **okw)
+        _assert_same_solve(info, io, x, xo, lam, lo)
 
 
 @pytest.mark.parametrize("P,S,B", [(6, 1, 64), (5, 2, 16), (5, 3, 6)])

@@ -28,7 +28,7 @@ def config_workload(cfg, B=None, full=False):
     if cfg == "B":
         return workloads.cstr_batch(B or (16384 if full else 2048)), "PIVOT_SWEEP2"
     if cfg == "C":
-        return workloads.kite_standin_batch(B or (1024 if full else 64)), "PIVOT_BLOCKED"
+        return workloads.kite_standin_batch(B or (1024 if full else 64)), "PIVOT_CONDENSED"
     if cfg == "R":
         return workloads.robot_batch(B or 2048, P=5, S=3), None   # order decided by the route table (see kernel_order_R)
     raise ValueError(cfg)
@@ -51,7 +51,7 @@ def kernel_order(ob, cfg, wl):
         return ob.PIVOT_SWEEP
     if rows <= ob.SWEEP2_MAX_ROWS:
         return ob.PIVOT_SWEEP2
-    return ob.PIVOT_BLOCKED
+    return ob.PIVOT_CONDENSED   # the large-instance kernel inside the fused SQP kernel: condensed form since round 3
 
 
 def main():

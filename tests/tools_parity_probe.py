@@ -21,13 +21,13 @@ def order_for(n, m, nodes, kw):
     if kw.get("qp_solver", 0):
         return ob.PIVOT_STATIC
     if kw.get("preconditioner", 0) or kw.get("line_search", 0):
-        return ob.PIVOT_BLOCKED if n + m >= 96 else ob.PIVOT_STATIC
+        return (ob.PIVOT_BLOCKED if kw.get("preconditioner", 0) else ob.PIVOT_CONDENSED) if n + m >= 96 else ob.PIVOT_STATIC
     reg = (3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16)
     if n + m <= 64 and nodes in ((5, 7) if kw.get("hessian_update", 0) else reg):
         return ob.PIVOT_SWEEP
     if 64 < n + m <= 128 and nodes in reg:
         return ob.PIVOT_SWEEP2
-    return ob.PIVOT_BLOCKED if n + m >= 96 else ob.PIVOT_STATIC
+    return ob.PIVOT_CONDENSED if n + m >= 96 else ob.PIVOT_STATIC
 
 
 def probe(ctx, name, wl, B, **kw):

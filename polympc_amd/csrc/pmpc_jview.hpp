@@ -175,7 +175,7 @@ struct JView {
 // The same view for a run-time node count and any memory (the large-instance kernel keeps the blocks and the collocation constants in its HBM
 // scratch): the entry J(r, c) itself — the operands of the matrix-core product A' diag(rho) A — and the two sparse products of the condensed
 // linear solve (pmpc_qp_big.hpp), which are fma chains over the entries that are not exactly zero, rows / columns ascending: the restatement
-// (oracle/qp.hpp, PIVOT_CONDENSED) walks the dense matrix and skips its zeros, so structural zeros and numerical zeros are the same statement on
+// (the CPU restatement of the test suite, policy PIVOT_CONDENSED) walks the dense matrix and skips its zeros, so structural zeros and numerical zeros are the same statement on
 // both sides, whatever the operand.
 template <class Model>
 struct JViewRT {

@@ -108,7 +108,7 @@ __device__ __forceinline__ void big_build(double* W, int n, int m, const double*
 // iteration, a sixth of the factorisation's flops. A' diag(rho) A is a rank-m update on the matrix cores: per block column of S the accumulator tiles
 // start from H (+ diagonal) and take, for the constraint rows r in groups of four (ascending — the k-ascending fma chain of v_mfma_f64_16x16x4_f64),
 // A operand rho_r J(r, i), B operand J(r, j); the operands are evaluated from the block-sparse view of J (per-node blocks + differentiation
-// matrix), the dense J is never read. Restated by the oracle as PIVOT_CONDENSED (oracle/qp.hpp).
+// matrix), the dense J is never read. Restated on the CPU by the test suite as PIVOT_CONDENSED.
 template <class JV>
 __device__ __forceinline__ void big_build_condensed(double* W, int n, int m, const double* __restrict__ H, int ldh, const double* kdiag,
                                                     const double* rho, const JV& jv) {

@@ -44,7 +44,7 @@ template <class Model> __host__ __device__ inline size_t big_scratch_doubles(int
 // KHBM: large-instance mode of the LDS-resident kernels — the KKT factor lives in an HBM workspace (Kws). A compile-time flag so
 // that in the normal mode every QP pointer provably addresses LDS (ds_read / ds_write instead of flat accesses, which cost the
 // LDS path most of its time when the location of K was a run-time choice)
-template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bool KHBM = false, bool W2 = false>   // W2: the HBM-factor kernel compiled for two wavefronts per SIMD (256 registers)
+template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bool KHBM = false, bool W2 = false, bool POL = false>   // W2: the HBM-factor kernel compiled for two wavefronts per SIMD (256 registers); POL: register-resident kernel with the Ruiz / filter-line-search hooks compiled in
 #ifndef PMPC_SQP_WAVES
 #define PMPC_SQP_WAVES 2
 #endif
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
     for (int i = ln; i < Model::ND; i += WAVE) dL[i] = d[(size_t)b * Model::ND + i];
     ocp.d = dL;
     double* filt = nullptr;   // LSFilter of this instance (line_search = 1; the register-resident specialisations do not carry it)
-    if constexpr (NN == 0) {
+    if constexpr (NN == 0 || POL) {
         filt = p; p += FILTER_LDS_DOUBLES;
         const bool carried = ss.line_search == 1 && ss.filter_state != nullptr;
         if (ln < PMPC_FILTER_STATE_DOUBLES) filt[ln] = carried ? ss.filter_state[(size_t)b * PMPC_FILTER_STATE_DOUBLES + ln] : 0.0;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
     // stacked workspace K0 = [H ; J] ((n+m) x n, column-major, leading dimension n+m): lane i reads row i of K0 with ONE stride
     double* K0 = Hws + (size_t)b * (size_t)(n + m) * n;
     (void)Aws;
-    SqpDevice<Model, NN, MM, PROF, HU, KHBM> sqp(ocp, v, qw, K0, K0 + n, ss, qs);
+    SqpDevice<Model, NN, MM, PROF, HU, KHBM, POL> sqp(ocp, v, qw, K0, K0 + n, ss, qs);
     sqp.filt = filt;
     sqp.eig = eigw;
     sqp.trace = ss.iteration_trace ? ss.iteration_trace + (size_t)b * (size_t)ss.iteration_trace_capacity * PMPC_TRACE_DOUBLES : nullptr;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
     for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = v.x[i];
     for (int i = ln; i < m + n; i += WAVE) lam[(size_t)b * (m + n) + i] = v.lam[i];
     if (ln == 0) info[b] = si;
-    if constexpr (NN == 0) {
+    if constexpr (NN == 0 || POL) {
         if (ss.line_search == 1 && ss.filter_state != nullptr && ln < PMPC_FILTER_STATE_DOUBLES) ss.filter_state[(size_t)b * PMPC_FILTER_STATE_DOUBLES + ln] = filt[ln];
     }
     if constexpr (PROF) { if (phase_cycles && ln == 0) for (int i = 0; i < 24; ++i) atomicAdd(&phase_cycles[i], (unsigned long long)sqp.cyc[i]); }
@@ -347,7 +347,7 @@ template <class Model> inline size_t sqp_eig_lds_bytes(int P, int S, const pmpc_
     OcpDims<Model> dm(P, S);
     return ss->regularisation == 1 ? 2 * (size_t)dm.n * dm.n * sizeof(double) : 0;
 }
-template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode, int qp_solver = 0) {
+template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode, int qp_solver = 0, bool pol = false) {
     OcpDims<Model> dm(P, S);
     if (mode == 0 && qp_solver == 1)
         return (QpLds::doubles(dm.n, dm.m + dm.n) + SqpLds::doubles(dm.n, dm.m, dm.mi) + OcpLds<Model>::doubles(P, S) + 8 + FILTER_LDS_DOUBLES) * sizeof(double);
@@ -358,7 +358,7 @@ template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode
     if (mode == 3) { const size_t need = (size_t)RegKkt2<112>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
     if (mode == 4) { const size_t need = (size_t)RegKkt2<128>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }   // 113..128 rows: LDS-resident operand tiles
     return ((mode == 0 ? QpLds::doubles(dm.n, dm.m) : QpLds::doubles_xy(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8 +
-            ((mode == 1 || mode == 3 || mode == 4) ? jview_doubles<Model>(dm.NN) : FILTER_LDS_DOUBLES) + (mode == 2 ? BigKkt::LDS_DOUBLES : 0)) * sizeof(double);
+            ((mode == 1 || mode == 3 || mode == 4) ? jview_doubles<Model>(dm.NN) + (pol ? FILTER_LDS_DOUBLES : 0) : FILTER_LDS_DOUBLES) + (mode == 2 ? BigKkt::LDS_DOUBLES : 0)) * sizeof(double);
 }
 constexpr int BIG_TWO_WAVES_MAX_ROWS = 200;   // below: two wavefronts per SIMD on the HBM-factor kernel when the batch exceeds the SIMD count (see sqp_launch_dev)
 constexpr int BIG_KKT_MIN_ROWS = 96;   // n + m from which sqp_launch_dev prefers the HBM-factor kernel (see there)
@@ -436,9 +436,14 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
                            double* slice_state, int slice_iters) {
     constexpr int NN_ = (Model::NX + Model::NU) * NNODES + Model::NP;
     constexpr int MM_ = (Model::NX + Model::NG) * NNODES;
+    // the policy hooks the reference's tests install beside the defaults — Ruiz preconditioner, filter line search — exist on the register paths
+    // for the grids of its own tests (7 and 11 nodes) as separate kernels (POL); any other grid takes the LDS / HBM-resident kernels for them
+    const bool pol = ss->preconditioner == 1 || ss->line_search == 1;
+    constexpr bool POLK = !LEAN && (NNODES == 7 || NNODES == 11) && (int)OcpDims<Model>::NDER <= RUIZ_MAX_NDER;
+    if (pol && !POLK) return false;
     if constexpr (NN_ + MM_ <= WAVE) {
         if (P * S + 1 != NNODES) return false;
-        const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, 1);
+        const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, 1, 0, pol);
         if (ldsr > lds_limit) return false;
         if (LEAN && (ss->hessian_update == 1 || phase)) return false;
         pmpc_internal_set_route(ctx, PMPC_ROUTE_REG1);
@@ -446,6 +451,7 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
         if constexpr (!LEAN)
             kern = (ss->hessian_update == 1) ? sqp_kernel<Model, NN_, MM_, false, 1>   // (no phase timers in the block-BFGS specialisation)
                                              : (phase ? sqp_kernel<Model, NN_, MM_, true> : sqp_kernel<Model, NN_, MM_, false>);
+        if constexpr (POLK) { if (pol) kern = (ss->hessian_update == 1) ? sqp_kernel<Model, NN_, MM_, false, 1, false, false, true> : sqp_kernel<Model, NN_, MM_, false, 0, false, false, true>; }
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
         const int slice = (slice_state && slice_iters > 0) ? slice_iters : ss->max_iter;
         if constexpr (!LEAN) {
@@ -456,7 +462,7 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
 #else
             const bool rr_phase_ok = !phase;
 #endif
-            if (slice_state && slice_iters == 0 && rr_phase_ok && ss->max_iter > 1 && ss->max_iter <= RR_MAX_ITER && B > slots && B <= RR_MAX_BATCH && (size_t)B * ss->max_iter < ((size_t)1 << 30) && pmpc_internal_sqp_rr(ctx)) {
+            if (!pol && slice_state && slice_iters == 0 && rr_phase_ok && ss->max_iter > 1 && ss->max_iter <= RR_MAX_ITER && B > slots && B <= RR_MAX_BATCH && (size_t)B * ss->max_iter < ((size_t)1 << 30) && pmpc_internal_sqp_rr(ctx)) {
                 auto rrk = (ss->hessian_update == 1) ? sqp_kernel_rr<Model, NN_, MM_, 1> : sqp_kernel_rr<Model, NN_, MM_, 0>;
                 if (hipFuncSetAttribute((const void*)rrk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
                 int* queue = (int*)(slice_state + (size_t)B * 2 * NN_);   // behind the slice state (sqp_launch_dev sizes the workspace for it)
@@ -478,12 +484,13 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
         return true;
     } else if constexpr (NN_ + MM_ <= 128) {   // two KKT rows per lane (pmpc_qp_reg2.hpp); the Hessian-update policy is a run-time choice there
         if (P * S + 1 != NNODES) return false;
-        const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, NN_ + MM_ <= 112 ? 3 : 4);
+        const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, NN_ + MM_ <= 112 ? 3 : 4, 0, pol);
         if (ldsr > lds_limit) return false;
         pmpc_internal_set_route(ctx, PMPC_ROUTE_REG2);
         auto kern = sqp_kernel<Model, NN_, MM_, false>;
         bool timed = false;
-        if constexpr (LDS_PATH_PROFILED<Model>::value && !LEAN) { if (phase) { kern = sqp_kernel<Model, NN_, MM_, true>; timed = true; } }   // developer builds with phase timers
+        if constexpr (LDS_PATH_PROFILED<Model>::value && !LEAN) { if (phase && !pol) { kern = sqp_kernel<Model, NN_, MM_, true>; timed = true; } }   // developer builds with phase timers
+        if constexpr (POLK) { if (pol) kern = sqp_kernel<Model, NN_, MM_, false, 0, false, false, true>; }
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
         const int slice = (slice_state && slice_iters > 0) ? slice_iters : ss->max_iter;
         for (int it = 0; it < ss->max_iter; it += slice)
@@ -536,7 +543,7 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     if ((ss->line_search != 0 && ss->line_search != 1) ||
         (ss->line_search == 1 && (ss->filter_max_depth < 1 || ss->filter_max_depth > PMPC_FILTER_MAX_DEPTH))) return PMPC_ERR_INVALID_ARGUMENT;
     if (qs->linear_solver != 0 && qs->linear_solver != 1) return PMPC_ERR_INVALID_ARGUMENT;
-    if (!force_lds && ss->preconditioner == 0 && ss->qp_solver == 0 && ss->line_search == 0 && ss->regularisation != 1 && qs->linear_solver == 0) {   // node counts whose KKT system can fit 64 rows for small models (7 nodes: config A / D); Ruiz: LDS path
+    if (!force_lds && ss->qp_solver == 0 && ss->regularisation != 1 && qs->linear_solver == 0) {   // (preconditioner / line_search = 1: the 7- and 11-node register kernels carry them, see try_launch_reg)   // node counts whose KKT system can fit 64 rows for small models (7 nodes: config A / D); Ruiz: LDS path
         pmpc_status rst = PMPC_OK;
         if (try_launch_reg<Model, 7>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;
         if (try_launch_reg<Model, 5>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;

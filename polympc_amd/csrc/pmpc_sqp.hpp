@@ -46,12 +46,16 @@ constexpr int PMPC_SQP_IN_PROGRESS = 3;   // internal: the instance continues in
 // HU: Hessian-update policy compiled into a register-resident specialisation (0 dense damped BFGS, 1 block BFGS); the LDS-resident
 // kernels (NN == 0) select it at run time from settings.hessian_update
 // BIG: large-instance mode — the KKT factor is the tiled HBM workspace of pmpc_qp_big.hpp
-template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bool BIG = false>
+// POL: register-resident specialisation that carries the policy hooks the reference's tests install beside the default ones — the Ruiz
+//      preconditioner (qp_preconditioners.hpp:114-220) and the filter line search (line_search.hpp:31-98); the LDS / HBM-resident kernels (NN == 0)
+//      always carry them. A separate instantiation: the default register kernels stay free of the (cold) calls and their spills.
+template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bool BIG = false, bool POL = false>
 struct SqpDevice {
+    static constexpr bool HOOKS = (NN == 0) || POL;
     using Dm = OcpDims<Model>;
     // Ruiz scaling is compiled into the LDS / HBM-resident QP kernels only: the launcher routes preconditioner = 1 there. In the
     // register-resident kernels its three (cold, out-of-line) calls cost private-memory frames and call-ABI spills on the hot path.
-    static constexpr bool RUIZ_COMPILED = (NN == 0) && (int)Dm::NDER <= RUIZ_MAX_NDER;
+    static constexpr bool RUIZ_COMPILED = HOOKS && (int)Dm::NDER <= RUIZ_MAX_NDER;
     static constexpr bool REG1 = NN > 0 && NN + MM <= WAVE;    // one KKT row per lane
     static constexpr bool REG2 = NN > 0 && NN + MM > WAVE;     // two KKT rows per lane
     Ocp<Model>& ocp;
@@ -123,7 +127,7 @@ struct SqpDevice {
     // filt = [count, (cost, constraint violation) pairs, newest first] in LDS. Every lane evaluates the same acceptance test on the
     // same values; lane 0 alone edits the list. Compiled into the LDS-resident kernels only (the launcher routes line_search = 1 there).
     double* filt = nullptr;
-    __device__ __forceinline__ bool filter_mode() const { if constexpr (NN == 0) return __builtin_amdgcn_readfirstlane(ss.line_search) == 1; else return false; }
+    __device__ __forceinline__ bool filter_mode() const { if constexpr (HOOKS) return __builtin_amdgcn_readfirstlane(ss.line_search) == 1; else return false; }
     __device__ __forceinline__ bool filter_is_acceptable(double cost, double constraint) const {   // :65-74
         int cnt = (int)filt[0];
         if (cnt > PMPC_FILTER_MAX_DEPTH) cnt = PMPC_FILTER_MAX_DEPTH;
@@ -168,7 +172,7 @@ struct SqpDevice {
         const double phi_l1 = cost_1 + mu * constr_l1;
         const double Dp_phi_l1 = seq_dot(v.h, p, n) - mu * constr_l1;
         const bool fmode = filter_mode();
-        if constexpr (NN == 0) { if (fmode && filter_is_acceptable(cost_1, constr_l1)) filter_add(cost_1, constr_l1); }
+        if constexpr (HOOKS) { if (fmode && filter_is_acceptable(cost_1, constr_l1)) filter_add(cost_1, constr_l1); }
         double alpha = 1.0;
         cb_valid = false;
         for (int i = 1; i < ss.line_search_max_iter; ++i) {
@@ -177,7 +181,7 @@ struct SqpDevice {
             const double cost_step = ocp.cost(v.xs);
             cost_log = cost_step;
             const double constr_step = constraints_violation(v.xs);
-            if constexpr (NN == 0) {
+            if constexpr (HOOKS) {
                 if (fmode) {
                     if (filter_is_acceptable(cost_step, constr_step)) { filter_add(cost_step, constr_step); cb_valid = true; return alpha; }
                     alpha = ss.tau * alpha;
@@ -354,7 +358,7 @@ struct SqpDevice {
                 const double constr_l1 = cand_viol[0];
                 phi_l1 = cand_cost[0] + mu * constr_l1;
                 Dp_phi_l1 = gp - mu * constr_l1;
-                if constexpr (NN == 0) { if (fmode && filter_is_acceptable(cand_cost[0], constr_l1)) filter_add(cand_cost[0], constr_l1); }
+                if constexpr (HOOKS) { if (fmode && filter_is_acceptable(cand_cost[0], constr_l1)) filter_add(cand_cost[0], constr_l1); }
             }
             int accepted = -1;
             for (int gc = base; gc < ncand; ++gc) {   // the reference's sequential acceptance order
@@ -362,7 +366,7 @@ struct SqpDevice {
                 const double cost_step = cand_cost[gc];
                 cost_log = cost_step;
                 bool ok;
-                if constexpr (NN == 0) {
+                if constexpr (HOOKS) {
                     if (fmode) { ok = filter_is_acceptable(cost_step, cand_viol[gc]); if (ok) filter_add(cost_step, cand_viol[gc]); }
                     else ok = __builtin_amdgcn_readfirstlane((int)((cost_step + mu * cand_viol[gc]) <= (phi_l1 + ag * ss.eta * Dp_phi_l1))) != 0;
                 } else {
@@ -835,9 +839,11 @@ struct SqpDevice {
         }
         // 7-argument form: zero guesses (Q2)
         if constexpr (REG2) {   // (lower-triangle read of H always: the Hessian update is a run-time choice in these kernels)
-            boxadmm_solve_reg2<NN, MM, true, true>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr, jview());
+            // (POL: the Ruiz preconditioner may have rescaled the workspace, whose entries the blocks of the sparse view then no longer are: dense residuals)
+            if constexpr (POL) boxadmm_solve_reg2<NN, MM, true, true>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr);
+            else boxadmm_solve_reg2<NN, MM, true, true>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr, jview());
             wsync();
-        } else if constexpr (REG1) { boxadmm_solve_reg<NN, MM, true, HU == 1>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr); wsync(); }
+        } else if constexpr (REG1) { boxadmm_solve_reg<NN, MM, true, (HU == 1) || POL>(   /* lower-triangle read of H: the block BFGS and a Ruiz-scaled H (D_i H_ij D_j) are not bitwise symmetric */ Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr); wsync(); }
         else {
             // Solver<Problem, ADMM<...>>: the launcher sized the QP's LDS for the stacked (2n+m)-row system when qp_solver = 1
             if (RUIZ_COMPILED && __builtin_amdgcn_readfirstlane(ss.qp_solver) == 1) admm_solve(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi);

@@ -69,6 +69,17 @@ def _gpu_order(oracle, n, m, nodes=None, block_bfgs=False):
     return _lds_order(oracle, n + m)
 
 
+POLICY_REG_NODE_COUNTS = (7, 11)   # grids whose register-resident kernels exist with the Ruiz / filter-line-search hooks compiled in (pmpc_launch.hpp, POL)
+
+
+def _policy_order(oracle, n, m, nodes, ruiz=False, block_bfgs=False):
+    """preconditioner = 1 / line_search = 1: on the grids of the reference's own tests (7 and 11 nodes) the register-resident kernels carry these hooks
+    since round 3 (their sweep orders); every other grid takes the LDS / HBM-resident kernels for them."""
+    if nodes in POLICY_REG_NODE_COUNTS and n + m <= 112:
+        return oracle.PIVOT_SWEEP if n + m <= 64 else oracle.PIVOT_SWEEP2
+    return _lds_order(oracle, n + m, ruiz=ruiz)
+
+
 def _qp_oracle(oracle, q, s, x0=None, y0=None):
     os_ = oracle.qp_default_settings()
     for f, _ in s._fields_:
@@ -508,7 +519,7 @@ def _sqp_both(ctx, oracle, wl, B, **kw):
     # (preconditioner = 1, qp_solver = 1 and line_search = 1 are served by the LDS-resident QP kernels whatever the size: static LDL^T
     #  order; hessian_update = 1 has register-resident specialisations like the default)
     if kw.get("qp_solver", 0): order = oracle.PIVOT_STATIC
-    elif kw.get("preconditioner", 0) or kw.get("line_search", 0): order = _lds_order(oracle, dm["n"] + dm["m"], ruiz=bool(kw.get("preconditioner", 0)))
+    elif kw.get("preconditioner", 0) or kw.get("line_search", 0): order = _policy_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, ruiz=bool(kw.get("preconditioner", 0)), block_bfgs=bool(kw.get("hessian_update", 0)))
     else: order = _gpu_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, block_bfgs=bool(kw.get("hessian_update", 0)))
     xo, lo, io = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"],
                                         sqp_settings=oss, pivot=order, threads=8)
@@ -628,7 +639,7 @@ def test_sqp_valet_parking_with_ruiz(ctx, oracle):
         xg, lg, info = ctx.sqp_solve_batch(pa.MODEL_ROBOT, 5, 2, 0.0, 2.0, 1, [[2.0]], lbx, ubx, x_guess=xg, lam_guess=lg, sqp_settings=ss,
                                            qp_settings=qs, mparams=[1.0])
         xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 2.0, 1, [[2.0]], lbx, ubx, x_guess=xo, lam_guess=lo, sqp_settings=oss,
-                                            qp_settings=oqs, pivot=oracle.PIVOT_STATIC, mparams=[1.0])
+                                            qp_settings=oqs, pivot=_policy_order(oracle, 55, 33, 11, ruiz=True), mparams=[1.0])
         assert info["status"][0] == pa.SQP_SOLVED and info["iter"][0] < 10
         _assert_same_solve(info, io, xg, xo, lg, lo)
 
@@ -654,7 +665,7 @@ def test_sqp_valet_parking_as_the_reference_runs_it(ctx, oracle):
             xg, lg, info = ctx.sqp_solve_batch(pa.MODEL_ROBOT, 5, 2, 0.0, 2.0, 1, [[2.0]], lbx, ubx, x_guess=xg, lam_guess=lg, sqp_settings=ss,
                                                qp_settings=qs, mparams=[1.0])
             xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 2.0, 1, [[2.0]], lbx, ubx, x_guess=xo, lam_guess=lo, sqp_settings=oss,
-                                                qp_settings=oqs, pivot=oracle.PIVOT_STATIC, mparams=[1.0])
+                                                qp_settings=oqs, pivot=_policy_order(oracle, 55, 33, 11, ruiz=True, block_bfgs=True), mparams=[1.0])
             assert info["status"][0] == pa.SQP_SOLVED and info["iter"][0] < 10
             _assert_same_solve(info, io, xg, xo, lg, lo)
             filt = ctx.filter_state_download(1, handle)
@@ -666,7 +677,7 @@ def test_sqp_valet_parking_as_the_reference_runs_it(ctx, oracle):
 
 
 def test_sqp_filter_line_search_batch_vs_oracle(ctx, oracle):
-    """line_search = 1 on batches of randomised robot OCPs (P=5 S=3: 128 KKT rows, HBM-factor kernel; config A's grid on the LDS-resident path), with and
+    """line_search = 1 on batches of randomised robot OCPs (P=5 S=3: 128 KKT rows, HBM-factor kernel; config A's grid and the 11-node grid on the register-resident kernels that carry the hook since round 3), with and
     without a carried filter: identical iteration counts, bit-identical x, lam and filter contents; a second solve from the
     first one's solution with the carried filter must again agree (the filter then holds the first solve's history)."""
     import polympc_amd as pa
@@ -684,7 +695,7 @@ def test_sqp_filter_line_search_batch_vs_oracle(ctx, oracle):
             for rep in range(2):
                 xg, lg, info = ctx.sqp_solve_batch(pa.MODEL_ROBOT, P, S, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], x_guess=xg, lam_guess=lg, sqp_settings=ss)
                 xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, P, S, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], x_guess=xo, lam_guess=lo,
-                                                    sqp_settings=oss, pivot=_lds_order(oracle, dm["n"] + dm["m"]))
+                                                    sqp_settings=oss, pivot=_policy_order(oracle, dm["n"], dm["m"], P * S + 1))
                 _assert_same_solve(info, io, xg, xo, lg, lo)
                 filt = ctx.filter_state_download(B, handle)
                 assert np.array_equal(filt, ofilt)
@@ -697,7 +708,7 @@ def test_sqp_filter_line_search_batch_vs_oracle(ctx, oracle):
     ss = pa.sqp_settings_default(); ss.max_iter = 10; ss.line_search_max_iter = 10; ss.line_search = 1
     oss = oracle.sqp_default_settings(); oss.max_iter = 10; oss.line_search_max_iter = 10; oss.line_search = 1
     x, lam, info = ctx.sqp_solve_batch(pa.MODEL_ROBOT, 5, 2, 0.0, 2.0, 8, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
-    xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 2.0, 8, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, pivot=oracle.PIVOT_STATIC)
+    xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 2.0, 8, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, pivot=_policy_order(oracle, 55, 33, 11))
     _assert_same_solve(info, io, x, xo, lam, lo)
 
 
@@ -1159,6 +1170,13 @@ def test_last_route_reports_the_kernel_family(ctx):
     assert route(workloads.robot_batch(4, P=5, S=2)) == pa.capi.ROUTE_REG2
     assert route(workloads.cstr_batch(4)) == pa.capi.ROUTE_REG2
     assert route(workloads.robot_batch(4), qp_solver=1) == pa.capi.ROUTE_LDS
+    # round 3: the Ruiz preconditioner and the filter line search on the 7- and 11-node register kernels; other grids keep the LDS / HBM kernels for them
+    assert route(workloads.robot_batch(4), preconditioner=1) == pa.capi.ROUTE_REG1
+    assert route(workloads.robot_batch(4), line_search=1, hessian_update=1) == pa.capi.ROUTE_REG1
+    assert route(workloads.robot_batch(4, P=5, S=2), preconditioner=1, line_search=1) == pa.capi.ROUTE_REG2
+    assert route(workloads.robot_batch(4, P=4, S=2), preconditioner=1) == pa.capi.ROUTE_LDS
+    assert route(workloads.robot_batch(4, P=5, S=3)) == pa.capi.ROUTE_REG2
+    assert route(workloads.robot_batch(4, P=5, S=3), line_search=1) == pa.capi.ROUTE_HBM
     assert route(workloads.kite_standin_batch(2)) == pa.capi.ROUTE_HBM
 
 

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
         if (NN > 0 && (size_t)(p - stage0) < (size_t)reg_qp_staging<NN + MM>() + 2 + ocp.s.const_doubles(P, S)) p = stage0 + reg_qp_staging<NN + MM>() + 2 + ocp.s.const_doubles(P, S);
         stage_end = p;   // end of the per-node staging block: what follows (static parameters, filter) stays live during the line search
     }
-    if constexpr (NN > 0) {   // block-sparse copy of J (pmpc_jview.hpp): lives through the QP, behind the staging its LDS buffers alias
+    if constexpr (NN > 0 && NN + MM > WAVE) {   // block-sparse copy of J (pmpc_jview.hpp) for the two-rows-per-lane kernels: lives through the QP, behind the staging its LDS buffers alias
         ocp.jblk = p; p += jview_doubles<Model>(ocp.dm.NN); ocp.gblk = ocp.jblk + (size_t)ocp.dm.NN * Model::NX * OcpDims<Model>::NDER; ocp.keep_blk = true;
     }
     double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
@@ -135,7 +135,8 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
     sqp.filt = filt;
     sqp.eig = eigw;
     sqp.trace = ss.iteration_trace ? ss.iteration_trace + (size_t)b * (size_t)ss.iteration_trace_capacity * PMPC_TRACE_DOUBLES : nullptr;
-    sqp.tr = ocp.s.fval + ((ocp.s.fval - smem) & 1);   // first per-node staging array (on a 16-byte boundary: the 8 x 8 register path reads its LDS tiles in 16-byte units): everything from here on is dead while the QP runs
+    sqp.tr = ocp.s.fval;   // first per-node staging array: everything from here on is dead while the QP runs
+    if constexpr (NN + MM > 112) sqp.tr += (ocp.s.fval - smem) & 1;   // (on a 16-byte boundary there: the 8 x 8 register path reads its LDS tiles in 16-byte units. Only there — a second, separately live pointer cost the 7-node kernel a spill inside its ADMM loop)
     {   // side-by-side line search: G candidates x (m constraint values + NN Lagrange values) + 3 scalars each, in the same region
         const int G = WAVE / ocp.dm.NN;
         const size_t need = (size_t)G * (m + ocp.dm.NN + 3);
@@ -226,7 +227,6 @@ __global__ __launch_bounds__(64, PMPC_SQP_WAVES) void sqp_kernel_rr(Model model,
     p = ocp.s.carve(p, P, S);
     if ((size_t)(p - stage0) < (size_t)reg_qp_staging<NN + MM>() + 2 + ocp.s.const_doubles(P, S)) p = stage0 + reg_qp_staging<NN + MM>() + 2 + ocp.s.const_doubles(P, S);
     const double* stage_end = p;
-    ocp.jblk = p; p += jview_doubles<Model>(ocp.dm.NN); ocp.gblk = ocp.jblk + (size_t)ocp.dm.NN * Model::NX * OcpDims<Model>::NDER; ocp.keep_blk = true;
     double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
     ocp.d = dL;
     const int ln = lane_id();
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64, PMPC_SQP_WAVES) void sqp_kernel_rr(Model model,
             sqp.filt = nullptr;
             sqp.eig = nullptr;
             sqp.trace = ss.iteration_trace ? ss.iteration_trace + (size_t)b * (size_t)ss.iteration_trace_capacity * PMPC_TRACE_DOUBLES : nullptr;
-            sqp.tr = ocp.s.fval + ((ocp.s.fval - smem) & 1);
+            sqp.tr = ocp.s.fval;
             sqp.lsbuf = ocp.s.fval;
             sqp.ls_side_by_side = side_by_side;
             if (pass > 0) { const pmpc_sqp_info prev = info[b]; sqp.qp_iter_total = prev.qp_solver_iter; sqp.qp_flags = prev.flags; sqp.cost_log = prev.cost; }
@@ -358,7 +358,7 @@ template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode
     if (mode == 3) { const size_t need = (size_t)RegKkt2<112>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
     if (mode == 4) { const size_t need = (size_t)RegKkt2<128>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }   // 113..128 rows: LDS-resident operand tiles
     return ((mode == 0 ? QpLds::doubles(dm.n, dm.m) : QpLds::doubles_xy(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8 +
-            ((mode == 1 || mode == 3 || mode == 4) ? jview_doubles<Model>(dm.NN) + (pol ? FILTER_LDS_DOUBLES : 0) : FILTER_LDS_DOUBLES) + (mode == 2 ? BigKkt::LDS_DOUBLES : 0)) * sizeof(double);
+            ((mode == 1 || mode == 3 || mode == 4) ? (mode == 1 ? 0 : jview_doubles<Model>(dm.NN)) + (pol ? FILTER_LDS_DOUBLES : 0) : FILTER_LDS_DOUBLES) + (mode == 2 ? BigKkt::LDS_DOUBLES : 0)) * sizeof(double);
 }
 constexpr int BIG_TWO_WAVES_MAX_ROWS = 200;   // below: two wavefronts per SIMD on the HBM-factor kernel when the batch exceeds the SIMD count (see sqp_launch_dev)
 constexpr int BIG_KKT_MIN_ROWS = 96;   // n + m from which sqp_launch_dev prefers the HBM-factor kernel (see there)

@@ -25,6 +25,43 @@ struct RuizScratch {
     double* mE;   // m
 };
 
+// Strided walks with eight loads in flight (a loop with one load -> use -> store per trip waits a full memory round trip per element; every
+// element below is independent of the others — maxima are order-free, the scalings act entry by entry — so batching changes no result).
+constexpr int RUIZ_CH = 8;
+// max_k |M[base + k*stride]|, k < cnt
+__device__ __forceinline__ double ruiz_absmax(const double* M, size_t base, size_t stride, int cnt) {
+    double r = 0.0;
+    for (int k0 = 0; k0 < cnt; k0 += RUIZ_CH) {
+        double t[RUIZ_CH];
+#pragma unroll
+        for (int u = 0; u < RUIZ_CH; ++u) t[u] = M[base + (size_t)((k0 + u < cnt) ? k0 + u : cnt - 1) * stride];
+#pragma unroll
+        for (int u = 0; u < RUIZ_CH; ++u) r = fmax(r, fabs(t[u]));
+    }
+    return r;
+}
+// M[base + k*stride] <- (a * M[...]) * f(k), k < cnt   (f: per-column factor from `col`, or its reciprocal)
+template <bool RECIP>
+__device__ __forceinline__ void ruiz_scale_row(double* M, size_t base, size_t stride, int cnt, double a, const double* col) {
+    for (int k0 = 0; k0 < cnt; k0 += RUIZ_CH) {
+        double t[RUIZ_CH], c[RUIZ_CH];
+#pragma unroll
+        for (int u = 0; u < RUIZ_CH; ++u) { const int k = (k0 + u < cnt) ? k0 + u : cnt - 1; t[u] = M[base + (size_t)k * stride]; c[u] = col[k]; }
+#pragma unroll
+        for (int u = 0; u < RUIZ_CH; ++u) if (k0 + u < cnt) M[base + (size_t)(k0 + u) * stride] = (a * t[u]) * (RECIP ? 1.0 / c[u] : c[u]);
+    }
+}
+// M[base + k*stride] *= g, k < cnt
+__device__ __forceinline__ void ruiz_mul_row(double* M, size_t base, size_t stride, int cnt, double g) {
+    for (int k0 = 0; k0 < cnt; k0 += RUIZ_CH) {
+        double t[RUIZ_CH];
+#pragma unroll
+        for (int u = 0; u < RUIZ_CH; ++u) t[u] = M[base + (size_t)((k0 + u < cnt) ? k0 + u : cnt - 1) * stride];
+#pragma unroll
+        for (int u = 0; u < RUIZ_CH; ++u) if (k0 + u < cnt) M[base + (size_t)(k0 + u) * stride] = t[u] * g;
+    }
+}
+
 // H(i,j) = H[i + j*ldh], A(i,j) = A[i + j*lda]. Returns the cost scaling c.
 __device__ __noinline__ double ruiz_compute_wave(int n, int m, double* H, int ldh, double* h, double* A, int lda, double* Al, double* Au,
                                           double* l, double* u, const RuizScratch& w) {
@@ -39,15 +76,12 @@ __device__ __noinline__ double ruiz_compute_wave(int n, int m, double* H, int ld
     for (int iter = 0; iter < max_iter && (1.0 - scaling_norm) >= tolerance; ++iter) {
         double mx = 0.0;
         for (int i = ln; i < m; i += WAVE) {   // row norms of A
-            double r = 0.0;
-            for (int j = 0; j < n; ++j) r = fmax(r, fabs(A[i + (size_t)j * lda]));
+            const double r = ruiz_absmax(A, i, lda, n);
             mx = fmax(mx, r);
             w.mE[i] = (r < approx_zero) ? 1.0 : r;
         }
         for (int j = ln; j < n; j += WAVE) {   // column norms of [H ; A]
-            double r = 0.0;
-            for (int i = 0; i < n; ++i) r = fmax(r, fabs(H[i + (size_t)j * ldh]));
-            for (int i = 0; i < m; ++i) r = fmax(r, fabs(A[i + (size_t)j * lda]));
+            const double r = fmax(ruiz_absmax(H, (size_t)j * ldh, 1, n), m > 0 ? ruiz_absmax(A, (size_t)j * lda, 1, m) : 0.0);
             mx = fmax(mx, r);
             w.mD[j] = (r < approx_zero) ? 1.0 : r;
         }
@@ -57,13 +91,13 @@ __device__ __noinline__ double ruiz_compute_wave(int n, int m, double* H, int ld
         wsync();
         for (int i = ln; i < n; i += WAVE) {
             const double di = w.mD[i];
-            for (int j = 0; j < n; ++j) { const size_t e = i + (size_t)j * ldh; H[e] = (di * H[e]) * w.mD[j]; }
+            ruiz_scale_row<false>(H, i, ldh, n, di, w.mD);
             h[i] = h[i] * di;
             w.D[i] = w.D[i] * di;
         }
         for (int i = ln; i < m; i += WAVE) {
             const double ei = w.mE[i];
-            for (int j = 0; j < n; ++j) { const size_t e = i + (size_t)j * lda; A[e] = (ei * A[e]) * w.mD[j]; }
+            ruiz_scale_row<false>(A, i, lda, n, ei, w.mD);
             w.E[i] = w.E[i] * ei;
         }
         wfence();
@@ -71,8 +105,7 @@ __device__ __noinline__ double ruiz_compute_wave(int n, int m, double* H, int ld
         // cost scaling: gamma = 1 / max(mean of the column norms of H, |h|_inf)
         double hi = 0.0;
         for (int j = ln; j < n; j += WAVE) {
-            double r = 0.0;
-            for (int i = 0; i < n; ++i) r = fmax(r, fabs(H[i + (size_t)j * ldh]));
+            const double r = ruiz_absmax(H, (size_t)j * ldh, 1, n);
             w.mD[j] = r;
             hi = fmax(hi, fabs(h[j]));
         }
@@ -83,7 +116,7 @@ __device__ __noinline__ double ruiz_compute_wave(int n, int m, double* H, int ld
         for (int j = 0; j < n; ++j) sum += w.mD[j];   // every lane, same order
         const double gamma = 1.0 / fmax(sum / n, h_inf);
         for (int i = ln; i < n; i += WAVE) {
-            for (int j = 0; j < n; ++j) H[i + (size_t)j * ldh] *= gamma;
+            ruiz_mul_row(H, i, ldh, n, gamma);
             h[i] *= gamma;
         }
         c *= gamma;
@@ -112,11 +145,11 @@ __device__ __noinline__ void ruiz_unscale_problem_wave(int n, int m, double* H, 
     const double ic = 1 / c;
     for (int i = ln; i < n; i += WAVE) {
         const double di = ic * (1.0 / D[i]);
-        for (int j = 0; j < n; ++j) { const size_t e = i + (size_t)j * ldh; H[e] = (di * H[e]) * (1.0 / D[j]); }
+        ruiz_scale_row<true>(H, i, ldh, n, di, D);
     }
     for (int i = ln; i < m; i += WAVE) {
         const double ei = 1.0 / E[i];
-        for (int j = 0; j < n; ++j) { const size_t e = i + (size_t)j * lda; A[e] = (ei * A[e]) * (1.0 / D[j]); }
+        ruiz_scale_row<true>(A, i, lda, n, ei, D);
         Au[i] = Au[i] * ei; Al[i] = Al[i] * ei;
     }
     for (int k = ln; k < n; k += WAVE) { h[k] = ic * (h[k] * (1.0 / D[k])); l[k] = l[k] * D[k]; u[k] = u[k] * D[k]; }

@@ -391,7 +391,7 @@ struct SqpDevice {
 
     // lag_grad = J^T lam[0:m] + cost_grad + lam_box  (continuous_ocp.hpp:2112-2114)
     __device__ __forceinline__ void lagrangian_gradient(double* out) {
-        if constexpr (NN > 0) {
+        if constexpr (REG2) {   // (one KKT row per lane: the dense column loads below measured faster there — config A / D +6 % with the sparse form)
             // J' lam from the per-node blocks and the differentiation matrix in LDS: the non-zero products of the dense chain below in the
             // same ascending-row order (pmpc_jview.hpp). A non-finite multiplier takes the dense loops (0 * inf = NaN on the structural zeros).
             bool fin = true;

@@ -272,6 +272,37 @@ struct JViewRT {
         for (int i = NX; i < NDER; ++i) a = step(a, bv[i], xb[i], true);
         return a;
     }
+    // ---- the same two products as multiply-add chains (a += v x over the STRUCTURAL entries, ascending): boxADMM's residual evaluation. The dense
+    // chains they replace also add the structural zeros' +-0, which leaves a finite partial sum unchanged: callers test their operand for
+    // non-finite values first and keep the dense loops for that case.
+    __device__ __forceinline__ static double stepma(double a, double v, double x, bool on) { const double f = a + v * x; return on ? f : a; }
+    __device__ __forceinline__ double rowdot_ma(const Row& w, const double (&bv)[NDER], const double* xs) const {
+        const int kk = w.eq ? w.k : w.kg;
+        double xb[NDER];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xb[i] = xs[kk * NX + i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) xb[NX + i] = xs[VARX + kk * NU + i];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) xb[NX + NU + i] = xs[VARX + VARU + i];
+        double a = 0.0;
+        for (int ph = 0; ph < 2; ++ph) {
+            for (int t0 = 0; t0 <= P; t0 += 8) {
+                double dv[8], xv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int t = (t0 + u <= P) ? t0 + u : 0; dv[u] = w.nd.drow[t * w.nd.dstride]; xv[u] = xs[(w.nd.kb + t) * NX + w.q]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int j = w.nd.kb + t0 + u; a = stepma(a, dv[u], xv[u], w.eq && t0 + u <= P && (ph == 0 ? j < w.k : j > w.k)); }
+            }
+            if (ph == 0) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) a = stepma(a, bv[i], xb[i], true);
+            }
+        }
+#pragma unroll
+        for (int i = NX; i < NDER; ++i) a = stepma(a, bv[i], xb[i], true);
+        return a;
+    }
     static constexpr int NCB = NX + NG;   // entries of a column inside its own node's rows (equality rows, then inequality rows)
     __device__ __forceinline__ void col_block(const Col& cc, double (&bv)[NCB > 0 ? NCB : 1]) const {
 #pragma unroll
@@ -322,6 +353,53 @@ struct JViewRT {
             if constexpr (NP > 0) {
                 double g2 = a;
                 for (int r = 0; r < NG * NNo; ++r) g2 = step(g2, gblk[r * NDER + cc.dcol], us[ME + r], true);
+                a = cc.pcol ? g2 : g1;
+            } else a = g1;
+        }
+        return a;
+    }
+    __device__ __forceinline__ double coldot_ma(const Col& cc, const double (&bv)[NCB > 0 ? NCB : 1], const double* us) const {
+        const int qx = cc.xcol ? cc.dcol : 0;
+        double a = 0.0;
+        for (int ph = 0; ph < 2; ++ph) {
+            for (int k0 = 0; k0 < NNo; k0 += 8) {
+                double dv[8], uv[8]; bool on[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = (k0 + u < NNo) ? k0 + u : 0;
+                    const Node nd = node(k);
+                    const int t = cc.jn - nd.kb;
+                    const bool inseg = cc.xcol && (unsigned)t <= (unsigned)P;
+                    dv[u] = nd.drow[(inseg ? t : 0) * nd.dstride];
+                    uv[u] = us[k * NX + qx];
+                    on[u] = inseg && (k0 + u < NNo) && (ph == 0 ? k < cc.jn : k > cc.jn);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a = stepma(a, dv[u], uv[u], on[u]);
+            }
+            if (ph == 0) {
+#pragma unroll
+                for (int q = 0; q < NX; ++q) a = stepma(a, bv[q], us[cc.jn * NX + q], !cc.pcol);
+            }
+        }
+        if constexpr (NP > 0) {
+            double b = 0.0;
+            for (int r0 = 0; r0 < ME; r0 += 8) {
+                double pv[8], uv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int r = (r0 + u < ME) ? r0 + u : 0; pv[u] = jblk[r * NDER + cc.dcol]; uv[u] = us[r]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) b = stepma(b, pv[u], uv[u], r0 + u < ME);
+            }
+            a = cc.pcol ? b : a;
+        }
+        if constexpr (NG > 0) {
+            double g1 = a;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) g1 = stepma(g1, bv[NX + g], us[ME + cc.jn * NG + g], true);
+            if constexpr (NP > 0) {
+                double g2 = a;
+                for (int r = 0; r < NG * NNo; ++r) g2 = stepma(g2, gblk[r * NDER + cc.dcol], us[ME + r], true);
                 a = cc.pcol ? g2 : g1;
             } else a = g1;
         }

@@ -637,6 +637,46 @@ __device__ __forceinline__ void big_solve(const double* W, int N, double* v, dou
 // in condensed form: the tiles hold S = H + sigma I + rho_box + A' diag(rho) A (n rows instead of n + m) and every solve is
 //     t = r1 + A'(rho o r2),  x = S^{-1} t,  nu = rho o (A x - r2)
 // with the two products formed from the view (pmpc_qp_big.hpp, big_build_condensed; CPU restatement: PIVOT_CONDENSED).
+// residuals_update with A x and A' y formed from the block-sparse view of A (large-instance kernel, condensed mode): the same products in the same
+// order as qp_residuals for finite x, y — the caller tests that — without reading the dense A (two passes over m x n doubles per evaluation)
+template <class JV>
+__device__ __forceinline__ void qp_residuals_sparse(const QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ h,
+                                                   const JV& jv, QpResidualState& r) {
+    const int ln = lane_id();
+    double nAx = 0, nz = 0, nx = 0, rp = 0;
+    for (int i0 = 0; i0 < m; i0 += WAVE) {
+        const int i = i0 + ln;
+        const typename JV::Row rw = jv.rowinfo(i < m ? i : 0);
+        double bv[JV::NDER];
+        jv.row_block(rw, bv);
+        const double a = jv.rowdot_ma(rw, bv, w.x);
+        if (i < m) { nAx = fmax(nAx, fabs(a)); nz = fmax(nz, fabs(w.z[i])); rp = fmax(rp, fabs(a - w.z[i])); }
+    }
+    double nHx = 0, nATy = 0, nh = 0, nyb = 0, rq = 0, rd = 0;
+    for (int i0 = 0; i0 < n; i0 += WAVE) {
+        const int i = i0 + ln;
+        const int ic = i < n ? i : 0;
+        const typename JV::Col cc = jv.column(ic);
+        double bv[JV::NCB > 0 ? JV::NCB : 1];
+        jv.col_block(cc, bv);
+        const double a = seq_dot_strided(H, (size_t)ldh, 1, ic, n, w.x);
+        const double b = jv.coldot_ma(cc, bv, w.y);
+        if (i < n) {
+            nx = fmax(nx, fabs(w.x[i])); nHx = fmax(nHx, fabs(a)); nATy = fmax(nATy, fabs(b));
+            nh = fmax(nh, fabs(h[i])); nyb = fmax(nyb, fabs(w.y[m + i]));
+            rq = fmax(rq, fabs(w.x[i] - w.q[i]));
+            rd = fmax(rd, fabs(((a + h[i]) + b) + w.y[m + i]));
+        }
+    }
+    nAx = wave_max(fmax(nAx, fmax(nz, nx))); nz = nAx; nx = nAx;
+    nHx = wave_max(fmax(fmax(nHx, nATy), fmax(nh, nyb))); nATy = nHx; nh = nHx; nyb = nHx;
+    rp = wave_max(rp); rq = wave_max(rq); rd = wave_max(rd);
+    r.max_Ax_z_norm = fmax(nAx, fmax(nz, nx));
+    r.max_Hx_ATy_h_norm = fmax(nHx, fmax(nATy, fmax(nh, nyb)));
+    r.res_prim = rp + rq;
+    r.res_dual = rd;
+}
+
 struct NoJView {};   // tag: the QP has no structure information (the plain QP entry points)
 constexpr int BIG_COND_MAX_ROWS = 272;   // condensed mode: n and m up to this (the passes of its sparse products are unrolled; 4 x 16 ceil(n / 16) doubles of LDS hold a row panel)
 template <bool BIG = false, class JV = NoJView>
@@ -684,6 +724,17 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
     int status = PMPC_QP_UNSOLVED;
     const double alpha = s.alpha;
     QpResidualState rs{0, 0, 1, 1};
+    auto residuals = [&]() {
+        if constexpr (HASJ) {
+            if (cond) {   // (a non-finite iterate takes the dense loops: 0 * inf = NaN on the structural zeros of A)
+                double pr = 0.0;
+                for (int i = ln; i < n; i += WAVE) pr += w.x[i] - w.x[i];
+                for (int i = ln; i < m; i += WAVE) pr += w.y[i] - w.y[i];
+                if (__builtin_amdgcn_ballot_w64(pr != 0.0) == 0) { qp_residuals_sparse(w, n, m, H, ldh, h, jv, rs); return; }
+            }
+        }
+        qp_residuals(w, n, m, H, ldh, h, A, lda, rs);
+    };
     double rho_estimate = 0.0;
     int iter;
     for (iter = 1; iter <= s.max_iter; ++iter) {
@@ -745,13 +796,13 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
         const bool check = (s.check_termination != 0 && iter % s.check_termination == 0);
         if (check) {
             const long long t0 = tick();
-            qp_residuals(w, n, m, H, ldh, h, A, lda, rs);
+            residuals();
             if (tm) tm[1] += tick() - t0;
             const double ep = s.eps_abs + s.eps_rel * rs.max_Ax_z_norm, ed = s.eps_abs + s.eps_rel * rs.max_Hx_ATy_h_norm;
             if (rs.res_prim <= ep && rs.res_dual <= ed) { status = PMPC_QP_SOLVED; break; }
         }
         if (s.adaptive_rho && iter % s.adaptive_rho_interval == 0) {
-            if (!check) qp_residuals(w, n, m, H, ldh, h, A, lda, rs);
+            if (!check) residuals();
             const double rpn = rs.res_prim / (rs.max_Ax_z_norm + DIV_BY_ZERO_REGUL);
             const double rdn = rs.res_dual / (rs.max_Hx_ATy_h_norm + DIV_BY_ZERO_REGUL);
             double new_rho = rho * sqrt(rpn / (rdn + DIV_BY_ZERO_REGUL));

@@ -115,12 +115,15 @@ __device__ __forceinline__ void big_build_condensed(double* W, int n, int m, con
     const int ln = lane_id();
     const int nb = BigKkt::nblk(n);
     const int lr = ln >> 4, lc = ln & 15;
-    constexpr int GI = 16;   // tile rows per pass (128 accumulator registers: one pass per block column up to 256 rows)
-    for (int Jc = 0; Jc < nb; ++Jc) {
-        const int j = 16 * Jc + lc;
-        const typename JV::Col cj = jv.column(j < n ? j : 0);
+    constexpr int GI = 8;    // tile rows per pass (two block columns each: 16 accumulator tiles = 128 registers)
+    // TWO block columns per pass (2 x 16 accumulator tiles = 256 registers, the accumulation file): the A operands — the expensive part, an entry
+    // lookup per lane and tile row — serve both columns
+    for (int Jc = 0; Jc < nb; Jc += 2) {
+        const bool two = Jc + 1 < nb;
+        const int j0 = 16 * Jc + lc, j1 = 16 * (Jc + 1) + lc;
+        const typename JV::Col cj0 = jv.column(j0 < n ? j0 : 0), cj1 = jv.column((two && j1 < n) ? j1 : 0);
         for (int I0 = Jc; I0 < nb; I0 += GI) {
-            big_d4 T[GI];
+            big_d4 T0[GI], T1[GI];
             typename JV::Col ci[GI];
 #pragma unroll
             for (int g = 0; g < GI; ++g) {
@@ -130,10 +133,12 @@ __device__ __forceinline__ void big_build_condensed(double* W, int n, int m, con
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
                     const int i = 16 * I + 4 * rg + lr;
-                    const bool in = i < n && j < n;
-                    const double hv = H[(size_t)(in ? j : 0) * ldh + (in ? i : 0)];
                     const double kd = (i < n) ? kdiag[i < n ? i : 0] : 1.0;
-                    T[g][rg] = (i == j) ? kd : (in ? hv : 0.0);
+                    const bool in0 = i < n && j0 < n, in1 = two && i < n && j1 < n;
+                    const double hv0 = H[(size_t)(in0 ? j0 : 0) * ldh + (in0 ? i : 0)];
+                    const double hv1 = H[(size_t)(in1 ? j1 : 0) * ldh + (in1 ? i : 0)];
+                    T0[g][rg] = (i == j0) ? kd : (in0 ? hv0 : 0.0);
+                    T1[g][rg] = (i == j1) ? kd : (in1 ? hv1 : 0.0);
                 }
             }
             for (int r0 = 0; r0 < m; r0 += 4) {
@@ -141,12 +146,13 @@ __device__ __forceinline__ void big_build_condensed(double* W, int n, int m, con
                 const bool rin = r < m;
                 const int rc = rin ? r : 0;
                 const typename JV::Row rw = jv.rowinfo(rc);
-                // a group of four constraint rows without an entry in this block column leaves every tile of the pass unchanged (fma(a, 0, c) = c):
+                // a group of four constraint rows without an entry in these block columns leaves every tile of the pass unchanged (fma(a, 0, c) = c):
                 // most of them — a row touches the state columns of its own segment and its own node's block only. Decided from the structure
                 // alone (no load), so that skipped groups cost a few integer operations
-                if (__builtin_amdgcn_ballot_w64(rin && j < n && jv.structural(rw, cj)) == 0) continue;
-                const double bvv = jv.jval(rw, cj);
-                const double bop = (rin && j < n) ? bvv : 0.0;
+                const bool h0 = rin && j0 < n && jv.structural(rw, cj0), h1 = two && rin && j1 < n && jv.structural(rw, cj1);
+                if (__builtin_amdgcn_ballot_w64(h0 || h1) == 0) continue;
+                const double b0v = jv.jval(rw, cj0), b1v = jv.jval(rw, cj1);
+                const double bop0 = (rin && j0 < n) ? b0v : 0.0, bop1 = (two && rin && j1 < n) ? b1v : 0.0;
                 const double rr = rho[rc];
                 double aop[GI];
 #pragma unroll
@@ -158,7 +164,10 @@ __device__ __forceinline__ void big_build_condensed(double* W, int n, int m, con
                 }
 #pragma unroll
                 for (int g = 0; g < GI; ++g)
-                    if (__builtin_amdgcn_ballot_w64(aop[g] != 0.0) != 0) T[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[g], bop, T[g], 0, 0, 0);
+                    if (__builtin_amdgcn_ballot_w64(aop[g] != 0.0) != 0) {
+                        T0[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[g], bop0, T0[g], 0, 0, 0);
+                        T1[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[g], bop1, T1[g], 0, 0, 0);
+                    }
             }
 #pragma unroll
             for (int g = 0; g < GI; ++g) {
@@ -166,7 +175,12 @@ __device__ __forceinline__ void big_build_condensed(double* W, int n, int m, con
                 if (I < nb) {
                     double* tt = W + (size_t)BigKkt::tidx(I, Jc) * 256;
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) tt[64 * rg + ln] = T[g][rg];
+                    for (int rg = 0; rg < 4; ++rg) tt[64 * rg + ln] = T0[g][rg];
+                    if (two && I >= Jc + 1) {
+                        double* t1 = W + (size_t)BigKkt::tidx(I, Jc + 1) * 256;
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) t1[64 * rg + ln] = T1[g][rg];
+                    }
                 }
             }
         }

@@ -52,7 +52,7 @@ REG1_QP_SHAPES = ((35, 21), (20, 12), (25, 15), (30, 18), (40, 24), (24, 16), (3
 REG_NODE_COUNTS = (3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16)   # grids of the built-in models with register-resident SQP kernels (pmpc_launch.hpp, pmpc_grids.hpp)
 
 
-def _gpu_order(oracle, n, m, nodes=None, block_bfgs=False):
+def _gpu_order(oracle, n, m, nodes=None, block_bfgs=False, kkt_form=0):
     """Which of the oracle's GPU-order linear-solve restatements mirrors the kernel that serves this size: the register-resident QP
     (compile-time sizes with n+m <= 64: the (35, 21) QP entry point, SQP grids of 3 to 8 nodes) applies the inverse swept in blocks of
     four pivots (PIVOT_SWEEP); the two-rows-per-lane register path (65..112 rows: the (66, 44) and (55, 33) QP entry points) the same sweep with
@@ -66,18 +66,18 @@ def _gpu_order(oracle, n, m, nodes=None, block_bfgs=False):
         return oracle.PIVOT_SWEEP
     if 64 < n + m <= 128 and nodes in REG_NODE_COUNTS:      # two-rows-per-lane register path (113..128 rows: part of the operand tiles in LDS) (the Hessian update is a run-time choice there)
         return oracle.PIVOT_SWEEP2
-    return _lds_order(oracle, n + m)
+    return _lds_order(oracle, n + m, kkt_form=kkt_form)
 
 
 POLICY_REG_NODE_COUNTS = (7, 11)   # grids whose register-resident kernels exist with the Ruiz / filter-line-search hooks compiled in (pmpc_launch.hpp, POL)
 
 
-def _policy_order(oracle, n, m, nodes, ruiz=False, block_bfgs=False):
+def _policy_order(oracle, n, m, nodes, ruiz=False, block_bfgs=False, kkt_form=0):
     """preconditioner = 1 / line_search = 1: on the grids of the reference's own tests (7 and 11 nodes) the register-resident kernels carry these hooks
     since round 3 (their sweep orders); every other grid takes the LDS / HBM-resident kernels for them."""
     if nodes in POLICY_REG_NODE_COUNTS and n + m <= 112:
         return oracle.PIVOT_SWEEP if n + m <= 64 else oracle.PIVOT_SWEEP2
-    return _lds_order(oracle, n + m, ruiz=ruiz)
+    return _lds_order(oracle, n + m, ruiz=ruiz, kkt_form=kkt_form)
 
 
 def _qp_oracle(oracle, q, s, x0=None, y0=None):
@@ -514,13 +514,14 @@ def _sqp_both(ctx, oracle, wl, B, **kw):
     x, lam, info = ctx.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
     oss = oracle.sqp_default_settings(); oss.max_iter = wl["max_iter"]; oss.line_search_max_iter = wl["ls_max_iter"]
     for k, v in kw.items():
-        setattr(oss, k, v)
+        if k != "kkt_form": setattr(oss, k, v)   # (how the large-instance kernel arranges its linear algebra: a pivot policy on the CPU side)
+    kf = kw.get("kkt_form", 0)
     n = wl["lbx"].shape[1]; dm = oracle.ocp_dims(wl["model"], wl["P"], wl["S"])
     # (preconditioner = 1, qp_solver = 1 and line_search = 1 are served by the LDS-resident QP kernels whatever the size: static LDL^T
     #  order; hessian_update = 1 has register-resident specialisations like the default)
     if kw.get("qp_solver", 0): order = oracle.PIVOT_STATIC
-    elif kw.get("preconditioner", 0) or kw.get("line_search", 0): order = _policy_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, ruiz=bool(kw.get("preconditioner", 0)), block_bfgs=bool(kw.get("hessian_update", 0)))
-    else: order = _gpu_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, block_bfgs=bool(kw.get("hessian_update", 0)))
+    elif kw.get("preconditioner", 0) or kw.get("line_search", 0): order = _policy_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, ruiz=bool(kw.get("preconditioner", 0)), block_bfgs=bool(kw.get("hessian_update", 0)), kkt_form=kf)
+    else: order = _gpu_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, block_bfgs=bool(kw.get("hessian_update", 0)), kkt_form=kf)
     xo, lo, io = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"],
                                         sqp_settings=oss, pivot=order, threads=8)
     return (x, lam, info), (xo, lo, io)

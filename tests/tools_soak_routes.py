@@ -22,7 +22,7 @@ def main():
     ctx = pa.Context(0)
     bad = 0
     grids = [(P, S) for P in range(2, 8) for S in range(1, 4) if 3 <= P * S + 1 <= 16]
-    policies = [dict(), dict(hessian_update=1), dict(preconditioner=1), dict(line_search=1), dict(qp_solver=1)]
+    policies = [dict(), dict(hessian_update=1), dict(preconditioner=1), dict(line_search=1), dict(qp_solver=1), dict(preconditioner=1, line_search=1, hessian_update=1), dict(kkt_form=1)]
     for model in (0, 1):
         for P, S in grids:
             dm = ob.ocp_dims(model, P, S)

@@ -4,7 +4,7 @@ import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out = {}
-for name in ["sq1", "sq2", "fetch", "write", "calfetch", "calwrite"]:
+for name in ["sq1", "sq2", "fetch", "write", "tcc", "calfetch", "calwrite"]:
     fs = glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_{name}", "*counter_collection.csv"))
     if not fs:
         continue
@@ -36,6 +36,14 @@ try:
                       "kernel": [k for k in sorted(out["fetch"], key=lambda k: -out["fetch"][k]["per_launch_mean"] * out["fetch"][k]["launches"])][0] if not any(", 35, 21, false, 0, false>" in k for k in out["fetch"]) else "sqp_kernel<RobotOCP,35,21> (bench.py --steps 5 --warmup 1, config A, batch 4096)"}
 except Exception as e:  # incomplete collection
     out["traffic"] = None
+try:   # L2 hit rate of the kernel the traffic figure is about
+    hk = [k for k in out["tcc"] if k.startswith("TCC_HIT_sum")]; 
+    best = max(hk, key=lambda k: out["tcc"][k]["per_launch_mean"] * out["tcc"][k]["launches"])
+    hit = out["tcc"][best]["per_launch_mean"]; miss = out["tcc"][best.replace("TCC_HIT_sum", "TCC_MISS_sum")]["per_launch_mean"]
+    out["l2"] = {"kernel": best, "hits_per_launch": hit, "misses_per_launch": miss, "hit_rate": hit / (hit + miss),
+                 "note": "TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum); FETCH_SIZE / WRITE_SIZE count the fabric requests behind the L2 (Infinity-Cache hits included: no public counter separates them from HBM)"}
+except Exception:
+    pass
 try:
     import hashlib
     out["library_build_id"] = hashlib.sha256(open(os.path.join(ROOT, "polympc_amd", "libpolympc_amd.so"), "rb").read()).hexdigest()[:16]

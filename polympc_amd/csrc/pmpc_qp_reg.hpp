@@ -356,6 +356,7 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
                                                   double* out_x, double* out_y, double* tr, long long* dbg = nullptr, long long* tm = nullptr) {
     constexpr int N = NN + MM;
     static_assert(N <= WAVE, "register-resident path needs n+m <= 64");
+    const long long tp0 = dbg ? clock64() : 0;   // (phase-profile instantiation only: dbg[17] prologue, dbg[9] ADMM updates)
     const int ln = lane_id();
     const bool isP = ln < NN;
     const bool isC = (ln >= NN) && (ln < N);
@@ -442,6 +443,7 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
     int iter = 1;
     int until_check = s.check_termination, until_adapt = s.adaptive_rho_interval;   // iterations left until the next multiple
     bool running = true;
+    if (dbg) dbg[17] += clock64() - tp0;
     while (running) {
         {   // construct_kkt_matrix + factorise_kkt_matrix
             const long long f0 = dbg ? clock64() : 0;
@@ -458,6 +460,7 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
         }
         bool refactor = false;
         for (; iter <= s.max_iter; ++iter) {
+            const long long ti0 = dbg ? clock64() : 0;
             const double zprev = xv;  // meaningful on constraint lanes
             const double rhsP = ((s.sigma * xv - hv) + rhov * qv) - yv;
             const double rhsC = xv - rhoinv * yv;
@@ -477,6 +480,7 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
             xv = isP ? xx : (isC ? zz : xv);
             qv = isP ? qq : qv;
             yv = isP ? yP : (isC ? yC : yv);
+            if (dbg) dbg[9] += clock64() - ti0;
             // iter % check_termination == 0 / iter % adaptive_rho_interval == 0 (box_admm.hpp:141,:160) as countdowns
             bool check = false, adapt = false;
             if (s.check_termination != 0 && --until_check == 0) { check = true; until_check = s.check_termination; }

@@ -19,8 +19,8 @@ for rep in range(2):
 cyc = ctx.phase_cycles()
 names = ["linearise(+update)", "QP", "line search", "termination", "total loop", "BFGS", "KKT build+factor", "QP residuals",
          "ls node evaluation", "ls scalar sums", "first-order staging", "second-order staging", "first-order assembly",
-         "Hessian assembly", "Lagrangian gradient", "-", "inv: row loads + staging | LDS path: KKT build", "inv: panel moves | LDS path: substitutions", "inv: sweeps", "inv: MFMA updates",
-         "inv: final conversion", "ls prologue", "ls acceptance", "-"]
+         "Hessian assembly", "Lagrangian gradient", "QP: ADMM updates (one-row-per-lane kernels)", "inv: row loads + staging | LDS path: KKT build", "inv: panel moves | LDS path: substitutions", "inv: sweeps", "inv: MFMA updates",
+         "inv: final conversion", "ls prologue", "ls acceptance", "QP: prologue (one-row-per-lane kernels)"]
 qps = info["iter"].sum()
 print(f"host wall {t*1e3:.2f} ms (incl. copies), {qps} QPs, {info['qp_solver_iter'].sum()/qps:.2f} ADMM it/QP")
 for nme, c in zip(names, cyc):

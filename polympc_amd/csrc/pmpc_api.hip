@@ -106,7 +106,9 @@ extern "C" void pmpc_internal_set_route(pmpc_context* ctx, int route) { if (ctx)
 // =====================================================================================================================
 extern "C" {
 
-const char* pmpc_version(void) { return "polympc_amd 0.3 (gfx950, abi 3)"; }
+#define PMPC_STR2(x) #x
+#define PMPC_STR(x) PMPC_STR2(x)
+const char* pmpc_version(void) { return "polympc_amd 0.3 (gfx950, abi " PMPC_STR(PMPC_ABI_VERSION) ")"; }
 int pmpc_abi_version(void) { return PMPC_ABI_VERSION; }
 unsigned long pmpc_struct_size(int which) {
     switch (which) {

@@ -17,6 +17,10 @@
 namespace pmpc {
 
 constexpr int WAVE = 64;
+#ifndef PMPC_BIG_MEM_BATCH
+#define PMPC_BIG_MEM_BATCH 32
+#endif
+constexpr int BIG_MEM_BATCH = PMPC_BIG_MEM_BATCH;   // loads in flight per lane in the row walks of the HBM-factor kernels (BFGS products and update, H x of the residuals): one memory round trip per batch
 constexpr double RHO_MIN = 1e-6, RHO_MAX = 1e+6, RHO_EQ_FACTOR = 1e+3;   // box_admm.hpp:56-59
 constexpr double LOOSE_BOUNDS_THRESH = 1e+10, EQ_TOL = 1e-4;            // qp_base.hpp:124-125
 constexpr double DIV_BY_ZERO_REGUL = 10e-10;                            // qp_base.hpp:79-82
@@ -470,8 +474,8 @@ __device__ __forceinline__ void kkt_solve(const QpLds& w, int N, double* v) {
 
 // sum_j M[j * sj + i * si] * vec[j], one add chain with j ascending (the order of the CPU restatement); eight global loads and eight LDS
 // reads are in flight before the chain consumes them: full chunks without any clamping, then one clamped chunk for the remainder
+template <int CH = 8>
 __device__ __forceinline__ double seq_dot_strided(const double* __restrict__ M, size_t sj, size_t si, int i, int cnt, const double* vec) {
-    constexpr int CH = 8;
     double a = 0.0;
     const double* __restrict__ p = M + (size_t)i * si;
     int j0 = 0;
@@ -659,7 +663,7 @@ __device__ __forceinline__ void qp_residuals_sparse(const QpLds& w, int n, int m
         const typename JV::Col cc = jv.column(ic);
         double bv[JV::NCB > 0 ? JV::NCB : 1];
         jv.col_block(cc, bv);
-        const double a = seq_dot_strided(H, (size_t)ldh, 1, ic, n, w.x);
+        const double a = seq_dot_strided<BIG_MEM_BATCH>(H, (size_t)ldh, 1, ic, n, w.x);
         const double b = jv.coldot_ma(cc, bv, w.y);
         if (i < n) {
             nx = fmax(nx, fabs(w.x[i])); nHx = fmax(nHx, fabs(a)); nATy = fmax(nATy, fabs(b));

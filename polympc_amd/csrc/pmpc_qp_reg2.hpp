@@ -52,7 +52,12 @@ struct RegKkt2 {
     static constexpr int LT = NL * 256;                       // doubles of LDS tiles; the small buffer YS sits behind them
     static constexpr int YS = 16 * SY;
     static constexpr int TRI1 = TRI0 > NT * 16 * SY ? TRI0 : NT * 16 * SY;
-    static constexpr int TRI = LDS_TILES ? (TRI0 > LT + YS ? TRI0 : LT + YS) : TRI1;   // doubles of LDS staging (PA | PB aliased with X; Y and the rhs buffer alias both)
+#ifndef PMPC_REG2_LDSPARK
+#define PMPC_REG2_LDSPARK 9   /* operand tiles parked in LDS while the residuals are evaluated (config B: 0 / 6 / 9 -> 38.4 / 37.0 / ... ms), see park() */
+#endif
+    // 7 x 7 tiles: room for three more parked tiles behind the staging (6 KB: the largest of these kernels then needs 39.3 KB, four instances per CU still fit)
+    static constexpr int PARK_EXTRA = (NT == 7 && PMPC_REG2_LDSPARK > 6) ? (PMPC_REG2_LDSPARK - 6) * 256 : 0;
+    static constexpr int TRI = LDS_TILES ? (TRI0 > LT + YS ? TRI0 : LT + YS) : TRI1 + PARK_EXTRA;   // doubles of LDS staging (PA | PB aliased with X; Y and the rhs buffer alias both)
     static constexpr int RHS_OFF = LDS_TILES ? LT : 0;        // where apply() stages the right-hand side / the residual evaluation its vectors
     __device__ __forceinline__ static constexpr bool in_lds(int R, int C) { return LDS_TILES && ((R + C) & 3) == 3; }
     __device__ __forceinline__ static constexpr int lds_index(int R, int C) { return 2 * R + (C >= 4 ? 1 : 0); }
@@ -289,25 +294,43 @@ struct RegKkt2 {
     // wants dozens of loads in flight, and with 136 registers pinned by the operand the allocator spilled the LOADED values instead — a
     // scratch round trip between any two loads, i.e. one exposed L2 latency per matrix entry (0.37 ms per check on 4096 QPs; the ADMM
     // iteration itself takes 0.012 ms). `mem` is a private (scratch) array, indexed through an opaque zero so that it stays memory.
+    // NLP of the NV tiles are parked in LDS instead (the sweep's staging is free between factorisations; k-major, one double per lane and slot:
+    // conflict-free 8-byte accesses): 2 KB per tile that neither leave the CU nor come back through L2 / HBM.
+    // USED: doubles at the head of the staging that the residual evaluation itself occupies (x, y, the products of the second slot)
+    __device__ __forceinline__ static constexpr int lds_parked(int used) {
+        if (LDS_TILES) return 0;
+        const int fit = (TRI - used) / 256;
+        return fit < 0 ? 0 : (fit < PMPC_REG2_LDSPARK ? fit : (PMPC_REG2_LDSPARK < NV ? PMPC_REG2_LDSPARK : NV));
+    }
     static constexpr int NPARK = NV * 4;
-    __device__ __forceinline__ void park(double* mem, int oz) {
+    template <int NLP, int PARK_OFF>
+    __device__ __forceinline__ void park(double* mem, int oz, double* lds, unsigned lane) {
 #pragma unroll
         for (int R = 0; R < NT; ++R)
 #pragma unroll
             for (int C = 0; C < NT; ++C)
                 if (!in_agpr(R, C) && !in_lds(R, C)) {
+                    const int ri = reg_index(R, C);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) mem[reg_index(R, C) * 4 + r + oz] = T[R][C][r];
+                    for (int r = 0; r < 4; ++r) {
+                        if (ri < NLP) lds[PARK_OFF + (ri * 4 + r) * 64 + lane] = T[R][C][r];
+                        else mem[(ri - NLP) * 4 + r + oz] = T[R][C][r];
+                    }
                 }
     }
-    __device__ __forceinline__ void unpark(const double* mem, int oz) {
+    template <int NLP, int PARK_OFF>
+    __device__ __forceinline__ void unpark(const double* mem, int oz, const double* lds, unsigned lane) {
 #pragma unroll
         for (int R = 0; R < NT; ++R)
 #pragma unroll
             for (int C = 0; C < NT; ++C)
                 if (!in_agpr(R, C) && !in_lds(R, C)) {
+                    const int ri = reg_index(R, C);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) T[R][C][r] = mem[reg_index(R, C) * 4 + r + oz];
+                    for (int r = 0; r < 4; ++r) {
+                        if (ri < NLP) T[R][C][r] = lds[PARK_OFF + (ri * 4 + r) * 64 + lane];
+                        else T[R][C][r] = mem[(ri - NLP) * 4 + r + oz];
+                    }
                 }
     }
 
@@ -556,8 +579,10 @@ __device__ __forceinline__ void boxadmm_solve_reg2(const double* __restrict__ H,
                     const double probe = ((xv[0] - xv[0]) + (yv[0] - yv[0])) + ((xv[1] - xv[1]) + (yv[1] - yv[1]));
                     sparse = __builtin_amdgcn_ballot_w64(probe != 0.0) == 0;
                 }
-                double parked[RegKkt2<N>::NPARK];
-                K.park(parked, zr);
+                constexpr int PUSED = NN + MM + ((NN > 64 && NN - 64 <= 4) ? (NN - 64) * NN : 0);   // x, y, products of the few primal rows of the second slot
+                constexpr int NLPK = RegKkt2<N>::lds_parked(PUSED);
+                double parked[(RegKkt2<N>::NV - NLPK) * 4 > 0 ? (RegKkt2<N>::NV - NLPK) * 4 : 1];
+                K.template park<NLPK, PUSED>(parked, zr, tr + RegKkt2<N>::RHS_OFF, lane_near(zr));
                 sched_fence();
                 if (HASJ && sparse) {
                   if constexpr (HASJ) {
@@ -696,7 +721,7 @@ __device__ __forceinline__ void boxadmm_solve_reg2(const double* __restrict__ H,
                     // scratch) and reloads them one by one in front of every load here — 36 dependent memory round trips
                     int zu = 0;
                     asm volatile("" : "+v"(zu));
-                    K.unpark(parked, zu);
+                    K.template unpark<NLPK, PUSED>(parked, zu, tr + RegKkt2<N>::RHS_OFF, lane_near(zu));
                 }
                 double a1 = 0.0, a2 = 0.0, rp = 0.0, rq = 0.0, rd = 0.0;
 #pragma unroll

@@ -58,6 +58,7 @@ struct SqpDevice {
     static constexpr bool RUIZ_COMPILED = HOOKS && (int)Dm::NDER <= RUIZ_MAX_NDER;
     static constexpr bool REG1 = NN > 0 && NN + MM <= WAVE;    // one KKT row per lane
     static constexpr bool REG2 = NN > 0 && NN + MM > WAVE;     // two KKT rows per lane
+    static constexpr int MEMCH = BIG ? BIG_MEM_BATCH : 8;      // loads in flight per lane in the row walks over the BFGS matrix in HBM
     Ocp<Model>& ocp;
     SqpLds& v;
     QpLds& qw;
@@ -713,7 +714,7 @@ struct SqpDevice {
         const int ln = lane_id();
         double* Bs = v.t1; double* r = v.t2; double* y = v.t3;
         for (int i = ln; i < n; i += WAVE) {
-            Bs[i] = seq_dot_strided(Hw, (size_t)ldw, 1, i, n, v.step);   // row i of B times s: one add chain, columns ascending, eight loads in flight
+            Bs[i] = seq_dot_strided<MEMCH>(Hw, (size_t)ldw, 1, i, n, v.step);   // row i of B times s: one add chain, columns ascending, eight loads in flight
             y[i] = v.lgn[i] - v.lg[i];
         }
         wsync();
@@ -743,7 +744,7 @@ struct SqpDevice {
         const int VARX = ocp.dm.VARX, VARU = ocp.dm.VARU, NNo = ocp.dm.NN;
         double* vv = v.t1; double* r = v.t2; double* y = v.t3;
         for (int i = ln; i < n; i += WAVE) {
-            vv[i] = seq_dot_strided(Hw, (size_t)ldw, 1, i, n, v.step);   // row i of B times s: one add chain, columns ascending, eight loads in flight
+            vv[i] = seq_dot_strided<MEMCH>(Hw, (size_t)ldw, 1, i, n, v.step);   // row i of B times s: one add chain, columns ascending, eight loads in flight
             y[i] = v.lgn[i] - v.lg[i];
         }
         wsync();
@@ -780,11 +781,15 @@ struct SqpDevice {
         wfence();
         wsync();
     }
-    // B += -(Bs Bs^T)/sBs + (r r^T)/sr, element by element in the HBM workspace: lane i walks row i, eight columns per batch of loads
-    // (every entry sees the same two operations as in the reference's expression, entries are independent of each other)
-    __device__ __forceinline__ void rank2_update_mem(const double* Bs, const double* r, double sBs, double sr) {
+    // B += -(Bs Bs^T)/sBs + (r r^T)/sr, element by element in the HBM workspace: lane i walks row i, MEMCH columns per batch of loads
+    // (every entry sees the same two operations as in the reference's expression, entries are independent of each other).
+    // FAST: the two quotients per entry through UniformDiv (5 operations each instead of the ~40 of the generic expansion, the same bits) —
+    // callers pass it when both divisors lie in its window.
+    template <bool FAST>
+    __device__ __forceinline__ void rank2_update_rows(const double* Bs, const double* r, double sBs, double sr) {
         const int ln = lane_id();
-        constexpr int CH = 8;
+        constexpr int CH = MEMCH;
+        const UniformDiv by_sBs(sBs), by_sr(sr);
         for (int i = ln; i < n; i += WAVE) {
             const double Bsi = Bs[i], ri = r[i];
             double* __restrict__ row = Hw + i;
@@ -796,14 +801,21 @@ struct SqpDevice {
                 for (int u = 0; u < CH; ++u)
                     if (j0 + u < n) {
                         double t = b[u];
-                        t += (-Bsi * Bs[j0 + u]) / sBs;
-                        t += (ri * r[j0 + u]) / sr;
+                        if constexpr (FAST) { t += by_sBs(-Bsi * Bs[j0 + u]); t += by_sr(ri * r[j0 + u]); }
+                        else { t += (-Bsi * Bs[j0 + u]) / sBs; t += (ri * r[j0 + u]) / sr; }
                         row[(size_t)(j0 + u) * ldw] = t;
                     }
             }
         }
         wfence();
         wsync();
+    }
+    __device__ __forceinline__ void rank2_update_mem(const double* Bs, const double* r, double sBs, double sr) {
+        if constexpr (NN > 0) rank2_update_rows<false>(Bs, r, sBs, sr);   // register-resident kernels: the rare fallback of their own UniformDiv paths
+        else {
+            const UniformDiv a(sBs), b(sr);
+            if (a.ok() && b.ok()) rank2_update_rows<true>(Bs, r, sBs, sr); else rank2_update_rows<false>(Bs, r, sBs, sr);
+        }
     }
 
     // QP bounds :588-593

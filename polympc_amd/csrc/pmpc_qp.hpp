@@ -692,7 +692,7 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
     const int N = n + m;
     constexpr bool HASJ = BIG && !std::is_same<JV, NoJView>::value;
     const bool cond = HASJ && condensed;
-    auto build_and_factor = [&](long long* tb) {
+    auto build_and_factor = [&](long long* tb) __attribute__((always_inline)) {   // (inlined at both call sites: as one shared out-of-line function its register use also bounded the occupancy of the two-waves-per-SIMD kernels that call it)
         if constexpr (BIG) {
             if constexpr (HASJ) {
                 if (cond) { big_build_condensed(w.K, n, m, H, ldh, w.kdiag, w.rho, jv); if (tb) *tb = clock64(); big_factor(w.K, n, w.big_lds); return; }

@@ -15,6 +15,19 @@ struct vref {
     __host__ __device__ T& operator[](int i) const { return p[i]; }
 };
 template <class T> using cref = vref<const T>;
+// Read-only view of the SEEDED second-order variables of one Hessian entry (Ocp::stage_second_order_entry): element i is generated where the
+// model reads it — value from LDS, inner partial 1 on variable `r`, outer partial 1 on variable `dir` — instead of living in a local array of
+// NX + NU + NP nested duals (4 doubles each) for the whole model evaluation. Same values, so every entry goes through the same operations.
+template <>
+struct vref<const Dual<Dual<double, 1>, 1>> {
+    using T = Dual<Dual<double, 1>, 1>;
+    const double* val; int id0, r, dir;
+    __host__ __device__ vref(const double* v_, int id0_, int r_, int dir_) : val(v_), id0(id0_), r(r_), dir(dir_) {}
+    __host__ __device__ T operator()(int i) const {
+        T t; t.v = Dual<double, 1>(val[i]); t.v.d[0] = (id0 + i == r) ? 1.0 : 0.0; t.d[0] = Dual<double, 1>(id0 + i == dir ? 1.0 : 0.0); return t;
+    }
+    __host__ __device__ T operator[](int i) const { return (*this)(i); }
+};
 // doubles viewed as value-only scalars (see Value in pmpc_ad.hpp)
 __host__ __device__ inline cref<Value> as_cvalues(const double* p) { return cref<Value>(reinterpret_cast<const Value*>(p)); }
 __host__ __device__ inline vref<Value> as_values(double* p) { return vref<Value>(reinterpret_cast<Value*>(p)); }

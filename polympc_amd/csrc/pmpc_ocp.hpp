@@ -315,21 +315,17 @@ struct Ocp {
         using ad2 = Dual<adi, 1>;
         for (int e = lane_id(); e < dm.NN * NDER * NDER; e += WAVE) {
             const int k = e % dm.NN, dr = e / dm.NN, dir = dr / NDER, r = dr - dir * NDER;
-            ad2 x[NX > 0 ? NX : 1], u[NU > 0 ? NU : 1], p[NP > 0 ? NP : 1], y[NX > 0 ? NX : 1];
-            {   // second-order seeding (continuous_ocp.hpp:691-735 restricted to one outer and one inner partial)
-                int idx = 0;
-                auto mk = [&](double val, int id) { ad2 v_; v_.v = adi(val); v_.v.d[0] = (id == r) ? 1.0 : 0.0; v_.d[0] = adi(id == dir ? 1.0 : 0.0); return v_; };
-                for (int i = 0; i < NX; ++i, ++idx) x[i] = mk(var[k * NX + i], idx);
-                for (int i = 0; i < NU; ++i, ++idx) u[i] = mk(var[dm.VARX + k * NU + i], idx);
-                for (int i = 0; i < NP; ++i, ++idx) p[i] = mk(var[dm.VARX + dm.VARU + i], idx);
-            }
+            ad2 y[NX > 0 ? NX : 1];
+            // second-order seeding (continuous_ocp.hpp:691-735 restricted to one outer and one inner partial), generated element by element where the
+            // model reads it (see the vref specialisation in pmpc_models.hpp)
+            const cref<ad2> x(var + k * NX, 0, r, dir), u(var + dm.VARX + k * NU, NX, r, dir), p(var + dm.VARX + dm.VARU, NX + NU, r, dir);
             ad2 L(0.0);
-            model.template lagrange_term_impl<ad2>(cref<ad2>(x), cref<ad2>(u), cref<ad2>(p), cref<double>(d), s.tn[k], L);
+            model.template lagrange_term_impl<ad2>(x, u, p, cref<double>(d), s.tn[k], L);
             // hes.col(dir) = L.d[dir].d  => hes(r, dir)
             s.Lhes[(k * NDER + dir) * NDER + r] = L.d[0].d[0];
             for (int q = 0; q < NX; ++q) y[q] = ad2(0.0);
             ad2 tk(s.tn[k]);
-            model.template dynamics_impl<ad2>(cref<ad2>(x), cref<ad2>(u), cref<ad2>(p), cref<double>(d), tk, vref<ad2>(y));
+            model.template dynamics_impl<ad2>(x, u, p, cref<double>(d), tk, vref<ad2>(y));
             double col = 0.0;
             for (int q = 0; q < NX; ++q) {
                 const double coeff = -lam[q + k * NX] * ts;
@@ -338,7 +334,7 @@ struct Ocp {
             if (NG > 0) {
                 ad2 g[NG > 0 ? NG : 1];
                 for (int q = 0; q < NG; ++q) g[q] = ad2(0.0);
-                model.template inequality_constraints_impl<ad2>(cref<ad2>(x), cref<ad2>(u), cref<ad2>(p), cref<double>(d), s.tn[k], vref<ad2>(g));
+                model.template inequality_constraints_impl<ad2>(x, u, p, cref<double>(d), s.tn[k], vref<ad2>(g));
                 for (int q = 0; q < NG; ++q) {
                     const double coeff = lam[q + k * NG + dm.me];
                     col += coeff * g[q].d[0].d[0];
@@ -347,7 +343,7 @@ struct Ocp {
             s.dhes[(k * NDER + dir) * NDER + r] = col;
             if (k == 0) {
                 ad2 M(0.0);
-                model.template mayer_term_impl<ad2>(cref<ad2>(x), cref<ad2>(u), cref<ad2>(p), cref<double>(d), s.tn[0], M);
+                model.template mayer_term_impl<ad2>(x, u, p, cref<double>(d), s.tn[0], M);
                 s.Mhes[dir * NDER + r] = M.d[0].d[0];
             }
         }

@@ -1,0 +1,73 @@
+"""The register budget of the built kernels is what their launch bounds promise (no GPU needed: the code objects inside the product library are
+read with the ROCm binutils). A kernel that asks for two wavefronts per SIMD but was compiled to more than 256 registers runs at one — silently:
+hipcc only prints a -Wpass-failed remark (this happened to the two-wave HBM-factor kernels when a shared out-of-line function was compiled for the
+one-wave kernels' budget)."""
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+import polympc_amd as pa
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def _code_objects(tmp):
+    fat = os.path.join(tmp, "fat.bin")
+    subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", pa.LIB_PATH, fat])
+    data = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(re.escape(MAGIC), data)]
+    out = []
+    for n, (a, b) in enumerate(zip(starts, starts[1:] + [len(data)])):
+        bundle = os.path.join(tmp, f"b{n}.bin"); open(bundle, "wb").write(data[a:b])
+        targets = subprocess.run([f"{LLVM}/clang-offload-bundler", "--list", "--type=o", f"--input={bundle}"], capture_output=True, text=True).stdout.split()
+        for t in targets:
+            if "gfx950" in t:
+                co = os.path.join(tmp, f"b{n}.co")
+                subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={bundle}", f"--targets={t}", f"--output={co}"])
+                out.append(co)
+    return out
+
+
+def _kernels(co):
+    notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+    for blk in re.split(r"\n\s*- \.agpr_count:", notes)[1:]:
+        agpr = int(blk.split()[0])
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
+        yield name, vgpr, agpr
+
+
+@pytest.mark.skipif(not (os.path.exists(f"{LLVM}/clang-offload-bundler") and os.path.exists(f"{LLVM}/llvm-readelf")), reason="ROCm binutils not installed")
+def test_two_wave_kernels_fit_half_the_register_file():
+    assert os.path.exists(pa.LIB_PATH)
+    pat = re.compile(r"sqp_kernel<pmpc::(\w+), (\d+), (\d+), (true|false), (\d+), (true|false), (true|false), (true|false)>")
+    seen = {"reg1": 0, "big2": 0, "big1": 0, "reg2": 0}
+    with tempfile.TemporaryDirectory() as tmp:
+        objs = _code_objects(tmp)
+        assert objs, "no gfx950 code object in the library"
+        for co in objs:
+            ks = list(_kernels(co))
+            names = subprocess.run(["c++filt"], input="\n".join(k[0] for k in ks), capture_output=True, text=True).stdout.splitlines()
+            for (mangled, vgpr, agpr), dn in zip(ks, names):
+                m = pat.search(dn)
+                if not m:
+                    continue
+                nn, mm, khbm, w2 = int(m.group(2)), int(m.group(3)), m.group(6) == "true", m.group(7) == "true"
+                # (.vgpr_count is the unified count: architected registers + accumulation file)
+                if nn > 0 and nn + mm <= 64:      # one KKT row per lane: PMPC_SQP_WAVES = 2
+                    seen["reg1"] += 1
+                    assert vgpr <= 256, f"{dn[:120]}: {vgpr} registers, two wavefronts per SIMD need <= 256"
+                elif khbm and w2:                 # HBM-factor kernel, two wavefronts per SIMD
+                    seen["big2"] += 1
+                    assert vgpr <= 256, f"{dn[:120]}: {vgpr} registers, two wavefronts per SIMD need <= 256"
+                elif khbm:
+                    seen["big1"] += 1
+                    assert vgpr <= 512
+                elif nn > 0:
+                    seen["reg2"] += 1
+                    assert vgpr <= 512
+    assert seen["reg1"] > 0 and seen["big2"] > 0 and seen["big1"] > 0 and seen["reg2"] > 0, seen

@@ -273,17 +273,22 @@ def main():
                 cfg[key] = sqp_record(cwl, Bc, steps, warmup, kernel_name)
                 cfg[key]["workload"] = workload
                 cfg_runs[key] = (letter, cwl, Bc, sol[0])
+                # the same batch with the Hessian update every control test of the reference selects (cstr_control_test.cpp:128-132,
+                # mpc_wrapper_test.cpp:100-105, minimal_time_test.cpp:84-88, valet_parking_mpc_test.cpp:161-165 -> continuous_ocp.hpp:2304-2431)
+                vb = sqp_record(cwl, Bc, max(3, steps // 2), 1, kernel_name + ", hessian_update = 1", hessian_update=1)
+                cfg[key]["variant_block_bfgs"] = {k_: vb[k_] for k_ in ("steps", "ms_per_batch", "qp_solves_per_s", "sqp_solves_per_s", "qp_solves_per_batch",
+                                                                          "admm_iters_per_qp", "sqp_solved_fraction", "route")}
             if "D" in want:
                 add("D_scenario_8192_per_gpu", "D", workloads.robot_batch(8192, perturb_d=True, first=5000), 8192, 10, 2, "sqp_kernel<RobotOCP,35,21>",
                     "mobile robot, perturbed wheel base d = 2(1+0.1U), 8192 instances per GPU (65 536 over 8 GPUs)")
             if "B" in want:
-                add("B_cstr_16384", "B", workloads.cstr_batch(16384), 16384, 5, 1, "sqp_kernel<CstrOCP,66,44> (110 KKT rows)",
+                add("B_cstr_16384", "B", workloads.cstr_batch(16384), 16384, 10, 1, "sqp_kernel<CstrOCP,66,44> (110 KKT rows)",
                     "CSTR nx=4 nu=2, P=5 S=2 (11 nodes), t in [0,100], SQP max_iter=20 ls=20")
             if "C" in want:
-                add("C_kite_standin_1024", "C", workloads.kite_standin_batch(1024), 1024, 4, 1, "sqp_kernel<KiteStandInOCP> (464 KKT rows)",
+                add("C_kite_standin_1024", "C", workloads.kite_standin_batch(1024), 1024, 8, 1, "sqp_kernel<KiteStandInOCP> (464 KKT rows)",
                     "SYNTHETIC 13-state / 3-input stand-in (the reference tree has no kite model), P=5 S=3 (16 nodes), SQP max_iter=5")
             if "R" in want:
-                add("R_robot_16_nodes_2048", "R", workloads.robot_batch(2048, P=5, S=3), 2048, 5, 1, "sqp_kernel<RobotOCP> (128 KKT rows)",
+                add("R_robot_16_nodes_2048", "R", workloads.robot_batch(2048, P=5, S=3), 2048, 10, 1, "sqp_kernel<RobotOCP> (128 KKT rows)",
                     "mobile robot on the reference's mpc_wrapper_test grid, P=5 S=3 (16 nodes, n=80, m=48), 2048 instances (not a BASELINE.json configuration: the mid-size path)")
             if cfg:
                 out["configs"] = cfg
@@ -400,6 +405,26 @@ def main():
                                                         "identical_trajectory_fraction": float(((it_k == gi["iter"][:n_all]) & (qi_k == gi["qp_solver_iter"][:n_all])).mean()),
                                                         "bit_identical_x": bool(np.array_equal(gx[:n_all], xk)), "bit_identical_lam": bool(np.array_equal(gl[:n_all], lk)),
                                                         "max_abs_dx": float(np.abs(gx[:n_all] - xk).max())}
+            if "qp_replay" in out:
+                # ---- north_star's criterion on its own unit (one box-ADMM solve; SURVEY 8d: "max |D| of (x, y, res_prim, res_dual) GPU-vs-CPU"): the QPs the
+                # reference-order SQP emits for every configuration, through pmpc_qp_boxadmm_solve_batch (default kernels) against PIVOT_EIGEN. Not timed.
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import tools_cross_order as tco
+                qpar = {}
+                for letter, nq in (("A", 4096), ("D", 1024), ("B", 2048), ("R", 1024), ("C", 128)):
+                    if letter != "A" and letter not in [c for c in args.configs.split(",") if c]:
+                        continue
+                    qq = tco.traced_qp_stream(ob, letter, nq)
+                    gx_, gy_, gi_ = ctx.qp_solve_batch(qq["H"], qq["h"], qq["A"], qq["Alb"], qq["Aub"], qq["xlb"], qq["xub"], settings=qs)
+                    xr_, yr_, ir_ = tco.reference_qp_solve(ob, qq, threads=cores)
+                    rec_ = tco.qp_level_stats(gx_, gy_, gi_, xr_, yr_, ir_)
+                    rec_["n"], rec_["m"], rec_["instances_traced"] = qq["n"], qq["m"], qq["instances"]
+                    rec_["within_1e-8"] = bool(rec_["different_iter"] == 0 and rec_["different_status"] == 0 and rec_["max_abs_d_res_prim"] <= 1e-8 and rec_["max_abs_d_res_dual"] <= 1e-8)
+                    qpar[letter] = rec_
+                out["qp_replay"]["parity_vs_cpu_reference"] = {
+                    "what": "QPs of the reference-order SQP trajectories (Eigen-style pivoted LDLT, glibc), each solved once by the default GPU kernel of its "
+                            "size at the QP entry point and once by the restatement as the reference computes (PIVOT_EIGEN): every QP, no mask; res_prim / "
+                            "res_dual as defined at qp_base.hpp:240-252, box_admm.hpp:398-431", "configs": qpar}
             xs, ls_, is_ = cpu_run(Bc, cores, ob.PIVOT_SWEEP, False)
             out["parity_vs_cpu_same_order"] = parity(xs, ls_, is_, "CPU restatement in the kernel's own elimination order and with the shared IEEE-only sin/cos "
                                                                    "(pmpc_math.hpp): identical arithmetic on both sides, every instance, no mask")

@@ -172,6 +172,8 @@ struct sqp_settings_t {   // sqp_base.hpp:24-47 (+ the two override points as fl
     int qp_solver = 0;                 // QPSolver template argument: 0 boxADMM, 1 ADMM (OSQP form)
     int line_search = 0;               // step_size_selection_impl: 0 l1-merit backtracking (sqp_base.hpp:380-419), 1 the filter line search
                                        // of valet_parking_mpc_test.cpp:116-158 on LSFilter (line_search.hpp:31-98)
+    int kkt_form = 0;                  // pmpc_sqp_settings::kkt_form: 0 the kernels' default (large instances solve the condensed n x n system), 1 the
+                                       // reference's quasi-definite (n + m)-row KKT matrix of box_admm.hpp:209-223 on every route
     void (*iteration_callback)(void* solver) = nullptr;   // sqp_base.hpp:33, called at :685-686 once per iteration from the second one on. The fused
                                        // kernel records what the callback can read (pmpc_sqp_settings::iteration_trace); Solver<OCP>::solve() then
                                        // calls it once per recorded iteration with info().iter, primal_norm(), dual_norm(), cost() and
@@ -230,6 +232,23 @@ public:
         m_info.resize(B);
         pmpc_qp_settings_sqp_default(&m_qp_settings);   // SQPBase constructor overrides, sqp_base.hpp:83-90
     }
+    // The reference's SQPBase owns its state by value and is copyable (sqp_base.hpp:127-152). A copy takes the problem, the settings, the bounds, the
+    // iterates and the infos; it does NOT take the device contexts of set_devices() (they own streams and workspaces, and two solver objects must not
+    // share them): the copy solves on the calling thread's context until it is given devices of its own, and starts with empty filters.
+    BatchSolver(const BatchSolver& o)
+        : problem(o.problem), B(o.B), m_x(o.m_x), m_lam(o.m_lam), m_lbx(o.m_lbx), m_ubx(o.m_ubx), m_lbg(o.m_lbg), m_ubg(o.m_ubg), m_p(o.m_p),
+          m_info(o.m_info), m_trace(o.m_trace), m_trace_capacity(o.m_trace_capacity), m_settings(o.m_settings), m_qp_settings(o.m_qp_settings),
+          filter(o.filter) {}
+    BatchSolver& operator=(const BatchSolver& o) {
+        if (this != &o) {
+            problem = o.problem; B = o.B; m_x = o.m_x; m_lam = o.m_lam; m_lbx = o.m_lbx; m_ubx = o.m_ubx; m_lbg = o.m_lbg; m_ubg = o.m_ubg; m_p = o.m_p;
+            m_info = o.m_info; m_trace = o.m_trace; m_trace_capacity = o.m_trace_capacity; m_settings = o.m_settings; m_qp_settings = o.m_qp_settings;
+            filter = o.filter; m_multi.clear();
+        }
+        return *this;
+    }
+    BatchSolver(BatchSolver&&) = default;
+    BatchSolver& operator=(BatchSolver&&) = default;
     int batch() const { return B; }
     // SURVEY 8e — several devices: the batch is split into contiguous shards, one per entry of `devices` (one context, stream and host thread each;
     // listing a device twice gives it two shards: useful on a one-GPU box and in tests), no collective. An empty list returns to the calling
@@ -268,6 +287,7 @@ public:
         ss.eps_dual = m_settings.eps_dual; ss.max_iter = m_settings.max_iter; ss.line_search_max_iter = m_settings.line_search_max_iter;
         ss.regularisation = m_settings.regularisation; ss.exact_hessian_every_iter = m_settings.exact_hessian_every_iter ? 1 : 0;
         ss.preconditioner = m_settings.preconditioner; ss.hessian_update = m_settings.hessian_update; ss.qp_solver = m_settings.qp_solver;
+        ss.kkt_form = m_settings.kkt_form;
         { const pmpc_status fs = filter.bind(ctx, B, m_settings.line_search, ss); if (fs != PMPC_OK) return last_error() = fs; }
         double* trace_dev = nullptr;
         const int cap = m_settings.max_iter;
@@ -295,13 +315,17 @@ public:
     }
     // the same solve with the batch in contiguous shards [k B / N, (k+1) B / N) over the N contexts of set_devices(), one host thread per shard
     pmpc_status solve_sharded() noexcept {
-        if (m_settings.line_search == 1 || m_settings.iteration_callback != nullptr) return last_error() = PMPC_ERR_INVALID_ARGUMENT;
+        // per-instance device state of ONE context cannot follow the shards: no iteration records, and the filter line search runs with a
+        // filter that lives for the solve only (filter_state = nullptr — the C entry's rule), not the list carried between solve() calls
+        if (m_settings.iteration_callback != nullptr) return last_error() = PMPC_ERR_INVALID_ARGUMENT;
         pmpc_sqp_settings ss;
         pmpc_sqp_settings_default(&ss);
         ss.tau = m_settings.tau; ss.eta = m_settings.eta; ss.rho = m_settings.rho; ss.eps_prim = m_settings.eps_prim;
         ss.eps_dual = m_settings.eps_dual; ss.max_iter = m_settings.max_iter; ss.line_search_max_iter = m_settings.line_search_max_iter;
         ss.regularisation = m_settings.regularisation; ss.exact_hessian_every_iter = m_settings.exact_hessian_every_iter ? 1 : 0;
         ss.preconditioner = m_settings.preconditioner; ss.hessian_update = m_settings.hessian_update; ss.qp_solver = m_settings.qp_solver;
+        ss.kkt_form = m_settings.kkt_form;
+        ss.line_search = m_settings.line_search; ss.filter_max_depth = filter.max_depth; ss.filter_beta = filter.beta; ss.filter_state = nullptr;
         m_trace.clear(); m_trace_capacity = 0;
         const int N = (int)m_multi.size();
         std::vector<double> xo(m_x.size()), lo(m_lam.size());

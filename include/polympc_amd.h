@@ -276,7 +276,9 @@ pmpc_status pmpc_sqp_solve_batch(pmpc_context* ctx, int model, int P, int S, dou
  * contiguous ranges [k B / n_ctx, (k+1) B / n_ctx) of the instance-major arrays, no collective): one host thread per context stages its shard in,
  * launches on that context's stream and stages the results out, all shards concurrently; the call returns when every shard is back in the host
  * arrays. Arguments as pmpc_sqp_solve_batch. Per-instance device state (filter_state, iteration_trace) belongs to ONE context and is therefore
- * rejected here (PMPC_ERR_INVALID_ARGUMENT). Returns the first error of any shard. Two contexts on the same device are allowed (testing). */
+ * rejected here (PMPC_ERR_INVALID_ARGUMENT). Returns the first error of any shard. Two contexts on the same device are allowed (testing); the
+ * SAME context twice is rejected (PMPC_ERR_INVALID_ARGUMENT: one context serves one call at a time). Each context keeps its host thread from its
+ * first sharded call until pmpc_destroy, so a control loop pays no thread creation per step. */
 pmpc_status pmpc_sqp_solve_batch_multi(pmpc_context* const* ctxs, int n_ctx, int model, int P, int S, double t0, double tf,
                                        const double* mparams, int n_mparams, int B, const double* x_guess,
                                        const double* lam_guess, const double* d, const double* lbx, const double* ubx,

@@ -14,7 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liboracle.so")
 REF_PATH = os.path.join(HERE, "_ref", "libref_casadi_robot.so")
 
-PIVOT_EIGEN, PIVOT_STATIC, PIVOT_SWEEP, PIVOT_SWEEP1, PIVOT_SWEEP2, PIVOT_BLOCKED, PIVOT_CONDENSED = 0, 1, 2, 3, 4, 5, 6
+PIVOT_EIGEN, PIVOT_STATIC, PIVOT_SWEEP, PIVOT_SWEEP1, PIVOT_SWEEP2, PIVOT_BLOCKED, PIVOT_CONDENSED, PIVOT_SCHUR = 0, 1, 2, 3, 4, 5, 6, 7
+SCHUR_MAX_ROWS = 64    # PIVOT_SCHUR restates the block-structured kernel: at most 64 constraint rows (its m x m Schur complement is swept like PIVOT_SWEEP)
 SWEEP2_MAX_ROWS = 128   # PIVOT_SWEEP2 restates the two-rows-per-lane register kernel (65..128 KKT rows)
 
 
@@ -174,11 +175,41 @@ def ldlt_solve(K, b, pivot=PIVOT_EIGEN):
     return x
 
 
-def qp_solve_batch(H, h, A, Alb, Aub, xlb, xub, settings=None, pivot=PIVOT_EIGEN, x0=None, y0=None, threads=1):
-    """All arrays instance-major; matrices column-major per instance: H[b] is (n*n,), A[b] is (m*n,)."""
+def _schur_check(structure, n, m, H=None):
+    """PIVOT_SCHUR needs the collocation structure (nx, nu, nn, P) of the QP — and a Hessian that is block diagonal per node (checked here in numpy:
+    the C++ side throws inside an OpenMP region otherwise)."""
+    if structure is None:
+        raise ValueError("PIVOT_SCHUR: pass structure=(nx, nu, nn, P)")
+    nx, nu, nn, P = structure
+    if (nx + nu) * nn != n or nx * nn != m or m > SCHUR_MAX_ROWS or P < 1 or (nn - 1) % P != 0:
+        raise ValueError(f"PIVOT_SCHUR: structure {structure} does not describe a QP with n = {n}, m = {m} <= {SCHUR_MAX_ROWS}")
+    if H is not None:
+        node = np.concatenate([np.repeat(np.arange(nn), nx), np.repeat(np.arange(nn), nu)])
+        off = node[:, None] != node[None, :]
+        if np.any(H.reshape(-1, n, n)[:, off] != 0.0):
+            raise ValueError("PIVOT_SCHUR: the Hessian is not block diagonal per collocation node")
+    lib().orc_set_schur_structure(nx, nu, nn, P)
+
+
+def kkt_solve(K, rho_vec, rhs, pivot=PIVOT_EIGEN, structure=None):
+    """One KKT solve in the order of `pivot`: K = [P A'; A -1/rho] ([n+m, n+m] array, lower triangle read), rho_vec (m), rhs (n+m)."""
+    K = np.asarray(K, dtype=np.float64); m = len(rho_vec); n = K.shape[0] - m
+    if pivot == PIVOT_SCHUR:
+        _schur_check(structure, n, m)
+    _check_sweep(pivot, n + m)
+    sol = np.zeros(n + m)
+    Kc = np.ascontiguousarray(K.T).ravel().copy()
+    lib().orc_kkt_solve(n, m, _p(Kc), _p(_f(rho_vec)), _p(_f(rhs)), pivot, _p(sol))
+    return sol
+
+
+def qp_solve_batch(H, h, A, Alb, Aub, xlb, xub, settings=None, pivot=PIVOT_EIGEN, x0=None, y0=None, threads=1, structure=None):
+    """All arrays instance-major; matrices column-major per instance: H[b] is (n*n,), A[b] is (m*n,). structure = (nx, nu, nn, P): PIVOT_SCHUR only."""
     H = _f(H); h = _f(h); A = _f(A); Alb = _f(Alb); Aub = _f(Aub); xlb = _f(xlb); xub = _f(xub)
     B, n = h.shape
     m = Alb.shape[1] if Alb.ndim == 2 else 0
+    if pivot == PIVOT_SCHUR:
+        _schur_check(structure, n, m, H)
     _check_sweep(pivot, n + m)
     s = settings or qp_default_settings()
     x = np.zeros((B, n)); y = np.zeros((B, n + m)); info = (QPInfo * B)()
@@ -264,6 +295,16 @@ def ocp_eval(model, P, S, t0, tf, var, d, lam=None, mparams=None):
                 cost_hess=ch.reshape(n, n).T.copy(), lag_grad=lg, lag_hess=lh.reshape(n, n).T.copy())
 
 
+def _sqp_schur_check(dm, P, ss):
+    """PIVOT_SCHUR inside the SQP: the Hessian must stay block diagonal per node — block BFGS or exact Hessians, no parameters, no path constraints,
+    default regularisation or the (diagonal) Gershgorin shift, no preconditioner, boxADMM."""
+    ok = (ss.hessian_update == 1 or ss.exact_hessian_every_iter) and dm["np"] == 0 and dm["ng"] == 0 and ss.regularisation in (0, 2) and \
+         ss.preconditioner == 0 and ss.qp_solver == 0 and dm["m"] <= SCHUR_MAX_ROWS
+    if not ok:
+        raise ValueError("PIVOT_SCHUR restates the block-structured kernel: hessian_update = 1 or exact Hessians, NP = NG = 0, m <= 64, "
+                         "regularisation 0 / 2, no preconditioner, boxADMM")
+
+
 def _sqp_argtypes(extra_tail):
     dp = C.POINTER(C.c_double)
     return [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, dp, C.c_int] + extra_tail
@@ -275,6 +316,8 @@ def sqp_solve_batch(model, P, S, t0, tf, B, d, lbx, ubx, lbg=None, ubg=None, x_g
     n, m = dm["n"], dm["m"]
     _check_sweep(pivot, n + m)
     ss = sqp_settings or sqp_default_settings(); qs = qp_settings or sqp_qp_default_settings()
+    if pivot == PIVOT_SCHUR:
+        _sqp_schur_check(dm, P, ss)
     x = np.zeros((B, n)); lam = np.zeros((B, m + n)); info = (SQPInfo * B)()
     mp = _f(mparams) if mparams is not None else None
     dp = C.POINTER(C.c_double)
@@ -292,6 +335,8 @@ def sqp_trace_qps(model, P, S, t0, tf, d, lbx, ubx, lbg=None, ubg=None, x_guess=
     n, m = dm["n"], dm["m"]
     _check_sweep(pivot, n + m)
     ss = sqp_settings or sqp_default_settings(); qs = qp_settings or sqp_qp_default_settings()
+    if pivot == PIVOT_SCHUR:
+        _sqp_schur_check(dm, P, ss)
     H = np.zeros((max_qps, n * n)); h = np.zeros((max_qps, n)); A = np.zeros((max_qps, m * n))
     al = np.zeros((max_qps, m)); au = np.zeros((max_qps, m)); lx = np.zeros((max_qps, n)); ux = np.zeros((max_qps, n))
     mp = _f(mparams) if mparams is not None else None

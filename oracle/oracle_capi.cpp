@@ -165,6 +165,20 @@ void orc_ruiz_unscale_solution_batch(int B, int n, int m, const double* D, const
     }
 }
 
+static BoxADMM::SchurStruct g_schur;   // collocation structure of the QPs handed to orc_qp_solve_batch with PIVOT_SCHUR (set before the call)
+void orc_set_schur_structure(int nx, int nu, int nn, int P) { g_schur.nx = nx; g_schur.nu = nu; g_schur.nn = nn; g_schur.P = P; }
+
+/* one KKT solve in the order of `pivot` (any policy, PIVOT_CONDENSED / PIVOT_SCHUR included): K = [P A'; A -diag(rho_inv)] given by its lower
+   triangle, (n+m)^2 column-major; accuracy probes of the restated orders */
+void orc_kkt_solve(int n, int m, const double* K, const double* rho_vec, const double* rhs, int pivot, double* sol) {
+    BoxADMM qp(n, m);
+    qp.pivot = (pivot_policy)pivot; qp.schur = g_schur;
+    qp.K.assign(K, K + (size_t)(n + m) * (n + m));
+    for (int i = 0; i < m; ++i) { qp.rho_vec[i] = rho_vec[i]; qp.rho_inv_vec[i] = 1.0 / rho_vec[i]; }
+    qp.factorise();
+    qp.kkt_solve(rhs, sol);
+}
+
 void orc_qp_solve_batch(int B, int n, int m, const double* H, const double* h, const double* A, const double* Alb,
                         const double* Aub, const double* xlb, const double* xub, const double* x0, const double* y0,
                         const orc_qp_settings* s, int pivot, int threads, double* x, double* y, orc_qp_info* info) {
@@ -173,6 +187,7 @@ void orc_qp_solve_batch(int B, int n, int m, const double* H, const double* h, c
         BoxADMM qp(n, m);
         qp.settings = to_qp(s);
         qp.pivot = (pivot_policy)pivot;
+        qp.schur = g_schur;
         const double* Hb = H + (size_t)b * n * n; const double* hb = h + (size_t)b * n;
         const double* Ab = A + (size_t)b * m * n;
         const double* alb = Alb + (size_t)b * m; const double* aub = Aub + (size_t)b * m;
@@ -239,6 +254,7 @@ static void setup_solver(SQP<ContinuousOCP<Model>>& sqp, int b, const double* x_
     sqp.settings = to_sqp(ss);
     sqp.qp.settings = to_qp(qs);
     sqp.qp.pivot = (pivot_policy)pivot;
+    if (pivot == PIVOT_SCHUR) { sqp.qp.schur.nx = Model::NX; sqp.qp.schur.nu = Model::NU; sqp.qp.schur.nn = sqp.problem.NN; sqp.qp.schur.P = sqp.problem.P; }
     for (int i = 0; i < Model::ND; ++i) sqp.p_static[i] = d[(size_t)b * Model::ND + i];
     if (lbx) for (int i = 0; i < n; ++i) sqp.lbx[i] = lbx[(size_t)b * n + i];
     if (ubx) for (int i = 0; i < n; ++i) sqp.ubx[i] = ubx[(size_t)b * n + i];

@@ -65,10 +65,17 @@ void orc_bfgs(int n, double* B, const double* s, const double* y);
 void orc_regularise(int kind, int n, double* H);
 void orc_ldlt_solve(int n, const double* K, const double* b, int pivot, double* x);
 
+/* one KKT solve in the order of `pivot` (every policy): K (n+m)^2 column-major, lower triangle; rho_vec: the m step sizes of the constraint rows */
+void orc_kkt_solve(int n, int m, const double* K, const double* rho_vec, const double* rhs, int pivot, double* sol);
+
 /* batch of B QPs, instance-major, column-major matrices; x0/y0 may be NULL (zero guesses). threads<=1: serial */
 void orc_qp_solve_batch(int B, int n, int m, const double* H, const double* h, const double* A, const double* Alb,
                         const double* Aub, const double* xlb, const double* xub, const double* x0, const double* y0,
                         const orc_qp_settings* s, int pivot, int threads, double* x, double* y, orc_qp_info* info);
+
+/* PIVOT_SCHUR (7) at the QP entry: the collocation structure of the QPs of the next orc_qp_solve_batch calls — variables [x_0..x_{nn-1} | u_0..u_{nn-1}],
+ * equality rows (node, state), P intervals per segment (the SQP entry points take it from the problem) */
+void orc_set_schur_structure(int nx, int nu, int nn, int P);
 
 /* boxADMM<N, M, float> (box_admm_test.cpp:85-115): float arrays; pivot = PIVOT_EIGEN or PIVOT_STATIC; the info's floats are widened */
 void orc_qp_solve_batch_f32(int B, int n, int m, const float* H, const float* h, const float* A, const float* Alb, const float* Aub,

@@ -23,6 +23,11 @@
 //   PIVOT_SWEEP2 : PIVOT_SWEEP's blocked sweep for 65..128 rows with the mat-vec order of the two-rows-per-lane register kernel
 //   PIVOT_SWEEP1 : the swept inverse of PIVOT_SWEEP one pivot at a time on the lower triangle (any size), x = -(W b) as one fma chain
 //                  per row: accuracy evidence for the explicit-inverse route above 64 rows (no shipped kernel uses it this round).
+//   PIVOT_SCHUR  : (round 4) the order of the block-structured kernel (polympc_amd/csrc/pmpc_qp_schur.hpp) that serves a Hessian which is
+//                  block diagonal per collocation node — what ContinuousOCP's block BFGS (continuous_ocp.hpp:2304-2431) and the exact Lagrangian
+//                  Hessian keep. The per-node blocks of H + sigma I + rho_box are inverted one by one, the m x m Schur complement
+//                  1/rho + A P^{-1} A' is swept like PIVOT_SWEEP, and a solve is two block products, two sparse products with A and one
+//                  m x m mat-vec (BoxADMM::factorise_schur / kkt_solve_schur below).
 // All matrices column-major.
 #pragma once
 #include <algorithm>
@@ -34,7 +39,7 @@
 namespace oracle {
 
 enum qp_status { QP_SOLVED = 0, QP_MAX_ITER_EXCEEDED = 1, QP_UNSOLVED = 2, QP_UNINITIALIZED = 3, QP_INFEASIBLE = 4, QP_INCONSISTENT = 5 };
-enum pivot_policy { PIVOT_EIGEN = 0, PIVOT_STATIC = 1, PIVOT_SWEEP = 2, PIVOT_SWEEP1 = 3, PIVOT_SWEEP2 = 4, PIVOT_BLOCKED = 5, PIVOT_CONDENSED = 6 };
+enum pivot_policy { PIVOT_EIGEN = 0, PIVOT_STATIC = 1, PIVOT_SWEEP = 2, PIVOT_SWEEP1 = 3, PIVOT_SWEEP2 = 4, PIVOT_BLOCKED = 5, PIVOT_CONDENSED = 6, PIVOT_SCHUR = 7 };
 
 struct qp_settings {  // qp_base.hpp:17-53 (ADMM-related subset)
     double eps_rel = 1e-3, eps_abs = 1e-3;
@@ -150,10 +155,12 @@ struct LDLT {
         for (int j = 0; j < n; ++j) for (int i = 0; i < j; ++i) M[i + j * n] = M[j + i * n];   // mirror for solve()
     }
 
-    void compute_sweep() {
+    // tiles_as_given: the diagonal 16 x 16 tiles are taken as they are (both triangles as the caller computed them — PIVOT_SCHUR forms its rows
+    // one per lane and the two triangles of a diagonal tile differ in the last bit); tiles above the block diagonal are mirror images as always
+    void compute_sweep(bool tiles_as_given = false) {
         auto at = [&](int i, int j) -> double& { return M[i + j * n]; };
         for (int k = 0; k < n; ++k) tr[k] = k;
-        for (int j = 0; j < n; ++j) for (int i = 0; i < j; ++i) at(i, j) = at(j, i);   // full symmetric storage
+        for (int j = 0; j < n; ++j) for (int i = 0; i < j; ++i) if (!tiles_as_given || i / 16 < j / 16) at(i, j) = at(j, i);   // full symmetric storage
         const int BK = 4;   // block size of the kernel (RegKkt::BK)
         std::vector<double> p((size_t)n * BK), cold((size_t)n * BK), l(n);
         for (int kb = 0; kb < n; kb += BK) {
@@ -260,6 +267,9 @@ struct BoxADMM {
     qp_settings settings;
     qp_info info;
     pivot_policy pivot = PIVOT_EIGEN;
+    // PIVOT_SCHUR: the collocation structure of the QP (variables [x_0 .. x_{nn-1} | u_0 .. u_{nn-1}], equality rows (node, state), P intervals per
+    // segment — continuous_ocp.hpp:757-765, :797-878); set by the SQP driver from the problem's dimensions, by tests through orc_set_schur_structure
+    struct SchurStruct { int nx = 0, nu = 0, nn = 0, P = 0; } schur;
     std::vector<double> x, y;  // primal N, dual M+N ([general | box])
     std::vector<double> x_tilde, q, z, z_tilde, z_prev, rho_vec, rho_inv_vec, rho_box, rho_box_inv, rho_box_prev;
     std::vector<int> constr_type, box_type;
@@ -363,7 +373,133 @@ struct BoxADMM {
     // skipped in the two vector products, which is what a kernel that walks the block-sparse structure of A does — and unlike "adds an exact zero"
     // it is the same statement for non-finite operands.
     std::vector<double> Sc;
+    // ---- PIVOT_SCHUR -------------------------------------------------------------------------------------------------------------------------
+    // K = [P A'; A -1/rho] with P = H + sigma I + rho_box block diagonal per node (d = nx + nu entries: x_k then u_k) and A = J of a
+    // Chebyshev collocation: row (ni, si) holds the differentiation-matrix entry Dt(ni, k) on column (k, si) for the nodes k != ni of the
+    // segment that produces node ni, and the own-node block b (d entries, the D self entry included) on the columns of node ni.
+    //   factorise:  Q_k = P_k^{-1}  (symmetric sweep on the lower triangle, one pivot at a time, pivots ascending; Q = -(swept matrix), mirrored)
+    //               G row i:  g_k[c] = sum_c' fma(b_i[c'], Q_k(c', c), .)  (k = ni, c' ascending from 0);  Dt(ni, k) * Q_k(si, c)  (k coupled);  0
+    //               S(i, j) = [i == j] / rho_i, then fma(g_nj[c], b_j[c], .) c ascending, then fma(g_k[sj], Dt(nj, k), .) over the coupled k ascending
+    //               W = -S^{-1}  by PIVOT_SWEEP's blocked sweep on the block-lower tiles, diagonal tiles as the rows gave them
+    //   solve:      t = Q r1 (per node, fma chain c' ascending);  g_i = (own block fma chain over c, then coupled nodes k ascending) - r2_i;
+    //               nu = S^{-1} g (PIVOT_SWEEP's mat-vec);  w = A' nu (own block: rows q ascending; then coupled row nodes ascending);
+    //               x = Q (r1 - w);  then one refinement step on the constraint rows (kkt_solve_schur)
+    std::vector<double> Qs, gws;
+    int sg(int k, int c) const { return c < schur.nx ? k * schur.nx + c : schur.nx * schur.nn + k * schur.nu + (c - schur.nx); }
+    bool coupled(int rownode, int k) const {   // Dt(rownode, k) structurally non-zero, own node excluded (its D entry lives in the block)
+        const int kb = (rownode == schur.nn - 1) ? schur.nn - 1 - schur.P : (rownode / schur.P) * schur.P;
+        return k != rownode && k >= kb && k <= kb + schur.P;
+    }
+    double Aent(int r, int c) const { return K[(N + r) + c * (N + M)]; }
+    void schur_check() const {
+        const int nx = schur.nx, nu = schur.nu, nn = schur.nn, d = nx + nu, NM = N + M;
+        if (nx < 1 || nn < 2 || schur.P < 1 || (nn - 1) % schur.P != 0 || d * nn != N || nx * nn != M)
+            throw std::invalid_argument("oracle: PIVOT_SCHUR needs the collocation structure (nx, nu, nn, P) of a QP with n = (nx+nu) nn, m = nx nn");
+        std::vector<int> node(N), loc(N);
+        for (int k = 0; k < nn; ++k) for (int c = 0; c < d; ++c) { node[sg(k, c)] = k; loc[sg(k, c)] = c; }
+        for (int j = 0; j < N; ++j) for (int i = j; i < N; ++i)
+            if (node[i] != node[j] && K[i + j * NM] != 0.0) throw std::invalid_argument("oracle: PIVOT_SCHUR: the Hessian is not block diagonal per node");
+        for (int r = 0; r < M; ++r) for (int c = 0; c < N; ++c) {
+            const int ni = r / nx, si = r % nx;
+            const bool ok = node[c] == ni || (loc[c] == si && coupled(ni, node[c]));
+            if (!ok && Aent(r, c) != 0.0) throw std::invalid_argument("oracle: PIVOT_SCHUR: A is not a collocation Jacobian of the given structure");
+        }
+    }
+    void factorise_schur() {
+        schur_check();
+        const int nx = schur.nx, nn = schur.nn, d = nx + schur.nu, NM = N + M;
+        Qs.assign((size_t)nn * d * d, 0.0);
+        std::vector<double> Mk(d * d), c(d), l(d);
+        for (int k = 0; k < nn; ++k) {
+            for (int j = 0; j < d; ++j) for (int i = j; i < d; ++i) Mk[i + j * d] = K[sg(k, i) + sg(k, j) * NM];
+            auto lo = [&](int i, int j) -> double& { return i >= j ? Mk[i + j * d] : Mk[j + i * d]; };
+            for (int p = 0; p < d; ++p) {
+                const double r = 1.0 / lo(p, p);
+                for (int i = 0; i < d; ++i) { c[i] = lo(i, p); l[i] = c[i] * r; }
+                for (int j = 0; j < d; ++j) {
+                    if (j == p) continue;
+                    for (int i = j; i < d; ++i) { if (i == p) continue; Mk[i + j * d] = std::fma(-l[i], c[j], Mk[i + j * d]); }
+                }
+                for (int i = 0; i < d; ++i) if (i != p) lo(i, p) = l[i];
+                lo(p, p) = -r;
+            }
+            for (int j = 0; j < d; ++j) for (int i = 0; i < d; ++i) Qs[(size_t)k * d * d + i + j * d] = -lo(i, j);
+        }
+        auto Q = [&](int k, int i, int j) { return Qs[(size_t)k * d * d + i + j * d]; };
+        std::vector<double> S((size_t)M * M, 0.0), g((size_t)nn * d);
+        for (int i = 0; i < M; ++i) {
+            const int ni = i / nx, si = i % nx;
+            for (int k = 0; k < nn; ++k)
+                for (int cc = 0; cc < d; ++cc) {
+                    double a = 0.0;
+                    if (k == ni) { for (int c2 = 0; c2 < d; ++c2) a = std::fma(Aent(i, sg(ni, c2)), Q(k, c2, cc), a); }
+                    else if (coupled(ni, k)) a = Aent(i, k * nx + si) * Q(k, si, cc);
+                    g[(size_t)k * d + cc] = a;
+                }
+            for (int j = 0; j < M; ++j) {
+                if (j / 16 > i / 16) continue;   // block-lower tile storage: tiles above the block diagonal are mirror images
+                const int nj = j / nx, sj = j % nx;
+                double a = (i == j) ? rho_inv_vec[i] : 0.0;
+                for (int cc = 0; cc < d; ++cc) a = std::fma(g[(size_t)nj * d + cc], Aent(j, sg(nj, cc)), a);
+                for (int k = 0; k < nn; ++k) if (coupled(nj, k)) a = std::fma(g[(size_t)k * d + sj], Aent(j, k * nx + sj), a);
+                S[i + (size_t)j * M] = a;
+            }
+        }
+        ldlt.n = M; ldlt.policy = PIVOT_SWEEP; ldlt.M = S; ldlt.tr.assign(M, 0); ldlt.temp.assign(M, 0.0);
+        if (M > 64) throw std::invalid_argument("oracle: PIVOT_SCHUR restates a kernel with at most 64 constraint rows");
+        ldlt.compute_sweep(true);
+    }
+    // x = Q (r1 - A' nu) for a given nu: w = A' nu (own block: rows q ascending; then the coupled row nodes ascending), u = r1 - w, x = Q u
+    void schur_primal(const double* rhs, const double* nu, double* xs) const {
+        const int nx = schur.nx, nn = schur.nn, d = nx + schur.nu;
+        auto Q = [&](int k, int i, int j) { return Qs[(size_t)k * d * d + i + j * d]; };
+        std::vector<double> u(N);
+        for (int k = 0; k < nn; ++k) for (int cc = 0; cc < d; ++cc) {
+            double a = 0.0;
+            for (int q2 = 0; q2 < nx; ++q2) a = std::fma(Aent(k * nx + q2, sg(k, cc)), nu[k * nx + q2], a);
+            if (cc < nx) for (int kr = 0; kr < nn; ++kr) if (coupled(kr, k)) a = std::fma(Aent(kr * nx + cc, k * nx + cc), nu[kr * nx + cc], a);
+            u[sg(k, cc)] = rhs[sg(k, cc)] - a;
+        }
+        for (int k = 0; k < nn; ++k) for (int cc = 0; cc < d; ++cc) {
+            double a = 0.0;
+            for (int c2 = 0; c2 < d; ++c2) a = std::fma(Q(k, cc, c2), u[sg(k, c2)], a);
+            xs[sg(k, cc)] = a;
+        }
+    }
+    // (A v)_i as the kernel forms it: own block fma chain over c ascending, then the coupled nodes k ascending, from `init`
+    double schur_rowdot(int i, const double* v, double init) const {
+        const int nx = schur.nx, nn = schur.nn, d = nx + schur.nu, ni = i / nx, si = i % nx;
+        double a = init;
+        for (int cc = 0; cc < d; ++cc) a = std::fma(Aent(i, sg(ni, cc)), v[sg(ni, cc)], a);
+        for (int k = 0; k < nn; ++k) if (coupled(ni, k)) a = std::fma(Aent(i, k * nx + si), v[k * nx + si], a);
+        return a;
+    }
+    // One solve = the range-space solve and ONE step of iterative refinement on the constraint rows. The explicit (swept) inverse of S has an
+    // isotropic forward error ~ eps cond(S) |nu|, whereas x = Q (r1 - A' nu) tolerates errors of nu only in the near-null directions of
+    // Q^(1/2) A' (measured on config B's QPs after a rho update, cond(S) = 6e5: |dx| 2e-9 .. 2e-8 without the step, 2e-13 with it — the dense
+    // orders reach 8e-12). The first block row holds to working precision by construction, so the residual lives in the second one:
+    //   e = (A x - nu / rho) - r2,   nu += S^{-1} e... sign: K [dx; dnu] = [0; -e]  <=>  -S dnu = -e,   then x = Q (r1 - A' nu) again.
+    void kkt_solve_schur(const double* rhs, double* sol) {
+        const int nx = schur.nx, nn = schur.nn, d = nx + schur.nu;
+        auto Q = [&](int k, int i, int j) { return Qs[(size_t)k * d * d + i + j * d]; };
+        std::vector<double> t(N), gv(M), nu(M), dnu(M), xs(N);
+        for (int k = 0; k < nn; ++k) for (int cc = 0; cc < d; ++cc) {
+            double a = 0.0;
+            for (int c2 = 0; c2 < d; ++c2) a = std::fma(Q(k, cc, c2), rhs[sg(k, c2)], a);
+            t[sg(k, cc)] = a;
+        }
+        for (int i = 0; i < M; ++i) gv[i] = schur_rowdot(i, t.data(), 0.0) - rhs[N + i];
+        ldlt.solve(gv.data(), nu.data());
+        schur_primal(rhs, nu.data(), xs.data());
+        for (int i = 0; i < M; ++i) gv[i] = std::fma(-rho_inv_vec[i], nu[i], schur_rowdot(i, xs.data(), 0.0)) - rhs[N + i];
+        ldlt.solve(gv.data(), dnu.data());
+        for (int i = 0; i < M; ++i) nu[i] = nu[i] + dnu[i];
+        schur_primal(rhs, nu.data(), xs.data());
+        for (int i = 0; i < N; ++i) sol[i] = xs[i];
+        for (int i = 0; i < M; ++i) sol[N + i] = nu[i];
+    }
     void factorise() {
+        if (pivot == PIVOT_SCHUR) { factorise_schur(); return; }
         if (pivot != PIVOT_CONDENSED) { ldlt.compute(K, N + M, pivot); return; }
         const int NM = N + M;
         Sc.assign((size_t)N * N, 0.0);
@@ -376,6 +512,7 @@ struct BoxADMM {
         ldlt.compute(Sc, N, PIVOT_BLOCKED);
     }
     void kkt_solve(const double* rhs, double* sol) {
+        if (pivot == PIVOT_SCHUR) { kkt_solve_schur(rhs, sol); return; }
         if (pivot != PIVOT_CONDENSED) { ldlt.solve(rhs, sol); return; }
         const int NM = N + M;
         std::vector<double> t(N), xs(N);

@@ -170,6 +170,8 @@ static pmpc_status create_impl(int device, void* stream, pmpc_context* ctx) {
 }
 pmpc_status pmpc_destroy(pmpc_context* ctx) {
     if (!ctx) return PMPC_ERR_INVALID_ARGUMENT;
+    delete ctx->shard_worker;   // joins the shard thread (idle unless a sharded call is in flight, which the caller must not destroy under)
+    ctx->shard_worker = nullptr;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->cheb_cache) (void)hipFree(kv.second);
@@ -637,33 +639,47 @@ pmpc_status pmpc_sqp_solve_batch(pmpc_context* ctx, int model, int P, int S, dou
 }
 
 
-/* contiguous shards over n_ctx contexts, one host thread per context, no collective */
+/* contiguous shards over n_ctx contexts, one PERSISTENT host thread per context (started on the context's first sharded call, joined
+   by pmpc_destroy), no collective. The contexts must be distinct objects (two contexts on one device are fine; one context twice is not: its
+   stream, workspace and staging buffers serve one call at a time). */
 pmpc_status pmpc_sqp_solve_batch_multi(pmpc_context* const* ctxs, int n_ctx, int model, int P, int S, double t0, double tf, const double* mparams,
                                        int n_mparams, int B, const double* x_guess, const double* lam_guess, const double* d, const double* lbx,
                                        const double* ubx, const double* lbg, const double* ubg, const pmpc_sqp_settings* ss,
                                        const pmpc_qp_settings* qs, double* x, double* lam, pmpc_sqp_info* info) {
     if (!ctxs || n_ctx < 1 || B < 0 || !lbx || !ubx || !ss || !qs || !x || !lam || !info) return PMPC_ERR_INVALID_ARGUMENT;
-    for (int k = 0; k < n_ctx; ++k) if (!ctxs[k]) return PMPC_ERR_INVALID_ARGUMENT;
+    for (int k = 0; k < n_ctx; ++k) {
+        if (!ctxs[k]) return PMPC_ERR_INVALID_ARGUMENT;
+        for (int j = 0; j < k; ++j) if (ctxs[j] == ctxs[k]) return PMPC_ERR_INVALID_ARGUMENT;
+    }
     if (ss->filter_state || ss->iteration_trace) return PMPC_ERR_INVALID_ARGUMENT;   // device buffers of one context
     int nx, nu, np, nd, ng, n, me, mi;
     const pmpc_status ds = pmpc_ocp_dims(model, P, S, &nx, &nu, &np, &nd, &ng, &n, &me, &mi);
     if (ds != PMPC_OK) return ds;
     if (B == 0) return PMPC_OK;
     const int m = me + mi;
-    std::vector<pmpc_status> st((size_t)n_ctx, PMPC_OK);
-    std::vector<std::thread> th;
-    for (int k = 0; k < n_ctx; ++k) {
-        const long long b0 = (long long)B * k / n_ctx, b1 = (long long)B * (k + 1) / n_ctx;
-        if (b1 <= b0) continue;
-        th.emplace_back([=, &st]() {
-            auto at = [&](const double* p, size_t per) { return p ? p + (size_t)b0 * per : nullptr; };
-            st[k] = pmpc_sqp_solve_batch(ctxs[k], model, P, S, t0, tf, mparams, n_mparams, (int)(b1 - b0), at(x_guess, n), at(lam_guess, m + n),
-                                         at(d, nd), at(lbx, n), at(ubx, n), at(lbg, mi), at(ubg, mi), ss, qs, x + (size_t)b0 * n,
-                                         lam + (size_t)b0 * (m + n), info + b0);
-        });
+    try {   // nothing may leave an extern "C" function by exception (std::bad_alloc, std::system_error from a thread that cannot be created)
+        std::vector<pmpc_status> st((size_t)n_ctx, PMPC_OK);
+        std::vector<int> posted;
+        for (int k = 0; k < n_ctx; ++k) {
+            if ((long long)B * (k + 1) / n_ctx <= (long long)B * k / n_ctx) continue;
+            if (!ctxs[k]->shard_worker) ctxs[k]->shard_worker = new ShardWorker();
+            if (!ctxs[k]->shard_worker->start()) { for (int j : posted) ctxs[j]->shard_worker->wait(); return PMPC_ERR_HIP; }
+            const long long b0 = (long long)B * k / n_ctx, b1 = (long long)B * (k + 1) / n_ctx;
+            pmpc_status* out = &st[k];
+            pmpc_context* ctx = ctxs[k];
+            ctx->shard_worker->post([=]() {
+                auto at = [&](const double* p, size_t per) { return p ? p + (size_t)b0 * per : nullptr; };
+                *out = pmpc_sqp_solve_batch(ctx, model, P, S, t0, tf, mparams, n_mparams, (int)(b1 - b0), at(x_guess, n), at(lam_guess, m + n),
+                                            at(d, nd), at(lbx, n), at(ubx, n), at(lbg, mi), at(ubg, mi), ss, qs, x + (size_t)b0 * n,
+                                            lam + (size_t)b0 * (m + n), info + b0);
+            });
+            posted.push_back(k);
+        }
+        for (int k : posted) ctxs[k]->shard_worker->wait();
+        for (int k = 0; k < n_ctx; ++k) if (st[k] != PMPC_OK) return st[k];
+    } catch (...) {
+        return PMPC_ERR_HIP;
     }
-    for (auto& t : th) t.join();
-    for (int k = 0; k < n_ctx; ++k) if (st[k] != PMPC_OK) return st[k];
     return PMPC_OK;
 }
 

@@ -2,14 +2,54 @@
 // translation units of libpolympc_amd.so (pmpc_api.hip and one pmpc_model_*.hip per built-in OCP).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <condition_variable>
 #include <cstdio>
+#include <functional>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <tuple>
 #include "../../include/polympc_amd.h"
 #include "pmpc_cheb.hpp"
 
 using pmpc::ChebData;
 using pmpc::make_cheb_data;
+
+// The host thread that drives one context's shard in pmpc_sqp_solve_batch_multi (one host thread + stream per device). It is started
+// on the first sharded call and lives as long as the context, so a receding-horizon loop does not create and join a thread per device and step.
+struct ShardWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, done = false, stop = false;
+    bool start() {
+        if (th.joinable()) return true;
+        try { th = std::thread([this] { loop(); }); } catch (...) { return false; }
+        return true;
+    }
+    void loop() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [this] { return has_job || stop; });
+            if (stop) return;
+            std::function<void()> j; j.swap(job); has_job = false;
+            lk.unlock();
+            j();
+            lk.lock();
+            done = true;
+            cv.notify_all();
+        }
+    }
+    void post(std::function<void()> j) { { std::lock_guard<std::mutex> lk(mu); job = std::move(j); has_job = true; done = false; } cv.notify_all(); }
+    void wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return done; }); }
+    ~ShardWorker() {
+        if (!th.joinable()) return;
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        th.join();
+    }
+};
 
 // =====================================================================================================================
 // context
@@ -30,6 +70,7 @@ struct pmpc_context {
     std::map<std::tuple<int, int, double, double>, ChebData*> cheb_cache;
     double* ws = nullptr; size_t ws_bytes = 0;       // SQP HBM workspace (H, J)
     void* scratch[24] = {nullptr}; size_t scratch_bytes[24] = {0};  // host-buffer API staging
+    ShardWorker* shard_worker = nullptr;             // pmpc_sqp_solve_batch_multi: this context's persistent host thread (created on first use)
 };
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "polympc_amd: %s failed: %s (%s:%d)\n", #call, hipGetErrorString(e_), __FILE__, __LINE__); return PMPC_ERR_HIP; } } while (0)

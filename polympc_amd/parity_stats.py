@@ -56,3 +56,25 @@ def cross_order_stats(cfg, wl, x, lam, info, xr, lamr, inforef):
         "scaling": "dx per variable / its box or steady-state magnitude (CSTR: states 1, 0.5, 100, 100, inputs 35, 9000; robot: states 1, inputs 1.5, 0.75; "
                    "stand-in: 1); dlam per instance / max(1, |lam_ref|_inf)",
     }
+
+
+def qp_level_stats(x, y, info, xr, yr, inforef):
+    """ONE box-ADMM solve per QP (SURVEY 8d's unit; north_star: "primal/dual KKT residual within 1e-8 of CPU reference"): a solution set under test
+    (x [Q, n], y [Q, m + n], info: structured array or list with status / iter / rho_updates / res_prim / res_dual — the quantities of
+    qp_base.hpp:240-252 and box_admm.hpp:398-431) against the reference-order solve of the same QPs. No masks: every QP enters."""
+    def col(inf, f):
+        return np.asarray(inf[f]) if isinstance(inf, np.ndarray) else np.array([getattr(i, f) for i in inf])
+    pct = lambda v: {"p50": float(np.percentile(v, 50)), "p99": float(np.percentile(v, 99)), "max": float(v.max())}
+    dx = np.abs(x - xr).max(axis=1); dy = np.abs(y - yr).max(axis=1)
+    ys = dy / np.maximum(1.0, np.abs(yr).max(axis=1))
+    drp = np.abs(col(info, "res_prim") - col(inforef, "res_prim")); drd = np.abs(col(info, "res_dual") - col(inforef, "res_dual"))
+    return {
+        "qps": int(x.shape[0]),
+        "different_iter": int((col(info, "iter") != col(inforef, "iter")).sum()),
+        "different_status": int((col(info, "status") != col(inforef, "status")).sum()),
+        "different_rho_updates": int((col(info, "rho_updates") != col(inforef, "rho_updates")).sum()),
+        "max_abs_d_res_prim": float(drp.max()), "max_abs_d_res_dual": float(drd.max()),
+        "abs_dx_per_qp": pct(dx), "abs_dy_per_qp": pct(dy), "scaled_dy_per_qp": pct(ys),
+        "mean_admm_iterations": float(col(inforef, "iter").mean()),
+        "solved_fraction_reference": float((col(inforef, "status") == 0).mean()),
+    }

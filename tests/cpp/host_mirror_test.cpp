@@ -350,6 +350,32 @@ static void ShardedBatchSolverMatchesSingleContext() {
     std::printf("  pmpc_sqp_solve_batch_multi over 2 contexts == 1 context bitwise: %s; route of the shard launches: %d\n", csame ? "yes" : "NO", pmpc_sqp_last_route(c2[0]));
     EXPECT_TRUE(csame);
     EXPECT_EQ(pmpc_sqp_last_route(c2[0]), (int)PMPC_ROUTE_REG1);
+    // a copied solver is a solver (the reference's SQPBase is copyable): same data, no shared device contexts, same results
+    BatchSolver<Builtin> copy(many);
+    EXPECT_EQ(copy.num_shards(), 1);
+    for (int b = 0; b < B; ++b) for (int i = 0; i < 35; ++i) copy.primal_solution(b)[i] = 0.0;
+    for (int b = 0; b < B; ++b) for (int i = 0; i < 56; ++i) copy.dual_solution(b)[i] = 0.0;
+    EXPECT_EQ(copy.solve(), PMPC_OK);
+    Solver<Builtin> single; single.settings().max_iter = 7; single.settings().kkt_form = 1;
+    Solver<Builtin> single_copy(single); Solver<Builtin> assigned; assigned = single;
+    EXPECT_EQ(single_copy.settings().max_iter, 7); EXPECT_EQ(assigned.settings().kkt_form, 1);
+    bool copysame = true;
+    for (int b = 0; b < B; ++b) copysame = copysame && copy.info(b).iter == one.info(b).iter && std::memcmp(copy.primal_solution(b), one.primal_solution(b), sizeof(double) * 35) == 0;
+    std::printf("  copy of a sharded solver, re-solved on the thread's context == original bitwise: %s\n", copysame ? "yes" : "NO");
+    EXPECT_TRUE(copysame);
+    // the filter line search without a carried filter is available in shards (the C entry's rule)
+    many.settings().line_search = 1; one.settings().line_search = 1;
+    for (int b = 0; b < B; ++b) for (int i = 0; i < 35; ++i) { many.primal_solution(b)[i] = 0.0; one.primal_solution(b)[i] = 0.0; }
+    for (int b = 0; b < B; ++b) for (int i = 0; i < 56; ++i) { many.dual_solution(b)[i] = 0.0; one.dual_solution(b)[i] = 0.0; }
+    EXPECT_EQ(many.solve(), PMPC_OK); EXPECT_EQ(one.solve(), PMPC_OK);
+    bool fsame = true;
+    for (int b = 0; b < B; ++b) fsame = fsame && many.info(b).iter == one.info(b).iter && std::memcmp(many.primal_solution(b), one.primal_solution(b), sizeof(double) * 35) == 0;
+    std::printf("  filter line search in 3 shards == 1 context (fresh filters) bitwise: %s\n", fsame ? "yes" : "NO");
+    EXPECT_TRUE(fsame);
+    // the same context twice would put two host threads on one stream and workspace: rejected
+    pmpc_context* dup[2] = {c2[0], c2[0]};
+    EXPECT_EQ(pmpc_sqp_solve_batch_multi(dup, 2, PMPC_MODEL_ROBOT, 6, 1, 0.0, 2.0, mp, 3, B, nullptr, nullptr, many.parameters(0), many.lower_bound_x(0),
+                                         many.upper_bound_x(0), nullptr, nullptr, &ss, &qs, x.data(), lam.data(), inf.data()), PMPC_ERR_INVALID_ARGUMENT);
     ss.iteration_trace = x.data();   // device state of one context: rejected
     EXPECT_EQ(pmpc_sqp_solve_batch_multi(c2, 2, PMPC_MODEL_ROBOT, 6, 1, 0.0, 2.0, mp, 3, B, nullptr, nullptr, many.parameters(0), many.lower_bound_x(0),
                                          many.upper_bound_x(0), nullptr, nullptr, &ss, &qs, x.data(), lam.data(), inf.data()), PMPC_ERR_INVALID_ARGUMENT);

@@ -574,26 +574,15 @@ def test_sqp_with_admm_qp_solver(oracle, pivot):
     assert i2[0].status == oracle.SQP_SOLVED and i2[0].iter < i1[0].iter
 
 
-def test_sqp_cstr(oracle):  # cstr_control_test.cpp:137-183 (Eigen pivot policy)
-    ss = oracle.sqp_default_settings(); ss.max_iter = 20; ss.line_search_max_iter = 20
-    n = 66
-    lbx = np.full(n, -inf); ubx = np.full(n, inf)
-    lbx[40:44] = ubx[40:44] = [1.0, 0.5, 100.0, 100.0]
-    lbx[44:] = np.tile([3.0, -9000.0], 11); ubx[44:] = np.tile([35.0, 0.0], 11)
-    d = np.zeros((1, 1))
-    x, lam, i1 = oracle.sqp_solve_batch(oracle.MODEL_CSTR, 5, 2, 0.0, 100.0, 1, d, lbx[None], ubx[None], sqp_settings=ss)
-    lbx[40:44] = ubx[40:44] = [1.1, 0.508, 100.5, 100.1]
-    x2, lam2, i2 = oracle.sqp_solve_batch(oracle.MODEL_CSTR, 5, 2, 0.0, 100.0, 1, d, lbx[None], ubx[None], x_guess=x, lam_guess=lam, sqp_settings=ss)
-    assert i2[0].status == oracle.SQP_SOLVED
-
-
-def _cstr_reference_scenario(oracle, pivot, regularisation=0):
-    """cstr_control_test.cpp:137-183: cold solve from x0 = (1, 0.5, 100, 100), then a second solve warm-started from its primal / dual solution
-    with x0 = (1.1, 0.508, 100.5, 100.1)."""
+def _cstr_reference_scenario(oracle, pivot, regularisation=0, hessian_update=1, perturb=0.0):
+    """cstr_control_test.cpp:137-183 as the reference runs it: MySolver overrides hessian_update_impl with the problem's sparsity-preserving block BFGS
+    (:128-132 -> continuous_ocp.hpp:2304-2431; `hessian_update = 1`), max_iter = ls_max = 20, cold solve from x0 = (1, 0.5, 100, 100), then a second
+    solve warm-started from its primal / dual solution with x0 = (1.1, 0.508, 100.5, 100.1). `perturb` moves the first coordinate of the cold x0."""
     ss = oracle.sqp_default_settings(); ss.max_iter = 20; ss.line_search_max_iter = 20; ss.regularisation = regularisation
+    ss.hessian_update = hessian_update
     n = 66
     lbx = np.full(n, -inf); ubx = np.full(n, inf)
-    lbx[40:44] = ubx[40:44] = [1.0, 0.5, 100.0, 100.0]
+    lbx[40:44] = ubx[40:44] = [1.0 + perturb, 0.5, 100.0, 100.0]
     lbx[44:] = np.tile([3.0, -9000.0], 11); ubx[44:] = np.tile([35.0, 0.0], 11)
     d = np.zeros((1, 1))
     x, lam, i1 = oracle.sqp_solve_batch(oracle.MODEL_CSTR, 5, 2, 0.0, 100.0, 1, d, lbx[None], ubx[None], sqp_settings=ss, pivot=pivot)
@@ -602,27 +591,66 @@ def _cstr_reference_scenario(oracle, pivot, regularisation=0):
     return (x, i1[0]), (x2, i2[0])
 
 
-def test_sqp_cstr_warm_start_needs_regularisation_to_be_well_posed(oracle, transcendental_functions):
-    """The second solve of cstr_control_test.cpp starts from multipliers for which the exact Lagrangian Hessian is indefinite, and the reference
-    applies no regularisation there: the first QPs run into their iteration cap with steps of size 1e4..1e30 and whether the iteration comes
-    back is decided by rounding. Measured on the restatement: with glibc's exp and the Eigen-style pivoted order (the reference's arithmetic) it
-    returns to the optimum in 6 iterations; the same order with the IEEE-only exp, the static order and the swept inverse either come back
-    (after 9-10 iterations) or overflow to NaN — after which the reference's own termination test (norms that drop NaNs) reports SOLVED.
-    What is NOT fragile, and is what a device run can be held to: the cold solve (7 iterations, 401 ADMM iterations in every order), and the
-    warm solve with the Gershgorin shift the reference uses wherever it keeps exact Hessians (dense_sparse_compare.cpp:109-122): 4 iterations,
-    240 ADMM iterations, the same optimum, in every order and with either function set."""
+def test_sqp_cstr(oracle):
+    """cstr_control_test.cpp:137-183 with the Hessian update that test selects (block BFGS, :128-132). The test is SPARSE: its QP solver is
+    boxADMM<VAR_SIZE, NUM_EQ, double, SPARSE, SimplicialLDLT> (:139-140, helpers.hpp:44-49) and SimplicialLDLT does NOT pivot numerically (a
+    fill-reducing symmetric permutation, then plain LDL^T) — the restatement nearest to it is the static, non-pivoted order (PIVOT_STATIC), with
+    glibc's exp. There the scenario runs as the reference asserts (:177): cold SOLVED in 7 SQP / 380 ADMM iterations, warm SOLVED in 4 / 403.
+    (The assembly of the SPARSE members was read against the DENSE ones the restatement follows — _cost_grad_hess_sparse_update :1687-1905,
+    _equalities_linearised_sparse_update :958-1022, lagrangian_gradient_hessian<SPARSE> :2178-2301: the same values, stored by column.)"""
+    with oracle.libm():
+        (x1, i1), (x2, i2) = _cstr_reference_scenario(oracle, oracle.PIVOT_STATIC)
+    assert (i1.iter, i1.qp_solver_iter, i1.status) == (7, 380, oracle.SQP_SOLVED)
+    assert (i2.iter, i2.qp_solver_iter, i2.status) == (4, 403, oracle.SQP_SOLVED) and np.isfinite(x2).all() and i2.max_violation <= 1e-3
+
+
+def test_sqp_cstr_warm_solve_is_a_last_bit_property(oracle):
+    """OPEN DISCREPANCY, pinned as what it is (next to HS071's `iter < 50`). The warm solve of cstr_control_test.cpp starts from multipliers for which the
+    exact Lagrangian Hessian is INDEFINITE (five node blocks have an eigenvalue of -6 ... -45; the Hessian reduced to the null space of the linearised
+    dynamics is positive definite, smallest eigenvalue 1e-6 from R = 5e-7) and the reference applies no regularisation (hessian_regularisation_*_impl is
+    the no-op default, sqp_base.hpp:304-305). boxADMM on that non-convex QP runs to its cap with multipliers of 1e14; the line search then takes
+    alpha = 2^-17, and whether the block-BFGS iteration recovers is decided by rounding: over {Eigen-pivoted, static, swept} orders x {glibc, IEEE-only
+    exp} x a 1e-13 perturbation of x0 the restatement ends SOLVED (4 ... 15 iterations) in some members and at MAX_ITER_EXCEEDED (20 iterations, every QP
+    at its cap) in most. The reference binary is one member (SimplicialLDLT's AMD order is not available here); `EXPECT_TRUE(SOLVED)` (:177) holds in the
+    member nearest to it (test_sqp_cstr) and is not a property of the algorithm. What IS robust, in every member: the cold solve (7 / 380, SOLVED), and
+    the warm solve once the Gershgorin shift of dense_sparse_compare.cpp:109-122 makes the QP convex (4 / 240, SOLVED, same optimum to 1e-7)."""
+    outcomes = {}
+    for glibc in (True, False):
+        prev = oracle.set_libm(glibc)
+        try:
+            for pivot in (oracle.PIVOT_EIGEN, oracle.PIVOT_STATIC, oracle.PIVOT_SWEEP2):
+                for dx in (0.0, 1e-13, -1e-13):
+                    (x1, i1), (x2, i2) = _cstr_reference_scenario(oracle, pivot, perturb=dx)
+                    assert (i1.iter, i1.qp_solver_iter, i1.status) == (7, 380, oracle.SQP_SOLVED), (glibc, pivot, dx)
+                    outcomes[(glibc, pivot, dx)] = (i2.iter, i2.status)
+                (x1, i1), (x2, i2) = _cstr_reference_scenario(oracle, pivot, regularisation=2)
+                assert (i2.iter, i2.qp_solver_iter, i2.status) == (4, 240, oracle.SQP_SOLVED) and np.isfinite(x2).all(), (glibc, pivot)
+        finally:
+            oracle.set_libm(prev)
+    solved = [k for k, v in outcomes.items() if v[1] == oracle.SQP_SOLVED]
+    capped = [k for k, v in outcomes.items() if v[1] != oracle.SQP_SOLVED]
+    assert solved and capped, outcomes                                   # the ensemble straddles the reference's assertion
+    assert (True, oracle.PIVOT_STATIC, 0.0) in solved                    # the non-pivoted order with glibc (nearest to SimplicialLDLT) meets it
+    assert all(outcomes[k][0] == 20 for k in capped)
+
+
+def test_sqp_cstr_dense_bfgs_variant(oracle, transcendental_functions):
+    """The same scenario with the DENSE default update (bfgs.hpp; NOT what cstr_control_test.cpp runs — kept as the round-2/3 record): the warm solve is
+    equally ill-posed without regularisation (steps of 1e4..1e30; with glibc's exp and the Eigen-style pivoted order it returns to the optimum in 6
+    steps, other members overflow to NaN, after which the reference's termination test — norms that drop NaNs — reports SOLVED), and robust with the
+    Gershgorin shift: 4 iterations, 240 ADMM iterations, the same optimum, in every order and with either function set."""
     ref = None
     for pivot in (oracle.PIVOT_EIGEN, oracle.PIVOT_STATIC, oracle.PIVOT_SWEEP2):
-        (x1, i1), (x2, i2) = _cstr_reference_scenario(oracle, pivot, regularisation=2)
+        (x1, i1), (x2, i2) = _cstr_reference_scenario(oracle, pivot, regularisation=2, hessian_update=0)
         assert (i1.iter, i1.status) == (7, oracle.SQP_SOLVED)
         assert (i2.iter, i2.qp_solver_iter, i2.status) == (4, 240, oracle.SQP_SOLVED) and np.isfinite(x2).all()
         ref = x2 if ref is None else ref
         assert (np.abs(x2 - ref) / np.maximum(1.0, np.abs(ref))).max() <= 1e-7
-        (x1, i1), (x2u, i2u) = _cstr_reference_scenario(oracle, pivot, regularisation=0)
+        (x1, i1), (x2u, i2u) = _cstr_reference_scenario(oracle, pivot, regularisation=0, hessian_update=0)
         assert (i1.iter, i1.qp_solver_iter, i1.status) == (7, 401, oracle.SQP_SOLVED)
-        assert i2u.status == oracle.SQP_SOLVED            # the reference's assertion (:181) — met, with or without a finite iterate
+        assert i2u.status == oracle.SQP_SOLVED
         if pivot == oracle.PIVOT_EIGEN and transcendental_functions == "glibc":
-            assert i2u.iter == 6 and np.isfinite(x2u).all() and abs(i2u.cost - 11662.3) < 1.0   # the reference's arithmetic: comes back
+            assert i2u.iter == 6 and np.isfinite(x2u).all() and abs(i2u.cost - 11662.3) < 1.0
 
 
 def test_static_and_eigen_pivot_agree_on_config_A(oracle):
@@ -654,6 +682,24 @@ def _cross_order(oracle, cfg, B=None, full=False, kernel_glibc=False):
     xk, lk, ik = tco.oracle_run(oracle, wl, n, tco.kernel_order(oracle, cfg, wl), kernel_glibc, 8)
     xr, lr, ir = tco.oracle_run(oracle, wl, n, oracle.PIVOT_EIGEN, True, 8)
     return tco.cross_order_stats(cfg, wl, xk, lk, ik, xr, lr, ir)
+
+
+@pytest.mark.parametrize("cfg,min_qps", [("A", 1024), ("D", 512), ("B", 512), ("R", 512), ("C", 48)])
+def test_kernel_orders_against_the_reference_order_one_qp_at_a_time(oracle, cfg, min_qps):
+    """north_star's criterion on its own unit (one box-ADMM solve): the QPs of the reference-order SQP trajectories of every BASELINE
+    configuration, each solved ONCE in the order of the kernel that serves its size at the QP entry point and once as the reference computes
+    (PIVOT_EIGEN). Every QP: identical ADMM iteration counts / status / rho updates, residuals within 1e-8 (measured: <= 4.3e-10). The GPU test of
+    the same name (tests/test_gpu_parity.py) puts the kernels themselves through it at larger counts."""
+    import tools_cross_order as tco
+    q = tco.traced_qp_stream(oracle, cfg, min_qps)
+    rows = q["n"] + q["m"]
+    order = oracle.PIVOT_SWEEP if rows <= 64 else (oracle.PIVOT_SWEEP2 if rows <= oracle.SWEEP2_MAX_ROWS else oracle.PIVOT_BLOCKED)
+    x, y, i = oracle.qp_solve_batch(q["H"], q["h"], q["A"], q["Alb"], q["Aub"], q["xlb"], q["xub"], settings=oracle.sqp_qp_default_settings(),
+                                    pivot=order, threads=8)
+    xr, yr, ir = tco.reference_qp_solve(oracle, q, threads=8)
+    rec = tco.qp_level_stats(x, y, i, xr, yr, ir)
+    assert rec["different_iter"] == 0 and rec["different_status"] == 0 and rec["different_rho_updates"] == 0, rec
+    assert rec["max_abs_d_res_prim"] <= 1e-8 and rec["max_abs_d_res_dual"] <= 1e-8, rec
 
 
 def test_kernel_orders_against_the_reference_order_on_the_full_benchmark_streams(oracle, transcendental_functions):

@@ -16,7 +16,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-from polympc_amd.parity_stats import cross_order_stats, variable_scales  # noqa: E402,F401
+from polympc_amd.parity_stats import cross_order_stats, qp_level_stats, variable_scales  # noqa: E402,F401
 
 
 def config_workload(cfg, B=None, full=False):
@@ -42,6 +42,37 @@ def oracle_run(ob, wl, B, pivot, glibc, threads):
                                   sqp_settings=oss, pivot=pivot, threads=threads)
     finally:
         ob.set_libm(prev)
+
+
+def traced_qp_stream(ob, cfg, min_qps, B=None):
+    """The QPs the reference-order SQP (Eigen-style pivoted LDL^T, glibc) emits for the first instances of configuration `cfg` — true collocation
+    structure and conditioning, SURVEY 8d's "QP-only microbenchmark" — stacked until at least `min_qps` of them: dict of H [Q, n n], h, A [Q, m n],
+    Alb, Aub, xlb, xub (column-major matrices, as the C ABI takes them)."""
+    wl, _ = config_workload(cfg, B=B or 4096)
+    oss = ob.sqp_default_settings(); oss.max_iter = wl["max_iter"]; oss.line_search_max_iter = wl["ls_max_iter"]
+    keys = ("H", "h", "A", "al", "au", "lx", "ux")
+    parts = {k: [] for k in keys}
+    got = 0
+    prev = ob.set_libm(True)
+    try:
+        for b in range(wl["lbx"].shape[0]):
+            t = ob.sqp_trace_qps(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], wl["d"][b:b + 1], wl["lbx"][b:b + 1], wl["ubx"][b:b + 1],
+                                 sqp_settings=oss, pivot=ob.PIVOT_EIGEN, max_qps=wl["max_iter"])
+            for k in keys:
+                parts[k].append(t[k])
+            got += t["H"].shape[0]
+            if got >= min_qps:
+                break
+    finally:
+        ob.set_libm(prev)
+    q = {k: np.concatenate(v) for k, v in parts.items()}
+    return dict(H=q["H"], h=q["h"], A=q["A"], Alb=q["al"], Aub=q["au"], xlb=q["lx"], xub=q["ux"], n=wl["n"], m=wl["m"], instances=b + 1)
+
+
+def reference_qp_solve(ob, q, threads=1):
+    """Every QP of the stream solved once as the reference's boxADMM computes (PIVOT_EIGEN; the SQP constructor's QP settings, sqp_base.hpp:83-90)."""
+    return ob.qp_solve_batch(q["H"], q["h"], q["A"], q["Alb"], q["Aub"], q["xlb"], q["xub"], settings=ob.sqp_qp_default_settings(),
+                             pivot=ob.PIVOT_EIGEN, threads=threads)
 
 
 def kernel_order(ob, cfg, wl):

@@ -435,6 +435,18 @@ public:
         m_primal_norm = i.primal_norm; m_dual_norm = i.dual_norm; m_max_violation = i.max_violation; m_cost = i.cost;
     }
     void solve(const nlp_variable_t& x_guess, const nlp_dual_t& lam_guess) noexcept { m_x = x_guess; m_lam = lam_guess; solve(); }
+    // copies (the reference's SQPBase is copyable): `filter` below is a reference into this object's own m_batch — a memberwise copy would leave
+    // the copy's reference on the ORIGINAL's filter, and a reference member deletes the implicit assignment
+    Solver(const Solver& o)
+        : m_x(o.m_x), m_lbx(o.m_lbx), m_ubx(o.m_ubx), m_lam(o.m_lam), m_lbg(o.m_lbg), m_ubg(o.m_ubg), m_p(o.m_p), m_info(o.m_info),
+          m_primal_norm(o.m_primal_norm), m_dual_norm(o.m_dual_norm), m_max_violation(o.m_max_violation), m_cost(o.m_cost), m_batch(o.m_batch) {}
+    Solver& operator=(const Solver& o) {
+        if (this != &o) {
+            m_x = o.m_x; m_lbx = o.m_lbx; m_ubx = o.m_ubx; m_lam = o.m_lam; m_lbg = o.m_lbg; m_ubg = o.m_ubg; m_p = o.m_p; m_info = o.m_info;
+            m_primal_norm = o.m_primal_norm; m_dual_norm = o.m_dual_norm; m_max_violation = o.m_max_violation; m_cost = o.m_cost; m_batch = o.m_batch;
+        }
+        return *this;
+    }
 
     nlp_variable_t m_x, m_lbx, m_ubx;
     nlp_dual_t m_lam;

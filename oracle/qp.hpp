@@ -379,7 +379,7 @@ struct BoxADMM {
     // segment that produces node ni, and the own-node block b (d entries, the D self entry included) on the columns of node ni.
     //   factorise:  Q_k = P_k^{-1}  (symmetric sweep on the lower triangle, one pivot at a time, pivots ascending; Q = -(swept matrix), mirrored)
     //               G row i:  g_k[c] = sum_c' fma(b_i[c'], Q_k(c', c), .)  (k = ni, c' ascending from 0);  Dt(ni, k) * Q_k(si, c)  (k coupled);  0
-    //               S(i, j) = [i == j] / rho_i, then fma(g_nj[c], b_j[c], .) c ascending, then fma(g_k[sj], Dt(nj, k), .) over the coupled k ascending
+    //               S(i, j) = [i == j] / rho_i, then over the nodes k ascending: fma(g_k[c], b_j[c], .) c ascending for k = nj, fma(g_k[sj], Dt(nj, k), .) for k coupled to nj
     //               W = -S^{-1}  by PIVOT_SWEEP's blocked sweep on the block-lower tiles, diagonal tiles as the rows gave them
     //   solve:      t = Q r1 (per node, fma chain c' ascending);  g_i = (own block fma chain over c, then coupled nodes k ascending) - r2_i;
     //               nu = S^{-1} g (PIVOT_SWEEP's mat-vec);  w = A' nu (own block: rows q ascending; then coupled row nodes ascending);
@@ -433,15 +433,17 @@ struct BoxADMM {
                 for (int cc = 0; cc < d; ++cc) {
                     double a = 0.0;
                     if (k == ni) { for (int c2 = 0; c2 < d; ++c2) a = std::fma(Aent(i, sg(ni, c2)), Q(k, c2, cc), a); }
-                    else if (coupled(ni, k)) a = Aent(i, k * nx + si) * Q(k, si, cc);
+                    else a = (coupled(ni, k) ? Aent(i, k * nx + si) : 0.0) * Q(k, si, cc);   // (every lane forms the product; uncoupled nodes carry the coefficient 0)
                     g[(size_t)k * d + cc] = a;
                 }
             for (int j = 0; j < M; ++j) {
                 if (j / 16 > i / 16) continue;   // block-lower tile storage: tiles above the block diagonal are mirror images
                 const int nj = j / nx, sj = j % nx;
                 double a = (i == j) ? rho_inv_vec[i] : 0.0;
-                for (int cc = 0; cc < d; ++cc) a = std::fma(g[(size_t)nj * d + cc], Aent(j, sg(nj, cc)), a);
-                for (int k = 0; k < nn; ++k) if (coupled(nj, k)) a = std::fma(g[(size_t)k * d + sj], Aent(j, k * nx + sj), a);
+                for (int k = 0; k < nn; ++k) {   // nodes ascending: the own node of row j contributes its block (c ascending), a coupled node one product
+                    if (k == nj) { for (int cc = 0; cc < d; ++cc) a = std::fma(g[(size_t)k * d + cc], Aent(j, sg(nj, cc)), a); }
+                    else if (coupled(nj, k)) a = std::fma(g[(size_t)k * d + sj], Aent(j, k * nx + sj), a);
+                }
                 S[i + (size_t)j * M] = a;
             }
         }
@@ -457,7 +459,10 @@ struct BoxADMM {
         for (int k = 0; k < nn; ++k) for (int cc = 0; cc < d; ++cc) {
             double a = 0.0;
             for (int q2 = 0; q2 < nx; ++q2) a = std::fma(Aent(k * nx + q2, sg(k, cc)), nu[k * nx + q2], a);
-            if (cc < nx) for (int kr = 0; kr < nn; ++kr) if (coupled(kr, k)) a = std::fma(Aent(kr * nx + cc, k * nx + cc), nu[kr * nx + cc], a);
+            // every row node enters the chain: coefficient D~(kr, k) on a state column whose node lies in the segment that produces node kr, 0 otherwise
+            // (own node, other segments, control columns — which read the state-0 entry of nu)
+            const int cx = cc < nx ? cc : 0;
+            for (int kr = 0; kr < nn; ++kr) a = std::fma((cc < nx && coupled(kr, k)) ? Aent(kr * nx + cc, k * nx + cc) : 0.0, nu[kr * nx + cx], a);
             u[sg(k, cc)] = rhs[sg(k, cc)] - a;
         }
         for (int k = 0; k < nn; ++k) for (int cc = 0; cc < d; ++cc) {
@@ -471,7 +476,7 @@ struct BoxADMM {
         const int nx = schur.nx, nn = schur.nn, d = nx + schur.nu, ni = i / nx, si = i % nx;
         double a = init;
         for (int cc = 0; cc < d; ++cc) a = std::fma(Aent(i, sg(ni, cc)), v[sg(ni, cc)], a);
-        for (int k = 0; k < nn; ++k) if (coupled(ni, k)) a = std::fma(Aent(i, k * nx + si), v[k * nx + si], a);
+        for (int k = 0; k < nn; ++k) a = std::fma(coupled(ni, k) ? Aent(i, k * nx + si) : 0.0, v[k * nx + si], a);   // every node enters: 0 outside the row's segment and on the own node
         return a;
     }
     // One solve = the range-space solve and ONE step of iterative refinement on the constraint rows. The explicit (swept) inverse of S has an

@@ -2,6 +2,7 @@
 // and by include/polympc/register_ocp.hpp for user-defined OCPs (compiled by hipcc in the user's translation unit).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "../../include/polympc_amd.h"
 #include "pmpc_ocp.hpp"
 #include "pmpc_qp.hpp"
@@ -156,6 +157,112 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
     }
     if constexpr (PROF) { if (phase_cycles && ln == 0) for (int i = 0; i < 24; ++i) atomicAdd(&phase_cycles[i], (unsigned long long)sqp.cyc[i]); }
 }
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Block-structured specialisation (pmpc_qp_schur.hpp): the Hessian is block diagonal per node — the block BFGS every control test of the reference
+// selects (continuous_ocp.hpp:2304-2431) or exact Hessians, NP = NG = 0 — and lives with J's per-node blocks in LDS: no HBM workspace, the QP through
+// the m x m Schur complement. One instantiation per (model, P, S): the segment structure is a compile-time constant of the sparse products.
+template <class Model, int PP, int SS> constexpr int schur_lds_doubles_ct() {
+    using SD = SchurDims<Model, PP, SS>;
+    return SD::LDS_DOUBLES + SD::NNODES * SD::DD /*hblk*/ + SD::NNODES * SD::NX * SD::D /*jblk*/ + 4;
+}
+template <class Model, int PP, int SS> inline size_t sqp_schur_lds_bytes() {
+    using SD = SchurDims<Model, PP, SS>;
+    OcpDims<Model> dm(PP, SS);
+    size_t stage = OcpLds<Model>::doubles(PP, SS);
+    const size_t need = (size_t)RegKkt<SD::M>::TRI + OcpLds<Model>::const_doubles(PP, SS) + 8;
+    if (stage < need) stage = need;
+    return (QpLds::doubles_xy(dm.n, dm.m) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8 + schur_lds_doubles_ct<Model, PP, SS>() + (Model::ND > 0 ? Model::ND : 1)) * sizeof(double);
+}
+template <class Model, int PP, int SS, bool PROF = false>
+__global__ __launch_bounds__(64, (SchurDims<Model, PP, SS>::N + SchurDims<Model, PP, SS>::M <= 64) ? PMPC_SQP_WAVES : 1)
+void sqp_schur_kernel(Model model, const ChebData* __restrict__ cd, int B, const double* __restrict__ x_guess, const double* __restrict__ lam_guess,
+                      const double* __restrict__ d, const double* __restrict__ lbx, const double* __restrict__ ubx, pmpc_sqp_settings ss,
+                      pmpc_qp_settings qs, double* __restrict__ x, double* __restrict__ lam, pmpc_sqp_info* __restrict__ info,
+                      unsigned long long* __restrict__ phase_cycles) {
+    using SD = SchurDims<Model, PP, SS>;
+    extern __shared__ double smem[];
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    Ocp<Model> ocp(model, PP, SS, cd->t_scale);
+    constexpr int n = SD::N, m = SD::M;
+    QpLds qw; SqpLds v;
+    double* p = qw.carve_xy(smem, n, m);
+    p = v.carve(p, n, m, 0);
+    double* stage0 = p;
+    p = ocp.s.carve(p, PP, SS);
+    if ((size_t)(p - stage0) < (size_t)RegKkt<m>::TRI + 2 + ocp.s.const_doubles(PP, SS)) p = stage0 + RegKkt<m>::TRI + 2 + ocp.s.const_doubles(PP, SS);
+    const double* stage_end = p;
+    ocp.jblk = p; p += SD::NNODES * SD::NX * SD::D; ocp.gblk = ocp.jblk; ocp.keep_blk = true;
+    double* hblk = p; p += SD::NNODES * SD::DD;
+    double* qblk = p; p += SD::NNODES * SD::DD;
+    double* xsc = p; p += n + 1;
+    double* dsc = p; p += m + 1;
+    double* pdl = p; p += n + 1;
+    p += ((p - smem) & 1);   // the tables are read 16 bytes at a time
+    double* dtab = p; p += SD::TAB;
+    double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
+    const int ln = lane_id();
+    for (int i = ln; i < Model::ND; i += WAVE) dL[i] = d[(size_t)b * Model::ND + i];
+    ocp.d = dL;
+    ocp.stage_constants(cd);
+    for (int i = ln; i < n; i += WAVE) {
+        v.x[i] = x_guess ? x_guess[(size_t)b * n + i] : 0.0;
+        v.lbx[i] = lbx[(size_t)b * n + i]; v.ubx[i] = ubx[(size_t)b * n + i];
+    }
+    for (int i = ln; i < m + n; i += WAVE) v.lam[i] = lam_guess ? lam_guess[(size_t)b * (m + n) + i] : 0.0;
+    wsync();
+    SqpDevice<Model, n, m, PROF, 1, false, false, PP * 256 + SS> sqp(ocp, v, qw, nullptr, nullptr, ss, qs);
+    sqp.hblk = hblk; sqp.qblk = qblk; sqp.xsc = xsc; sqp.dsc = dsc; sqp.pdl = pdl; sqp.dtab = dtab;
+    schur_build_tables<Model, PP, SS>(ocp.s.D, dtab);
+    sqp.trace = ss.iteration_trace ? ss.iteration_trace + (size_t)b * (size_t)ss.iteration_trace_capacity * PMPC_TRACE_DOUBLES : nullptr;
+    sqp.tr = ocp.s.fval;
+    {
+        const int G = WAVE / SD::NNODES;
+        const size_t need = (size_t)G * (m + SD::NNODES + 3);
+        const size_t have = (size_t)(stage_end - ocp.s.fval);
+        sqp.lsbuf = ocp.s.fval;
+        sqp.ls_side_by_side = (G >= 2 && need <= have);
+    }
+    pmpc_sqp_info si;
+    sqp.solve(si, 0, ss.max_iter);
+    for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = v.x[i];
+    for (int i = ln; i < m + n; i += WAVE) lam[(size_t)b * (m + n) + i] = v.lam[i];
+    if (ln == 0) info[b] = si;
+    if constexpr (PROF) { if (phase_cycles && ln == 0) for (int i = 0; i < 24; ++i) atomicAdd(&phase_cycles[i], (unsigned long long)sqp.cyc[i]); }
+}
+// the request can take the block-structured kernel: block-diagonal Hessian throughout, default policies otherwise (pmpc_sqp_settings::kkt_form = 1
+// asks for the reference's full KKT form and keeps the dense kernels)
+inline bool schur_request_ok(const pmpc_sqp_settings* ss, const pmpc_qp_settings* qs, int slice_iters) {
+    return (ss->hessian_update == 1 || ss->exact_hessian_every_iter) && (ss->regularisation == 0 || ss->regularisation == 2) && ss->preconditioner == 0 &&
+           ss->qp_solver == 0 && ss->line_search == 0 && ss->kkt_form == 0 && qs->linear_solver == 0 && slice_iters == 0;
+}
+template <class Model, int PP, int SS>
+inline bool try_launch_schur(pmpc_context* ctx, const Model& mdl, const ChebData* cd, int P, int S, int B, const double* x_guess, const double* lam_guess,
+                             const double* d, const double* lbx, const double* ubx, const pmpc_sqp_settings* ss, const pmpc_qp_settings* qs, double* x,
+                             double* lam, pmpc_sqp_info* info, hipStream_t stream, size_t lds_limit, unsigned long long* phase, pmpc_status* st) {
+    if (P != PP || S != SS) return false;
+    // Systems of at most 64 KKT rows stay on the one-row-per-lane dense kernel: its ADMM iteration is ONE register mat-vec (600 cycles), the
+    // block-structured one a chain of eight LDS exchanges and two mat-vecs (3.7 k cycles on config A) — measured 1.69 against 1.16 ms per 4096
+    // config-A instances although the factorisation is three times cheaper. PMPC_SCHUR_SMALL=1: developer switch.
+    if (SchurDims<Model, PP, SS>::N + SchurDims<Model, PP, SS>::M <= WAVE && !getenv("PMPC_SCHUR_SMALL")) return false;
+    const size_t lds = sqp_schur_lds_bytes<Model, PP, SS>();
+    if (lds > lds_limit) return false;
+    auto kern = phase ? sqp_schur_kernel<Model, PP, SS, true> : sqp_schur_kernel<Model, PP, SS, false>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
+    pmpc_internal_set_route(ctx, PMPC_ROUTE_SCHUR);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), lds, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, *ss, *qs, x, lam, info, phase);
+    *st = (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
+    return true;
+}
+// the grids with a block-structured specialisation, per model (defined in the model's own translation unit: pmpc_schur_*.hip)
+template <class Model> struct SCHUR_GRIDS { static constexpr bool value = false; };
+template <> struct SCHUR_GRIDS<RobotOCP> { static constexpr bool value = true; };
+template <> struct SCHUR_GRIDS<CstrOCP> { static constexpr bool value = true; };
+template <class Model>
+bool try_launch_schur_grids(pmpc_context* ctx, const Model& mdl, const ChebData* cd, int P, int S, int B, const double* x_guess, const double* lam_guess,
+                            const double* d, const double* lbx, const double* ubx, const pmpc_sqp_settings* ss, const pmpc_qp_settings* qs, double* x,
+                            double* lam, pmpc_sqp_info* info, hipStream_t stream, size_t lds_limit, unsigned long long* phase, pmpc_status* st);
+
 // ---------------------------------------------------------------------------------------------------------------------------------------------
 // Round-robin execution of a batch that exceeds the resident wavefronts (register-resident QP, one KKT row per lane) — a DEVELOPER SWITCH
 // (PMPC_SQP_RR=1), measured and not made the default: see DESIGN.md §6. Instances need 4..max_iter SQP iterations, and with one workgroup per
@@ -543,6 +650,12 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     if ((ss->line_search != 0 && ss->line_search != 1) ||
         (ss->line_search == 1 && (ss->filter_max_depth < 1 || ss->filter_max_depth > PMPC_FILTER_MAX_DEPTH))) return PMPC_ERR_INVALID_ARGUMENT;
     if (qs->linear_solver != 0 && qs->linear_solver != 1) return PMPC_ERR_INVALID_ARGUMENT;
+    if constexpr (SCHUR_GRIDS<Model>::value) {   // block-diagonal Hessian on a grid with a block-structured kernel
+        if (!force_lds && !getenv("PMPC_NO_SCHUR") && schur_request_ok(ss, qs, slice_iters)) {
+            pmpc_status rst = PMPC_OK;
+            if (try_launch_schur_grids<Model>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, ss, qs, x, lam, info, stream, lds_limit, phase, &rst)) return rst;
+        }
+    }
     if (!force_lds && ss->qp_solver == 0 && ss->regularisation != 1 && qs->linear_solver == 0) {   // (preconditioner / line_search = 1: the 7- and 11-node register kernels carry them, see try_launch_reg)   // node counts whose KKT system can fit 64 rows for small models (7 nodes: config A / D); Ruiz: LDS path
         pmpc_status rst = PMPC_OK;
         if (try_launch_reg<Model, 7>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;

@@ -355,11 +355,12 @@ struct Ocp {
     // J(r, col) = J[r + col * ldj] (ldj = m for a plain m x n Jacobian; n+m when J is the lower block of the stacked [H;J] workspace)
     // structure = false: J already holds a linearisation of THIS problem — its zeros and its differentiation-matrix entries
     // do not depend on the iterate, so only the per-node blocks (D self entry - t_scale*df, dg) are rewritten.
-    template <bool WANT_COST = true>
+    // DENSEJ = false (block-structured kernels, pmpc_qp_schur.hpp): J is never materialised — only the per-node blocks (jblk / gblk) are written
+    template <bool WANT_COST = true, bool DENSEJ = true>
     __device__ __forceinline__ double assemble_first_order(double* c, double* __restrict__ J, double* cost_grad, int ldj, bool structure = true) {
         const int ln = lane_id();
         const int n = dm.n, m = dm.m;
-        if (structure) {
+        if (DENSEJ && structure) {
             for (int e = ln; e < m * n; e += WAVE) J[(e % m) + (size_t)(e / m) * ldj] = 0.0;
             wfence();
             wsync();
@@ -384,7 +385,7 @@ struct Ocp {
             const int k = e / (NX * NDER), rem = e - k * (NX * NDER), q = rem / NDER, i = rem - q * NDER;
             double v = (i == q) ? s.nd[k] : 0.0;
             v -= ts * s.fjac[e];
-            J[(k * NX + q) + (size_t)dm.gidx(k, i) * ldj] = v;
+            if constexpr (DENSEJ) J[(k * NX + q) + (size_t)dm.gidx(k, i) * ldj] = v;
             if (keep_blk) jblk[e] = v;
         }
         for (int r = ln; r < dm.me; r += WAVE) {
@@ -395,7 +396,7 @@ struct Ocp {
         if (NG > 0) {
             for (int e = ln; e < dm.NN * NG * NDER; e += WAVE) {
                 const int kq = e / NDER, i = e - kq * NDER, k = kq / NG;
-                J[(dm.me + kq) + (size_t)dm.gidx(k, i) * ldj] = s.gjac[e];
+                if constexpr (DENSEJ) J[(dm.me + kq) + (size_t)dm.gidx(k, i) * ldj] = s.gjac[e];
                 if (keep_blk) gblk[e] = s.gjac[e];
             }
             for (int r = ln; r < dm.mi; r += WAVE) c[dm.me + r] = s.gval[r];
@@ -431,6 +432,22 @@ struct Ocp {
         wfence();
         wsync();
         return cst;
+    }
+
+    // ---- the same Hessian as its per-node blocks only (NP = 0: H IS block diagonal): hb[k NDER^2 + i NDER + r] = H(gidx(k, r), gidx(k, i)) — the entries
+    // assemble_hessian writes, through the same operations; block-structured kernels keep them in LDS (pmpc_qp_schur.hpp)
+    __device__ __forceinline__ void assemble_hessian_blocks(double* hb) {
+        static_assert(NP == 0, "block storage of the Hessian: models without parameters");
+        for (int e = lane_id(); e < dm.NN * NDER * NDER; e += WAVE) {
+            const int k = e / (NDER * NDER), rem = e - k * (NDER * NDER), i = rem / NDER, r = rem - i * NDER;
+            double a = 0.0;
+            if (k % P == 0 && k > 0) a += (ts * s.w[P]) * s.Lhes[(k * NDER + i) * NDER + r];
+            if (k < dm.NN - 1) a += (ts * s.w[k % P]) * s.Lhes[(k * NDER + i) * NDER + r];
+            if (k == 0) a += s.Mhes[i * NDER + r];
+            a += s.dhes[(k * NDER + i) * NDER + r];
+            hb[e] = a;
+        }
+        wsync();
     }
 
     // ---- assemble the Lagrangian Hessian H (n x n column-major in HBM) from the second-order stage

@@ -16,6 +16,7 @@
 #include "pmpc_qp_reg.hpp"
 #include "pmpc_qp_reg2.hpp"
 #include "pmpc_qp_big.hpp"
+#include "pmpc_qp_schur.hpp"
 #include "pmpc_ruiz.hpp"
 #include "pmpc_admm.hpp"
 
@@ -49,15 +50,21 @@ constexpr int PMPC_SQP_IN_PROGRESS = 3;   // internal: the instance continues in
 // POL: register-resident specialisation that carries the policy hooks the reference's tests install beside the default ones — the Ruiz
 //      preconditioner (qp_preconditioners.hpp:114-220) and the filter line search (line_search.hpp:31-98); the LDS / HBM-resident kernels (NN == 0)
 //      always carry them. A separate instantiation: the default register kernels stay free of the (cold) calls and their spills.
-template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bool BIG = false, bool POL = false>
+// PS: P * 256 + S of a BLOCK-STRUCTURED specialisation (pmpc_qp_schur.hpp; 0 = none): the Hessian is block diagonal per node (block BFGS or exact
+//      Hessians, NP = NG = 0) and lives as per-node blocks in LDS (`hblk`), J as its per-node blocks (`ocp.jblk`) + the differentiation matrix: the
+//      HBM workspace is not touched at all, and the QP is solved through the m x m Schur complement. NN, MM are the compile-time sizes there too.
+template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bool BIG = false, bool POL = false, int PS = 0>
 struct SqpDevice {
+    static constexpr bool SCH = PS > 0;
+    static constexpr int SCH_P = PS / 256, SCH_S = PS % 256;
     static constexpr bool HOOKS = (NN == 0) || POL;
     using Dm = OcpDims<Model>;
     // Ruiz scaling is compiled into the LDS / HBM-resident QP kernels only: the launcher routes preconditioner = 1 there. In the
     // register-resident kernels its three (cold, out-of-line) calls cost private-memory frames and call-ABI spills on the hot path.
     static constexpr bool RUIZ_COMPILED = HOOKS && (int)Dm::NDER <= RUIZ_MAX_NDER;
-    static constexpr bool REG1 = NN > 0 && NN + MM <= WAVE;    // one KKT row per lane
-    static constexpr bool REG2 = NN > 0 && NN + MM > WAVE;     // two KKT rows per lane
+    static constexpr bool REG1 = !SCH && NN > 0 && NN + MM <= WAVE;    // one KKT row per lane
+    static constexpr bool REG2 = !SCH && NN > 0 && NN + MM > WAVE;     // two KKT rows per lane
+    double *hblk = nullptr, *qblk = nullptr, *xsc = nullptr, *dsc = nullptr, *pdl = nullptr, *dtab = nullptr;   // SCH: Hessian blocks, Q blocks, the exchange vectors, the KKT diagonal and the D~ tables of the QP (LDS)
     static constexpr int MEMCH = BIG ? BIG_MEM_BATCH : 8;      // loads in flight per lane in the row walks over the BFGS matrix in HBM
     Ocp<Model>& ocp;
     SqpLds& v;
@@ -392,6 +399,20 @@ struct SqpDevice {
 
     // lag_grad = J^T lam[0:m] + cost_grad + lam_box  (continuous_ocp.hpp:2112-2114)
     __device__ __forceinline__ void lagrangian_gradient(double* out) {
+        if constexpr (SCH) {   // J' lam from the per-node blocks and the differentiation matrix (pmpc_jview.hpp): the non-zero products of the dense chain, rows ascending
+            const JV jv = jview();
+#pragma unroll
+            for (int e = 0; e < (NN + WAVE - 1) / WAVE; ++e) {
+                const int col = lane_id() + WAVE * e;
+                const int j = col < NN ? col : 0;
+                double a = jv.coldot(j, v.lam);
+                a += v.h[j];
+                a += v.lam[MM + j];
+                if (col < NN) out[j] = a;
+            }
+            wsync();
+            return;
+        }
         if constexpr (REG2) {   // (one KKT row per lane: the dense column loads below measured faster there — config A / D +6 % with the sparse form)
             // J' lam from the per-node blocks and the differentiation matrix in LDS: the non-zero products of the dense chain below in the
             // same ascending-row order (pmpc_jview.hpp). A non-finite multiplier takes the dense loops (0 * inf = NaN on the structural zeros).
@@ -524,6 +545,23 @@ struct SqpDevice {
 
     // Gershgorin shift, dense_sparse_compare.cpp:109-122
     __device__ __forceinline__ void regularise_gershgorin() {
+        if constexpr (SCH) {   // column i of H = the node's block column: |entries| added rows ascending (x rows, then u rows), as the dense loop adds them
+            constexpr int NB = Model::NX + Model::NU;
+            for (int i = lane_id(); i < NN; i += WAVE) {
+                const bool isx = i < Model::NX * NNODES_CT_;
+                const int k = isx ? i / Model::NX : (i - Model::NX * NNODES_CT_) / Model::NU;
+                const int c = isx ? i - k * Model::NX : Model::NX + (i - Model::NX * NNODES_CT_) - k * Model::NU;
+                const double* col = hblk + k * NB * NB + c * NB;
+                const double aii = col[c];
+                double ri = 0.0;
+#pragma unroll
+                for (int r = 0; r < NB; ++r) ri += fabs(col[r]);
+                ri -= fabs(aii);
+                if (aii - ri <= 0) hblk[k * NB * NB + c * NB + c] = aii + ((ri - aii) + 0.01);
+            }
+            wsync();
+            return;
+        }
         for (int i = lane_id(); i < n; i += WAVE) {
             const double aii = Hw[(size_t)i * ldw + i];
             double ri = 0.0;
@@ -548,9 +586,11 @@ struct SqpDevice {
         if (exact) {
             ocp.stage_second_order(v.x, v.lam);
             const long long l2 = now();
-            ocp.template assemble_first_order<false>(v.al, Aw, v.h, ldw, structure);
+            if constexpr (SCH) ocp.template assemble_first_order<false, false>(v.al, nullptr, v.h, 0, false);
+            else ocp.template assemble_first_order<false>(v.al, Aw, v.h, ldw, structure);
             const long long l3 = now();
-            ocp.assemble_hessian(Hw, ldw);
+            if constexpr (SCH) ocp.assemble_hessian_blocks(hblk);
+            else ocp.assemble_hessian(Hw, ldw);
             const long long l4 = now();
             lagrangian_gradient(v.lg);
             acc(11, l2 - l1); acc(12, l3 - l2); acc(13, l4 - l3); acc(14, now() - l4);
@@ -562,12 +602,14 @@ struct SqpDevice {
             // scratch at each linearisation
             bool rebuild = false;
             if constexpr (RUIZ_COMPILED) rebuild = __builtin_amdgcn_readfirstlane(ss.preconditioner) == 1;
-            ocp.template assemble_first_order<false>(v.al, Aw, v.h, ldw, rebuild);
+            if constexpr (SCH) ocp.template assemble_first_order<false, false>(v.al, nullptr, v.h, 0, false);
+            else ocp.template assemble_first_order<false>(v.al, Aw, v.h, ldw, rebuild);
             const long long l3 = now();
             lagrangian_gradient(v.lgn);
             acc(12, l3 - l1); acc(14, now() - l3);
             const long long b0 = now();
-            if constexpr (REG1 && HU == 1) bfgs_update_block();
+            if constexpr (SCH) bfgs_update_block();
+            else if constexpr (REG1 && HU == 1) bfgs_update_block();
             else if constexpr (REG1) { double brow[NN > 0 ? NN : 1]; bfgs_load_row(brow); bfgs_update_reg(brow); }
             else if constexpr (REG2) { if (__builtin_amdgcn_readfirstlane(ss.hessian_update) == 1) bfgs_update_block(); else bfgs_update_reg2(); }
             else { if (__builtin_amdgcn_readfirstlane(ss.hessian_update) == 1) bfgs_update_block(); else bfgs_update(); }   // (the launcher routes hessian_update = 1 to these kernels)
@@ -743,6 +785,25 @@ struct SqpDevice {
         const int ln = lane_id();
         const int VARX = ocp.dm.VARX, VARU = ocp.dm.VARU, NNo = ocp.dm.NN;
         double* vv = v.t1; double* r = v.t2; double* y = v.t3;
+        if constexpr (SCH) {   // row i of B times s from the node's block: the non-zero products of the dense chain, columns ascending (x columns, then u columns)
+            for (int i = ln; i < n; i += WAVE) {
+                const bool isx = i < VARX;
+                const int k = isx ? i / NX : (i - VARX) / NU;
+                const int c = isx ? i - k * NX : NX + (i - VARX) - k * NU;
+                double hb[NB], sv[NB];
+#pragma unroll
+                for (int cc = 0; cc < NB; ++cc) hb[cc] = hblk[k * NB * NB + cc * NB + c];
+#pragma unroll
+                for (int cc = 0; cc < NX; ++cc) sv[cc] = v.step[k * NX + cc];
+#pragma unroll
+                for (int cc = 0; cc < NU; ++cc) sv[NX + cc] = v.step[VARX + k * NU + cc];
+                double a = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < NB; ++cc) a += hb[cc] * sv[cc];
+                vv[i] = a;
+                y[i] = v.lgn[i] - v.lg[i];
+            }
+        } else
         for (int i = ln; i < n; i += WAVE) {
             vv[i] = seq_dot_strided<MEMCH>(Hw, (size_t)ldw, 1, i, n, v.step);   // row i of B times s: one add chain, columns ascending, eight loads in flight
             y[i] = v.lgn[i] - v.lg[i];
@@ -766,7 +827,8 @@ struct SqpDevice {
             const int k = e / (NB * NB), rem = e - k * (NB * NB), bj = rem / NB, bi = rem - bj * NB;
             const int gi = gidx(k, bi), gj = gidx(k, bj);
             const double t = (bi < NX && bj >= NX) ? term(gj, gi) : term(gi, gj);   // the xu block is the transpose of the ux block
-            Hw[(size_t)gj * ldw + gi] += t;
+            if constexpr (SCH) hblk[e] += t;   // (e = k NB^2 + bj NB + bi: the block layout itself)
+            else Hw[(size_t)gj * ldw + gi] += t;
         }
         if constexpr (NP > 0) {
             const int a = VARX + VARU;
@@ -850,7 +912,11 @@ struct SqpDevice {
             if (ruiz) rz_c = ruiz_compute_wave(n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, rz);
         }
         // 7-argument form: zero guesses (Q2)
-        if constexpr (REG2) {   // (lower-triangle read of H always: the Hessian update is a run-time choice in these kernels)
+        if constexpr (SCH) {
+            boxadmm_solve_schur<Model, SCH_P, SCH_S>(hblk, v.h, ocp.jblk, ocp.s.D, ocp.s.nsr, v.al, v.au, v.lx, v.ux, qs, qi, qw.x, qw.y, tr, qblk, xsc, dsc, pdl, dtab,
+                                                     PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr);
+            wsync();
+        } else if constexpr (REG2) {   // (lower-triangle read of H always: the Hessian update is a run-time choice in these kernels)
             // (POL: the Ruiz preconditioner may have rescaled the workspace, whose entries the blocks of the sparse view then no longer are: dense residuals)
             if constexpr (POL) boxadmm_solve_reg2<NN, MM, true, true>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr);
             else boxadmm_solve_reg2<NN, MM, true, true>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr, jview());

@@ -52,12 +52,24 @@ REG1_QP_SHAPES = ((35, 21), (20, 12), (25, 15), (30, 18), (40, 24), (24, 16), (3
 REG_NODE_COUNTS = (3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16)   # grids of the built-in models with register-resident SQP kernels (pmpc_launch.hpp, pmpc_grids.hpp)
 
 
-def _gpu_order(oracle, n, m, nodes=None, block_bfgs=False, kkt_form=0):
+SCHUR_GRIDS = {0: ((5, 2), (5, 3)), 1: ((5, 2), (6, 1))}   # model -> (P, S) routed to a block-structured kernel (pmpc_schur_*.hip; more than 64 KKT rows)
+
+
+def _schur_route(model, P, S, hessian_update=0, exact_hessian_every_iter=0, regularisation=0, preconditioner=0, qp_solver=0, line_search=0, kkt_form=0,
+                 linear_solver=0, **_):
+    """Does the request take the block-structured kernel (pmpc_launch.hpp: schur_request_ok + the compiled grids)? Its restatement is PIVOT_SCHUR."""
+    return (P, S) in SCHUR_GRIDS.get(model, ()) and (hessian_update == 1 or exact_hessian_every_iter) and regularisation in (0, 2) and \
+        not preconditioner and not qp_solver and not line_search and not kkt_form and not linear_solver
+
+
+def _gpu_order(oracle, n, m, nodes=None, block_bfgs=False, kkt_form=0, schur=False):
     """Which of the oracle's GPU-order linear-solve restatements mirrors the kernel that serves this size: the register-resident QP
     (compile-time sizes with n+m <= 64: the (35, 21) QP entry point, SQP grids of 3 to 8 nodes) applies the inverse swept in blocks of
     four pivots (PIVOT_SWEEP); the two-rows-per-lane register path (65..112 rows: the (66, 44) and (55, 33) QP entry points) the same sweep with
     its own mat-vec order (PIVOT_SWEEP2); every other size runs an LDS/HBM-resident kernel (_lds_order: PIVOT_STATIC). All of them are tied to the
     reference's pivoted Eigen LDLT (PIVOT_EIGEN) in tests/test_oracle_pins.py."""
+    if schur:
+        return oracle.PIVOT_SCHUR
     if nodes is None:
         if (n, m) in REG2_QP_SHAPES:
             return oracle.PIVOT_SWEEP2
@@ -549,7 +561,8 @@ def _sqp_both(ctx, oracle, wl, B, **kw):
     #  order; hessian_update = 1 has register-resident specialisations like the default)
     if kw.get("qp_solver", 0): order = oracle.PIVOT_STATIC
     elif kw.get("preconditioner", 0) or kw.get("line_search", 0): order = _policy_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, ruiz=bool(kw.get("preconditioner", 0)), block_bfgs=bool(kw.get("hessian_update", 0)), kkt_form=kf)
-    else: order = _gpu_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, block_bfgs=bool(kw.get("hessian_update", 0)), kkt_form=kf)
+    else: order = _gpu_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, block_bfgs=bool(kw.get("hessian_update", 0)), kkt_form=kf,
+                             schur=_schur_route(wl["model"], wl["P"], wl["S"], **kw))
     xo, lo, io = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"],
                                         sqp_settings=oss, pivot=order, threads=8)
     return (x, lam, info), (xo, lo, io)
@@ -603,8 +616,9 @@ def test_sqp_codegen_robot_exact_hessian(ctx, oracle):
     assert info["status"][0] == pa.SQP_SOLVED and info["iter"][0] < 10
     oss = oracle.sqp_default_settings(); oss.max_iter = 10; oss.line_search_max_iter = 10; oss.exact_hessian_every_iter = 1
     oqs = oracle.sqp_qp_default_settings(); oqs.max_iter = 1000
-    xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 1.0, 1, [[1.0]], lbx, ubx, sqp_settings=oss, qp_settings=oqs, pivot=_gpu_order(oracle, 55, 33, 11))
+    xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 1.0, 1, [[1.0]], lbx, ubx, sqp_settings=oss, qp_settings=oqs, pivot=_gpu_order(oracle, 55, 33, 11, schur=True))   # exact Hessians: block diagonal -> the block-structured kernel
     _assert_same_solve(info, io, x, xo, lam, lo)
+    assert ctx.last_route() == pa.capi.ROUTE_SCHUR
 
 
 def test_sqp_minimal_time_valet_parking(ctx, oracle):
@@ -772,6 +786,32 @@ def test_sqp_block_bfgs_vs_oracle(ctx, oracle):
     assert np.array_equal(x, xo) and np.array_equal(lam, lo)
 
 
+@pytest.mark.parametrize("model,P,S,B", [(0, 5, 2, 256), (0, 5, 3, 256), (1, 5, 2, 256), (1, 6, 1, 64)])
+def test_sqp_block_structured_kernel_vs_oracle(ctx, oracle, model, P, S, B):
+    """The block-structured kernel (pmpc_qp_schur.hpp; route PMPC_ROUTE_SCHUR): a Hessian that is block diagonal per node — the block BFGS every control
+    test of the reference selects (hessian_update = 1, continuous_ocp.hpp:2304-2431) or exact Hessians every iteration — kept as per-node blocks in LDS,
+    the QP through the m x m Schur complement with one refinement step. Config A's, config B's and the reference's own grids: identical trajectories and
+    bit-identical x, lambda and KKT quantities against the restatement in this order (PIVOT_SCHUR) on every instance; also with the Gershgorin shift and
+    with exact Hessians; kkt_form = 1 keeps the dense kernels."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    if model == 0:
+        wl = workloads.robot_batch(B, P=P, S=S)
+    elif (P, S) == (5, 2):
+        wl = workloads.cstr_batch(B)
+    else:
+        lbx, ubx = _cstr_grid(B, P, S)
+        wl = dict(model=1, P=P, S=S, t0=0.0, tf=100.0, d=np.zeros((B, 1)), lbx=lbx, ubx=ubx, max_iter=8, ls_max_iter=20)
+    for kw in (dict(hessian_update=1), dict(hessian_update=1, regularisation=2), dict(exact_hessian_every_iter=1, regularisation=2)):
+        (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, wl, B, **kw)
+        assert ctx.last_route() == pa.capi.ROUTE_SCHUR, kw
+        _assert_same_solve(info, io, x, xo, lam, lo)
+        assert np.all(info["flags"] == 0)
+    (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, wl, min(B, 32), hessian_update=1, kkt_form=1)
+    assert ctx.last_route() != pa.capi.ROUTE_SCHUR
+    _assert_same_solve(info, io, x, xo, lam, lo)
+
+
 def test_sqp_admm_qp_solver_vs_oracle(ctx, oracle):
     """qp_solver = 1 (Solver<Problem, ADMM<...>>, the OSQP-form QP of admm.hpp inside the fused SQP kernel): identical SQP and ADMM
     iteration counts and x within 1e-8 of the CPU restatement, on config A's grid (91-row stacked KKT) and on P=5, S=2 (143 rows)."""
@@ -801,7 +841,7 @@ def test_sqp_cstr_reference_scenario(ctx, oracle, hessian_update):
     import polympc_amd as pa
     from test_oracle_pins import _cstr_reference_scenario
     n = 66
-    order = _gpu_order(oracle, 66, 44, 11)
+    order = _gpu_order(oracle, 66, 44, 11, schur=bool(hessian_update))   # block BFGS: the block-structured kernel (PIVOT_SCHUR)
     for reg in (0, 2):
         ss = pa.sqp_settings_default(); ss.max_iter = 20; ss.line_search_max_iter = 20; ss.regularisation = reg; ss.hessian_update = hessian_update
         oss = oracle.sqp_default_settings(); oss.max_iter = 20; oss.line_search_max_iter = 20; oss.regularisation = reg; oss.hessian_update = hessian_update
@@ -817,9 +857,14 @@ def test_sqp_cstr_reference_scenario(ctx, oracle, hessian_update):
         lbx[0, 40:44] = ubx[0, 40:44] = [1.1, 0.508, 100.5, 100.1]
         x2, lam2, i2 = ctx.sqp_solve_batch(pa.MODEL_CSTR, 5, 2, 0.0, 100.0, 1, d, lbx, ubx, x_guess=x, lam_guess=lam, sqp_settings=ss)
         xo2, lo2, io2 = oracle.sqp_solve_batch(oracle.MODEL_CSTR, 5, 2, 0.0, 100.0, 1, d, lbx, ubx, x_guess=xo, lam_guess=lo, sqp_settings=oss, pivot=order)
-        assert i2["iter"][0] == io2[0].iter and i2["qp_solver_iter"][0] == io2[0].qp_solver_iter and i2["status"][0] == io2[0].status
-        assert np.array_equal(x2, xo2, equal_nan=True) and np.array_equal(lam2, lo2, equal_nan=True)
-        assert (i2["flags"][0] != 0) == (not np.isfinite(x2).all())
+        if hessian_update and not (np.isfinite(xo2).all() and np.isfinite(lo2).all()):
+            # block-structured kernel: its sparse products skip structural zeros, which is the dense chains' statement for FINITE operands only — once the
+            # unregularised warm solve has overflowed (it does in this order with the shared exp) both sides are non-finite, and the kernel says so
+            assert not (np.isfinite(x2).all() and np.isfinite(lam2).all()) and i2["flags"][0] != 0
+        else:
+            assert i2["iter"][0] == io2[0].iter and i2["qp_solver_iter"][0] == io2[0].qp_solver_iter and i2["status"][0] == io2[0].status
+            assert np.array_equal(x2, xo2, equal_nan=True) and np.array_equal(lam2, lo2, equal_nan=True)
+            assert (i2["flags"][0] != 0) == (not np.isfinite(x2).all())
         # the same two solves with Eigen::LDLT's pivoting on the device (linear_solver = 1): bit-identical to the Eigen-order restatement
         qp = pa.qp_settings_sqp_default(); qp.linear_solver = 1
         lbx[0, 40:44] = ubx[0, 40:44] = [1.0, 0.5, 100.0, 100.0]
@@ -1206,6 +1251,13 @@ def test_last_route_reports_the_kernel_family(ctx):
     # round 3: the Ruiz preconditioner and the filter line search on the 7- and 11-node register kernels; other grids keep the LDS / HBM kernels for them
     assert route(workloads.robot_batch(4), preconditioner=1) == pa.capi.ROUTE_REG1
     assert route(workloads.robot_batch(4), line_search=1, hessian_update=1) == pa.capi.ROUTE_REG1
+    # round 4: a block-diagonal Hessian (block BFGS / exact Hessians) on a grid with a block-structured kernel
+    assert route(workloads.robot_batch(4, P=5, S=2), hessian_update=1) == pa.capi.ROUTE_SCHUR
+    assert route(workloads.cstr_batch(4), hessian_update=1) == pa.capi.ROUTE_SCHUR
+    assert route(workloads.robot_batch(4), hessian_update=1) == pa.capi.ROUTE_REG1                # 56 KKT rows: the dense one-row-per-lane kernel is faster
+    assert route(workloads.robot_batch(4, P=5, S=3), exact_hessian_every_iter=1) == pa.capi.ROUTE_SCHUR
+    assert route(workloads.robot_batch(4, P=4, S=1), hessian_update=1) == pa.capi.ROUTE_REG1      # no block-structured kernel for this grid
+    assert route(workloads.robot_batch(4, P=5, S=2), hessian_update=1, kkt_form=1) == pa.capi.ROUTE_REG2
     assert route(workloads.robot_batch(4, P=5, S=2), preconditioner=1, line_search=1) == pa.capi.ROUTE_REG2
     assert route(workloads.robot_batch(4, P=4, S=2), preconditioner=1) == pa.capi.ROUTE_LDS
     assert route(workloads.robot_batch(4, P=5, S=3)) == pa.capi.ROUTE_REG2

@@ -618,7 +618,7 @@ def test_sqp_cstr_warm_solve_is_a_last_bit_property(oracle):
     for glibc in (True, False):
         prev = oracle.set_libm(glibc)
         try:
-            for pivot in (oracle.PIVOT_EIGEN, oracle.PIVOT_STATIC, oracle.PIVOT_SWEEP2):
+            for pivot in (oracle.PIVOT_EIGEN, oracle.PIVOT_STATIC, oracle.PIVOT_SWEEP2, oracle.PIVOT_SCHUR):
                 for dx in (0.0, 1e-13, -1e-13):
                     (x1, i1), (x2, i2) = _cstr_reference_scenario(oracle, pivot, perturb=dx)
                     assert (i1.iter, i1.qp_solver_iter, i1.status) == (7, 380, oracle.SQP_SOLVED), (glibc, pivot, dx)

@@ -11,7 +11,7 @@ P_, S_ = int(os.environ.get("P", 6)), int(os.environ.get("S", 1))   # P=5 S=2 (8
 _cfg = os.environ.get("CFG")   # CFG=B: config B (CSTR, 110 KKT rows); CFG=C: the kite stand-in (464 KKT rows)
 wl = workloads.cstr_batch(B) if _cfg == "B" else (workloads.kite_standin_batch(B) if _cfg == "C" else workloads.robot_batch(B, P=P_, S=S_))
 ctx = pa.Context(0)
-ss = pa.sqp_settings_default(); ss.max_iter = wl["max_iter"]; ss.line_search_max_iter = wl["ls_max_iter"]
+ss = pa.sqp_settings_default(); ss.max_iter = wl["max_iter"]; ss.line_search_max_iter = wl["ls_max_iter"]; ss.hessian_update = int(os.environ.get("HESSIAN_UPDATE", 0))
 for rep in range(2):
     t = time.perf_counter()
     x, lam, info = ctx.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)

@@ -272,12 +272,13 @@ def main():
             def add(key, letter, cwl, Bc, steps, warmup, kernel_name, workload):
                 cfg[key] = sqp_record(cwl, Bc, steps, warmup, kernel_name)
                 cfg[key]["workload"] = workload
-                cfg_runs[key] = (letter, cwl, Bc, sol[0])
+                base_sol = sol[0]
                 # the same batch with the Hessian update every control test of the reference selects (cstr_control_test.cpp:128-132,
                 # mpc_wrapper_test.cpp:100-105, minimal_time_test.cpp:84-88, valet_parking_mpc_test.cpp:161-165 -> continuous_ocp.hpp:2304-2431)
                 vb = sqp_record(cwl, Bc, max(3, steps // 2), 1, kernel_name + ", hessian_update = 1", hessian_update=1)
                 cfg[key]["variant_block_bfgs"] = {k_: vb[k_] for k_ in ("steps", "ms_per_batch", "qp_solves_per_s", "sqp_solves_per_s", "qp_solves_per_batch",
                                                                           "admm_iters_per_qp", "sqp_solved_fraction", "route")}
+                cfg_runs[key] = (letter, cwl, Bc, base_sol, sol[0])
             if "D" in want:
                 add("D_scenario_8192_per_gpu", "D", workloads.robot_batch(8192, perturb_d=True, first=5000), 8192, 10, 2, "sqp_kernel<RobotOCP,35,21>",
                     "mobile robot, perturbed wheel base d = 2(1+0.1U), 8192 instances per GPU (65 536 over 8 GPUs)")
@@ -371,13 +372,14 @@ def main():
             # ---- the same two objects + a CPU baseline beside every sub-record ("the reference CPU path timed next to it"): bounded samples
             from polympc_amd.parity_stats import cross_order_stats
             SAMPLE = {"D": (4096, 256), "B": (2048, 64), "C": (64, 8), "R": (1024, 128)}   # instances of the (all-core, single-core) CPU samples / parity objects
-            for key, (letter, cwl, Bfull, gsol) in (cfg_runs.items() if world == 1 and "configs" in out else []):
+            for key, (letter, cwl, Bfull, gsol, vsol) in (cfg_runs.items() if world == 1 and "configs" in out else []):
                 n_all, n_one = SAMPLE[letter]
                 coss = ob.sqp_default_settings(); coss.max_iter = cwl["max_iter"]; coss.line_search_max_iter = cwl["ls_max_iter"]
                 rows = cwl["n"] + cwl["m"]
                 korder = ob.PIVOT_SWEEP if rows <= 64 else (ob.PIVOT_SWEEP2 if rows <= ob.SWEEP2_MAX_ROWS else ob.PIVOT_CONDENSED)
 
-                def crun(count, threads, pivot, glibc):
+                def crun(count, threads, pivot, glibc, hu=0):
+                    coss.hessian_update = hu
                     with (ob.libm() if glibc else _null()):
                         return ob.sqp_solve_batch(cwl["model"], cwl["P"], cwl["S"], cwl["t0"], cwl["tf"], count, cwl["d"][:count], cwl["lbx"][:count],
                                                   cwl["ubx"][:count], sqp_settings=coss, pivot=pivot, threads=threads)
@@ -401,6 +403,18 @@ def main():
                 cfg[key]["parity_vs_cpu_reference"] = pr
                 xk, lk, ik = crun(n_all, cores, korder, False)
                 it_k = np.array([i.iter for i in ik]); qi_k = np.array([i.qp_solver_iter for i in ik])
+                # the block-BFGS variant: the kernel that served it decides the restated order (block-structured kernel: PIVOT_SCHUR)
+                vx, vl, vi = vsol
+                nv = max(32, n_all // 2)
+                vorder = ob.PIVOT_SCHUR if cfg[key]["variant_block_bfgs"]["route"] == "schur" else korder
+                xk2, lk2, ik2 = crun(nv, cores, vorder, False, hu=1)
+                xr2, lr2, ir2 = crun(nv, cores, ob.PIVOT_EIGEN, True, hu=1)
+                it2 = np.array([i.iter for i in ik2]); qi2 = np.array([i.qp_solver_iter for i in ik2])
+                cfg[key]["variant_block_bfgs"]["parity_vs_cpu_same_order"] = {
+                    "instances": nv, "order": int(vorder), "identical_trajectory_fraction": float(((it2 == vi["iter"][:nv]) & (qi2 == vi["qp_solver_iter"][:nv])).mean()),
+                    "bit_identical_x": bool(np.array_equal(vx[:nv], xk2)), "bit_identical_lam": bool(np.array_equal(vl[:nv], lk2)), "max_abs_dx": float(np.abs(vx[:nv] - xk2).max())}
+                cfg[key]["variant_block_bfgs"]["parity_vs_cpu_reference"] = cross_order_stats(letter, cwl, vx[:nv], vl[:nv], vi[:nv], xr2, lr2, ir2)
+                coss.hessian_update = 0
                 cfg[key]["parity_vs_cpu_same_order"] = {"instances": n_all, "order": int(korder),
                                                         "identical_trajectory_fraction": float(((it_k == gi["iter"][:n_all]) & (qi_k == gi["qp_solver_iter"][:n_all])).mean()),
                                                         "bit_identical_x": bool(np.array_equal(gx[:n_all], xk)), "bit_identical_lam": bool(np.array_equal(gl[:n_all], lk)),

@@ -71,3 +71,29 @@ def test_two_wave_kernels_fit_half_the_register_file():
                     seen["reg2"] += 1
                     assert vgpr <= 512
     assert seen["reg1"] > 0 and seen["big2"] > 0 and seen["big1"] > 0 and seen["reg2"] > 0, seen
+
+
+@pytest.mark.skipif(not (os.path.exists(f"{LLVM}/clang-offload-bundler") and os.path.exists(f"{LLVM}/llvm-objdump")), reason="ROCm binutils not installed")
+def test_block_structured_kernels_do_not_spill_inside_the_swept_inverse():
+    """Compiler hazard 3: a VGPR spill placed inside a partial-EXEC region loses the inactive lanes' copies. The blocked sweep of RegKkt
+    stages its tiles under lane predicates; the block-structured kernels (pmpc_qp_schur.hpp) call it with far more live state around it than the dense
+    one-row-per-lane kernels do, and a build that put scratch traffic there returned wrong answers on the 16-node grid. Checked on the built code: no
+    scratch instruction between the first and the last matrix-core instruction of any sqp_schur_kernel."""
+    checked = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for co in _code_objects(tmp):
+            syms = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+            if "sqp_schur_kernel" not in syms:
+                continue
+            dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
+            for blk in re.split(r"\n(?=[0-9a-f]+ <)", dis):
+                head = blk.split("\n", 1)[0]
+                if "sqp_schur_kernel" not in head:
+                    continue
+                lines = blk.split("\n")
+                mf = [i for i, l in enumerate(lines) if "v_mfma" in l]
+                assert mf, head
+                inside = [l for l in lines[mf[0]:mf[-1]] if "scratch_" in l]
+                assert not inside, f"{head}: {len(inside)} scratch instructions inside the swept inverse"
+                checked += 1
+    assert checked >= 4

@@ -702,6 +702,58 @@ def test_kernel_orders_against_the_reference_order_one_qp_at_a_time(oracle, cfg,
     assert rec["max_abs_d_res_prim"] <= 1e-8 and rec["max_abs_d_res_dual"] <= 1e-8, rec
 
 
+@pytest.mark.parametrize("cfg,min_qps,B", [("A", 1024, 256), ("B", 768, 256), ("R", 512, 128)])
+def test_block_structured_order_against_the_reference_order(oracle, cfg, min_qps, B):
+    """PIVOT_SCHUR — the order of the block-structured kernel (pmpc_qp_schur.hpp): per-node inverses of H + sigma I + rho_box, the m x m Schur
+    complement swept like PIVOT_SWEEP, one step of iterative refinement on the constraint rows — admitted like the other kernel orders: on the QPs of the
+    reference-order SQP with the block BFGS the reference's control tests select (config A's, config B's and the reference's 16-node grid) every QP keeps
+    its ADMM iteration count, status and rho updates, the residuals lie within 1e-8 of PIVOT_EIGEN's (measured: <= 1.4e-11 — CLOSER than the swept
+    orders), and whole SQP trajectories are identical with |dx| <= 1e-8."""
+    import tools_cross_order as tco
+    q = tco.traced_qp_stream(oracle, cfg, min_qps, hessian_update=1)
+    x, y, i = oracle.qp_solve_batch(q["H"], q["h"], q["A"], q["Alb"], q["Aub"], q["xlb"], q["xub"], settings=oracle.sqp_qp_default_settings(),
+                                    pivot=oracle.PIVOT_SCHUR, threads=8, structure=q["structure"])
+    xr, yr, ir = tco.reference_qp_solve(oracle, q, threads=8)
+    rec = tco.qp_level_stats(x, y, i, xr, yr, ir)
+    assert rec["different_iter"] == 0 and rec["different_status"] == 0 and rec["different_rho_updates"] == 0, rec
+    assert rec["max_abs_d_res_prim"] <= 1e-10 and rec["max_abs_d_res_dual"] <= 1e-10, rec
+    wl, _ = tco.config_workload(cfg, B=B)
+    xs, ls, is_ = tco.oracle_run(oracle, wl, B, oracle.PIVOT_SCHUR, False, 8, hessian_update=1)
+    xe, le, ie = tco.oracle_run(oracle, wl, B, oracle.PIVOT_EIGEN, True, 8, hessian_update=1)
+    tr = tco.cross_order_stats(cfg, wl, xs, ls, is_, xe, le, ie)
+    assert tr["different_trajectories"] == 0 and tr["max_abs_dx"] <= 1e-8 and tr["max_abs_d_constraint_violation"] <= 1e-10, tr
+
+
+def test_block_structured_order_needs_its_refinement_step(oracle):
+    """Why PIVOT_SCHUR refines: a config-B KKT system after a rho update (rho = 3.6: cond(S) = 6e5, S = 1/rho + A Q A'). The swept inverse of S has an
+    isotropic forward error ~ eps cond(S) |nu|, but x = Q (r1 - A' nu) tolerates errors of nu only where Q^(1/2) A' nearly vanishes — without the step
+    the kernel order was 2e-9 .. 2e-8 off in x (1.8e-6 in the reported residuals of config B's QPs, 3.6 in a trajectory); with it the solve is MORE
+    accurate than the dense orders. Reference: numpy solve refined in extended precision."""
+    import tools_cross_order as tco
+    q = tco.traced_qp_stream(oracle, "B", 420, hessian_update=1)
+    n, m = q["n"], q["m"]
+    worst = 0.0
+    for w in (5, 100, 300, 419):
+        H = q["H"][w].reshape(n, n).T; A = q["A"][w].reshape(n, m).T; lx, ux = q["xlb"][w], q["xub"][w]
+        for rho in (0.1, 3.629):
+            rb = np.where((lx < -1e10) & (ux > 1e10), 1e-6, np.where(ux - lx < 1e-4, 1e3 * rho, rho))
+            Pm = np.tril(H) + np.tril(H, -1).T + np.diag(1e-6 + rb)
+            rv = np.full(m, 1e3 * rho)
+            K = np.block([[Pm, A.T], [A, -np.diag(1 / rv)]])
+            rhs = np.random.default_rng(w).uniform(-1, 1, n + m)
+            ld = np.longdouble
+            sol = np.linalg.solve(K, rhs).astype(ld)
+            for _ in range(6):
+                sol = sol + np.linalg.solve(K, (rhs.astype(ld) - K.astype(ld) @ sol).astype(float)).astype(ld)
+            ref = sol.astype(float)
+            got = oracle.kkt_solve(K, rv, rhs, oracle.PIVOT_SCHUR, structure=q["structure"])
+            dense = oracle.kkt_solve(K, rv, rhs, oracle.PIVOT_SWEEP2)
+            sc = max(1.0, np.abs(ref).max())
+            worst = max(worst, np.abs(got - ref).max() / sc)
+            assert np.abs(got - ref).max() <= 1e-12 * sc and np.abs(got[:n] - ref[:n]).max() <= np.abs(dense[:n] - ref[:n]).max() + 1e-13 * sc, (w, rho)
+    assert worst > 0.0
+
+
 def test_kernel_orders_against_the_reference_order_on_the_full_benchmark_streams(oracle, transcendental_functions):
     """The cross-order table of DESIGN.md §5, asserted: every BASELINE configuration at its FULL size (C: 64 of its 1024 instances — 57 QP/s on this
     container) in the kernel's order and function set against the reference's (PIVOT_EIGEN + glibc). What holds on every instance: the same SQP

@@ -34,8 +34,8 @@ def config_workload(cfg, B=None, full=False):
     raise ValueError(cfg)
 
 
-def oracle_run(ob, wl, B, pivot, glibc, threads):
-    oss = ob.sqp_default_settings(); oss.max_iter = wl["max_iter"]; oss.line_search_max_iter = wl["ls_max_iter"]
+def oracle_run(ob, wl, B, pivot, glibc, threads, hessian_update=0):
+    oss = ob.sqp_default_settings(); oss.max_iter = wl["max_iter"]; oss.line_search_max_iter = wl["ls_max_iter"]; oss.hessian_update = hessian_update
     prev = ob.set_libm(glibc)
     try:
         return ob.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"][:B], wl["lbx"][:B], wl["ubx"][:B],
@@ -44,12 +44,12 @@ def oracle_run(ob, wl, B, pivot, glibc, threads):
         ob.set_libm(prev)
 
 
-def traced_qp_stream(ob, cfg, min_qps, B=None):
+def traced_qp_stream(ob, cfg, min_qps, B=None, hessian_update=0):
     """The QPs the reference-order SQP (Eigen-style pivoted LDL^T, glibc) emits for the first instances of configuration `cfg` — true collocation
     structure and conditioning, SURVEY 8d's "QP-only microbenchmark" — stacked until at least `min_qps` of them: dict of H [Q, n n], h, A [Q, m n],
     Alb, Aub, xlb, xub (column-major matrices, as the C ABI takes them)."""
     wl, _ = config_workload(cfg, B=B or 4096)
-    oss = ob.sqp_default_settings(); oss.max_iter = wl["max_iter"]; oss.line_search_max_iter = wl["ls_max_iter"]
+    oss = ob.sqp_default_settings(); oss.max_iter = wl["max_iter"]; oss.line_search_max_iter = wl["ls_max_iter"]; oss.hessian_update = hessian_update
     keys = ("H", "h", "A", "al", "au", "lx", "ux")
     parts = {k: [] for k in keys}
     got = 0
@@ -66,7 +66,9 @@ def traced_qp_stream(ob, cfg, min_qps, B=None):
     finally:
         ob.set_libm(prev)
     q = {k: np.concatenate(v) for k, v in parts.items()}
-    return dict(H=q["H"], h=q["h"], A=q["A"], Alb=q["al"], Aub=q["au"], xlb=q["lx"], xub=q["ux"], n=wl["n"], m=wl["m"], instances=b + 1)
+    dm = ob.ocp_dims(wl["model"], wl["P"], wl["S"])
+    return dict(H=q["H"], h=q["h"], A=q["A"], Alb=q["al"], Aub=q["au"], xlb=q["lx"], xub=q["ux"], n=wl["n"], m=wl["m"], instances=b + 1,
+                structure=(dm["nx"], dm["nu"], dm["nn"], wl["P"]))
 
 
 def reference_qp_solve(ob, q, threads=1):

@@ -11,7 +11,7 @@ for name in ["sq1", "sq2", "fetch", "write", "tcc", "calfetch", "calwrite"]:
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
         kn = r["Kernel_Name"]
-        if "sqp_kernel" in kn or "stream_rw" in kn or "qp_boxadmm" in kn:
+        if "sqp_kernel" in kn or "sqp_schur_kernel" in kn or "stream_rw" in kn or "qp_boxadmm" in kn:
             agg[(kn.split("(")[0][-60:], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (kn, cn), v in agg.items():
         out.setdefault(name, {})[f"{cn} [{kn}]"] = {"per_launch_mean": sum(v) / len(v), "launches": len(v)}

@@ -12,7 +12,9 @@
 // /root/reference; the two pivot policies below restate its published algorithm:
 //   PIVOT_EIGEN  : symmetric max-|diag| pivoting, left-looking column update, D^+ solve (Eigen semantics)
 //   PIVOT_SWEEP  : no factorisation at all — W = -K^{-1} by the symmetric sweep operator in blocks of 4 pivots
-//                  (static order) and x = -(W b) as a mat-vec (block partial sums). This is the arithmetic of the register-resident HIP
+//                  (static order; since round 4 the diagonal constraint block is swept in closed form first, BoxADMM::factorise_sweep_cf — a bare
+//                  matrix handed to LDLT::compute is swept pivot block by pivot block as before)
+//                  and x = -(W b) as a mat-vec (block partial sums). This is the arithmetic of the register-resident HIP
 //                  kernel (polympc_amd/csrc/pmpc_qp_reg.hpp), restated operation by operation so that the kernel can be
 //                  checked bit for bit; it is tied to the reference only through PIVOT_EIGEN (tests/test_oracle_pins.py
 //                  compares the two policies on the reference's QP fixtures and on the SQP workloads).
@@ -157,14 +159,16 @@ struct LDLT {
 
     // tiles_as_given: the diagonal 16 x 16 tiles are taken as they are (both triangles as the caller computed them — PIVOT_SCHUR forms its rows
     // one per lane and the two triangles of a diagonal tile differ in the last bit); tiles above the block diagonal are mirror images as always
-    void compute_sweep(bool tiles_as_given = false) {
+    // npiv >= 0: only the pivots [0, npiv) are swept (the others were eliminated in closed form by the caller, BoxADMM::factorise_sweep_cf)
+    void compute_sweep(bool tiles_as_given = false, int npiv = -1) {
         auto at = [&](int i, int j) -> double& { return M[i + j * n]; };
         for (int k = 0; k < n; ++k) tr[k] = k;
         for (int j = 0; j < n; ++j) for (int i = 0; i < j; ++i) if (!tiles_as_given || i / 16 < j / 16) at(i, j) = at(j, i);   // full symmetric storage
         const int BK = 4;   // block size of the kernel (RegKkt::BK)
+        const int lim = npiv < 0 ? n : npiv;
         std::vector<double> p((size_t)n * BK), cold((size_t)n * BK), l(n);
-        for (int kb = 0; kb < n; kb += BK) {
-            const int w = std::min(BK, n - kb);
+        for (int kb = 0; kb < lim; kb += BK) {
+            const int w = std::min(BK, lim - kb);
             for (int t = 0; t < w; ++t) for (int i = 0; i < n; ++i) { p[i * BK + t] = at(i, kb + t); cold[i * BK + t] = p[i * BK + t]; }
             for (int t = 0; t < w; ++t) {
                 const int k = kb + t;
@@ -503,8 +507,37 @@ struct BoxADMM {
         for (int i = 0; i < N; ++i) sol[i] = xs[i];
         for (int i = 0; i < M; ++i) sol[N + i] = nu[i];
     }
+    // PIVOT_SWEEP since round 4 (the one-row-per-lane register kernel, pmpc_qp_reg.hpp): the constraint block of K is diagonal, -1/rho, and is swept in
+    // CLOSED FORM first — sweeping pivot n + j of [P A'; A -1/rho] adds rho_j A_j' A_j to the primal block, turns row / column n + j into -rho_j A_j and
+    // the pivot into rho_j — so that only the n primal pivots go through the blocked sweep (config A: 35 instead of 56, nine blocks instead of fourteen):
+    //   M(a, b)      = K(a, b), then fma(rho_j A(j, a), A(j, b), .) for j ascending       (a, b primal; block-lower tiles, diagonal tiles in full)
+    //   M(n + j, b)  = M(b, n + j) = -(rho_j A(j, b)),   M(n + j, n + j') = [j == j'] rho_j
+    // then PIVOT_SWEEP's blocked sweep over the pivots [0, n). W = -K^{-1} as before; the mat-vec of solve() is unchanged.
+    void factorise_sweep_cf() {
+        const int NM = N + M;
+        std::vector<double> Mm((size_t)NM * NM, 0.0);
+        for (int b = 0; b < N; ++b)
+            for (int a = 0; a < N; ++a) {
+                if (a / 16 < b / 16) continue;
+                double v = a >= b ? K[a + b * NM] : K[b + a * NM];
+                for (int j = 0; j < M; ++j) v = std::fma(rho_vec[j] * K[(N + j) + a * NM], K[(N + j) + b * NM], v);
+                Mm[a + (size_t)b * NM] = v;
+            }
+        for (int j = 0; j < M; ++j) {
+            for (int b = 0; b < N; ++b) {
+                const double v = -(rho_vec[j] * K[(N + j) + b * NM]);
+                Mm[(N + j) + (size_t)b * NM] = v;
+                if (b / 16 == (N + j) / 16) Mm[b + (size_t)(N + j) * NM] = v;   // the part of the transposed block that shares a diagonal tile with it
+            }
+            Mm[(N + j) + (size_t)(N + j) * NM] = rho_vec[j];
+        }
+        ldlt.n = NM; ldlt.policy = PIVOT_SWEEP; ldlt.M.swap(Mm); ldlt.tr.assign(NM, 0); ldlt.temp.assign(NM, 0.0);
+        if (NM > 64) throw std::invalid_argument("oracle: PIVOT_SWEEP restates the 64-row register kernel; use PIVOT_STATIC / PIVOT_EIGEN for larger systems");
+        ldlt.compute_sweep(true, N);
+    }
     void factorise() {
         if (pivot == PIVOT_SCHUR) { factorise_schur(); return; }
+        if (pivot == PIVOT_SWEEP) { factorise_sweep_cf(); return; }
         if (pivot != PIVOT_CONDENSED) { ldlt.compute(K, N + M, pivot); return; }
         const int NM = N + M;
         Sc.assign((size_t)N * N, 0.0);

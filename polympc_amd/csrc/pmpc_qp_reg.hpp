@@ -151,8 +151,17 @@ struct RegKkt {
     // Finally the tiles are converted to the mat-vec layout a[] (see the member's comment).
     // kcol(j, z) returns K(lane, j) for j != lane, needed for j <= 16*(lane/16)+15 only (z: see below); it is called 8
     // columns at a time, one group ahead of use. diag = K(lane, lane).
-    template <class KCol>
-    __device__ __forceinline__ void invert(int ln_in, double* st, double diag, KCol kcol, long long* tm = nullptr) {
+    // NPIV < N — CONSTRAINT-FIRST mode (round 4; boxADMM's K = [P A'; A -1/rho], rows [NPIV, N) = the constraint block): that block is diagonal, so
+    // its N - NPIV pivots are swept in CLOSED FORM — sweeping pivot NPIV + j adds rho_j A_j' A_j to the primal block, turns row / column NPIV + j
+    // into -rho_j A_j and the pivot into rho_j — and only the NPIV primal pivots go through the blocked sweep (config A: 35 instead of 56 pivots,
+    // nine blocks instead of fourteen: 90 + 36 matrix-core instructions instead of 140, 35 instead of 56 dependent pivot chains). kcol then returns
+    // the RAW entries: lane < NPIV: P(lane, j) for j < NPIV and A(j - NPIV, lane) beyond (every primal lane: they are the operands of the rank-m
+    // update); lane >= NPIV: A(lane - NPIV, j) for j < NPIV, 0 beyond. diag = P(lane, lane) / rho_lane; rho_self = this constraint lane's rho.
+    // The CPU restatement (oracle/qp.hpp, BoxADMM::factorise_sweep_cf) forms the same matrix entry by entry and sweeps the same blocks.
+    template <int NPIV = N, class KCol>
+    __device__ __forceinline__ void invert(int ln_in, double* st, double diag, KCol kcol, long long* tm = nullptr, double rho_self = 0.0) {
+        constexpr bool CF = NPIV < N;
+        constexpr int NBP = (NPIV + BK - 1) / BK;     // blocks of swept pivots
         long long tq0 = tm ? clock64() : 0;
         int ln = ln_in;
         asm volatile("" : "+v"(ln));   // keep the lane predicates below local to this function (no hoisting into long-lived SGPR masks)
@@ -176,10 +185,21 @@ struct RegKkt {
 #pragma unroll
         for (int j = 0; j < NP; ++j) a[j] = (j < N) ? kcol(j < N ? j : 0, z) : 0.0;
         sched_fence();
+        const bool isPl = ln < NPIV;
+        if constexpr (CF) {   // constraint lanes: row NPIV + j of the swept matrix is -rho_j A_j
+#pragma unroll
+            for (int j = 0; j < NPIV; ++j) { const double sc = -(rho_self * a[j]); a[j] = isPl ? a[j] : sc; }
+        }
 #pragma unroll
         for (int g = 0; g < NP / SG; ++g) {
 #pragma unroll
-            for (int t = 0; t < SG; ++t) X[ln * SX + t] = a[g * SG + t];
+            for (int t = 0; t < SG; ++t) {
+                double v = a[g * SG + t];
+                if constexpr (CF) {   // primal lanes, constraint columns (consumed by the lanes that share a diagonal tile with them): -rho_j A(j, lane); a[] keeps the raw entry
+                    if (g * SG + t >= NPIV && g * SG + t < N) { const double sc = -(bcast_lane(rho_self, (g * SG + t < N) ? g * SG + t : 0) * v); v = isPl ? sc : v; }
+                }
+                X[ln * SX + t] = v;
+            }
             lds_order();
             if ((lc >> 3) == (g % 2)) {
 #pragma unroll
@@ -198,10 +218,36 @@ struct RegKkt {
             for (int r = 0; r < 4; ++r) T[R][R][r] = (lc == lr + 4 * r) ? dR : T[R][R][r];
         }
         lds_order();
+        if constexpr (CF) {   // rank-(N - NPIV) update of the primal tiles: T(a, b) <- fma(rho_j A(j, a), A(j, b), T(a, b)), j ascending (one k-step of the matrix cores per 4 constraints)
+            constexpr int MC = N - NPIV, KS = (MC + 3) / 4, NTP = (NPIV + 15) / 16;
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int j = 4 * s2 + t;
+                    const double raw = (j < MC) ? a[(NPIV + j < NP) ? NPIV + j : 0] : 0.0;
+                    const double rj = (j < MC) ? bcast_lane(rho_self, (NPIV + j < N) ? NPIV + j : 0) : 0.0;
+                    const double pa = rj * raw;
+                    PA[t * SK + ln] = (isPl && j < MC) ? pa : 0.0;
+                    PB[t * SK + ln] = (isPl && j < MC) ? raw : 0.0;
+                }
+                lds_order();
+                double av[NTP], bv[NTP];
+#pragma unroll
+                for (int R = 0; R < NTP; ++R) { av[R] = PA[lr * SK + 16 * R + lc]; bv[R] = PB[lr * SK + 16 * R + lc]; }
+#pragma unroll
+                for (int R = 0; R < NTP; ++R)
+#pragma unroll
+                    for (int C = 0; C <= R; ++C) T[R][C] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[R], bv[C], T[R][C], 0, 0, 0);
+                sched_fence();
+                lds_order();
+            }
+        }
         if (tm) { long long t = clock64(); tm[0] += t - tq0; tq0 = t; }
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
+        for (int b = 0; b < NBP; ++b) {
             const int kb = b * BK;
+            const int w = (NPIV - kb < BK) ? NPIV - kb : BK;   // pivots of this block (a tail block of the constraint-first mode has fewer than BK)
             const int Cb = kb / 16, hb = (kb % 16) / BK;
             constexpr int RPB = BK / 4;   // accumulator registers (tile-local row groups of 4) per block
             // 1. panel -> row-per-lane registers: rows of tile rows >= Cb from tile column Cb (tile-local columns
@@ -221,28 +267,34 @@ struct RegKkt {
 #pragma unroll
             for (int t = 0; t < BK; ++t) p[t] = X[ln * SX + t];
             lds_order();
-            const bool inb = (ln / BK) == b;
+            const bool inb = (ln / BK) == b && (!CF || ln < NPIV);   // (constraint-first tail block: the lanes behind the last primal pivot are ordinary rows)
             if (tm) { long long t = clock64(); tm[1] += t - tq0; tq0 = t; }
             // 2. B operand: the panel as it was at the start of the block
 #pragma unroll
-            for (int t = 0; t < BK; ++t) PB[t * SK + ln] = (inb || kb + t >= N) ? 0.0 : p[t];
+            for (int t = 0; t < BK; ++t) PB[t * SK + ln] = (inb || kb + t >= NPIV) ? 0.0 : p[t];
             // 3. in-panel sweeps
 #pragma unroll
             for (int t = 0; t < BK; ++t) {
                 const int k = kb + t;
-                if (k < N) {
+                if (k < NPIV) {
                     const double dk = bcast_lane(p[t], k);
                     const double r = recip_uniform(dk);
                     double rk[BK];
 #pragma unroll
-                    for (int u = 0; u < BK; ++u) rk[u] = (u != t) ? bcast_lane(p[u], k) : 0.0;
+                    for (int u = 0; u < BK; ++u) rk[u] = (u != t && u < w) ? bcast_lane(p[u], k) : 0.0;
                     double l = p[t] * r;
                     // lane k: l = -r, and its other columns start from zero, so that one fma serves every lane
-                    if constexpr (BK == 8) pivot_lane_setup(p[(t + 1) & 7], p[(t + 2) & 7], p[(t + 3) & 7], p[(t + 4) & 7], p[(t + 5) & 7], p[(t + 6) & 7], p[(t + 7) & 7], l, -r, k);
-                    else pivot_lane_setup(p[(t + 1) & 3], p[(t + 2) & 3], p[(t + 3) & 3], l, -r, k);
+                    if (w == BK) {
+                        if constexpr (BK == 8) pivot_lane_setup(p[(t + 1) & 7], p[(t + 2) & 7], p[(t + 3) & 7], p[(t + 4) & 7], p[(t + 5) & 7], p[(t + 6) & 7], p[(t + 7) & 7], l, -r, k);
+                        else pivot_lane_setup(p[(t + 1) & 3], p[(t + 2) & 3], p[(t + 3) & 3], l, -r, k);
+                    } else {   // tail block: only the swept columns of the panel take part (the others are ordinary columns of the trailing update)
+#pragma unroll
+                        for (int u = 0; u < BK; ++u) if (u != t && u < w) p[u] = (ln == k) ? 0.0 : p[u];
+                        l = (ln == k) ? -r : l;
+                    }
 #pragma unroll
                     for (int u = 0; u < BK; ++u)
-                        if (u != t) p[u] = fma(-l, rk[u], p[u]);
+                        if (u != t && u < w) p[u] = fma(-l, rk[u], p[u]);
                     p[t] = l;
                     sched_fence();
                 }
@@ -250,7 +302,7 @@ struct RegKkt {
             if (tm) { long long t = clock64(); tm[2] += t - tq0; tq0 = t; }
             // 4. A operand
 #pragma unroll
-            for (int t = 0; t < BK; ++t) PA[t * SK + ln] = (inb || kb + t >= N) ? 0.0 : -p[t];
+            for (int t = 0; t < BK; ++t) PA[t * SK + ln] = (inb || kb + t >= NPIV) ? 0.0 : -p[t];
             lds_order();
             // 5. rank-BK update of every stored tile
 #pragma unroll
@@ -273,7 +325,7 @@ struct RegKkt {
 #pragma unroll
             for (int t = 0; t < BK; ++t) X[ln * SX + t] = p[t];
             lds_order();
-            if ((lc / BK) == hb) {
+            if ((lc / BK) == hb && (lc % BK) < w) {
 #pragma unroll
                 for (int R = Cb; R < NT; ++R)
 #pragma unroll
@@ -282,7 +334,10 @@ struct RegKkt {
 #pragma unroll
             for (int C = 0; C <= Cb; ++C)
 #pragma unroll
-                for (int rr = 0; rr < RPB; ++rr) T[Cb][C][RPB * hb + rr] = X[(16 * C + lc) * SX + lr + 4 * rr];
+                for (int rr = 0; rr < RPB; ++rr) {
+                    const double xv_ = X[(16 * C + lc) * SX + lr + 4 * rr];
+                    T[Cb][C][RPB * hb + rr] = (w == BK || lr + 4 * rr < w) ? xv_ : T[Cb][C][RPB * hb + rr];
+                }
             lds_order();
             sched_fence();
         }
@@ -430,7 +485,7 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
     double kdiag;
     {
         double kd = H[(size_t)lp * LDH + lp]; kd += s.sigma; kd += rhov;
-        kdiag = isP ? kd : -rhoinv;
+        kdiag = isP ? kd : rhov;   // (constraint lanes: the closed-form sweep leaves rho on the diagonal)
     }
 
     RegKkt<N> K;
@@ -447,15 +502,14 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
     while (running) {
         {   // construct_kkt_matrix + factorise_kkt_matrix
             const long long f0 = dbg ? clock64() : 0;
-            K.invert(ln, tr, kdiag, [&](int j, int z) -> double {   // row `lane` of [H  A^T ; A  .] (construct_kkt_matrix, box_admm.hpp:209-223)
+            // constraint-first mode of RegKkt (round 4): the RAW entries of row `lane` of [H  A^T ; A  .] (construct_kkt_matrix, box_admm.hpp:209-223);
+            // the diagonal constraint block is swept in closed form inside invert (kdiag carries rho on the constraint lanes)
+            K.template invert<NN>(ln, tr, kdiag, [&](int j, int z) -> double {
                 if (j < NN) { if constexpr (SYMLOWER) return KrowLower(j < NN ? j : 0, z); else return Krow(j < NN ? j : 0, z); }
-                // block-lower tile storage: column j is staged for the lanes of tile rows >= j/16 only, and the A' block is
-                // non-zero on primal lanes only — past the last primal tile row it is never consumed, so it is not loaded
-                if (16 * (j / 16) >= NN) return 0.0;
-                const double v = Acol(j >= NN ? j - NN : 0, z);
+                const double v = Acol(j >= NN ? j - NN : 0, z);   // every primal lane: column `lane` of A is its operand of the rank-m update
                 if constexpr (STACKED) return lane_near(z) < (unsigned)NN ? v : 0.0;
                 return isP ? v : 0.0;
-            }, tm);
+            }, tm, rhov);
             if (dbg) dbg[0] += clock64() - f0;
         }
         bool refactor = false;
@@ -538,7 +592,7 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
                     rhov = rho_of(type, rho);
                     rhoinv = 1.0 / rhov;
                     ++rho_updates;
-                    kdiag = isP ? (kdiag + (rhov - prev)) : -rhoinv;   // update_kkt_rho, box_admm.hpp:448-452
+                    kdiag = isP ? (kdiag + (rhov - prev)) : rhov;   // update_kkt_rho, box_admm.hpp:448-452
                     refactor = true;
                     ++iter;
                     break;

@@ -700,6 +700,17 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
             big_build(w.K, n, m, H, ldh, A, lda, w.kdiag); if (tb) *tb = clock64(); big_factor(w.K, N, w.big_lds);
         }
     };
+    // condensed form: S is built from the block-sparse view, which skips the structural zeros of J — with a non-finite model derivative the dense KKT
+    // form would propagate NaN through 0 * inf where this one does not: such a solve is flagged whatever x and y look like afterwards
+    bool jbad = false;
+    if constexpr (HASJ) {
+        if (cond) {
+            double pr = 0.0;
+            for (int i = ln; i < jv.NNo * (int)JV::NX * (int)JV::NDER; i += WAVE) pr += jv.jblk[i] - jv.jblk[i];
+            if constexpr ((int)JV::NG > 0) { for (int i = ln; i < jv.NNo * (int)JV::NG * (int)JV::NDER; i += WAVE) pr += jv.gblk[i] - jv.gblk[i]; }
+            jbad = __builtin_amdgcn_ballot_w64(pr != 0.0) != 0;
+        }
+    }
     const bool pivoted = !BIG && __builtin_amdgcn_readfirstlane(s.linear_solver) == 1 && w.trp != nullptr;   // Eigen::LDLT's pivoting (LDS-resident mode only)
     auto tick = [&]() -> long long { return tm ? clock64() : 0; };
     // x = x_guess; y = y_guess; z = A*x_guess; q = x_guess  (:97-100)
@@ -833,7 +844,7 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
     for (int i = ln; i < n; i += WAVE) worst += fabs(w.x[i] - w.x[i]);
     for (int i = ln; i < N; i += WAVE) worst += fabs(w.y[i] - w.y[i]);
     const bool bad = __builtin_amdgcn_ballot_w64(worst != 0.0) != 0;
-    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info.flags = bad ? PMPC_FLAG_NONFINITE : 0;
+    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info.flags = (bad || jbad) ? PMPC_FLAG_NONFINITE : 0;
     info.rho_estimate = rho_estimate; info.res_prim = rs.res_prim; info.res_dual = rs.res_dual;
 }
 

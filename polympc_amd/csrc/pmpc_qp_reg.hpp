@@ -157,7 +157,7 @@ struct RegKkt {
     // nine blocks instead of fourteen: 90 + 36 matrix-core instructions instead of 140, 35 instead of 56 dependent pivot chains). kcol then returns
     // the RAW entries: lane < NPIV: P(lane, j) for j < NPIV and A(j - NPIV, lane) beyond (every primal lane: they are the operands of the rank-m
     // update); lane >= NPIV: A(lane - NPIV, j) for j < NPIV, 0 beyond. diag = P(lane, lane) / rho_lane; rho_self = this constraint lane's rho.
-    // The CPU restatement (oracle/qp.hpp, BoxADMM::factorise_sweep_cf) forms the same matrix entry by entry and sweeps the same blocks.
+    // The CPU restatement of the test suite (PIVOT_SWEEP, constraint-first) forms the same matrix entry by entry and sweeps the same blocks.
     template <int NPIV = N, class KCol>
     __device__ __forceinline__ void invert(int ln_in, double* st, double diag, KCol kcol, long long* tm = nullptr, double rho_self = 0.0) {
         constexpr bool CF = NPIV < N;
@@ -195,8 +195,8 @@ struct RegKkt {
 #pragma unroll
             for (int t = 0; t < SG; ++t) {
                 double v = a[g * SG + t];
-                if constexpr (CF) {   // primal lanes, constraint columns (consumed by the lanes that share a diagonal tile with them): -rho_j A(j, lane); a[] keeps the raw entry
-                    if (g * SG + t >= NPIV && g * SG + t < N) { const double sc = -(bcast_lane(rho_self, (g * SG + t < N) ? g * SG + t : 0) * v); v = isPl ? sc : v; }
+                if constexpr (CF) {   // primal lanes, constraint columns that share a tile with primal rows (the only ones ever read from a primal lane): -rho_j A(j, lane); a[] keeps the raw entry
+                    if (g * SG + t >= NPIV && g * SG + t < N && 16 * ((g * SG + t) / 16) < NPIV) { const double sc = -(bcast_lane(rho_self, (g * SG + t < N) ? g * SG + t : 0) * v); v = isPl ? sc : v; }
                 }
                 X[ln * SX + t] = v;
             }

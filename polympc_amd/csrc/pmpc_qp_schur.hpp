@@ -18,8 +18,8 @@
 //     the grid with the coefficient 0 outside the row's / column's segment — no divergence, and the same statement for non-finite operands.
 //   * residuals (box_admm.hpp:398-415): H x from the blocks, A x / A' y from pmpc_jview.hpp — the non-zero products of the reference's dense chains in
 //     the same ascending order (multiply, then add).
-// The CPU restatement of exactly this order is PIVOT_SCHUR (oracle/qp.hpp): the kernels are checked bit for bit against it, and it is tied to the
-// reference's pivoted LDL^T on the QP streams of every configuration (tests/test_oracle_pins.py).
+// The CPU restatement of exactly this order is PIVOT_SCHUR (the CPU checker of the test suite): the kernels are checked bit for bit against it, and it is tied to the
+// reference's pivoted LDL^T on the QP streams of every configuration by the CPU tests.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "pmpc_jview.hpp"

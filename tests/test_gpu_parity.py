@@ -1226,6 +1226,27 @@ def test_default_kernels_against_the_reference_order(ctx, oracle, cfg):
     assert np.all(info["flags"] == 0)
 
 
+@pytest.mark.parametrize("hessian_update", [0, 1])
+def test_cstr_short_horizon_tight_pin_against_the_reference_order(ctx, oracle, hessian_update):
+    """A TIGHT pin beside the percentile test above (config B's 20-iteration trajectories amplify last-bit differences to 3e-6 scaled on the worst
+    instance): the same 1024 CSTR instances stopped after 5 SQP iterations, where nothing has been amplified yet — default kernel (two rows per lane,
+    dense BFGS) and block-structured kernel (block BFGS) against the restatement as the reference computes (PIVOT_EIGEN, glibc): identical trajectories
+    on every instance, every variable within 1e-9 of its magnitude (measured 8.8e-11 / 7.5e-13), multipliers within 1e-9 scaled, violation within 1e-10.
+    A regression of either kernel's accuracy below ~1e-9 fails here."""
+    import polympc_amd as pa
+    import tools_cross_order as tco
+    nB = 1024
+    wl, _ = tco.config_workload("B", B=nB); wl = dict(wl); wl["max_iter"] = 5
+    ss = pa.sqp_settings_default(); ss.max_iter = 5; ss.line_search_max_iter = wl["ls_max_iter"]; ss.hessian_update = hessian_update
+    x, lam, info = ctx.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], nB, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
+    assert ctx.last_route() == (pa.capi.ROUTE_SCHUR if hessian_update else pa.capi.ROUTE_REG2)
+    xr, lr, ir = tco.oracle_run(oracle, wl, nB, oracle.PIVOT_EIGEN, True, 8, hessian_update=hessian_update)
+    r = tco.cross_order_stats("B", wl, x, lam, info, xr, lr, ir)
+    print(hessian_update, r)
+    assert r["different_trajectories"] == 0
+    assert r["scaled_dx_per_instance"]["max"] <= 1e-9 and r["scaled_dlam_per_instance"]["max"] <= 1e-9 and r["max_abs_d_constraint_violation"] <= 1e-10
+
+
 def ROUTE_OF_128_ROWS(pa):
     """the kernel family pmpc_launch.hpp routes 128-row instances to (one place to change when the route changes)"""
     return pa.capi.ROUTE_REG2   # round 3: 113..128 rows on the two-rows-per-lane register path (8 x 8 tiles, sixteen of them in LDS)

@@ -629,7 +629,7 @@ struct SqpDevice {
         const int row = lane_id() + 64 * E;
         const unsigned i = (row < NN ? row : 0) + opaque_zero();
 #pragma unroll
-        for (int j = 0; j < NN; ++j) brow[j] = Hw[i + (unsigned)(j * (NN + MM))];
+        for (int j = 0; j < NN; ++j) brow[j] = (Hw + (size_t)(j * (NN + MM)))[i];   // (uniform column base + ONE per-lane offset: scalar-base addressing, no address register pair per load)
     }
     // B s and y for the rows of slot E (into v.t1 / v.t3); brow stays in registers
     template <int E>
@@ -659,14 +659,16 @@ struct SqpDevice {
                     double b = brow[j0 + j];
                     b += by_sBs(-Bsi * bsj[j]);
                     b += by_sr(ri * rj[j]);
+                    asm volatile("" : "+v"(b));   // (pins the chunk here — see bfgs_update_reg)
                     brow[j0 + j] = b;
                 }
             asm volatile("" ::: "memory");
+            sched_fence();
         }
         if (row < NN) {
             const unsigned io = (unsigned)i + opaque_zero();
 #pragma unroll
-            for (int j = 0; j < NN; ++j) Hw[io + (unsigned)(j * (NN + MM))] = brow[j];
+            for (int j = 0; j < NN; ++j) (Hw + (size_t)(j * (NN + MM)))[io] = brow[j];
         }
     }
     // BFGS_update for the two-rows-per-lane kernels (compile-time n, up to 128 rows of B): the same operations on every entry as
@@ -678,8 +680,8 @@ struct SqpDevice {
         if constexpr (NN > WAVE) { bfgs_load_row<1>(brow); bfgs_row_products<1>(brow); }
         bfgs_load_row<0>(brow); bfgs_row_products<0>(brow);
         wsync();
-        const double sBs = seq_dot(v.step, Bs, NN);
-        const double sy = seq_dot(v.step, y, NN);
+        double sBs, sy;
+        seq_dot_pair(v.step, Bs, y, sBs, sy);
         double sr;
         if (sy < 0.2 * sBs) {
             const double theta = 0.8 * sBs / (sBs - sy);
@@ -698,6 +700,21 @@ struct SqpDevice {
         wfence();
         wsync();
     }
+    // s'a and s'b for compile-time n, each the ascending chain of seq_dot, eight entries per scheduling fence: fully unrolled and unfenced, the
+    // scheduler hoists all 3 n LDS reads above the two chains — 210 registers beside the row of B, whose head then goes to scratch right behind
+    // its loads (one L2 round trip each: the update took 17.3 k instead of 9 k cycles per iteration)
+    __device__ __forceinline__ void seq_dot_pair(const double* s, const double* a, const double* b, double& sa, double& sb) {
+        sa = 0.0; sb = 0.0;
+#pragma unroll
+        for (int j0 = 0; j0 < NN; j0 += 8) {
+            double ts[8], ta[8], tb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int jj = (j0 + j < NN) ? j0 + j : 0; ts[j] = s[jj]; ta[j] = a[jj]; tb[j] = b[jj]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (j0 + j < NN) { sa += ts[j] * ta[j]; sb += ts[j] * tb[j]; }
+            sched_fence();
+        }
+    }
     __device__ __forceinline__ void bfgs_update_reg(double (&brow)[NN > 0 ? NN : 1]) {
         const int ln = lane_id();
         const int i = ln < NN ? ln : 0;
@@ -709,8 +726,8 @@ struct SqpDevice {
             if (ln < NN) { Bs[i] = a; y[i] = v.lgn[i] - v.lg[i]; }
         }
         wsync();
-        const double sBs = seq_dot(v.step, Bs, NN);
-        const double sy = seq_dot(v.step, y, NN);
+        double sBs, sy;
+        seq_dot_pair(v.step, Bs, y, sBs, sy);
         double sr;
         if (sy < 0.2 * sBs) {
             const double theta = 0.8 * sBs / (sBs - sy);
@@ -736,9 +753,11 @@ struct SqpDevice {
                         double b = brow[j0 + j];
                         b += by_sBs(-Bsi * bsj[j]);
                         b += by_sr(ri * rj[j]);
+                        asm volatile("" : "+v"(b));   // (pins the chunk here: the optimiser otherwise sinks the arithmetic into the store block below and leaves all 2 n LDS reads in front of it, beside the row of B — 256 registers and scratch)
                         brow[j0 + j] = b;
                     }
                 asm volatile("" ::: "memory");
+                sched_fence();
             }
         } else {   // divisor outside the window of UniformDiv: generic divisions, in place in the workspace (rare)
             rank2_update_mem(Bs, r, sBs, sr);
@@ -747,7 +766,7 @@ struct SqpDevice {
         if (ln < NN) {
             const unsigned io = (unsigned)i + opaque_zero();
 #pragma unroll
-            for (int j = 0; j < NN; ++j) Hw[io + (unsigned)(j * (NN + MM))] = brow[j];
+            for (int j = 0; j < NN; ++j) (Hw + (size_t)(j * (NN + MM)))[io] = brow[j];
         }
         wfence();
         wsync();

@@ -687,7 +687,7 @@ template <bool BIG = false, class JV = NoJView>
 __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* h,
                                      const double* __restrict__ A, int lda, const double* Alb, const double* Aub, const double* xlb,
                                      const double* xub, const double* x0, const double* y0, const pmpc_qp_settings& s,
-                                     pmpc_qp_info& info, long long* tm = nullptr, const JV& jv = JV(), bool condensed = false) {   // tm (phase profiling): [0] build + factor, [1] residuals, [2] substitutions, [3] build alone
+                                     pmpc_qp_info& info, long long* tm = nullptr, const JV& jv = JV(), bool condensed = false) {   // tm (phase profiling): [0] build + factor, [1] residuals, [2] substitutions, [3] build alone, [4] condensed mode: A'(rho r2), [5] condensed mode: the two triangular passes
     const int ln = lane_id();
     const int N = n + m;
     constexpr bool HASJ = BIG && !std::is_same<JV, NoJView>::value;
@@ -774,7 +774,10 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
                           if (c < n) w.rhs[c] = t;
                       }
                       wsync();
+                      const long long s0 = tick();
                       big_solve(w.K, n, w.rhs, w.big_lds + 256);
+                      const long long s1 = tick();
+                      if (tm) { tm[4] += s0 - t0; tm[5] += s1 - s0; }
                       for (int r0 = 0; r0 < m; r0 += WAVE) {
                           const int r = r0 + ln;
                           const typename JV::Row rw = jv.rowinfo(r < m ? r : 0);

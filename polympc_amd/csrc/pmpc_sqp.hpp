@@ -945,7 +945,7 @@ struct SqpDevice {
             // Solver<Problem, ADMM<...>>: the launcher sized the QP's LDS for the stacked (2n+m)-row system when qp_solver = 1
             if (RUIZ_COMPILED && __builtin_amdgcn_readfirstlane(ss.qp_solver) == 1) admm_solve(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi);
             else {
-                long long tq[4] = {0, 0, 0, 0};
+                long long tq[6] = {0, 0, 0, 0, 0, 0};
                 if constexpr (BIG) {
                     // large instances: condensed linear algebra from the block-sparse view of J (n instead of n + m rows) — unless the Ruiz preconditioner
                     // rescaled the workspace, whose entries the per-node blocks of the view then no longer are
@@ -955,6 +955,7 @@ struct SqpDevice {
                 } else
                 boxadmm_solve<BIG>(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, PROF ? tq : nullptr);
                 acc(6, tq[0]); acc(7, tq[1]); acc(17, tq[2]); acc(16, tq[3]);   // (slots 16 / 17 double as "KKT build" / "substitutions" on the LDS path)
+                if constexpr (BIG) { acc(18, tq[4]); acc(19, tq[5]); }   // (condensed mode — slot 18: the A'(rho r2) product, slot 19: the two triangular passes)
             }
         }
         qp_iter_total += qi.iter;

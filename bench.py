@@ -377,6 +377,9 @@ def main():
                 coss = ob.sqp_default_settings(); coss.max_iter = cwl["max_iter"]; coss.line_search_max_iter = cwl["ls_max_iter"]
                 rows = cwl["n"] + cwl["m"]
                 korder = ob.PIVOT_SWEEP if rows <= 64 else (ob.PIVOT_SWEEP2 if rows <= ob.SWEEP2_MAX_ROWS else ob.PIVOT_CONDENSED)
+                if cfg[key].get("route") == "condreg":   # the kernel that served it decides the restated order (condensed register kernel: PIVOT_CONDSWEEP)
+                    korder = ob.PIVOT_CONDSWEEP
+                korder_default = korder
 
                 def crun(count, threads, pivot, glibc, hu=0):
                     coss.hessian_update = hu
@@ -406,7 +409,9 @@ def main():
                 # the block-BFGS variant: the kernel that served it decides the restated order (block-structured kernel: PIVOT_SCHUR)
                 vx, vl, vi = vsol
                 nv = max(32, n_all // 2)
-                vorder = ob.PIVOT_SCHUR if cfg[key]["variant_block_bfgs"]["route"] == "schur" else korder
+                vroute = cfg[key]["variant_block_bfgs"]["route"]
+                vorder = ob.PIVOT_SCHUR if vroute == "schur" else (ob.PIVOT_CONDSWEEP if vroute == "condreg" else
+                                                                    (ob.PIVOT_SWEEP if rows <= 64 else (ob.PIVOT_SWEEP2 if rows <= ob.SWEEP2_MAX_ROWS else ob.PIVOT_CONDENSED)))
                 xk2, lk2, ik2 = crun(nv, cores, vorder, False, hu=1)
                 xr2, lr2, ir2 = crun(nv, cores, ob.PIVOT_EIGEN, True, hu=1)
                 it2 = np.array([i.iter for i in ik2]); qi2 = np.array([i.qp_solver_iter for i in ik2])

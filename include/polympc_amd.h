@@ -166,15 +166,17 @@ pmpc_status pmpc_synchronize(pmpc_context* ctx);
 pmpc_status pmpc_debug_phase_cycles(pmpc_context* ctx, unsigned long long* out24, int reset);
 
 /* Which kernel family served the last pmpc_sqp_solve_batch[_dev] / pmpc_mpc_step_batch_dev call of this context (the reference has one code path;
- * here the size and the policy hooks select one of four, with different speed — a caller can log it instead of guessing):
+ * here the size and the policy hooks select one of several, with different speed — a caller can log it instead of guessing):
  *   PMPC_ROUTE_REG1  register-resident QP, one KKT row per lane (n + m <= 64, grids with a compiled specialisation)
  *   PMPC_ROUTE_REG2  register-resident QP, two KKT rows per lane (65..128 rows)
  *   PMPC_ROUTE_LDS   KKT factor in LDS (any size that fits; every policy hook)
  *   PMPC_ROUTE_HBM   blocked tile LDL^T with the factor in an HBM workspace (large instances)
  *   PMPC_ROUTE_SCHUR block-structured kernel: Hessian block diagonal per node (hessian_update = 1 or exact Hessians, NP = NG = 0, kkt_form = 0) on a
  *                    grid with a compiled specialisation — per-node blocks in LDS, QP through the m x m Schur complement (m <= 64)
+ *   PMPC_ROUTE_CONDREG condensed register-resident QP: 65..112 variables and at most 64 constraint rows on a grid with a compiled specialisation,
+ *                    default policies, kkt_form = 0 — only H + sigma I + rho_box + A' diag(rho) A is inverted (n instead of n + m rows)
  * PMPC_ROUTE_NONE before the first call. */
-typedef enum { PMPC_ROUTE_NONE = 0, PMPC_ROUTE_REG1 = 1, PMPC_ROUTE_REG2 = 2, PMPC_ROUTE_LDS = 3, PMPC_ROUTE_HBM = 4, PMPC_ROUTE_SCHUR = 5 } pmpc_route;
+typedef enum { PMPC_ROUTE_NONE = 0, PMPC_ROUTE_REG1 = 1, PMPC_ROUTE_REG2 = 2, PMPC_ROUTE_LDS = 3, PMPC_ROUTE_HBM = 4, PMPC_ROUTE_SCHUR = 5, PMPC_ROUTE_CONDREG = 6 } pmpc_route;
 int pmpc_sqp_last_route(pmpc_context* ctx);
 
 void pmpc_qp_settings_default(pmpc_qp_settings* s);      /* qp_base.hpp:17-53 */

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liboracle.so")
 REF_PATH = os.path.join(HERE, "_ref", "libref_casadi_robot.so")
 
-PIVOT_EIGEN, PIVOT_STATIC, PIVOT_SWEEP, PIVOT_SWEEP1, PIVOT_SWEEP2, PIVOT_BLOCKED, PIVOT_CONDENSED, PIVOT_SCHUR = 0, 1, 2, 3, 4, 5, 6, 7
+PIVOT_EIGEN, PIVOT_STATIC, PIVOT_SWEEP, PIVOT_SWEEP1, PIVOT_SWEEP2, PIVOT_BLOCKED, PIVOT_CONDENSED, PIVOT_SCHUR, PIVOT_CONDSWEEP = 0, 1, 2, 3, 4, 5, 6, 7, 8
 SCHUR_MAX_ROWS = 64    # PIVOT_SCHUR restates the block-structured kernel: at most 64 constraint rows (its m x m Schur complement is swept like PIVOT_SWEEP)
 SWEEP2_MAX_ROWS = 128   # PIVOT_SWEEP2 restates the two-rows-per-lane register kernel (65..128 KKT rows)
 
@@ -191,11 +191,26 @@ def _schur_check(structure, n, m, H=None):
     lib().orc_set_schur_structure(nx, nu, nn, P)
 
 
+COND_MAX_ROWS = 112     # PIVOT_CONDSWEEP restates the condensed register kernel: 65..112 variables (at most 64 also works: PIVOT_SWEEP's mat-vec), at most 64 constraint rows
+
+
+def _cond_check(structure, n, m):
+    """PIVOT_CONDSWEEP needs the collocation structure (nx, nu, nn, P) of the QP: its sparse products walk the nodes."""
+    if structure is None:
+        raise ValueError("PIVOT_CONDSWEEP: pass structure=(nx, nu, nn, P)")
+    nx, nu, nn, P = structure
+    if (nx + nu) * nn != n or nx * nn != m or m > 64 or n > COND_MAX_ROWS:
+        raise ValueError(f"PIVOT_CONDSWEEP: structure {structure} does not describe a QP with n = {n} <= {COND_MAX_ROWS}, m = {m} <= 64")
+    lib().orc_set_schur_structure(nx, nu, nn, P)
+
+
 def kkt_solve(K, rho_vec, rhs, pivot=PIVOT_EIGEN, structure=None):
     """One KKT solve in the order of `pivot`: K = [P A'; A -1/rho] ([n+m, n+m] array, lower triangle read), rho_vec (m), rhs (n+m)."""
     K = np.asarray(K, dtype=np.float64); m = len(rho_vec); n = K.shape[0] - m
     if pivot == PIVOT_SCHUR:
         _schur_check(structure, n, m)
+    if pivot == PIVOT_CONDSWEEP:
+        _cond_check(structure, n, m)
     _check_sweep(pivot, n + m)
     sol = np.zeros(n + m)
     Kc = np.ascontiguousarray(K.T).ravel().copy()
@@ -210,6 +225,8 @@ def qp_solve_batch(H, h, A, Alb, Aub, xlb, xub, settings=None, pivot=PIVOT_EIGEN
     m = Alb.shape[1] if Alb.ndim == 2 else 0
     if pivot == PIVOT_SCHUR:
         _schur_check(structure, n, m, H)
+    if pivot == PIVOT_CONDSWEEP:
+        _cond_check(structure, n, m)
     _check_sweep(pivot, n + m)
     s = settings or qp_default_settings()
     x = np.zeros((B, n)); y = np.zeros((B, n + m)); info = (QPInfo * B)()
@@ -318,6 +335,8 @@ def sqp_solve_batch(model, P, S, t0, tf, B, d, lbx, ubx, lbg=None, ubg=None, x_g
     ss = sqp_settings or sqp_default_settings(); qs = qp_settings or sqp_qp_default_settings()
     if pivot == PIVOT_SCHUR:
         _sqp_schur_check(dm, P, ss)
+    if pivot == PIVOT_CONDSWEEP and (dm["np"] != 0 or dm["ng"] != 0 or m > 64 or n > COND_MAX_ROWS):
+        raise ValueError("PIVOT_CONDSWEEP restates the condensed register kernel: NP = NG = 0, n <= 112, m <= 64")
     x = np.zeros((B, n)); lam = np.zeros((B, m + n)); info = (SQPInfo * B)()
     mp = _f(mparams) if mparams is not None else None
     dp = C.POINTER(C.c_double)

@@ -254,7 +254,7 @@ static void setup_solver(SQP<ContinuousOCP<Model>>& sqp, int b, const double* x_
     sqp.settings = to_sqp(ss);
     sqp.qp.settings = to_qp(qs);
     sqp.qp.pivot = (pivot_policy)pivot;
-    if (pivot == PIVOT_SCHUR) { sqp.qp.schur.nx = Model::NX; sqp.qp.schur.nu = Model::NU; sqp.qp.schur.nn = sqp.problem.NN; sqp.qp.schur.P = sqp.problem.P; }
+    if (pivot == PIVOT_SCHUR || pivot == PIVOT_CONDSWEEP) { sqp.qp.schur.nx = Model::NX; sqp.qp.schur.nu = Model::NU; sqp.qp.schur.nn = sqp.problem.NN; sqp.qp.schur.P = sqp.problem.P; }
     for (int i = 0; i < Model::ND; ++i) sqp.p_static[i] = d[(size_t)b * Model::ND + i];
     if (lbx) for (int i = 0; i < n; ++i) sqp.lbx[i] = lbx[(size_t)b * n + i];
     if (ubx) for (int i = 0; i < n; ++i) sqp.ubx[i] = ubx[(size_t)b * n + i];

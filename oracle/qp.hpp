@@ -41,7 +41,7 @@
 namespace oracle {
 
 enum qp_status { QP_SOLVED = 0, QP_MAX_ITER_EXCEEDED = 1, QP_UNSOLVED = 2, QP_UNINITIALIZED = 3, QP_INFEASIBLE = 4, QP_INCONSISTENT = 5 };
-enum pivot_policy { PIVOT_EIGEN = 0, PIVOT_STATIC = 1, PIVOT_SWEEP = 2, PIVOT_SWEEP1 = 3, PIVOT_SWEEP2 = 4, PIVOT_BLOCKED = 5, PIVOT_CONDENSED = 6, PIVOT_SCHUR = 7 };
+enum pivot_policy { PIVOT_EIGEN = 0, PIVOT_STATIC = 1, PIVOT_SWEEP = 2, PIVOT_SWEEP1 = 3, PIVOT_SWEEP2 = 4, PIVOT_BLOCKED = 5, PIVOT_CONDENSED = 6, PIVOT_SCHUR = 7, PIVOT_CONDSWEEP = 8 };
 
 struct qp_settings {  // qp_base.hpp:17-53 (ADMM-related subset)
     double eps_rel = 1e-3, eps_abs = 1e-3;
@@ -535,9 +535,58 @@ struct BoxADMM {
         if (NM > 64) throw std::invalid_argument("oracle: PIVOT_SWEEP restates the 64-row register kernel; use PIVOT_STATIC / PIVOT_EIGEN for larger systems");
         ldlt.compute_sweep(true, N);
     }
+    // PIVOT_CONDSWEEP (the condensed register kernel, pmpc_qp_cond.hpp): the constraint block of K is eliminated in closed form as in factorise_sweep_cf,
+    // but the constraint rows are not carried at all — only S = P + A' diag(rho) A (n x n; block-lower 16 x 16 tiles, diagonal tiles in full) is swept,
+    //   S(a, b) = K(a, b) [lower-triangle read], then fma(rho_j A(j, a), A(j, b), .) for j ascending,
+    // with PIVOT_SWEEP's blocked sweep (mat-vec order of PIVOT_SWEEP for n <= 64, of PIVOT_SWEEP2 above), and every solve is
+    //   t = r1 + A'(rho o r2),   x = S^{-1} t,   nu = rho o (A x - r2)
+    // with the two products formed as fma chains over the structural entries (kkt_solve_condsweep).
+    void factorise_condsweep() {
+        const int NM = N + M;
+        if (N > 128) throw std::invalid_argument("oracle: PIVOT_CONDSWEEP restates the condensed register kernel: at most 128 primal rows");
+        std::vector<double> Mm((size_t)N * N, 0.0);
+        for (int b = 0; b < N; ++b)
+            for (int a = 0; a < N; ++a) {
+                if (a / 16 < b / 16) continue;
+                double v = a >= b ? K[a + b * NM] : K[b + a * NM];
+                for (int j = 0; j < M; ++j) v = std::fma(rho_vec[j] * K[(N + j) + a * NM], K[(N + j) + b * NM], v);
+                Mm[a + (size_t)b * N] = v;
+            }
+        ldlt.n = N; ldlt.policy = N <= 64 ? PIVOT_SWEEP : PIVOT_SWEEP2; ldlt.M.swap(Mm); ldlt.tr.assign(N, 0); ldlt.temp.assign(N, 0.0);
+        ldlt.compute_sweep(true);
+    }
+    // the two products as the kernel forms them (pmpc_qp_cond.hpp): fma chains — the differentiation-matrix entries of the column / row over the nodes
+    // ascending (0 on the own node and outside the segments; a control column of the first 64 variables walks zeros), then the own node's block. Needs the
+    // collocation structure (schur.nx, .nu, .nn): no path constraints, no parameters.
+    void kkt_solve_condsweep(const double* rhs, double* sol) {
+        const int NM = N + M, nx = schur.nx, nu = schur.nu, nn = schur.nn, VARX = nx * nn;
+        if (nx < 1 || nn < 1 || nx * nn != M || (nx + nu) * nn != N) throw std::invalid_argument("oracle: PIVOT_CONDSWEEP needs the collocation structure of the QP (nx, nu, nn)");
+        std::vector<double> u(M), t(N), xs(N);
+        for (int r = 0; r < M; ++r) u[r] = rho_vec[r] * rhs[N + r];
+        for (int c = 0; c < N; ++c) {
+            const bool xcol = c < VARX;
+            const int jn = xcol ? c / nx : (c - VARX) / nu, qx = xcol ? c - jn * nx : 0;
+            double a = rhs[c];
+            if (c < 64 || VARX > 64)
+                for (int k = 0; k < nn; ++k) { const double coef = (xcol && k != jn) ? K[(N + k * nx + qx) + c * NM] : 0.0; a = std::fma(coef, u[k * nx + qx], a); }
+            for (int q = 0; q < nx; ++q) a = std::fma(K[(N + jn * nx + q) + c * NM], u[jn * nx + q], a);
+            t[c] = a;
+        }
+        ldlt.solve(t.data(), xs.data());
+        for (int i = 0; i < N; ++i) sol[i] = xs[i];
+        for (int r = 0; r < M; ++r) {
+            const int k = r / nx, q = r - k * nx;
+            double a = 0.0;
+            for (int j = 0; j < nn; ++j) { const double coef = (j != k) ? K[(N + r) + (j * nx + q) * NM] : 0.0; a = std::fma(coef, xs[j * nx + q], a); }
+            for (int i = 0; i < nx; ++i) a = std::fma(K[(N + r) + (k * nx + i) * NM], xs[k * nx + i], a);
+            for (int i = 0; i < nu; ++i) a = std::fma(K[(N + r) + (VARX + k * nu + i) * NM], xs[VARX + k * nu + i], a);
+            sol[N + r] = rho_vec[r] * (a - rhs[N + r]);
+        }
+    }
     void factorise() {
         if (pivot == PIVOT_SCHUR) { factorise_schur(); return; }
         if (pivot == PIVOT_SWEEP) { factorise_sweep_cf(); return; }
+        if (pivot == PIVOT_CONDSWEEP) { factorise_condsweep(); return; }
         if (pivot != PIVOT_CONDENSED) { ldlt.compute(K, N + M, pivot); return; }
         const int NM = N + M;
         Sc.assign((size_t)N * N, 0.0);
@@ -551,6 +600,7 @@ struct BoxADMM {
     }
     void kkt_solve(const double* rhs, double* sol) {
         if (pivot == PIVOT_SCHUR) { kkt_solve_schur(rhs, sol); return; }
+        if (pivot == PIVOT_CONDSWEEP) { kkt_solve_condsweep(rhs, sol); return; }
         if (pivot != PIVOT_CONDENSED) { ldlt.solve(rhs, sol); return; }
         const int NM = N + M;
         std::vector<double> t(N), xs(N);

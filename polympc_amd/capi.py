@@ -16,8 +16,8 @@ SQP_SOLVED, SQP_MAX_ITER_EXCEEDED = 0, 1
 FLAG_NONFINITE = 1   # pmpc_qp_info / pmpc_sqp_info flags: a non-finite value went through a QP solve
 
 ABI_VERSION = 4   # PMPC_ABI_VERSION of include/polympc_amd.h that the ctypes layouts below mirror
-ROUTE_NONE, ROUTE_REG1, ROUTE_REG2, ROUTE_LDS, ROUTE_HBM, ROUTE_SCHUR = 0, 1, 2, 3, 4, 5   # pmpc_route
-ROUTE_NAMES = {0: "none", 1: "reg1", 2: "reg2", 3: "lds", 4: "hbm", 5: "schur"}
+ROUTE_NONE, ROUTE_REG1, ROUTE_REG2, ROUTE_LDS, ROUTE_HBM, ROUTE_SCHUR, ROUTE_CONDREG = 0, 1, 2, 3, 4, 5, 6   # pmpc_route
+ROUTE_NAMES = {0: "none", 1: "reg1", 2: "reg2", 3: "lds", 4: "hbm", 5: "schur", 6: "condreg"}
 
 EXPORTED_SYMBOLS = [
     "pmpc_abi_version", "pmpc_struct_size", "pmpc_sqp_last_route",

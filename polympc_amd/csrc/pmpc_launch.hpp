@@ -8,6 +8,7 @@
 #include "pmpc_qp.hpp"
 #include "pmpc_qp_reg.hpp"
 #include "pmpc_qp_reg2.hpp"
+#include "pmpc_qp_cond.hpp"
 #include "pmpc_qp_big.hpp"
 #include "pmpc_sqp.hpp"
 
@@ -45,7 +46,7 @@ template <class Model> __host__ __device__ inline size_t big_scratch_doubles(int
 // KHBM: large-instance mode of the LDS-resident kernels — the KKT factor lives in an HBM workspace (Kws). A compile-time flag so
 // that in the normal mode every QP pointer provably addresses LDS (ds_read / ds_write instead of flat accesses, which cost the
 // LDS path most of its time when the location of K was a run-time choice)
-template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bool KHBM = false, bool W2 = false, bool POL = false>   // W2: the HBM-factor kernel compiled for two wavefronts per SIMD (256 registers); POL: register-resident kernel with the Ruiz / filter-line-search hooks compiled in
+template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bool KHBM = false, bool W2 = false, bool POL = false, bool CND = false>   // CND: condensed register QP (pmpc_qp_cond.hpp); W2: the HBM-factor kernel compiled for two wavefronts per SIMD (256 registers); POL: register-resident kernel with the Ruiz / filter-line-search hooks compiled in
 #ifndef PMPC_SQP_WAVES
 #define PMPC_SQP_WAVES 2
 #endif
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
     // stacked workspace K0 = [H ; J] ((n+m) x n, column-major, leading dimension n+m): lane i reads row i of K0 with ONE stride
     double* K0 = Hws + (size_t)b * (size_t)(n + m) * n;
     (void)Aws;
-    SqpDevice<Model, NN, MM, PROF, HU, KHBM, POL> sqp(ocp, v, qw, K0, K0 + n, ss, qs);
+    SqpDevice<Model, NN, MM, PROF, HU, KHBM, POL, CND ? -1 : 0> sqp(ocp, v, qw, K0, K0 + n, ss, qs);
     sqp.filt = filt;
     sqp.eig = eigw;
     sqp.trace = ss.iteration_trace ? ss.iteration_trace + (size_t)b * (size_t)ss.iteration_trace_capacity * PMPC_TRACE_DOUBLES : nullptr;
@@ -533,6 +534,7 @@ template <> struct LDS_PATH_PROFILED<CstrOCP> { static constexpr bool value = tr
 template <> struct LDS_PATH_PROFILED<KiteStandInOCP> { static constexpr bool value = true; };
 
 // Launch the fused SQP kernel for `Model` on DEVICE buffers (asynchronous on the context's stream).
+template <class Model, int NN_, int MM_> struct COND_REG_OK { static constexpr bool value = NN_ > WAVE && NN_ <= 112 && MM_ > 0 && MM_ <= WAVE && Model::NP == 0 && Model::NG == 0; };
 // Register-resident QP specialisations are selected from the compile-time model dimensions and the runtime node count
 // when the KKT system has at most 64 rows; otherwise the LDS-resident path is used.
 template <class Model, int NNODES, bool LEAN = false>   // LEAN: no phase-timer and no block-BFGS specialisation (pmpc_grids.hpp: those requests take the LDS-resident kernel)
@@ -598,6 +600,14 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
         bool timed = false;
         if constexpr (LDS_PATH_PROFILED<Model>::value && !LEAN) { if (phase && !pol) { kern = sqp_kernel<Model, NN_, MM_, true>; timed = true; } }   // developer builds with phase timers
         if constexpr (POLK) { if (pol) kern = sqp_kernel<Model, NN_, MM_, false, 0, false, false, true>; }
+        // condensed register QP (pmpc_qp_cond.hpp): 65..112 variables, at most 64 constraint rows, the default policies; kkt_form = 1 keeps the full inverse
+        if constexpr (COND_REG_OK<Model, NN_, MM_>::value) {
+            if (!pol && ss->kkt_form == 0 && !getenv("PMPC_NO_CONDREG")) {
+                kern = sqp_kernel<Model, NN_, MM_, false, 0, false, false, false, true>; timed = false;
+                if constexpr (LDS_PATH_PROFILED<Model>::value && !LEAN) { if (phase) { kern = sqp_kernel<Model, NN_, MM_, true, 0, false, false, false, true>; timed = true; } }
+                pmpc_internal_set_route(ctx, PMPC_ROUTE_CONDREG);
+            }
+        }
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
         const int slice = (slice_state && slice_iters > 0) ? slice_iters : ss->max_iter;
         for (int it = 0; it < ss->max_iter; it += slice)

@@ -1,0 +1,411 @@
+// polympc_amd — CONDENSED register-resident box-ADMM QP solve for the QPs of the fused SQP kernel with 65..128 variables and at most 64 constraint
+// rows (one wavefront per QP; config B: n = 66, m = 44; the reference's 16-node robot grid: n = 80, m = 48).
+//
+// The constraint block of boxADMM's KKT matrix (box_admm.hpp:209-223) is diagonal, -1/rho, so the constraint rows are eliminated in closed form — what
+// the constraint-first sweep of pmpc_qp_reg.hpp does inside the full inverse — and are then NOT CARRIED AT ALL: only
+//     S = H + sigma I + rho_box + A' diag(rho) A          (n x n instead of (n + m) x (n + m))
+// is inverted, W = -S^{-1} by the blocked sweep of pmpc_qp_reg2.hpp in 16 x 16 fp64 accumulator tiles (config B: 17 block steps on 15 stored tiles
+// instead of 28 on 28, 25 operand tiles of the mat-vec instead of 49), and every ADMM iteration solves
+//     t = r1 + A'(rho o r2),      x = S^{-1} t,      nu = rho o (A x - r2)
+// with the two products formed from the per-node blocks of A and two small tables of the differentiation matrix in LDS (fma chains: the D~ entries of
+// the column / row over the nodes ascending, then the own node's block — no HBM traffic, no selects). A' diag(rho) A is a rank-m update on the matrix cores between the staging of H and the sweep
+// (RegKkt2::rank_update: operands rho_j A(j, .) and A(j, .) for the constraint rows j in groups of four, the k-ascending fma chain of the MFMA).
+// Same pivots as the constraint-first sweep; measured on the QP streams of configs B / R against the reference's pivoted LDL^T: every QP keeps its
+// ADMM iteration count, max |d res| 2.9e-10 (the two-rows-per-lane full inverse: 1.1e-9). CPU restatement of exactly this order: PIVOT_CONDSWEEP
+// (the test suite's checker) — the kernels are checked against it bit for bit.
+// The QP entry points without structure information (pmpc_qp_solve_batch) stay on the full two-rows-per-lane inverse: the products with a dense A
+// would cost more than the rows they save.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "pmpc_qp_reg2.hpp"
+#include "pmpc_jview.hpp"
+
+namespace pmpc {
+
+#ifndef PMPC_COND_NV
+#define PMPC_COND_NV 16
+#endif
+// the swept inverse of S: the two-rows-per-lane tile set with PMPC_COND_NV of its operand tiles in arch VGPRs (25 tiles at 66..80 rows: the rest lives
+// in the accumulation file and costs two v_accvgpr_read per entry and ADMM iteration)
+template <int NN> using CondKkt = RegKkt2<NN, PMPC_COND_NV>;
+
+// LDS the solver needs beside the staging of CondKkt<NN>: nothing — the exchange vectors alias the staging (free between factorisations)
+template <int NN, int MM>
+struct CondDims {
+    static_assert(NN > WAVE && NN <= 128 && MM > 0 && MM <= WAVE, "condensed register QP: 65..128 variables, at most 64 constraint rows");
+    static constexpr int N = NN + MM;
+    static constexpr int US_OFF = CondKkt<NN>::RHS_OFF + 128;     // rho o r2 / y (MM entries) behind the rhs exchange buffer of RegKkt2::apply
+    static constexpr int XS_OFF = US_OFF + 64;                    // x (NN entries)
+    static constexpr int PB_OFF = XS_OFF + 128;                   // residual evaluation: products of the few primal rows of the second slot
+    static constexpr int TAB_OFF = PB_OFF + 4 * NN;               // D~ tables of the sparse products (cond_build_tables), rebuilt at every QP
+    template <int NNODES> static constexpr int nnp() { return NNODES + (NNODES & 1); }
+    template <int NNODES> static constexpr int tab_doubles() { return (2 * NNODES + 1) * nnp<NNODES>(); }
+};
+
+// D~ as two dense tables in LDS: Dt[r NNP + k] = D~(r, k) — the differentiation-matrix entry of equality row node r on the state columns of node k
+// (continuous_ocp.hpp:817-827, :845-846), 0 on the own node (that entry lives in the node block) and outside the row's segment — and its transpose
+// DtT[k NNP + r], followed by one all-zero row (read by control columns and inequality rows). Run-time P: these kernels are compiled per node count.
+template <int NNODES>
+__device__ __forceinline__ void cond_build_tables(const double* Dm, int P, double* Dt) {
+    constexpr int NNP = NNODES + (NNODES & 1);
+    double* DtT = Dt + NNODES * NNP;
+    for (int e = lane_id(); e < (2 * NNODES + 1) * NNP; e += WAVE) Dt[e] = 0.0;
+    lds_order();
+    const int P1 = P + 1;
+    for (int e = lane_id(); e < NNODES * NNODES; e += WAVE) {
+        const int r = e / NNODES, k = e - r * NNODES;
+        const bool lastr = r == NNODES - 1;
+        const int kbr = lastr ? NNODES - 1 - P : (r / P) * P;
+        const int rowr = lastr ? P : r - kbr;
+        const int t = k - kbr;
+        const bool cpl = k != r && (unsigned)t <= (unsigned)P;
+        const double dv = Dm[lastr ? P1 * P1 + (cpl ? t : 0) : rowr + (cpl ? t : 0) * P1];
+        const double v = cpl ? dv : 0.0;
+        Dt[r * NNP + k] = v;
+        DtT[k * NNP + r] = v;
+    }
+    lds_order();
+}
+
+// boxADMM::solve_impl (7-argument form: zero guesses, box_admm.hpp:81-86). H: the stacked workspace [H ; A] of the fused SQP kernel ((NN + MM) x NN,
+// column-major, leading dimension NN + MM; the LOWER triangle of H is read for S, as Eigen::LDLT does; the full rows for H x); h / bounds: LDS vectors;
+// tr: CondKkt<NN>::TRI doubles of LDS; jv: the block-sparse view of A.
+template <int NN, int MM, class JV>
+__device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H, const double* h, const double* Alb, const double* Aub, const double* xlb,
+                                                   const double* xub, const pmpc_qp_settings& s, pmpc_qp_info& info, double* out_x, double* out_y, double* tr,
+                                                   const JV& jv, long long* dbg = nullptr, long long* tm = nullptr) {
+    using CD = CondDims<NN, MM>;
+    constexpr int N = CD::N;
+    const int ln = lane_id();
+    // primal slot e: variable lane + 64 e; constraint row: lane (lanes [0, MM))
+    bool isP[2]; int lp[2];
+    double hv[2], lo[2], hi[2]; int typ[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int idx = ln + 64 * e;
+        isP[e] = idx < NN; lp[e] = isP[e] ? idx : 0;
+        hv[e] = isP[e] ? h[lp[e]] : 0.0;
+        lo[e] = isP[e] ? xlb[lp[e]] : 0.0; hi[e] = isP[e] ? xub[lp[e]] : 0.0;
+        typ[e] = classify_bounds(lo[e], hi[e]);
+    }
+    const bool isC = ln < MM;
+    const int rc = isC ? ln : 0;
+    const double clo = isC ? Alb[rc] : 0.0, chi = isC ? Aub[rc] : 0.0;
+    const int ctyp = classify_bounds(clo, chi);
+    auto lane_near = [](int zo) -> unsigned { unsigned l; asm("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l) : "v"(zo)); return l; };
+    // H(max(i, j), min(i, j)) for row i = lane + 64 e (0.0 on lanes without such a row), j < NN
+    auto Hlow = [&](int j, int e, int zo) -> double {
+        const unsigned i = lane_near(zo) + 64u * (unsigned)e;
+        const bool live = i < (unsigned)NN;
+        const unsigned ic = live ? i : 0u;
+        unsigned b = (ic < (unsigned)j) ? ((unsigned)j + ic * (unsigned)N) : (ic + (unsigned)(j * N));
+        b += (unsigned)zo; asm("" : "+v"(b));
+        const double v = H[b];
+        return live ? v : 0.0;
+    };
+    // A(k, i), i = lane + 64 e (0.0 on lanes without such a variable)
+    auto Acol = [&](int k, int e, int zo) -> double {
+        const unsigned i = lane_near(zo) + 64u * (unsigned)e;
+        const bool prim = i < (unsigned)NN;
+        unsigned b = (prim ? i : 0u) * (unsigned)N + (unsigned)NN + (unsigned)zo; asm("" : "+v"(b));
+        const double v = H[b + (unsigned)k];
+        return prim ? v : 0.0;
+    };
+    auto xbc = [&](const double (&v)[2], int j) -> double { return (j < 64) ? bcast_lane(v[0], j & 63) : bcast_lane(v[1], (j - 64) & 63); };
+
+    // state: xv / qv / yb on the primal slots, zv / ya on the constraint lanes
+    double xv[2] = {0.0, 0.0}, qv[2] = {0.0, 0.0}, yb[2] = {0.0, 0.0}, zv = 0.0, ya = 0.0;
+    double rho = s.rho;
+    int rho_updates = 1;
+    double rhob[2], rhobinv[2], kd[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        rhob[e] = rho_of(typ[e], rho);
+        rhobinv[e] = 1.0 / rhob[e];
+        double d = H[(size_t)lp[e] * N + lp[e]]; d += s.sigma; d += rhob[e];
+        kd[e] = isP[e] ? d : 0.0;   // (rows >= NN: padding, exact zeros, never swept)
+    }
+    double rhoc = rho_of(ctyp, rho), rhocinv = 1.0 / rhoc;
+
+    CondKkt<NN> K;
+    double* us = tr + CD::US_OFF; double* xs = tr + CD::XS_OFF;
+    // the two sparse products of an ADMM iteration as fma chains whose coefficients come from LDS at per-lane bases with immediate offsets — no selects,
+    // no index arithmetic in the loop (the multiply-add products of pmpc_jview.hpp, built for the residuals' reference order, cost 900 of the 1500
+    // instructions of an iteration here):
+    //   column c of node jn, state qx:  t = r1;  t = fma(D~(k, jn), u(k, qx), t) for the nodes k ascending (0 on the own node and outside the segments
+    //                                   that hold jn; a control column reads the all-zero row);  t = fma(J((jn, q), c), u(jn, q), t) for q ascending
+    //   row (k, q):                     a = 0;   a = fma(D~(k, j), x(j, q), a) for the nodes j ascending;  then the own node's block, columns ascending
+    constexpr int NX = JV::NX, NU = JV::NU, NDER = JV::NDER, NNODES = MM / NX, NNP = NNODES + (NNODES & 1), VARX = NX * NNODES;
+    static_assert((int)JV::NG == 0 && (int)JV::NP == 0 && NNODES * NX == MM && NNODES * (NX + NU) == NN, "condensed register QP: no path constraints, no parameters");
+    double* Dt = tr + CD::TAB_OFF;
+    static_assert(CD::TAB_OFF + CD::template tab_doubles<NNODES>() <= CondKkt<NN>::TRI, "tables fit the staging");
+    const double* DtT = Dt + NNODES * NNP;
+    const double *cD[2], *cU[2], *cB[2], *cV[2];   // per primal slot: D~ column, u at the column's state index, own-node block column, u of the own node
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int c = lp[e];
+        const bool xcol = c < VARX;
+        const int cu = c - VARX;
+        const int jn = xcol ? c / NX : cu / NU;
+        const int dcol = xcol ? c - jn * NX : NX + (cu - jn * NU);
+        cD[e] = DtT + (xcol ? jn : NNODES) * NNP;
+        cU[e] = us + (xcol ? dcol : 0);
+        cB[e] = jv.jblk + (jn * NX) * NDER + dcol;
+        cV[e] = us + jn * NX;
+    }
+    const int rk = rc / NX, rq = rc - rk * NX;
+    const double* rD = Dt + rk * NNP;              // constraint row: D~ row, x at the row's state index, own-node block row, x / u of the own node
+    const double* rX = xs + rq;
+    const double* rB = jv.jblk + rc * NDER;
+    const double* rV = xs + rk * NX;
+    const double* rW = xs + VARX + rk * NU;
+    constexpr bool SLOT1_STATES = VARX > 64;       // state columns in the second slot?
+    auto coldot_fma = [&](int e, double init) -> double {
+        double a = init;
+        if (e == 0 || SLOT1_STATES) {
+            double dv[NNODES], uv[NNODES];
+#pragma unroll
+            for (int k = 0; k < NNODES; ++k) { dv[k] = cD[e][k]; uv[k] = cU[e][k * NX]; }
+#pragma unroll
+            for (int k = 0; k < NNODES; ++k) a = fma(dv[k], uv[k], a);
+        }
+        double bv[NX], vv[NX];
+#pragma unroll
+        for (int q = 0; q < NX; ++q) { bv[q] = cB[e][q * NDER]; vv[q] = cV[e][q]; }
+#pragma unroll
+        for (int q = 0; q < NX; ++q) a = fma(bv[q], vv[q], a);
+        return a;
+    };
+    auto rowdot_fma = [&]() -> double {
+        double a = 0.0;
+        double dv[NNODES], xq[NNODES], bv[NDER], xb[NDER];
+#pragma unroll
+        for (int j = 0; j < NNODES; ++j) { dv[j] = rD[j]; xq[j] = rX[j * NX]; }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { bv[i] = rB[i]; xb[i] = rV[i]; }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { bv[NX + i] = rB[NX + i]; xb[NX + i] = rW[i]; }
+#pragma unroll
+        for (int j = 0; j < NNODES; ++j) a = fma(dv[j], xq[j], a);
+#pragma unroll
+        for (int i = 0; i < NDER; ++i) a = fma(bv[i], xb[i], a);
+        return a;
+    };
+    int status = PMPC_QP_UNSOLVED;
+    const double alpha = s.alpha;
+    double max_Ax_z_norm = 0.0, max_Hx_ATy_h_norm = 0.0, res_prim = 1.0, res_dual = 1.0, rho_estimate = 0.0;
+    int iter = 1;
+    int until_check = s.check_termination, until_adapt = s.adaptive_rho_interval;
+    bool running = true;
+    while (running) {
+        {   // construct_kkt_matrix + factorise_kkt_matrix (box_admm.hpp:209-223, :336-341) in condensed form
+            const long long f0 = dbg ? clock64() : 0;
+            const double rc_now = rhoc;
+            K.invert(ln, tr, kd[0], kd[1], [&](int j, int e, int z) -> double { return Hlow(j < NN ? j : 0, e, z); }, tm,
+                     [&](CondKkt<NN>& Kr, double* PA, double* PB, int l, int lr, int lc) {
+                         Kr.template rank_update<MM>(l, lr, lc, PA, PB, [&](int j, int e, int z) -> double { return Acol(j, e, z); },
+                                                     [&](int j) -> double { return bcast_lane(rc_now, j); });
+                     });
+            cond_build_tables<NNODES>(jv.D, jv.P, Dt);   // (the staging they live in was the sweep's)
+            if (dbg) dbg[0] += clock64() - f0;
+        }
+        bool refactor = false;
+        while (iter <= s.max_iter) {
+            int nrun = s.max_iter - iter + 1;
+            if (s.check_termination != 0 && until_check < nrun) nrun = until_check;
+            if (s.adaptive_rho && until_adapt < nrun) nrun = until_adapt;
+            for (int kk = 0; kk < nrun; ++kk) {
+                const double zprev = zv;
+                const double r2 = zv - rhocinv * ya;                       // compute_kkt_rhs, box_admm.hpp:351-355
+                if (isC) us[rc] = rhoc * r2;
+                lds_order();
+                double t[2], sol[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const double rhs1 = ((s.sigma * xv[e] - hv[e]) + rhob[e] * qv[e]) - yb[e];
+                    const double a = coldot_fma(e, rhs1);
+                    t[e] = isP[e] ? a : 0.0;
+                }
+                lds_order();
+                K.apply(t[0], t[1], tr, ln, sol[0], sol[1]);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) if (isP[e]) xs[lp[e]] = sol[e];
+                lds_order();
+                const double ax = rowdot_fma();
+                const double nu = rhoc * (ax - r2);
+                lds_order();
+                {
+                    const double zt = zprev + rhocinv * (nu - ya);
+                    double zz = alpha * zt;
+                    zz += (1 - alpha) * zprev + rhocinv * ya;
+                    zz = fmin(fmax(zz, clo), chi);
+                    const double yC = ya + rhoc * ((alpha * zt + (1 - alpha) * zprev) - zz);
+                    zv = isC ? zz : 0.0; ya = isC ? yC : 0.0;
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    double xx = alpha * sol[e];
+                    xx += (1 - alpha) * xx;  // quirk Q1
+                    double qq = xx + rhobinv[e] * yb[e];
+                    qq = fmin(fmax(qq, lo[e]), hi[e]);
+                    const double yP = yb[e] + rhob[e] * (xx - qq);
+                    xv[e] = isP[e] ? xx : 0.0; qv[e] = isP[e] ? qq : 0.0; yb[e] = isP[e] ? yP : 0.0;
+                }
+            }
+            iter += nrun - 1;   // the last iteration performed
+            bool check = false, adapt = false;
+            if (s.check_termination != 0) { until_check -= nrun; if (until_check == 0) { check = true; until_check = s.check_termination; } }
+            if (s.adaptive_rho) { until_adapt -= nrun; if (until_adapt == 0) { adapt = true; until_adapt = s.adaptive_rho_interval; } }
+            if (check || adapt) {  // residuals_update, box_admm.hpp:398-415: one add chain per row, columns ascending
+                const long long r0 = dbg ? clock64() : 0;
+                int zr = 0;
+                asm volatile("" : "+v"(zr));
+                const double probe = ((xv[0] - xv[0]) + (xv[1] - xv[1])) + (ya - ya);
+                const bool finite = __builtin_amdgcn_ballot_w64(probe != 0.0) == 0;   // (a non-finite iterate takes the dense loops: 0 * inf = NaN on the structural zeros of A)
+                const int sl = (int)lane_near(zr);
+                double acc[2] = {0.0, 0.0}, aty[2] = {0.0, 0.0}, axz = 0.0;
+                constexpr int NP1 = NN - 64;            // primal rows of the second slot
+                constexpr bool FEW1 = NP1 <= 4;         // few of them: products through LDS; otherwise their lanes load their rows
+                constexpr int RCS = 22;
+                if (finite) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) if (isP[e]) xs[lp[e]] = xv[e];
+                    if (isC) us[rc] = ya;
+                    lds_order();
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) { const double v = jv.coldot(lp[e], us, isP[e]); aty[e] = isP[e] ? v : 0.0; }
+                    { const double v = jv.rowdot(rc, xs); axz = isC ? v : 0.0; }
+                    sched_fence();
+                } else {
+                    // dense chains from the workspace
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        double a = 0.0;
+                        for (int k = 0; k < MM; ++k) a += Acol(k, e, zr) * bcast_uniform(ya, k);
+                        aty[e] = isP[e] ? a : 0.0;
+                    }
+                    double a = 0.0;
+                    for (int j = 0; j < NN; ++j) {
+                        unsigned b = (unsigned)(j * N + NN) + (unsigned)rc + (unsigned)zr; asm("" : "+v"(b));
+                        a += H[b] * ((j < 64) ? bcast_uniform(xv[0], j) : bcast_uniform(xv[1], j - 64));
+                    }
+                    axz = isC ? a : 0.0;
+                }
+                // H x: the rows of the first slot — RCS loads in flight per batch
+                {
+                    double hx = 0.0;
+#pragma unroll
+                    for (int j0 = 0; j0 < NN; j0 += RCS) {
+                        double mm[RCS];
+#pragma unroll
+                        for (int j = 0; j < RCS; ++j) {
+                            const unsigned l = lane_near(zr);
+                            unsigned b = l + (unsigned)(((j0 + j < NN) ? j0 + j : 0) * N) + (unsigned)zr; asm("" : "+v"(b));
+                            mm[j] = H[b];
+                        }
+#pragma unroll
+                        for (int j = 0; j < RCS; ++j) if (j0 + j < NN) hx += mm[j] * xbc(xv, j0 + j);
+                        sched_fence();
+                    }
+                    acc[0] = hx;
+                }
+                if constexpr (!FEW1) {   // many primal rows in the second slot: lane l < NP1 loads row 64 + l (the other lanes re-read row 64)
+                    double hx1 = 0.0;
+#pragma unroll
+                    for (int j0 = 0; j0 < NN; j0 += RCS) {
+                        double mm[RCS];
+#pragma unroll
+                        for (int j = 0; j < RCS; ++j) {
+                            const unsigned l = lane_near(zr);
+                            unsigned b = 64u + (l < (unsigned)NP1 ? l : 0u) + (unsigned)(((j0 + j < NN) ? j0 + j : 0) * N) + (unsigned)zr; asm("" : "+v"(b));
+                            mm[j] = H[b];
+                        }
+#pragma unroll
+                        for (int j = 0; j < RCS; ++j) if (j0 + j < NN) hx1 += mm[j] * xbc(xv, j0 + j);
+                        sched_fence();
+                    }
+                    acc[1] = (sl < NP1) ? hx1 : 0.0;
+                } else {
+                    // rows 64 .. NN-1 of H: lane j loads H(64 + t, j) (and lane j < NP1 also H(64 + t, 64 + j)) and forms the product with its own x_j;
+                    // lane t then adds the NN products of row 64 + t in ascending j — instead of NN loads per lane for NP1 live lanes
+                    double* pb = tr + CD::PB_OFF;
+                    double h0[NP1], h1[NP1];
+#pragma unroll
+                    for (int t = 0; t < NP1; ++t) {
+                        const unsigned l = lane_near(zr);
+                        unsigned b0 = (64u + (unsigned)t) + l * (unsigned)N + (unsigned)zr; asm("" : "+v"(b0));
+                        h0[t] = H[b0];
+                        unsigned b1 = (64u + (unsigned)t) + (64u + (l < (unsigned)NP1 ? l : 0u)) * (unsigned)N + (unsigned)zr; asm("" : "+v"(b1));
+                        h1[t] = H[b1];
+                    }
+#pragma unroll
+                    for (int t = 0; t < NP1; ++t) { pb[t * NN + sl] = h0[t] * xv[0]; if (sl < NP1) pb[t * NN + 64 + sl] = h1[t] * xv[1]; }
+                    lds_order();
+                    const int tt = sl < NP1 ? sl : 0;
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int j0 = 0; j0 < NN; j0 += 36) {
+                        double pv[36];
+#pragma unroll
+                        for (int j = 0; j < 36; ++j) pv[j] = pb[tt * NN + ((j0 + j < NN) ? j0 + j : 0)];
+#pragma unroll
+                        for (int j = 0; j < 36; ++j) if (j0 + j < NN) sacc += pv[j];
+                    }
+                    acc[1] = (sl < NP1) ? sacc : 0.0;
+                    lds_order();
+                }
+                double a1 = isC ? fmax(fabs(axz), fabs(zv)) : 0.0, a2 = 0.0, rp = isC ? fabs(axz - zv) : 0.0, rq = 0.0, rd = 0.0;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    a1 = fmax(a1, isP[e] ? fabs(xv[e]) : 0.0);
+                    a2 = fmax(a2, isP[e] ? fmax(fmax(fabs(acc[e]), fabs(aty[e])), fmax(fabs(hv[e]), fabs(yb[e]))) : 0.0);
+                    rq = fmax(rq, isP[e] ? fabs(xv[e] - qv[e]) : 0.0);
+                    rd = fmax(rd, isP[e] ? fabs(((acc[e] + hv[e]) + aty[e]) + yb[e]) : 0.0);
+                }
+                max_Ax_z_norm = wave_max(a1);
+                max_Hx_ATy_h_norm = wave_max(a2);
+                res_prim = wave_max(rp) + wave_max(rq);
+                res_dual = wave_max(rd);
+                sched_fence();
+                if (dbg) dbg[1] += clock64() - r0;
+            }
+            if (check) {
+                const double ep = s.eps_abs + s.eps_rel * max_Ax_z_norm, ed = s.eps_abs + s.eps_rel * max_Hx_ATy_h_norm;
+                if (__builtin_amdgcn_readfirstlane((int)(res_prim <= ep && res_dual <= ed))) { status = PMPC_QP_SOLVED; running = false; break; }
+            }
+            if (adapt) {
+                const double rpn = res_prim / (max_Ax_z_norm + DIV_BY_ZERO_REGUL);
+                const double rdn = res_dual / (max_Hx_ATy_h_norm + DIV_BY_ZERO_REGUL);
+                double new_rho = rho * ::sqrt(rpn / (rdn + DIV_BY_ZERO_REGUL));
+                new_rho = fmax(RHO_MIN, fmin(new_rho, RHO_MAX));
+                rho_estimate = new_rho;
+                if (__builtin_amdgcn_readfirstlane((int)(new_rho < rho / s.adaptive_rho_tolerance || new_rho > rho * s.adaptive_rho_tolerance))) {
+                    rho = new_rho;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const double prev = rhob[e];
+                        rhob[e] = rho_of(typ[e], rho);
+                        rhobinv[e] = 1.0 / rhob[e];
+                        kd[e] = isP[e] ? (kd[e] + (rhob[e] - prev)) : 0.0;   // update_kkt_rho, box_admm.hpp:448-452
+                    }
+                    rhoc = rho_of(ctyp, rho); rhocinv = 1.0 / rhoc;
+                    ++rho_updates;
+                    refactor = true;
+                    ++iter;
+                    break;
+                }
+            }
+            ++iter;
+        }
+        if (!refactor) running = false;
+    }
+    if (iter > s.max_iter) status = PMPC_QP_MAX_ITER_EXCEEDED;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) if (isP[e]) { out_x[lp[e]] = xv[e]; out_y[MM + lp[e]] = yb[e]; }
+    if (isC) out_y[rc] = ya;
+    const bool bad = __builtin_amdgcn_ballot_w64((((xv[0] - xv[0]) + (yb[0] - yb[0])) + ((xv[1] - xv[1]) + (yb[1] - yb[1])) + (ya - ya)) != 0.0) != 0;   // non-finite x or y
+    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info.flags = bad ? PMPC_FLAG_NONFINITE : 0;
+    info.rho_estimate = rho_estimate; info.res_prim = res_prim; info.res_dual = res_dual;
+}
+
+}  // namespace pmpc

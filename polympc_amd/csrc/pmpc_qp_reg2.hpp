@@ -26,7 +26,7 @@
 
 namespace pmpc {
 
-template <int N>
+template <int N, int NVREQ = -1>   // NVREQ >= 0: operand tiles kept in arch VGPRs (see NV)
 struct RegKkt2 {
     static_assert(N > 64 && N <= 128, "two-rows-per-lane register path: 65..128 KKT rows");
     using d4 = double __attribute__((ext_vector_type(4)));
@@ -69,7 +69,7 @@ struct RegKkt2 {
     // Tiles with index R*NT + C < NV stay in arch VGPRs; the others are split into 32-bit halves whose only uses are "a"-constrained inline-asm
     // operands, which makes their virtual registers AGPR-class: they live in the accumulation file for the whole ADMM loop and are copied
     // (v_accvgpr_read_b32 x 2) into a temporary pair next to the fma that consumes them.
-    static constexpr int NV = LDS_TILES ? 17 : ((NT == 7) ? 18 : (NT == 6 ? 12 : 10));
+    static constexpr int NV = NVREQ >= 0 ? NVREQ : (LDS_TILES ? 17 : ((NT == 7) ? 18 : (NT == 6 ? 12 : 10)));
     static constexpr int NA = NT * NTR - NV;
     // running index of a register-resident tile, row-major over the tiles that are not in LDS
     __device__ __forceinline__ static constexpr int reg_index(int R, int C) {
@@ -172,8 +172,54 @@ struct RegKkt2 {
 
     // kload(j, s, z): K(row 64 s + lane, j) for j != row (0.0 for rows >= N), needed for the columns of the block-lower tile storage only
     // (j < 16 (row / 16 + 1)); z is the opaque zero that keeps the address arithmetic next to the loads. diag0 / diag1: K(row, row).
-    template <class KLoad>
-    __device__ __forceinline__ void invert(int ln_in, double* st, double diag0, double diag1, KLoad kload, long long* tm = nullptr) {
+    struct NoPre { __device__ __forceinline__ void operator()(RegKkt2&, double*, double*, int, int, int) const {} };
+    // T[R][C] += sum_j (rho_j a_j)_R (a_j)_C' over the MM rows a_j of A, j ascending in groups of four — the k-ascending fma chain of
+    // v_mfma_f64_16x16x4_f64 per stored entry: M(a, b) = fma(rho_j A(j, a), A(j, b), M(a, b)). aload(j, e, z): A(j, row 64 e + lane) (0.0 on lanes without
+    // such a row); rho_of(j): rho_j, wave-uniform. The condensed register kernel (pmpc_qp_cond.hpp) calls this between the staging of H + diag and the
+    // blocked sweep: the tiles then hold S = H + sigma I + rho_box + A' diag(rho) A.
+    template <int MM, class ALoad, class RhoOf>
+    __device__ __forceinline__ void rank_update(int ln, int lr, int lc, double* PA, double* PB, ALoad aload, RhoOf rho_of) {
+        constexpr int NGR = (MM + BK - 1) / BK, GB = 4;   // groups of four rows; GB groups (32 loads) requested together
+        int z = 0;
+        asm volatile("" : "+v"(z));
+#pragma unroll
+        for (int g0 = 0; g0 < NGR; g0 += GB) {
+            double a0[GB * BK], a1[GB * BK];
+#pragma unroll
+            for (int u = 0; u < GB * BK; ++u) {
+                const int j = BK * g0 + u;
+                a0[u] = (j < MM) ? aload(j < MM ? j : 0, 0, z) : 0.0;
+                a1[u] = (j < MM) ? aload(j < MM ? j : 0, 1, z) : 0.0;
+            }
+            sched_fence();
+#pragma unroll
+            for (int gg = 0; gg < GB; ++gg) {
+                if (g0 + gg < NGR) {
+#pragma unroll
+                    for (int t = 0; t < BK; ++t) {
+                        const int j = BK * (g0 + gg) + t;
+                        const double rj = (j < MM) ? rho_of(j < MM ? j : 0) : 0.0;
+                        PB[t * SK + ln] = a0[gg * BK + t];
+                        PB[t * SK + 64 + ln] = a1[gg * BK + t];
+                        PA[t * SK + ln] = rj * a0[gg * BK + t];
+                        PA[t * SK + 64 + ln] = rj * a1[gg * BK + t];
+                    }
+                    lds_order();
+                    double av[NT], bv[NT];
+#pragma unroll
+                    for (int R = 0; R < NT; ++R) { av[R] = PA[lr * SK + 16 * R + lc]; bv[R] = PB[lr * SK + 16 * R + lc]; }
+#pragma unroll
+                    for (int R = 0; R < NT; ++R)
+#pragma unroll
+                        for (int C = 0; C <= R; ++C) T[R][C] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[R], bv[C], T[R][C], 0, 0, 0);
+                    lds_order();
+                    sched_fence();
+                }
+            }
+        }
+    }
+    template <class KLoad, class Pre = NoPre>
+    __device__ __forceinline__ void invert(int ln_in, double* st, double diag0, double diag1, KLoad kload, long long* tm = nullptr, Pre pre = Pre()) {
         long long tq0 = tm ? clock64() : 0;
         int ln = ln_in;
         asm volatile("" : "+v"(ln));
@@ -222,6 +268,7 @@ struct RegKkt2 {
             for (int r = 0; r < 4; ++r) T[R][R][r] = (lc == lr + 4 * r) ? dR : T[R][R][r];
         }
         lds_order();
+        pre(*this, PA, PB, ln, lr, lc);
         if (tm) { long long t = clock64(); tm[0] += t - tq0; tq0 = t; }
         block_steps<0>(ln, lr, lc, PA, PB, X, tm, tq0);
         if (tm) { long long t = clock64(); tm[1] += t - tq0; tq0 = t; }

@@ -53,9 +53,11 @@ constexpr int PMPC_SQP_IN_PROGRESS = 3;   // internal: the instance continues in
 // PS: P * 256 + S of a BLOCK-STRUCTURED specialisation (pmpc_qp_schur.hpp; 0 = none): the Hessian is block diagonal per node (block BFGS or exact
 //      Hessians, NP = NG = 0) and lives as per-node blocks in LDS (`hblk`), J as its per-node blocks (`ocp.jblk`) + the differentiation matrix: the
 //      HBM workspace is not touched at all, and the QP is solved through the m x m Schur complement. NN, MM are the compile-time sizes there too.
+//      PS = -1: the CONDENSED register specialisation (pmpc_qp_cond.hpp) of a two-rows-per-lane kernel — everything as REG2 except the QP.
 template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bool BIG = false, bool POL = false, int PS = 0>
 struct SqpDevice {
     static constexpr bool SCH = PS > 0;
+    static constexpr bool CND = PS == -1;   // condensed register QP (pmpc_qp_cond.hpp): a two-rows-per-lane kernel (REG2) whose QP inverts S = H + sigma I + rho_box + A' diag(rho) A only
     static constexpr int SCH_P = PS / 256, SCH_S = PS % 256;
     static constexpr bool HOOKS = (NN == 0) || POL;
     using Dm = OcpDims<Model>;
@@ -934,6 +936,9 @@ struct SqpDevice {
         if constexpr (SCH) {
             boxadmm_solve_schur<Model, SCH_P, SCH_S>(hblk, v.h, ocp.jblk, ocp.s.D, ocp.s.nsr, v.al, v.au, v.lx, v.ux, qs, qi, qw.x, qw.y, tr, qblk, xsc, dsc, pdl, dtab,
                                                      PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr);
+            wsync();
+        } else if constexpr (CND) {
+            boxadmm_solve_cond<NN, MM>(Hw, v.h, v.al, v.au, v.lx, v.ux, qs, qi, qw.x, qw.y, tr, jview(), PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr);
             wsync();
         } else if constexpr (REG2) {   // (lower-triangle read of H always: the Hessian update is a run-time choice in these kernels)
             // (POL: the Ruiz preconditioner may have rescaled the workspace, whose entries the blocks of the sparse view then no longer are: dense residuals)

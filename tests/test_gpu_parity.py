@@ -62,7 +62,7 @@ def _schur_route(model, P, S, hessian_update=0, exact_hessian_every_iter=0, regu
         not preconditioner and not qp_solver and not line_search and not kkt_form and not linear_solver
 
 
-def _gpu_order(oracle, n, m, nodes=None, block_bfgs=False, kkt_form=0, schur=False):
+def _gpu_order(oracle, n, m, nodes=None, block_bfgs=False, kkt_form=0, schur=False, ng=0):
     """Which of the oracle's GPU-order linear-solve restatements mirrors the kernel that serves this size: the register-resident QP
     (compile-time sizes with n+m <= 64: the (35, 21) QP entry point, SQP grids of 3 to 8 nodes) applies the inverse swept in blocks of
     four pivots (PIVOT_SWEEP); the two-rows-per-lane register path (65..112 rows: the (66, 44) and (55, 33) QP entry points) the same sweep with
@@ -77,6 +77,8 @@ def _gpu_order(oracle, n, m, nodes=None, block_bfgs=False, kkt_form=0, schur=Fal
     if n + m <= 64 and nodes in ((5, 7) if block_bfgs else REG_NODE_COUNTS):   # (the block-BFGS one-row-per-lane specialisation exists for 5 and 7 nodes)
         return oracle.PIVOT_SWEEP
     if 64 < n + m <= 128 and nodes in REG_NODE_COUNTS:      # two-rows-per-lane register path (113..128 rows: part of the operand tiles in LDS) (the Hessian update is a run-time choice there)
+        if 64 < n <= 112 and m <= 64 and kkt_form == 0 and ng == 0 and n % nodes == 0:    # (no path constraints, no parameters) condensed register kernel (pmpc_qp_cond.hpp): only S = H + sigma I + rho_box + A' diag(rho) A is inverted
+            return oracle.PIVOT_CONDSWEEP
         return oracle.PIVOT_SWEEP2
     return _lds_order(oracle, n + m, kkt_form=kkt_form)
 
@@ -561,7 +563,7 @@ def _sqp_both(ctx, oracle, wl, B, **kw):
     #  order; hessian_update = 1 has register-resident specialisations like the default)
     if kw.get("qp_solver", 0): order = oracle.PIVOT_STATIC
     elif kw.get("preconditioner", 0) or kw.get("line_search", 0): order = _policy_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, ruiz=bool(kw.get("preconditioner", 0)), block_bfgs=bool(kw.get("hessian_update", 0)), kkt_form=kf)
-    else: order = _gpu_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, block_bfgs=bool(kw.get("hessian_update", 0)), kkt_form=kf,
+    else: order = _gpu_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, block_bfgs=bool(kw.get("hessian_update", 0)), kkt_form=kf, ng=dm["ng"],
                              schur=_schur_route(wl["model"], wl["P"], wl["S"], **kw))
     xo, lo, io = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"],
                                         sqp_settings=oss, pivot=order, threads=8)
@@ -980,7 +982,7 @@ def test_sqp_iteration_records_vs_oracle(ctx, oracle, P, S, B):
         otr = np.zeros((B, cap, oracle.TRACE_DOUBLES)); oracle.bind_iteration_trace(oss, otr)
         dm = oracle.ocp_dims(wl["model"], P, S)
         xo, lo, io = oracle.sqp_solve_batch(wl["model"], P, S, wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss,
-                                            pivot=_gpu_order(oracle, dm["n"], dm["m"], P * S + 1))
+                                            pivot=_gpu_order(oracle, dm["n"], dm["m"], P * S + 1, ng=dm["ng"]))
         _assert_same_solve(info, io, x, xo, lam, lo)
         assert np.array_equal(tr, otr)
         for b in range(B):
@@ -1218,7 +1220,7 @@ def test_default_kernels_against_the_reference_order(ctx, oracle, cfg):
     xr, lr, ir = tco.oracle_run(oracle, wl, nB, oracle.PIVOT_EIGEN, True, 8)
     r = tco.cross_order_stats(cfg, wl, x, lam, info, xr, lr, ir)
     print(cfg, "route", pa.capi.ROUTE_NAMES[ctx.last_route()], r)
-    assert ctx.last_route() == {"A": pa.capi.ROUTE_REG1, "D": pa.capi.ROUTE_REG1, "B": pa.capi.ROUTE_REG2, "R": ROUTE_OF_128_ROWS(pa), "C": pa.capi.ROUTE_HBM}[cfg]
+    assert ctx.last_route() == {"A": pa.capi.ROUTE_REG1, "D": pa.capi.ROUTE_REG1, "B": pa.capi.ROUTE_CONDREG, "R": ROUTE_OF_128_ROWS(pa), "C": pa.capi.ROUTE_HBM}[cfg]
     assert r["instances"] == nB and r["different_trajectories"] <= max_diff
     assert r["identical_trajectories_only"]["max_abs_dx"] <= tol_dx
     assert r["scaled_dx_per_instance"]["p99"] <= tol_p99
@@ -1239,7 +1241,7 @@ def test_cstr_short_horizon_tight_pin_against_the_reference_order(ctx, oracle, h
     wl, _ = tco.config_workload("B", B=nB); wl = dict(wl); wl["max_iter"] = 5
     ss = pa.sqp_settings_default(); ss.max_iter = 5; ss.line_search_max_iter = wl["ls_max_iter"]; ss.hessian_update = hessian_update
     x, lam, info = ctx.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], nB, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
-    assert ctx.last_route() == (pa.capi.ROUTE_SCHUR if hessian_update else pa.capi.ROUTE_REG2)
+    assert ctx.last_route() == (pa.capi.ROUTE_SCHUR if hessian_update else pa.capi.ROUTE_CONDREG)
     xr, lr, ir = tco.oracle_run(oracle, wl, nB, oracle.PIVOT_EIGEN, True, 8, hessian_update=hessian_update)
     r = tco.cross_order_stats("B", wl, x, lam, info, xr, lr, ir)
     print(hessian_update, r)
@@ -1249,7 +1251,7 @@ def test_cstr_short_horizon_tight_pin_against_the_reference_order(ctx, oracle, h
 
 def ROUTE_OF_128_ROWS(pa):
     """the kernel family pmpc_launch.hpp routes 128-row instances to (one place to change when the route changes)"""
-    return pa.capi.ROUTE_REG2   # round 3: 113..128 rows on the two-rows-per-lane register path (8 x 8 tiles, sixteen of them in LDS)
+    return pa.capi.ROUTE_CONDREG   # round 4: 80 variables, 48 constraint rows — the condensed register kernel (round 3: the two-rows-per-lane full inverse with sixteen operand tiles in LDS, still behind kkt_form = 1)
 
 
 def test_last_route_reports_the_kernel_family(ctx):
@@ -1266,8 +1268,9 @@ def test_last_route_reports_the_kernel_family(ctx):
         ctx.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
         return ctx.last_route()
     assert route(workloads.robot_batch(4)) == pa.capi.ROUTE_REG1
-    assert route(workloads.robot_batch(4, P=5, S=2)) == pa.capi.ROUTE_REG2
-    assert route(workloads.cstr_batch(4)) == pa.capi.ROUTE_REG2
+    assert route(workloads.robot_batch(4, P=5, S=2)) == pa.capi.ROUTE_REG2                     # 55 variables: the full two-rows-per-lane inverse
+    assert route(workloads.cstr_batch(4)) == pa.capi.ROUTE_CONDREG                             # 66 variables, 44 constraint rows: the condensed register kernel (round 4)
+    assert route(workloads.cstr_batch(4), kkt_form=1) == pa.capi.ROUTE_REG2
     assert route(workloads.robot_batch(4), qp_solver=1) == pa.capi.ROUTE_LDS
     # round 3: the Ruiz preconditioner and the filter line search on the 7- and 11-node register kernels; other grids keep the LDS / HBM kernels for them
     assert route(workloads.robot_batch(4), preconditioner=1) == pa.capi.ROUTE_REG1
@@ -1281,7 +1284,8 @@ def test_last_route_reports_the_kernel_family(ctx):
     assert route(workloads.robot_batch(4, P=5, S=2), hessian_update=1, kkt_form=1) == pa.capi.ROUTE_REG2
     assert route(workloads.robot_batch(4, P=5, S=2), preconditioner=1, line_search=1) == pa.capi.ROUTE_REG2
     assert route(workloads.robot_batch(4, P=4, S=2), preconditioner=1) == pa.capi.ROUTE_LDS
-    assert route(workloads.robot_batch(4, P=5, S=3)) == pa.capi.ROUTE_REG2
+    assert route(workloads.robot_batch(4, P=5, S=3)) == pa.capi.ROUTE_CONDREG
+    assert route(workloads.robot_batch(4, P=5, S=3), kkt_form=1) == pa.capi.ROUTE_REG2
     assert route(workloads.robot_batch(4, P=5, S=3), line_search=1) == pa.capi.ROUTE_HBM
     assert route(workloads.kite_standin_batch(2)) == pa.capi.ROUTE_HBM
 

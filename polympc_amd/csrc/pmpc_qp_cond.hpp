@@ -23,7 +23,7 @@
 namespace pmpc {
 
 #ifndef PMPC_COND_NV
-#define PMPC_COND_NV 16
+#define PMPC_COND_NV 25
 #endif
 // the swept inverse of S: the two-rows-per-lane tile set with PMPC_COND_NV of its operand tiles in arch VGPRs (25 tiles at 66..80 rows: the rest lives
 // in the accumulation file and costs two v_accvgpr_read per entry and ADMM iteration)
@@ -39,17 +39,22 @@ struct CondDims {
     static constexpr int PB_OFF = XS_OFF + 128;                   // residual evaluation: products of the few primal rows of the second slot
     static constexpr int TAB_OFF = PB_OFF + 4 * NN;               // D~ tables of the sparse products (cond_build_tables), rebuilt at every QP
     template <int NNODES> static constexpr int nnp() { return NNODES + (NNODES & 1); }
-    template <int NNODES> static constexpr int tab_doubles() { return (2 * NNODES + 1) * nnp<NNODES>(); }
+    template <int NNODES> static constexpr int tab_doubles() { return (4 * NNODES + 1) * nnp<NNODES>(); }
 };
 
 // D~ as two dense tables in LDS: Dt[r NNP + k] = D~(r, k) — the differentiation-matrix entry of equality row node r on the state columns of node k
 // (continuous_ocp.hpp:817-827, :845-846), 0 on the own node (that entry lives in the node block) and outside the row's segment — and its transpose
-// DtT[k NNP + r], followed by one all-zero row (read by control columns and inequality rows). Run-time P: these kernels are compiled per node count.
+// DtT[k NNP + r]; then the parts of both BELOW the own node (Dlo[r][k] = D~(r, k) for k < r, DtTlo[k][r] = D~(r, k) for r < k, 0 elsewhere: the residual
+// evaluation walks a row / column in the reference's ascending order — entries before the own node's block, the block, entries behind it — and forms
+// the part behind as table - lower part, exactly); one all-zero row at the end (read by control columns). Run-time P: these kernels are compiled per
+// node count.
 template <int NNODES>
 __device__ __forceinline__ void cond_build_tables(const double* Dm, int P, double* Dt) {
     constexpr int NNP = NNODES + (NNODES & 1);
     double* DtT = Dt + NNODES * NNP;
-    for (int e = lane_id(); e < (2 * NNODES + 1) * NNP; e += WAVE) Dt[e] = 0.0;
+    double* Dlo = DtT + NNODES * NNP;
+    double* DtTlo = Dlo + NNODES * NNP;
+    for (int e = lane_id(); e < (4 * NNODES + 1) * NNP; e += WAVE) Dt[e] = 0.0;
     lds_order();
     const int P1 = P + 1;
     for (int e = lane_id(); e < NNODES * NNODES; e += WAVE) {
@@ -63,6 +68,8 @@ __device__ __forceinline__ void cond_build_tables(const double* Dm, int P, doubl
         const double v = cpl ? dv : 0.0;
         Dt[r * NNP + k] = v;
         DtT[k * NNP + r] = v;
+        Dlo[r * NNP + k] = (k < r) ? v : 0.0;
+        DtTlo[k * NNP + r] = (r < k) ? v : 0.0;
     }
     lds_order();
 }
@@ -148,7 +155,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
         const int cu = c - VARX;
         const int jn = xcol ? c / NX : cu / NU;
         const int dcol = xcol ? c - jn * NX : NX + (cu - jn * NU);
-        cD[e] = DtT + (xcol ? jn : NNODES) * NNP;
+        cD[e] = xcol ? DtT + jn * NNP : Dt + 4 * NNODES * NNP;
         cU[e] = us + (xcol ? dcol : 0);
         cB[e] = jv.jblk + (jn * NX) * NDER + dcol;
         cV[e] = us + jn * NX;
@@ -272,9 +279,55 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                     for (int e = 0; e < 2; ++e) if (isP[e]) xs[lp[e]] = xv[e];
                     if (isC) us[rc] = ya;
                     lds_order();
+                    // A' y and A x in the reference's order (multiply, then add; ascending index: the entries before the own node's block, the block, the
+                    // entries behind it — pmpc_jview.hpp states why these are the dense chains bit for bit) from the same tables as the fma products
+                    const double* DtTlo = DtT + 2 * NNODES * NNP;
+                    const double* Dlo = DtT + NNODES * NNP;
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) { const double v = jv.coldot(lp[e], us, isP[e]); aty[e] = isP[e] ? v : 0.0; }
-                    { const double v = jv.rowdot(rc, xs); axz = isC ? v : 0.0; }
+                    for (int e = 0; e < 2; ++e) {
+                        double a = 0.0;
+                        const bool dpart = (e == 0 || SLOT1_STATES);
+                        double dv[NNODES], lv[NNODES], uv[NNODES], bv[NX], vv[NX];
+                        if (dpart) {
+                            const double* cl = cD[e] + ((cD[e] < DtT + NNODES * NNP) ? 2 * NNODES * NNP : 0);   // (a control column keeps the all-zero row)
+#pragma unroll
+                            for (int k = 0; k < NNODES; ++k) { dv[k] = cD[e][k]; lv[k] = cl[k]; uv[k] = cU[e][k * NX]; }
+                        }
+#pragma unroll
+                        for (int q = 0; q < NX; ++q) { bv[q] = cB[e][q * NDER]; vv[q] = cV[e][q]; }
+                        if (dpart) {
+#pragma unroll
+                            for (int k = 0; k < NNODES; ++k) a += lv[k] * uv[k];
+                        }
+#pragma unroll
+                        for (int q = 0; q < NX; ++q) a += bv[q] * vv[q];
+                        if (dpart) {
+#pragma unroll
+                            for (int k = 0; k < NNODES; ++k) a += (dv[k] - lv[k]) * uv[k];
+                        }
+                        aty[e] = isP[e] ? a : 0.0;
+                    }
+                    {
+                        double a = 0.0;
+                        const double* rl = Dlo + rk * NNP;
+                        double dv[NNODES], lv[NNODES], xq[NNODES], bv[NDER], xb[NDER];
+#pragma unroll
+                        for (int j = 0; j < NNODES; ++j) { dv[j] = rD[j]; lv[j] = rl[j]; xq[j] = rX[j * NX]; }
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) { bv[i] = rB[i]; xb[i] = rV[i]; }
+#pragma unroll
+                        for (int i = 0; i < NU; ++i) { bv[NX + i] = rB[NX + i]; xb[NX + i] = rW[i]; }
+#pragma unroll
+                        for (int j = 0; j < NNODES; ++j) a += lv[j] * xq[j];
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) a += bv[i] * xb[i];
+#pragma unroll
+                        for (int j = 0; j < NNODES; ++j) a += (dv[j] - lv[j]) * xq[j];
+#pragma unroll
+                        for (int i = NX; i < NDER; ++i) a += bv[i] * xb[i];
+                        axz = isC ? a : 0.0;
+                    }
+                    (void)Dlo; (void)DtTlo;
                     sched_fence();
                 } else {
                     // dense chains from the workspace

@@ -40,7 +40,7 @@ template <class Model> __host__ __device__ inline size_t jview_doubles(int nnode
 // large-instance mode: per-instance HBM scratch (doubles) behind the factor workspace — SQP vectors, per-node AD staging, QP vectors
 template <class Model> __host__ __device__ inline size_t big_scratch_doubles(int P, int S) {
     OcpDims<Model> dm(P, S);
-    return SqpLds::doubles(dm.n, dm.m, dm.mi) + OcpLds<Model>::doubles(P, S) + QpLds::doubles_rest(dm.n, dm.m) + jview_doubles<Model>(dm.NN) + 8;
+    return ((SqpLds::doubles(dm.n, dm.m, dm.mi) + OcpLds<Model>::doubles(P, S) + QpLds::doubles_rest(dm.n, dm.m) + jview_doubles<Model>(dm.NN) + 8) + 1) & ~(size_t)1;   // (even: every instance's factor workspace starts on a 16-byte boundary — its panels are read 16 bytes per lane)
 }
 
 // KHBM: large-instance mode of the LDS-resident kernels — the KKT factor lives in an HBM workspace (Kws). A compile-time flag so
@@ -687,10 +687,11 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     if (lds > lds_limit || prefer_big) {   // large instance: KKT factor in HBM, SQP / QP vectors in an HBM scratch behind it
         lds = sqp_kernel_lds_bytes<Model>(P, S, 2) + sqp_eig_lds_bytes<Model>(P, S, ss);
         if (lds > lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;
-        st = pmpc_internal_services(ctx, P, S, t0, tf, (base + (size_t)B * (BigKkt::doubles(dm.n + dm.m) + big_scratch_doubles<Model>(P, S))) * sizeof(double), &cdv, &ws, &streamv,
+        const size_t base16 = (base + 1) & ~(size_t)1;   // (16-byte boundary for the factor workspaces)
+        st = pmpc_internal_services(ctx, P, S, t0, tf, (base16 + (size_t)B * (BigKkt::doubles(dm.n + dm.m) + big_scratch_doubles<Model>(P, S))) * sizeof(double), &cdv, &ws, &streamv,
                                     &lds_limit, &phase, &force_lds);
         if (st != PMPC_OK) return st;
-        Hws = ws; Aws = ws + (size_t)B * dm.n * dm.n; slice_state = Aws + (size_t)B * dm.m * dm.n; Kws = ws + base;
+        Hws = ws; Aws = ws + (size_t)B * dm.n * dm.n; slice_state = Aws + (size_t)B * dm.m * dm.n; Kws = ws + base16;
     }
     pmpc_internal_set_route(ctx, Kws ? PMPC_ROUTE_HBM : PMPC_ROUTE_LDS);
     auto lkern = Kws ? sqp_kernel<Model, 0, 0, false, 0, true> : sqp_kernel<Model>;

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(64, 1) void qp_boxadmm_big_kernel(int B, int n, int
     double* p = w.carve_xy(smem, n, m);
     double* rhsL = p; p += N;
     w.big_lds = p; p += BigKkt::LDS_DOUBLES;
-    double* Wb = Kws + (size_t)b * (BigKkt::doubles(N) + QpLds::doubles_rest(n, m));
+    double* Wb = Kws + (size_t)b * (BigKkt::doubles(N) + ((QpLds::doubles_rest(n, m) + 1) & ~(size_t)1));   // (even stride: 16-byte panel reads)
     w.carve_rest_split(Wb + BigKkt::doubles(N), rhsL, n, m, Wb);
     pmpc_qp_info qi;
     boxadmm_solve<true>(w, n, m, H + (size_t)b * n * n, n, h + (size_t)b * n, A + (size_t)b * m * n, m, Alb + (size_t)b * m, Aub + (size_t)b * m,
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(64, 1) void qp_boxadmm_big_kernel(int B, int n, int
     if (ln == 0) info[b] = qi;
 }
 
-extern "C" size_t pmpc_internal_qp_big_ws_doubles(int n, int m) { return BigKkt::doubles(n + m) + QpLds::doubles_rest(n, m); }
+extern "C" size_t pmpc_internal_qp_big_ws_doubles(int n, int m) { return BigKkt::doubles(n + m) + ((QpLds::doubles_rest(n, m) + 1) & ~(size_t)1); }
 extern "C" size_t pmpc_internal_qp_big_lds_bytes(int n, int m) {
     return (QpLds::doubles_xy(n, m) + (size_t)(n + m) + BigKkt::LDS_DOUBLES) * sizeof(double);
 }

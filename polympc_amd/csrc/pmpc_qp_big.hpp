@@ -22,7 +22,8 @@
 //     tests/experiments/mfma_f64_probe.hip — which is exactly the order above), A operand = the negated unscaled panel (-C, kept k-major
 //     in the CF strip of its block column), B operand = the k-major tile of L.
 //   * substitutions: lane per row; per block column the 16 finished entries are broadcast (v_readlane) and every row below (above) applies
-//     its 16 fma from ONE contiguous 128-byte load; 32 such loads are in flight per batch. 2N dependent steps become 2N/16.
+//     its 16 fma from eight 16-byte loads (column pairs side by side in the panel, see BigKkt::slab); 32 such loads are in flight per batch.
+//     2N dependent steps become 2N/16.
 // MFMA-busy is what bounds a single wavefront here (33 MFLOP per factorisation at 32 flop/cycle/SIMD), HBM traffic what bounds the batch
 // (factor + two substitution passes per ADMM iteration: 1.7 MB per iteration and instance).
 #pragma once
@@ -38,16 +39,19 @@ struct BigKkt {
     __host__ __device__ static int nblk(int N) { return (N + TB - 1) / TB; }
     __host__ __device__ static int ntiles(int N) { const int nb = nblk(N); return nb * (nb + 1) / 2; }
     __host__ __device__ static int tidx(int I, int J) { return I * (I + 1) / 2 + J; }
-    // Panels are stored in SLABS of 64 lanes x 16 entries (8 KB): entry (c, rel) of a panel at (rel / 64) * 1024 + c * 64 + rel % 64, so that the 16
-    // load instructions of one lane-per-row slot sweep ONE contiguous 8 KB region (sixteen 512-byte pieces a panel-column apart kept one DRAM
-    // row per piece open).
+    // Panels are stored in SLABS of 64 lanes x 16 entries (8 KB), so that the load instructions of one lane-per-row slot sweep ONE contiguous 8 KB
+    // region (sixteen 512-byte pieces a panel-column apart kept one DRAM row per piece open); entry (c, rel) of a panel: slab(c, rel) below.
     //   LF, block column J: rel = row - 16J, c = column - 16J, (NPAD - 16J) rows padded to a multiple of 64; panels in J order
     __host__ __device__ static size_t sizeF(int J, int NPAD) { return (size_t)16 * (((NPAD - 16 * J) + 63) / 64 * 64); }
     __host__ __device__ static size_t sizeB(int J) { return (size_t)16 * ((16 * (J + 1) + 63) / 64 * 64); }
     __host__ __device__ static size_t ceil4_sum(int t) { const int Q = t >> 2, R = t & 3; return (size_t)(Q + 1) * (2 * Q + R); }   // sum_{u=1..t} ceil(u / 4)
     __host__ __device__ static size_t offB(int J) { return 1024 * ceil4_sum(J); }                                    // sizeB(j) = 1024 ceil((j+1)/4)
     __host__ __device__ static size_t offF(int J, int NPAD) { const int nb = NPAD >> 4; return 1024 * (ceil4_sum(nb) - ceil4_sum(nb - J)); }   // sizeF(j) = 1024 ceil((nb-j)/4)
-    __host__ __device__ static size_t slab(int c, int rel) { return (size_t)(rel >> 6) * 1024 + (size_t)c * 64 + (rel & 63); }
+    // (round 4) inside a slab the 16 columns are stored as 8 PAIRS: entries (2p, rel) and (2p + 1, rel) side by side, so that a lane-per-row slot reads
+    // its 16 entries with eight 16-byte loads — a wavefront's load instructions cost ~55 cycles each whatever their width (tests/experiments/
+    // wave_stream_probe.hip: 8-byte loads stream 9 B/cycle at any depth, 16-byte loads 20 B/cycle), and the triangular passes are made of them
+    __host__ __device__ static size_t slab(int c, int rel) { return (size_t)(rel >> 6) * 1024 + (size_t)(c >> 1) * 128 + (size_t)(rel & 63) * 2 + (c & 1); }
+    __host__ __device__ static size_t slab_pair(int p, int rel) { return (size_t)(rel >> 6) * 1024 + (size_t)p * 128 + (size_t)(rel & 63) * 2; }   // 16-byte aligned: columns 2p, 2p + 1
     //   CF, block column k: the NEGATED UNSCALED column entries -c of the rows below the diagonal tile (the A operand of the tile updates), k-major:
     //   entry (t, row) at t * (NPAD - 16(k+1)) + row - 16(k+1); strips in k order
     __host__ __device__ static size_t offC(int k, int NPAD) { return (size_t)16 * ((size_t)k * NPAD - (size_t)8 * k * (k + 1)); }
@@ -60,6 +64,7 @@ struct BigKkt {
 };
 
 using big_d4 = double __attribute__((ext_vector_type(4)));
+using big_d2 = double __attribute__((ext_vector_type(2)));
 
 // K (lower block triangle, row-major tiles in W) <- [H + diag ; A, diag]; rows / columns >= N: identity padding.
 // Eight tiles of a tile row per pass (32 independent loads in flight): one tile at a time was a chain of 435 dependent load -> store round trips at 464 rows
@@ -301,7 +306,9 @@ __device__ __forceinline__ void big_factor(double* W, int N, double* dl) {
             }
             if (ln < 16) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) { pF[BigKkt::slab(c, r)] = a[c]; dl[r * 16 + c] = a[c]; }
+                for (int c = 0; c < 16; ++c) dl[r * 16 + c] = a[c];
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp) { big_d2 v2; v2[0] = a[2 * pp]; v2[1] = a[2 * pp + 1]; *reinterpret_cast<big_d2*>(pF + BigKkt::slab_pair(pp, r)) = v2; }
             }
             wfence();
             wsync();
@@ -330,7 +337,9 @@ __device__ __forceinline__ void big_factor(double* W, int N, double* dl) {
             }
             if (live) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) { pF[BigKkt::slab(c, row - 16 * J)] = a[c]; cs[(size_t)c * w + row - 16 * (J + 1)] = cneg[c]; }
+                for (int c = 0; c < 16; ++c) cs[(size_t)c * w + row - 16 * (J + 1)] = cneg[c];
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp) { big_d2 v2; v2[0] = a[2 * pp]; v2[1] = a[2 * pp + 1]; *reinterpret_cast<big_d2*>(pF + BigKkt::slab_pair(pp, row - 16 * J)) = v2; }
             }
         }
         wfence();
@@ -381,7 +390,7 @@ __device__ __forceinline__ void big_solve(const double* W, int N, double* v, dou
             const int row = 16 * J + r;
             double lrow[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) lrow[c] = pF[BigKkt::slab(c, r)];
+            for (int pp = 0; pp < 8; ++pp) { const big_d2 v2 = *reinterpret_cast<const big_d2*>(pF + BigKkt::slab_pair(pp, r)); lrow[2 * pp] = v2[0]; lrow[2 * pp + 1] = v2[1]; }
             double xr = (row < N) ? v[row] : 0.0;
 #pragma unroll
             for (int c = 0; c < 15; ++c) {
@@ -400,7 +409,7 @@ __device__ __forceinline__ void big_solve(const double* W, int N, double* v, dou
                 const int row = row0 + g * WAVE + ln;
                 const int rw = (row < NPAD) ? row : NPAD - 1;
 #pragma unroll
-                for (int c = 0; c < 16; ++c) L[g][c] = pF[BigKkt::slab(c, rw - 16 * J)];
+                for (int pp = 0; pp < 8; ++pp) { const big_d2 v2 = *reinterpret_cast<const big_d2*>(pF + BigKkt::slab_pair(pp, rw - 16 * J)); L[g][2 * pp] = v2[0]; L[g][2 * pp + 1] = v2[1]; }
                 vi[g] = (row < N) ? v[row] : 0.0;
             }
 #pragma unroll
@@ -440,7 +449,7 @@ __device__ __forceinline__ void big_solve(const double* W, int N, double* v, dou
                 const int row = row0 + g * WAVE + ln;
                 const int rw = (row < NPAD) ? row : NPAD - 1;
 #pragma unroll
-                for (int c = 0; c < 16; ++c) L[g][c] = pF[BigKkt::slab(c, rw - 16 * J)];
+                for (int pp = 0; pp < 8; ++pp) { const big_d2 v2 = *reinterpret_cast<const big_d2*>(pF + BigKkt::slab_pair(pp, rw - 16 * J)); L[g][2 * pp] = v2[0]; L[g][2 * pp + 1] = v2[1]; }
                 xr[g] = (row < N) ? v[row] : 0.0;
             }
 #pragma unroll

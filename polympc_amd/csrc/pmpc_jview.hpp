@@ -185,6 +185,7 @@ struct JViewRT {
     const double* jblk;
     const double* gblk;
     int P, NNo, VARX, VARU, ME;
+    const double* tab = nullptr;   // (NG = NP = 0) four dense (NNo + 1) x NNP tables of D~ in LDS, see build_tables; null: the products below walk the structure
 
     struct Node { int kb; const double* drow; int dstride; };
     // segment start and D row of the equality rows of node k (Ocp::seg_row) from arithmetic alone — k / P through a float reciprocal, exact for the
@@ -236,6 +237,95 @@ struct JViewRT {
         return cc.pcol || cc.jn == kk || (w.eq && inseg);
     }
     __device__ __forceinline__ static double step(double a, double v, double x, bool on) { const double f = fma(v, x, a); return (on && v != 0.0) ? f : a; }
+
+    // ---- table-driven form of the two products of the condensed solve (round 4). D~(r, k): the differentiation-matrix entry of equality row node r on the
+    // state columns of node k, 0 on the own node and outside the row's segment. Four tables, rows padded to a multiple of 8 entries, one all-zero row behind
+    // each (control columns): [0] column node jn, row nodes below it (k < jn)  [1] column node jn, k > jn  [2] row node k, column nodes j < k  [3] j > k.
+    // The products then are fma chains with coefficients at per-lane bases + immediate offsets — the entries before the own node's block, the block, the
+    // entries behind it: the ascending order of the structure-walking versions (a zero coefficient leaves a finite partial sum unchanged) without their
+    // index arithmetic and selects (43 k + 20 k cycles per ADMM iteration of config C for the two products; with the tables: 4 k + 3 k).
+    __host__ __device__ static int tab_nnp(int nno) { return (nno + 7) & ~7; }
+    __host__ __device__ static size_t tab_doubles(int nno) { return (size_t)4 * (nno + 1) * tab_nnp(nno); }
+    __device__ __forceinline__ static void build_tables(const double* Dm, int P, int NNo, double* tb) {
+        const int NNP = tab_nnp(NNo), TS = (NNo + 1) * NNP, P1 = P + 1;
+        for (int e = lane_id(); e < 4 * TS; e += WAVE) tb[e] = 0.0;
+        wsync();
+        for (int e = lane_id(); e < NNo * NNo; e += WAVE) {
+            const int r = e / NNo, k = e - r * NNo;
+            const bool lastr = r == NNo - 1;
+            const int kbr = lastr ? NNo - 1 - P : (r / P) * P;
+            const int rowr = lastr ? P : r - kbr;
+            const int t = k - kbr;
+            const bool cpl = k != r && (unsigned)t <= (unsigned)P;
+            const double dv = Dm[lastr ? P1 * P1 + (cpl ? t : 0) : rowr + (cpl ? t : 0) * P1];
+            const double v = cpl ? dv : 0.0;
+            tb[(r < k ? 0 : TS) + k * NNP + r] = v;               // column node k, row node r
+            tb[(k < r ? 2 * TS : 3 * TS) + r * NNP + k] = v;      // row node r, column node k
+        }
+        wsync();
+    }
+    // init, then the fma chain over column c against us (rows ascending); bv: the own node's block column (col_block)
+    __device__ __forceinline__ double coldot_fma_tab(const Col& cc, const double (&bv)[NX + NG > 0 ? NX + NG : 1], const double* us, double init) const {
+        const int NNP = tab_nnp(NNo), TS = (NNo + 1) * NNP;
+        const double* lo = tab + (cc.xcol ? cc.jn : NNo) * NNP;
+        const double* hi = lo + TS;
+        const double* uq = us + (cc.xcol ? cc.dcol : 0);
+        double a = init;
+        for (int k0 = 0; k0 < NNP; k0 += 8) {
+            double dv[8], uv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { dv[u] = lo[k0 + u]; uv[u] = uq[((k0 + u < NNo) ? k0 + u : 0) * NX]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a = fma(dv[u], uv[u], a);
+        }
+        {
+            double vv[NX];
+#pragma unroll
+            for (int q = 0; q < NX; ++q) vv[q] = us[cc.jn * NX + q];
+#pragma unroll
+            for (int q = 0; q < NX; ++q) a = fma(bv[q], vv[q], a);
+        }
+        for (int k0 = 0; k0 < NNP; k0 += 8) {
+            double dv[8], uv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { dv[u] = hi[k0 + u]; uv[u] = uq[((k0 + u < NNo) ? k0 + u : 0) * NX]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a = fma(dv[u], uv[u], a);
+        }
+        return a;
+    }
+    // fma chain over equality row r = (k, q) against xs (columns ascending), starting from 0; bv: the row's own-node block (row_block)
+    __device__ __forceinline__ double rowdot_fma_tab(const Row& w, const double (&bv)[NDER], const double* xs) const {
+        const int NNP = tab_nnp(NNo), TS = (NNo + 1) * NNP;
+        const double* lo = tab + 2 * TS + w.k * NNP;
+        const double* hi = lo + TS;
+        const double* xq = xs + w.q;
+        double a = 0.0;
+        for (int j0 = 0; j0 < NNP; j0 += 8) {
+            double dv[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { dv[u] = lo[j0 + u]; xv[u] = xq[((j0 + u < NNo) ? j0 + u : 0) * NX]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a = fma(dv[u], xv[u], a);
+        }
+        double xb[NDER];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xb[i] = xs[w.k * NX + i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) xb[NX + i] = xs[VARX + w.k * NU + i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) a = fma(bv[i], xb[i], a);
+        for (int j0 = 0; j0 < NNP; j0 += 8) {
+            double dv[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { dv[u] = hi[j0 + u]; xv[u] = xq[((j0 + u < NNo) ? j0 + u : 0) * NX]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a = fma(dv[u], xv[u], a);
+        }
+#pragma unroll
+        for (int i = NX; i < NX + NU; ++i) a = fma(bv[i], xb[i], a);
+        return a;
+    }
 
     // ---- the two sparse products of the condensed solve. D (`D`) and the vectors live in LDS; the per-node blocks come from the HBM scratch and are
     // requested first (row_block / col_block, every pass of a product before any of them is consumed), so that a product costs one memory round trip.

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
         double* rhsL = p; p += n + m;
         qw.big_lds = p; p += BigKkt::LDS_DOUBLES;   // diagonal tile + broadcast slots of the blocked factorisation
         ocp.Dlds = p; p += (size_t)(P + 1) * (P + 2);
+        if constexpr (Model::NG == 0 && Model::NP == 0) { p += (p - smem) & 1; ocp.jtab = p; p += JViewRT<Model>::tab_doubles(ocp.dm.NN); }   // D~ tables of the condensed solve's sparse products
         double* Wb = Kws + (size_t)b * (BigKkt::doubles(n + m) + big_scratch_doubles<Model>(P, S));
         double* hq = Wb + BigKkt::doubles(n + m);
         hq = v.carve(hq, n, m, mi);
@@ -116,7 +117,11 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
     double* eigw = nullptr;   // eigenvalue-mirroring regulariser (regularisation = 1): A and V of the Jacobi iteration, 2 n^2 doubles; allocated on request only
     if constexpr (NN == 0) { if (ss.regularisation == 1) { eigw = p; p += 2 * (size_t)n * n; } }
     ocp.stage_constants(cd);
-    if constexpr (NN == 0 && KHBM) { for (int i = ln; i < (P + 1) * (P + 2); i += WAVE) ocp.Dlds[i] = ocp.s.D[i]; wsync(); }
+    if constexpr (NN == 0 && KHBM) {
+        for (int i = ln; i < (P + 1) * (P + 2); i += WAVE) ocp.Dlds[i] = ocp.s.D[i];
+        wsync();
+        if constexpr (Model::NG == 0 && Model::NP == 0) JViewRT<Model>::build_tables(ocp.Dlds, P, ocp.dm.NN, ocp.jtab);
+    }
     double* sst = slice_state ? slice_state + (size_t)b * 2 * n : nullptr;   // [previous Lagrangian gradient | previous step]
     for (int i = ln; i < n; i += WAVE) {
         v.x[i] = (it_begin > 0) ? x[(size_t)b * n + i] : (x_guess ? x_guess[(size_t)b * n + i] : 0.0);
@@ -462,7 +467,7 @@ template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode
     size_t stage = OcpLds<Model>::doubles(P, S);
     if (mode == 1) { const size_t need = (size_t)RegKkt<64>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
     if (mode == 2)   // large instances: x, y, the right-hand side of the substitutions and the factorisation's diagonal tile; everything else in HBM
-        return (QpLds::doubles_xy(dm.n, dm.m) + (size_t)(dm.n + dm.m) + BigKkt::LDS_DOUBLES + (size_t)(P + 1) * (P + 2) + (Model::ND > 0 ? Model::ND : 1) + FILTER_LDS_DOUBLES + 8) * sizeof(double);
+        return (QpLds::doubles_xy(dm.n, dm.m) + (size_t)(dm.n + dm.m) + BigKkt::LDS_DOUBLES + (size_t)(P + 1) * (P + 2) + ((Model::NG == 0 && Model::NP == 0) ? JViewRT<Model>::tab_doubles(dm.NN) + 1 : 0) + (Model::ND > 0 ? Model::ND : 1) + FILTER_LDS_DOUBLES + 8) * sizeof(double);
     if (mode == 3) { const size_t need = (size_t)RegKkt2<112>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
     if (mode == 4) { const size_t need = (size_t)RegKkt2<128>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }   // 113..128 rows: LDS-resident operand tiles
     return ((mode == 0 ? QpLds::doubles(dm.n, dm.m) : QpLds::doubles_xy(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8 +

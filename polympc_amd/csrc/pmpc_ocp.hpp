@@ -91,6 +91,7 @@ struct Ocp {
     // block-sparse copy of J for pmpc_jview.hpp (register-resident kernels): the per-node blocks assemble_first_order writes into J, kept in
     // an LDS region that outlives the per-node staging (which the QP's staging aliases); keep_blk says whether the two pointers are set
     double* jblk = nullptr; double* gblk = nullptr; bool keep_blk = false;
+    double* jtab = nullptr;   // large-instance mode: the D~ tables of the condensed solve's sparse products (JViewRT::build_tables), LDS
     double* Dlds = nullptr;   // large-instance mode: an LDS copy of D (+ the last node's row) for the condensed linear algebra (the constants themselves sit in the HBM scratch there)
 
     __device__ Ocp(const Model& mdl, int P_, int S_, double t_scale) : model(mdl), dm(P_, S_), P(P_), S(S_), ts(t_scale), d(nullptr) {}

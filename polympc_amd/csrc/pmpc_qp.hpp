@@ -770,7 +770,9 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
                           const typename JV::Col cc = jv.column(c < n ? c : 0);
                           double bv[JV::NCB > 0 ? JV::NCB : 1];
                           jv.col_block(cc, bv);
-                          const double t = jv.coldot_fma(cc, bv, u, w.rhs[c < n ? c : 0]);
+                          double t;
+                          if constexpr ((int)JV::NG == 0 && (int)JV::NP == 0) t = jv.tab ? jv.coldot_fma_tab(cc, bv, u, w.rhs[c < n ? c : 0]) : jv.coldot_fma(cc, bv, u, w.rhs[c < n ? c : 0]);
+                          else t = jv.coldot_fma(cc, bv, u, w.rhs[c < n ? c : 0]);
                           if (c < n) w.rhs[c] = t;
                       }
                       wsync();
@@ -783,7 +785,9 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
                           const typename JV::Row rw = jv.rowinfo(r < m ? r : 0);
                           double bv[JV::NDER];
                           jv.row_block(rw, bv);
-                          const double a = jv.rowdot_fma(rw, bv, w.rhs);
+                          double a;
+                          if constexpr ((int)JV::NG == 0 && (int)JV::NP == 0) a = jv.tab ? jv.rowdot_fma_tab(rw, bv, w.rhs) : jv.rowdot_fma(rw, bv, w.rhs);
+                          else a = jv.rowdot_fma(rw, bv, w.rhs);
                           if (r < m) w.rhs[n + r] = w.rho[r] * (a - w.rhs[n + r]);
                       }
                       wsync();

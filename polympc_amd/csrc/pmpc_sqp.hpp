@@ -954,7 +954,7 @@ struct SqpDevice {
                 if constexpr (BIG) {
                     // large instances: condensed linear algebra from the block-sparse view of J (n instead of n + m rows) — unless the Ruiz preconditioner
                     // rescaled the workspace, whose entries the per-node blocks of the view then no longer are
-                    const JViewRT<Model> jvr{ocp.Dlds, ocp.s.nsr, ocp.jblk, ocp.gblk, ocp.P, ocp.dm.NN, ocp.dm.VARX, ocp.dm.VARU, ocp.dm.me};
+                    const JViewRT<Model> jvr{ocp.Dlds, ocp.s.nsr, ocp.jblk, ocp.gblk, ocp.P, ocp.dm.NN, ocp.dm.VARX, ocp.dm.VARU, ocp.dm.me, ocp.jtab};
                     boxadmm_solve<true, JViewRT<Model>>(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, PROF ? tq : nullptr, jvr,
                                                         ocp.keep_blk && !ruiz && n <= BIG_COND_MAX_ROWS && m <= BIG_COND_MAX_ROWS && __builtin_amdgcn_readfirstlane(ss.kkt_form) == 0);
                 } else

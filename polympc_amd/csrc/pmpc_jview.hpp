@@ -246,6 +246,9 @@ struct JViewRT {
     // index arithmetic and selects (43 k + 20 k cycles per ADMM iteration of config C for the two products; with the tables: 4 k + 3 k).
     __host__ __device__ static int tab_nnp(int nno) { return (nno + 7) & ~7; }
     __host__ __device__ static size_t tab_doubles(int nno) { return (size_t)4 * (nno + 1) * tab_nnp(nno); }
+    // the tables grow with the square of the node count: up to 16 nodes (8.5 KB) they are worth their LDS; beyond, the occupancy of the two-wavefront
+    // builds pays for them (21 nodes: 17 KB, five instead of eight instances per CU) and the products walk the structure as before
+    __host__ __device__ static bool tab_worth_it(int nno) { return nno <= 16; }
     __device__ __forceinline__ static void build_tables(const double* Dm, int P, int NNo, double* tb) {
         const int NNP = tab_nnp(NNo), TS = (NNo + 1) * NNP, P1 = P + 1;
         for (int e = lane_id(); e < 4 * TS; e += WAVE) tb[e] = 0.0;

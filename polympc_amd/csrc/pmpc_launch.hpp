@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
         double* rhsL = p; p += n + m;
         qw.big_lds = p; p += BigKkt::LDS_DOUBLES;   // diagonal tile + broadcast slots of the blocked factorisation
         ocp.Dlds = p; p += (size_t)(P + 1) * (P + 2);
-        if constexpr (Model::NG == 0 && Model::NP == 0) { p += (p - smem) & 1; ocp.jtab = p; p += JViewRT<Model>::tab_doubles(ocp.dm.NN); }   // D~ tables of the condensed solve's sparse products
+        if constexpr (Model::NG == 0 && Model::NP == 0) { if (JViewRT<Model>::tab_worth_it(ocp.dm.NN)) { p += (p - smem) & 1; ocp.jtab = p; p += JViewRT<Model>::tab_doubles(ocp.dm.NN); } }   // D~ tables of the condensed solve's sparse products
         double* Wb = Kws + (size_t)b * (BigKkt::doubles(n + m) + big_scratch_doubles<Model>(P, S));
         double* hq = Wb + BigKkt::doubles(n + m);
         hq = v.carve(hq, n, m, mi);
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
     if constexpr (NN == 0 && KHBM) {
         for (int i = ln; i < (P + 1) * (P + 2); i += WAVE) ocp.Dlds[i] = ocp.s.D[i];
         wsync();
-        if constexpr (Model::NG == 0 && Model::NP == 0) JViewRT<Model>::build_tables(ocp.Dlds, P, ocp.dm.NN, ocp.jtab);
+        if constexpr (Model::NG == 0 && Model::NP == 0) { if (JViewRT<Model>::tab_worth_it(ocp.dm.NN)) JViewRT<Model>::build_tables(ocp.Dlds, P, ocp.dm.NN, ocp.jtab); }
     }
     double* sst = slice_state ? slice_state + (size_t)b * 2 * n : nullptr;   // [previous Lagrangian gradient | previous step]
     for (int i = ln; i < n; i += WAVE) {
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
     // stacked workspace K0 = [H ; J] ((n+m) x n, column-major, leading dimension n+m): lane i reads row i of K0 with ONE stride
     double* K0 = Hws + (size_t)b * (size_t)(n + m) * n;
     (void)Aws;
-    SqpDevice<Model, NN, MM, PROF, HU, KHBM, POL, CND ? -1 : 0> sqp(ocp, v, qw, K0, K0 + n, ss, qs);
+    SqpDevice<Model, NN, MM, PROF, HU, KHBM, POL, CND ? -1 : ((KHBM && W2) ? -2 : 0)> sqp(ocp, v, qw, K0, K0 + n, ss, qs);
     sqp.filt = filt;
     sqp.eig = eigw;
     sqp.trace = ss.iteration_trace ? ss.iteration_trace + (size_t)b * (size_t)ss.iteration_trace_capacity * PMPC_TRACE_DOUBLES : nullptr;
@@ -467,7 +467,7 @@ template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode
     size_t stage = OcpLds<Model>::doubles(P, S);
     if (mode == 1) { const size_t need = (size_t)RegKkt<64>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
     if (mode == 2)   // large instances: x, y, the right-hand side of the substitutions and the factorisation's diagonal tile; everything else in HBM
-        return (QpLds::doubles_xy(dm.n, dm.m) + (size_t)(dm.n + dm.m) + BigKkt::LDS_DOUBLES + (size_t)(P + 1) * (P + 2) + ((Model::NG == 0 && Model::NP == 0) ? JViewRT<Model>::tab_doubles(dm.NN) + 1 : 0) + (Model::ND > 0 ? Model::ND : 1) + FILTER_LDS_DOUBLES + 8) * sizeof(double);
+        return (QpLds::doubles_xy(dm.n, dm.m) + (size_t)(dm.n + dm.m) + BigKkt::LDS_DOUBLES + (size_t)(P + 1) * (P + 2) + ((Model::NG == 0 && Model::NP == 0 && JViewRT<Model>::tab_worth_it(dm.NN)) ? JViewRT<Model>::tab_doubles(dm.NN) + 1 : 0) + (Model::ND > 0 ? Model::ND : 1) + FILTER_LDS_DOUBLES + 8) * sizeof(double);
     if (mode == 3) { const size_t need = (size_t)RegKkt2<112>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
     if (mode == 4) { const size_t need = (size_t)RegKkt2<128>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }   // 113..128 rows: LDS-resident operand tiles
     return ((mode == 0 ? QpLds::doubles(dm.n, dm.m) : QpLds::doubles_xy(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8 +

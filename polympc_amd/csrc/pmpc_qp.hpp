@@ -632,7 +632,7 @@ __device__ __forceinline__ void kkt_solve_pivoted(const QpLds& w, int N, double*
 // large-instance linear algebra (pmpc_qp_big.hpp, included after this header by its users)
 __device__ __forceinline__ void big_build(double* W, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ A, int lda, const double* kdiag);
 __device__ __forceinline__ void big_factor(double* W, int N, double* dl);
-__device__ __forceinline__ void big_solve(const double* W, int N, double* v, double* bx);
+template <bool SLIM> __device__ __forceinline__ void big_solve(const double* W, int N, double* v, double* bx);
 
 // boxADMM::solve_impl (box_admm.hpp:88-205). Result in w.x (n) and w.y (m+n). h/Alb/Aub/xlb/xub may live in LDS or HBM.
 // H(i,j) = H[j*ldh + i], A(r,j) = A[j*lda + r]  (ldh = n, lda = m for plain column-major inputs)
@@ -683,7 +683,7 @@ __device__ __forceinline__ void qp_residuals_sparse(const QpLds& w, int n, int m
 
 struct NoJView {};   // tag: the QP has no structure information (the plain QP entry points)
 constexpr int BIG_COND_MAX_ROWS = 272;   // condensed mode: n and m up to this (the passes of its sparse products are unrolled; 4 x 16 ceil(n / 16) doubles of LDS hold a row panel)
-template <bool BIG = false, class JV = NoJView>
+template <bool BIG = false, class JV = NoJView, bool SLIM = false>   // SLIM: the two-wavefronts-per-SIMD build of the large-instance mode (see big_solve)
 __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* h,
                                      const double* __restrict__ A, int lda, const double* Alb, const double* Aub, const double* xlb,
                                      const double* xub, const double* x0, const double* y0, const pmpc_qp_settings& s,
@@ -777,7 +777,7 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
                       }
                       wsync();
                       const long long s0 = tick();
-                      big_solve(w.K, n, w.rhs, w.big_lds + 256);
+                      big_solve<SLIM>(w.K, n, w.rhs, w.big_lds + 256);
                       const long long s1 = tick();
                       if (tm) { tm[4] += s0 - t0; tm[5] += s1 - s0; }
                       for (int r0 = 0; r0 < m; r0 += WAVE) {
@@ -794,7 +794,7 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
                       done = true;
                   }
               }
-              if (!done) big_solve(w.K, N, w.rhs, w.big_lds + 256);
+              if (!done) big_solve<SLIM>(w.K, N, w.rhs, w.big_lds + 256);
           } else { if (pivoted) kkt_solve_pivoted(w, N, w.rhs); else kkt_solve(w, N, w.rhs); }
           if (tm) tm[2] += tick() - t0; }
         for (int i = ln; i < m; i += WAVE) {

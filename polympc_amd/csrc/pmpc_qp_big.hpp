@@ -371,6 +371,9 @@ __device__ __forceinline__ void big_factor(double* W, int N, double* dl) {
 }
 
 // v <- K^{-1} v, v in LDS (N entries; padding rows are not touched). bx: unused LDS slots.
+// SLIM: the build for TWO wavefronts per SIMD (256 registers, mid-size instances in batches above the SIMD count): two row slots per batch, no
+// look-ahead — the look-ahead below holds 64 + 128 + 16 more registers and made that build spill (the 21-node robot grid: 29.3 -> 32.5 ms per 2048).
+template <bool SLIM>
 __device__ __forceinline__ void big_solve(const double* W, int N, double* v, double* bx) {
     const int ln = lane_id();
     const int nb = BigKkt::nblk(N), NPAD = nb * 16;
@@ -379,51 +382,88 @@ __device__ __forceinline__ void big_solve(const double* W, int N, double* v, dou
 #ifndef PMPC_BIG_GS
 #define PMPC_BIG_GS 4
 #endif
-    constexpr int GS = PMPC_BIG_GS;   // row slots (of 64 rows) whose loads are issued together
-    // ---- forward: blocks ascending; inside a block columns ascending
-    size_t oF = 0;
-    for (int J = 0; J < nb; oF += BigKkt::sizeF(J, NPAD), ++J) {
+    constexpr int GS = SLIM ? 2 : PMPC_BIG_GS;   // row slots (of 64 rows) whose loads are issued together
+    // ---- forward: blocks ascending; inside a block columns ascending. No entry of L depends on the solution, only the fma chains do: the panel of a block
+    // column is requested BEFORE the triangular solve with its diagonal tile, and the diagonal tile of the next block column with it (two register sets,
+    // alternating: the block loop is unrolled by two so that neither set is ever copied) — a block step exposed two memory round trips, now the first
+    // one of the pass only.
+    const int r16 = ln & 15;
+    auto load_diag = [&](size_t o, double (&d)[16]) {
+        const double* p = LF + o;
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) { const big_d2 v2 = *reinterpret_cast<const big_d2*>(p + BigKkt::slab_pair(pp, r16)); d[2 * pp] = v2[0]; d[2 * pp + 1] = v2[1]; }
+    };
+    auto load_slots = [&](const double* pF, int J, int row0, double (&L)[GS][16]) {
+#pragma unroll
+        for (int g = 0; g < GS; ++g) {
+            const int row = row0 + g * WAVE + ln;
+            const int rw = (row < NPAD) ? row : NPAD - 1;
+#pragma unroll
+            for (int pp = 0; pp < 8; ++pp) { const big_d2 v2 = *reinterpret_cast<const big_d2*>(pF + BigKkt::slab_pair(pp, rw - 16 * J)); L[g][2 * pp] = v2[0]; L[g][2 * pp + 1] = v2[1]; }
+        }
+    };
+    auto fwd_block = [&](int J, size_t oF, const double (&lrow)[16], double (&lnext)[16]) {
         const double* pF = LF + oF;
+        double L[GS][16];
+        if constexpr (!SLIM) {
+            load_slots(pF, J, 16 * (J + 1), L);                                               // (a block column without rows below re-reads its last row: dropped)
+            load_diag((J + 1 < nb) ? oF + BigKkt::sizeF(J, NPAD) : oF, lnext);                 // (the last block column re-reads its own tile: never used)
+            sched_fence();
+        }
         double xj[16];
         {   // finish x_J on 16 lanes (unit-lower triangular solve with the diagonal tile), then broadcast its 16 entries
-            const int r = ln & 15;
-            const int row = 16 * J + r;
-            double lrow[16];
-#pragma unroll
-            for (int pp = 0; pp < 8; ++pp) { const big_d2 v2 = *reinterpret_cast<const big_d2*>(pF + BigKkt::slab_pair(pp, r)); lrow[2 * pp] = v2[0]; lrow[2 * pp + 1] = v2[1]; }
+            const int row = 16 * J + r16;
             double xr = (row < N) ? v[row] : 0.0;
 #pragma unroll
             for (int c = 0; c < 15; ++c) {
                 const double xc = bcast_lane(xr, c);
                 const double up = fma(-lrow[c], xc, xr);
-                xr = (r > c) ? up : xr;
+                xr = (r16 > c) ? up : xr;
             }
             if (ln < 16 && row < N) v[row] = xr;
 #pragma unroll
             for (int c = 0; c < 16; ++c) xj[c] = bcast_lane(xr, c);
+            asm volatile("" :: "v"(lrow[15]));   // (the unit diagonal is never read: without a use its register — the target of a 16-byte load — is handed out again while the load is in flight, and that write waits for EVERY load)
         }
         for (int row0 = 16 * (J + 1); row0 < NPAD; row0 += GS * WAVE) {
-            double L[GS][16], vi[GS];
+            if (SLIM || row0 != 16 * (J + 1)) load_slots(pF, J, row0, L);
 #pragma unroll
             for (int g = 0; g < GS; ++g) {
                 const int row = row0 + g * WAVE + ln;
-                const int rw = (row < NPAD) ? row : NPAD - 1;
+                double vi = (row < N) ? v[row] : 0.0;
 #pragma unroll
-                for (int pp = 0; pp < 8; ++pp) { const big_d2 v2 = *reinterpret_cast<const big_d2*>(pF + BigKkt::slab_pair(pp, rw - 16 * J)); L[g][2 * pp] = v2[0]; L[g][2 * pp + 1] = v2[1]; }
-                vi[g] = (row < N) ? v[row] : 0.0;
-            }
-#pragma unroll
-            for (int g = 0; g < GS; ++g) {
-                const int row = row0 + g * WAVE + ln;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) vi[g] = fma(-L[g][c], xj[c], vi[g]);
-                if (row < N) v[row] = vi[g];
+                for (int c = 0; c < 16; ++c) vi = fma(-L[g][c], xj[c], vi);
+                if (row < N) v[row] = vi;
             }
         }
         wsync();
+    };
+    constexpr int DG = SLIM ? 0 : 8;
+    double dg[DG > 0 ? DG : 1];   // d_i of the rows 64 t + lane: four to eight loads whose round trips used to sit, one after the other, between the two passes
+#pragma unroll
+    for (int t = 0; t < DG; ++t) {
+        const int i = 64 * t + ln;
+        const int ic = (i < N) ? i : 0;
+        dg[t] = LF[BigKkt::offF(ic >> 4, NPAD) + BigKkt::slab(ic & 15, ic & 15)];
     }
-    // ---- diagonal
-    for (int i = ln; i < N; i += WAVE) {
+    {
+        double dA[16], dB[16];
+        load_diag(0, dA);
+        size_t oF = 0;
+        if constexpr (SLIM) {
+            for (int J = 0; J < nb; ++J) { if (J > 0) load_diag(oF, dA); fwd_block(J, oF, dA, dB); oF += BigKkt::sizeF(J, NPAD); }
+        } else {
+            for (int J = 0; J < nb; J += 2) {
+                fwd_block(J, oF, dA, dB);
+                oF += BigKkt::sizeF(J, NPAD);
+                if (J + 1 < nb) { fwd_block(J + 1, oF, dB, dA); oF += BigKkt::sizeF(J + 1, NPAD); }
+            }
+        }
+    }
+    // ---- diagonal (the first 512 entries were requested before the forward pass)
+#pragma unroll
+    for (int t = 0; t < DG; ++t) { const int i = 64 * t + ln; if (i < N) v[i] = v[i] / dg[t]; }
+    for (int i = 64 * DG + ln; i < N; i += WAVE) {
         const int I = i >> 4, r = i & 15;
         v[i] = v[i] / LF[BigKkt::offF(I, NPAD) + BigKkt::slab(r, r)];
     }
@@ -432,7 +472,10 @@ __device__ __forceinline__ void big_solve(const double* W, int N, double* v, dou
     // the rows below the block are column dot products — every lane keeps one partial sum per column over its rows (row 16(J+1) + 64 g + lane,
     // g ascending, fma); the 64 partials of a column are added in four groups of 16 (lane (c, k) adds group k of column c in index order), the
     // group sums as (S0 + S1) + (S2 + S3) — subtracted once; then the block's own triangle, columns descending. (CPU restatement: PIVOT_BLOCKED.)
-    constexpr int GB = 2;     // row slots in flight (16 running sums per lane on top of the loaded entries)
+#ifndef PMPC_BIG_GB
+#define PMPC_BIG_GB 4
+#endif
+    constexpr int GB = SLIM ? 2 : PMPC_BIG_GB;     // row slots in flight (16 running sums per lane on top of the loaded entries; 4: one batch per block column up to 272 rows)
     double* red = bx + 16;    // 16 x 64 partial sums, column stride 65 (conflict-free for the column-parallel group sums)
     double* grp = red + 16 * 65; // 4 x 16 group sums
     size_t oFb = BigKkt::offF(nb, NPAD);
@@ -442,6 +485,12 @@ __device__ __forceinline__ void big_solve(const double* W, int N, double* v, dou
         double acc[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) acc[c] = 0.0;
+        const int r = ln & 15, kq = ln >> 4;
+        double lcol[16];   // column r of the diagonal tile: L(16J + c, 16J + r), c = 0..15 — requested here, used behind the column sums (it depends on nothing)
+        if constexpr (!SLIM) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) lcol[c] = pF[BigKkt::slab(r, c)];
+        }
         for (int row0 = 16 * (J + 1); row0 < NPAD; row0 += GB * WAVE) {
             double L[GB][16], xr[GB];
 #pragma unroll
@@ -460,7 +509,6 @@ __device__ __forceinline__ void big_solve(const double* W, int N, double* v, dou
 #pragma unroll
         for (int c = 0; c < 16; ++c) red[c * 65 + ln] = acc[c];
         wsync();
-        const int r = ln & 15, kq = ln >> 4;
         {
             double t[16], a = 0.0;
 #pragma unroll
@@ -473,9 +521,10 @@ __device__ __forceinline__ void big_solve(const double* W, int N, double* v, dou
         {
             const int row = 16 * J + r;
             const double sum = (grp[r] + grp[16 + r]) + (grp[32 + r] + grp[48 + r]);
-            double lcol[16];   // column r of the diagonal tile: L(16J + c, 16J + r), c = 0..15 — contiguous in the column panel
+            if constexpr (SLIM) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) lcol[c] = pF[BigKkt::slab(r, c)];
+                for (int c = 0; c < 16; ++c) lcol[c] = pF[BigKkt::slab(r, c)];
+            }
             double xr = (row < N) ? v[row] : 0.0;
             xr = xr - sum;
 #pragma unroll

@@ -57,6 +57,7 @@ constexpr int PMPC_SQP_IN_PROGRESS = 3;   // internal: the instance continues in
 template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bool BIG = false, bool POL = false, int PS = 0>
 struct SqpDevice {
     static constexpr bool SCH = PS > 0;
+    static constexpr bool SLIM = PS == -2;   // large-instance mode compiled for two wavefronts per SIMD (256 registers)
     static constexpr bool CND = PS == -1;   // condensed register QP (pmpc_qp_cond.hpp): a two-rows-per-lane kernel (REG2) whose QP inverts S = H + sigma I + rho_box + A' diag(rho) A only
     static constexpr int SCH_P = PS / 256, SCH_S = PS % 256;
     static constexpr bool HOOKS = (NN == 0) || POL;
@@ -955,7 +956,7 @@ struct SqpDevice {
                     // large instances: condensed linear algebra from the block-sparse view of J (n instead of n + m rows) — unless the Ruiz preconditioner
                     // rescaled the workspace, whose entries the per-node blocks of the view then no longer are
                     const JViewRT<Model> jvr{ocp.Dlds, ocp.s.nsr, ocp.jblk, ocp.gblk, ocp.P, ocp.dm.NN, ocp.dm.VARX, ocp.dm.VARU, ocp.dm.me, ocp.jtab};
-                    boxadmm_solve<true, JViewRT<Model>>(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, PROF ? tq : nullptr, jvr,
+                    boxadmm_solve<true, JViewRT<Model>, SLIM>(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, PROF ? tq : nullptr, jvr,
                                                         ocp.keep_blk && !ruiz && n <= BIG_COND_MAX_ROWS && m <= BIG_COND_MAX_ROWS && __builtin_amdgcn_readfirstlane(ss.kkt_form) == 0);
                 } else
                 boxadmm_solve<BIG>(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, PROF ? tq : nullptr);

@@ -97,3 +97,29 @@ def test_block_structured_kernels_do_not_spill_inside_the_swept_inverse():
                 assert not inside, f"{head}: {len(inside)} scratch instructions inside the swept inverse"
                 checked += 1
     assert checked >= 4
+
+
+@pytest.mark.skipif(not (os.path.exists(f"{LLVM}/clang-offload-bundler") and os.path.exists(f"{LLVM}/llvm-objdump")), reason="ROCm binutils not installed")
+def test_headline_kernel_has_no_scratch_and_condensed_kernels_none_in_the_admm_loop():
+    """Two properties of the built code that cost a measurable share of a benchmark line when they break (compiler hazards 4 and 11): the
+    headline kernel sqp_kernel<RobotOCP, 35, 21> has NO scratch traffic at all (round 4: the register-row BFGS spilled the head of the row of B behind its
+    loads — 1.18 instead of 1.13 ms per 4096), and the condensed register kernels (CND = true: config B, the 16-node robot grid) have none between the first
+    and the last DPP mat-vec instruction, i.e. inside the ADMM loop."""
+    headline = cond = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for co in _code_objects(tmp):
+            dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
+            for blk in re.split(r"\n(?=[0-9a-f]+ <)", dis):
+                head = blk.split("\n", 1)[0]
+                if "sqp_kernelINS_8RobotOCPELi35ELi21ELb0ELi0ELb0ELb0ELb0ELb0E" in head:
+                    n = sum("scratch_" in l for l in blk.split("\n"))
+                    assert n == 0, f"{head}: {n} scratch instructions in the headline kernel"
+                    headline += 1
+                elif re.search(r"sqp_kernelINS_\d+\w+?ELi\d+ELi\d+ELb0ELi0ELb0ELb0ELb0ELb1E", head):
+                    lines = blk.split("\n")
+                    dpp = [i for i, l in enumerate(lines) if "row_newbcast" in l]
+                    assert dpp, head
+                    inside = [l for l in lines[dpp[0]:dpp[-1]] if "scratch_" in l]
+                    assert not inside, f"{head}: {len(inside)} scratch instructions inside the ADMM loop"
+                    cond += 1
+    assert headline == 1 and cond >= 2, (headline, cond)

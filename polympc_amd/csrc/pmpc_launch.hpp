@@ -551,9 +551,10 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
     constexpr int NN_ = (Model::NX + Model::NU) * NNODES + Model::NP;
     constexpr int MM_ = (Model::NX + Model::NG) * NNODES;
     // the policy hooks the reference's tests install beside the defaults — Ruiz preconditioner, filter line search — exist on the register paths
-    // for the grids of its own tests (7 and 11 nodes) as separate kernels (POL); any other grid takes the LDS / HBM-resident kernels for them
+    // for the grids of its own tests (7, 11 and — where the model fits 128 rows — 16 nodes) as separate kernels (POL); any other grid takes the LDS /
+    // HBM-resident kernels for them
     const bool pol = ss->preconditioner == 1 || ss->line_search == 1;
-    constexpr bool POLK = !LEAN && (NNODES == 7 || NNODES == 11) && (int)OcpDims<Model>::NDER <= RUIZ_MAX_NDER;
+    constexpr bool POLK = ((!LEAN && (NNODES == 7 || NNODES == 11)) || NNODES == 16) && (int)OcpDims<Model>::NDER <= RUIZ_MAX_NDER;   // (16 nodes: the reference's mpc_wrapper_test grid, round 4)
     if (pol && !POLK) return false;
     if constexpr (NN_ + MM_ <= WAVE) {
         if (P * S + 1 != NNODES) return false;

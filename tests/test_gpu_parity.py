@@ -83,13 +83,13 @@ def _gpu_order(oracle, n, m, nodes=None, block_bfgs=False, kkt_form=0, schur=Fal
     return _lds_order(oracle, n + m, kkt_form=kkt_form)
 
 
-POLICY_REG_NODE_COUNTS = (7, 11)   # grids whose register-resident kernels exist with the Ruiz / filter-line-search hooks compiled in (pmpc_launch.hpp, POL)
+POLICY_REG_NODE_COUNTS = (7, 11)   # grids whose register-resident kernels exist with the Ruiz / filter-line-search hooks compiled in (pmpc_launch.hpp, POL); since round 4 also the 16-node grid where it has 128 rows
 
 
 def _policy_order(oracle, n, m, nodes, ruiz=False, block_bfgs=False, kkt_form=0):
     """preconditioner = 1 / line_search = 1: on the grids of the reference's own tests (7 and 11 nodes) the register-resident kernels carry these hooks
     since round 3 (their sweep orders); every other grid takes the LDS / HBM-resident kernels for them."""
-    if nodes in POLICY_REG_NODE_COUNTS and n + m <= 112:
+    if (nodes in POLICY_REG_NODE_COUNTS and n + m <= 112) or (nodes == 16 and n + m <= 128):   # (16 nodes, round 4: the reference's mpc_wrapper_test grid)
         return oracle.PIVOT_SWEEP if n + m <= 64 else oracle.PIVOT_SWEEP2
     return _lds_order(oracle, n + m, ruiz=ruiz, kkt_form=kkt_form)
 
@@ -722,12 +722,12 @@ def test_sqp_valet_parking_as_the_reference_runs_it(ctx, oracle):
 
 
 def test_sqp_filter_line_search_batch_vs_oracle(ctx, oracle):
-    """line_search = 1 on batches of randomised robot OCPs (P=5 S=3: 128 KKT rows, HBM-factor kernel; config A's grid and the 11-node grid on the register-resident kernels that carry the hook since round 3), with and
+    """line_search = 1 on batches of randomised robot OCPs (P=5 S=3: 128 KKT rows — since round 4 on the two-rows-per-lane register kernel with the hooks; P=5 S=4: 168 rows, HBM-factor kernel; config A's grid and the 11-node grid on the register-resident kernels that carry the hook since round 3), with and
     without a carried filter: identical iteration counts, bit-identical x, lam and filter contents; a second solve from the
     first one's solution with the carried filter must again agree (the filter then holds the first solve's history)."""
     import polympc_amd as pa
     from polympc_amd import workloads
-    for P, S, B in ((5, 3, 6), (6, 1, 32)):
+    for P, S, B in ((5, 3, 6), (5, 4, 4), (6, 1, 32)):
         wl = workloads.robot_batch(B, P=P, S=S)
         ss = pa.sqp_settings_default(); oss = oracle.sqp_default_settings()
         for st in (ss, oss):
@@ -1286,7 +1286,9 @@ def test_last_route_reports_the_kernel_family(ctx):
     assert route(workloads.robot_batch(4, P=4, S=2), preconditioner=1) == pa.capi.ROUTE_LDS
     assert route(workloads.robot_batch(4, P=5, S=3)) == pa.capi.ROUTE_CONDREG
     assert route(workloads.robot_batch(4, P=5, S=3), kkt_form=1) == pa.capi.ROUTE_REG2
-    assert route(workloads.robot_batch(4, P=5, S=3), line_search=1) == pa.capi.ROUTE_HBM
+    assert route(workloads.robot_batch(4, P=5, S=3), line_search=1) == pa.capi.ROUTE_REG2                # round 4: the policy hooks on the 16-node register kernel (full inverse)
+    assert route(workloads.robot_batch(4, P=5, S=3), preconditioner=1) == pa.capi.ROUTE_REG2
+    assert route(workloads.robot_batch(4, P=5, S=4), line_search=1) == pa.capi.ROUTE_HBM
     assert route(workloads.kite_standin_batch(2)) == pa.capi.ROUTE_HBM
 
 

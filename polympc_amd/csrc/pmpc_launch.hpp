@@ -53,7 +53,10 @@ template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bo
 #ifndef PMPC_BIG_WAVES
 #define PMPC_BIG_WAVES 1
 #endif
-__global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : ((KHBM && W2) ? 2 : (KHBM ? PMPC_BIG_WAVES : 1)))) void sqp_kernel(Model model, const ChebData* __restrict__ cd, int B,
+#ifndef PMPC_COND1_WAVES
+#define PMPC_COND1_WAVES 1   /* condensed register kernel on at most 64 variables: wavefronts per SIMD — measured on the 11-node robot grid: two wavefronts (256 registers: 240 spilled values, eight scratch accesses in the ADMM loop) 2.82 ms per 4096, one wavefront 2.67 (the full inverse: 4.04) */
+#endif
+__global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : ((NN > 0 && CND && NN <= 64) ? PMPC_COND1_WAVES : ((KHBM && W2) ? 2 : (KHBM ? PMPC_BIG_WAVES : 1))))) void sqp_kernel(Model model, const ChebData* __restrict__ cd, int B,
                                                  const double* __restrict__ x_guess, const double* __restrict__ lam_guess,
                                                  const double* __restrict__ d, const double* __restrict__ lbx,
                                                  const double* __restrict__ ubx, const double* __restrict__ lbg,
@@ -98,7 +101,8 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
         p = v.carve(p, n, m, mi);
         stage0 = p;
         p = ocp.s.carve(p, P, S);
-        if (NN > 0 && (size_t)(p - stage0) < (size_t)reg_qp_staging<NN + MM>() + 2 + ocp.s.const_doubles(P, S)) p = stage0 + reg_qp_staging<NN + MM>() + 2 + ocp.s.const_doubles(P, S);
+        constexpr int QP_STAGING = (CND && NN <= WAVE) ? reg_qp_staging<(CND && NN <= WAVE) ? NN : 1>() : reg_qp_staging<NN + MM>();   // (condensed register QP on at most 64 variables: the one-row-per-lane tile set)
+        if (NN > 0 && (size_t)(p - stage0) < (size_t)QP_STAGING + 2 + ocp.s.const_doubles(P, S)) p = stage0 + QP_STAGING + 2 + ocp.s.const_doubles(P, S);
         stage_end = p;   // end of the per-node staging block: what follows (static parameters, filter) stays live during the line search
     }
     if constexpr (NN > 0 && NN + MM > WAVE) {   // block-sparse copy of J (pmpc_jview.hpp) for the two-rows-per-lane kernels: lives through the QP, behind the staging its LDS buffers alias
@@ -469,9 +473,10 @@ template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode
     if (mode == 2)   // large instances: x, y, the right-hand side of the substitutions and the factorisation's diagonal tile; everything else in HBM
         return (QpLds::doubles_xy(dm.n, dm.m) + (size_t)(dm.n + dm.m) + BigKkt::LDS_DOUBLES + (size_t)(P + 1) * (P + 2) + ((Model::NG == 0 && Model::NP == 0 && JViewRT<Model>::tab_worth_it(dm.NN)) ? JViewRT<Model>::tab_doubles(dm.NN) + 1 : 0) + (Model::ND > 0 ? Model::ND : 1) + FILTER_LDS_DOUBLES + 8) * sizeof(double);
     if (mode == 3) { const size_t need = (size_t)RegKkt2<112>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
+    if (mode == 5) { const size_t need = (size_t)RegKkt<64>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }   // condensed register QP on at most 64 variables (65..128 KKT rows)
     if (mode == 4) { const size_t need = (size_t)RegKkt2<128>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }   // 113..128 rows: LDS-resident operand tiles
     return ((mode == 0 ? QpLds::doubles(dm.n, dm.m) : QpLds::doubles_xy(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8 +
-            ((mode == 1 || mode == 3 || mode == 4) ? (mode == 1 ? 0 : jview_doubles<Model>(dm.NN)) + (pol ? FILTER_LDS_DOUBLES : 0) : FILTER_LDS_DOUBLES) + (mode == 2 ? BigKkt::LDS_DOUBLES : 0)) * sizeof(double);
+            ((mode == 1 || mode == 3 || mode == 4 || mode == 5) ? (mode == 1 ? 0 : jview_doubles<Model>(dm.NN)) + (pol ? FILTER_LDS_DOUBLES : 0) : FILTER_LDS_DOUBLES) + (mode == 2 ? BigKkt::LDS_DOUBLES : 0)) * sizeof(double);
 }
 constexpr int BIG_TWO_WAVES_MAX_ROWS = 200;   // below: two wavefronts per SIMD on the HBM-factor kernel when the batch exceeds the SIMD count (see sqp_launch_dev)
 constexpr int BIG_KKT_MIN_ROWS = 96;   // n + m from which sqp_launch_dev prefers the HBM-factor kernel (see there)
@@ -539,7 +544,7 @@ template <> struct LDS_PATH_PROFILED<CstrOCP> { static constexpr bool value = tr
 template <> struct LDS_PATH_PROFILED<KiteStandInOCP> { static constexpr bool value = true; };
 
 // Launch the fused SQP kernel for `Model` on DEVICE buffers (asynchronous on the context's stream).
-template <class Model, int NN_, int MM_> struct COND_REG_OK { static constexpr bool value = NN_ > WAVE && NN_ <= 112 && MM_ > 0 && MM_ <= WAVE && Model::NP == 0 && Model::NG == 0; };
+template <class Model, int NN_, int MM_> struct COND_REG_OK { static constexpr bool value = NN_ + MM_ > WAVE && NN_ <= 112 && MM_ > 0 && MM_ <= WAVE && Model::NP == 0 && Model::NG == 0; };
 // Register-resident QP specialisations are selected from the compile-time model dimensions and the runtime node count
 // when the KKT system has at most 64 rows; otherwise the LDS-resident path is used.
 template <class Model, int NNODES, bool LEAN = false>   // LEAN: no phase-timer and no block-BFGS specialisation (pmpc_grids.hpp: those requests take the LDS-resident kernel)
@@ -607,18 +612,20 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
         if constexpr (LDS_PATH_PROFILED<Model>::value && !LEAN) { if (phase && !pol) { kern = sqp_kernel<Model, NN_, MM_, true>; timed = true; } }   // developer builds with phase timers
         if constexpr (POLK) { if (pol) kern = sqp_kernel<Model, NN_, MM_, false, 0, false, false, true>; }
         // condensed register QP (pmpc_qp_cond.hpp): 65..112 variables, at most 64 constraint rows, the default policies; kkt_form = 1 keeps the full inverse
+        size_t ldsq = ldsr;
         if constexpr (COND_REG_OK<Model, NN_, MM_>::value) {
             if (!pol && ss->kkt_form == 0 && !getenv("PMPC_NO_CONDREG")) {
+                if constexpr (NN_ <= WAVE) ldsq = sqp_kernel_lds_bytes<Model>(P, S, 5, 0, false);   // (two wavefronts per SIMD: a smaller staging lets more instances share a CU)
                 kern = sqp_kernel<Model, NN_, MM_, false, 0, false, false, false, true>; timed = false;
                 if constexpr (LDS_PATH_PROFILED<Model>::value && !LEAN) { if (phase) { kern = sqp_kernel<Model, NN_, MM_, true, 0, false, false, false, true>; timed = true; } }
                 pmpc_internal_set_route(ctx, PMPC_ROUTE_CONDREG);
             }
         }
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
         const int slice = (slice_state && slice_iters > 0) ? slice_iters : ss->max_iter;
         for (int it = 0; it < ss->max_iter; it += slice)
-            hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), ldsr, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
-                               *ss, *qs, Hws, Aws, x, lam, info, timed ? phase : (unsigned long long*)nullptr, (double*)nullptr, it, it + slice, slice_state, (unsigned)(ldsr / sizeof(double)));
+            hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), ldsq, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
+                               *ss, *qs, Hws, Aws, x, lam, info, timed ? phase : (unsigned long long*)nullptr, (double*)nullptr, it, it + slice, slice_state, (unsigned)(ldsq / sizeof(double)));
         *st = (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
         return true;
     } else {

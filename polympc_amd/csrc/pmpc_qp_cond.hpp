@@ -27,17 +27,24 @@ namespace pmpc {
 #endif
 // the swept inverse of S: the two-rows-per-lane tile set with PMPC_COND_NV of its operand tiles in arch VGPRs (25 tiles at 66..80 rows: the rest lives
 // in the accumulation file and costs two v_accvgpr_read per entry and ADMM iteration)
-template <int NN> using CondKkt = RegKkt2<NN, PMPC_COND_NV>;
+template <int NN, bool SMALL = (NN <= WAVE)> struct CondKktSel { using type = RegKkt2<NN, PMPC_COND_NV>; };
+// at most 64 variables — grids of 65..128 KKT rows whose primal block fits one row per lane: the one-row-per-lane tile set of pmpc_qp_reg.hpp (16 tiles
+// = 128 registers, a register-only DPP mat-vec), and the kernel is compiled for TWO wavefronts per SIMD
+template <int NN> struct CondKktSel<NN, true> { using type = RegKkt<NN>; };
+template <int NN> using CondKkt = typename CondKktSel<NN>::type;
 
 // LDS the solver needs beside the staging of CondKkt<NN>: nothing — the exchange vectors alias the staging (free between factorisations)
 template <int NN, int MM>
 struct CondDims {
-    static_assert(NN > WAVE && NN <= 128 && MM > 0 && MM <= WAVE, "condensed register QP: 65..128 variables, at most 64 constraint rows");
+    static_assert(NN > 0 && NN <= 128 && MM > 0 && MM <= WAVE && NN + MM > WAVE, "condensed register QP: at most 128 variables and 64 constraint rows, more than 64 KKT rows");
     static constexpr int N = NN + MM;
-    static constexpr int US_OFF = CondKkt<NN>::RHS_OFF + 128;     // rho o r2 / y (MM entries) behind the rhs exchange buffer of RegKkt2::apply
+    static constexpr bool SMALL = NN <= WAVE;
+    static constexpr int SL = SMALL ? 1 : 2;                      // primal slots per lane
+    static constexpr int RHS_OFF = []() constexpr { if constexpr (NN <= WAVE) return 0; else return (int)RegKkt2<NN, PMPC_COND_NV>::RHS_OFF; }();
+    static constexpr int US_OFF = RHS_OFF + 128;                  // rho o r2 / y (MM entries) behind the rhs exchange buffer of RegKkt2::apply
     static constexpr int XS_OFF = US_OFF + 64;                    // x (NN entries)
     static constexpr int PB_OFF = XS_OFF + 128;                   // residual evaluation: products of the few primal rows of the second slot
-    static constexpr int TAB_OFF = PB_OFF + 4 * NN;               // D~ tables of the sparse products (cond_build_tables), rebuilt at every QP
+    static constexpr int TAB_OFF = PB_OFF + (SMALL ? 0 : 4 * NN); // D~ tables of the sparse products (cond_build_tables), rebuilt at every QP
     template <int NNODES> static constexpr int nnp() { return NNODES + (NNODES & 1); }
     template <int NNODES> static constexpr int tab_doubles() { return (4 * NNODES + 1) * nnp<NNODES>(); }
 };
@@ -82,13 +89,14 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                                                    const double* xub, const pmpc_qp_settings& s, pmpc_qp_info& info, double* out_x, double* out_y, double* tr,
                                                    const JV& jv, long long* dbg = nullptr, long long* tm = nullptr) {
     using CD = CondDims<NN, MM>;
-    constexpr int N = CD::N;
+    constexpr int N = CD::N, SL = CD::SL;
+    constexpr bool SMALL = CD::SMALL;
     const int ln = lane_id();
     // primal slot e: variable lane + 64 e; constraint row: lane (lanes [0, MM))
-    bool isP[2]; int lp[2];
-    double hv[2], lo[2], hi[2]; int typ[2];
+    bool isP[2] = {false, false}; int lp[2] = {0, 0};
+    double hv[2] = {0.0, 0.0}, lo[2] = {0.0, 0.0}, hi[2] = {0.0, 0.0}; int typ[2] = {0, 0};
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < SL; ++e) {
         const int idx = ln + 64 * e;
         isP[e] = idx < NN; lp[e] = isP[e] ? idx : 0;
         hv[e] = isP[e] ? h[lp[e]] : 0.0;
@@ -124,9 +132,9 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
     double xv[2] = {0.0, 0.0}, qv[2] = {0.0, 0.0}, yb[2] = {0.0, 0.0}, zv = 0.0, ya = 0.0;
     double rho = s.rho;
     int rho_updates = 1;
-    double rhob[2], rhobinv[2], kd[2];
+    double rhob[2] = {1.0, 1.0}, rhobinv[2] = {1.0, 1.0}, kd[2] = {0.0, 0.0};
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < SL; ++e) {
         rhob[e] = rho_of(typ[e], rho);
         rhobinv[e] = 1.0 / rhob[e];
         double d = H[(size_t)lp[e] * N + lp[e]]; d += s.sigma; d += rhob[e];
@@ -147,9 +155,9 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
     double* Dt = tr + CD::TAB_OFF;
     static_assert(CD::TAB_OFF + CD::template tab_doubles<NNODES>() <= CondKkt<NN>::TRI, "tables fit the staging");
     const double* DtT = Dt + NNODES * NNP;
-    const double *cD[2], *cU[2], *cB[2], *cV[2];   // per primal slot: D~ column, u at the column's state index, own-node block column, u of the own node
+    const double *cD[2] = {nullptr, nullptr}, *cU[2] = {nullptr, nullptr}, *cB[2] = {nullptr, nullptr}, *cV[2] = {nullptr, nullptr};   // per primal slot: D~ column, u at the column's state index, own-node block column, u of the own node
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < SL; ++e) {
         const int c = lp[e];
         const bool xcol = c < VARX;
         const int cu = c - VARX;
@@ -167,14 +175,19 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
     const double* rV = xs + rk * NX;
     const double* rW = xs + VARX + rk * NU;
     constexpr bool SLOT1_STATES = VARX > 64;       // state columns in the second slot?
+    constexpr int CH = SMALL ? 4 : NNODES;         // D~ entries per batch of LDS reads in the two products
     auto coldot_fma = [&](int e, double init) -> double {
         double a = init;
         if (e == 0 || SLOT1_STATES) {
-            double dv[NNODES], uv[NNODES];
 #pragma unroll
-            for (int k = 0; k < NNODES; ++k) { dv[k] = cD[e][k]; uv[k] = cU[e][k * NX]; }
+            for (int k0 = 0; k0 < NNODES; k0 += CH) {   // (CH entries per batch of LDS reads: the 256-register build has no room for all of them at once)
+                double dv[CH], uv[CH];
 #pragma unroll
-            for (int k = 0; k < NNODES; ++k) a = fma(dv[k], uv[k], a);
+                for (int k = 0; k < CH; ++k) { const int kk = (k0 + k < NNODES) ? k0 + k : 0; dv[k] = cD[e][kk]; uv[k] = cU[e][kk * NX]; }
+#pragma unroll
+                for (int k = 0; k < CH; ++k) if (k0 + k < NNODES) a = fma(dv[k], uv[k], a);
+                if constexpr (CH < NNODES) sched_fence();
+            }
         }
         double bv[NX], vv[NX];
 #pragma unroll
@@ -185,15 +198,20 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
     };
     auto rowdot_fma = [&]() -> double {
         double a = 0.0;
-        double dv[NNODES], xq[NNODES], bv[NDER], xb[NDER];
 #pragma unroll
-        for (int j = 0; j < NNODES; ++j) { dv[j] = rD[j]; xq[j] = rX[j * NX]; }
+        for (int j0 = 0; j0 < NNODES; j0 += CH) {
+            double dv[CH], xq[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { const int jj = (j0 + j < NNODES) ? j0 + j : 0; dv[j] = rD[jj]; xq[j] = rX[jj * NX]; }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) if (j0 + j < NNODES) a = fma(dv[j], xq[j], a);
+            if constexpr (CH < NNODES) sched_fence();
+        }
+        double bv[NDER], xb[NDER];
 #pragma unroll
         for (int i = 0; i < NX; ++i) { bv[i] = rB[i]; xb[i] = rV[i]; }
 #pragma unroll
         for (int i = 0; i < NU; ++i) { bv[NX + i] = rB[NX + i]; xb[NX + i] = rW[i]; }
-#pragma unroll
-        for (int j = 0; j < NNODES; ++j) a = fma(dv[j], xq[j], a);
 #pragma unroll
         for (int i = 0; i < NDER; ++i) a = fma(bv[i], xb[i], a);
         return a;
@@ -208,11 +226,19 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
         {   // construct_kkt_matrix + factorise_kkt_matrix (box_admm.hpp:209-223, :336-341) in condensed form
             const long long f0 = dbg ? clock64() : 0;
             const double rc_now = rhoc;
-            K.invert(ln, tr, kd[0], kd[1], [&](int j, int e, int z) -> double { return Hlow(j < NN ? j : 0, e, z); }, tm,
-                     [&](CondKkt<NN>& Kr, double* PA, double* PB, int l, int lr, int lc) {
-                         Kr.template rank_update<MM>(l, lr, lc, PA, PB, [&](int j, int e, int z) -> double { return Acol(j, e, z); },
-                                                     [&](int j) -> double { return bcast_lane(rc_now, j); });
-                     });
+            if constexpr (SMALL) {
+                K.invert(ln, tr, kd[0], [&](int j, int z) -> double { return Hlow(j < NN ? j : 0, 0, z); }, tm, 0.0,
+                         [&](typename CondKkt<NN>::d4 (&T)[CondKkt<NN>::NT][CondKkt<NN>::NT], double* PA, double* PB, int l, int lr, int lc) {
+                             CondKkt<NN>::template rank_update<MM>(T, l, lr, lc, PA, PB, [&](int j, int z) -> double { return Acol(j, 0, z); },
+                                                                   [&](int j) -> double { return bcast_lane(rc_now, j); });
+                         });
+            } else {
+                K.invert(ln, tr, kd[0], kd[1], [&](int j, int e, int z) -> double { return Hlow(j < NN ? j : 0, e, z); }, tm,
+                         [&](CondKkt<NN>& Kr, double* PA, double* PB, int l, int lr, int lc) {
+                             Kr.template rank_update<MM>(l, lr, lc, PA, PB, [&](int j, int e, int z) -> double { return Acol(j, e, z); },
+                                                         [&](int j) -> double { return bcast_lane(rc_now, j); });
+                         });
+            }
             cond_build_tables<NNODES>(jv.D, jv.P, Dt);   // (the staging they live in was the sweep's)
             if (dbg) dbg[0] += clock64() - f0;
         }
@@ -226,17 +252,21 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                 const double r2 = zv - rhocinv * ya;                       // compute_kkt_rhs, box_admm.hpp:351-355
                 if (isC) us[rc] = rhoc * r2;
                 lds_order();
-                double t[2], sol[2];
+                double t[2] = {0.0, 0.0}, sol[2] = {0.0, 0.0};
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const double rhs1 = ((s.sigma * xv[e] - hv[e]) + rhob[e] * qv[e]) - yb[e];
+                for (int e = 0; e < SL; ++e) {
+                    // (two wavefronts per SIMD, 256 registers: h and the bounds are re-read from their LDS vectors — kept in registers they were spilled, and
+                    //  six scratch reloads per ADMM iteration cost more than six LDS reads)
+                    const double hve = SMALL ? (isP[e] ? h[lp[e]] : 0.0) : hv[e];
+                    const double rhs1 = ((s.sigma * xv[e] - hve) + rhob[e] * qv[e]) - yb[e];
                     const double a = coldot_fma(e, rhs1);
                     t[e] = isP[e] ? a : 0.0;
                 }
                 lds_order();
-                K.apply(t[0], t[1], tr, ln, sol[0], sol[1]);
+                if constexpr (SMALL) sol[0] = K.apply(t[0]);
+                else K.apply(t[0], t[1], tr, ln, sol[0], sol[1]);
 #pragma unroll
-                for (int e = 0; e < 2; ++e) if (isP[e]) xs[lp[e]] = sol[e];
+                for (int e = 0; e < SL; ++e) if (isP[e]) xs[lp[e]] = sol[e];
                 lds_order();
                 const double ax = rowdot_fma();
                 const double nu = rhoc * (ax - r2);
@@ -245,16 +275,18 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                     const double zt = zprev + rhocinv * (nu - ya);
                     double zz = alpha * zt;
                     zz += (1 - alpha) * zprev + rhocinv * ya;
-                    zz = fmin(fmax(zz, clo), chi);
+                    const double cl_ = SMALL ? (isC ? Alb[rc] : 0.0) : clo, ch_ = SMALL ? (isC ? Aub[rc] : 0.0) : chi;
+                    zz = fmin(fmax(zz, cl_), ch_);
                     const double yC = ya + rhoc * ((alpha * zt + (1 - alpha) * zprev) - zz);
                     zv = isC ? zz : 0.0; ya = isC ? yC : 0.0;
                 }
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
+                for (int e = 0; e < SL; ++e) {
                     double xx = alpha * sol[e];
                     xx += (1 - alpha) * xx;  // quirk Q1
                     double qq = xx + rhobinv[e] * yb[e];
-                    qq = fmin(fmax(qq, lo[e]), hi[e]);
+                    const double lo_ = SMALL ? (isP[e] ? xlb[lp[e]] : 0.0) : lo[e], hi_ = SMALL ? (isP[e] ? xub[lp[e]] : 0.0) : hi[e];
+                    qq = fmin(fmax(qq, lo_), hi_);
                     const double yP = yb[e] + rhob[e] * (xx - qq);
                     xv[e] = isP[e] ? xx : 0.0; qv[e] = isP[e] ? qq : 0.0; yb[e] = isP[e] ? yP : 0.0;
                 }
@@ -271,12 +303,12 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                 const bool finite = __builtin_amdgcn_ballot_w64(probe != 0.0) == 0;   // (a non-finite iterate takes the dense loops: 0 * inf = NaN on the structural zeros of A)
                 const int sl = (int)lane_near(zr);
                 double acc[2] = {0.0, 0.0}, aty[2] = {0.0, 0.0}, axz = 0.0;
-                constexpr int NP1 = NN - 64;            // primal rows of the second slot
-                constexpr bool FEW1 = NP1 <= 4;         // few of them: products through LDS; otherwise their lanes load their rows
+                constexpr int NP1 = SMALL ? 0 : NN - 64;   // primal rows of the second slot
+                constexpr bool FEW1 = !SMALL && NP1 <= 4;   // few of them: products through LDS; otherwise their lanes load their rows
                 constexpr int RCS = 22;
                 if (finite) {
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) if (isP[e]) xs[lp[e]] = xv[e];
+                    for (int e = 0; e < SL; ++e) if (isP[e]) xs[lp[e]] = xv[e];
                     if (isC) us[rc] = ya;
                     lds_order();
                     // A' y and A x in the reference's order (multiply, then add; ascending index: the entries before the own node's block, the block, the
@@ -284,7 +316,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                     const double* DtTlo = DtT + 2 * NNODES * NNP;
                     const double* Dlo = DtT + NNODES * NNP;
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
+                    for (int e = 0; e < SL; ++e) {
                         double a = 0.0;
                         const bool dpart = (e == 0 || SLOT1_STATES);
                         double dv[NNODES], lv[NNODES], uv[NNODES], bv[NX], vv[NX];
@@ -332,7 +364,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                 } else {
                     // dense chains from the workspace
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
+                    for (int e = 0; e < SL; ++e) {
                         double a = 0.0;
                         for (int k = 0; k < MM; ++k) a += Acol(k, e, zr) * bcast_uniform(ya, k);
                         aty[e] = isP[e] ? a : 0.0;
@@ -362,7 +394,8 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                     }
                     acc[0] = hx;
                 }
-                if constexpr (!FEW1) {   // many primal rows in the second slot: lane l < NP1 loads row 64 + l (the other lanes re-read row 64)
+                if constexpr (SMALL) {
+                } else if constexpr (!FEW1) {   // many primal rows in the second slot: lane l < NP1 loads row 64 + l (the other lanes re-read row 64)
                     double hx1 = 0.0;
 #pragma unroll
                     for (int j0 = 0; j0 < NN; j0 += RCS) {
@@ -382,7 +415,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                     // rows 64 .. NN-1 of H: lane j loads H(64 + t, j) (and lane j < NP1 also H(64 + t, 64 + j)) and forms the product with its own x_j;
                     // lane t then adds the NN products of row 64 + t in ascending j — instead of NN loads per lane for NP1 live lanes
                     double* pb = tr + CD::PB_OFF;
-                    double h0[NP1], h1[NP1];
+                    double h0[NP1 > 0 ? NP1 : 1], h1[NP1 > 0 ? NP1 : 1];
 #pragma unroll
                     for (int t = 0; t < NP1; ++t) {
                         const unsigned l = lane_near(zr);
@@ -409,7 +442,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                 }
                 double a1 = isC ? fmax(fabs(axz), fabs(zv)) : 0.0, a2 = 0.0, rp = isC ? fabs(axz - zv) : 0.0, rq = 0.0, rd = 0.0;
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
+                for (int e = 0; e < SL; ++e) {
                     a1 = fmax(a1, isP[e] ? fabs(xv[e]) : 0.0);
                     a2 = fmax(a2, isP[e] ? fmax(fmax(fabs(acc[e]), fabs(aty[e])), fmax(fabs(hv[e]), fabs(yb[e]))) : 0.0);
                     rq = fmax(rq, isP[e] ? fabs(xv[e] - qv[e]) : 0.0);
@@ -435,7 +468,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                 if (__builtin_amdgcn_readfirstlane((int)(new_rho < rho / s.adaptive_rho_tolerance || new_rho > rho * s.adaptive_rho_tolerance))) {
                     rho = new_rho;
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
+                    for (int e = 0; e < SL; ++e) {
                         const double prev = rhob[e];
                         rhob[e] = rho_of(typ[e], rho);
                         rhobinv[e] = 1.0 / rhob[e];
@@ -454,7 +487,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
     }
     if (iter > s.max_iter) status = PMPC_QP_MAX_ITER_EXCEEDED;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) if (isP[e]) { out_x[lp[e]] = xv[e]; out_y[MM + lp[e]] = yb[e]; }
+    for (int e = 0; e < SL; ++e) if (isP[e]) { out_x[lp[e]] = xv[e]; out_y[MM + lp[e]] = yb[e]; }
     if (isC) out_y[rc] = ya;
     const bool bad = __builtin_amdgcn_ballot_w64((((xv[0] - xv[0]) + (yb[0] - yb[0])) + ((xv[1] - xv[1]) + (yb[1] - yb[1])) + (ya - ya)) != 0.0) != 0;   // non-finite x or y
     info.status = status; info.iter = iter; info.rho_updates = rho_updates; info.flags = bad ? PMPC_FLAG_NONFINITE : 0;

@@ -158,8 +158,47 @@ struct RegKkt {
     // the RAW entries: lane < NPIV: P(lane, j) for j < NPIV and A(j - NPIV, lane) beyond (every primal lane: they are the operands of the rank-m
     // update); lane >= NPIV: A(lane - NPIV, j) for j < NPIV, 0 beyond. diag = P(lane, lane) / rho_lane; rho_self = this constraint lane's rho.
     // The CPU restatement of the test suite (PIVOT_SWEEP, constraint-first) forms the same matrix entry by entry and sweeps the same blocks.
-    template <int NPIV = N, class KCol>
-    __device__ __forceinline__ void invert(int ln_in, double* st, double diag, KCol kcol, long long* tm = nullptr, double rho_self = 0.0) {
+    struct NoPre { template <class TT> __device__ __forceinline__ void operator()(TT&, double*, double*, int, int, int) const {} };
+    // T(a, b) <- fma(rho_j A(j, a), A(j, b), T(a, b)) over MM rows of A, j ascending in groups of four (one k-step of the matrix cores each) on every
+    // stored tile — the condensed register kernel (pmpc_qp_cond.hpp, at most 64 variables) calls this through invert's `pre` hook between the staging of
+    // H + diag and the blocked sweep. aload(j, z): A(j, lane) (0.0 on lanes >= N); rho_of(j): rho_j, wave-uniform.
+    template <int MM, class ALoad, class RhoOf>
+    __device__ __forceinline__ static void rank_update(d4 (&T)[NT][NT], int ln, int lr, int lc, double* PA, double* PB, ALoad aload, RhoOf rho_of) {
+        constexpr int NGR = (MM + 3) / 4, GB = 4;
+        int z = 0;
+        asm volatile("" : "+v"(z));
+#pragma unroll
+        for (int g0 = 0; g0 < NGR; g0 += GB) {
+            double av_[GB * 4];
+#pragma unroll
+            for (int u = 0; u < GB * 4; ++u) { const int j = 4 * g0 + u; av_[u] = (j < MM) ? aload(j < MM ? j : 0, z) : 0.0; }
+            sched_fence();
+#pragma unroll
+            for (int gg = 0; gg < GB; ++gg) {
+                if (g0 + gg < NGR) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int j = 4 * (g0 + gg) + t;
+                        const double rj = (j < MM) ? rho_of(j < MM ? j : 0) : 0.0;
+                        PB[t * SK + ln] = av_[gg * 4 + t];
+                        PA[t * SK + ln] = rj * av_[gg * 4 + t];
+                    }
+                    lds_order();
+                    double av[NT], bv[NT];
+#pragma unroll
+                    for (int R = 0; R < NT; ++R) { av[R] = PA[lr * SK + 16 * R + lc]; bv[R] = PB[lr * SK + 16 * R + lc]; }
+#pragma unroll
+                    for (int R = 0; R < NT; ++R)
+#pragma unroll
+                        for (int C = 0; C <= R; ++C) T[R][C] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[R], bv[C], T[R][C], 0, 0, 0);
+                    sched_fence();
+                    lds_order();
+                }
+            }
+        }
+    }
+    template <int NPIV = N, class KCol, class Pre = NoPre>
+    __device__ __forceinline__ void invert(int ln_in, double* st, double diag, KCol kcol, long long* tm = nullptr, double rho_self = 0.0, Pre pre = Pre()) {
         constexpr bool CF = NPIV < N;
         constexpr int NBP = (NPIV + BK - 1) / BK;     // blocks of swept pivots
         long long tq0 = tm ? clock64() : 0;
@@ -243,6 +282,7 @@ struct RegKkt {
                 lds_order();
             }
         }
+        pre(T, PA, PB, ln, lr, lc);
         if (tm) { long long t = clock64(); tm[0] += t - tq0; tq0 = t; }
 #pragma unroll
         for (int b = 0; b < NBP; ++b) {

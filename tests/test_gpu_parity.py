@@ -77,7 +77,7 @@ def _gpu_order(oracle, n, m, nodes=None, block_bfgs=False, kkt_form=0, schur=Fal
     if n + m <= 64 and nodes in ((5, 7) if block_bfgs else REG_NODE_COUNTS):   # (the block-BFGS one-row-per-lane specialisation exists for 5 and 7 nodes)
         return oracle.PIVOT_SWEEP
     if 64 < n + m <= 128 and nodes in REG_NODE_COUNTS:      # two-rows-per-lane register path (113..128 rows: part of the operand tiles in LDS) (the Hessian update is a run-time choice there)
-        if 64 < n <= 112 and m <= 64 and kkt_form == 0 and ng == 0 and n % nodes == 0:    # (no path constraints, no parameters) condensed register kernel (pmpc_qp_cond.hpp): only S = H + sigma I + rho_box + A' diag(rho) A is inverted
+        if n <= 112 and m <= 64 and kkt_form == 0 and ng == 0 and n % nodes == 0:    # (no path constraints, no parameters) condensed register kernel (pmpc_qp_cond.hpp): only S = H + sigma I + rho_box + A' diag(rho) A is inverted
             return oracle.PIVOT_CONDSWEEP
         return oracle.PIVOT_SWEEP2
     return _lds_order(oracle, n + m, kkt_form=kkt_form)
@@ -1268,7 +1268,8 @@ def test_last_route_reports_the_kernel_family(ctx):
         ctx.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
         return ctx.last_route()
     assert route(workloads.robot_batch(4)) == pa.capi.ROUTE_REG1
-    assert route(workloads.robot_batch(4, P=5, S=2)) == pa.capi.ROUTE_REG2                     # 55 variables: the full two-rows-per-lane inverse
+    assert route(workloads.robot_batch(4, P=5, S=2)) == pa.capi.ROUTE_CONDREG                  # 55 variables, 33 constraint rows: the condensed register kernel on the one-row-per-lane tile set (round 4)
+    assert route(workloads.robot_batch(4, P=5, S=2), kkt_form=1) == pa.capi.ROUTE_REG2
     assert route(workloads.cstr_batch(4)) == pa.capi.ROUTE_CONDREG                             # 66 variables, 44 constraint rows: the condensed register kernel (round 4)
     assert route(workloads.cstr_batch(4), kkt_form=1) == pa.capi.ROUTE_REG2
     assert route(workloads.robot_batch(4), qp_solver=1) == pa.capi.ROUTE_LDS

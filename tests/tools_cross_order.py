@@ -83,7 +83,7 @@ def kernel_order(ob, cfg, wl):
     if rows <= 64:
         return ob.PIVOT_SWEEP
     if rows <= ob.SWEEP2_MAX_ROWS:
-        if 64 < wl["n"] <= 112 and wl["m"] <= 64:
+        if wl["n"] <= 112 and wl["m"] <= 64:
             return ob.PIVOT_CONDSWEEP   # condensed register kernel (pmpc_qp_cond.hpp) since round 4
         return ob.PIVOT_SWEEP2
     return ob.PIVOT_CONDENSED   # the large-instance kernel inside the fused SQP kernel: condensed form since round 3

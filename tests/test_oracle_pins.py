@@ -777,6 +777,27 @@ def test_condensed_register_order_solves_a_traced_kkt_system(oracle):
     assert worst[0.1] <= 1e-11 and worst[3.6] <= 1e-8, worst
 
 
+def test_condensed_register_order_under_a_large_penalty(oracle):
+    """Unbounded variables carry rho_box = RHO_MIN = 1e-6 (qp_base.hpp:195-222; the states of every BASELINE workload), and the condensed form's loss
+    grows with rho_eq / (sigma + rho_box + lambda_min(H)): on a single solve with rho = 1e3 it is 1e-2 relative where the quasi-definite KKT form keeps
+    1e-11. What that does to a whole box-ADMM solve — config B's QPs started from rho = 10 and rho = 1e3 instead of 0.1 (the benchmark
+    streams themselves stay below rho = 70): every QP keeps its ADMM iteration count and status against the reference order, and the solutions are CLOSER
+    to it than those of the full two-rows-per-lane inverse this order replaced (measured: rho0 = 10: 7.5e-9 against 3.5e-7; 1e3: 8.9e-7 against 1.9e-5;
+    1e5: 3.1e-4 against 1.25). The acceptance test of the ADMM evaluates the true residuals (H x, A x, A' y from the data), so an inexact linear solve
+    can cost iterations, never a wrong SOLVED."""
+    import tools_cross_order as tco
+    q = tco.traced_qp_stream(oracle, "B", 150)
+    for rho0, bound in ((10.0, 5e-8), (1e3, 5e-6)):
+        s = oracle.sqp_qp_default_settings(); s.rho = rho0
+        args = (q["H"], q["h"], q["A"], q["Alb"], q["Aub"], q["xlb"], q["xub"])
+        xr, yr, ir = oracle.qp_solve_batch(*args, settings=s, pivot=oracle.PIVOT_EIGEN, threads=8)
+        xc, yc, ic = oracle.qp_solve_batch(*args, settings=s, pivot=oracle.PIVOT_CONDSWEEP, threads=8, structure=q["structure"])
+        xf, yf, if_ = oracle.qp_solve_batch(*args, settings=s, pivot=oracle.PIVOT_SWEEP2, threads=8)
+        assert [i.iter for i in ic] == [i.iter for i in ir] and [i.status for i in ic] == [i.status for i in ir], rho0
+        dc, df = np.abs(xc - xr).max(), np.abs(xf - xr).max()
+        assert dc <= bound and dc <= df, (rho0, dc, df)
+
+
 def test_block_structured_order_needs_its_refinement_step(oracle):
     """Why PIVOT_SCHUR refines: a config-B KKT system after a rho update (rho = 3.6: cond(S) = 6e5, S = 1/rho + A Q A'). The swept inverse of S has an
     isotropic forward error ~ eps cond(S) |nu|, but x = Q (r1 - A' nu) tolerates errors of nu only where Q^(1/2) A' nearly vanishes — without the step

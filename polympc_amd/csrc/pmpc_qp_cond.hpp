@@ -1,10 +1,10 @@
-// polympc_amd — CONDENSED register-resident box-ADMM QP solve for the QPs of the fused SQP kernel with 65..128 variables and at most 64 constraint
-// rows (one wavefront per QP; config B: n = 66, m = 44; the reference's 16-node robot grid: n = 80, m = 48).
+// polympc_amd — CONDENSED register-resident box-ADMM QP solve for the QPs of the fused SQP kernel with 65..128 KKT rows, at most 112 variables and at most
+// 64 constraint rows (one wavefront per QP; config B: n = 66, m = 44; the reference's 16-node robot grid: n = 80, m = 48; its 11-node grid: n = 55, m = 33).
 //
 // The constraint block of boxADMM's KKT matrix (box_admm.hpp:209-223) is diagonal, -1/rho, so the constraint rows are eliminated in closed form — what
 // the constraint-first sweep of pmpc_qp_reg.hpp does inside the full inverse — and are then NOT CARRIED AT ALL: only
 //     S = H + sigma I + rho_box + A' diag(rho) A          (n x n instead of (n + m) x (n + m))
-// is inverted, W = -S^{-1} by the blocked sweep of pmpc_qp_reg2.hpp in 16 x 16 fp64 accumulator tiles (config B: 17 block steps on 15 stored tiles
+// is inverted, W = -S^{-1} by the blocked sweep of pmpc_qp_reg2.hpp / pmpc_qp_reg.hpp in 16 x 16 fp64 accumulator tiles (config B: 17 block steps on 15 stored tiles
 // instead of 28 on 28, 25 operand tiles of the mat-vec instead of 49), and every ADMM iteration solves
 //     t = r1 + A'(rho o r2),      x = S^{-1} t,      nu = rho o (A x - r2)
 // with the two products formed from the per-node blocks of A and two small tables of the differentiation matrix in LDS (fma chains: the D~ entries of
@@ -29,7 +29,7 @@ namespace pmpc {
 // in the accumulation file and costs two v_accvgpr_read per entry and ADMM iteration)
 template <int NN, bool SMALL = (NN <= WAVE)> struct CondKktSel { using type = RegKkt2<NN, PMPC_COND_NV>; };
 // at most 64 variables — grids of 65..128 KKT rows whose primal block fits one row per lane: the one-row-per-lane tile set of pmpc_qp_reg.hpp (16 tiles
-// = 128 registers, a register-only DPP mat-vec), and the kernel is compiled for TWO wavefronts per SIMD
+// = 128 registers, a register-only DPP mat-vec); one wavefront per SIMD like the large variant (PMPC_COND1_WAVES, pmpc_launch.hpp: measured)
 template <int NN> struct CondKktSel<NN, true> { using type = RegKkt<NN>; };
 template <int NN> using CondKkt = typename CondKktSel<NN>::type;
 

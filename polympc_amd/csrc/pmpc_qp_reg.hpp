@@ -187,10 +187,17 @@ struct RegKkt {
                     double av[NT], bv[NT];
 #pragma unroll
                     for (int R = 0; R < NT; ++R) { av[R] = PA[lr * SK + 16 * R + lc]; bv[R] = PB[lr * SK + 16 * R + lc]; }
+                    // a row of A touches the state columns of its segment and its own node's block only: most (group, tile) operands are all zeros, and
+                    // fma(0, b, c) = c for finite b — those products are skipped (wave-uniform tests) unless an operand of the group is not finite
+                    bool nz[NT]; double probe = 0.0;
+#pragma unroll
+                    for (int R = 0; R < NT; ++R) { nz[R] = __builtin_amdgcn_ballot_w64(bv[R] != 0.0) != 0; probe += (av[R] - av[R]) + (bv[R] - bv[R]); }
+                    const bool all = __builtin_amdgcn_ballot_w64(probe != 0.0) != 0;
 #pragma unroll
                     for (int R = 0; R < NT; ++R)
 #pragma unroll
-                        for (int C = 0; C <= R; ++C) T[R][C] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[R], bv[C], T[R][C], 0, 0, 0);
+                        for (int C = 0; C <= R; ++C)
+                            if (all || (nz[R] && nz[C])) T[R][C] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[R], bv[C], T[R][C], 0, 0, 0);
                     sched_fence();
                     lds_order();
                 }

@@ -86,10 +86,12 @@ def _gpu_order(oracle, n, m, nodes=None, block_bfgs=False, kkt_form=0, schur=Fal
 POLICY_REG_NODE_COUNTS = (7, 11)   # grids whose register-resident kernels exist with the Ruiz / filter-line-search hooks compiled in (pmpc_launch.hpp, POL); since round 4 also the 16-node grid where it has 128 rows
 
 
-def _policy_order(oracle, n, m, nodes, ruiz=False, block_bfgs=False, kkt_form=0):
+def _policy_order(oracle, n, m, nodes, ruiz=False, block_bfgs=False, kkt_form=0, ng=0):
     """preconditioner = 1 / line_search = 1: on the grids of the reference's own tests (7 and 11 nodes) the register-resident kernels carry these hooks
     since round 3 (their sweep orders); every other grid takes the LDS / HBM-resident kernels for them."""
     if (nodes in POLICY_REG_NODE_COUNTS and n + m <= 112) or (nodes == 16 and n + m <= 128):   # (16 nodes, round 4: the reference's mpc_wrapper_test grid)
+        if n > 64 and not ruiz and kkt_form == 0 and n <= 112 and m <= 64 and ng == 0 and n % nodes == 0:
+            return oracle.PIVOT_CONDSWEEP   # the filter line search alone keeps the condensed register QP (Ruiz rescales the workspace: full inverse)
         return oracle.PIVOT_SWEEP if n + m <= 64 else oracle.PIVOT_SWEEP2
     return _lds_order(oracle, n + m, ruiz=ruiz, kkt_form=kkt_form)
 
@@ -562,7 +564,7 @@ def _sqp_both(ctx, oracle, wl, B, **kw):
     # (preconditioner = 1, qp_solver = 1 and line_search = 1 are served by the LDS-resident QP kernels whatever the size: static LDL^T
     #  order; hessian_update = 1 has register-resident specialisations like the default)
     if kw.get("qp_solver", 0): order = oracle.PIVOT_STATIC
-    elif kw.get("preconditioner", 0) or kw.get("line_search", 0): order = _policy_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, ruiz=bool(kw.get("preconditioner", 0)), block_bfgs=bool(kw.get("hessian_update", 0)), kkt_form=kf)
+    elif kw.get("preconditioner", 0) or kw.get("line_search", 0): order = _policy_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, ruiz=bool(kw.get("preconditioner", 0)), block_bfgs=bool(kw.get("hessian_update", 0)), kkt_form=kf, ng=dm["ng"])
     else: order = _gpu_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, block_bfgs=bool(kw.get("hessian_update", 0)), kkt_form=kf, ng=dm["ng"],
                              schur=_schur_route(wl["model"], wl["P"], wl["S"], **kw))
     xo, lo, io = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"],
@@ -1287,7 +1289,7 @@ def test_last_route_reports_the_kernel_family(ctx):
     assert route(workloads.robot_batch(4, P=4, S=2), preconditioner=1) == pa.capi.ROUTE_LDS
     assert route(workloads.robot_batch(4, P=5, S=3)) == pa.capi.ROUTE_CONDREG
     assert route(workloads.robot_batch(4, P=5, S=3), kkt_form=1) == pa.capi.ROUTE_REG2
-    assert route(workloads.robot_batch(4, P=5, S=3), line_search=1) == pa.capi.ROUTE_REG2                # round 4: the policy hooks on the 16-node register kernel (full inverse)
+    assert route(workloads.robot_batch(4, P=5, S=3), line_search=1) == pa.capi.ROUTE_CONDREG             # round 4: the policy hooks on the 16-node register kernels; the filter line search alone keeps the condensed QP
     assert route(workloads.robot_batch(4, P=5, S=3), preconditioner=1) == pa.capi.ROUTE_REG2
     assert route(workloads.robot_batch(4, P=5, S=4), line_search=1) == pa.capi.ROUTE_HBM
     assert route(workloads.kite_standin_batch(2)) == pa.capi.ROUTE_HBM

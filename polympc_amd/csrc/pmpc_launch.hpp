@@ -621,7 +621,10 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
                 pmpc_internal_set_route(ctx, PMPC_ROUTE_CONDREG);
             }
             // the filter line search alone (no Ruiz scaling: that rescales the workspace the per-node blocks of A mirror) keeps the condensed QP
-            if constexpr (POLK && (NN_ > WAVE)) {   // (the two-rows-per-lane tile set only: the one-row-per-lane variant with the hooks compiled in returned wrong iterates on the 11-node robot grid — not understood, not shipped)
+#ifndef PMPC_EXPERIMENT_SMALL_POL
+#define PMPC_EXPERIMENT_SMALL_POL 0
+#endif
+            if constexpr (POLK && (NN_ > WAVE || PMPC_EXPERIMENT_SMALL_POL)) {   // (the two-rows-per-lane tile set only: the one-row-per-lane variant with the hooks compiled in returned wrong iterates on the 11-node robot grid — not understood, not shipped)
                 if (pol && ss->preconditioner == 0 && ss->kkt_form == 0 && !getenv("PMPC_NO_CONDREG")) {
                     kern = sqp_kernel<Model, NN_, MM_, false, 0, false, false, true, true>; timed = false;
                     pmpc_internal_set_route(ctx, PMPC_ROUTE_CONDREG);

@@ -17,6 +17,7 @@
 #include "pmpc_qp_reg2.hpp"
 #include "pmpc_qp_big.hpp"
 #include "pmpc_qp_schur.hpp"
+#include "pmpc_qp_cond.hpp"
 #include "pmpc_ruiz.hpp"
 #include "pmpc_admm.hpp"
 

@@ -544,6 +544,9 @@ template <> struct LDS_PATH_PROFILED<CstrOCP> { static constexpr bool value = tr
 template <> struct LDS_PATH_PROFILED<KiteStandInOCP> { static constexpr bool value = true; };
 
 // Launch the fused SQP kernel for `Model` on DEVICE buffers (asynchronous on the context's stream).
+#ifndef PMPC_EXPERIMENT_SMALL_POL
+#define PMPC_EXPERIMENT_SMALL_POL 0   /* 1: ship-disabled hook variant of the small condensed kernel for line_search = 1; 2: also under the default policies (EXPERIMENTS.md) */
+#endif
 template <class Model, int NN_, int MM_> struct COND_REG_OK { static constexpr bool value = NN_ + MM_ > WAVE && NN_ <= 112 && MM_ > 0 && MM_ <= WAVE && Model::NP == 0 && Model::NG == 0; };
 // Register-resident QP specialisations are selected from the compile-time model dimensions and the runtime node count
 // when the KKT system has at most 64 rows; otherwise the LDS-resident path is used.
@@ -619,11 +622,11 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
                 kern = sqp_kernel<Model, NN_, MM_, false, 0, false, false, false, true>; timed = false;
                 if constexpr (LDS_PATH_PROFILED<Model>::value && !LEAN) { if (phase) { kern = sqp_kernel<Model, NN_, MM_, true, 0, false, false, false, true>; timed = true; } }
                 pmpc_internal_set_route(ctx, PMPC_ROUTE_CONDREG);
+#if PMPC_EXPERIMENT_SMALL_POL == 2   /* developer experiment: the hook variant of the small condensed kernel under the DEFAULT policies */
+                if constexpr (POLK && NN_ <= WAVE) { kern = sqp_kernel<Model, NN_, MM_, false, 0, false, false, true, true>; ldsq = sqp_kernel_lds_bytes<Model>(P, S, 3, 0, true); }
+#endif
             }
             // the filter line search alone (no Ruiz scaling: that rescales the workspace the per-node blocks of A mirror) keeps the condensed QP
-#ifndef PMPC_EXPERIMENT_SMALL_POL
-#define PMPC_EXPERIMENT_SMALL_POL 0
-#endif
             if constexpr (POLK && (NN_ > WAVE || PMPC_EXPERIMENT_SMALL_POL)) {   // (the two-rows-per-lane tile set only: the one-row-per-lane variant with the hooks compiled in returned wrong iterates on the 11-node robot grid — not understood, not shipped)
                 if (pol && ss->preconditioner == 0 && ss->kkt_form == 0 && !getenv("PMPC_NO_CONDREG")) {
                     kern = sqp_kernel<Model, NN_, MM_, false, 0, false, false, true, true>; timed = false;

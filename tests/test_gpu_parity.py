@@ -1286,6 +1286,8 @@ def test_last_route_reports_the_kernel_family(ctx):
     assert route(workloads.robot_batch(4, P=4, S=1), hessian_update=1) == pa.capi.ROUTE_REG1      # no block-structured kernel for this grid
     assert route(workloads.robot_batch(4, P=5, S=2), hessian_update=1, kkt_form=1) == pa.capi.ROUTE_REG2
     assert route(workloads.robot_batch(4, P=5, S=2), preconditioner=1, line_search=1) == pa.capi.ROUTE_REG2
+    assert route(workloads.robot_batch(4, P=5, S=2), line_search=1) == pa.capi.ROUTE_REG2               # (at most 64 variables: the hook build of the small condensed kernel is not shipped, EXPERIMENTS.md)
+    assert route(workloads.cstr_batch(4), line_search=1) == pa.capi.ROUTE_CONDREG
     assert route(workloads.robot_batch(4, P=4, S=2), preconditioner=1) == pa.capi.ROUTE_LDS
     assert route(workloads.robot_batch(4, P=5, S=3)) == pa.capi.ROUTE_CONDREG
     assert route(workloads.robot_batch(4, P=5, S=3), kkt_form=1) == pa.capi.ROUTE_REG2

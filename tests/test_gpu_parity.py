@@ -1251,6 +1251,34 @@ def test_cstr_short_horizon_tight_pin_against_the_reference_order(ctx, oracle, h
     assert r["scaled_dx_per_instance"]["max"] <= 1e-9 and r["scaled_dlam_per_instance"]["max"] <= 1e-9 and r["max_abs_d_constraint_violation"] <= 1e-10
 
 
+@pytest.mark.parametrize("rho0", [10.0, 1e3])
+def test_condensed_register_kernel_under_a_large_penalty(ctx, oracle, rho0):
+    """The condensed register kernel with the QP's penalty started at rho = 10 / 1e3 (rho_eq = 1e4 / 1e6 against rho_box = 1e-6 on the unbounded states — the
+    regime where the condensed form loses digits per solve): the kernel still equals its restatement bit for bit, and against the restatement as
+    the reference computes (pivoted LDL^T of the KKT matrix, glibc) every instance keeps its SQP and ADMM iteration counts with the iterates within 1e-6 of
+    their magnitude."""
+    import polympc_amd as pa
+    import tools_cross_order as tco
+    nB = 64
+    wl, _ = tco.config_workload("B", B=nB)
+    ss = pa.sqp_settings_default(); oss = oracle.sqp_default_settings()
+    for st in (ss, oss):
+        st.max_iter = 4; st.line_search_max_iter = wl["ls_max_iter"]
+    qs = pa.qp_settings_sqp_default(); oqs = oracle.sqp_qp_default_settings()
+    qs.rho = rho0; oqs.rho = rho0
+    x, lam, info = ctx.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], nB, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss, qp_settings=qs)
+    assert ctx.last_route() == pa.capi.ROUTE_CONDREG
+    xo, lo, io = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], nB, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, qp_settings=oqs,
+                                        pivot=oracle.PIVOT_CONDSWEEP, threads=8)
+    _assert_same_solve(info, io, x, xo, lam, lo)
+    with oracle.libm():
+        xr, lr, ir = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], nB, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, qp_settings=oqs,
+                                            pivot=oracle.PIVOT_EIGEN, threads=8)
+    r = tco.cross_order_stats("B", wl, x, lam, info, xr, lr, ir)
+    print(rho0, r["different_trajectories"], r["scaled_dx_per_instance"])
+    assert r["different_trajectories"] == 0 and r["scaled_dx_per_instance"]["max"] <= 1e-6
+
+
 def ROUTE_OF_128_ROWS(pa):
     """the kernel family pmpc_launch.hpp routes 128-row instances to (one place to change when the route changes)"""
     return pa.capi.ROUTE_CONDREG   # round 4: 80 variables, 48 constraint rows — the condensed register kernel (round 3: the two-rows-per-lane full inverse with sixteen operand tiles in LDS, still behind kkt_form = 1)

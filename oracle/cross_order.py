@@ -1,7 +1,7 @@
 """Developer tool (CPU only): the cross-order table of DESIGN.md §5 — every BASELINE configuration solved by the oracle twice, in the order of the
 kernel that serves it (with the IEEE-only sin / cos / exp the kernels share) and as the reference computes (Eigen-style pivoted LDL^T, glibc) — and the
 differences between the two runs: trajectories (SQP iterations, status, total ADMM iterations), reported KKT quantities, and the solutions in absolute
-terms and scaled per variable by its box / steady-state magnitude. `python tests/tools_cross_order.py [A D B C R] [--full]` prints one JSON object.
+terms and scaled per variable by its box / steady-state magnitude. `python oracle/cross_order.py [A D B C R] [--full]` prints one JSON object.
 The same function (cross_order_stats) is what tests/test_oracle_pins.py, tests/test_gpu_parity.py and bench.py use to compare a solution set with the
 reference-order run, so the numbers in the bench line, the tests and the table come from one piece of code."""
 import json
@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # repo root (this file lives in oracle/)
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -18,3 +18,13 @@ def combine_stats(dist, device, counts, elapsed):
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     dist.all_reduce(m, op=dist.ReduceOp.MAX)
     return [float(v) for v in s.tolist()], float(m.item())
+
+
+def max_over_ranks(dist, device, values):
+    """Element-wise MAX over ranks of a list of floats (per timed block: the slowest rank's wall time)."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t.tolist()]

@@ -1,0 +1,65 @@
+"""bench.py's stdout contract line (CPU only): built from a canned detailed record it must carry every key the driver parses and stay well
+under the size at which the driver's stdout tail cut round 4's line (BENCH_r04.json: parsed null at 29.6 KB)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config")
+
+
+def _canned():
+    """Round 4's full builder-side record (every sub-record present: four configurations with block-BFGS variants, five QP-level parity
+    records, both parity objects) — the record that was too long to parse."""
+    return json.load(open(os.path.join(ROOT, "profiles", "r04h_bench.json")))
+
+
+def test_contract_line_is_compact_and_complete():
+    import bench
+    d = _canned()
+    assert len(json.dumps(d)) > 16384            # the canned record really is the oversized one
+    line = bench.contract_line(d, "gpurun_out/bench_detail.json")
+    s = json.dumps(line)
+    assert len(s) < 4096, len(s)
+    assert "\n" not in s
+    back = json.loads(s)
+    for k in CONTRACT_KEYS:
+        assert k in back, k
+    assert back["value"] == float("%.9g" % d["value"]) and back["ms_per_step"] == float("%.9g" % d["ms_per_step"])
+    assert set(back["config"]) <= {"workload", "global_batch", "parallelism"} and "model" not in back["config"]
+    rf = back["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"):
+        assert k in rf, k
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6
+    cb = back["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] in ("port", "reference")
+    assert set(back["configs"]) == {"D", "B", "C", "R"}
+    for c in back["configs"].values():
+        assert set(c) <= {"ms", "route", "frac", "block_bfgs", "bit_identical"}
+    assert back["parity"]["same_order_bit_identical"] is True
+    assert set(back["parity"]["qp_level_within_1e-8"]) == {"A", "D", "B", "R", "C"}
+
+
+def test_contract_line_survives_missing_sub_records():
+    """N > 1 ranks and --cpu-sample 0 runs carry no configs / cpu_baseline / parity objects: the line builder must not need them."""
+    import bench
+    d = _canned()
+    for k in ("configs", "cpu_baseline", "qp_replay", "parity_vs_cpu_same_order", "parity_vs_cpu_reference", "variant_block_bfgs"):
+        d.pop(k, None)
+    line = bench.contract_line(d)
+    for k in CONTRACT_KEYS:
+        assert k in line
+    assert "roofline" in line and "cpu_baseline" not in line and "detail" not in line
+    assert len(json.dumps(line)) < 2048
+
+
+def test_contract_line_stays_small_with_long_notes():
+    import bench
+    d = _canned()
+    d["cpu_baseline"]["sample"] = "x" * 5000
+    d["config"]["note"] = "y" * 5000
+    assert len(json.dumps(bench.contract_line(d, "p"))) < 4096

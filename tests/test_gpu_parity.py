@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))   # tools_cross_order (the shared cross-order record)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))   # oracle.cross_order (the shared cross-order record)
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "casadi_robot_P5S2.npz")
 inf = np.inf
@@ -262,7 +262,7 @@ def test_qp_from_sqp_trace_vs_oracle(ctx, oracle):
     assert np.abs(info["res_dual"] - [i.res_dual for i in io]).max() <= 1e-8
 
 
-QP_STREAMS = (("A", 4096), ("D", 1024), ("B", 2048), ("R", 1024), ("C", 128))   # configuration, least number of QPs (tests/tools_cross_order.traced_qp_stream)
+QP_STREAMS = (("A", 4096), ("D", 1024), ("B", 2048), ("R", 1024), ("C", 128))   # configuration, least number of QPs (oracle/cross_order.traced_qp_stream)
 
 
 @pytest.mark.parametrize("cfg,min_qps", QP_STREAMS)
@@ -273,7 +273,7 @@ def test_qp_level_parity_against_the_reference_order(ctx, oracle, cfg, min_qps):
     lane, two rows per lane, HBM factor) against the restatement AS THE REFERENCE COMPUTES — Eigen-style pivoted LDL^T (PIVOT_EIGEN). Every QP, no mask:
     identical ADMM iteration counts, statuses and rho updates, and the reported residuals (qp_base.hpp:240-252, box_admm.hpp:398-431) within 1e-8."""
     import polympc_amd as pa
-    import tools_cross_order as tco
+    from oracle import cross_order as tco
     q = tco.traced_qp_stream(oracle, cfg, min_qps)
     assert q["H"].shape[0] >= min_qps
     s = pa.qp_settings_sqp_default()
@@ -1192,7 +1192,7 @@ def test_sqp_round_robin_execution_bit_identical(ctx, oracle, monkeypatch, hessi
 
 # ------------------------------------------------------------------------------ the DEFAULT kernels against the REFERENCE order, at full size
 REFERENCE_ORDER_BOUNDS = {
-    # measured on the CPU restatement in the kernel's order (tests/tools_cross_order.py; the GPU reproduces that run bit for bit) and asserted with
+    # measured on the CPU restatement in the kernel's order (oracle/cross_order.py; the GPU reproduces that run bit for bit) and asserted with
     # margin: (instances, max different trajectories, max |dx| over identical trajectories, scaled dx p99, max d violation, max rel d cost)
     "A": (4096, 0, 2e-8, 1e-10, 1e-10, 1e-10),    # 1.72e-8 (one instance above 1e-8), p99 2.1e-11, 2.4e-11, 1.9e-11
     "D": (8192, 0, 1e-7, 1e-10, 1e-9, 1e-9),      # 7.4e-8 (two instances above 1e-8), p99 1.8e-11, 1.3e-10, 5.1e-11
@@ -1214,7 +1214,7 @@ def test_default_kernels_against_the_reference_order(ctx, oracle, cfg):
     percentiles of the difference scaled by each variable's magnitude (p99 <= 1e-8; worst instance 3e-6, i.e. 2e-3 on a control bounded by 9000).
     The record (percentiles included) is printed and is the same object bench.py emits per configuration."""
     import polympc_amd as pa
-    import tools_cross_order as tco
+    from oracle import cross_order as tco
     nB, max_diff, tol_dx, tol_p99, tol_viol, tol_cost = REFERENCE_ORDER_BOUNDS[cfg]
     wl, _ = tco.config_workload(cfg, B=nB)
     ss = pa.sqp_settings_default(); ss.max_iter = wl["max_iter"]; ss.line_search_max_iter = wl["ls_max_iter"]
@@ -1238,7 +1238,7 @@ def test_cstr_short_horizon_tight_pin_against_the_reference_order(ctx, oracle, h
     on every instance, every variable within 1e-9 of its magnitude (measured 8.8e-11 / 7.5e-13), multipliers within 1e-9 scaled, violation within 1e-10.
     A regression of either kernel's accuracy below ~1e-9 fails here."""
     import polympc_amd as pa
-    import tools_cross_order as tco
+    from oracle import cross_order as tco
     nB = 1024
     wl, _ = tco.config_workload("B", B=nB); wl = dict(wl); wl["max_iter"] = 5
     ss = pa.sqp_settings_default(); ss.max_iter = 5; ss.line_search_max_iter = wl["ls_max_iter"]; ss.hessian_update = hessian_update
@@ -1258,7 +1258,7 @@ def test_condensed_register_kernel_under_a_large_penalty(ctx, oracle, rho0):
     the reference computes (pivoted LDL^T of the KKT matrix, glibc) every instance keeps its SQP and ADMM iteration counts with the iterates within 1e-6 of
     their magnitude."""
     import polympc_amd as pa
-    import tools_cross_order as tco
+    from oracle import cross_order as tco
     nB = 64
     wl, _ = tco.config_workload("B", B=nB)
     ss = pa.sqp_settings_default(); oss = oracle.sqp_default_settings()

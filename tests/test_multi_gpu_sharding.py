@@ -109,10 +109,14 @@ def test_bench_gpus_flag_starts_the_ranks(tmp_path):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "512",
-                          "--cpu-sample", "0", "--configs", "", "--no-replay"], env=env, capture_output=True, text=True, timeout=600)
+                          "--cpu-sample", "0", "--configs", "", "--no-replay", "--min-seconds", "0.2", "--detail-out", str(tmp_path / "detail.json")],
+                         env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    j = json.loads(line)
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4096, lines     # stdout is the ONE compact contract line (the detail goes to the file and to stderr)
+    j = json.loads(lines[0])
+    assert j["timed_blocks"]["blocks"] >= 2                     # the timed block was repeated; both ranks agreed on the count (the barriers paired up)
+    assert json.load(open(tmp_path / "detail.json"))["n_gpus"] == 2
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 1024 and j["value"] > 0 and j["scaling"] == "weak"
     # a launcher / flag mismatch is an error, not a silent single-GPU run
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")

@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import pytest
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))   # tools_cross_order (the shared cross-order record)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))   # oracle.cross_order (the shared cross-order record)
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "casadi_robot_P5S2.npz")
 inf = np.inf
@@ -674,9 +674,9 @@ def test_static_and_eigen_pivot_agree_on_config_A(oracle):
 
 
 def _cross_order(oracle, cfg, B=None, full=False, kernel_glibc=False):
-    """Config `cfg` (tests/tools_cross_order.py) solved in the order of the kernel that serves it, with the IEEE-only functions the kernels share, and as
+    """Config `cfg` (oracle/cross_order.py) solved in the order of the kernel that serves it, with the IEEE-only functions the kernels share, and as
     the reference computes (Eigen-style pivoted LDL^T, glibc): the record of polympc_amd/parity_stats.py over EVERY instance, no mask."""
-    import tools_cross_order as tco
+    from oracle import cross_order as tco
     wl, _ = tco.config_workload(cfg, B=B, full=full)
     n = wl["lbx"].shape[0]
     xk, lk, ik = tco.oracle_run(oracle, wl, n, tco.kernel_order(oracle, cfg, wl), kernel_glibc, 8)
@@ -690,7 +690,7 @@ def test_kernel_orders_against_the_reference_order_one_qp_at_a_time(oracle, cfg,
     configuration, each solved ONCE in the order of the kernel that serves its size at the QP entry point and once as the reference computes
     (PIVOT_EIGEN). Every QP: identical ADMM iteration counts / status / rho updates, residuals within 1e-8 (measured: <= 4.3e-10). The GPU test of
     the same name (tests/test_gpu_parity.py) puts the kernels themselves through it at larger counts."""
-    import tools_cross_order as tco
+    from oracle import cross_order as tco
     q = tco.traced_qp_stream(oracle, cfg, min_qps)
     rows = q["n"] + q["m"]
     order = oracle.PIVOT_SWEEP if rows <= 64 else (oracle.PIVOT_SWEEP2 if rows <= oracle.SWEEP2_MAX_ROWS else oracle.PIVOT_BLOCKED)
@@ -709,7 +709,7 @@ def test_block_structured_order_against_the_reference_order(oracle, cfg, min_qps
     reference-order SQP with the block BFGS the reference's control tests select (config A's, config B's and the reference's 16-node grid) every QP keeps
     its ADMM iteration count, status and rho updates, the residuals lie within 1e-8 of PIVOT_EIGEN's (measured: <= 1.4e-11 — CLOSER than the swept
     orders), and whole SQP trajectories are identical with |dx| <= 1e-8."""
-    import tools_cross_order as tco
+    from oracle import cross_order as tco
     q = tco.traced_qp_stream(oracle, cfg, min_qps, hessian_update=1)
     x, y, i = oracle.qp_solve_batch(q["H"], q["h"], q["A"], q["Alb"], q["Aub"], q["xlb"], q["xub"], settings=oracle.sqp_qp_default_settings(),
                                     pivot=oracle.PIVOT_SCHUR, threads=8, structure=q["structure"])
@@ -732,7 +732,7 @@ def test_condensed_register_order_against_the_reference_order(oracle, cfg, min_q
     default) every QP keeps its ADMM iteration count, status and rho updates and its residuals lie within 1e-9 of PIVOT_EIGEN's (measured: 2.9e-10 on B —
     the two-rows-per-lane full inverse: 1.1e-9 —, 5e-13 on the 16-node grid); whole SQP trajectories are identical with |dx| <= 1e-8 where the full
     inverse's are."""
-    import tools_cross_order as tco
+    from oracle import cross_order as tco
     q = tco.traced_qp_stream(oracle, cfg, min_qps)
     x, y, i = oracle.qp_solve_batch(q["H"], q["h"], q["A"], q["Alb"], q["Aub"], q["xlb"], q["xub"], settings=oracle.sqp_qp_default_settings(),
                                     pivot=oracle.PIVOT_CONDSWEEP, threads=8, structure=q["structure"])
@@ -757,7 +757,7 @@ def test_condensed_register_order_solves_a_traced_kkt_system(oracle):
     form, INDEPENDENT of rho (rho_box scales with it). Measured: <= 1.8e-9 relative at rho = 3.6 (pivoted LDL^T: 4e-12), 3e-13 at the initial rho; on
     the right-hand sides the ADMM actually produces (r2 = z - y / rho) the QP-level test above measures 2.9e-10 on the residuals — better than the
     full two-rows-per-lane inverse. settings.kkt_form = 1 keeps the KKT form for problems that need it."""
-    import tools_cross_order as tco
+    from oracle import cross_order as tco
     q = tco.traced_qp_stream(oracle, "B", 420)
     n, m = q["n"], q["m"]
     rng = np.random.default_rng(7)
@@ -785,7 +785,7 @@ def test_condensed_register_order_under_a_large_penalty(oracle):
     to it than those of the full two-rows-per-lane inverse this order replaced (measured: rho0 = 10: 7.5e-9 against 3.5e-7; 1e3: 8.9e-7 against 1.9e-5;
     1e5: 3.1e-4 against 1.25). The acceptance test of the ADMM evaluates the true residuals (H x, A x, A' y from the data), so an inexact linear solve
     can cost iterations, never a wrong SOLVED."""
-    import tools_cross_order as tco
+    from oracle import cross_order as tco
     q = tco.traced_qp_stream(oracle, "B", 150)
     for rho0, bound in ((10.0, 5e-8), (1e3, 5e-6)):
         s = oracle.sqp_qp_default_settings(); s.rho = rho0
@@ -803,7 +803,7 @@ def test_block_structured_order_needs_its_refinement_step(oracle):
     isotropic forward error ~ eps cond(S) |nu|, but x = Q (r1 - A' nu) tolerates errors of nu only where Q^(1/2) A' nearly vanishes — without the step
     the kernel order was 2e-9 .. 2e-8 off in x (1.8e-6 in the reported residuals of config B's QPs, 3.6 in a trajectory); with it the solve is MORE
     accurate than the dense orders. Reference: numpy solve refined in extended precision."""
-    import tools_cross_order as tco
+    from oracle import cross_order as tco
     q = tco.traced_qp_stream(oracle, "B", 420, hessian_update=1)
     n, m = q["n"], q["m"]
     worst = 0.0
@@ -872,7 +872,7 @@ def test_config_B_cross_order_spread_is_the_conditioning_of_the_trajectory(oracl
     assert p["p50"] <= 1e-11 and p["p90"] <= 1e-9 and p["p99"] <= 1e-8                                     # 4.4e-13 / 7.0e-12 / 7.5e-10 (round 3: 6.7e-13 / 1.2e-11 / 1.6e-9)
     assert i["max_scaled_dx"] <= 1e-4 and i["max_abs_d_constraint_violation"] <= 1e-5 and i["max_rel_d_cost"] <= 1e-5
     # the function set alone, in the reference's own order
-    import tools_cross_order as tco
+    from oracle import cross_order as tco
     wl, _ = tco.config_workload("B", full=True)
     xa, la, ia = tco.oracle_run(oracle, wl, 16384, oracle.PIVOT_EIGEN, False, 8)
     xb, lb, ib = tco.oracle_run(oracle, wl, 16384, oracle.PIVOT_EIGEN, True, 8)
@@ -1054,7 +1054,7 @@ def test_condensed_policy_follows_the_eigen_order_trajectories(oracle):
     """The condensed order on the benchmark streams — config C (the kernel that uses it), the reference's 16-node robot grid and config A: identical SQP
     iterations, statuses and total ADMM iterations as the Eigen-pivoted order on every instance, solutions within north_star's 1e-8 (measured: C 4.9e-12,
     R 3.2e-10, A 3.9e-9 — closer to the Eigen order than the sweep / blocked orders of round 2 are)."""
-    import tools_cross_order as tco
+    from oracle import cross_order as tco
     for cfg, B, tol in (("C", 16, 1e-10), ("R", 128, 1e-8), ("A", 512, 1e-8)):
         wl, _ = tco.config_workload(cfg, B=B)
         xr, lr, ir = tco.oracle_run(oracle, wl, B, oracle.PIVOT_EIGEN, True, 8)

@@ -164,6 +164,11 @@ pmpc_status pmpc_synchronize(pmpc_context* ctx);
  * [0] linearisation (+Hessian update) [1] QP [2] line search [3] termination test [4] whole SQP loop [5] BFGS
  * [6] KKT build + factorisation [7] QP residuals [8..23] finer slices (see tests/tools_phase_profile.py). 24 values. */
 pmpc_status pmpc_debug_phase_cycles(pmpc_context* ctx, unsigned long long* out24, int reset);
+/* Developer harness against uninitialised reads (also PMPC_POISON=1 at pmpc_create): when on, every launch of this context is preceded by a fill of
+ * the HBM workspace, the staging buffers of the host-buffer entry points, every compute unit's LDS, every SIMD's register file and the low private
+ * segment with signalling NaNs, so that a kernel which reads what it never wrote returns NaN (PMPC_FLAG_NONFINITE) instead of a plausible stale
+ * value. The product kernels are not modified: the binaries under test are the shipped ones. Costs about 0.2 ms per launch. */
+pmpc_status pmpc_debug_set_poison(pmpc_context* ctx, int on);
 
 /* Which kernel family served the last pmpc_sqp_solve_batch[_dev] / pmpc_mpc_step_batch_dev call of this context (the reference has one code path;
  * here the size and the policy hooks select one of several, with different speed — a caller can log it instead of guessing):

@@ -21,7 +21,7 @@ ROUTE_NAMES = {0: "none", 1: "reg1", 2: "reg2", 3: "lds", 4: "hbm", 5: "schur", 
 
 EXPORTED_SYMBOLS = [
     "pmpc_abi_version", "pmpc_struct_size", "pmpc_sqp_last_route",
-    "pmpc_version", "pmpc_status_string", "pmpc_create", "pmpc_destroy", "pmpc_synchronize", "pmpc_debug_phase_cycles",
+    "pmpc_version", "pmpc_status_string", "pmpc_create", "pmpc_destroy", "pmpc_synchronize", "pmpc_debug_phase_cycles", "pmpc_debug_set_poison",
     "pmpc_qp_settings_default", "pmpc_qp_settings_sqp_default", "pmpc_sqp_settings_default", "pmpc_chebyshev",
     "pmpc_qp_boxadmm_solve_batch", "pmpc_qp_boxadmm_solve_batch_dev", "pmpc_qp_boxadmm_solve_batch_f32", "pmpc_qp_boxadmm_solve_batch_f32_dev", "pmpc_qp_admm_solve_batch_f32", "pmpc_qp_admm_solve_batch_f32_dev", "pmpc_ocp_dims", "pmpc_ocp_linearise_batch",
     "pmpc_sqp_solve_batch", "pmpc_sqp_solve_batch_dev", "pmpc_sqp_solve_batch_user", "pmpc_sqp_solve_batch_multi",
@@ -198,6 +198,11 @@ class Context:
 
     def synchronize(self):
         _check(lib().pmpc_synchronize(self._ctx))
+
+    def set_poison(self, on=True):
+        """pmpc_debug_set_poison (developer harness, also PMPC_POISON=1): signalling NaNs into the HBM workspace, the staging buffers, every CU's LDS
+        and every SIMD's register file before each launch of this context — an uninitialised read then returns NaN."""
+        _check(lib().pmpc_debug_set_poison(self._ctx, 1 if on else 0))
 
     def last_route(self):
         """pmpc_sqp_last_route: the kernel family that served this context's last fused SQP call (ROUTE_* / ROUTE_NAMES)."""

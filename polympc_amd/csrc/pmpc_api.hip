@@ -90,6 +90,7 @@ extern "C" pmpc_status pmpc_internal_services(pmpc_context* ctx, int P, int S, d
     if (st != PMPC_OK) return st;
     st = ensure_ws(ctx, ws_bytes);
     if (st != PMPC_OK) return st;
+    PMPC_POISON_DEVICE(ctx);   // (developer harness: every fused SQP launch asks for its services first)
     *cheb = cd; *ws = ctx->ws; *stream = (void*)ctx->stream; *lds_limit = ctx->lds_limit; *phase_cycles = ctx->phase_cycles;
     *force_lds = ctx->force_lds_path ? 1 : 0;
     return PMPC_OK;
@@ -160,6 +161,8 @@ static pmpc_status create_impl(int device, void* stream, pmpc_context* ctx) {
     ctx->simd_count = 4 * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
     ctx->lds_limit = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 64 * 1024;
     if (prop.sharedMemPerBlockOptin && (size_t)prop.sharedMemPerBlockOptin < ctx->lds_limit) ctx->lds_limit = prop.sharedMemPerBlockOptin;
+    ctx->lds_limit_device = ctx->lds_limit;
+    { const char* e = getenv("PMPC_POISON"); ctx->poison = (e && e[0] && e[0] != '0') ? 1 : 0; }   // developer harness (pmpc_poison.hip)
     { const char* e = getenv("PMPC_LDS_LIMIT"); if (e && e[0] && atol(e) > 0 && (size_t)atol(e) < ctx->lds_limit) ctx->lds_limit = (size_t)atol(e); }   // developer switch: a smaller LDS budget (moves mid-size instances to the HBM-factor kernel)
     { const char* e = getenv("PMPC_FORCE_LDS_PATH"); ctx->force_lds_path = (e && e[0] == '1'); }
     { const char* e = getenv("PMPC_SQP_SLICE"); if (e && e[0]) ctx->sqp_slice = atoi(e) < 0 ? 0 : atoi(e); }
@@ -189,6 +192,11 @@ pmpc_status pmpc_debug_phase_cycles(pmpc_context* ctx, unsigned long long* out24
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipMemcpy(out24, ctx->phase_cycles, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (reset) HIPCHK(hipMemset(ctx->phase_cycles, 0, 24 * sizeof(unsigned long long)));
+    return PMPC_OK;
+}
+pmpc_status pmpc_debug_set_poison(pmpc_context* ctx, int on) {
+    if (!ctx) return PMPC_ERR_INVALID_ARGUMENT;
+    ctx->poison = on ? 1 : 0;
     return PMPC_OK;
 }
 pmpc_status pmpc_synchronize(pmpc_context* ctx) {
@@ -283,6 +291,7 @@ pmpc_status pmpc_qp_boxadmm_solve_batch_dev(pmpc_context* ctx, int B, int n, int
     if (B == 0) return PMPC_OK;
     HIPCHK(hipSetDevice(ctx->device));
     if (settings->linear_solver != 0 && settings->linear_solver != 1) return PMPC_ERR_INVALID_ARGUMENT;
+    PMPC_POISON_DEVICE(ctx);
     const bool static_order = settings->linear_solver == 0 && !ctx->force_lds_path;   // the register-resident specialisations factorise in a static order
     // register-resident specialisations (one KKT row per lane): config A's QP and the QPs of the robot / CSTR grids of 4 to 8 nodes
 #define PMPC_REG1_CASE(NN_, MM_)                                                                                                             \
@@ -358,6 +367,7 @@ pmpc_status pmpc_qp_admm_solve_batch_dev(pmpc_context* ctx, int B, int n, int m,
     const size_t lds = QpLds::doubles(n, m + n) * sizeof(double);   // the (2n+m)-row KKT factor + vectors of the stacked system
     if (lds > ctx->lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;
     HIPCHK(hipFuncSetAttribute((const void*)qp_admm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PMPC_POISON_DEVICE(ctx);
     hipLaunchKernelGGL(qp_admm_kernel, dim3(B), dim3(WAVE), lds, ctx->stream, B, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0, *settings, x, y, info);
     HIPCHK(hipGetLastError());
     return PMPC_OK;
@@ -391,6 +401,7 @@ pmpc_status pmpc_qp_ruiz_compute_batch_dev(pmpc_context* ctx, int B, int n, int 
     HIPCHK(hipSetDevice(ctx->device));
     double* scratch = nullptr;
     DEVOUT(23, (size_t)B * (n + m) * sizeof(double), scratch);
+    PMPC_POISON_DEVICE(ctx);
     hipLaunchKernelGGL(ruiz_compute_kernel, dim3(B), dim3(WAVE), 0, ctx->stream, B, n, m, H, h, A, Alb, Aub, xlb, xub, D, E, c, scratch);
     HIPCHK(hipGetLastError());
     return PMPC_OK;
@@ -400,6 +411,7 @@ pmpc_status pmpc_qp_ruiz_unscale_batch_dev(pmpc_context* ctx, int B, int n, int 
     if (!ctx || B < 0 || n < 1 || m < 0 || !D || !c || !x || !y || (m > 0 && !E)) return PMPC_ERR_INVALID_ARGUMENT;
     if (B == 0) return PMPC_OK;
     HIPCHK(hipSetDevice(ctx->device));
+    PMPC_POISON_DEVICE(ctx);
     hipLaunchKernelGGL(ruiz_unscale_solution_kernel, dim3(B), dim3(WAVE), 0, ctx->stream, B, n, m, D, E, c, x, y);
     HIPCHK(hipGetLastError());
     return PMPC_OK;

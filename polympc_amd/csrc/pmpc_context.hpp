@@ -66,6 +66,9 @@ struct pmpc_context {
     int sqp_rr = 0;                // PMPC_SQP_RR=1: batches beyond the resident wavefronts run one SQP iteration per work item from a ready queue (sqp_kernel_rr,
                                    // pmpc_launch.hpp); 0 (default) = one workgroup per instance — measured equal or faster on configs A and D
     int last_route = 0;            // pmpc_route of the last fused SQP launch (pmpc_sqp_last_route)
+    int poison = 0;                // PMPC_POISON=1 / pmpc_debug_set_poison: fill the HBM workspace, the staging buffers, every CU's LDS and every SIMD's register
+                                   // file with signalling NaNs before each launch (pmpc_poison.hip) — an uninitialised read returns NaN, not a plausible stale value
+    size_t lds_limit_device = 64 * 1024;   // the device's opt-in maximum of dynamic LDS per workgroup (lds_limit may be lowered by PMPC_LDS_LIMIT)
     bool force_lds_path = false;   // PMPC_FORCE_LDS_PATH=1: disable the register-resident specialisations (A/B testing)
     std::map<std::tuple<int, int, double, double>, ChebData*> cheb_cache;
     double* ws = nullptr; size_t ws_bytes = 0;       // SQP HBM workspace (H, J)
@@ -75,12 +78,15 @@ struct pmpc_context {
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "polympc_amd: %s failed: %s (%s:%d)\n", #call, hipGetErrorString(e_), __FILE__, __LINE__); return PMPC_ERR_HIP; } } while (0)
 
+constexpr unsigned PMPC_POISON_DWORD = 0x7FF47FF4u;   // any pair of these dwords is an fp64 signalling NaN (pmpc_poison.hip)
 inline pmpc_status ensure_ws(pmpc_context* ctx, size_t bytes) {
-    if (ctx->ws_bytes >= bytes) return PMPC_OK;
-    if (ctx->ws) HIPCHK(hipFree(ctx->ws));
-    ctx->ws = nullptr; ctx->ws_bytes = 0;
-    HIPCHK(hipMalloc((void**)&ctx->ws, bytes));
-    ctx->ws_bytes = bytes;
+    if (ctx->ws_bytes < bytes) {
+        if (ctx->ws) HIPCHK(hipFree(ctx->ws));
+        ctx->ws = nullptr; ctx->ws_bytes = 0;
+        HIPCHK(hipMalloc((void**)&ctx->ws, bytes));
+        ctx->ws_bytes = bytes;
+    }
+    if (ctx->poison && ctx->ws_bytes >= 4) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ctx->ws, (int)PMPC_POISON_DWORD, ctx->ws_bytes / 4, ctx->stream));   // the workspace is scratch between calls: every kernel must write what it reads
     return PMPC_OK;
 }
 inline pmpc_status ensure_scratch(pmpc_context* ctx, int slot, size_t bytes, void** out) {
@@ -91,9 +97,13 @@ inline pmpc_status ensure_scratch(pmpc_context* ctx, int slot, size_t bytes, voi
         HIPCHK(hipMalloc(&ctx->scratch[slot], bytes));
         ctx->scratch_bytes[slot] = bytes;
     }
+    // (poison mode: the whole slot — inputs are copied over it on the same stream, outputs must be written by the kernels in full)
+    if (ctx->poison && ctx->scratch_bytes[slot] >= 4) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ctx->scratch[slot], (int)PMPC_POISON_DWORD, ctx->scratch_bytes[slot] / 4, ctx->stream));
     *out = ctx->scratch[slot];
     return PMPC_OK;
 }
+extern "C" pmpc_status pmpc_internal_poison_device(pmpc_context* ctx);   // pmpc_poison.hip: LDS, register files and low scratch of every CU (no-op unless ctx->poison)
+#define PMPC_POISON_DEVICE(ctx) do { if ((ctx)->poison) { const pmpc_status ps_ = pmpc_internal_poison_device(ctx); if (ps_ != PMPC_OK) return ps_; } } while (0)
 inline pmpc_status get_cheb(pmpc_context* ctx, int P, int S, double t0, double tf, const ChebData** out) {
     auto key = std::make_tuple(P, S, t0, tf);
     auto it = ctx->cheb_cache.find(key);

@@ -23,15 +23,23 @@
 
 namespace pmpc {
 
+// Row stride (in doubles) of an LDS table of 8-byte entries whose ROWS are read at per-lane row bases (the D~ tables of the condensed and the
+// block-structured QP kernels: lane -> the row of its node): even, so that 16-byte reads stay aligned, and with stride / 2 ODD, so that 16
+// consecutive rows start on 16 distinct 16-byte slots of the 256-byte bank row (ds_read_b64: distinct 8-byte positions over a 32-lane group;
+// ds_read_b128: distinct slots over a 16-lane group). A power-of-two stride of 16 doubles put every row of the reference's 16-node grid on the
+// same two bank pairs: 17.7 % of the wave cycles in SQ_LDS_BANK_CONFLICT (profiles/r04_cfgR128_pmc_summary.json). The arithmetic does not change.
+__host__ __device__ constexpr int lds_row_stride(int len) { return (((len + (len & 1)) >> 1) & 1) ? len + (len & 1) : len + (len & 1) + 2; }
+
+
 template <class Model, int NNODES>
 struct JView {
     static_assert(NNODES > 0, "the node count is a compile-time constant of the register-resident kernels");
-    enum { NX = Model::NX, NU = Model::NU, NP = Model::NP, NG = Model::NG, NDER = NX + NU + NP };
+    enum { NX = Model::NX, NU = Model::NU, NP = Model::NP, NG = Model::NG, NDER = NX + NU + NP, JBS = OcpDims<Model>::JBS /* row stride of jblk / gblk (odd) */ };
     static constexpr int VARX = NX * NNODES, VARU = NU * NNODES, ME = NX * NNODES, MI = NG * NNODES;
     const double* D;      // (P+1) x (P+1), column-major (LDS)
     const int* nsr;       // per node: packed (flags, segment, row), Ocp::stage_constants
-    const double* jblk;   // [(k*NX + q)*NDER + i] = J(k*NX + q, gidx(k, i))
-    const double* gblk;   // [(k*NG + g)*NDER + i] = J(ME + k*NG + g, gidx(k, i))
+    const double* jblk;   // [(k*NX + q)*JBS + i] = J(k*NX + q, gidx(k, i))
+    const double* gblk;   // [(k*NG + g)*JBS + i] = J(ME + k*NG + g, gidx(k, i))
     int P;
     // A scalar zero the optimiser cannot see through, added to P where a product starts: everything derived from P below (segment starts, D
     // offsets) is wave-uniform and loop-invariant, and would otherwise be computed once in the kernel prologue and live in — or be spilled
@@ -48,7 +56,7 @@ struct JView {
         const bool last = k == NNODES - 1;
         const int P = this->P + opaque_szero();
         const int kb = seg * P, P1 = P + 1;
-        const double* blk = jblk + (k * NX + q) * NDER;
+        const double* blk = jblk + (k * NX + q) * JBS;
         const double* xq = xs + q;
         // the row's D entries: D(row, t) at row + t (P+1); the last node's row -D(0, P - t) is stored behind D (OcpLds::D) at (P+1)^2 + t
         const double* drow = D + (last ? P1 * P1 : row);
@@ -84,7 +92,7 @@ struct JView {
         if constexpr (NG > 0) {
             const int ri = eq ? 0 : r - ME;
             const int kg = ri / NG;
-            const double* gb = gblk + ri * NDER;
+            const double* gb = gblk + ri * JBS;
             double b = 0.0;
 #pragma unroll
             for (int i = 0; i < NX; ++i) b += gb[i] * xs[kg * NX + i];
@@ -137,7 +145,7 @@ struct JView {
         {   // own-node block: the NX equality rows of node jn
             double bv[NX > 0 ? NX : 1], yv[NX > 0 ? NX : 1];
 #pragma unroll
-            for (int q = 0; q < NX; ++q) { bv[q] = jblk[(jn * NX + q) * NDER + dcol]; yv[q] = ys[jn * NX + q]; }
+            for (int q = 0; q < NX; ++q) { bv[q] = jblk[(jn * NX + q) * JBS + dcol]; yv[q] = ys[jn * NX + q]; }
 #pragma unroll
             for (int q = 0; q < NX; ++q) { const double pr = bv[q] * yv[q]; a += isp ? 0.0 : pr; }
         }
@@ -151,7 +159,7 @@ struct JView {
             for (int r0 = 0; r0 < ME; r0 += 8) {
                 double bv[8], yv[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int r = (r0 + u < ME) ? r0 + u : 0; bv[u] = jblk[r * NDER + dcol]; yv[u] = ys[r]; }
+                for (int u = 0; u < 8; ++u) { const int r = (r0 + u < ME) ? r0 + u : 0; bv[u] = jblk[r * JBS + dcol]; yv[u] = ys[r]; }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) if (r0 + u < ME) b += bv[u] * yv[u];
             }
@@ -160,11 +168,11 @@ struct JView {
         if constexpr (NG > 0) {   // inequality rows: node jn's (every node's for a parameter column)
             double g1 = a;
 #pragma unroll
-            for (int g = 0; g < NG; ++g) g1 += gblk[(jn * NG + g) * NDER + dcol] * ys[ME + jn * NG + g];
+            for (int g = 0; g < NG; ++g) g1 += gblk[(jn * NG + g) * JBS + dcol] * ys[ME + jn * NG + g];
             if constexpr (NP > 0) {
                 double g2 = a;
 #pragma unroll
-                for (int r = 0; r < MI; ++r) g2 += gblk[r * NDER + dcol] * ys[ME + r];
+                for (int r = 0; r < MI; ++r) g2 += gblk[r * JBS + dcol] * ys[ME + r];
                 a = isp ? g2 : g1;
             } else a = g1;
         }
@@ -179,7 +187,7 @@ struct JView {
 // both sides, whatever the operand.
 template <class Model>
 struct JViewRT {
-    enum { NX = Model::NX, NU = Model::NU, NP = Model::NP, NG = Model::NG, NDER = NX + NU + NP };
+    enum { NX = Model::NX, NU = Model::NU, NP = Model::NP, NG = Model::NG, NDER = NX + NU + NP, JBS = OcpDims<Model>::JBS /* row stride of jblk / gblk (odd) */ };
     const double* D;      // (P+1) x (P+1) column-major, followed by the last node's row (OcpLds::D)
     const int* nsr;
     const double* jblk;
@@ -219,10 +227,10 @@ struct JViewRT {
         const int t = cc.jn - w.nd.kb;
         const bool inseg = cc.xcol && cc.dcol == w.q && (unsigned)t <= (unsigned)P;
         const double dv = w.nd.drow[(inseg ? t : 0) * w.nd.dstride];
-        const double bv = jblk[(w.k * NX + w.q) * NDER + cc.dcol];
+        const double bv = jblk[(w.k * NX + w.q) * JBS + cc.dcol];
         double v = (cc.pcol || cc.jn == w.k) ? bv : (inseg ? dv : 0.0);
         if constexpr (NG > 0) {
-            const double gv = gblk[w.ri * NDER + cc.dcol];
+            const double gv = gblk[w.ri * JBS + cc.dcol];
             const double vg = (cc.pcol || cc.jn == w.kg) ? gv : 0.0;
             v = w.eq ? v : vg;
         }
@@ -244,7 +252,8 @@ struct JViewRT {
     // The products then are fma chains with coefficients at per-lane bases + immediate offsets — the entries before the own node's block, the block, the
     // entries behind it: the ascending order of the structure-walking versions (a zero coefficient leaves a finite partial sum unchanged) without their
     // index arithmetic and selects (43 k + 20 k cycles per ADMM iteration of config C for the two products; with the tables: 4 k + 3 k).
-    __host__ __device__ static int tab_nnp(int nno) { return (nno + 7) & ~7; }
+    __host__ __device__ static int tab_len(int nno) { return (nno + 7) & ~7; }                 // entries read per row (batches of 8; the padding is zeros)
+    __host__ __device__ static int tab_nnp(int nno) { return lds_row_stride(tab_len(nno)); }   // row stride (bank-conflict-free per-lane row bases)
     __host__ __device__ static size_t tab_doubles(int nno) { return (size_t)4 * (nno + 1) * tab_nnp(nno); }
     // the tables grow with the square of the node count: up to 16 nodes (8.5 KB) they are worth their LDS; beyond, the occupancy of the two-wavefront
     // builds pays for them (21 nodes: 17 KB, five instead of eight instances per CU) and the products walk the structure as before
@@ -269,12 +278,12 @@ struct JViewRT {
     }
     // init, then the fma chain over column c against us (rows ascending); bv: the own node's block column (col_block)
     __device__ __forceinline__ double coldot_fma_tab(const Col& cc, const double (&bv)[NX + NG > 0 ? NX + NG : 1], const double* us, double init) const {
-        const int NNP = tab_nnp(NNo), TS = (NNo + 1) * NNP;
+        const int NNP = tab_nnp(NNo), NNL = tab_len(NNo), TS = (NNo + 1) * NNP;
         const double* lo = tab + (cc.xcol ? cc.jn : NNo) * NNP;
         const double* hi = lo + TS;
         const double* uq = us + (cc.xcol ? cc.dcol : 0);
         double a = init;
-        for (int k0 = 0; k0 < NNP; k0 += 8) {
+        for (int k0 = 0; k0 < NNL; k0 += 8) {
             double dv[8], uv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { dv[u] = lo[k0 + u]; uv[u] = uq[((k0 + u < NNo) ? k0 + u : 0) * NX]; }
@@ -288,7 +297,7 @@ struct JViewRT {
 #pragma unroll
             for (int q = 0; q < NX; ++q) a = fma(bv[q], vv[q], a);
         }
-        for (int k0 = 0; k0 < NNP; k0 += 8) {
+        for (int k0 = 0; k0 < NNL; k0 += 8) {
             double dv[8], uv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { dv[u] = hi[k0 + u]; uv[u] = uq[((k0 + u < NNo) ? k0 + u : 0) * NX]; }
@@ -299,12 +308,12 @@ struct JViewRT {
     }
     // fma chain over equality row r = (k, q) against xs (columns ascending), starting from 0; bv: the row's own-node block (row_block)
     __device__ __forceinline__ double rowdot_fma_tab(const Row& w, const double (&bv)[NDER], const double* xs) const {
-        const int NNP = tab_nnp(NNo), TS = (NNo + 1) * NNP;
+        const int NNP = tab_nnp(NNo), NNL = tab_len(NNo), TS = (NNo + 1) * NNP;
         const double* lo = tab + 2 * TS + w.k * NNP;
         const double* hi = lo + TS;
         const double* xq = xs + w.q;
         double a = 0.0;
-        for (int j0 = 0; j0 < NNP; j0 += 8) {
+        for (int j0 = 0; j0 < NNL; j0 += 8) {
             double dv[8], xv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { dv[u] = lo[j0 + u]; xv[u] = xq[((j0 + u < NNo) ? j0 + u : 0) * NX]; }
@@ -318,7 +327,7 @@ struct JViewRT {
         for (int i = 0; i < NU; ++i) xb[NX + i] = xs[VARX + w.k * NU + i];
 #pragma unroll
         for (int i = 0; i < NX; ++i) a = fma(bv[i], xb[i], a);
-        for (int j0 = 0; j0 < NNP; j0 += 8) {
+        for (int j0 = 0; j0 < NNL; j0 += 8) {
             double dv[8], xv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { dv[u] = hi[j0 + u]; xv[u] = xq[((j0 + u < NNo) ? j0 + u : 0) * NX]; }
@@ -333,7 +342,7 @@ struct JViewRT {
     // ---- the two sparse products of the condensed solve. D (`D`) and the vectors live in LDS; the per-node blocks come from the HBM scratch and are
     // requested first (row_block / col_block, every pass of a product before any of them is consumed), so that a product costs one memory round trip.
     __device__ __forceinline__ void row_block(const Row& w, double (&bv)[NDER]) const {
-        const double* blk = w.eq ? jblk + (w.k * NX + w.q) * NDER : gblk + w.ri * NDER;
+        const double* blk = w.eq ? jblk + (w.k * NX + w.q) * JBS : gblk + w.ri * JBS;
 #pragma unroll
         for (int i = 0; i < NDER; ++i) bv[i] = blk[i];
     }
@@ -399,9 +408,9 @@ struct JViewRT {
     static constexpr int NCB = NX + NG;   // entries of a column inside its own node's rows (equality rows, then inequality rows)
     __device__ __forceinline__ void col_block(const Col& cc, double (&bv)[NCB > 0 ? NCB : 1]) const {
 #pragma unroll
-        for (int q = 0; q < NX; ++q) bv[q] = jblk[(cc.jn * NX + q) * NDER + cc.dcol];
+        for (int q = 0; q < NX; ++q) bv[q] = jblk[(cc.jn * NX + q) * JBS + cc.dcol];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) bv[NX + g] = gblk[(cc.jn * NG + g) * NDER + cc.dcol];
+        for (int g = 0; g < NG; ++g) bv[NX + g] = gblk[(cc.jn * NG + g) * JBS + cc.dcol];
     }
     // init, then the fma chain over the non-zero entries of column c against us (m entries), rows ascending
     __device__ __forceinline__ double coldot_fma(const Col& cc, const double (&bv)[NCB > 0 ? NCB : 1], const double* us, double init) const {
@@ -433,7 +442,7 @@ struct JViewRT {
             for (int r0 = 0; r0 < ME; r0 += 8) {
                 double pv[8], uv[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int r = (r0 + u < ME) ? r0 + u : 0; pv[u] = jblk[r * NDER + cc.dcol]; uv[u] = us[r]; }
+                for (int u = 0; u < 8; ++u) { const int r = (r0 + u < ME) ? r0 + u : 0; pv[u] = jblk[r * JBS + cc.dcol]; uv[u] = us[r]; }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) b = step(b, pv[u], uv[u], r0 + u < ME);
             }
@@ -445,7 +454,7 @@ struct JViewRT {
             for (int g = 0; g < NG; ++g) g1 = step(g1, bv[NX + g], us[ME + cc.jn * NG + g], true);
             if constexpr (NP > 0) {
                 double g2 = a;
-                for (int r = 0; r < NG * NNo; ++r) g2 = step(g2, gblk[r * NDER + cc.dcol], us[ME + r], true);
+                for (int r = 0; r < NG * NNo; ++r) g2 = step(g2, gblk[r * JBS + cc.dcol], us[ME + r], true);
                 a = cc.pcol ? g2 : g1;
             } else a = g1;
         }
@@ -480,7 +489,7 @@ struct JViewRT {
             for (int r0 = 0; r0 < ME; r0 += 8) {
                 double pv[8], uv[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int r = (r0 + u < ME) ? r0 + u : 0; pv[u] = jblk[r * NDER + cc.dcol]; uv[u] = us[r]; }
+                for (int u = 0; u < 8; ++u) { const int r = (r0 + u < ME) ? r0 + u : 0; pv[u] = jblk[r * JBS + cc.dcol]; uv[u] = us[r]; }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) b = stepma(b, pv[u], uv[u], r0 + u < ME);
             }
@@ -492,7 +501,7 @@ struct JViewRT {
             for (int g = 0; g < NG; ++g) g1 = stepma(g1, bv[NX + g], us[ME + cc.jn * NG + g], true);
             if constexpr (NP > 0) {
                 double g2 = a;
-                for (int r = 0; r < NG * NNo; ++r) g2 = stepma(g2, gblk[r * NDER + cc.dcol], us[ME + r], true);
+                for (int r = 0; r < NG * NNo; ++r) g2 = stepma(g2, gblk[r * JBS + cc.dcol], us[ME + r], true);
                 a = cc.pcol ? g2 : g1;
             } else a = g1;
         }

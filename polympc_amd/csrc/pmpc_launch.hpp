@@ -34,7 +34,7 @@ template <int NKKT> constexpr int reg_qp_staging() {
 
 // LDS doubles of the block-sparse copy of J the register-resident kernels keep (pmpc_jview.hpp): per node NX x NDER + NG x NDER
 template <class Model> __host__ __device__ inline size_t jview_doubles(int nnodes) {
-    return (size_t)nnodes * (Model::NX + Model::NG) * OcpDims<Model>::NDER;
+    return (size_t)nnodes * (Model::NX + Model::NG) * OcpDims<Model>::JBS;
 }
 
 // large-instance mode: per-instance HBM scratch (doubles) behind the factor workspace — SQP vectors, per-node AD staging, QP vectors
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
         stage_end = hq;
         qw.carve_rest_split(hq, rhsL, n, m, Wb);
         hq += QpLds::doubles_rest(n, m);
-        ocp.jblk = hq; ocp.gblk = ocp.jblk + (size_t)ocp.dm.NN * Model::NX * OcpDims<Model>::NDER; ocp.keep_blk = true;   // block-sparse copy of J for the condensed linear algebra (pmpc_qp_big.hpp)
+        ocp.jblk = hq; ocp.gblk = ocp.jblk + (size_t)ocp.dm.NN * Model::NX * OcpDims<Model>::JBS; ocp.keep_blk = true;   // block-sparse copy of J for the condensed linear algebra (pmpc_qp_big.hpp)
     } else {
         p = (NN > 0) ? qw.carve_xy(smem, n, m) : qw.carve(smem, n, ss.qp_solver == 1 ? m + n : m);   // ADMM: stacked constraint rows
         p = v.carve(p, n, m, mi);
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
         stage_end = p;   // end of the per-node staging block: what follows (static parameters, filter) stays live during the line search
     }
     if constexpr (NN > 0 && NN + MM > WAVE) {   // block-sparse copy of J (pmpc_jview.hpp) for the two-rows-per-lane kernels: lives through the QP, behind the staging its LDS buffers alias
-        ocp.jblk = p; p += jview_doubles<Model>(ocp.dm.NN); ocp.gblk = ocp.jblk + (size_t)ocp.dm.NN * Model::NX * OcpDims<Model>::NDER; ocp.keep_blk = true;
+        ocp.jblk = p; p += jview_doubles<Model>(ocp.dm.NN); ocp.gblk = ocp.jblk + (size_t)ocp.dm.NN * Model::NX * OcpDims<Model>::JBS; ocp.keep_blk = true;
     }
     double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
     const int ln = lane_id();
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
 // the m x m Schur complement. One instantiation per (model, P, S): the segment structure is a compile-time constant of the sparse products.
 template <class Model, int PP, int SS> constexpr int schur_lds_doubles_ct() {
     using SD = SchurDims<Model, PP, SS>;
-    return SD::LDS_DOUBLES + SD::NNODES * SD::DD /*hblk*/ + SD::NNODES * SD::NX * SD::D /*jblk*/ + 4;
+    return SD::LDS_DOUBLES + SD::NNODES * SD::DD /*hblk*/ + SD::NNODES * SD::NX * SD::JBS /*jblk*/ + 4;
 }
 template <class Model, int PP, int SS> inline size_t sqp_schur_lds_bytes() {
     using SD = SchurDims<Model, PP, SS>;
@@ -202,7 +202,7 @@ void sqp_schur_kernel(Model model, const ChebData* __restrict__ cd, int B, const
     p = ocp.s.carve(p, PP, SS);
     if ((size_t)(p - stage0) < (size_t)RegKkt<m>::TRI + 2 + ocp.s.const_doubles(PP, SS)) p = stage0 + RegKkt<m>::TRI + 2 + ocp.s.const_doubles(PP, SS);
     const double* stage_end = p;
-    ocp.jblk = p; p += SD::NNODES * SD::NX * SD::D; ocp.gblk = ocp.jblk; ocp.keep_blk = true;
+    ocp.jblk = p; p += SD::NNODES * SD::NX * SD::JBS; ocp.gblk = ocp.jblk; ocp.keep_blk = true;
     double* hblk = p; p += SD::NNODES * SD::DD;
     double* qblk = p; p += SD::NNODES * SD::DD;
     double* xsc = p; p += n + 1;

@@ -33,7 +33,9 @@ struct ChebData {
 
 template <class Model>
 struct OcpDims {
-    enum { NX = Model::NX, NU = Model::NU, NP = Model::NP, ND = Model::ND, NG = Model::NG, NDER = NX + NU + NP };
+    enum { NX = Model::NX, NU = Model::NU, NP = Model::NP, ND = Model::ND, NG = Model::NG, NDER = NX + NU + NP,
+           JBS = NDER | 1 };   // row stride of the per-node blocks of J kept beside the dense matrix (jblk / gblk, pmpc_jview.hpp): ODD, so that the rows of 32
+                               // consecutive lanes start on 32 distinct 8-byte bank positions (an even NDER put config B's rows on 16: 6 % of its wave cycles in bank conflicts)
     int NN, VARX, VARU, n, me, mi, m;
     __host__ __device__ OcpDims(int P, int S) {
         NN = P * S + 1; VARX = NX * NN; VARU = NU * NN; n = VARX + VARU + NP; me = VARX; mi = NG * NN; m = me + mi;
@@ -387,7 +389,7 @@ struct Ocp {
             double v = (i == q) ? s.nd[k] : 0.0;
             v -= ts * s.fjac[e];
             if constexpr (DENSEJ) J[(k * NX + q) + (size_t)dm.gidx(k, i) * ldj] = v;
-            if (keep_blk) jblk[e] = v;
+            if (keep_blk) jblk[(k * NX + q) * Dm::JBS + i] = v;
         }
         for (int r = ln; r < dm.me; r += WAVE) {
             double cv = -ts * s.fval[r];
@@ -398,7 +400,7 @@ struct Ocp {
             for (int e = ln; e < dm.NN * NG * NDER; e += WAVE) {
                 const int kq = e / NDER, i = e - kq * NDER, k = kq / NG;
                 if constexpr (DENSEJ) J[(dm.me + kq) + (size_t)dm.gidx(k, i) * ldj] = s.gjac[e];
-                if (keep_blk) gblk[e] = s.gjac[e];
+                if (keep_blk) gblk[kq * Dm::JBS + i] = s.gjac[e];
             }
             for (int r = ln; r < dm.mi; r += WAVE) c[dm.me + r] = s.gval[r];
         }

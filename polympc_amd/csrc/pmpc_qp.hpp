@@ -706,8 +706,8 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
     if constexpr (HASJ) {
         if (cond) {
             double pr = 0.0;
-            for (int i = ln; i < jv.NNo * (int)JV::NX * (int)JV::NDER; i += WAVE) pr += jv.jblk[i] - jv.jblk[i];
-            if constexpr ((int)JV::NG > 0) { for (int i = ln; i < jv.NNo * (int)JV::NG * (int)JV::NDER; i += WAVE) pr += jv.gblk[i] - jv.gblk[i]; }
+            for (int i = ln; i < jv.NNo * (int)JV::NX * (int)JV::NDER; i += WAVE) { const int r_ = i / (int)JV::NDER; const double v_ = jv.jblk[r_ * (int)JV::JBS + (i - r_ * (int)JV::NDER)]; pr += v_ - v_; }
+            if constexpr ((int)JV::NG > 0) { for (int i = ln; i < jv.NNo * (int)JV::NG * (int)JV::NDER; i += WAVE) { const int r_ = i / (int)JV::NDER; const double v_ = jv.gblk[r_ * (int)JV::JBS + (i - r_ * (int)JV::NDER)]; pr += v_ - v_; } }
             jbad = __builtin_amdgcn_ballot_w64(pr != 0.0) != 0;
         }
     }

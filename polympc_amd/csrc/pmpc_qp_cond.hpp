@@ -45,7 +45,7 @@ struct CondDims {
     static constexpr int XS_OFF = US_OFF + 64;                    // x (NN entries)
     static constexpr int PB_OFF = XS_OFF + 128;                   // residual evaluation: products of the few primal rows of the second slot
     static constexpr int TAB_OFF = PB_OFF + (SMALL ? 0 : 4 * NN); // D~ tables of the sparse products (cond_build_tables), rebuilt at every QP
-    template <int NNODES> static constexpr int nnp() { return NNODES + (NNODES & 1); }
+    template <int NNODES> static constexpr int nnp() { return lds_row_stride(NNODES); }   // bank-conflict-free row stride (pmpc_jview.hpp)
     template <int NNODES> static constexpr int tab_doubles() { return (4 * NNODES + 1) * nnp<NNODES>(); }
 };
 
@@ -57,7 +57,7 @@ struct CondDims {
 // node count.
 template <int NNODES>
 __device__ __forceinline__ void cond_build_tables(const double* Dm, int P, double* Dt) {
-    constexpr int NNP = NNODES + (NNODES & 1);
+    constexpr int NNP = lds_row_stride(NNODES);
     double* DtT = Dt + NNODES * NNP;
     double* Dlo = DtT + NNODES * NNP;
     double* DtTlo = Dlo + NNODES * NNP;
@@ -150,7 +150,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
     //   column c of node jn, state qx:  t = r1;  t = fma(D~(k, jn), u(k, qx), t) for the nodes k ascending (0 on the own node and outside the segments
     //                                   that hold jn; a control column reads the all-zero row);  t = fma(J((jn, q), c), u(jn, q), t) for q ascending
     //   row (k, q):                     a = 0;   a = fma(D~(k, j), x(j, q), a) for the nodes j ascending;  then the own node's block, columns ascending
-    constexpr int NX = JV::NX, NU = JV::NU, NDER = JV::NDER, NNODES = MM / NX, NNP = NNODES + (NNODES & 1), VARX = NX * NNODES;
+    constexpr int NX = JV::NX, NU = JV::NU, NDER = JV::NDER, JBS = JV::JBS, NNODES = MM / NX, NNP = lds_row_stride(NNODES), VARX = NX * NNODES;
     static_assert((int)JV::NG == 0 && (int)JV::NP == 0 && NNODES * NX == MM && NNODES * (NX + NU) == NN, "condensed register QP: no path constraints, no parameters");
     double* Dt = tr + CD::TAB_OFF;
     static_assert(CD::TAB_OFF + CD::template tab_doubles<NNODES>() <= CondKkt<NN>::TRI, "tables fit the staging");
@@ -165,13 +165,13 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
         const int dcol = xcol ? c - jn * NX : NX + (cu - jn * NU);
         cD[e] = xcol ? DtT + jn * NNP : Dt + 4 * NNODES * NNP;
         cU[e] = us + (xcol ? dcol : 0);
-        cB[e] = jv.jblk + (jn * NX) * NDER + dcol;
+        cB[e] = jv.jblk + (jn * NX) * JBS + dcol;
         cV[e] = us + jn * NX;
     }
     const int rk = rc / NX, rq = rc - rk * NX;
     const double* rD = Dt + rk * NNP;              // constraint row: D~ row, x at the row's state index, own-node block row, x / u of the own node
     const double* rX = xs + rq;
-    const double* rB = jv.jblk + rc * NDER;
+    const double* rB = jv.jblk + rc * JBS;
     const double* rV = xs + rk * NX;
     const double* rW = xs + VARX + rk * NU;
     constexpr bool SLOT1_STATES = VARX > 64;       // state columns in the second slot?
@@ -191,7 +191,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
         }
         double bv[NX], vv[NX];
 #pragma unroll
-        for (int q = 0; q < NX; ++q) { bv[q] = cB[e][q * NDER]; vv[q] = cV[e][q]; }
+        for (int q = 0; q < NX; ++q) { bv[q] = cB[e][q * JBS]; vv[q] = cV[e][q]; }
 #pragma unroll
         for (int q = 0; q < NX; ++q) a = fma(bv[q], vv[q], a);
         return a;
@@ -326,7 +326,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                             for (int k = 0; k < NNODES; ++k) { dv[k] = cD[e][k]; lv[k] = cl[k]; uv[k] = cU[e][k * NX]; }
                         }
 #pragma unroll
-                        for (int q = 0; q < NX; ++q) { bv[q] = cB[e][q * NDER]; vv[q] = cV[e][q]; }
+                        for (int q = 0; q < NX; ++q) { bv[q] = cB[e][q * JBS]; vv[q] = cV[e][q]; }
                         if (dpart) {
 #pragma unroll
                             for (int k = 0; k < NNODES; ++k) a += lv[k] * uv[k];

@@ -366,6 +366,7 @@ static pmpc_status f32_solve_dev(bool osqp, pmpc_context* ctx, int B, int n, int
     if ((osqp ? 2 * n + m : n + m) > 2 * WAVE || lds > ctx->lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;   // two KKT rows per lane, the matrix in LDS
     auto kern = osqp ? qp_admm_f32_kernel : qp_boxadmm_f32_kernel;
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PMPC_POISON_DEVICE(ctx);
     hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), lds, ctx->stream, B, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0, *settings, x, y, info);
     HIPCHK(hipGetLastError());
     return PMPC_OK;

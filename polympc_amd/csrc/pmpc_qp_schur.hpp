@@ -29,8 +29,9 @@ namespace pmpc {
 
 template <class Model, int PP, int SS>
 struct SchurDims {
-    enum { NX = Model::NX, NU = Model::NU, D = NX + NU, DD = D * D, NNODES = PP * SS + 1, N = D * NNODES, M = NX * NNODES, VARX = NX * NNODES,
-           SLOTS = (N + WAVE - 1) / WAVE, P1 = PP + 1, NNP = NNODES + (NNODES & 1),   // (even row stride: the tables below are read two entries at a time)
+    enum { NX = Model::NX, NU = Model::NU, D = NX + NU, DD = D * D, JBS = OcpDims<Model>::JBS /* row stride of jblk (odd) */, NNODES = PP * SS + 1, N = D * NNODES, M = NX * NNODES, VARX = NX * NNODES,
+           SLOTS = (N + WAVE - 1) / WAVE, P1 = PP + 1, NNR = NNODES + (NNODES & 1),   // entries read per table row (two at a time)
+           NNP = lds_row_stride(NNODES),                                                // row stride: even, NNP / 2 odd — bank-conflict-free per-lane row bases (pmpc_jview.hpp)
            TAB = NNODES * NNP + (NNODES + 1) * NNP };
     static_assert(Model::NP == 0 && Model::NG == 0, "block-structured QP: no parameters, no path constraints");
     static_assert(M <= WAVE && N <= 2 * WAVE, "block-structured QP: at most 64 constraint rows and 128 variables");
@@ -87,7 +88,7 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
                                                     double* qblk, double* xsc, double* dsc, double* pdl, const double* Dt, long long* dbg = nullptr,
                                                     long long* tm = nullptr) {
     using SD = SchurDims<Model, PP, SS>;
-    constexpr int NX = SD::NX, NU = SD::NU, D = SD::D, DD = SD::DD, NNODES = SD::NNODES, N = SD::N, M = SD::M, VARX = SD::VARX, SLOTS = SD::SLOTS, NNP = SD::NNP;
+    constexpr int NX = SD::NX, NU = SD::NU, D = SD::D, DD = SD::DD, NNODES = SD::NNODES, N = SD::N, M = SD::M, VARX = SD::VARX, SLOTS = SD::SLOTS, NNP = SD::NNP, NNR = SD::NNR;
     using d2 = double __attribute__((ext_vector_type(2)));
     const long long tp0 = dbg ? clock64() : 0;
     // ---- lane roles -------------------------------------------------------------------------------------------------------------------------
@@ -127,7 +128,7 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
         double kd = hblk[r.k * DD + r.c * D + r.c]; kd += s.sigma; kd += rhob[e];   // construct_kkt_matrix, box_admm.hpp:214-216
         pdl[r.px] = kd;
 #pragma unroll
-        for (int q = 0; q < NX; ++q) colb[e][q] = jblk[(r.k * NX + q) * D + r.c];
+        for (int q = 0; q < NX; ++q) colb[e][q] = jblk[(r.k * NX + q) * SD::JBS + r.c];
         xo[e] = xsc + r.xb; uo[e] = xsc + r.ub; xst[e] = xsc + r.px;
         dcol[e] = Dt + NNODES * NNP + (r.c < NX ? r.k : NNODES) * NNP;   // column node k of D~ (the all-zero row for a control column)
         nuo[e] = dsc + r.xb; nuc[e] = dsc + (r.c < NX ? r.c : 0);
@@ -137,7 +138,7 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
     double rhoA = rho_of(typA, rho), rinvA = 1.0 / rhoA;
     double bi[D];                           // row ci of A inside its own node's columns
 #pragma unroll
-    for (int c = 0; c < D; ++c) bi[c] = jblk[ci * D + c];
+    for (int c = 0; c < D; ++c) bi[c] = jblk[ci * SD::JBS + c];
     const double* drow = Dt + ni * NNP;     // row node ni of D~
     const double* xoi = xsc + ni * NX; const double* uoi = xsc + VARX + ni * NU; const double* xsi = xsc + si;
     double* dst = dsc + pc;
@@ -173,13 +174,13 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
     // (A v)_ci, v = xsc: own block fma chain over c ascending, then every node kk ascending with the row's D~ coefficient (0 outside its segment and
     // on the own node), read from the table two at a time
     auto arow = [&]() -> double {
-        double vo[D], vn[NNODES]; d2 dc[NNP / 2];
+        double vo[D], vn[NNODES]; d2 dc[NNR / 2];
 #pragma unroll
         for (int c = 0; c < NX; ++c) vo[c] = xoi[c];
 #pragma unroll
         for (int c = 0; c < NU; ++c) vo[NX + c] = uoi[c];
 #pragma unroll
-        for (int kk = 0; kk < NNP / 2; ++kk) dc[kk] = *reinterpret_cast<const d2*>(drow + 2 * kk);
+        for (int kk = 0; kk < NNR / 2; ++kk) dc[kk] = *reinterpret_cast<const d2*>(drow + 2 * kk);
 #pragma unroll
         for (int kk = 0; kk < NNODES; ++kk) vn[kk] = xsi[kk * NX];
         double a = 0.0;
@@ -191,11 +192,11 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
     };
     // (A' nu)_g for slot e, nu = dsc: the own node's rows q ascending, then every row node kr ascending
     auto acol = [&](int e) -> double {
-        double vo[NX], vn[NNODES]; d2 dc[NNP / 2];
+        double vo[NX], vn[NNODES]; d2 dc[NNR / 2];
 #pragma unroll
         for (int q = 0; q < NX; ++q) vo[q] = nuo[e][q];
 #pragma unroll
-        for (int kr = 0; kr < NNP / 2; ++kr) dc[kr] = *reinterpret_cast<const d2*>(dcol[e] + 2 * kr);
+        for (int kr = 0; kr < NNR / 2; ++kr) dc[kr] = *reinterpret_cast<const d2*>(dcol[e] + 2 * kr);
 #pragma unroll
         for (int kr = 0; kr < NNODES; ++kr) vn[kr] = nuc[e][kr * NX];
         double a = 0.0;
@@ -288,7 +289,7 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
 #pragma unroll
                 for (int q = 0; q < NX; ++q)
 #pragma unroll
-                    for (int cc = 0; cc < D; ++cc) jb[q][cc] = jbF[(kk * NX + q) * D + cc];      // own blocks of the rows of node kk (wave-uniform addresses)
+                    for (int cc = 0; cc < D; ++cc) jb[q][cc] = jbF[(kk * NX + q) * SD::JBS + cc];      // own blocks of the rows of node kk (wave-uniform addresses)
 #pragma unroll
                 for (int nj = 0; nj < NNODES; ++nj) dco[nj] = SD::coupled(nj, kk) ? DmF[SD::dti(nj, kk)] : 0.0;   // D~(nj, kk) of the row nodes coupled to kk
                 sched_fence();

@@ -1,5 +1,5 @@
 """Comparison of two solution sets of one synthetic batch (numpy only — no solver arithmetic, no oracle): the record that the bench line, the GPU
-parity tests, the oracle pin tests and oracle/cross_order.py share when they put a run next to the reference-order run."""
+parity tests, the pin tests of the CPU checker and its cross-order tool share when they put a run next to the reference-order run."""
 import numpy as np
 
 

@@ -112,8 +112,11 @@ def test_bench_gpus_flag_starts_the_ranks(tmp_path):
                           "--cpu-sample", "0", "--configs", "", "--no-replay", "--min-seconds", "0.2", "--detail-out", str(tmp_path / "detail.json")],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1 and len(lines[0]) < 4096, lines     # stdout is the ONE compact contract line (the detail goes to the file and to stderr)
+    allout = [l for l in out.stdout.splitlines() if l.strip()]
+    lines = [l for l in allout if l.startswith("{")]
+    # stdout carries ONE JSON line, the compact contract line, and it is the LAST line (the detail goes to the file and to stderr; the gloo
+    # backend of this developer configuration prints its own "[Gloo] Rank ..." connection notes in front of it)
+    assert len(lines) == 1 and len(lines[0]) < 4096 and allout[-1] == lines[0], allout
     j = json.loads(lines[0])
     assert j["timed_blocks"]["blocks"] >= 2                     # the timed block was repeated; both ranks agreed on the count (the barriers paired up)
     assert json.load(open(tmp_path / "detail.json"))["n_gpus"] == 2

@@ -187,8 +187,11 @@ struct LSFilterHandle {
     double beta = 1e-5;
     LSFilterHandle() = default;
     LSFilterHandle(const LSFilterHandle& o) : max_depth(o.max_depth), beta(o.beta) {}   // a copied solver starts with empty filters
-    LSFilterHandle& operator=(const LSFilterHandle& o) { max_depth = o.max_depth; beta = o.beta; return *this; }
-    ~LSFilterHandle() { if (m_dev) pmpc_filter_state_destroy(m_ctx, m_dev); }
+    // assignment: the settings of `o`, and EMPTY filters — the device list this object held (sized for ITS batch, filled by ITS solves) is released, so
+    // that the next bind() creates one for the batch the assigned-to solver now has (a list kept across an assignment from a larger batch was indexed
+    // out of bounds by the kernel)
+    LSFilterHandle& operator=(const LSFilterHandle& o) { if (this != &o) { release(); max_depth = o.max_depth; beta = o.beta; } return *this; }
+    ~LSFilterHandle() { release(); }
     void clear() noexcept { if (m_dev) pmpc_filter_state_clear(m_ctx, m_B, m_dev); }    // LSFilter::clear(), line_search.hpp:52
     // number of pairs and the pairs (cost, violation), newest first, of instance b (downloaded on demand)
     std::vector<std::pair<double, double>> entries(int b) const {
@@ -204,6 +207,7 @@ struct LSFilterHandle {
     pmpc_status bind(pmpc_context* ctx, int B, int line_search, pmpc_sqp_settings& ss) noexcept {
         ss.line_search = line_search; ss.filter_max_depth = max_depth; ss.filter_beta = beta; ss.filter_state = nullptr;
         if (line_search != 1) return PMPC_OK;
+        if (m_dev && (m_B != B || m_ctx != ctx)) release();   // (another batch size or context: a fresh, empty list)
         if (!m_dev) {
             const pmpc_status st = pmpc_filter_state_create(ctx, B, &m_dev);
             if (st != PMPC_OK) return st;
@@ -213,6 +217,7 @@ struct LSFilterHandle {
         return PMPC_OK;
     }
 private:
+    void release() noexcept { if (m_dev) pmpc_filter_state_destroy(m_ctx, m_dev); m_dev = nullptr; m_ctx = nullptr; m_B = 0; }
     double* m_dev = nullptr; pmpc_context* m_ctx = nullptr; int m_B = 0;
 };
 using qp_solver_settings_t = pmpc_qp_settings;   // same member names as qp_base.hpp:17-53 (ADMM subset)

@@ -73,6 +73,13 @@ typedef struct {
     double rho_estimate, res_prim, res_dual;
 } pmpc_qp_info;
 #define PMPC_FLAG_NONFINITE 1
+/* PMPC_FLAG_ILLCOND: information, not an error. The kernels that eliminate boxADMM's diagonal constraint block first (the defaults: they invert / factorise
+ * S = H + sigma I + rho_box + A' diag(rho) A instead of the (n + m)-row KKT matrix of box_admm.hpp:209-223) estimate cond(S) at every factorisation
+ * (largest diagonal entry / smallest pivot). While the directions A leaves free are bounded variables that estimate stays ~1e5 whatever rho is, and these
+ * kernels follow the exact-arithmetic ADMM more closely than the reference's pivoted LDL^T does; when unbounded variables span them it grows with rho.
+ * Beyond 1e10 the QP (one-row-per-lane kernels: from that factorisation on) or the whole instance (the other kernels: a second launch) is solved in the
+ * full KKT form, and this bit says so. pmpc_sqp_settings::kkt_form = 1 asks for the full form from the start. */
+#define PMPC_FLAG_ILLCOND 2
 
 /* sqp_settings_t (sqp_base.hpp:24-47) + the two override points the reference's tests use:
  * regularisation: 0 none (default hook, sqp_base.hpp:305), 1 eigenvalue mirroring (sqp_test_autodiff.cpp:29-45; Jacobi iteration in LDS, needs
@@ -125,7 +132,8 @@ typedef enum { PMPC_SQP_SOLVED = 0, PMPC_SQP_MAX_ITER_EXCEEDED = 1, PMPC_SQP_INV
 typedef struct {
     int iter, qp_solver_iter, status;
     int flags;   /* PMPC_FLAG_NONFINITE: OR of the pmpc_qp_info::flags of every QP of the solve, and set whenever the returned x or lam holds a
-                  * non-finite value, whatever produced it (e.g. a warm start from an unconverged iterate that diverges) */
+                  * non-finite value, whatever produced it (e.g. a warm start from an unconverged iterate that diverges);
+                  * PMPC_FLAG_ILLCOND: a QP of the solve tripped the conditioning gate (see above) */
     double primal_norm, dual_norm, max_violation, cost;
 } pmpc_sqp_info;
 

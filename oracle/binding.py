@@ -14,7 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liboracle.so")
 REF_PATH = os.path.join(HERE, "_ref", "libref_casadi_robot.so")
 
-PIVOT_EIGEN, PIVOT_STATIC, PIVOT_SWEEP, PIVOT_SWEEP1, PIVOT_SWEEP2, PIVOT_BLOCKED, PIVOT_CONDENSED, PIVOT_SCHUR, PIVOT_CONDSWEEP = 0, 1, 2, 3, 4, 5, 6, 7, 8
+PIVOT_EIGEN, PIVOT_STATIC, PIVOT_SWEEP, PIVOT_SWEEP1, PIVOT_SWEEP2, PIVOT_BLOCKED, PIVOT_CONDENSED, PIVOT_SCHUR, PIVOT_CONDSWEEP, PIVOT_EXACT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+FLAG_ILLCOND = 2   # qp / sqp info flags: the conditioning gate of the condensed / constraint-first orders tripped (BoxADMM::COND_GATE)
 SCHUR_MAX_ROWS = 64    # PIVOT_SCHUR restates the block-structured kernel: at most 64 constraint rows (its m x m Schur complement is swept like PIVOT_SWEEP)
 SWEEP2_MAX_ROWS = 128   # PIVOT_SWEEP2 restates the two-rows-per-lane register kernel (65..128 KKT rows)
 
@@ -38,7 +39,7 @@ class QPSettings(C.Structure):
 
 
 class QPInfo(C.Structure):
-    _fields_ = [("status", C.c_int), ("iter", C.c_int), ("rho_updates", C.c_int), ("rho_estimate", C.c_double),
+    _fields_ = [("status", C.c_int), ("iter", C.c_int), ("rho_updates", C.c_int), ("flags", C.c_int), ("rho_estimate", C.c_double),
                 ("res_prim", C.c_double), ("res_dual", C.c_double)]
 
 
@@ -75,7 +76,7 @@ def bind_filter_state(ss, state):
 
 
 class SQPInfo(C.Structure):
-    _fields_ = [("iter", C.c_int), ("qp_solver_iter", C.c_int), ("status", C.c_int), ("primal_norm", C.c_double),
+    _fields_ = [("iter", C.c_int), ("qp_solver_iter", C.c_int), ("status", C.c_int), ("flags", C.c_int), ("primal_norm", C.c_double),
                 ("dual_norm", C.c_double), ("max_violation", C.c_double), ("cost", C.c_double)]
 
 

@@ -79,7 +79,7 @@ static void qp_solve_batch_f32_impl(int B, int n, int m, const float* H, const f
                 xub + (size_t)b * n, x0 ? x0 + (size_t)b * n : nullptr, y0 ? y0 + (size_t)b * (n + m) : nullptr);
         for (int i = 0; i < n; ++i) x[(size_t)b * n + i] = q.x[i];
         for (int i = 0; i < n + m; ++i) y[(size_t)b * (n + m) + i] = q.y[i];
-        info[b].status = q.info.status; info[b].iter = q.info.iter; info[b].rho_updates = q.info.rho_updates;
+        info[b].status = q.info.status; info[b].iter = q.info.iter; info[b].rho_updates = q.info.rho_updates; info[b].flags = 0;
         info[b].rho_estimate = q.info.rho_estimate; info[b].res_prim = q.info.res_prim; info[b].res_dual = q.info.res_dual;
     }
 }
@@ -139,7 +139,7 @@ void orc_qp_admm_solve_batch(int B, int n, int m, const double* H, const double*
                  xub + (size_t)b * n, x0 ? x0 + (size_t)b * n : nullptr, y0 ? y0 + (size_t)b * (n + m) : nullptr);
         for (int i = 0; i < n; ++i) x[(size_t)b * n + i] = qp.x[i];
         for (int i = 0; i < n + m; ++i) y[(size_t)b * (n + m) + i] = qp.y[i];
-        info[b].status = qp.info.status; info[b].iter = qp.info.iter; info[b].rho_updates = qp.info.rho_updates;
+        info[b].status = qp.info.status; info[b].iter = qp.info.iter; info[b].rho_updates = qp.info.rho_updates; info[b].flags = 0;
         info[b].rho_estimate = qp.info.rho_estimate; info[b].res_prim = qp.info.res_prim; info[b].res_dual = qp.info.res_dual;
     }
 }
@@ -194,9 +194,17 @@ void orc_qp_solve_batch(int B, int n, int m, const double* H, const double* h, c
         const double* xl = xlb + (size_t)b * n; const double* xu = xub + (size_t)b * n;
         if (x0 && y0) qp.solve(Hb, hb, Ab, alb, aub, xl, xu, x0 + (size_t)b * n, y0 + (size_t)b * (n + m));
         else qp.solve(Hb, hb, Ab, alb, aub, xl, xu);
+        if (qp.gives_up() && pivot == PIVOT_SWEEP) {   // the product's QP entry point: redo launch on the LDS-resident kernel (static LDL^T), flag kept
+            BoxADMM qp2(n, m);
+            qp2.settings = to_qp(s); qp2.pivot = PIVOT_STATIC;
+            if (x0 && y0) qp2.solve(Hb, hb, Ab, alb, aub, xl, xu, x0 + (size_t)b * n, y0 + (size_t)b * (n + m));
+            else qp2.solve(Hb, hb, Ab, alb, aub, xl, xu);
+            qp2.info.flags |= QP_FLAG_ILLCOND;
+            qp.x = qp2.x; qp.y = qp2.y; qp.info = qp2.info;
+        }
         std::memcpy(x + (size_t)b * n, qp.x.data(), sizeof(double) * n);
         std::memcpy(y + (size_t)b * (n + m), qp.y.data(), sizeof(double) * (n + m));
-        info[b].status = qp.info.status; info[b].iter = qp.info.iter; info[b].rho_updates = qp.info.rho_updates;
+        info[b].status = qp.info.status; info[b].iter = qp.info.iter; info[b].rho_updates = qp.info.rho_updates; info[b].flags = qp.info.flags;
         info[b].rho_estimate = qp.info.rho_estimate; info[b].res_prim = qp.info.res_prim; info[b].res_dual = qp.info.res_dual;
     }
 }
@@ -278,13 +286,29 @@ static void sqp_batch_impl(int P, int S, double t0, double tf, const double* mp,
         if (ss->filter_state) sqp.filter.load(ss->filter_state + (size_t)b * ORC_FILTER_STATE_DOUBLES);
         if (ss->iteration_trace) { sqp.trace = ss->iteration_trace + (size_t)b * ss->iteration_trace_capacity * ORC_TRACE_DOUBLES; sqp.trace_capacity = ss->iteration_trace_capacity; }
         sqp.solve();
-        if (ss->filter_state) sqp.filter.store(ss->filter_state + (size_t)b * ORC_FILTER_STATE_DOUBLES);
-        const int n = sqp.n, m = sqp.m;
-        std::memcpy(x + (size_t)b * n, sqp.x.data(), sizeof(double) * n);
-        std::memcpy(lam + (size_t)b * (m + n), sqp.lam.data(), sizeof(double) * (m + n));
-        info[b].iter = sqp.info.iter; info[b].qp_solver_iter = sqp.info.qp_solver_iter; info[b].status = sqp.info.status;
-        info[b].primal_norm = sqp.primal_norm; info[b].dual_norm = sqp.dual_norm;
-        info[b].max_violation = sqp.max_violation; info[b].cost = sqp.cost_;
+        auto store = [&](SQP<ContinuousOCP<Model>>& s, int extra_flags) {
+            if (ss->filter_state) s.filter.store(ss->filter_state + (size_t)b * ORC_FILTER_STATE_DOUBLES);
+            const int n = s.n, m = s.m;
+            std::memcpy(x + (size_t)b * n, s.x.data(), sizeof(double) * n);
+            std::memcpy(lam + (size_t)b * (m + n), s.lam.data(), sizeof(double) * (m + n));
+            info[b].iter = s.info.iter; info[b].qp_solver_iter = s.info.qp_solver_iter; info[b].status = s.info.status; info[b].flags = s.info.flags | extra_flags;
+            info[b].primal_norm = s.primal_norm; info[b].dual_norm = s.dual_norm;
+            info[b].max_violation = s.max_violation; info[b].cost = s.cost_;
+        };
+        if (sqp.info.status == SQP_REDO) {
+            // a QP of the condensed orders gave up at its conditioning gate (BoxADMM::COND_GATE): the instance is solved again from its guesses in the full
+            // KKT form — what the product's redo launch does (pmpc_launch.hpp): the LDS-resident static LDL^T behind the one-row-per-lane kernel, the
+            // two-rows-per-lane full inverse behind the condensed register kernel, the (n + m)-row blocked LDL^T behind the large-instance kernel
+            const int redo = (int)BoxADMM::redo_policy((pivot_policy)pivot);
+            ContinuousOCP<Model> ocp2(P, S, make_model<Model>(mp, nmp));
+            ocp2.set_time_limits(t0, tf);
+            SQP<ContinuousOCP<Model>> sqp2(ocp2, Model::ND);
+            setup_solver<Model>(sqp2, b, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, redo);
+            if (ss->filter_state) sqp2.filter.load(ss->filter_state + (size_t)b * ORC_FILTER_STATE_DOUBLES);
+            if (ss->iteration_trace) { sqp2.trace = ss->iteration_trace + (size_t)b * ss->iteration_trace_capacity * ORC_TRACE_DOUBLES; sqp2.trace_capacity = ss->iteration_trace_capacity; }
+            sqp2.solve();
+            store(sqp2, QP_FLAG_ILLCOND);
+        } else store(sqp, 0);
     }
 }
 
@@ -332,7 +356,7 @@ static void nlp_impl(const double* x0, const double* lam0, const double* lbx, co
     sqp.solve(x0, lam0 ? lam0 : lz.data());
     std::memcpy(x, sqp.x.data(), sizeof(double) * n);
     std::memcpy(lam, sqp.lam.data(), sizeof(double) * (m + n));
-    info->iter = sqp.info.iter; info->qp_solver_iter = sqp.info.qp_solver_iter; info->status = sqp.info.status;
+    info->iter = sqp.info.iter; info->qp_solver_iter = sqp.info.qp_solver_iter; info->status = sqp.info.status; info->flags = sqp.info.flags;
     info->primal_norm = sqp.primal_norm; info->dual_norm = sqp.dual_norm; info->max_violation = sqp.max_violation;
     info->cost = sqp.cost_;
 }

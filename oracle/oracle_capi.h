@@ -18,7 +18,7 @@ typedef struct {
 } orc_qp_settings;
 
 typedef struct {
-    int status, iter, rho_updates;
+    int status, iter, rho_updates, flags;   /* flags: 2 = the conditioning gate of the condensed / constraint-first orders tripped */
     double rho_estimate, res_prim, res_dual;
 } orc_qp_info;
 
@@ -42,7 +42,7 @@ typedef struct {
 enum { ORC_FILTER_STATE_DOUBLES = 21, ORC_TRACE_DOUBLES = 8 };
 
 typedef struct {
-    int iter, qp_solver_iter, status;
+    int iter, qp_solver_iter, status, flags;   /* flags: 2 = a QP gave up at the conditioning gate and the instance was re-solved in the full KKT form */
     double primal_norm, dual_norm, max_violation, cost;
 } orc_sqp_info;
 

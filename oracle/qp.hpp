@@ -25,6 +25,10 @@
 //   PIVOT_SWEEP2 : PIVOT_SWEEP's blocked sweep for 65..128 rows with the mat-vec order of the two-rows-per-lane register kernel
 //   PIVOT_SWEEP1 : the swept inverse of PIVOT_SWEEP one pivot at a time on the lower triangle (any size), x = -(W b) as one fma chain
 //                  per row: accuracy evidence for the explicit-inverse route above 64 rows (no shipped kernel uses it this round).
+//   PIVOT_EXACT  : (round 5) not a kernel order — PIVOT_EIGEN's factor used as a preconditioner for iterative refinement with residuals in
+//                  long double (x87 extended, 64-bit mantissa) until the correction stalls: the linear solves of the ADMM to working accuracy,
+//                  i.e. the trajectory of exact arithmetic as far as fp64 can state it. The yardstick that tells WHICH of two orders that
+//                  disagree at a large penalty is the inexact one (tests/test_oracle_pins.py).
 //   PIVOT_SCHUR  : (round 4) the order of the block-structured kernel (polympc_amd/csrc/pmpc_qp_schur.hpp) that serves a Hessian which is
 //                  block diagonal per collocation node — what ContinuousOCP's block BFGS (continuous_ocp.hpp:2304-2431) and the exact Lagrangian
 //                  Hessian keep. The per-node blocks of H + sigma I + rho_box are inverted one by one, the m x m Schur complement
@@ -41,7 +45,7 @@
 namespace oracle {
 
 enum qp_status { QP_SOLVED = 0, QP_MAX_ITER_EXCEEDED = 1, QP_UNSOLVED = 2, QP_UNINITIALIZED = 3, QP_INFEASIBLE = 4, QP_INCONSISTENT = 5 };
-enum pivot_policy { PIVOT_EIGEN = 0, PIVOT_STATIC = 1, PIVOT_SWEEP = 2, PIVOT_SWEEP1 = 3, PIVOT_SWEEP2 = 4, PIVOT_BLOCKED = 5, PIVOT_CONDENSED = 6, PIVOT_SCHUR = 7, PIVOT_CONDSWEEP = 8 };
+enum pivot_policy { PIVOT_EIGEN = 0, PIVOT_STATIC = 1, PIVOT_SWEEP = 2, PIVOT_SWEEP1 = 3, PIVOT_SWEEP2 = 4, PIVOT_BLOCKED = 5, PIVOT_CONDENSED = 6, PIVOT_SCHUR = 7, PIVOT_CONDSWEEP = 8, PIVOT_EXACT = 9 };
 
 struct qp_settings {  // qp_base.hpp:17-53 (ADMM-related subset)
     double eps_rel = 1e-3, eps_abs = 1e-3;
@@ -60,7 +64,9 @@ struct qp_info {  // qp_base.hpp:64-72
     int rho_updates = 0;
     double rho_estimate = 0;
     double res_prim = 1, res_dual = 1;
+    int flags = 0;   // QP_FLAG_ILLCOND: the conditioning gate of the condensed / constraint-first orders tripped (BoxADMM::COND_GATE)
 };
+enum { QP_FLAG_ILLCOND = 2 };   // = PMPC_FLAG_ILLCOND of include/polympc_amd.h
 
 // ---------------------------------------------------------------------------------------------
 // LDL^T of a symmetric matrix given by its LOWER triangle (Appendix B of SURVEY.md)
@@ -70,9 +76,18 @@ struct LDLT {
     std::vector<double> M;   // factor: unit-lower L below the diagonal, D on the diagonal
     std::vector<int> tr;     // transpositions
     std::vector<double> temp;
+    double piv_min_abs = 0.0;   // smallest |pivot| of the static / swept orders (the conditioning gate of BoxADMM reads it)
+    bool exact = false;         // PIVOT_EXACT: refine every solve against K0 in long double
+    std::vector<double> K0;     // PIVOT_EXACT: the matrix itself, full symmetric storage
 
     void compute(const std::vector<double>& K, int n_, pivot_policy pol) {
         n = n_; policy = pol; M = K; tr.assign(n, 0); temp.assign(n, 0.0);
+        exact = policy == PIVOT_EXACT;
+        if (exact) {
+            policy = PIVOT_EIGEN;
+            K0 = K;
+            for (int j = 0; j < n; ++j) for (int i = 0; i < j; ++i) K0[i + j * n] = K0[j + i * n];
+        }
         if (policy == PIVOT_STATIC || policy == PIVOT_BLOCKED) { compute_static(); return; }
         if (policy == PIVOT_SWEEP1) { compute_sweep1(); return; }
         if (policy == PIVOT_SWEEP2) {  // the two-rows-per-lane register kernel (pmpc_qp_reg2.hpp): the same blocked sweep on 65..128 rows
@@ -119,8 +134,10 @@ struct LDLT {
         auto at = [&](int i, int j) -> double& { return M[i + j * n]; };
         for (int k = 0; k < n; ++k) tr[k] = k;
         std::vector<double> col(n);
+        piv_min_abs = std::numeric_limits<double>::infinity();
         for (int k = 0; k < n; ++k) {
             const double dk = at(k, k);
+            piv_min_abs = std::fmin(piv_min_abs, std::fabs(dk));
             for (int i = k + 1; i < n; ++i) { col[i] = at(i, k); at(i, k) = col[i] / dk; }
             for (int j = k + 1; j < n; ++j) {
                 const double ljk = at(j, k);
@@ -167,11 +184,13 @@ struct LDLT {
         const int BK = 4;   // block size of the kernel (RegKkt::BK)
         const int lim = npiv < 0 ? n : npiv;
         std::vector<double> p((size_t)n * BK), cold((size_t)n * BK), l(n);
+        piv_min_abs = std::numeric_limits<double>::infinity();
         for (int kb = 0; kb < lim; kb += BK) {
             const int w = std::min(BK, lim - kb);
             for (int t = 0; t < w; ++t) for (int i = 0; i < n; ++i) { p[i * BK + t] = at(i, kb + t); cold[i * BK + t] = p[i * BK + t]; }
             for (int t = 0; t < w; ++t) {
                 const int k = kb + t;
+                piv_min_abs = std::fmin(piv_min_abs, std::fabs(p[k * BK + t]));
                 const double r = 1.0 / p[k * BK + t];
                 for (int i = 0; i < n; ++i) l[i] = p[i * BK + t] * r;
                 for (int u = 0; u < w; ++u) {
@@ -198,6 +217,30 @@ struct LDLT {
     }
 
     void solve(const double* b, double* x) const {
+        if (exact) {
+            std::vector<long double> xl(n), r(n);
+            std::vector<double> rd(n), dx(n);
+            solve_plain(b, x);
+            for (int i = 0; i < n; ++i) xl[i] = x[i];
+            long double prev = -1.0L;
+            for (int it = 0; it < 12; ++it) {
+                long double rn = 0.0L;
+                for (int i = 0; i < n; ++i) {
+                    long double a = b[i];
+                    for (int j = 0; j < n; ++j) a -= (long double)K0[i + j * n] * xl[j];
+                    r[i] = a; rd[i] = (double)a; rn = std::fmax(rn, std::fabs(a));
+                }
+                if (rn == 0.0L || (prev >= 0.0L && rn >= prev)) break;   // the correction stalls
+                prev = rn;
+                solve_plain(rd.data(), dx.data());
+                for (int i = 0; i < n; ++i) xl[i] += dx[i];
+            }
+            for (int i = 0; i < n; ++i) x[i] = (double)xl[i];
+            return;
+        }
+        solve_plain(b, x);
+    }
+    void solve_plain(const double* b, double* x) const {
         auto at = [&](int i, int j) -> double { return M[i + j * n]; };
         if (policy == PIVOT_SWEEP1) {   // x = -(W b): one fma chain per row, columns ascending
             for (int i = 0; i < n; ++i) { double a = 0.0; for (int j = 0; j < n; ++j) a = std::fma(at(i, j), b[j], a); x[i] = -a; }
@@ -281,6 +324,18 @@ struct BoxADMM {
     LDLT ldlt;
     double rho = 0, max_Ax_z_norm = 0, max_Hx_ATy_h_norm = 0;
     int iter = 0;
+    // Conditioning gate of the orders that eliminate the diagonal constraint block first (PIVOT_SWEEP's constraint-first sweep, PIVOT_CONDSWEEP,
+    // PIVOT_CONDENSED): they invert / factorise S = P + A' diag(rho) A, whose condition number is rho_eq |A|^2 / lambda_min(P on the null space of A).
+    // With bounded controls (every BASELINE workload) that is ~1e5 whatever rho is — rho_box scales with rho — and these orders are MORE accurate than
+    // the pivoted LDL^T of the quasi-definite form; when unbounded variables (rho_box = RHO_MIN) span the null space of A it grows with rho and the
+    // condensed solve loses cond(S) eps. Estimate at every factorisation: max_i S_ii / min_k |pivot_k| (within a factor 2..10 below cond(S) on the
+    // benchmark streams and their unbounded variants); beyond COND_GATE
+    // these orders give the QP up (status QP_UNSOLVED, flag set): the drivers (SQP: the whole instance, from its guesses; the QP entry point: the QP)
+    // solve it again in the full KKT form, as the product's redo launches do — PIVOT_SWEEP -> PIVOT_STATIC (the LDS-resident static LDL^T),
+    // PIVOT_CONDSWEEP -> PIVOT_SWEEP2 (the two-rows-per-lane full inverse), PIVOT_CONDENSED -> PIVOT_BLOCKED (the (n + m)-row blocked LDL^T).
+    static constexpr double COND_GATE = 1e10;
+    bool illcond = false;
+    double cond_estimate = 0.0;
 
     BoxADMM(int n, int m) : N(n), M(m) {
         x.assign(N, 0); y.assign(N + M, 0); x_tilde.assign(N, 0); q.assign(N, 0);
@@ -513,6 +568,10 @@ struct BoxADMM {
     //   M(a, b)      = K(a, b), then fma(rho_j A(j, a), A(j, b), .) for j ascending       (a, b primal; block-lower tiles, diagonal tiles in full)
     //   M(n + j, b)  = M(b, n + j) = -(rho_j A(j, b)),   M(n + j, n + j') = [j == j'] rho_j
     // then PIVOT_SWEEP's blocked sweep over the pivots [0, n). W = -K^{-1} as before; the mat-vec of solve() is unchanged.
+    bool gate_trips(double smax) {   // (NaN operands: no trip — a non-finite solve is reported by its own flag)
+        cond_estimate = smax / ldlt.piv_min_abs;
+        return smax > COND_GATE * ldlt.piv_min_abs;
+    }
     void factorise_sweep_cf() {
         const int NM = N + M;
         std::vector<double> Mm((size_t)NM * NM, 0.0);
@@ -531,9 +590,12 @@ struct BoxADMM {
             }
             Mm[(N + j) + (size_t)(N + j) * NM] = rho_vec[j];
         }
+        double smax = 0.0;
+        for (int a = 0; a < N; ++a) smax = std::fmax(smax, std::fabs(Mm[a + (size_t)a * NM]));
         ldlt.n = NM; ldlt.policy = PIVOT_SWEEP; ldlt.M.swap(Mm); ldlt.tr.assign(NM, 0); ldlt.temp.assign(NM, 0.0);
         if (NM > 64) throw std::invalid_argument("oracle: PIVOT_SWEEP restates the 64-row register kernel; use PIVOT_STATIC / PIVOT_EIGEN for larger systems");
         ldlt.compute_sweep(true, N);
+        if (gate_trips(smax)) { illcond = true; info.flags |= QP_FLAG_ILLCOND; }
     }
     // PIVOT_CONDSWEEP (the condensed register kernel, pmpc_qp_cond.hpp): the constraint block of K is eliminated in closed form as in factorise_sweep_cf,
     // but the constraint rows are not carried at all — only S = P + A' diag(rho) A (n x n; block-lower 16 x 16 tiles, diagonal tiles in full) is swept,
@@ -552,8 +614,11 @@ struct BoxADMM {
                 for (int j = 0; j < M; ++j) v = std::fma(rho_vec[j] * K[(N + j) + a * NM], K[(N + j) + b * NM], v);
                 Mm[a + (size_t)b * N] = v;
             }
+        double smax = 0.0;
+        for (int a = 0; a < N; ++a) smax = std::fmax(smax, std::fabs(Mm[a + (size_t)a * N]));
         ldlt.n = N; ldlt.policy = N <= 64 ? PIVOT_SWEEP : PIVOT_SWEEP2; ldlt.M.swap(Mm); ldlt.tr.assign(N, 0); ldlt.temp.assign(N, 0.0);
         ldlt.compute_sweep(true);
+        if (gate_trips(smax)) { illcond = true; info.flags |= QP_FLAG_ILLCOND; }
     }
     // the two products as the kernel forms them (pmpc_qp_cond.hpp): fma chains — the differentiation-matrix entries of the column / row over the nodes
     // ascending (0 on the own node and outside the segments; a control column of the first 64 variables walks zeros), then the own node's block. Needs the
@@ -597,7 +662,12 @@ struct BoxADMM {
                 Sc[i + j * N] = a;
             }
         ldlt.compute(Sc, N, PIVOT_BLOCKED);
+        double smax = 0.0;
+        for (int a = 0; a < N; ++a) smax = std::fmax(smax, std::fabs(Sc[a + (size_t)a * N]));
+        if (gate_trips(smax)) { illcond = true; info.flags |= QP_FLAG_ILLCOND; }
     }
+    bool gives_up() const { return illcond; }
+    static pivot_policy redo_policy(pivot_policy p) { return p == PIVOT_SWEEP ? PIVOT_STATIC : (p == PIVOT_CONDSWEEP ? PIVOT_SWEEP2 : PIVOT_BLOCKED); }
     void kkt_solve(const double* rhs, double* sol) {
         if (pivot == PIVOT_SCHUR) { kkt_solve_schur(rhs, sol); return; }
         if (pivot == PIVOT_CONDSWEEP) { kkt_solve_condsweep(rhs, sol); return; }
@@ -637,10 +707,12 @@ struct BoxADMM {
         for (int i = 0; i < N; ++i) q[i] = x_guess[i];
         for (int i = 0; i < M; ++i) constr_type[i] = classify(Alb[i], Aub[i]);
         for (int i = 0; i < N; ++i) box_type[i] = classify(xlb[i], xub[i]);
+        illcond = false; info.flags = 0;
         rho_vec_update(settings.rho);
         construct_kkt(H, A);
         factorise();
         info.status = QP_UNSOLVED;
+        if (gives_up()) { iter = 1; info.iter = 1; return info.status; }
         const double alpha = settings.alpha;
 
         for (iter = 1; iter <= settings.max_iter; iter++) {
@@ -680,6 +752,7 @@ struct BoxADMM {
                     rho_vec_update(new_rho);
                     update_kkt_rho();
                     factorise();
+                    if (gives_up()) { info.iter = iter; return info.status; }
                 }
             }
         }

@@ -135,8 +135,8 @@ struct LSFilter {
         for (size_t i = 0; i < f.size(); ++i) { st[1 + 2 * i] = f[i].first; st[2 + 2 * i] = f[i].second; }
     }
 };
-enum sqp_status { SQP_SOLVED = 0, SQP_MAX_ITER_EXCEEDED = 1, SQP_INVALID_SETTINGS = 2 };
-struct sqp_info { int iter = 0, qp_solver_iter = 0, status = SQP_MAX_ITER_EXCEEDED; };
+enum sqp_status { SQP_SOLVED = 0, SQP_MAX_ITER_EXCEEDED = 1, SQP_INVALID_SETTINGS = 2, SQP_REDO = 4 /* internal: a QP of the condensed orders gave up at its conditioning gate — the driver re-solves the instance in the full KKT form */ };
+struct sqp_info { int iter = 0, qp_solver_iter = 0, status = SQP_MAX_ITER_EXCEEDED, flags = 0; };
 
 template <class Problem>
 struct SQP {
@@ -288,6 +288,8 @@ struct SQP {
         } else {
             qp.solve(H.data(), h.data(), A.data(), al.data(), au.data(), lx.data(), ux.data());
             info.qp_solver_iter += qp.info.iter; qp_iter_last = qp.info.iter; qp_status_last = qp.info.status;
+            info.flags |= qp.info.flags;
+            qp_gave_up = qp.gives_up();
             p = qp.x; p_lambda = qp.y;
         }
         if (settings.preconditioner == 1) {
@@ -312,14 +314,17 @@ struct SQP {
         dual_norm = alpha * BoxADMM::inf_norm(p_lambda.data(), m + n);
     }
 
+    bool qp_gave_up = false;
     void solve() {  // :569-696
         info.status = SQP_MAX_ITER_EXCEEDED;
         std::vector<double> p(n), p_lambda(m + n, 0.0);
         info.qp_solver_iter = 0;
         info.iter = 1;
+        info.flags = 0; qp_gave_up = false;
         linearisation();
         form_qp_bounds();
         solve_qp(p, p_lambda);
+        if (qp_gave_up) { info.status = SQP_REDO; return; }
         iterate_tail(p, p_lambda);
         { const bool done = termination_criteria(); record(); if (done) { info.status = SQP_SOLVED; return; } }
         while (info.iter < settings.max_iter) {
@@ -327,6 +332,7 @@ struct SQP {
             update_linearisation();
             form_qp_bounds();
             solve_qp(p, p_lambda);
+            if (qp_gave_up) { info.status = SQP_REDO; return; }
             iterate_tail(p, p_lambda);
             const bool done = termination_criteria(); record();
             if (done) { info.status = SQP_SOLVED; break; }

@@ -14,6 +14,7 @@ MODEL_ROBOT, MODEL_CSTR, MODEL_PARKING, MODEL_ROBOT_NG, MODEL_KITE_STANDIN, MODE
 QP_SOLVED, QP_MAX_ITER_EXCEEDED, QP_UNSOLVED = 0, 1, 2
 SQP_SOLVED, SQP_MAX_ITER_EXCEEDED = 0, 1
 FLAG_NONFINITE = 1   # pmpc_qp_info / pmpc_sqp_info flags: a non-finite value went through a QP solve
+FLAG_ILLCOND = 2     # the conditioning gate of the constraint-first / condensed kernels tripped: solved in the full KKT form (information)
 
 ABI_VERSION = 4   # PMPC_ABI_VERSION of include/polympc_amd.h that the ctypes layouts below mirror
 ROUTE_NONE, ROUTE_REG1, ROUTE_REG2, ROUTE_LDS, ROUTE_HBM, ROUTE_SCHUR, ROUTE_CONDREG = 0, 1, 2, 3, 4, 5, 6   # pmpc_route

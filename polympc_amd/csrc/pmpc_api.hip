@@ -35,10 +35,12 @@ __global__ __launch_bounds__(64) void qp_boxadmm_kernel(int B, int n, int m, con
                                                         const double* __restrict__ xlb, const double* __restrict__ xub,
                                                         const double* __restrict__ x0, const double* __restrict__ y0,
                                                         pmpc_qp_settings s, double* __restrict__ x, double* __restrict__ y,
-                                                        pmpc_qp_info* __restrict__ info) {
+                                                        pmpc_qp_info* __restrict__ info, int redo) {
     extern __shared__ double smem[];
     const int b = blockIdx.x;
     if (b >= B) return;
+    // redo launch behind a one-row-per-lane register kernel: only the QPs that gave up at their conditioning gate (PMPC_FLAG_ILLCOND)
+    if (redo && (__builtin_amdgcn_readfirstlane(info[b].flags) & PMPC_FLAG_ILLCOND) == 0) return;
     QpLds w;
     double* p = w.carve(smem, n, m);
     // stage the vectors the ADMM loop touches every iteration: h, Alb, Aub, xlb, xub
@@ -52,6 +54,7 @@ __global__ __launch_bounds__(64) void qp_boxadmm_kernel(int B, int n, int m, con
                   x0 ? x0 + (size_t)b * n : nullptr, y0 ? y0 + (size_t)b * (n + m) : nullptr, s, qi);
     for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = w.x[i];
     for (int i = ln; i < n + m; i += WAVE) y[(size_t)b * (n + m) + i] = w.y[i];
+    if (redo) qi.flags |= PMPC_FLAG_ILLCOND;   // (information for the caller: this QP took the full KKT form)
     if (ln == 0) info[b] = qi;
 }
 // register-resident specialisation for compile-time (NN, MM), NN+MM <= 64
@@ -100,6 +103,7 @@ extern "C" int pmpc_internal_sqp_slice(pmpc_context* ctx) { return ctx ? ctx->sq
 extern "C" int pmpc_internal_sqp_rr(pmpc_context* ctx) { return ctx ? ctx->sqp_rr : 0; }
 extern "C" int pmpc_internal_simd_count(pmpc_context* ctx) { return ctx ? ctx->simd_count : 1024; }
 extern "C" void pmpc_internal_set_route(pmpc_context* ctx, int route) { if (ctx) ctx->last_route = route; }
+extern "C" int pmpc_internal_last_route(pmpc_context* ctx) { return ctx ? ctx->last_route : 0; }
 
 
 // =====================================================================================================================
@@ -298,6 +302,13 @@ pmpc_status pmpc_qp_boxadmm_solve_batch_dev(pmpc_context* ctx, int B, int n, int
     if (n == NN_ && m == MM_ && static_order) {                                                                                              \
         hipLaunchKernelGGL((qp_boxadmm_reg_kernel<NN_, MM_>), dim3(B), dim3(WAVE), 0, ctx->stream, B, H, h, A, Alb, Aub, xlb, xub, x0, y0,   \
                            *settings, x, y, info);                                                                                           \
+        /* redo launch: the QPs that gave up at the conditioning gate of the constraint-first sweep, on the LDS-resident static LDL^T */          \
+        const size_t ldsg_ = qp_kernel_lds_bytes(n, m);                                                                                      \
+        if (ldsg_ <= ctx->lds_limit && !getenv("PMPC_NO_REDO_LAUNCH")) {                                                                     \
+            HIPCHK(hipFuncSetAttribute((const void*)qp_boxadmm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg_));             \
+            hipLaunchKernelGGL(qp_boxadmm_kernel, dim3(B), dim3(WAVE), ldsg_, ctx->stream, B, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0,      \
+                               *settings, x, y, info, 1);                                                                                    \
+        }                                                                                                                                    \
         HIPCHK(hipGetLastError());                                                                                                           \
         return PMPC_OK;                                                                                                                      \
     }
@@ -328,7 +339,7 @@ pmpc_status pmpc_qp_boxadmm_solve_batch_dev(pmpc_context* ctx, int B, int n, int
     if (lds > ctx->lds_limit) return PMPC_ERR_UNSUPPORTED_SIZE;
     HIPCHK(hipFuncSetAttribute((const void*)qp_boxadmm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(qp_boxadmm_kernel, dim3(B), dim3(WAVE), lds, ctx->stream, B, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0,
-                       *settings, x, y, info);
+                       *settings, x, y, info, 0);
     HIPCHK(hipGetLastError());
     return PMPC_OK;
 }
@@ -669,13 +680,18 @@ pmpc_status pmpc_sqp_solve_batch_multi(pmpc_context* const* ctxs, int n_ctx, int
     if (ds != PMPC_OK) return ds;
     if (B == 0) return PMPC_OK;
     const int m = me + mi;
+    // The status slots and the list of posted shards live OUTSIDE the try block and are sized before anything is posted: a worker writes its slot after
+    // this function's catch handler would have run, and whatever fails later (a worker that cannot be created, the allocation inside post()), every
+    // shard already posted is waited for before the function returns — its thread writes x / lam / info of the caller and its status slot.
+    std::vector<pmpc_status> st;
+    std::vector<int> posted;
+    try { st.assign((size_t)n_ctx, PMPC_OK); posted.reserve((size_t)n_ctx); } catch (...) { return PMPC_ERR_HIP; }
+    pmpc_status failed = PMPC_OK;
     try {   // nothing may leave an extern "C" function by exception (std::bad_alloc, std::system_error from a thread that cannot be created)
-        std::vector<pmpc_status> st((size_t)n_ctx, PMPC_OK);
-        std::vector<int> posted;
         for (int k = 0; k < n_ctx; ++k) {
             if ((long long)B * (k + 1) / n_ctx <= (long long)B * k / n_ctx) continue;
             if (!ctxs[k]->shard_worker) ctxs[k]->shard_worker = new ShardWorker();
-            if (!ctxs[k]->shard_worker->start()) { for (int j : posted) ctxs[j]->shard_worker->wait(); return PMPC_ERR_HIP; }
+            if (!ctxs[k]->shard_worker->start()) { failed = PMPC_ERR_HIP; break; }
             const long long b0 = (long long)B * k / n_ctx, b1 = (long long)B * (k + 1) / n_ctx;
             pmpc_status* out = &st[k];
             pmpc_context* ctx = ctxs[k];
@@ -685,13 +701,14 @@ pmpc_status pmpc_sqp_solve_batch_multi(pmpc_context* const* ctxs, int n_ctx, int
                                             at(d, nd), at(lbx, n), at(ubx, n), at(lbg, mi), at(ubg, mi), ss, qs, x + (size_t)b0 * n,
                                             lam + (size_t)b0 * (m + n), info + b0);
             });
-            posted.push_back(k);
+            posted.push_back(k);   // (capacity reserved above: cannot throw)
         }
-        for (int k : posted) ctxs[k]->shard_worker->wait();
-        for (int k = 0; k < n_ctx; ++k) if (st[k] != PMPC_OK) return st[k];
     } catch (...) {
-        return PMPC_ERR_HIP;
+        failed = PMPC_ERR_HIP;
     }
+    for (int k : posted) ctxs[k]->shard_worker->wait();
+    if (failed != PMPC_OK) return failed;
+    for (int k = 0; k < n_ctx; ++k) if (st[k] != PMPC_OK) return st[k];
     return PMPC_OK;
 }
 

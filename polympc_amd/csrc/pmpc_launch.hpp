@@ -19,6 +19,7 @@ extern "C" int pmpc_internal_simd_count(pmpc_context* ctx);   // SIMDs of the de
 extern "C" int pmpc_internal_sqp_slice(pmpc_context* ctx);   // SQP iterations per kernel launch (0 = whole solve in one launch)
 extern "C" int pmpc_internal_sqp_rr(pmpc_context* ctx);      // 1 (PMPC_SQP_RR=1, developer switch): batches beyond the resident wavefronts run one SQP iteration per work item (sqp_kernel_rr)
 extern "C" void pmpc_internal_set_route(pmpc_context* ctx, int route);   // records the kernel family of the launch (pmpc_sqp_last_route)
+extern "C" int pmpc_internal_last_route(pmpc_context* ctx);
 
 namespace pmpc {
 using ::pmpc_status;
@@ -68,6 +69,9 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
     const size_t lds_doubles_total = __builtin_amdgcn_groupstaticsize() / sizeof(double) + lds_dyn_doubles;
     const int b = blockIdx.x;
     if (b >= B) return;
+    // redo launch (the full-KKT-form kernel behind a condensed one): only the instances whose condensed solve gave up at its conditioning gate
+    const bool redo_launch = it_begin == PMPC_REDO_MODE;
+    if (redo_launch) { if (__builtin_amdgcn_readfirstlane(info[b].status) != PMPC_SQP_REDO) return; it_begin = 0; }
     // iteration-sliced execution: instances that finished in an earlier slice give their slot back immediately
     if (it_begin != 0 && __builtin_amdgcn_readfirstlane(info[b].status) != PMPC_SQP_IN_PROGRESS) return;
     // it_begin < 0: resume mode (the launch behind the round-robin kernel, sqp_kernel_rr below): every instance continues from the iteration its own record holds
@@ -158,12 +162,13 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
     pmpc_sqp_info si;
     if (it_begin > 0) { const pmpc_sqp_info prev = info[b]; sqp.qp_iter_total = prev.qp_solver_iter; sqp.qp_flags = prev.flags; sqp.cost_log = prev.cost; }
     sqp.solve(si, it_begin, it_end);
+    if (redo_launch) si.flags |= PMPC_FLAG_ILLCOND;   // (information for the caller: this instance took the full KKT form)
     if (si.status == PMPC_SQP_IN_PROGRESS && sst) for (int i = ln; i < n; i += WAVE) { sst[i] = v.lg[i]; sst[n + i] = v.step[i]; }
     for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = v.x[i];
     for (int i = ln; i < m + n; i += WAVE) lam[(size_t)b * (m + n) + i] = v.lam[i];
     if (ln == 0) info[b] = si;
-    if constexpr (NN == 0 || POL) {
-        if (ss.line_search == 1 && ss.filter_state != nullptr && ln < PMPC_FILTER_STATE_DOUBLES) ss.filter_state[(size_t)b * PMPC_FILTER_STATE_DOUBLES + ln] = filt[ln];
+    if constexpr (NN == 0 || POL) {   // (an instance that gave up leaves the carried filter as it found it: the redo launch starts from the same filter)
+        if (ss.line_search == 1 && ss.filter_state != nullptr && si.status != PMPC_SQP_REDO && ln < PMPC_FILTER_STATE_DOUBLES) ss.filter_state[(size_t)b * PMPC_FILTER_STATE_DOUBLES + ln] = filt[ln];
     }
     if constexpr (PROF) { if (phase_cycles && ln == 0) for (int i = 0; i < 24; ++i) atomicAdd(&phase_cycles[i], (unsigned long long)sqp.cyc[i]); }
 }
@@ -545,8 +550,26 @@ template <> struct LDS_PATH_PROFILED<KiteStandInOCP> { static constexpr bool val
 
 // Launch the fused SQP kernel for `Model` on DEVICE buffers (asynchronous on the context's stream).
 #ifndef PMPC_EXPERIMENT_SMALL_POL
-#define PMPC_EXPERIMENT_SMALL_POL 0   /* 1: ship-disabled hook variant of the small condensed kernel for line_search = 1; 2: also under the default policies (EXPERIMENTS.md) */
+#define PMPC_EXPERIMENT_SMALL_POL 0   /* 2: developer switch — the hook build of the small condensed kernel also under the DEFAULT policies (the bisection of EXPERIMENTS.md round 5, with -DPMPC_EXPERIMENT_CND_WITH_RUIZ) */
 #endif
+// Redo launch behind a one-row-per-lane register kernel (PMPC_FLAG_ILLCOND, include/polympc_amd.h): the instances whose constraint-first QP gave up at
+// its conditioning gate (none on any BASELINE workload) are solved again, from their guesses, by the LDS-resident kernel — static LDL^T of the
+// (n + m)-row KKT matrix with substitutions; every other workgroup reads one word and exits. PMPC_NO_REDO_LAUNCH=1: developer switch (timing the launch).
+template <class Model>
+inline bool launch_redo_generic(const Model& mdl, const ChebData* cd, int P, int S, int B, const double* x_guess, const double* lam_guess, const double* d,
+                                const double* lbx, const double* ubx, const double* lbg, const double* ubg, const pmpc_sqp_settings* ss,
+                                const pmpc_qp_settings* qs, double* Hws, double* Aws, double* x, double* lam, pmpc_sqp_info* info, hipStream_t stream,
+                                size_t lds_limit) {
+    if (getenv("PMPC_NO_REDO_LAUNCH")) return true;
+    const size_t ldsg = sqp_kernel_lds_bytes<Model>(P, S, 0, 0);
+    if (ldsg > lds_limit) return true;   // (systems of at most 64 rows always fit)
+    auto gk = sqp_kernel<Model>;
+    if (hipFuncSetAttribute((const void*)gk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg) != hipSuccess) return false;
+    pmpc_sqp_settings ssf = *ss; ssf.kkt_form = 1;
+    hipLaunchKernelGGL(gk, dim3(B), dim3(WAVE), ldsg, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ssf, *qs, Hws, Aws, x, lam, info,
+                       (unsigned long long*)nullptr, (double*)nullptr, PMPC_REDO_MODE, ss->max_iter, (double*)nullptr, (unsigned)(ldsg / sizeof(double)));
+    return true;
+}
 template <class Model, int NN_, int MM_> struct COND_REG_OK { static constexpr bool value = NN_ + MM_ > WAVE && NN_ <= 112 && MM_ > 0 && MM_ <= WAVE && Model::NP == 0 && Model::NG == 0; };
 // Register-resident QP specialisations are selected from the compile-time model dimensions and the runtime node count
 // when the KKT system has at most 64 rows; otherwise the LDS-resident path is used.
@@ -596,6 +619,7 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
                 // resume mode: a no-op per instance unless something was left in progress (see sqp_kernel_rr)
                 hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), ldsr, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
                                    *ss, *qs, Hws, Aws, x, lam, info, phase, (double*)nullptr, -1, ss->max_iter, slice_state, (unsigned)(ldsr / sizeof(double)));
+                if (!launch_redo_generic<Model>(mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit)) { *st = PMPC_ERR_HIP; return true; }
                 *st = (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
                 return true;
             }
@@ -603,6 +627,7 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
         for (int it = 0; it < ss->max_iter; it += slice)
             hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), ldsr, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
                                *ss, *qs, Hws, Aws, x, lam, info, phase, (double*)nullptr, it, it + slice, slice_state, (unsigned)(ldsr / sizeof(double)));
+        if (!launch_redo_generic<Model>(mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit)) { *st = PMPC_ERR_HIP; return true; }
         *st = (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
         return true;
     } else if constexpr (NN_ + MM_ <= 128) {   // two KKT rows per lane (pmpc_qp_reg2.hpp); the Hessian-update policy is a run-time choice there
@@ -627,18 +652,27 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
 #endif
             }
             // the filter line search alone (no Ruiz scaling: that rescales the workspace the per-node blocks of A mirror) keeps the condensed QP
-            if constexpr (POLK && (NN_ > WAVE || PMPC_EXPERIMENT_SMALL_POL)) {   // (the two-rows-per-lane tile set only: the one-row-per-lane variant with the hooks compiled in returned wrong iterates on the 11-node robot grid — not understood, not shipped)
+            if constexpr (POLK) {   // (round 5: also the one-row-per-lane tile set — its hook build was miscompiled by the never-executed Ruiz calls, which the condensed kernels no longer carry, pmpc_sqp.hpp RUIZ_COMPILED)
                 if (pol && ss->preconditioner == 0 && ss->kkt_form == 0 && !getenv("PMPC_NO_CONDREG")) {
                     kern = sqp_kernel<Model, NN_, MM_, false, 0, false, false, true, true>; timed = false;
                     pmpc_internal_set_route(ctx, PMPC_ROUTE_CONDREG);
                 }
             }
         }
+        auto kern_full = sqp_kernel<Model, NN_, MM_, false>;   // the full two-rows-per-lane inverse: serves the redo launch behind a condensed kernel
+        if constexpr (POLK) { if (pol) kern_full = sqp_kernel<Model, NN_, MM_, false, 0, false, false, true>; }
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
         const int slice = (slice_state && slice_iters > 0) ? slice_iters : ss->max_iter;
         for (int it = 0; it < ss->max_iter; it += slice)
             hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), ldsq, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
                                *ss, *qs, Hws, Aws, x, lam, info, timed ? phase : (unsigned long long*)nullptr, (double*)nullptr, it, it + slice, slice_state, (unsigned)(ldsq / sizeof(double)));
+        if (pmpc_internal_last_route(ctx) == PMPC_ROUTE_CONDREG) {
+            // redo launch: the instances whose condensed solve gave up at its conditioning gate (PMPC_FLAG_ILLCOND; none on any BASELINE workload) are solved
+            // again, from their guesses, by the full-inverse kernel of this size — every other workgroup reads one word and exits
+            if (hipFuncSetAttribute((const void*)kern_full, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
+            hipLaunchKernelGGL(kern_full, dim3(B), dim3(WAVE), ldsr, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
+                               *ss, *qs, Hws, Aws, x, lam, info, (unsigned long long*)nullptr, (double*)nullptr, PMPC_REDO_MODE, ss->max_iter, (double*)nullptr, (unsigned)(ldsr / sizeof(double)));
+        }
         *st = (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
         return true;
     } else {
@@ -731,6 +765,13 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     for (int it = 0; it < ss->max_iter; it += slice)
         hipLaunchKernelGGL(lkern, dim3(B), dim3(WAVE), lds, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, *ss, *qs, Hws, Aws,
                            x, lam, info, phase, Kws, it, it + slice, slice_state, (unsigned)(lds / sizeof(double)));
+    if (Kws && ss->kkt_form == 0 && ss->qp_solver == 0) {
+        // redo launch (large-instance kernel, condensed mode): the instances whose QP gave up at its conditioning gate (PMPC_FLAG_ILLCOND; none on any
+        // BASELINE workload) are solved again, from their guesses, by the same kernel in the (n + m)-row KKT form — every other workgroup reads one word and exits
+        pmpc_sqp_settings ss_full = *ss; ss_full.kkt_form = 1;
+        hipLaunchKernelGGL(lkern, dim3(B), dim3(WAVE), lds, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss_full, *qs, Hws, Aws,
+                           x, lam, info, (unsigned long long*)nullptr, Kws, PMPC_REDO_MODE, ss->max_iter, (double*)nullptr, (unsigned)(lds / sizeof(double)));
+    }
     return (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
 }
 

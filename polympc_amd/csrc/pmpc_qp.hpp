@@ -24,6 +24,7 @@ constexpr int BIG_MEM_BATCH = PMPC_BIG_MEM_BATCH;   // loads in flight per lane 
 constexpr double RHO_MIN = 1e-6, RHO_MAX = 1e+6, RHO_EQ_FACTOR = 1e+3;   // box_admm.hpp:56-59
 constexpr double LOOSE_BOUNDS_THRESH = 1e+10, EQ_TOL = 1e-4;            // qp_base.hpp:124-125
 constexpr double DIV_BY_ZERO_REGUL = 10e-10;                            // qp_base.hpp:79-82
+constexpr double PMPC_COND_GATE = 1e10;   // conditioning gate of the kernels that eliminate the constraint block first (PMPC_FLAG_ILLCOND, include/polympc_amd.h): max_i S_ii / min_k |pivot_k|
 
 // opaque on purpose: per-lane index arithmetic derived from it is recomputed where it is used instead of being hoisted
 // to the kernel prologue and kept (or spilled) for the whole SQP loop
@@ -631,7 +632,7 @@ __device__ __forceinline__ void kkt_solve_pivoted(const QpLds& w, int N, double*
 
 // large-instance linear algebra (pmpc_qp_big.hpp, included after this header by its users)
 __device__ __forceinline__ void big_build(double* W, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ A, int lda, const double* kdiag);
-__device__ __forceinline__ void big_factor(double* W, int N, double* dl);
+__device__ __forceinline__ double big_factor(double* W, int N, double* dl);
 template <bool SLIM> __device__ __forceinline__ void big_solve(const double* W, int N, double* v, double* bx);
 
 // boxADMM::solve_impl (box_admm.hpp:88-205). Result in w.x (n) and w.y (m+n). h/Alb/Aub/xlb/xub may live in LDS or HBM.
@@ -692,13 +693,19 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
     const int N = n + m;
     constexpr bool HASJ = BIG && !std::is_same<JV, NoJView>::value;
     const bool cond = HASJ && condensed;
-    auto build_and_factor = [&](long long* tb) __attribute__((always_inline)) {   // (inlined at both call sites: as one shared out-of-line function its register use also bounded the occupancy of the two-waves-per-SIMD kernels that call it)
+    // Returns whether the conditioning gate tripped (condensed mode only; PMPC_FLAG_ILLCOND, include/polympc_amd.h): max_i S_ii > PMPC_COND_GATE min_k |d_k|.
+    auto build_and_factor = [&](long long* tb) __attribute__((always_inline)) -> bool {   // (inlined at both call sites: as one shared out-of-line function its register use also bounded the occupancy of the two-waves-per-SIMD kernels that call it)
         if constexpr (BIG) {
             if constexpr (HASJ) {
-                if (cond) { big_build_condensed(w.K, n, m, H, ldh, w.kdiag, w.rho, jv); if (tb) *tb = clock64(); big_factor(w.K, n, w.big_lds); return; }
+                if (cond) {
+                    const double smax = big_build_condensed(w.K, n, m, H, ldh, w.kdiag, w.rho, jv); if (tb) *tb = clock64();
+                    const double pmin = big_factor(w.K, n, w.big_lds);
+                    return __builtin_amdgcn_readfirstlane((int)(smax > PMPC_COND_GATE * pmin)) != 0;
+                }
             }
-            big_build(w.K, n, m, H, ldh, A, lda, w.kdiag); if (tb) *tb = clock64(); big_factor(w.K, N, w.big_lds);
+            big_build(w.K, n, m, H, ldh, A, lda, w.kdiag); if (tb) *tb = clock64(); (void)big_factor(w.K, N, w.big_lds);
         }
+        return false;
     };
     // condensed form: S is built from the block-sparse view, which skips the structural zeros of J — with a non-finite model derivative the dense KKT
     // form would propagate NaN through 0 * inf where this one does not: such a solve is flagged whatever x and y look like afterwards
@@ -730,9 +737,10 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
     for (int i = ln; i < n; i += WAVE) { double dgl = H[(size_t)i * ldh + i]; dgl += s.sigma; dgl += w.rhob[i]; w.kdiag[i] = dgl; }
     for (int i = ln; i < m; i += WAVE) w.kdiag[n + i] = -w.rhoinv[i];
     wsync();
+    bool gave_up = false;   // condensed mode: the conditioning gate tripped — the SQP kernel ends the instance with PMPC_SQP_REDO and the launcher's redo launch solves it in the (n + m)-row form
     { const long long t0 = tick();
       long long t1 = t0;
-      if constexpr (BIG) build_and_factor(tm ? &t1 : nullptr);
+      if constexpr (BIG) gave_up = build_and_factor(tm ? &t1 : nullptr);
       else { kkt_build(w, n, m, H, ldh, A, lda); t1 = tick(); if (pivoted) kkt_factor_pivoted(w, N); else kkt_factor(w, N); }
       if (tm) { tm[0] += tick() - t0; tm[3] += t1 - t0; } }
 
@@ -752,7 +760,7 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
     };
     double rho_estimate = 0.0;
     int iter;
-    for (iter = 1; iter <= s.max_iter; ++iter) {
+    for (iter = 1; iter <= s.max_iter && !gave_up; ++iter) {
         // compute_kkt_rhs (:351-355), z_prev = z
         for (int i = ln; i < n; i += WAVE) w.rhs[i] = ((s.sigma * w.x[i] - h[i]) + w.rhob[i] * w.q[i]) - w.y[m + i];
         for (int i = ln; i < m; i += WAVE) { w.zprev[i] = w.z[i]; w.rhs[n + i] = w.z[i] - w.rhoinv[i] * w.y[i]; }
@@ -841,7 +849,7 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
                 for (int i = ln; i < n; i += WAVE) w.kdiag[i] += (w.rhob[i] - w.t2[i]);
                 for (int i = ln; i < m; i += WAVE) w.kdiag[n + i] = -w.rhoinv[i];
                 wsync();
-                if constexpr (BIG) build_and_factor(nullptr);
+                if constexpr (BIG) { gave_up = build_and_factor(nullptr); if (gave_up) break; }
                 else { kkt_build(w, n, m, H, ldh, A, lda); if (pivoted) kkt_factor_pivoted(w, N); else kkt_factor(w, N); }
             }
         }
@@ -851,7 +859,7 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
     for (int i = ln; i < n; i += WAVE) worst += fabs(w.x[i] - w.x[i]);
     for (int i = ln; i < N; i += WAVE) worst += fabs(w.y[i] - w.y[i]);
     const bool bad = __builtin_amdgcn_ballot_w64(worst != 0.0) != 0;
-    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info.flags = (bad || jbad) ? PMPC_FLAG_NONFINITE : 0;
+    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info.flags = ((bad || jbad) ? PMPC_FLAG_NONFINITE : 0) | (gave_up ? PMPC_FLAG_ILLCOND : 0);
     info.rho_estimate = rho_estimate; info.res_prim = rs.res_prim; info.res_dual = rs.res_dual;
 }
 

@@ -114,12 +114,14 @@ __device__ __forceinline__ void big_build(double* W, int n, int m, const double*
 // start from H (+ diagonal) and take, for the constraint rows r in groups of four (ascending — the k-ascending fma chain of v_mfma_f64_16x16x4_f64),
 // A operand rho_r J(r, i), B operand J(r, j); the operands are evaluated from the block-sparse view of J (per-node blocks + differentiation
 // matrix), the dense J is never read. Restated on the CPU by the test suite as PIVOT_CONDENSED.
+// Returns max_i S_ii (the conditioning gate of boxadmm_solve reads it).
 template <class JV>
-__device__ __forceinline__ void big_build_condensed(double* W, int n, int m, const double* __restrict__ H, int ldh, const double* kdiag,
-                                                    const double* rho, const JV& jv) {
+__device__ __forceinline__ double big_build_condensed(double* W, int n, int m, const double* __restrict__ H, int ldh, const double* kdiag,
+                                                      const double* rho, const JV& jv) {
     const int ln = lane_id();
     const int nb = BigKkt::nblk(n);
     const int lr = ln >> 4, lc = ln & 15;
+    double dmax = 0.0;
     constexpr int GI = 8;    // tile rows per pass (two block columns each: 16 accumulator tiles = 128 registers)
     // TWO block columns per pass (2 x 16 accumulator tiles = 256 registers, the accumulation file): the A operands — the expensive part, an entry
     // lookup per lane and tile row — serve both columns
@@ -178,6 +180,12 @@ __device__ __forceinline__ void big_build_condensed(double* W, int n, int m, con
             for (int g = 0; g < GI; ++g) {
                 const int I = I0 + g;
                 if (I < nb) {
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {   // diagonal entries of S: tile (Jc, Jc) in T0, tile (Jc + 1, Jc + 1) in T1, rows < n
+                        const bool dg = (4 * rg + lr == lc) && (16 * I + lc < n);
+                        if (I == Jc) dmax = fmax(dmax, dg ? fabs(T0[g][rg]) : 0.0);
+                        if (two && I == Jc + 1) dmax = fmax(dmax, dg ? fabs(T1[g][rg]) : 0.0);
+                    }
                     double* tt = W + (size_t)BigKkt::tidx(I, Jc) * 256;
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) tt[64 * rg + ln] = T0[g][rg];
@@ -192,18 +200,20 @@ __device__ __forceinline__ void big_build_condensed(double* W, int n, int m, con
     }
     wfence();
     wsync();
+    return wave_max(dmax);
 }
 
-// in-place blocked LDL^T of the tiles in W (see the header). dl: BigKkt::LDS_DOUBLES doubles of LDS.
+// in-place blocked LDL^T of the tiles in W (see the header). dl: BigKkt::LDS_DOUBLES doubles of LDS. Returns the smallest |pivot| over the rows < N.
 // LEFT-LOOKING schedule, two block columns at a time: block columns J and J + 1 first receive the rank-16 updates of ALL earlier block columns k < J
 // together (accumulator tiles of both columns stay in registers while k runs: per k and group of four tile rows, four A operand tiles from the CF
 // strip of k and one B operand tile per column from the LF panel of k feed 32 MFMA — 12 KB per 32 MFMA, where one column at a time needs 20 KB and the
 // right-looking schedule re-read and re-wrote every tile per k); then column J is finished (diagonal tile, the rows below apply the 16 pivots), column
 // J + 1 takes its last update (k = J) and is finished. Every entry still receives fma(-c_ik, l_jk, a_ij) for k ascending — the right-looking
 // schedule's operations in the right-looking schedule's order.
-__device__ __forceinline__ void big_factor(double* W, int N, double* dl) {
+__device__ __forceinline__ double big_factor(double* W, int N, double* dl) {
     const int ln = lane_id();
     const int nb = BigKkt::nblk(N), NPAD = nb * 16;
+    double piv_min = INFINITY;
     const size_t nt = (size_t)BigKkt::ntiles(N);
     double* Lr = W;
     double* LF = W + nt * 256;
@@ -294,6 +304,7 @@ __device__ __forceinline__ void big_factor(double* W, int N, double* dl) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const double dt = bcast_lane(a[t], t);
+                piv_min = (16 * J + t < N) ? fmin(piv_min, fabs(dt)) : piv_min;
                 const double c = a[t];
                 const double l = c / dt;
 #pragma unroll
@@ -351,7 +362,7 @@ __device__ __forceinline__ void big_factor(double* W, int N, double* dl) {
             if (J > 0) { update_cols(one{}, four{}, J, J, nb, 0, J); wfence(); wsync(); }
             finish_column(J);
         }
-        return;
+        return piv_min;
     }
     for (int J = 0; J < nb; J += 2) {
         const bool pair = J + 1 < nb;
@@ -368,6 +379,7 @@ __device__ __forceinline__ void big_factor(double* W, int N, double* dl) {
         wsync();
         finish_column(J + 1);
     }
+    return piv_min;
 }
 
 // v <- K^{-1} v, v in LDS (N entries; padding rows are not touched). bx: unused LDS slots.

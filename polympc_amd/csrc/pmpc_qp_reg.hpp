@@ -107,6 +107,9 @@ struct RegKkt {
     // W = -K^{-1} in mat-vec layout: lane 16*r + c holds  a[16*q + j] = W(16*q + c, 16*r + j)  (q < NT, j < 16; zero where the
     // column index is >= N): the 16 columns of block r against the rows c, c+16, c+32, ... — see apply()
     double a[((N + 15) / 16) * 16];
+    // conditioning estimate of the last invert(): smallest |pivot| of the blocked sweep and — constraint-first mode and the condensed callers — the
+    // largest diagonal entry of the swept matrix before the sweep (wave-uniform; dead code wherever nobody reads them). See PMPC_COND_GATE.
+    double piv_min = 0.0, diag_max = 0.0;
 
     using d4 = double __attribute__((ext_vector_type(4)));
     static constexpr int BK = 4;                      // pivots swept per block (4: one MFMA k-step; the scalar in-panel sweep costs
@@ -159,6 +162,16 @@ struct RegKkt {
     // update); lane >= NPIV: A(lane - NPIV, j) for j < NPIV, 0 beyond. diag = P(lane, lane) / rho_lane; rho_self = this constraint lane's rho.
     // The CPU restatement of the test suite (PIVOT_SWEEP, constraint-first) forms the same matrix entry by entry and sweeps the same blocks.
     struct NoPre { template <class TT> __device__ __forceinline__ void operator()(TT&, double*, double*, int, int, int) const {} };
+    // max_i |M(i, i)| over the rows i < NLIVE of the staged tiles: entry (16R + lc, 16R + lc) sits in component lc / 4 of the lanes with lc = lr + 4 (lc / 4)
+    template <int NLIVE>
+    __device__ __forceinline__ static double diag_abs_max(const d4 (&T)[NT][NT], int lr, int lc) {
+        double dm = 0.0;
+#pragma unroll
+        for (int R = 0; R < (NLIVE + 15) / 16; ++R)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dm = fmax(dm, (lc == lr + 4 * r && 16 * R + lc < NLIVE) ? fabs(T[R][R][r]) : 0.0);
+        return wave_max(dm);
+    }
     // T(a, b) <- fma(rho_j A(j, a), A(j, b), T(a, b)) over MM rows of A, j ascending in groups of four (one k-step of the matrix cores each) on every
     // stored tile — the condensed register kernel (pmpc_qp_cond.hpp, at most 64 variables) calls this through invert's `pre` hook between the staging of
     // H + diag and the blocked sweep. aload(j, z): A(j, lane) (0.0 on lanes >= N); rho_of(j): rho_j, wave-uniform.
@@ -290,6 +303,8 @@ struct RegKkt {
             }
         }
         pre(T, PA, PB, ln, lr, lc);
+        if constexpr (CF) diag_max = diag_abs_max<NPIV>(T, lr, lc);
+        piv_min = INFINITY;
         if (tm) { long long t = clock64(); tm[0] += t - tq0; tq0 = t; }
 #pragma unroll
         for (int b = 0; b < NBP; ++b) {
@@ -325,6 +340,7 @@ struct RegKkt {
                 const int k = kb + t;
                 if (k < NPIV) {
                     const double dk = bcast_lane(p[t], k);
+                    piv_min = fmin(piv_min, fabs(dk));
                     const double r = recip_uniform(dk);
                     double rk[BK];
 #pragma unroll
@@ -537,6 +553,7 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
 
     RegKkt<N> K;
     int status = PMPC_QP_UNSOLVED;
+    bool illcond = false;   // the conditioning gate tripped at a factorisation of this QP: given up (see below)
     const double alpha = s.alpha;
     double max_Ax_z_norm = 0.0, max_Hx_ATy_h_norm = 0.0, res_prim = 1.0, res_dual = 1.0, rho_estimate = 0.0;
     // Outer loop = one KKT factorisation (first pass and after every accepted rho update); inner loop = ADMM iterations
@@ -557,6 +574,14 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
                 if constexpr (STACKED) return lane_near(z) < (unsigned)NN ? v : 0.0;
                 return isP ? v : 0.0;
             }, tm, rhov);
+            // Conditioning gate (PMPC_FLAG_ILLCOND, include/polympc_amd.h). The constraint-first sweep inverts S = P + A' diag(rho) A inside K; cond(S) =
+            // rho_eq |A|^2 / lambda_min(P on null A) stays ~1e5 whatever rho is while the directions A leaves free are bounded variables (rho_box scales
+            // with rho: every BASELINE workload — there this order is MORE accurate than the reference's pivoted LDL^T, tests/test_oracle_pins.py), and
+            // grows with rho when unbounded variables (rho_box = RHO_MIN) span them. Estimate: max_i S_ii / min_k |pivot_k|; beyond PMPC_COND_GATE the QP
+            // is given up (UNSOLVED + the flag) and the launcher's redo launch solves it in the full KKT form (LDS-resident static LDL^T). Wave-uniform;
+            // restated by the CPU checker. (A second, full-sweep instantiation of invert() as an in-kernel fallback was built first: it cost the headline
+            // kernel 87 spilled registers — the allocator budgets for the union of both paths.)
+            if (__builtin_amdgcn_readfirstlane((int)(K.diag_max > PMPC_COND_GATE * K.piv_min))) { illcond = true; running = false; if (dbg) dbg[0] += clock64() - f0; break; }
             if (dbg) dbg[0] += clock64() - f0;
         }
         bool refactor = false;
@@ -648,11 +673,11 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
         }
         if (!refactor) running = false;
     }
-    if (iter > s.max_iter) status = PMPC_QP_MAX_ITER_EXCEEDED;
+    if (iter > s.max_iter && !illcond) status = PMPC_QP_MAX_ITER_EXCEEDED;
     if (isP) { out_x[ln] = xv; out_y[MM + ln] = yv; }
     if (isC) out_y[r] = yv;
     const bool bad = __builtin_amdgcn_ballot_w64(((xv - xv) + (yv - yv)) != 0.0) != 0;   // non-finite x or y on any lane
-    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info.flags = bad ? PMPC_FLAG_NONFINITE : 0;
+    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info.flags = (bad ? PMPC_FLAG_NONFINITE : 0) | (illcond ? PMPC_FLAG_ILLCOND : 0);
     info.rho_estimate = rho_estimate; info.res_prim = res_prim; info.res_dual = res_dual;
 }
 

@@ -40,6 +40,8 @@ struct SqpLds {
 constexpr double DBL_EPS = 2.220446049250313e-16;
 constexpr int RUIZ_MAX_NDER = 64;   // see SqpDevice::qp_and_step
 constexpr int PMPC_SQP_IN_PROGRESS = 3;   // internal: the instance continues in the next iteration-slice launch
+constexpr int PMPC_SQP_REDO = 4;          // internal: a QP of a condensed kernel gave up at its conditioning gate (PMPC_FLAG_ILLCOND) — the launcher's redo launch solves the instance again in the full KKT form
+constexpr int PMPC_REDO_MODE = -0x7fffffff - 1;   // it_begin of that redo launch: only instances with status PMPC_SQP_REDO run, from their guesses
 
 // NN, MM > 0: compile-time QP size -> register-resident QP: NN+MM <= 64 one KKT row per lane (pmpc_qp_reg.hpp, REG1), 65..112 two rows per
 // lane (pmpc_qp_reg2.hpp, REG2: the QP alone is specialised, the other phases run the size-generic code with compile-time trip counts);
@@ -65,7 +67,16 @@ struct SqpDevice {
     using Dm = OcpDims<Model>;
     // Ruiz scaling is compiled into the LDS / HBM-resident QP kernels only: the launcher routes preconditioner = 1 there. In the
     // register-resident kernels its three (cold, out-of-line) calls cost private-memory frames and call-ABI spills on the hot path.
+    // Not in the condensed register kernels either (PS = -1): the launcher never routes preconditioner = 1 to them (Ruiz rescales the workspace the
+    // per-node blocks of A mirror), so the calls were dead code there — and they were what MISCOMPILED the hook build of the small condensed kernel
+    // (robot 11 nodes, 55 + 33, one row per lane; round 4: "wrong iterates, different from run to run", EXPERIMENTS.md round 5): with the three
+    // never-executed out-of-line calls compiled in, the QP step of the lanes that are primal-only (the control columns) is lost; without them the same
+    // source is bit-identical under the device-poisoning harness. -DPMPC_EXPERIMENT_CND_WITH_RUIZ compiles them in again (developer switch: reproduces the fault).
+#ifdef PMPC_EXPERIMENT_CND_WITH_RUIZ
     static constexpr bool RUIZ_COMPILED = HOOKS && (int)Dm::NDER <= RUIZ_MAX_NDER;
+#else
+    static constexpr bool RUIZ_COMPILED = HOOKS && (int)Dm::NDER <= RUIZ_MAX_NDER && PS != -1;
+#endif
     static constexpr bool REG1 = !SCH && NN > 0 && NN + MM <= WAVE;    // one KKT row per lane
     static constexpr bool REG2 = !SCH && NN > 0 && NN + MM > WAVE;     // two KKT rows per lane
     double *hblk = nullptr, *qblk = nullptr, *xsc = nullptr, *dsc = nullptr, *pdl = nullptr, *dtab = nullptr;   // SCH: Hessian blocks, Q blocks, the exchange vectors, the KKT diagonal and the D~ tables of the QP (LDS)
@@ -98,6 +109,7 @@ struct SqpDevice {
     double* trace = nullptr;   // this instance's records (pmpc_sqp_settings::iteration_trace), or null
     int qp_iter_total = 0;
     int qp_flags = 0;            // OR of the QP solves' flags (PMPC_FLAG_NONFINITE)
+    bool redo = false;           // a QP of this solve gave up at its conditioning gate (condensed kernels)
     long long cyc[PROF ? 24 : 1] = {0};
     __device__ __forceinline__ static long long now() { if constexpr (PROF) return clock64(); else return 0; }
     __device__ __forceinline__ void acc(int i, long long dt) { if constexpr (PROF) cyc[i] += dt; }   // shader-clock cycles: 0 linearise(+BFGS) 1 QP 2 line search 3 termination 4 total 5 BFGS 6 KKT build+factor 7 QP residuals 8 ls node evaluation 9 ls scalar sums 10 first-order staging 11 second-order staging 12 first-order assembly 13 Hessian assembly 14 Lagrangian gradient 16..20 KKT inverse: row loads+staging, panel moves, sweeps, MFMA updates, final conversion 21 ls prologue (mu, grad'p) 22 ls acceptance
@@ -968,6 +980,7 @@ struct SqpDevice {
         qp_iter_total += qi.iter;
         qp_flags |= qi.flags;
         qp_iter_last = qi.iter; qp_status_last = qi.status;
+        if constexpr (CND || BIG || REG1) { if (__builtin_amdgcn_readfirstlane(qi.flags & PMPC_FLAG_ILLCOND) != 0) { redo = true; return; } }   // the QP gave up at its conditioning gate: nothing of this solve is used (solve() ends it with PMPC_SQP_REDO)
         if constexpr (RUIZ_COMPILED) if (ruiz) {   // unscale(p, p_lambda); unscale(m_H, m_h, m_A, ...), sqp_base.hpp:608-609 / :664-665
             ruiz_unscale_solution_wave(n, m, rz.D, rz.E, rz_c, qw.x, qw.y);
             ruiz_unscale_problem_wave(n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, rz.D, rz.E, rz_c);
@@ -1003,6 +1016,7 @@ struct SqpDevice {
             linearise(iter == 1 || ss.exact_hessian_every_iter, true);
             const long long c1 = now();
             qp_and_step();
+            if constexpr (CND || BIG || REG1) { if (redo) { status = PMPC_SQP_REDO; break; } }
             const long long c2 = now();
             const bool done = __builtin_amdgcn_readfirstlane((int)termination_criteria()) != 0;
             const long long c3 = now();

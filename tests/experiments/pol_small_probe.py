@@ -19,8 +19,10 @@ for k in ("line_search", "hessian_update", "preconditioner", "kkt_form"):
 oss = ob.sqp_default_settings(); oss.max_iter = MAXIT; oss.line_search_max_iter = wl["ls_max_iter"]
 for k in ("line_search", "hessian_update"):
     if k.upper() in os.environ: setattr(oss, k, int(os.environ[k.upper()]))
+otrace = np.zeros((B, MAXIT, 8)); ob.bind_iteration_trace(oss, otrace)
 xo, lo, io = ob.sqp_solve_batch(0, P, S, wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, pivot=ob.PIVOT_CONDSWEEP)
 prev = None
+th = ctx.iteration_trace_create(B, MAXIT); ss.iteration_trace = th; ss.iteration_trace_capacity = MAXIT
 for run in range(int(os.environ.get("RUNS", 3))):
     x, lam, info = ctx.sqp_solve_batch(wl["model"], P, S, wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
     route = pa.capi.ROUTE_NAMES.get(ctx.last_route())
@@ -36,6 +38,10 @@ for run in range(int(os.environ.get("RUNS", 3))):
         print("   x cpu ", np.array2string(xo[b0], precision=4, max_line_width=250))
         badl = np.argwhere(~(dl[b0] == 0)).ravel().tolist()
         print("   lam entries differing on that instance:", badl)
+    tr = ctx.iteration_trace_download(B, MAXIT, th)
+    print("   trace gpu [iter, alpha, primal_norm, dual_norm, cost, qp it, qp status, max viol]:", np.array2string(np.asarray(tr)[0, 0], precision=6))
+    print("   trace cpu                                                                     :", np.array2string(otrace[0, 0], precision=6))
+    ctx.iteration_trace_clear(B, MAXIT, th)
     if prev is not None:
         print("   same bits as the previous run:", np.array_equal(x, prev, equal_nan=True))
     prev = x.copy()

@@ -90,8 +90,8 @@ def _policy_order(oracle, n, m, nodes, ruiz=False, block_bfgs=False, kkt_form=0,
     """preconditioner = 1 / line_search = 1: on the grids of the reference's own tests (7 and 11 nodes) the register-resident kernels carry these hooks
     since round 3 (their sweep orders); every other grid takes the LDS / HBM-resident kernels for them."""
     if (nodes in POLICY_REG_NODE_COUNTS and n + m <= 112) or (nodes == 16 and n + m <= 128):   # (16 nodes, round 4: the reference's mpc_wrapper_test grid)
-        if n > 64 and not ruiz and kkt_form == 0 and n <= 112 and m <= 64 and ng == 0 and n % nodes == 0:
-            return oracle.PIVOT_CONDSWEEP   # the filter line search alone keeps the condensed register QP (Ruiz rescales the workspace: full inverse)
+        if n + m > 64 and not ruiz and kkt_form == 0 and n <= 112 and m <= 64 and ng == 0 and n % nodes == 0:
+            return oracle.PIVOT_CONDSWEEP   # the filter line search alone keeps the condensed register QP (Ruiz rescales the workspace: full inverse); since round 5 also on at most 64 variables
         return oracle.PIVOT_SWEEP if n + m <= 64 else oracle.PIVOT_SWEEP2
     return _lds_order(oracle, n + m, ruiz=ruiz, kkt_form=kkt_form)
 
@@ -861,14 +861,22 @@ def test_sqp_cstr_reference_scenario(ctx, oracle, hessian_update):
         lbx[0, 40:44] = ubx[0, 40:44] = [1.1, 0.508, 100.5, 100.1]
         x2, lam2, i2 = ctx.sqp_solve_batch(pa.MODEL_CSTR, 5, 2, 0.0, 100.0, 1, d, lbx, ubx, x_guess=x, lam_guess=lam, sqp_settings=ss)
         xo2, lo2, io2 = oracle.sqp_solve_batch(oracle.MODEL_CSTR, 5, 2, 0.0, 100.0, 1, d, lbx, ubx, x_guess=xo, lam_guess=lo, sqp_settings=oss, pivot=order)
-        if hessian_update and not (np.isfinite(xo2).all() and np.isfinite(lo2).all()):
-            # block-structured kernel: its sparse products skip structural zeros, which is the dense chains' statement for FINITE operands only — once the
-            # unregularised warm solve has overflowed (it does in this order with the shared exp) both sides are non-finite, and the kernel says so
-            assert not (np.isfinite(x2).all() and np.isfinite(lam2).all()) and i2["flags"][0] != 0
-        else:
-            assert i2["iter"][0] == io2[0].iter and i2["qp_solver_iter"][0] == io2[0].qp_solver_iter and i2["status"][0] == io2[0].status
-            assert np.array_equal(x2, xo2, equal_nan=True) and np.array_equal(lam2, lo2, equal_nan=True)
-            assert (i2["flags"][0] != 0) == (not np.isfinite(x2).all())
+        # whatever the restatement in the kernel's order does, the kernel does it bit for bit — and the outcome itself is pinned, not merely mirrored:
+        assert i2["iter"][0] == io2[0].iter and i2["qp_solver_iter"][0] == io2[0].qp_solver_iter and i2["status"][0] == io2[0].status
+        assert np.array_equal(x2, xo2, equal_nan=True) and np.array_equal(lam2, lo2, equal_nan=True)
+        assert bool(i2["flags"][0] & pa.capi.FLAG_NONFINITE) == (not (np.isfinite(x2).all() and np.isfinite(lam2).all()))
+        if reg == 0 and hessian_update:
+            # OPEN DISCREPANCY against cstr_control_test.cpp:177, stated as what it is instead of being accepted silently: the reference asserts
+            # SOLVED for this warm solve; the block-structured order ends it finite at MAX_ITER_EXCEEDED (every QP at its cap) — and so does the restatement
+            # with every linear solve carried to exact arithmetic (PIVOT_EXACT, either function set): the unregularised indefinite Hessian, not an
+            # elimination order, decides it. A change of this outcome — in either direction — must be looked at.
+            assert i2["status"][0] == pa.SQP_MAX_ITER_EXCEEDED and (i2["iter"][0], i2["qp_solver_iter"][0]) == (20, 2020)
+            assert np.isfinite(x2).all() and np.isfinite(lam2).all() and i2["flags"][0] == 0
+        if reg == 0 and not hessian_update:
+            # the dense-BFGS variant: SOLVED as :177 asserts — after an overflow (the termination test's norms drop NaNs), which the info word reports; the
+            # condensed kernel meets multipliers of 1e14 on the way, trips its conditioning gate and the instance is re-solved in the full KKT form
+            assert i2["status"][0] == pa.SQP_SOLVED
+            assert i2["flags"][0] & pa.capi.FLAG_ILLCOND
         # the same two solves with Eigen::LDLT's pivoting on the device (linear_solver = 1): bit-identical to the Eigen-order restatement
         qp = pa.qp_settings_sqp_default(); qp.linear_solver = 1
         lbx[0, 40:44] = ubx[0, 40:44] = [1.0, 0.5, 100.0, 100.0]
@@ -1185,7 +1193,8 @@ def test_sqp_round_robin_execution_bit_identical(ctx, oracle, monkeypatch, hessi
                                         sqp_settings=oss, pivot=_gpu_order(oracle, 35, 21, 7, block_bfgs=bool(hessian_update)), threads=8)
     fin = np.isfinite(x).all(axis=1) & np.isfinite(xo).all(axis=1)   # (a warm start from an unconverged iterate can diverge: identically on both sides)
     assert np.array_equal(np.isfinite(x).all(axis=1), np.isfinite(xo).all(axis=1)) and fin.mean() > 0.99
-    assert np.array_equal(info["flags"] != 0, ~(np.isfinite(x).all(axis=1) & np.isfinite(lam).all(axis=1)))   # PMPC_FLAG_NONFINITE marks exactly the non-finite results
+    assert np.array_equal((info["flags"] & pa.capi.FLAG_NONFINITE) != 0, ~(np.isfinite(x).all(axis=1) & np.isfinite(lam).all(axis=1)))   # PMPC_FLAG_NONFINITE marks exactly the non-finite results
+    assert np.array_equal(info["flags"], np.array([i.flags for i in io]) | (info["flags"] & pa.capi.FLAG_NONFINITE))   # (PMPC_FLAG_ILLCOND — a diverging warm start can trip the conditioning gate — exactly where the restatement sets it)
     _assert_same_solve(info[fin], [i for i, f in zip(io, fin) if f], x[fin], xo[fin], lam[fin], lo[fin])
     assert np.array_equal(info["iter"], np.array([i.iter for i in io])) and np.array_equal(info["status"], np.array([i.status for i in io]))
 
@@ -1251,12 +1260,14 @@ def test_cstr_short_horizon_tight_pin_against_the_reference_order(ctx, oracle, h
     assert r["scaled_dx_per_instance"]["max"] <= 1e-9 and r["scaled_dlam_per_instance"]["max"] <= 1e-9 and r["max_abs_d_constraint_violation"] <= 1e-10
 
 
-@pytest.mark.parametrize("rho0", [10.0, 1e3])
+@pytest.mark.parametrize("rho0", [10.0, 1e3, 1e5])
 def test_condensed_register_kernel_under_a_large_penalty(ctx, oracle, rho0):
-    """The condensed register kernel with the QP's penalty started at rho = 10 / 1e3 (rho_eq = 1e4 / 1e6 against rho_box = 1e-6 on the unbounded states — the
-    regime where the condensed form loses digits per solve): the kernel still equals its restatement bit for bit, and against the restatement as
-    the reference computes (pivoted LDL^T of the KKT matrix, glibc) every instance keeps its SQP and ADMM iteration counts with the iterates within 1e-6 of
-    their magnitude."""
+    """The condensed register kernel with the QP's penalty started at rho = 10 / 1e3 / 1e5 (rho_eq up to 1e8; RHO_MAX = 1e6, box_admm.hpp:56-59): the kernel
+    equals its restatement bit for bit, the conditioning gate stays silent (the directions A leaves free are the bounded controls: cond(S) ~ 1e5 whatever
+    rho is), every instance keeps the SQP and ADMM iteration counts of the run as the reference computes (pivoted LDL^T of the KKT matrix, glibc) — and
+    where the two runs differ it is the REFERENCE order that left exact arithmetic: against PIVOT_EXACT (every linear solve refined in long double) the
+    kernel's iterates are the closer ones (round 5 finding; tests/test_oracle_pins.py::test_kernel_orders_follow_exact_arithmetic_more_closely_than_the_reference_order
+    pins it per QP). At rho0 = 1e5 neither run reproduces the exact one to 1e-8 — the computation itself is that ill-conditioned."""
     import polympc_amd as pa
     from oracle import cross_order as tco
     nB = 64
@@ -1274,9 +1285,60 @@ def test_condensed_register_kernel_under_a_large_penalty(ctx, oracle, rho0):
     with oracle.libm():
         xr, lr, ir = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], nB, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, qp_settings=oqs,
                                             pivot=oracle.PIVOT_EIGEN, threads=8)
+        xe, le, ie = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], nB, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, qp_settings=oqs,
+                                            pivot=oracle.PIVOT_EXACT, threads=8)
+    assert np.all(info["flags"] == 0)
     r = tco.cross_order_stats("B", wl, x, lam, info, xr, lr, ir)
-    print(rho0, r["different_trajectories"], r["scaled_dx_per_instance"])
-    assert r["different_trajectories"] == 0 and r["scaled_dx_per_instance"]["max"] <= 1e-6
+    rk = tco.cross_order_stats("B", wl, x, lam, info, xe, le, ie)
+    rr = tco.cross_order_stats("B", wl, xr, lr, ir, xe, le, ie)
+    print(rho0, "vs reference order", r["different_trajectories"], r["scaled_dx_per_instance"]["max"], "| kernel vs exact", rk["scaled_dx_per_instance"]["max"],
+          "reference order vs exact", rr["scaled_dx_per_instance"]["max"])
+    assert r["different_trajectories"] == 0 and rk["different_trajectories"] == 0
+    assert rk["scaled_dx_per_instance"]["max"] <= max(2 * rr["scaled_dx_per_instance"]["max"], 1e-9)
+    if rho0 <= 1e3: assert r["scaled_dx_per_instance"]["max"] <= 1e-6
+
+
+def _free_controls(wl, nx):
+    """the workload with every bound removed except the pinned initial state: the directions the collocation Jacobian leaves free then carry
+    rho_box = RHO_MIN instead of rho — the one situation in which the condensed form loses digits as rho grows (PMPC_FLAG_ILLCOND)"""
+    nn = wl["P"] * wl["S"] + 1
+    w = dict(wl); w["lbx"] = wl["lbx"].copy(); w["ubx"] = wl["ubx"].copy()
+    w["lbx"][:, nx * nn:] = -np.inf; w["ubx"][:, nx * nn:] = np.inf
+    return w
+
+
+@pytest.mark.parametrize("case", ["robot_11", "robot_16", "cstr_11", "robot_7", "kite"])
+def test_conditioning_gate_and_the_redo_launch(ctx, oracle, case):
+    """PMPC_FLAG_ILLCOND end to end. Controls unbounded and the QP penalty started at 1e4: the kernels that eliminate the constraint block first meet
+    cond(S) > 1e10 in the first QP. The one-row-per-lane kernel (robot, 7 nodes) continues that QP on the full primal-first sweep; the condensed register
+    kernels (robot 11 / 16 nodes, CSTR) and the large-instance kernel (kite stand-in) give the QP up and the launcher's redo launch solves the instance
+    again in the full KKT form. Bit for bit what the restatement does under the same rule, flag included; with the bounds in place the flag stays clear."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    B = 6
+    wl, nx = {"robot_11": (workloads.robot_batch(B, P=5, S=2), 3), "robot_16": (workloads.robot_batch(B, P=5, S=3), 3), "cstr_11": (workloads.cstr_batch(B), 4),
+              "robot_7": (workloads.robot_batch(B), 3), "kite": (workloads.kite_standin_batch(B), 13)}[case]
+    n, m = wl["n"], wl["m"]
+    order = oracle.PIVOT_SWEEP if n + m <= 64 else (oracle.PIVOT_CONDSWEEP if n + m <= 128 else oracle.PIVOT_CONDENSED)
+    for free in (False, True):
+        w = _free_controls(wl, nx) if free else wl
+        ss = pa.sqp_settings_default(); oss = oracle.sqp_default_settings()
+        for st in (ss, oss):
+            st.max_iter = 3; st.line_search_max_iter = wl["ls_max_iter"]
+        qs = pa.qp_settings_sqp_default(); oqs = oracle.sqp_qp_default_settings()
+        qs.rho = 1e4; oqs.rho = 1e4
+        x, lam, info = ctx.sqp_solve_batch(w["model"], w["P"], w["S"], w["t0"], w["tf"], B, w["d"], w["lbx"], w["ubx"], sqp_settings=ss, qp_settings=qs)
+        xo, lo, io = oracle.sqp_solve_batch(w["model"], w["P"], w["S"], w["t0"], w["tf"], B, w["d"], w["lbx"], w["ubx"], sqp_settings=oss, qp_settings=oqs,
+                                            pivot=order, threads=4)
+        fo = np.array([i.flags for i in io])
+        print(case, "free controls" if free else "bounded", "flags gpu", info["flags"].tolist(), "cpu", fo.tolist(), "status", info["status"].tolist())
+        assert np.array_equal(info["flags"] & pa.capi.FLAG_ILLCOND, fo & oracle.FLAG_ILLCOND)
+        assert np.all(info["status"] <= pa.SQP_MAX_ITER_EXCEEDED)          # (the internal REDO status never leaves the library)
+        _assert_same_solve(info, io, x, xo, lam, lo)
+        if free:
+            assert np.all(info["flags"] & pa.capi.FLAG_ILLCOND)
+        else:
+            assert np.all(info["flags"] == 0)
 
 
 def ROUTE_OF_128_ROWS(pa):
@@ -1314,7 +1376,7 @@ def test_last_route_reports_the_kernel_family(ctx):
     assert route(workloads.robot_batch(4, P=4, S=1), hessian_update=1) == pa.capi.ROUTE_REG1      # no block-structured kernel for this grid
     assert route(workloads.robot_batch(4, P=5, S=2), hessian_update=1, kkt_form=1) == pa.capi.ROUTE_REG2
     assert route(workloads.robot_batch(4, P=5, S=2), preconditioner=1, line_search=1) == pa.capi.ROUTE_REG2
-    assert route(workloads.robot_batch(4, P=5, S=2), line_search=1) == pa.capi.ROUTE_REG2               # (at most 64 variables: the hook build of the small condensed kernel is not shipped, EXPERIMENTS.md)
+    assert route(workloads.robot_batch(4, P=5, S=2), line_search=1) == pa.capi.ROUTE_CONDREG            # round 5: the hook build of the small condensed kernel — compiled WITHOUT the Ruiz calls a condensed kernel never executes (they were what miscompiled it, EXPERIMENTS.md)
     assert route(workloads.cstr_batch(4), line_search=1) == pa.capi.ROUTE_CONDREG
     assert route(workloads.robot_batch(4, P=4, S=2), preconditioner=1) == pa.capi.ROUTE_LDS
     assert route(workloads.robot_batch(4, P=5, S=3)) == pa.capi.ROUTE_CONDREG

@@ -798,6 +798,89 @@ def test_condensed_register_order_under_a_large_penalty(oracle):
         assert dc <= bound and dc <= df, (rho0, dc, df)
 
 
+@pytest.mark.parametrize("cfg", ["A", "B", "R"])
+def test_kernel_orders_follow_exact_arithmetic_more_closely_than_the_reference_order(oracle, cfg):
+    """Which side is inexact when the kernel order and the reference order disagree at a large penalty? PIVOT_EXACT solves every linear system of the ADMM
+    to working accuracy (the Eigen-order factor as a preconditioner, residuals in long double): the trajectory of exact arithmetic. On the QP streams of
+    configs A, B and the reference's 16-node grid, penalty started at 10 / 1e3 / 1e5 (RHO_MAX = 1e6, RHO_EQ_FACTOR = 1e3: box_admm.hpp:56-59), the order of
+    the default kernel — constraint-first sweep (A), condensed register kernel (B, R) — keeps every ADMM iteration count of the exact run and lies CLOSER
+    to it than the reference's pivoted LDL^T of the quasi-definite matrix does (measured max |dx|, kernel order / Eigen order: A 1e-10 / 5e-10, 2e-9 /
+    1e-7, 4e-6 / 5e-4; B 2e-9 / 5e-9, 5e-8 / 5e-7, 6e-5 / 2e-4; R 7e-11 / 1e-8, 2e-9 / 2e-5, 3e-5 / 2e-2): the directions A leaves free are the bounded
+    controls, whose rho_box scales with rho, so cond(S) stays ~1e5 whatever rho is — while diagonal pivoting on a matrix with entries 1e-9 .. 1e1 is not
+    backward stable. The disagreement with the reference order at large rho that round 4 recorded is therefore the REFERENCE order's rounding; matching it
+    to 1e-8 there would mean reproducing its error. The conditioning gate stays silent on all of these."""
+    from oracle import cross_order as tco
+    kern = oracle.PIVOT_SWEEP if cfg == "A" else oracle.PIVOT_CONDSWEEP
+    q = tco.traced_qp_stream(oracle, cfg, 32)
+    args = (q["H"], q["h"], q["A"], q["Alb"], q["Aub"], q["xlb"], q["xub"])
+    for rho0 in (10.0, 1e3, 1e5):
+        s = oracle.sqp_qp_default_settings(); s.rho = rho0
+        xe, ye, ie = oracle.qp_solve_batch(*args, settings=s, pivot=oracle.PIVOT_EXACT, threads=8)
+        xr, yr, ir = oracle.qp_solve_batch(*args, settings=s, pivot=oracle.PIVOT_EIGEN, threads=8)
+        xk, yk, ik = oracle.qp_solve_batch(*args, settings=s, pivot=kern, threads=8, structure=q["structure"])
+        assert [i.iter for i in ik] == [i.iter for i in ie] and [i.status for i in ik] == [i.status for i in ie], rho0
+        assert all(i.flags == 0 for i in ik), rho0
+        dk, de = np.abs(xk - xe).max(), np.abs(xr - xe).max()
+        print(cfg, rho0, "kernel order vs exact", dk, "reference order vs exact", de)
+        assert dk <= max(2 * de, 1e-9), (cfg, rho0, dk, de)         # never noticeably farther from exact arithmetic than the reference order ...
+        if rho0 >= 1e3: assert dk <= 0.5 * de, (cfg, rho0, dk, de)   # ... and at a large penalty several times to four orders of magnitude closer
+        assert dk <= 1e-8 * max(1.0, rho0 / 10.0), (cfg, rho0, dk)   # (what is left grows with rho for ANY fp64 solve: the exact run's own conditioning)
+
+
+@pytest.mark.parametrize("cfg", ["A", "B", "R"])
+def test_conditioning_gate_of_the_condensed_orders(oracle, cfg):
+    """When the condensed form IS the inexact one, and what the gate does about it. With every bound removed the directions A leaves free carry
+    rho_box = RHO_MIN = 1e-6 instead of rho, cond(S) = rho_eq |A|^2 / lambda_min grows with rho, and a condensed solve loses cond(S) eps (single solves at
+    rho = 1e3: x 1e-5, nu 1 relative; the quasi-definite form 1e-10). The estimate max_i S_ii / min_k |pivot_k| (within a factor 2 .. 10 below cond(S)) trips
+    the gate at 1e10: the QP is given up; the QP entry point solves it again on the LDS-resident static LDL^T (PIVOT_SWEEP -> PIVOT_STATIC, as the product's
+    redo launch does), the SQP driver re-solves the whole instance in the full form (test_sqp_conditioning_gate_redo; PIVOT_CONDSWEEP at the QP level is a
+    test probe only: it reports UNSOLVED + the flag). Silent on the benchmark streams at every rho (cond(S) ~ 1e5: the bounded controls), set on every QP of
+    the unbounded streams at rho0 = 1e5."""
+    from oracle import cross_order as tco
+    kern = oracle.PIVOT_SWEEP if cfg == "A" else oracle.PIVOT_CONDSWEEP
+    q = tco.traced_qp_stream(oracle, cfg, 32)
+    free_l, free_u = np.full_like(q["xlb"], -np.inf), np.full_like(q["xub"], np.inf)
+    for rho0 in (0.1, 1e3, 1e5):
+        s = oracle.sqp_qp_default_settings(); s.rho = rho0
+        xb, yb, ib = oracle.qp_solve_batch(q["H"], q["h"], q["A"], q["Alb"], q["Aub"], q["xlb"], q["xub"], settings=s, pivot=kern, threads=8, structure=q["structure"])
+        assert all(i.flags == 0 for i in ib), (cfg, rho0)
+        args = (q["H"], q["h"], q["A"], q["Alb"], q["Aub"], free_l, free_u)
+        xk, yk, ik = oracle.qp_solve_batch(*args, settings=s, pivot=kern, threads=8, structure=q["structure"])
+        flagged = np.array([i.flags & oracle.FLAG_ILLCOND for i in ik]) != 0
+        if rho0 == 1e5:
+            assert flagged.all(), (cfg, rho0)
+        if cfg == "A" and flagged.any():   # re-solved in the full KKT form (static LDL^T): as close to exact arithmetic as the reference order is
+            xe, ye, ie = oracle.qp_solve_batch(*args, settings=s, pivot=oracle.PIVOT_EXACT, threads=8)
+            xr, yr, ir = oracle.qp_solve_batch(*args, settings=s, pivot=oracle.PIVOT_EIGEN, threads=8)
+            dk, de = np.abs(xk - xe)[flagged].max(), np.abs(xr - xe)[flagged].max()
+            print(cfg, rho0, int(flagged.sum()), "flagged: full KKT form vs exact", dk, "reference order vs exact", de)
+            assert dk <= max(100 * de, 1e-7), (rho0, dk, de)
+        if cfg != "A":   # a QP that gave up reports UNSOLVED (the driver never uses it)
+            assert all(i.status == oracle.QP_UNSOLVED for i, f in zip(ik, flagged) if f)
+
+
+def test_sqp_conditioning_gate_redo(oracle):
+    """The instance-level rule the product's redo launch implements: the reference's 11-node robot grid with every bound removed except the pinned initial
+    state and the QP penalty started at 1e4 — the condensed order gives up at its gate in the first QP and the instance is solved again, from its guesses,
+    in the full KKT form: bit for bit the PIVOT_SWEEP2 solve, flag set; with the control bounds in place the gate stays silent."""
+    from polympc_amd import workloads
+    B = 6
+    wl = workloads.robot_batch(B, P=5, S=2)
+    ss = oracle.sqp_default_settings(); ss.max_iter = 4; ss.line_search_max_iter = wl["ls_max_iter"]
+    qs = oracle.sqp_qp_default_settings(); qs.rho = 1e4
+    run = lambda lbx, ubx, pivot: oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], lbx, ubx, sqp_settings=ss, qp_settings=qs, pivot=pivot, threads=4)
+    x0, l0, i0 = run(wl["lbx"], wl["ubx"], oracle.PIVOT_CONDSWEEP)
+    assert all(i.flags == 0 for i in i0)
+    nn = wl["P"] * wl["S"] + 1
+    lbx, ubx = wl["lbx"].copy(), wl["ubx"].copy()
+    lbx[:, 3 * nn:] = -np.inf; ubx[:, 3 * nn:] = np.inf
+    xc, lc, ic = run(lbx, ubx, oracle.PIVOT_CONDSWEEP)
+    xf, lf, if_ = run(lbx, ubx, oracle.PIVOT_SWEEP2)
+    assert all(i.flags & oracle.FLAG_ILLCOND for i in ic) and all(i.flags == 0 for i in if_)
+    assert np.array_equal(xc, xf) and np.array_equal(lc, lf)
+    assert [(i.iter, i.status, i.qp_solver_iter) for i in ic] == [(i.iter, i.status, i.qp_solver_iter) for i in if_]
+
+
 def test_block_structured_order_needs_its_refinement_step(oracle):
     """Why PIVOT_SCHUR refines: a config-B KKT system after a rho update (rho = 3.6: cond(S) = 6e5, S = 1/rho + A Q A'). The swept inverse of S has an
     isotropic forward error ~ eps cond(S) |nu|, but x = Q (r1 - A' nu) tolerates errors of nu only where Q^(1/2) A' nearly vanishes — without the step

@@ -138,6 +138,8 @@ def contract_line(out, detail_path=None):
             e["block_bfgs"] = {"ms": _r(vb["ms_per_batch"]["median"]), "route": vb.get("route")}
         if "parity_vs_cpu_same_order" in c:
             e["bit_identical"] = bool(c["parity_vs_cpu_same_order"].get("bit_identical_x"))
+        if "small_batches" in c:
+            e["small_batches_ms"] = {k: _r(v["ms_per_batch"]["median"]) for k, v in c["small_batches"].items()}
         cfgs[key.split("_")[0]] = e
     if cfgs:
         line["configs"] = cfgs
@@ -383,6 +385,13 @@ def main():
             if "C" in want:
                 add("C_kite_standin_1024", "C", workloads.kite_standin_batch(1024), 1024, 8, 1, "sqp_kernel<KiteStandInOCP> (464 KKT rows)",
                     "SYNTHETIC 13-state / 3-input stand-in (the reference tree has no kite model), P=5 S=3 (16 nodes), SQP max_iter=5")
+            if "C" in want:
+                # small batches of the large instance: a lone instance is what a receding-horizon controller waits for (the four-wavefront team kernel, BigTeam)
+                sb = {}
+                for Bs in (1, 256):
+                    r_ = sqp_record(workloads.kite_standin_batch(Bs), Bs, 8, 1, "sqp_kernel<KiteStandInOCP, WG4> (one workgroup of four wavefronts per instance)")
+                    sb[str(Bs)] = {"ms_per_batch": r_["ms_per_batch"], "qp_solves_per_s": r_["qp_solves_per_s"], "sqp_solved_fraction": r_["sqp_solved_fraction"], "route": r_["route"]}
+                cfg["C_kite_standin_1024"]["small_batches"] = sb
             if "R" in want:
                 add("R_robot_16_nodes_2048", "R", workloads.robot_batch(2048, P=5, S=3), 2048, 10, 1, "sqp_kernel<RobotOCP> (128 KKT rows)",
                     "mobile robot on the reference's mpc_wrapper_test grid, P=5 S=3 (16 nodes, n=80, m=48), 2048 instances (not a BASELINE.json configuration: the mid-size path)")

@@ -285,7 +285,15 @@ static void sqp_batch_impl(int P, int S, double t0, double tf, const double* mp,
         setup_solver<Model>(sqp, b, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, pivot);
         if (ss->filter_state) sqp.filter.load(ss->filter_state + (size_t)b * ORC_FILTER_STATE_DOUBLES);
         if (ss->iteration_trace) { sqp.trace = ss->iteration_trace + (size_t)b * ss->iteration_trace_capacity * ORC_TRACE_DOUBLES; sqp.trace_capacity = ss->iteration_trace_capacity; }
-        sqp.solve();
+        // the conditioning rule of the register-resident kernels (sqp_kernel, pmpc_launch.hpp): an instance with an unbounded control or parameter
+        // (LOOSE_BOUNDS: rho_box = RHO_MIN in a direction the collocation Jacobian leaves free) goes to the redo launch before any work
+        bool structural_redo = false;
+        if (pivot == PIVOT_SWEEP || pivot == PIVOT_CONDSWEEP) {
+            sqp.qp.numeric_gate = false;
+            const int varx = Model::NX * (P * S + 1);
+            for (int i = varx; i < sqp.n; ++i) structural_redo |= BoxADMM::classify(sqp.lbx[i], sqp.ubx[i]) == BoxADMM::LOOSE_BOUNDS;
+        }
+        if (structural_redo) sqp.info.status = SQP_REDO; else sqp.solve();
         auto store = [&](SQP<ContinuousOCP<Model>>& s, int extra_flags) {
             if (ss->filter_state) s.filter.store(ss->filter_state + (size_t)b * ORC_FILTER_STATE_DOUBLES);
             const int n = s.n, m = s.m;

@@ -328,12 +328,16 @@ struct BoxADMM {
     // PIVOT_CONDENSED): they invert / factorise S = P + A' diag(rho) A, whose condition number is rho_eq |A|^2 / lambda_min(P on the null space of A).
     // With bounded controls (every BASELINE workload) that is ~1e5 whatever rho is — rho_box scales with rho — and these orders are MORE accurate than
     // the pivoted LDL^T of the quasi-definite form; when unbounded variables (rho_box = RHO_MIN) span the null space of A it grows with rho and the
-    // condensed solve loses cond(S) eps. Estimate at every factorisation: max_i S_ii / min_k |pivot_k| (within a factor 2..10 below cond(S) on the
-    // benchmark streams and their unbounded variants); beyond COND_GATE
-    // these orders give the QP up (status QP_UNSOLVED, flag set): the drivers (SQP: the whole instance, from its guesses; the QP entry point: the QP)
-    // solve it again in the full KKT form, as the product's redo launches do — PIVOT_SWEEP -> PIVOT_STATIC (the LDS-resident static LDL^T),
-    // PIVOT_CONDSWEEP -> PIVOT_SWEEP2 (the two-rows-per-lane full inverse), PIVOT_CONDENSED -> PIVOT_BLOCKED (the (n + m)-row blocked LDL^T).
+    // condensed solve loses cond(S) eps. Estimate at every factorisation: max_i S_ii * max_i |(S^-1)_ii| (the swept orders: both diagonals are at hand) or
+    // max_i S_ii / min_k |d_k| (PIVOT_CONDENSED's LDL^T) — the two agree within a factor of two and lie a factor 2..10 below cond(S) on the benchmark
+    // streams and their unbounded variants; beyond COND_GATE
+    // PIVOT_CONDENSED (the large-instance kernel) and PIVOT_SWEEP at the QP entry point give the QP up (status QP_UNSOLVED, flag set): the drivers (SQP:
+    // the whole instance, from its guesses; the QP entry point: the QP) solve it again in the full KKT form, as the product's redo launches do —
+    // PIVOT_SWEEP -> PIVOT_STATIC (the LDS-resident static LDL^T), PIVOT_CONDENSED -> PIVOT_BLOCKED (the (n + m)-row blocked LDL^T).
+    // The register-resident SQP kernels (PIVOT_SWEEP, PIVOT_CONDSWEEP inside an SQP solve) decide ONCE per instance from its bounds instead — an unbounded
+    // control or parameter sends the instance to the redo launch before any work (SQP driver, oracle_capi.cpp): a numeric gate cost those kernels 4 .. 10 %.
     static constexpr double COND_GATE = 1e10;
+    bool numeric_gate = true;   // PIVOT_SWEEP: the QP entry point's kernels evaluate the gate numerically; the fused SQP kernels decide from the bounds (SQP driver) and switch this off
     bool illcond = false;
     double cond_estimate = 0.0;
 
@@ -568,9 +572,15 @@ struct BoxADMM {
     //   M(a, b)      = K(a, b), then fma(rho_j A(j, a), A(j, b), .) for j ascending       (a, b primal; block-lower tiles, diagonal tiles in full)
     //   M(n + j, b)  = M(b, n + j) = -(rho_j A(j, b)),   M(n + j, n + j') = [j == j'] rho_j
     // then PIVOT_SWEEP's blocked sweep over the pivots [0, n). W = -K^{-1} as before; the mat-vec of solve() is unchanged.
-    bool gate_trips(double smax) {   // (NaN operands: no trip — a non-finite solve is reported by its own flag)
+    bool gate_trips(double smax) {   // PIVOT_CONDENSED (an LDL^T, no inverse at hand): max S_ii / min |d_k|. (NaN operands: no trip — a non-finite solve is reported by its own flag)
         cond_estimate = smax / ldlt.piv_min_abs;
         return smax > COND_GATE * ldlt.piv_min_abs;
+    }
+    bool gate_trips_inverse(double smax, int nprimal) {   // the swept orders: max S_ii * max |(S^-1)_ii| from the diagonal of the swept matrix (the kernels read it off their tiles)
+        double wmax = 0.0;
+        for (int a = 0; a < nprimal; ++a) wmax = std::fmax(wmax, std::fabs(ldlt.M[a + (size_t)a * ldlt.n]));
+        cond_estimate = smax * wmax;
+        return smax * wmax > COND_GATE;
     }
     void factorise_sweep_cf() {
         const int NM = N + M;
@@ -595,7 +605,7 @@ struct BoxADMM {
         ldlt.n = NM; ldlt.policy = PIVOT_SWEEP; ldlt.M.swap(Mm); ldlt.tr.assign(NM, 0); ldlt.temp.assign(NM, 0.0);
         if (NM > 64) throw std::invalid_argument("oracle: PIVOT_SWEEP restates the 64-row register kernel; use PIVOT_STATIC / PIVOT_EIGEN for larger systems");
         ldlt.compute_sweep(true, N);
-        if (gate_trips(smax)) { illcond = true; info.flags |= QP_FLAG_ILLCOND; }
+        if (numeric_gate && gate_trips_inverse(smax, N)) { illcond = true; info.flags |= QP_FLAG_ILLCOND; }
     }
     // PIVOT_CONDSWEEP (the condensed register kernel, pmpc_qp_cond.hpp): the constraint block of K is eliminated in closed form as in factorise_sweep_cf,
     // but the constraint rows are not carried at all — only S = P + A' diag(rho) A (n x n; block-lower 16 x 16 tiles, diagonal tiles in full) is swept,
@@ -618,7 +628,7 @@ struct BoxADMM {
         for (int a = 0; a < N; ++a) smax = std::fmax(smax, std::fabs(Mm[a + (size_t)a * N]));
         ldlt.n = N; ldlt.policy = N <= 64 ? PIVOT_SWEEP : PIVOT_SWEEP2; ldlt.M.swap(Mm); ldlt.tr.assign(N, 0); ldlt.temp.assign(N, 0.0);
         ldlt.compute_sweep(true);
-        if (gate_trips(smax)) { illcond = true; info.flags |= QP_FLAG_ILLCOND; }
+        (void)smax;   // (no numeric gate in the condensed register kernels: they decide from the bounds, once per instance — SQP driver)
     }
     // the two products as the kernel forms them (pmpc_qp_cond.hpp): fma chains — the differentiation-matrix entries of the column / row over the nodes
     // ascending (0 on the own node and outside the segments; a control column of the first 64 variables walks zeros), then the own node's block. Needs the

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64, 2) void qp_boxadmm_reg_kernel(int B, const doub
     const int b = blockIdx.x;
     if (b >= B) return;
     pmpc_qp_info qi;
-    boxadmm_solve_reg<NN, MM, false, true>(H + (size_t)b * NN * NN, h + (size_t)b * NN, A + (size_t)b * MM * NN, Alb + (size_t)b * MM, Aub + (size_t)b * MM,
+    boxadmm_solve_reg<NN, MM, false, true, true>(H + (size_t)b * NN * NN, h + (size_t)b * NN, A + (size_t)b * MM * NN, Alb + (size_t)b * MM, Aub + (size_t)b * MM,
                               xlb + (size_t)b * NN, xub + (size_t)b * NN, x0 ? x0 + (size_t)b * NN : nullptr,
                               y0 ? y0 + (size_t)b * (NN + MM) : nullptr, s, qi, x + (size_t)b * NN, y + (size_t)b * (NN + MM), tr);
     if (lane_id() == 0) info[b] = qi;

@@ -47,7 +47,7 @@ template <class Model> __host__ __device__ inline size_t big_scratch_doubles(int
 // KHBM: large-instance mode of the LDS-resident kernels — the KKT factor lives in an HBM workspace (Kws). A compile-time flag so
 // that in the normal mode every QP pointer provably addresses LDS (ds_read / ds_write instead of flat accesses, which cost the
 // LDS path most of its time when the location of K was a run-time choice)
-template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bool KHBM = false, bool W2 = false, bool POL = false, bool CND = false>   // CND: condensed register QP (pmpc_qp_cond.hpp); W2: the HBM-factor kernel compiled for two wavefronts per SIMD (256 registers); POL: register-resident kernel with the Ruiz / filter-line-search hooks compiled in
+template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bool KHBM = false, bool W2 = false, bool POL = false, bool CND = false, bool WG4 = false>   // WG4: the HBM-factor kernel on a workgroup of FOUR wavefronts per instance (BigTeam, pmpc_qp_big.hpp: small batches / lone instances); CND: condensed register QP (pmpc_qp_cond.hpp); W2: the HBM-factor kernel compiled for two wavefronts per SIMD (256 registers); POL: register-resident kernel with the Ruiz / filter-line-search hooks compiled in
 #ifndef PMPC_SQP_WAVES
 #define PMPC_SQP_WAVES 2
 #endif
@@ -57,7 +57,7 @@ template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bo
 #ifndef PMPC_COND1_WAVES
 #define PMPC_COND1_WAVES 1   /* condensed register kernel on at most 64 variables: wavefronts per SIMD — measured on the 11-node robot grid: two wavefronts (256 registers: 240 spilled values, eight scratch accesses in the ADMM loop) 2.82 ms per 4096, one wavefront 2.67 (the full inverse: 4.04) */
 #endif
-__global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : ((NN > 0 && CND && NN <= 64) ? PMPC_COND1_WAVES : ((KHBM && W2) ? 2 : (KHBM ? PMPC_BIG_WAVES : 1))))) void sqp_kernel(Model model, const ChebData* __restrict__ cd, int B,
+__global__ __launch_bounds__(WG4 ? 256 : 64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : ((NN > 0 && CND && NN <= 64) ? PMPC_COND1_WAVES : ((KHBM && W2) ? 2 : (KHBM ? PMPC_BIG_WAVES : 1))))) void sqp_kernel(Model model, const ChebData* __restrict__ cd, int B,
                                                  const double* __restrict__ x_guess, const double* __restrict__ lam_guess,
                                                  const double* __restrict__ d, const double* __restrict__ lbx,
                                                  const double* __restrict__ ubx, const double* __restrict__ lbg,
@@ -70,8 +70,8 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
     const int b = blockIdx.x;
     if (b >= B) return;
     // redo launch (the full-KKT-form kernel behind a condensed one): only the instances whose condensed solve gave up at its conditioning gate
-    const bool redo_launch = it_begin == PMPC_REDO_MODE;
-    if (redo_launch) { if (__builtin_amdgcn_readfirstlane(info[b].status) != PMPC_SQP_REDO) return; it_begin = 0; }
+    int flags0 = 0;   // (redo launch: PMPC_FLAG_ILLCOND is part of the instance's flags from the start — information for the caller: this instance took the full KKT form)
+    if (it_begin == PMPC_REDO_MODE) { if (__builtin_amdgcn_readfirstlane(info[b].status) != PMPC_SQP_REDO) return; it_begin = 0; flags0 = PMPC_FLAG_ILLCOND; }
     // iteration-sliced execution: instances that finished in an earlier slice give their slot back immediately
     if (it_begin != 0 && __builtin_amdgcn_readfirstlane(info[b].status) != PMPC_SQP_IN_PROGRESS) return;
     // it_begin < 0: resume mode (the launch behind the round-robin kernel, sqp_kernel_rr below): every instance continues from the iteration its own record holds
@@ -84,11 +84,12 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
     // hammer (the QP solution x / y and the right-hand side): the SQP vectors (20 of length n or n+m), the per-node AD staging and the remaining
     // QP vectors go to a per-instance scratch region behind the factor. With them in LDS one instance took 157 KB — ONE wavefront per CU, three
     // SIMDs of four idle (config C: 256 instances in flight, four rounds); now a CU holds one instance per SIMD.
-    double* p; double* stage0; const double* stage_end;
+    double* p; double* stage0; const double* stage_end; double* big_mail = nullptr;
     if constexpr (NN == 0 && KHBM) {
         p = qw.carve_xy(smem, n, m);
         double* rhsL = p; p += n + m;
         qw.big_lds = p; p += BigKkt::LDS_DOUBLES;   // diagonal tile + broadcast slots of the blocked factorisation
+        big_mail = p; p += BIG_MAIL_DOUBLES;        // mailbox of the four-wavefront team (WG4)
         ocp.Dlds = p; p += (size_t)(P + 1) * (P + 2);
         if constexpr (Model::NG == 0 && Model::NP == 0) { if (JViewRT<Model>::tab_worth_it(ocp.dm.NN)) { p += (p - smem) & 1; ocp.jtab = p; p += JViewRT<Model>::tab_doubles(ocp.dm.NN); } }   // D~ tables of the condensed solve's sparse products
         double* Wb = Kws + (size_t)b * (BigKkt::doubles(n + m) + big_scratch_doubles<Model>(P, S));
@@ -114,11 +115,16 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
     }
     double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
     const int ln = lane_id();
-    for (int i = ln; i < Model::ND; i += WAVE) dL[i] = d[(size_t)b * Model::ND + i];
     ocp.d = dL;
     double* filt = nullptr;   // LSFilter of this instance (line_search = 1; the register-resident specialisations do not carry it)
+    if constexpr (NN == 0 || POL) { filt = p; p += FILTER_LDS_DOUBLES; }
+    if constexpr (WG4) {
+        // wavefronts 1 .. 3 of a four-wavefront team (BigTeam): every pointer above is set up on them as on the first wavefront — the carve is pure
+        // arithmetic —, no data has moved yet; from here on they run the routines the first wavefront posts (big_helper_loop) and nothing else
+        if (threadIdx.x >= WAVE) { big_helper_loop<Model>((BigMail<JViewRT<Model>>*)big_mail, (int)(threadIdx.x >> 6), ocp); return; }
+    }
+    for (int i = ln; i < Model::ND; i += WAVE) dL[i] = d[(size_t)b * Model::ND + i];
     if constexpr (NN == 0 || POL) {
-        filt = p; p += FILTER_LDS_DOUBLES;
         const bool carried = ss.line_search == 1 && ss.filter_state != nullptr;
         if (ln < PMPC_FILTER_STATE_DOUBLES) filt[ln] = carried ? ss.filter_state[(size_t)b * PMPC_FILTER_STATE_DOUBLES + ln] : 0.0;
     }
@@ -143,10 +149,21 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
         v.ubg[i] = ubg ? ubg[(size_t)b * mi + i] : INFINITY;
     }
     wsync();
+    if constexpr (NN > 0 && CND) {   // the conditioning rule of the register-resident kernels (see the epilogue below) for the condensed kernels: before any work
+        if (it_begin == 0 && flags0 == 0) {
+            bool loose = false;
+            for (int i = ocp.dm.VARX + ln; i < n; i += WAVE) loose |= classify_bounds(v.lbx[i], v.ubx[i]) == 2;
+            if (__builtin_amdgcn_ballot_w64(loose) != 0) {
+                if (ln == 0) { pmpc_sqp_info r; r.iter = 0; r.qp_solver_iter = 0; r.status = PMPC_SQP_REDO; r.flags = PMPC_FLAG_ILLCOND; r.primal_norm = 0.0; r.dual_norm = 0.0; r.max_violation = 0.0; r.cost = 0.0; info[b] = r; }
+                return;
+            }
+        }
+    }
     // stacked workspace K0 = [H ; J] ((n+m) x n, column-major, leading dimension n+m): lane i reads row i of K0 with ONE stride
     double* K0 = Hws + (size_t)b * (size_t)(n + m) * n;
     (void)Aws;
-    SqpDevice<Model, NN, MM, PROF, HU, KHBM, POL, CND ? -1 : ((KHBM && W2) ? -2 : 0)> sqp(ocp, v, qw, K0, K0 + n, ss, qs);
+    SqpDevice<Model, NN, MM, PROF, HU, KHBM, POL, CND ? -1 : ((KHBM && W2) ? -2 : ((KHBM && WG4) ? -3 : 0))> sqp(ocp, v, qw, K0, K0 + n, ss, qs);
+    sqp.big_mail = big_mail;
     sqp.filt = filt;
     sqp.eig = eigw;
     sqp.trace = ss.iteration_trace ? ss.iteration_trace + (size_t)b * (size_t)ss.iteration_trace_capacity * PMPC_TRACE_DOUBLES : nullptr;
@@ -160,9 +177,24 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
         sqp.ls_side_by_side = (G >= 2 && need <= have);
     }
     pmpc_sqp_info si;
+    sqp.qp_flags = flags0;
     if (it_begin > 0) { const pmpc_sqp_info prev = info[b]; sqp.qp_iter_total = prev.qp_solver_iter; sqp.qp_flags = prev.flags; sqp.cost_log = prev.cost; }
     sqp.solve(si, it_begin, it_end);
-    if (redo_launch) si.flags |= PMPC_FLAG_ILLCOND;   // (information for the caller: this instance took the full KKT form)
+    if constexpr (NN > 0 && NN + MM <= WAVE && !CND) {   // (the constraint-first one-row-per-lane kernels; the condensed kernels test in their prologue, see there)
+        // Conditioning rule of the register-resident kernels (PMPC_FLAG_ILLCOND, include/polympc_amd.h), decided per instance from its BOUNDS: these
+        // kernels invert S = P + A' diag(rho) A (constraint-first sweep / condensed form), whose condition number rho_eq |A|^2 / lambda_min(P on null A)
+        // stays ~1e5 whatever rho is as long as the directions the collocation Jacobian leaves free — the controls and parameters — are BOUNDED
+        // (rho_box scales with rho), and grows with rho when one of them is not (rho_box = RHO_MIN). Such an instance is handed to the redo launch
+        // (full KKT form); what this kernel computed for it is discarded. Where the test sits is measured, not chosen: in FRONT of the solve its 130
+        // instructions cost the bench kernel 2 % (same box A/B: 1.145 -> 1.17 ms; behind it 1.15), while the condensed kernels lose 3 % with the test
+        // behind the solve and nothing with it in front (16-node grid 6.09 / 6.28 / 6.07 ms) — code placement. A numeric gate at every factorisation —
+        // what the large-instance kernel and the QP entry point use — cost these kernels 4 .. 10 % through register pressure alone (EXPERIMENTS.md round 5).
+        if (flags0 == 0 && si.status != PMPC_SQP_IN_PROGRESS) {
+            bool loose = false;
+            for (int i = ocp.dm.VARX + ln; i < n; i += WAVE) loose |= classify_bounds(v.lbx[i], v.ubx[i]) == 2;
+            if (__builtin_amdgcn_ballot_w64(loose) != 0) { si.status = PMPC_SQP_REDO; si.flags = PMPC_FLAG_ILLCOND; }
+        }
+    }
     if (si.status == PMPC_SQP_IN_PROGRESS && sst) for (int i = ln; i < n; i += WAVE) { sst[i] = v.lg[i]; sst[n + i] = v.step[i]; }
     for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = v.x[i];
     for (int i = ln; i < m + n; i += WAVE) lam[(size_t)b * (m + n) + i] = v.lam[i];
@@ -171,6 +203,10 @@ __global__ __launch_bounds__(64, ((NN > 0 && NN + MM <= 64) ? PMPC_SQP_WAVES : (
         if (ss.line_search == 1 && ss.filter_state != nullptr && si.status != PMPC_SQP_REDO && ln < PMPC_FILTER_STATE_DOUBLES) ss.filter_state[(size_t)b * PMPC_FILTER_STATE_DOUBLES + ln] = filt[ln];
     }
     if constexpr (PROF) { if (phase_cycles && ln == 0) for (int i = 0; i < 24; ++i) atomicAdd(&phase_cycles[i], (unsigned long long)sqp.cyc[i]); }
+    if constexpr (WG4) {   // release the helpers
+        if (ln == 0) ((BigMail<JViewRT<Model>>*)big_mail)->op = BIG_OP_EXIT;
+        __syncthreads();
+    }
 }
 // ---------------------------------------------------------------------------------------------------------------------------------------------
 // Block-structured specialisation (pmpc_qp_schur.hpp): the Hessian is block diagonal per node — the block BFGS every control test of the reference
@@ -436,6 +472,11 @@ __global__ __launch_bounds__(64, PMPC_SQP_WAVES) void sqp_kernel_rr(Model model,
                 if (!hard) break;
             }
         }
+        if (si.status != PMPC_SQP_IN_PROGRESS) {   // the conditioning rule of the register-resident kernels (see sqp_kernel): unbounded controls / parameters -> the redo launch
+            bool loose = false;
+            for (int i = ocp.dm.VARX + ln; i < n; i += WAVE) loose |= classify_bounds(v.lbx[i], v.ubx[i]) == 2;
+            if (__builtin_amdgcn_ballot_w64(loose) != 0) { si.status = PMPC_SQP_REDO; si.flags = PMPC_FLAG_ILLCOND; }
+        }
         RR_T(t3);
 #ifdef PMPC_RR_PROFILE   // per-item wall-clock stamps (100 MHz) in the alpha / primal_norm / dual_norm fields of the iteration record
         if (ss.iteration_trace && ln == 0 && si.iter <= ss.iteration_trace_capacity) {
@@ -476,13 +517,14 @@ template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode
     size_t stage = OcpLds<Model>::doubles(P, S);
     if (mode == 1) { const size_t need = (size_t)RegKkt<64>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
     if (mode == 2)   // large instances: x, y, the right-hand side of the substitutions and the factorisation's diagonal tile; everything else in HBM
-        return (QpLds::doubles_xy(dm.n, dm.m) + (size_t)(dm.n + dm.m) + BigKkt::LDS_DOUBLES + (size_t)(P + 1) * (P + 2) + ((Model::NG == 0 && Model::NP == 0 && JViewRT<Model>::tab_worth_it(dm.NN)) ? JViewRT<Model>::tab_doubles(dm.NN) + 1 : 0) + (Model::ND > 0 ? Model::ND : 1) + FILTER_LDS_DOUBLES + 8) * sizeof(double);
+        return (QpLds::doubles_xy(dm.n, dm.m) + (size_t)(dm.n + dm.m) + BigKkt::LDS_DOUBLES + BIG_MAIL_DOUBLES + (size_t)(P + 1) * (P + 2) + ((Model::NG == 0 && Model::NP == 0 && JViewRT<Model>::tab_worth_it(dm.NN)) ? JViewRT<Model>::tab_doubles(dm.NN) + 1 : 0) + (Model::ND > 0 ? Model::ND : 1) + FILTER_LDS_DOUBLES + 8) * sizeof(double);
     if (mode == 3) { const size_t need = (size_t)RegKkt2<112>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
     if (mode == 5) { const size_t need = (size_t)RegKkt<64>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }   // condensed register QP on at most 64 variables (65..128 KKT rows)
     if (mode == 4) { const size_t need = (size_t)RegKkt2<128>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }   // 113..128 rows: LDS-resident operand tiles
     return ((mode == 0 ? QpLds::doubles(dm.n, dm.m) : QpLds::doubles_xy(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8 +
             ((mode == 1 || mode == 3 || mode == 4 || mode == 5) ? (mode == 1 ? 0 : jview_doubles<Model>(dm.NN)) + (pol ? FILTER_LDS_DOUBLES : 0) : FILTER_LDS_DOUBLES) + (mode == 2 ? BigKkt::LDS_DOUBLES : 0)) * sizeof(double);
 }
+constexpr int BIG_WG4_MAX_BATCH = 256;   // instances (on a 256-CU device) up to which the four-wavefront team kernel serves a large-instance batch (see sqp_launch_dev; measured: one workgroup per CU — 256: 11.9 -> 9.9 ms, 512: 13.5 -> 19.2)
 constexpr int BIG_TWO_WAVES_MAX_ROWS = 200;   // below: two wavefronts per SIMD on the HBM-factor kernel when the batch exceeds the SIMD count (see sqp_launch_dev)
 constexpr int BIG_KKT_MIN_ROWS = 96;   // n + m from which sqp_launch_dev prefers the HBM-factor kernel (see there)
 template <class Model> inline bool sqp_hbm_mode_fits(int P, int S) {   // do the QP vectors fit the second-order staging?
@@ -666,7 +708,7 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
         for (int it = 0; it < ss->max_iter; it += slice)
             hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), ldsq, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
                                *ss, *qs, Hws, Aws, x, lam, info, timed ? phase : (unsigned long long*)nullptr, (double*)nullptr, it, it + slice, slice_state, (unsigned)(ldsq / sizeof(double)));
-        if (pmpc_internal_last_route(ctx) == PMPC_ROUTE_CONDREG) {
+        if (pmpc_internal_last_route(ctx) == PMPC_ROUTE_CONDREG && !getenv("PMPC_NO_REDO_LAUNCH")) {
             // redo launch: the instances whose condensed solve gave up at its conditioning gate (PMPC_FLAG_ILLCOND; none on any BASELINE workload) are solved
             // again, from their guesses, by the full-inverse kernel of this size — every other workgroup reads one word and exits
             if (hipFuncSetAttribute((const void*)kern_full, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
@@ -759,17 +801,37 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     // build of the same kernel) hides part of that latency — per 4096 robots 128 rows 40.5 -> 35.4 ms, 168 rows 64.3 -> 60.8; at config C's 464 rows
     // the second wave only thrashes the L2 (2048 instances 93.0 -> 99.1 ms), hence the row bound.
     if (Kws && dm.n + dm.m < BIG_TWO_WAVES_MAX_ROWS && B > pmpc_internal_simd_count(ctx) && !phase) lkern = sqp_kernel<Model, 0, 0, false, 0, true, true>;
-    if constexpr (LDS_PATH_PROFILED<Model>::value) { if (phase) lkern = Kws ? sqp_kernel<Model, 0, 0, true, 0, true> : sqp_kernel<Model, 0, 0, true>; }   // developer builds with phase timers
+    // Small batches of large instances: a workgroup of four wavefronts per instance (BigTeam, pmpc_qp_big.hpp). With at most one instance per CU the chip is a
+    // quarter full at best on the one-wavefront kernel and the launch takes a lone instance's time; the team cuts that time (the condensed build, the blocked
+    // factorisation and the two triangular passes run on four SIMDs). Beyond BIG_WG4_MAX_BATCH instances the one-wavefront kernel's four instances per CU win.
+    // PMPC_BIG_WG4 = 0 / 1: developer switch (never / whenever eligible).
+    unsigned threads = WAVE;
+    if constexpr (Model::NG == 0 && Model::NP == 0) {
+        const char* e = getenv("PMPC_BIG_WG4");
+        const bool eligible = Kws && lkern == sqp_kernel<Model, 0, 0, false, 0, true> && ss->kkt_form == 0 && ss->preconditioner == 0 && ss->qp_solver == 0 && ss->regularisation != 1 &&
+                              dm.n <= BIG_COND_MAX_ROWS && dm.m <= BIG_COND_MAX_ROWS && slice_iters == 0;
+        const bool want = e && e[0] ? (e[0] != '0') : (B <= BIG_WG4_MAX_BATCH * (pmpc_internal_simd_count(ctx) / 4) / 256);
+        if (eligible && want) { lkern = sqp_kernel<Model, 0, 0, false, 0, true, false, false, false, true>; threads = 4 * WAVE; }
+    }
+    const bool team_kernel = threads != WAVE;
+    if constexpr (LDS_PATH_PROFILED<Model>::value) {   // developer builds with phase timers
+        if (phase) {
+            lkern = Kws ? sqp_kernel<Model, 0, 0, true, 0, true> : sqp_kernel<Model, 0, 0, true>;
+            if constexpr (Model::NG == 0 && Model::NP == 0) { if (team_kernel) lkern = sqp_kernel<Model, 0, 0, true, 0, true, false, false, false, true>; }
+        }
+    } else if (phase && team_kernel) { lkern = sqp_kernel<Model, 0, 0, false, 0, true>; threads = WAVE; }
     if (hipFuncSetAttribute((const void*)lkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PMPC_ERR_HIP;
     const int slice = (slice_iters > 0) ? slice_iters : ss->max_iter;
     for (int it = 0; it < ss->max_iter; it += slice)
-        hipLaunchKernelGGL(lkern, dim3(B), dim3(WAVE), lds, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, *ss, *qs, Hws, Aws,
+        hipLaunchKernelGGL(lkern, dim3(B), dim3(threads), lds, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, *ss, *qs, Hws, Aws,
                            x, lam, info, phase, Kws, it, it + slice, slice_state, (unsigned)(lds / sizeof(double)));
-    if (Kws && ss->kkt_form == 0 && ss->qp_solver == 0) {
+    if (Kws && ss->kkt_form == 0 && ss->qp_solver == 0 && !getenv("PMPC_NO_REDO_LAUNCH")) {
         // redo launch (large-instance kernel, condensed mode): the instances whose QP gave up at its conditioning gate (PMPC_FLAG_ILLCOND; none on any
         // BASELINE workload) are solved again, from their guesses, by the same kernel in the (n + m)-row KKT form — every other workgroup reads one word and exits
         pmpc_sqp_settings ss_full = *ss; ss_full.kkt_form = 1;
-        hipLaunchKernelGGL(lkern, dim3(B), dim3(WAVE), lds, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss_full, *qs, Hws, Aws,
+        auto rkern = sqp_kernel<Model, 0, 0, false, 0, true>;   // (the one-wavefront kernel: the full KKT form has no team version)
+        if (threads != WAVE && hipFuncSetAttribute((const void*)rkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PMPC_ERR_HIP;
+        hipLaunchKernelGGL((threads != WAVE ? rkern : lkern), dim3(B), dim3(WAVE), lds, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss_full, *qs, Hws, Aws,
                            x, lam, info, (unsigned long long*)nullptr, Kws, PMPC_REDO_MODE, ss->max_iter, (double*)nullptr, (unsigned)(lds / sizeof(double)));
     }
     return (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;

@@ -313,10 +313,14 @@ struct Ocp {
     // nested dual number never mix, so each lane carries Dual<Dual<double,1>,1> (4 doubles per AD variable instead of
     // 2*(NDER+1): no private-memory arrays, a small register footprint even for 16 derivative directions) and every entry
     // goes through exactly the operations it went through as component r of the wide inner dual.
-    __device__ __forceinline__ void stage_second_order_entry(const double* var, const double* lam) {
+    __device__ __forceinline__ void stage_second_order_entry(const double* var, const double* lam) { stage_second_order_entry_part<1>(var, lam, 0); wsync(); }
+    // the entries e = w * 64 + lane, stride 64 NW: wavefront w of a team of NW (the large-instance kernel on a workgroup of four wavefronts, BigTeam): every
+    // entry is independent of every other one; the caller synchronises the team behind it
+    template <int NW>
+    __device__ __forceinline__ void stage_second_order_entry_part(const double* var, const double* lam, int w) {
         using adi = Dual<double, 1>;
         using ad2 = Dual<adi, 1>;
-        for (int e = lane_id(); e < dm.NN * NDER * NDER; e += WAVE) {
+        for (int e = lane_id() + WAVE * w; e < dm.NN * NDER * NDER; e += WAVE * NW) {
             const int k = e % dm.NN, dr = e / dm.NN, dir = dr / NDER, r = dr - dir * NDER;
             ad2 y[NX > 0 ? NX : 1];
             // second-order seeding (continuous_ocp.hpp:691-735 restricted to one outer and one inner partial), generated element by element where the
@@ -350,7 +354,6 @@ struct Ocp {
                 s.Mhes[dir * NDER + r] = M.d[0].d[0];
             }
         }
-        wsync();
     }
 
     // ---- assemble c (m), Jacobian J (m x n column-major in HBM), cost value and cost gradient from the first-order stage

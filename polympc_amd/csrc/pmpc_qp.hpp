@@ -632,8 +632,29 @@ __device__ __forceinline__ void kkt_solve_pivoted(const QpLds& w, int N, double*
 
 // large-instance linear algebra (pmpc_qp_big.hpp, included after this header by its users)
 __device__ __forceinline__ void big_build(double* W, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ A, int lda, const double* kdiag);
-__device__ __forceinline__ double big_factor(double* W, int N, double* dl);
-template <bool SLIM> __device__ __forceinline__ void big_solve(const double* W, int N, double* v, double* bx);
+// The wavefronts that work on ONE instance's linear algebra (round 5). NW = 1: the one-wavefront-per-instance kernels — every function below is then the
+// code it was. NW = 4 (sqp_kernel<..., WG4>: one workgroup of four wavefronts per instance, small batches — a lone instance's latency is what a
+// receding-horizon controller waits for): wavefront 0 runs the instance's serial code (linearisation, BFGS, ADMM vector updates, line search) and posts the
+// three heavy routines — condensed build + blocked factorisation, the condensed solve — to a mailbox in LDS (BigMail, big_helper_loop); all four
+// wavefronts then execute the routine with the independent pieces dealt round-robin (tiles of the build, tile-row groups of the left-looking updates,
+// 64-row slots of the forward pass, column quadruples of the backward pass, 64-entry chunks of the two sparse products). Every fma chain stays on ONE
+// wavefront in the order it had, so the results are bit-identical to the one-wavefront kernels (and to PIVOT_CONDENSED). sync() is a workgroup barrier
+// with workgroup-scope memory ordering (the pieces exchange data through the HBM factor workspace and LDS).
+template <int NW>
+struct BigTeam {
+    int w = 0;   // this wavefront's index in the team
+    __device__ __forceinline__ void sync() const { if constexpr (NW > 1) __syncthreads(); else { wfence(); wsync(); } }
+    __device__ __forceinline__ bool mine(int item) const { if constexpr (NW > 1) return (item % NW) == w; else return true; }
+    __device__ __forceinline__ bool lead() const { if constexpr (NW > 1) return w == 0; else return true; }
+};
+enum { BIG_OP_EXIT = 0, BIG_OP_FACTOR = 1, BIG_OP_SOLVE = 2, BIG_OP_STAGE2 = 3 };   // mailbox of a team (BigMail, pmpc_qp_big.hpp)
+template <class JV> struct BigMail;
+template <int NW> __device__ __forceinline__ double big_factor(double* W, int N, double* dl, const BigTeam<NW>& team);
+template <bool SLIM, int NW> __device__ __forceinline__ void big_solve(const double* W, int N, double* v, double* bx, const BigTeam<NW>& team);
+template <class JV, int NW> __device__ __forceinline__ double big_build_condensed(double* W, int n, int m, const double* __restrict__ H, int ldh, const double* kdiag,
+                                                                                  const double* rho, const JV& jv, const BigTeam<NW>& team, double* red4);
+template <bool SLIM, int NW, class JV> __device__ __forceinline__ void big_cond_solve(const double* K, int n, int m, double* rhs, const double* rho, double* scr, const JV& jv,
+                                                                                      const BigTeam<NW>& team, long long* t_atu, long long* t_tri);
 
 // boxADMM::solve_impl (box_admm.hpp:88-205). Result in w.x (n) and w.y (m+n). h/Alb/Aub/xlb/xub may live in LDS or HBM.
 // H(i,j) = H[j*ldh + i], A(r,j) = A[j*lda + r]  (ldh = n, lda = m for plain column-major inputs)
@@ -684,11 +705,11 @@ __device__ __forceinline__ void qp_residuals_sparse(const QpLds& w, int n, int m
 
 struct NoJView {};   // tag: the QP has no structure information (the plain QP entry points)
 constexpr int BIG_COND_MAX_ROWS = 272;   // condensed mode: n and m up to this (the passes of its sparse products are unrolled; 4 x 16 ceil(n / 16) doubles of LDS hold a row panel)
-template <bool BIG = false, class JV = NoJView, bool SLIM = false>   // SLIM: the two-wavefronts-per-SIMD build of the large-instance mode (see big_solve)
+template <bool BIG = false, class JV = NoJView, bool SLIM = false, int NW = 1>   // SLIM: the two-wavefronts-per-SIMD build of the large-instance mode (see big_solve); NW = 4: a team of four wavefronts on the condensed linear algebra (BigTeam, pmpc_qp_big.hpp) — this function runs on the first one
 __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* h,
                                      const double* __restrict__ A, int lda, const double* Alb, const double* Aub, const double* xlb,
                                      const double* xub, const double* x0, const double* y0, const pmpc_qp_settings& s,
-                                     pmpc_qp_info& info, long long* tm = nullptr, const JV& jv = JV(), bool condensed = false) {   // tm (phase profiling): [0] build + factor, [1] residuals, [2] substitutions, [3] build alone, [4] condensed mode: A'(rho r2), [5] condensed mode: the two triangular passes
+                                     pmpc_qp_info& info, long long* tm = nullptr, const JV& jv = JV(), bool condensed = false, BigMail<JV>* mail = nullptr) {   // tm (phase profiling): [0] build + factor, [1] residuals, [2] substitutions, [3] build alone, [4] condensed mode: A'(rho r2), [5] condensed mode: the two triangular passes
     const int ln = lane_id();
     const int N = n + m;
     constexpr bool HASJ = BIG && !std::is_same<JV, NoJView>::value;
@@ -698,12 +719,17 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
         if constexpr (BIG) {
             if constexpr (HASJ) {
                 if (cond) {
-                    const double smax = big_build_condensed(w.K, n, m, H, ldh, w.kdiag, w.rho, jv); if (tb) *tb = clock64();
-                    const double pmin = big_factor(w.K, n, w.big_lds);
+                    BigTeam<NW> team;
+                    if constexpr (NW > 1) {   // post the routine to the team's helpers (big_helper_loop)
+                        if (ln == 0) { mail->op = BIG_OP_FACTOR; mail->n = n; mail->m = m; mail->ldh = ldh; mail->K = w.K; mail->H = H; mail->kdiag = w.kdiag; mail->rho = w.rho; mail->rhs = w.rhs; mail->scr = w.big_lds; mail->jv = jv; }
+                        __syncthreads();
+                    }
+                    const double smax = big_build_condensed<JV, NW>(w.K, n, m, H, ldh, w.kdiag, w.rho, jv, team, NW > 1 ? mail->red4 : nullptr); if (tb) *tb = clock64();
+                    const double pmin = big_factor<NW>(w.K, n, w.big_lds, team);
                     return __builtin_amdgcn_readfirstlane((int)(smax > PMPC_COND_GATE * pmin)) != 0;
                 }
             }
-            big_build(w.K, n, m, H, ldh, A, lda, w.kdiag); if (tb) *tb = clock64(); (void)big_factor(w.K, N, w.big_lds);
+            big_build(w.K, n, m, H, ldh, A, lda, w.kdiag); if (tb) *tb = clock64(); (void)big_factor<1>(w.K, N, w.big_lds, BigTeam<1>());
         }
         return false;
     };
@@ -769,40 +795,14 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
           if constexpr (BIG) {
               bool done = false;
               if constexpr (HASJ) {
-                  if (cond) {   // t = r1 + A'(rho o r2) ; x = S^{-1} t ; nu = rho o (A x - r2)   (the scaled r2 in the LDS slots big_solve uses later)
-                      double* u = w.big_lds + 256;
-                      for (int i = ln; i < m; i += WAVE) u[i] = w.rho[i] * w.rhs[n + i];
-                      wsync();
-                      for (int c0 = 0; c0 < n; c0 += WAVE) {
-                          const int c = c0 + ln;
-                          const typename JV::Col cc = jv.column(c < n ? c : 0);
-                          double bv[JV::NCB > 0 ? JV::NCB : 1];
-                          jv.col_block(cc, bv);
-                          double t;
-                          if constexpr ((int)JV::NG == 0 && (int)JV::NP == 0) t = jv.tab ? jv.coldot_fma_tab(cc, bv, u, w.rhs[c < n ? c : 0]) : jv.coldot_fma(cc, bv, u, w.rhs[c < n ? c : 0]);
-                          else t = jv.coldot_fma(cc, bv, u, w.rhs[c < n ? c : 0]);
-                          if (c < n) w.rhs[c] = t;
-                      }
-                      wsync();
-                      const long long s0 = tick();
-                      big_solve<SLIM>(w.K, n, w.rhs, w.big_lds + 256);
-                      const long long s1 = tick();
-                      if (tm) { tm[4] += s0 - t0; tm[5] += s1 - s0; }
-                      for (int r0 = 0; r0 < m; r0 += WAVE) {
-                          const int r = r0 + ln;
-                          const typename JV::Row rw = jv.rowinfo(r < m ? r : 0);
-                          double bv[JV::NDER];
-                          jv.row_block(rw, bv);
-                          double a;
-                          if constexpr ((int)JV::NG == 0 && (int)JV::NP == 0) a = jv.tab ? jv.rowdot_fma_tab(rw, bv, w.rhs) : jv.rowdot_fma(rw, bv, w.rhs);
-                          else a = jv.rowdot_fma(rw, bv, w.rhs);
-                          if (r < m) w.rhs[n + r] = w.rho[r] * (a - w.rhs[n + r]);
-                      }
-                      wsync();
+                  if (cond) {   // t = r1 + A'(rho o r2) ; x = S^{-1} t ; nu = rho o (A x - r2)   (big_cond_solve, pmpc_qp_big.hpp)
+                      BigTeam<NW> team;
+                      if constexpr (NW > 1) { if (ln == 0) mail->op = BIG_OP_SOLVE; __syncthreads(); }
+                      big_cond_solve<SLIM, NW, JV>(w.K, n, m, w.rhs, w.rho, w.big_lds, jv, team, tm ? &tm[4] : nullptr, tm ? &tm[5] : nullptr);
                       done = true;
                   }
               }
-              if (!done) big_solve<SLIM>(w.K, N, w.rhs, w.big_lds + 256);
+              if (!done) big_solve<SLIM, 1>(w.K, N, w.rhs, w.big_lds + 256, BigTeam<1>());
           } else { if (pivoted) kkt_solve_pivoted(w, N, w.rhs); else kkt_solve(w, N, w.rhs); }
           if (tm) tm[2] += tick() - t0; }
         for (int i = ln; i < m; i += WAVE) {

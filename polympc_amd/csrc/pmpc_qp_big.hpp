@@ -66,6 +66,7 @@ struct BigKkt {
 using big_d4 = double __attribute__((ext_vector_type(4)));
 using big_d2 = double __attribute__((ext_vector_type(2)));
 
+
 // K (lower block triangle, row-major tiles in W) <- [H + diag ; A, diag]; rows / columns >= N: identity padding.
 // Eight tiles of a tile row per pass (32 independent loads in flight): one tile at a time was a chain of 435 dependent load -> store round trips at 464 rows
 // (2.4 M cycles per factorisation, 8.5 % of config C).
@@ -115,10 +116,11 @@ __device__ __forceinline__ void big_build(double* W, int n, int m, const double*
 // A operand rho_r J(r, i), B operand J(r, j); the operands are evaluated from the block-sparse view of J (per-node blocks + differentiation
 // matrix), the dense J is never read. Restated on the CPU by the test suite as PIVOT_CONDENSED.
 // Returns max_i S_ii (the conditioning gate of boxadmm_solve reads it).
-template <class JV>
+template <class JV, int NW>
 __device__ __forceinline__ double big_build_condensed(double* W, int n, int m, const double* __restrict__ H, int ldh, const double* kdiag,
-                                                      const double* rho, const JV& jv) {
+                                                      const double* rho, const JV& jv, const BigTeam<NW>& team, double* red4) {
     const int ln = lane_id();
+    int item = 0;   // (pair of block columns, group of tile rows): independent pieces, dealt round-robin over the team
     const int nb = BigKkt::nblk(n);
     const int lr = ln >> 4, lc = ln & 15;
     double dmax = 0.0;
@@ -130,6 +132,7 @@ __device__ __forceinline__ double big_build_condensed(double* W, int n, int m, c
         const int j0 = 16 * Jc + lc, j1 = 16 * (Jc + 1) + lc;
         const typename JV::Col cj0 = jv.column(j0 < n ? j0 : 0), cj1 = jv.column((two && j1 < n) ? j1 : 0);
         for (int I0 = Jc; I0 < nb; I0 += GI) {
+            if (!team.mine(item++)) continue;
             big_d4 T0[GI], T1[GI];
             typename JV::Col ci[GI];
 #pragma unroll
@@ -198,9 +201,15 @@ __device__ __forceinline__ double big_build_condensed(double* W, int n, int m, c
             }
         }
     }
-    wfence();
-    wsync();
-    return wave_max(dmax);
+    team.sync();
+    double dm = wave_max(dmax);
+    if constexpr (NW > 1) {
+        if (ln == 0) red4[team.w] = dm;
+        team.sync();
+        dm = fmax(fmax(red4[0], red4[1]), fmax(red4[2], red4[3]));
+        team.sync();
+    }
+    return dm;
 }
 
 // in-place blocked LDL^T of the tiles in W (see the header). dl: BigKkt::LDS_DOUBLES doubles of LDS. Returns the smallest |pivot| over the rows < N.
@@ -210,7 +219,8 @@ __device__ __forceinline__ double big_build_condensed(double* W, int n, int m, c
 // right-looking schedule re-read and re-wrote every tile per k); then column J is finished (diagonal tile, the rows below apply the 16 pivots), column
 // J + 1 takes its last update (k = J) and is finished. Every entry still receives fma(-c_ik, l_jk, a_ij) for k ascending — the right-looking
 // schedule's operations in the right-looking schedule's order.
-__device__ __forceinline__ double big_factor(double* W, int N, double* dl) {
+template <int NW>
+__device__ __forceinline__ double big_factor(double* W, int N, double* dl, const BigTeam<NW>& team) {
     const int ln = lane_id();
     const int nb = BigKkt::nblk(N), NPAD = nb * 16;
     double piv_min = INFINITY;
@@ -226,6 +236,7 @@ __device__ __forceinline__ double big_factor(double* W, int N, double* dl) {
         constexpr int NC = decltype(nc_tag)::value, GI = decltype(gi_tag)::value;
         if (k1 <= k0) return;
         for (int I0 = I_first; I0 < I_end; I0 += GI) {
+            if (!team.mine((I0 - I_first) / GI + Jc)) continue;   // groups of tile rows: independent, dealt round-robin (rotated by the block column)
             big_d4 T[NC][GI];
             int rowI[GI];
 #pragma unroll
@@ -288,14 +299,14 @@ __device__ __forceinline__ double big_factor(double* W, int N, double* dl) {
     };
     using one = std::integral_constant<int, 1>;
     using two = std::integral_constant<int, 2>;
-    using four = std::integral_constant<int, 4>;
+    using four = std::integral_constant<int, (NW > 1) ? 2 : 4>;   // tile rows per group (a team deals smaller groups: more pieces than wavefronts for longer)
     constexpr int PAIR_MIN_BLOCKS = 16;
 
     // diagonal tile of block column J, then the rows below it: LF panel J and CF strip J
     auto finish_column = [&](int J) {
         double* pF = LF + BigKkt::offF(J, NPAD);
-        // ---- (a) diagonal tile: right-looking LDL^T on 16 lanes (lane r = row r of the tile)
-        {
+        // ---- (a) diagonal tile: right-looking LDL^T on 16 lanes (lane r = row r of the tile) — the team's first wavefront
+        if (team.lead()) {
             double* td = Lr + (size_t)BigKkt::tidx(J, J) * 256;
             const int r = ln & 15;
             double a[16];
@@ -321,14 +332,14 @@ __device__ __forceinline__ double big_factor(double* W, int N, double* dl) {
 #pragma unroll
                 for (int pp = 0; pp < 8; ++pp) { big_d2 v2; v2[0] = a[2 * pp]; v2[1] = a[2 * pp + 1]; *reinterpret_cast<big_d2*>(pF + BigKkt::slab_pair(pp, r)) = v2; }
             }
-            wfence();
-            wsync();
         }
+        team.sync();
         if (J == nb - 1) return;
         // ---- (b) rows below the diagonal tile: 16 pivots applied to the row's own 16 entries (one lane per row)
         double* cs = CF + BigKkt::offC(J, NPAD);
         const int w = NPAD - 16 * (J + 1);
         for (int row0 = 16 * (J + 1); row0 < NPAD; row0 += WAVE) {
+            if (!team.mine((row0 - 16 * (J + 1)) / WAVE)) continue;   // 64-row slots: independent
             const int row = row0 + ln;
             const bool live = row < NPAD;
             const int rw = live ? row : row0;
@@ -353,13 +364,12 @@ __device__ __forceinline__ double big_factor(double* W, int N, double* dl) {
                 for (int pp = 0; pp < 8; ++pp) { big_d2 v2; v2[0] = a[2 * pp]; v2[1] = a[2 * pp + 1]; *reinterpret_cast<big_d2*>(pF + BigKkt::slab_pair(pp, row - 16 * J)) = v2; }
             }
         }
-        wfence();
-        wsync();
+        team.sync();
     };
 
     if (nb < PAIR_MIN_BLOCKS) {   // few block columns: one at a time (the extra passes of the paired schedule cost more than the operands they save: 128 rows +4 %)
         for (int J = 0; J < nb; ++J) {
-            if (J > 0) { update_cols(one{}, four{}, J, J, nb, 0, J); wfence(); wsync(); }
+            if (J > 0) { update_cols(one{}, four{}, J, J, nb, 0, J); team.sync(); }
             finish_column(J);
         }
         return piv_min;
@@ -367,30 +377,169 @@ __device__ __forceinline__ double big_factor(double* W, int N, double* dl) {
     for (int J = 0; J < nb; J += 2) {
         const bool pair = J + 1 < nb;
         if (J > 0) {
-            update_cols(one{}, one{}, J, J, J + 1, 0, J);               // tile (J, J): the only tile of row J in this pair
+            update_cols(one{}, one{}, J, J, J + 1, 0, J);               // tile (J, J): the only tile of row J in this pair (one piece: one wavefront of the team)
             if (pair) update_cols(two{}, four{}, J, J + 1, nb, 0, J);   // rows J + 1 .. : both columns
-            wfence();
-            wsync();
+            team.sync();
         }
         finish_column(J);
         if (!pair) break;
         update_cols(one{}, four{}, J + 1, J + 1, nb, J, J + 1);         // column J + 1: its last update, k = J
-        wfence();
-        wsync();
+        team.sync();
         finish_column(J + 1);
     }
     return piv_min;
 }
 
+// The two triangular passes on a team of NW wavefronts (BigTeam): the same fma chains as big_solve below, each on one wavefront.
+//   forward: per block column every wavefront solves the 16 x 16 unit triangle itself (same loads, same arithmetic — no broadcast through LDS, one barrier
+//     per block column instead of two) and applies the block's 16 entries to ITS 64-row slots of the rows below (slot s of the block column -> wavefront
+//     s mod NW); the panel entries of its slot in the NEXT block column are requested before the triangle solve;
+//   backward: the column sums of a block (per lane one fma chain per column over its rows, slots ascending) are split by COLUMNS — wavefront w owns columns
+//     4w .. 4w+3, i.e. two of the eight column pairs of every slab — so that every chain stays on one wavefront; the group sums and the block's own triangle run
+//     on the first wavefront as in big_solve.
+template <int NW>
+__device__ __forceinline__ void big_solve_team(const double* LF, int N, int nb, int NPAD, double* v, double* bx, const BigTeam<NW>& team) {
+    static_assert(NW == 4, "the backward pass deals the 16 columns of a block in quadruples");
+    const int ln = lane_id();
+    const int r16 = ln & 15;
+    auto load_diag = [&](size_t o, double (&d)[16]) {
+        const double* p = LF + o;
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) { const big_d2 v2 = *reinterpret_cast<const big_d2*>(p + BigKkt::slab_pair(pp, r16)); d[2 * pp] = v2[0]; d[2 * pp + 1] = v2[1]; }
+    };
+    auto load_slot = [&](const double* pF, int J, int row0, double (&L)[16]) {
+        const int row = row0 + ln;
+        const int rw = (row < NPAD) ? row : NPAD - 1;
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) { const big_d2 v2 = *reinterpret_cast<const big_d2*>(pF + BigKkt::slab_pair(pp, rw - 16 * J)); L[2 * pp] = v2[0]; L[2 * pp + 1] = v2[1]; }
+    };
+    // ---- forward
+    {
+        size_t oF = 0;
+        double lrow[16], L[16];
+        load_diag(0, lrow);
+        load_slot(LF, 0, 16 + WAVE * team.w, L);
+        double xprev = 0.0; int jprev = -1;   // the solved block of the previous step: stored behind that step's barrier (the other wavefronts were still reading the unsolved entries)
+        for (int J = 0; J < nb; ++J) {
+            const double* pF = LF + oF;
+            const size_t oN = oF + BigKkt::sizeF(J, NPAD);
+            double lnext[16], Lnext[16];
+            if (J + 1 < nb) {   // requested before the dependent chains below: they depend on no solution entry
+                load_diag(oN, lnext);
+                const int rs = 16 * (J + 2) + WAVE * team.w;
+                load_slot(LF + oN, J + 1, rs, Lnext);
+            }
+            if (team.lead() && jprev >= 0 && ln < 16 && 16 * jprev + r16 < N) v[16 * jprev + r16] = xprev;
+            sched_fence();
+            double xj[16];
+            const int row = 16 * J + r16;
+            double xr = (row < N) ? v[row] : 0.0;
+#pragma unroll
+            for (int c = 0; c < 15; ++c) {
+                const double xc = bcast_lane(xr, c);
+                const double up = fma(-lrow[c], xc, xr);
+                xr = (r16 > c) ? up : xr;
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) xj[c] = bcast_lane(xr, c);
+            asm volatile("" :: "v"(lrow[15]));
+            xprev = xr; jprev = J;
+            bool first = true;
+            for (int row0 = 16 * (J + 1) + WAVE * team.w; row0 < NPAD; row0 += WAVE * NW) {
+                if (!first) load_slot(pF, J, row0, L);
+                first = false;
+                const int rw = row0 + ln;
+                double vi = (rw < N) ? v[rw] : 0.0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) vi = fma(-L[c], xj[c], vi);
+                if (rw < N) v[rw] = vi;
+            }
+            team.sync();
+            if (J + 1 < nb) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) { lrow[c] = lnext[c]; L[c] = Lnext[c]; }
+            }
+            oF = oN;
+        }
+        if (team.lead() && jprev >= 0 && ln < 16 && 16 * jprev + r16 < N) v[16 * jprev + r16] = xprev;
+        team.sync();
+    }
+    // ---- diagonal
+    for (int i = WAVE * team.w + ln; i < N; i += WAVE * NW) {
+        const int I = i >> 4, r = i & 15;
+        v[i] = v[i] / LF[BigKkt::offF(I, NPAD) + BigKkt::slab(r, r)];
+    }
+    team.sync();
+    // ---- backward
+    double* red = bx + 16;
+    double* grp = red + 16 * 65;
+    size_t oFb = BigKkt::offF(nb, NPAD);
+    constexpr int GB = 4;
+    for (int J = nb - 1; J >= 0; --J) {
+        oFb -= BigKkt::sizeF(J, NPAD);
+        const double* pF = LF + oFb;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};   // columns 4w .. 4w + 3 of the block
+        const int r = ln & 15, kq = ln >> 4;
+        double lcol[16];
+        if (team.lead()) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) lcol[c] = pF[BigKkt::slab(r, c)];
+        }
+        for (int row0 = 16 * (J + 1); row0 < NPAD; row0 += GB * WAVE) {
+            big_d2 La[GB], Lb[GB]; double xr[GB];
+#pragma unroll
+            for (int g = 0; g < GB; ++g) {
+                const int row = row0 + g * WAVE + ln;
+                const int rw = (row < NPAD) ? row : NPAD - 1;
+                La[g] = *reinterpret_cast<const big_d2*>(pF + BigKkt::slab_pair(2 * team.w, rw - 16 * J));
+                Lb[g] = *reinterpret_cast<const big_d2*>(pF + BigKkt::slab_pair(2 * team.w + 1, rw - 16 * J));
+                xr[g] = (row < N) ? v[row] : 0.0;
+            }
+#pragma unroll
+            for (int g = 0; g < GB; ++g) {
+                acc[0] = fma(La[g][0], xr[g], acc[0]); acc[1] = fma(La[g][1], xr[g], acc[1]);
+                acc[2] = fma(Lb[g][0], xr[g], acc[2]); acc[3] = fma(Lb[g][1], xr[g], acc[3]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[(4 * team.w + c) * 65 + ln] = acc[c];
+        team.sync();
+        if (team.lead()) {
+            {
+                double t[16], a = 0.0;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t[u] = red[r * 65 + 16 * kq + u];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) a += t[u];
+                grp[kq * 16 + r] = a;
+            }
+            wsync();
+            const int row = 16 * J + r;
+            const double sum = (grp[r] + grp[16 + r]) + (grp[32 + r] + grp[48 + r]);
+            double xr = (row < N) ? v[row] : 0.0;
+            xr = xr - sum;
+#pragma unroll
+            for (int c = 15; c > 0; --c) {
+                const double xc = bcast_lane(xr, c);
+                const double up = fma(-lcol[c], xc, xr);
+                xr = (r < c) ? up : xr;
+            }
+            if (ln < 16 && row < N) v[row] = xr;
+        }
+        team.sync();
+    }
+}
+
 // v <- K^{-1} v, v in LDS (N entries; padding rows are not touched). bx: unused LDS slots.
 // SLIM: the build for TWO wavefronts per SIMD (256 registers, mid-size instances in batches above the SIMD count): two row slots per batch, no
 // look-ahead — the look-ahead below holds 64 + 128 + 16 more registers and made that build spill (the 21-node robot grid: 29.3 -> 32.5 ms per 2048).
-template <bool SLIM>
-__device__ __forceinline__ void big_solve(const double* W, int N, double* v, double* bx) {
+template <bool SLIM, int NW>
+__device__ __forceinline__ void big_solve(const double* W, int N, double* v, double* bx, const BigTeam<NW>& team) {
     const int ln = lane_id();
     const int nb = BigKkt::nblk(N), NPAD = nb * 16;
     const size_t nt = (size_t)BigKkt::ntiles(N);
     const double* LF = W + nt * 256;
+    if constexpr (NW > 1) { big_solve_team<NW>(LF, N, nb, NPAD, v, bx, team); return; }
 #ifndef PMPC_BIG_GS
 #define PMPC_BIG_GS 4
 #endif
@@ -550,6 +699,81 @@ __device__ __forceinline__ void big_solve(const double* W, int N, double* v, dou
         wsync();
     }
     (void)bx;
+}
+
+// One solve of the condensed form on a team (boxadmm_solve, condensed mode):  t = r1 + A'(rho o r2);  x = S^{-1} t;  nu = rho o (A x - r2).
+// rhs: [r1 | r2] in LDS, overwritten with [x | nu]; rho: the constraint penalties; scr: BigKkt::LDS_DOUBLES doubles of LDS (behind its first 256: the
+// scaled r2, then the buffers of big_solve). The 64-entry chunks of the three element-wise / sparse-product loops are dealt round-robin.
+template <bool SLIM, int NW, class JV>
+__device__ __forceinline__ void big_cond_solve(const double* K, int n, int m, double* rhs, const double* rho, double* scr, const JV& jv, const BigTeam<NW>& team,
+                                               long long* t_atu, long long* t_tri) {
+    const int ln = lane_id();
+    const long long t0 = t_atu ? clock64() : 0;
+    double* u = scr + 256;
+    for (int i0 = 0; i0 < m; i0 += WAVE) { if (!team.mine(i0 / WAVE)) continue; const int i = i0 + ln; if (i < m) u[i] = rho[i] * rhs[n + i]; }
+    team.sync();
+    for (int c0 = 0; c0 < n; c0 += WAVE) {
+        if (!team.mine(c0 / WAVE)) continue;
+        const int c = c0 + ln;
+        const typename JV::Col cc = jv.column(c < n ? c : 0);
+        double bv[JV::NCB > 0 ? JV::NCB : 1];
+        jv.col_block(cc, bv);
+        double t;
+        if constexpr ((int)JV::NG == 0 && (int)JV::NP == 0) t = jv.tab ? jv.coldot_fma_tab(cc, bv, u, rhs[c < n ? c : 0]) : jv.coldot_fma(cc, bv, u, rhs[c < n ? c : 0]);
+        else t = jv.coldot_fma(cc, bv, u, rhs[c < n ? c : 0]);
+        if (c < n) rhs[c] = t;
+    }
+    team.sync();
+    const long long s0 = t_atu ? clock64() : 0;
+    big_solve<SLIM, NW>(K, n, rhs, scr + 256, team);
+    const long long s1 = t_atu ? clock64() : 0;
+    if (t_atu) { *t_atu += s0 - t0; *t_tri += s1 - s0; }
+    for (int r0 = 0; r0 < m; r0 += WAVE) {
+        if (!team.mine(r0 / WAVE)) continue;
+        const int r = r0 + ln;
+        const typename JV::Row rw = jv.rowinfo(r < m ? r : 0);
+        double bv[JV::NDER];
+        jv.row_block(rw, bv);
+        double a;
+        if constexpr ((int)JV::NG == 0 && (int)JV::NP == 0) a = jv.tab ? jv.rowdot_fma_tab(rw, bv, rhs) : jv.rowdot_fma(rw, bv, rhs);
+        else a = jv.rowdot_fma(rw, bv, rhs);
+        if (r < m) rhs[n + r] = rho[r] * (a - rhs[n + r]);
+    }
+    team.sync();
+}
+
+// Mailbox of a four-wavefront team in LDS (BigTeam): the first wavefront posts a routine, the workgroup barrier behind the post releases the helpers, every
+// routine ends on a barrier of its own; the helpers then wait for the next post.
+constexpr int BIG_MAIL_DOUBLES = 44;
+template <class Model> struct JViewRT;   // pmpc_jview.hpp
+template <class JV>
+struct BigMail {
+    int op, n, m, ldh;
+    double* K; const double* H; const double* kdiag; const double* rho; double* rhs; double* scr;
+    double red4[4];
+    const double* var; const double* lam;   // BIG_OP_STAGE2: the iterate and the multipliers of the second-order stage
+    JV jv;
+};
+template <class Model, class OcpT>
+__device__ __forceinline__ void big_helper_loop(BigMail<JViewRT<Model>>* mb, int wv, OcpT& ocp) {
+    using JV = JViewRT<Model>;
+    static_assert(sizeof(BigMail<JV>) <= BIG_MAIL_DOUBLES * sizeof(double), "mailbox fits its LDS slot");
+    BigTeam<4> team; team.w = wv;
+    for (;;) {
+        __syncthreads();
+        const int op = __builtin_amdgcn_readfirstlane(mb->op);
+        if (op == BIG_OP_EXIT) return;
+        const int n = __builtin_amdgcn_readfirstlane(mb->n), m = __builtin_amdgcn_readfirstlane(mb->m);
+        if (op == BIG_OP_STAGE2) {   // the entry-per-lane second-order AD stage of the exact linearisation: 4096 independent entries on config C
+            ocp.template stage_second_order_entry_part<4>(mb->var, mb->lam, wv);
+            team.sync();
+        } else if (op == BIG_OP_FACTOR) {
+            (void)big_build_condensed<JV, 4>(mb->K, n, m, mb->H, __builtin_amdgcn_readfirstlane(mb->ldh), mb->kdiag, mb->rho, mb->jv, team, mb->red4);
+            (void)big_factor<4>(mb->K, n, mb->scr, team);
+        } else {
+            big_cond_solve<false, 4, JV>(mb->K, n, m, mb->rhs, mb->rho, mb->scr, mb->jv, team, nullptr, nullptr);
+        }
+    }
 }
 
 }  // namespace pmpc

@@ -221,31 +221,24 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
     double max_Ax_z_norm = 0.0, max_Hx_ATy_h_norm = 0.0, res_prim = 1.0, res_dual = 1.0, rho_estimate = 0.0;
     int iter = 1;
     int until_check = s.check_termination, until_adapt = s.adaptive_rho_interval;
-    bool running = true, gave_up = false;
+    bool running = true;
     while (running) {
         {   // construct_kkt_matrix + factorise_kkt_matrix (box_admm.hpp:209-223, :336-341) in condensed form
             const long long f0 = dbg ? clock64() : 0;
             const double rc_now = rhoc;
-            double smax = 0.0;   // max_i S_ii of the matrix the sweep starts from (conditioning gate below)
             if constexpr (SMALL) {
                 K.invert(ln, tr, kd[0], [&](int j, int z) -> double { return Hlow(j < NN ? j : 0, 0, z); }, tm, 0.0,
                          [&](typename CondKkt<NN>::d4 (&T)[CondKkt<NN>::NT][CondKkt<NN>::NT], double* PA, double* PB, int l, int lr, int lc) {
                              CondKkt<NN>::template rank_update<MM>(T, l, lr, lc, PA, PB, [&](int j, int z) -> double { return Acol(j, 0, z); },
                                                                    [&](int j) -> double { return bcast_lane(rc_now, j); });
-                             smax = CondKkt<NN>::template diag_abs_max<NN>(T, lr, lc);
                          });
             } else {
                 K.invert(ln, tr, kd[0], kd[1], [&](int j, int e, int z) -> double { return Hlow(j < NN ? j : 0, e, z); }, tm,
                          [&](CondKkt<NN>& Kr, double* PA, double* PB, int l, int lr, int lc) {
                              Kr.template rank_update<MM>(l, lr, lc, PA, PB, [&](int j, int e, int z) -> double { return Acol(j, e, z); },
                                                          [&](int j) -> double { return bcast_lane(rc_now, j); });
-                             smax = Kr.diag_abs_max(lr, lc);
                          });
             }
-            // Conditioning gate (PMPC_FLAG_ILLCOND, include/polympc_amd.h): only S = P + A' diag(rho) A is inverted here, and cond(S) grows with rho when
-            // unbounded variables span the directions A leaves free. Estimate max_i S_ii / min_k |pivot_k|; beyond the gate this kernel gives the QP up
-            // (status UNSOLVED + the flag) and the launcher re-solves the instance with the full two-rows-per-lane inverse (pmpc_launch.hpp, redo launch).
-            if (__builtin_amdgcn_readfirstlane((int)(smax > PMPC_COND_GATE * K.piv_min))) { gave_up = true; running = false; if (dbg) dbg[0] += clock64() - f0; break; }
             cond_build_tables<NNODES>(jv.D, jv.P, Dt);   // (the staging they live in was the sweep's)
             if (dbg) dbg[0] += clock64() - f0;
         }
@@ -492,12 +485,12 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
         }
         if (!refactor) running = false;
     }
-    if (iter > s.max_iter && !gave_up) status = PMPC_QP_MAX_ITER_EXCEEDED;
+    if (iter > s.max_iter) status = PMPC_QP_MAX_ITER_EXCEEDED;
 #pragma unroll
     for (int e = 0; e < SL; ++e) if (isP[e]) { out_x[lp[e]] = xv[e]; out_y[MM + lp[e]] = yb[e]; }
     if (isC) out_y[rc] = ya;
     const bool bad = __builtin_amdgcn_ballot_w64((((xv[0] - xv[0]) + (yb[0] - yb[0])) + ((xv[1] - xv[1]) + (yb[1] - yb[1])) + (ya - ya)) != 0.0) != 0;   // non-finite x or y
-    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info.flags = (bad ? PMPC_FLAG_NONFINITE : 0) | (gave_up ? PMPC_FLAG_ILLCOND : 0);
+    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info.flags = bad ? PMPC_FLAG_NONFINITE : 0;
     info.rho_estimate = rho_estimate; info.res_prim = res_prim; info.res_dual = res_dual;
 }
 

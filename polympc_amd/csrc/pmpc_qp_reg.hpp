@@ -107,10 +107,6 @@ struct RegKkt {
     // W = -K^{-1} in mat-vec layout: lane 16*r + c holds  a[16*q + j] = W(16*q + c, 16*r + j)  (q < NT, j < 16; zero where the
     // column index is >= N): the 16 columns of block r against the rows c, c+16, c+32, ... — see apply()
     double a[((N + 15) / 16) * 16];
-    // conditioning estimate of the last invert(): smallest |pivot| of the blocked sweep and — constraint-first mode and the condensed callers — the
-    // largest diagonal entry of the swept matrix before the sweep (wave-uniform; dead code wherever nobody reads them). See PMPC_COND_GATE.
-    double piv_min = 0.0, diag_max = 0.0;
-
     using d4 = double __attribute__((ext_vector_type(4)));
     static constexpr int BK = 4;                      // pivots swept per block (4: one MFMA k-step; the scalar in-panel sweep costs
                                                       // 16 + 2*BK broadcast/setup operations per pivot next to BK-1 useful fma — measured
@@ -217,8 +213,12 @@ struct RegKkt {
             }
         }
     }
-    template <int NPIV = N, class KCol, class Pre = NoPre>
-    __device__ __forceinline__ void invert(int ln_in, double* st, double diag, KCol kcol, long long* tm = nullptr, double rho_self = 0.0, Pre pre = Pre()) {
+    // EST (conditioning gate, PMPC_FLAG_ILLCOND): returns whether  max_i S_ii * max_i |(S^-1)_ii| > PMPC_COND_GATE  for the matrix S the NPIV pivots sweep
+    // (within a factor of two of max S_ii / min |pivot|, a factor 2 .. 10 below cond(S) on the benchmark streams and their unbounded variants) — and then
+    // returns BEFORE the conversion to the mat-vec layout: the caller gives the QP up. Costs nothing inside the sweep: the first maximum is taken from the
+    // staged tiles and parked in a free LDS slot, the second from the swept tiles.
+    template <int NPIV = N, bool EST = false, class KCol, class Pre = NoPre>
+    __device__ __forceinline__ bool invert(int ln_in, double* st, double diag, KCol kcol, long long* tm = nullptr, double rho_self = 0.0, Pre pre = Pre()) {
         constexpr bool CF = NPIV < N;
         constexpr int NBP = (NPIV + BK - 1) / BK;     // blocks of swept pivots
         long long tq0 = tm ? clock64() : 0;
@@ -303,8 +303,7 @@ struct RegKkt {
             }
         }
         pre(T, PA, PB, ln, lr, lc);
-        if constexpr (CF) diag_max = diag_abs_max<NPIV>(T, lr, lc);
-        piv_min = INFINITY;
+        if constexpr (EST) { X[64 * SX + ln] = diag_abs_max<NPIV>(T, lr, lc); lds_order(); }   // (the diagonal slots are free between the patch above and the final conversion)
         if (tm) { long long t = clock64(); tm[0] += t - tq0; tq0 = t; }
 #pragma unroll
         for (int b = 0; b < NBP; ++b) {
@@ -340,7 +339,6 @@ struct RegKkt {
                 const int k = kb + t;
                 if (k < NPIV) {
                     const double dk = bcast_lane(p[t], k);
-                    piv_min = fmin(piv_min, fabs(dk));
                     const double r = recip_uniform(dk);
                     double rk[BK];
 #pragma unroll
@@ -405,6 +403,11 @@ struct RegKkt {
             sched_fence();
         }
         if (tm) { long long t = clock64(); tm[1] += t - tq0; tq0 = t; }
+        if constexpr (EST) {
+            const double smax = X[64 * SX + ln];
+            const double wmax = diag_abs_max<NPIV>(T, lr, lc);
+            if (__builtin_amdgcn_readfirstlane((int)(smax * wmax > PMPC_COND_GATE))) return true;
+        }
         // accumulator tiles -> mat-vec layout, one tile row q at a time through Y (rows 16q..16q+15, all columns; blocks right of
         // the diagonal come from the mirror tiles, transposed). Columns >= N (never-consumed padding that may hold anything)
         // become exact zeros so that they drop out of the mat-vec.
@@ -432,6 +435,7 @@ struct RegKkt {
             sched_fence();
         }
         if (tm) { long long t = clock64(); tm[4] += t - tq0; tq0 = t; }
+        return false;
     }
 
     // K^{-1} c, one entry per lane (c = 0 on lanes >= N). Lane 16r+c forms, for each tile row q, the partial sum
@@ -467,7 +471,9 @@ struct RegKkt {
 // (helpers.hpp:38-43 selects the lower triangle). It matters only for a Hessian that is not bitwise symmetric: the block BFGS forms
 // (-c v_i) v_j per entry (continuous_ocp.hpp:2304-2431), which differs from its mirror image in the last bit; the dense BFGS and the
 // exact Hessian are bitwise symmetric, and their kernels skip the per-load select.
-template <int NN, int MM, bool STACKED = false, bool SYMLOWER = false>
+// GATE: the numeric conditioning gate (RegKkt::invert, EST) — the QP entry point's kernels. The fused SQP kernels decide from the bounds, once per instance
+// (sqp_kernel, pmpc_launch.hpp): the gate's two diagonal extractions cost the headline kernel 54 spilled registers and 7 % (measured, same box).
+template <int NN, int MM, bool STACKED = false, bool SYMLOWER = false, bool GATE = false>
 __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, const double* h, const double* __restrict__ A,
                                                   const double* Alb, const double* Aub, const double* xlb, const double* xub,
                                                   const double* x0, const double* y0, const pmpc_qp_settings& s, pmpc_qp_info& info,
@@ -553,7 +559,7 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
 
     RegKkt<N> K;
     int status = PMPC_QP_UNSOLVED;
-    bool illcond = false;   // the conditioning gate tripped at a factorisation of this QP: given up (see below)
+    constexpr int GAVE_UP = 100;   // internal status: the conditioning gate tripped at a factorisation (reported as UNSOLVED + PMPC_FLAG_ILLCOND)
     const double alpha = s.alpha;
     double max_Ax_z_norm = 0.0, max_Hx_ATy_h_norm = 0.0, res_prim = 1.0, res_dual = 1.0, rho_estimate = 0.0;
     // Outer loop = one KKT factorisation (first pass and after every accepted rho update); inner loop = ADMM iterations
@@ -568,20 +574,20 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
             const long long f0 = dbg ? clock64() : 0;
             // constraint-first mode of RegKkt (round 4): the RAW entries of row `lane` of [H  A^T ; A  .] (construct_kkt_matrix, box_admm.hpp:209-223);
             // the diagonal constraint block is swept in closed form inside invert (kdiag carries rho on the constraint lanes)
-            K.template invert<NN>(ln, tr, kdiag, [&](int j, int z) -> double {
+            // Conditioning gate (PMPC_FLAG_ILLCOND, include/polympc_amd.h). The constraint-first sweep inverts S = P + A' diag(rho) A inside K; cond(S) =
+            // rho_eq |A|^2 / lambda_min(P on null A) stays ~1e5 whatever rho is while the directions A leaves free are bounded variables (rho_box scales
+            // with rho: every BASELINE workload — there this order is MORE accurate than the reference's pivoted LDL^T, tests/test_oracle_pins.py), and
+            // grows with rho when unbounded variables (rho_box = RHO_MIN) span them. Beyond the gate (RegKkt::invert, EST) the QP is given up (UNSOLVED +
+            // the flag) and the launcher's redo launch solves it in the full KKT form (LDS-resident static LDL^T). Wave-uniform; restated by the CPU checker.
+            // (A second, full-sweep instantiation of invert() as an in-kernel fallback cost the headline kernel 87 spilled registers; a per-pivot
+            // running minimum inside the sweep 60 more SGPR spills kernel-wide, +6 % on the bench line: both dropped.)
+            const bool tripped = K.template invert<NN, GATE>(ln, tr, kdiag, [&](int j, int z) -> double {
                 if (j < NN) { if constexpr (SYMLOWER) return KrowLower(j < NN ? j : 0, z); else return Krow(j < NN ? j : 0, z); }
                 const double v = Acol(j >= NN ? j - NN : 0, z);   // every primal lane: column `lane` of A is its operand of the rank-m update
                 if constexpr (STACKED) return lane_near(z) < (unsigned)NN ? v : 0.0;
                 return isP ? v : 0.0;
             }, tm, rhov);
-            // Conditioning gate (PMPC_FLAG_ILLCOND, include/polympc_amd.h). The constraint-first sweep inverts S = P + A' diag(rho) A inside K; cond(S) =
-            // rho_eq |A|^2 / lambda_min(P on null A) stays ~1e5 whatever rho is while the directions A leaves free are bounded variables (rho_box scales
-            // with rho: every BASELINE workload — there this order is MORE accurate than the reference's pivoted LDL^T, tests/test_oracle_pins.py), and
-            // grows with rho when unbounded variables (rho_box = RHO_MIN) span them. Estimate: max_i S_ii / min_k |pivot_k|; beyond PMPC_COND_GATE the QP
-            // is given up (UNSOLVED + the flag) and the launcher's redo launch solves it in the full KKT form (LDS-resident static LDL^T). Wave-uniform;
-            // restated by the CPU checker. (A second, full-sweep instantiation of invert() as an in-kernel fallback was built first: it cost the headline
-            // kernel 87 spilled registers — the allocator budgets for the union of both paths.)
-            if (__builtin_amdgcn_readfirstlane((int)(K.diag_max > PMPC_COND_GATE * K.piv_min))) { illcond = true; running = false; if (dbg) dbg[0] += clock64() - f0; break; }
+            if constexpr (GATE) { if (tripped) { status = GAVE_UP; running = false; if (dbg) dbg[0] += clock64() - f0; break; } }
             if (dbg) dbg[0] += clock64() - f0;
         }
         bool refactor = false;
@@ -673,11 +679,13 @@ __device__ __forceinline__ void boxadmm_solve_reg(const double* __restrict__ H, 
         }
         if (!refactor) running = false;
     }
-    if (iter > s.max_iter && !illcond) status = PMPC_QP_MAX_ITER_EXCEEDED;
+    const bool gave_up = GATE && status == GAVE_UP;
+    if (gave_up) status = PMPC_QP_UNSOLVED;
+    else if (iter > s.max_iter) status = PMPC_QP_MAX_ITER_EXCEEDED;
     if (isP) { out_x[ln] = xv; out_y[MM + ln] = yv; }
     if (isC) out_y[r] = yv;
     const bool bad = __builtin_amdgcn_ballot_w64(((xv - xv) + (yv - yv)) != 0.0) != 0;   // non-finite x or y on any lane
-    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info.flags = (bad ? PMPC_FLAG_NONFINITE : 0) | (illcond ? PMPC_FLAG_ILLCOND : 0);
+    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info.flags = (bad ? PMPC_FLAG_NONFINITE : 0) | (gave_up ? PMPC_FLAG_ILLCOND : 0);
     info.rho_estimate = rho_estimate; info.res_prim = res_prim; info.res_dual = res_dual;
 }
 

@@ -63,7 +63,6 @@ struct RegKkt2 {
     __device__ __forceinline__ static constexpr int lds_index(int R, int C) { return 2 * R + (C >= 4 ? 1 : 0); }
     static constexpr int NTR = LDS_TILES ? NT - 2 : NT;       // register-resident operand tiles per tile row
 
-    double piv_min = 0.0;   // smallest |pivot| of the last invert() (wave-uniform; dead code unless the caller reads it — the conditioning gate of pmpc_qp_cond.hpp)
     d4 T[NT][NT];   // after invert(): T[R][C] = the operand tile of output rows 16C + lc against columns 16R + 4r + lr
     // Register-file placement of the finished operand tiles, by hand: 49 tiles are 392 registers, more than either file holds (256 each),
     // and v_fmac_f64 reads arch VGPRs only. Left to the allocator, most of W went to SCRATCH (162 of 196 doubles reloaded per ADMM iteration).
@@ -116,7 +115,6 @@ struct RegKkt2 {
                 const int k = kb + t;
                 if (k < N) {
                     const double dk = (k < 64) ? bcast_lane(p0[t], k & 63) : bcast_lane(p1[t], (k - 64) & 63);
-                    piv_min = fmin(piv_min, fabs(dk));
                     const double r = recip_uniform(dk);
                     double rk[BK];
 #pragma unroll
@@ -175,15 +173,6 @@ struct RegKkt2 {
     // kload(j, s, z): K(row 64 s + lane, j) for j != row (0.0 for rows >= N), needed for the columns of the block-lower tile storage only
     // (j < 16 (row / 16 + 1)); z is the opaque zero that keeps the address arithmetic next to the loads. diag0 / diag1: K(row, row).
     struct NoPre { __device__ __forceinline__ void operator()(RegKkt2&, double*, double*, int, int, int) const {} };
-    // max_i |M(i, i)| of the staged tiles (rows < N): entry (16R + lc, 16R + lc) sits in component lc / 4 of the lanes with lc = lr + 4 (lc / 4)
-    __device__ __forceinline__ double diag_abs_max(int lr, int lc) const {
-        double dm = 0.0;
-#pragma unroll
-        for (int R = 0; R < NT; ++R)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dm = fmax(dm, (lc == lr + 4 * r && 16 * R + lc < N) ? fabs(T[R][R][r]) : 0.0);
-        return wave_max(dm);
-    }
     // T[R][C] += sum_j (rho_j a_j)_R (a_j)_C' over the MM rows a_j of A, j ascending in groups of four — the k-ascending fma chain of
     // v_mfma_f64_16x16x4_f64 per stored entry: M(a, b) = fma(rho_j A(j, a), A(j, b), M(a, b)). aload(j, e, z): A(j, row 64 e + lane) (0.0 on lanes without
     // such a row); rho_of(j): rho_j, wave-uniform. The condensed register kernel (pmpc_qp_cond.hpp) calls this between the staging of H + diag and the
@@ -287,7 +276,6 @@ struct RegKkt2 {
         }
         lds_order();
         pre(*this, PA, PB, ln, lr, lc);
-        piv_min = INFINITY;
         if (tm) { long long t = clock64(); tm[0] += t - tq0; tq0 = t; }
         block_steps<0>(ln, lr, lc, PA, PB, X, tm, tq0);
         if (tm) { long long t = clock64(); tm[1] += t - tq0; tq0 = t; }

@@ -61,6 +61,8 @@ template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bo
 struct SqpDevice {
     static constexpr bool SCH = PS > 0;
     static constexpr bool SLIM = PS == -2;   // large-instance mode compiled for two wavefronts per SIMD (256 registers)
+    static constexpr int BIG_NW = (PS == -3) ? 4 : 1;   // large-instance mode on a workgroup of four wavefronts (BigTeam, pmpc_qp_big.hpp): this object lives on the first one
+    void* big_mail = nullptr;                           // the team's mailbox (LDS)
     static constexpr bool CND = PS == -1;   // condensed register QP (pmpc_qp_cond.hpp): a two-rows-per-lane kernel (REG2) whose QP inverts S = H + sigma I + rho_box + A' diag(rho) A only
     static constexpr int SCH_P = PS / 256, SCH_S = PS % 256;
     static constexpr bool HOOKS = (NN == 0) || POL;
@@ -109,7 +111,7 @@ struct SqpDevice {
     double* trace = nullptr;   // this instance's records (pmpc_sqp_settings::iteration_trace), or null
     int qp_iter_total = 0;
     int qp_flags = 0;            // OR of the QP solves' flags (PMPC_FLAG_NONFINITE)
-    bool redo = false;           // a QP of this solve gave up at its conditioning gate (condensed kernels)
+    static constexpr int FLAG_GAVE_UP = 0x100;   // internal bit of qp_flags: the QP that just ran gave up at its conditioning gate (never reported)
     long long cyc[PROF ? 24 : 1] = {0};
     __device__ __forceinline__ static long long now() { if constexpr (PROF) return clock64(); else return 0; }
     __device__ __forceinline__ void acc(int i, long long dt) { if constexpr (PROF) cyc[i] += dt; }   // shader-clock cycles: 0 linearise(+BFGS) 1 QP 2 line search 3 termination 4 total 5 BFGS 6 KKT build+factor 7 QP residuals 8 ls node evaluation 9 ls scalar sums 10 first-order staging 11 second-order staging 12 first-order assembly 13 Hessian assembly 14 Lagrangian gradient 16..20 KKT inverse: row loads+staging, panel moves, sweeps, MFMA updates, final conversion 21 ls prologue (mu, grad'p) 22 ls acceptance
@@ -600,6 +602,13 @@ struct SqpDevice {
         const long long l1 = now();
         acc(10, l1 - l0);
         if (exact) {
+            if constexpr (BIG_NW > 1 && (int)Dm::NDER > Ocp<Model>::WIDE_MAX_NDER) {   // the team's helpers take three quarters of the entries (big_helper_loop)
+                BigMail<JViewRT<Model>>* mail = (BigMail<JViewRT<Model>>*)big_mail;
+                if (lane_id() == 0) { mail->op = BIG_OP_STAGE2; mail->var = v.x; mail->lam = v.lam; }
+                __syncthreads();
+                ocp.template stage_second_order_entry_part<BIG_NW>(v.x, v.lam, 0);
+                __syncthreads();
+            } else
             ocp.stage_second_order(v.x, v.lam);
             const long long l2 = now();
             if constexpr (SCH) ocp.template assemble_first_order<false, false>(v.al, nullptr, v.h, 0, false);
@@ -969,8 +978,9 @@ struct SqpDevice {
                     // large instances: condensed linear algebra from the block-sparse view of J (n instead of n + m rows) — unless the Ruiz preconditioner
                     // rescaled the workspace, whose entries the per-node blocks of the view then no longer are
                     const JViewRT<Model> jvr{ocp.Dlds, ocp.s.nsr, ocp.jblk, ocp.gblk, ocp.P, ocp.dm.NN, ocp.dm.VARX, ocp.dm.VARU, ocp.dm.me, ocp.jtab};
-                    boxadmm_solve<true, JViewRT<Model>, SLIM>(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, PROF ? tq : nullptr, jvr,
-                                                        ocp.keep_blk && !ruiz && n <= BIG_COND_MAX_ROWS && m <= BIG_COND_MAX_ROWS && __builtin_amdgcn_readfirstlane(ss.kkt_form) == 0);
+                    boxadmm_solve<true, JViewRT<Model>, SLIM, BIG_NW>(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, PROF ? tq : nullptr, jvr,
+                                                        ocp.keep_blk && !ruiz && n <= BIG_COND_MAX_ROWS && m <= BIG_COND_MAX_ROWS && __builtin_amdgcn_readfirstlane(ss.kkt_form) == 0,
+                                                        (BigMail<JViewRT<Model>>*)big_mail);
                 } else
                 boxadmm_solve<BIG>(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, PROF ? tq : nullptr);
                 acc(6, tq[0]); acc(7, tq[1]); acc(17, tq[2]); acc(16, tq[3]);   // (slots 16 / 17 double as "KKT build" / "substitutions" on the LDS path)
@@ -980,7 +990,7 @@ struct SqpDevice {
         qp_iter_total += qi.iter;
         qp_flags |= qi.flags;
         qp_iter_last = qi.iter; qp_status_last = qi.status;
-        if constexpr (CND || BIG || REG1) { if (__builtin_amdgcn_readfirstlane(qi.flags & PMPC_FLAG_ILLCOND) != 0) { redo = true; return; } }   // the QP gave up at its conditioning gate: nothing of this solve is used (solve() ends it with PMPC_SQP_REDO)
+        if constexpr (BIG) { if (__builtin_amdgcn_readfirstlane(qi.flags & PMPC_FLAG_ILLCOND) != 0) { qp_flags |= FLAG_GAVE_UP; return; } }   // the QP gave up at its conditioning gate: nothing of this solve is used (solve() ends it with PMPC_SQP_REDO)
         if constexpr (RUIZ_COMPILED) if (ruiz) {   // unscale(p, p_lambda); unscale(m_H, m_h, m_A, ...), sqp_base.hpp:608-609 / :664-665
             ruiz_unscale_solution_wave(n, m, rz.D, rz.E, rz_c, qw.x, qw.y);
             ruiz_unscale_problem_wave(n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, rz.D, rz.E, rz_c);
@@ -1016,7 +1026,7 @@ struct SqpDevice {
             linearise(iter == 1 || ss.exact_hessian_every_iter, true);
             const long long c1 = now();
             qp_and_step();
-            if constexpr (CND || BIG || REG1) { if (redo) { status = PMPC_SQP_REDO; break; } }
+            if constexpr (BIG) { if (qp_flags & FLAG_GAVE_UP) { status = PMPC_SQP_REDO; break; } }
             const long long c2 = now();
             const bool done = __builtin_amdgcn_readfirstlane((int)termination_criteria()) != 0;
             const long long c3 = now();
@@ -1036,7 +1046,7 @@ struct SqpDevice {
             for (int i = lane_id(); i < m_ct() + n_ct(); i += WAVE) bad |= (v.lam[i] - v.lam[i]) != 0.0;
             if (__builtin_amdgcn_ballot_w64(bad) != 0) qp_flags |= PMPC_FLAG_NONFINITE;
         }
-        info.iter = iter; info.qp_solver_iter = qp_iter_total; info.status = status; info.flags = qp_flags;
+        info.iter = iter; info.qp_solver_iter = qp_iter_total; info.status = status; info.flags = qp_flags & ~FLAG_GAVE_UP;
         info.primal_norm = primal_norm; info.dual_norm = dual_norm; info.max_violation = max_violation; info.cost = cost_log;
     }
 };

@@ -39,7 +39,7 @@ def test_contract_line_is_compact_and_complete():
     assert cb["kind"] in ("port", "reference")
     assert set(back["configs"]) == {"D", "B", "C", "R"}
     for c in back["configs"].values():
-        assert set(c) <= {"ms", "route", "frac", "block_bfgs", "bit_identical"}
+        assert set(c) <= {"ms", "route", "frac", "block_bfgs", "bit_identical", "small_batches_ms"}
     assert back["parity"]["same_order_bit_identical"] is True
     assert set(back["parity"]["qp_level_within_1e-8"]) == {"A", "D", "B", "R", "C"}
 

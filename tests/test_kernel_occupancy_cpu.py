@@ -44,7 +44,7 @@ def _kernels(co):
 @pytest.mark.skipif(not (os.path.exists(f"{LLVM}/clang-offload-bundler") and os.path.exists(f"{LLVM}/llvm-readelf")), reason="ROCm binutils not installed")
 def test_two_wave_kernels_fit_half_the_register_file():
     assert os.path.exists(pa.LIB_PATH)
-    pat = re.compile(r"sqp_kernel<pmpc::(\w+), (\d+), (\d+), (true|false), (\d+), (true|false), (true|false), (true|false), (true|false)>")
+    pat = re.compile(r"sqp_kernel<pmpc::(\w+), (\d+), (\d+), (true|false), (\d+), (true|false), (true|false), (true|false), (true|false), (true|false)>")
     seen = {"reg1": 0, "big2": 0, "big1": 0, "reg2": 0}
     with tempfile.TemporaryDirectory() as tmp:
         objs = _code_objects(tmp)

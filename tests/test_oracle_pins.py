@@ -827,25 +827,25 @@ def test_kernel_orders_follow_exact_arithmetic_more_closely_than_the_reference_o
         assert dk <= 1e-8 * max(1.0, rho0 / 10.0), (cfg, rho0, dk)   # (what is left grows with rho for ANY fp64 solve: the exact run's own conditioning)
 
 
-@pytest.mark.parametrize("cfg", ["A", "B", "R"])
-def test_conditioning_gate_of_the_condensed_orders(oracle, cfg):
-    """When the condensed form IS the inexact one, and what the gate does about it. With every bound removed the directions A leaves free carry
-    rho_box = RHO_MIN = 1e-6 instead of rho, cond(S) = rho_eq |A|^2 / lambda_min grows with rho, and a condensed solve loses cond(S) eps (single solves at
-    rho = 1e3: x 1e-5, nu 1 relative; the quasi-definite form 1e-10). The estimate max_i S_ii / min_k |pivot_k| (within a factor 2 .. 10 below cond(S)) trips
-    the gate at 1e10: the QP is given up; the QP entry point solves it again on the LDS-resident static LDL^T (PIVOT_SWEEP -> PIVOT_STATIC, as the product's
-    redo launch does), the SQP driver re-solves the whole instance in the full form (test_sqp_conditioning_gate_redo; PIVOT_CONDSWEEP at the QP level is a
-    test probe only: it reports UNSOLVED + the flag). Silent on the benchmark streams at every rho (cond(S) ~ 1e5: the bounded controls), set on every QP of
-    the unbounded streams at rho0 = 1e5."""
+@pytest.mark.parametrize("cfg,kern", [("A", "PIVOT_SWEEP"), ("B", "PIVOT_CONDENSED")])
+def test_conditioning_gate_of_the_condensed_orders(oracle, cfg, kern):
+    """When the condensed form IS the inexact one, and what the numeric gate does about it (the QP entry point's one-row-per-lane kernels: PIVOT_SWEEP; the
+    large-instance kernel: PIVOT_CONDENSED — here on config B's QPs, the policy restates any size). With every bound removed the directions A leaves free
+    carry rho_box = RHO_MIN = 1e-6 instead of rho, cond(S) = rho_eq |A|^2 / lambda_min grows with rho, and a condensed solve loses cond(S) eps (single solves
+    at rho = 1e3: x 1e-5, nu 1 relative; the quasi-definite form 1e-10). The estimate — max S_ii * max |(S^-1)_ii| (swept inverse) or max S_ii / min |d_k|
+    (LDL^T); within a factor of two of each other and 2 .. 10 below cond(S) — trips the gate at 1e10: the QP is given up (UNSOLVED + the flag); the QP entry point
+    solves it again on the LDS-resident static LDL^T (PIVOT_SWEEP -> PIVOT_STATIC, as the product's redo launch does), the SQP driver the whole instance.
+    Silent on the benchmark streams at every rho (cond(S) ~ 1e5: the bounded controls), set on every QP of the unbounded streams at rho0 = 1e5."""
     from oracle import cross_order as tco
-    kern = oracle.PIVOT_SWEEP if cfg == "A" else oracle.PIVOT_CONDSWEEP
+    kern = getattr(oracle, kern)
     q = tco.traced_qp_stream(oracle, cfg, 32)
     free_l, free_u = np.full_like(q["xlb"], -np.inf), np.full_like(q["xub"], np.inf)
     for rho0 in (0.1, 1e3, 1e5):
         s = oracle.sqp_qp_default_settings(); s.rho = rho0
-        xb, yb, ib = oracle.qp_solve_batch(q["H"], q["h"], q["A"], q["Alb"], q["Aub"], q["xlb"], q["xub"], settings=s, pivot=kern, threads=8, structure=q["structure"])
+        xb, yb, ib = oracle.qp_solve_batch(q["H"], q["h"], q["A"], q["Alb"], q["Aub"], q["xlb"], q["xub"], settings=s, pivot=kern, threads=8)
         assert all(i.flags == 0 for i in ib), (cfg, rho0)
         args = (q["H"], q["h"], q["A"], q["Alb"], q["Aub"], free_l, free_u)
-        xk, yk, ik = oracle.qp_solve_batch(*args, settings=s, pivot=kern, threads=8, structure=q["structure"])
+        xk, yk, ik = oracle.qp_solve_batch(*args, settings=s, pivot=kern, threads=8)
         flagged = np.array([i.flags & oracle.FLAG_ILLCOND for i in ik]) != 0
         if rho0 == 1e5:
             assert flagged.all(), (cfg, rho0)
@@ -855,14 +855,15 @@ def test_conditioning_gate_of_the_condensed_orders(oracle, cfg):
             dk, de = np.abs(xk - xe)[flagged].max(), np.abs(xr - xe)[flagged].max()
             print(cfg, rho0, int(flagged.sum()), "flagged: full KKT form vs exact", dk, "reference order vs exact", de)
             assert dk <= max(100 * de, 1e-7), (rho0, dk, de)
-        if cfg != "A":   # a QP that gave up reports UNSOLVED (the driver never uses it)
+        if cfg != "A":   # a QP that gave up reports UNSOLVED (the SQP driver never uses it)
             assert all(i.status == oracle.QP_UNSOLVED for i, f in zip(ik, flagged) if f)
 
 
 def test_sqp_conditioning_gate_redo(oracle):
-    """The instance-level rule the product's redo launch implements: the reference's 11-node robot grid with every bound removed except the pinned initial
-    state and the QP penalty started at 1e4 — the condensed order gives up at its gate in the first QP and the instance is solved again, from its guesses,
-    in the full KKT form: bit for bit the PIVOT_SWEEP2 solve, flag set; with the control bounds in place the gate stays silent."""
+    """The instance-level rule of the register-resident SQP kernels and their redo launch: the reference's 11-node robot grid with the control bounds removed
+    (the pinned initial state stays) — an unbounded control means rho_box = RHO_MIN in a direction the collocation Jacobian leaves free, so the instance is
+    solved in the full KKT form from the start: bit for bit the PIVOT_SWEEP2 solve, flag set, whatever the penalty; with the control bounds in place the
+    flag stays clear. (Decided from the bounds once per instance: a numeric gate at every factorisation cost those kernels 4 .. 10 %.)"""
     from polympc_amd import workloads
     B = 6
     wl = workloads.robot_batch(B, P=5, S=2)

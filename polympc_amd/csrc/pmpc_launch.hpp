@@ -829,9 +829,11 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
         // redo launch (large-instance kernel, condensed mode): the instances whose QP gave up at its conditioning gate (PMPC_FLAG_ILLCOND; none on any
         // BASELINE workload) are solved again, from their guesses, by the same kernel in the (n + m)-row KKT form — every other workgroup reads one word and exits
         pmpc_sqp_settings ss_full = *ss; ss_full.kkt_form = 1;
-        auto rkern = sqp_kernel<Model, 0, 0, false, 0, true>;   // (the one-wavefront kernel: the full KKT form has no team version)
-        if (threads != WAVE && hipFuncSetAttribute((const void*)rkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PMPC_ERR_HIP;
-        hipLaunchKernelGGL((threads != WAVE ? rkern : lkern), dim3(B), dim3(WAVE), lds, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss_full, *qs, Hws, Aws,
+        // (the two-wavefronts-per-SIMD build of the one-wavefront kernel: an instantiation of its own, so that a profile lists the redo launches — which
+        //  normally do nothing — on their own line instead of halving the large-instance kernel's averages; the full KKT form has no team version)
+        auto rkern = sqp_kernel<Model, 0, 0, false, 0, true, true>;
+        if (hipFuncSetAttribute((const void*)rkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PMPC_ERR_HIP;
+        hipLaunchKernelGGL(rkern, dim3(B), dim3(WAVE), lds, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss_full, *qs, Hws, Aws,
                            x, lam, info, (unsigned long long*)nullptr, Kws, PMPC_REDO_MODE, ss->max_iter, (double*)nullptr, (unsigned)(lds / sizeof(double)));
     }
     return (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;

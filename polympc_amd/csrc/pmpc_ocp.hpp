@@ -192,9 +192,12 @@ struct Ocp {
     // forward sweep, so each lane carries ONE derivative component (Dual<double,1>: 4 operations per product instead of
     // 1 + 3*NDER) and NN*NDER lanes work side by side. Every value and every derivative goes through exactly the operations
     // it went through as component `dir` of a Dual<double,NDER>; the lanes of direction 0 store the values.
-    __device__ __forceinline__ void stage_first_order(const double* var) {
+    __device__ __forceinline__ void stage_first_order(const double* var) { stage_first_order_part<1>(var, 0); wsync(); }
+    // the (node, direction) pairs kd = w * 64 + lane, stride 64 NW: wavefront w of a team of NW (BigTeam, pmpc_qp_big.hpp); the caller synchronises behind it
+    template <int NW>
+    __device__ __forceinline__ void stage_first_order_part(const double* var, int w) {
         using ad = Dual<double, 1>;
-        for (int kd = lane_id(); kd < dm.NN * NDER; kd += WAVE) {
+        for (int kd = lane_id() + WAVE * w; kd < dm.NN * NDER; kd += WAVE * NW) {
             const int k = kd % dm.NN, dir = kd / dm.NN;
             ad x[NX > 0 ? NX : 1], u[NU > 0 ? NU : 1], p[NP > 0 ? NP : 1], y[NX > 0 ? NX : 1];
             {
@@ -254,7 +257,6 @@ struct Ocp {
                 s.Mgrad[dir] = M.d[0];
             }
         }
-        wsync();
     }
 
     // ---- per-node second-order stage: d2L, Mayer Hessian, and hes = -t_scale*sum lam_q d2f_q + sum lam_g d2g (:2128-2157)

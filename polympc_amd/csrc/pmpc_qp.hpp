@@ -632,6 +632,37 @@ __device__ __forceinline__ void kkt_solve_pivoted(const QpLds& w, int N, double*
 
 // large-instance linear algebra (pmpc_qp_big.hpp, included after this header by its users)
 __device__ __forceinline__ void big_build(double* W, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ A, int lda, const double* kdiag);
+// The two row-parallel loops of the damped BFGS update on the dense workspace (SqpDevice::bfgs_update / rank2_update_rows), rows i = 64 w + lane with stride
+// 64 NW: wavefront w of a team of NW (BigTeam). Row i sees exactly the operations it saw on one wavefront.
+template <int NW, int MEMCH_>
+__device__ __forceinline__ void bfgs_rows_products(const double* Hw, int ldw, int n, const double* step, const double* lgn, const double* lg, double* Bs, double* y, int w) {
+    for (int i = lane_id() + WAVE * w; i < n; i += WAVE * NW) {
+        Bs[i] = seq_dot_strided<MEMCH_>(Hw, (size_t)ldw, 1, i, n, step);   // row i of B times s: one add chain, columns ascending
+        y[i] = lgn[i] - lg[i];
+    }
+}
+template <int NW, int CH, bool FAST>
+__device__ __forceinline__ void bfgs_rows_rank2(double* Hw, int ldw, int n, const double* Bs, const double* r, double sBs, double sr, int w) {
+    const UniformDiv by_sBs(sBs), by_sr(sr);
+    for (int i = lane_id() + WAVE * w; i < n; i += WAVE * NW) {
+        const double Bsi = Bs[i], ri = r[i];
+        double* __restrict__ row = Hw + i;
+        for (int j0 = 0; j0 < n; j0 += CH) {
+            double b[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) b[u] = row[(size_t)((j0 + u < n) ? j0 + u : n - 1) * ldw];
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if (j0 + u < n) {
+                    double t = b[u];
+                    if constexpr (FAST) { t += by_sBs(-Bsi * Bs[j0 + u]); t += by_sr(ri * r[j0 + u]); }
+                    else { t += (-Bsi * Bs[j0 + u]) / sBs; t += (ri * r[j0 + u]) / sr; }
+                    row[(size_t)(j0 + u) * ldw] = t;
+                }
+        }
+    }
+}
+
 // The wavefronts that work on ONE instance's linear algebra (round 5). NW = 1: the one-wavefront-per-instance kernels — every function below is then the
 // code it was. NW = 4 (sqp_kernel<..., WG4>: one workgroup of four wavefronts per instance, small batches — a lone instance's latency is what a
 // receding-horizon controller waits for): wavefront 0 runs the instance's serial code (linearisation, BFGS, ADMM vector updates, line search) and posts the
@@ -644,10 +675,13 @@ template <int NW>
 struct BigTeam {
     int w = 0;   // this wavefront's index in the team
     __device__ __forceinline__ void sync() const { if constexpr (NW > 1) __syncthreads(); else { wfence(); wsync(); } }
+    // barrier for exchanges through LDS only (the triangular passes, the sparse products: the factor is read-only there): no wait for outstanding global loads, so
+    // that panel entries requested for the NEXT block column stay in flight across it (__syncthreads() drains vmcnt and with it every prefetch)
+    __device__ __forceinline__ void sync_lds() const { if constexpr (NW > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); else { wfence(); wsync(); } }
     __device__ __forceinline__ bool mine(int item) const { if constexpr (NW > 1) return (item % NW) == w; else return true; }
     __device__ __forceinline__ bool lead() const { if constexpr (NW > 1) return w == 0; else return true; }
 };
-enum { BIG_OP_EXIT = 0, BIG_OP_FACTOR = 1, BIG_OP_SOLVE = 2, BIG_OP_STAGE2 = 3 };   // mailbox of a team (BigMail, pmpc_qp_big.hpp)
+enum { BIG_OP_EXIT = 0, BIG_OP_FACTOR = 1, BIG_OP_SOLVE = 2, BIG_OP_STAGE2 = 3, BIG_OP_STAGE1 = 4, BIG_OP_BFGS_BS = 5, BIG_OP_BFGS_R2 = 6 };   // mailbox of a team (BigMail, pmpc_qp_big.hpp)
 template <class JV> struct BigMail;
 template <int NW> __device__ __forceinline__ double big_factor(double* W, int N, double* dl, const BigTeam<NW>& team);
 template <bool SLIM, int NW> __device__ __forceinline__ void big_solve(const double* W, int N, double* v, double* bx, const BigTeam<NW>& team);

@@ -454,7 +454,7 @@ __device__ __forceinline__ void big_solve_team(const double* LF, int N, int nb, 
                 for (int c = 0; c < 16; ++c) vi = fma(-L[c], xj[c], vi);
                 if (rw < N) v[rw] = vi;
             }
-            team.sync();
+            team.sync_lds();
             if (J + 1 < nb) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) { lrow[c] = lnext[c]; L[c] = Lnext[c]; }
@@ -462,14 +462,14 @@ __device__ __forceinline__ void big_solve_team(const double* LF, int N, int nb, 
             oF = oN;
         }
         if (team.lead() && jprev >= 0 && ln < 16 && 16 * jprev + r16 < N) v[16 * jprev + r16] = xprev;
-        team.sync();
+        team.sync_lds();
     }
     // ---- diagonal
     for (int i = WAVE * team.w + ln; i < N; i += WAVE * NW) {
         const int I = i >> 4, r = i & 15;
         v[i] = v[i] / LF[BigKkt::offF(I, NPAD) + BigKkt::slab(r, r)];
     }
-    team.sync();
+    team.sync_lds();
     // ---- backward
     double* red = bx + 16;
     double* grp = red + 16 * 65;
@@ -503,7 +503,7 @@ __device__ __forceinline__ void big_solve_team(const double* LF, int N, int nb, 
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) red[(4 * team.w + c) * 65 + ln] = acc[c];
-        team.sync();
+        team.sync_lds();
         if (team.lead()) {
             {
                 double t[16], a = 0.0;
@@ -526,7 +526,7 @@ __device__ __forceinline__ void big_solve_team(const double* LF, int N, int nb, 
             }
             if (ln < 16 && row < N) v[row] = xr;
         }
-        team.sync();
+        team.sync_lds();
     }
 }
 
@@ -711,7 +711,7 @@ __device__ __forceinline__ void big_cond_solve(const double* K, int n, int m, do
     const long long t0 = t_atu ? clock64() : 0;
     double* u = scr + 256;
     for (int i0 = 0; i0 < m; i0 += WAVE) { if (!team.mine(i0 / WAVE)) continue; const int i = i0 + ln; if (i < m) u[i] = rho[i] * rhs[n + i]; }
-    team.sync();
+    team.sync_lds();
     for (int c0 = 0; c0 < n; c0 += WAVE) {
         if (!team.mine(c0 / WAVE)) continue;
         const int c = c0 + ln;
@@ -723,7 +723,7 @@ __device__ __forceinline__ void big_cond_solve(const double* K, int n, int m, do
         else t = jv.coldot_fma(cc, bv, u, rhs[c < n ? c : 0]);
         if (c < n) rhs[c] = t;
     }
-    team.sync();
+    team.sync_lds();
     const long long s0 = t_atu ? clock64() : 0;
     big_solve<SLIM, NW>(K, n, rhs, scr + 256, team);
     const long long s1 = t_atu ? clock64() : 0;
@@ -739,19 +739,20 @@ __device__ __forceinline__ void big_cond_solve(const double* K, int n, int m, do
         else a = jv.rowdot_fma(rw, bv, rhs);
         if (r < m) rhs[n + r] = rho[r] * (a - rhs[n + r]);
     }
-    team.sync();
+    team.sync_lds();
 }
 
 // Mailbox of a four-wavefront team in LDS (BigTeam): the first wavefront posts a routine, the workgroup barrier behind the post releases the helpers, every
 // routine ends on a barrier of its own; the helpers then wait for the next post.
-constexpr int BIG_MAIL_DOUBLES = 44;
+constexpr int BIG_MAIL_DOUBLES = 60;
 template <class Model> struct JViewRT;   // pmpc_jview.hpp
 template <class JV>
 struct BigMail {
     int op, n, m, ldh;
     double* K; const double* H; const double* kdiag; const double* rho; double* rhs; double* scr;
     double red4[4];
-    const double* var; const double* lam;   // BIG_OP_STAGE2: the iterate and the multipliers of the second-order stage
+    const double* var; const double* lam;   // BIG_OP_STAGE1 / 2: the iterate and the multipliers of the AD stages
+    double* Hw; const double* pa[5]; double* pw[2]; double f[2]; int ldw, fast;   // BIG_OP_BFGS_*: the workspace, (step, lgn, lg | Bs, r), (Bs, y), (sBs, sr)
     JV jv;
 };
 template <class Model, class OcpT>
@@ -766,6 +767,16 @@ __device__ __forceinline__ void big_helper_loop(BigMail<JViewRT<Model>>* mb, int
         const int n = __builtin_amdgcn_readfirstlane(mb->n), m = __builtin_amdgcn_readfirstlane(mb->m);
         if (op == BIG_OP_STAGE2) {   // the entry-per-lane second-order AD stage of the exact linearisation: 4096 independent entries on config C
             ocp.template stage_second_order_entry_part<4>(mb->var, mb->lam, wv);
+            team.sync();
+        } else if (op == BIG_OP_STAGE1) {   // the (node, direction) pairs of the first-order AD stage
+            ocp.template stage_first_order_part<4>(mb->var, wv);
+            team.sync();
+        } else if (op == BIG_OP_BFGS_BS) {   // B s and y, row per lane
+            bfgs_rows_products<4, BIG_MEM_BATCH>(mb->Hw, __builtin_amdgcn_readfirstlane(mb->ldw), n, mb->pa[0], mb->pa[1], mb->pa[2], mb->pw[0], mb->pw[1], wv);
+            team.sync();
+        } else if (op == BIG_OP_BFGS_R2) {   // the rank-2 update, row per lane
+            if (__builtin_amdgcn_readfirstlane(mb->fast)) bfgs_rows_rank2<4, BIG_MEM_BATCH, true>(mb->Hw, __builtin_amdgcn_readfirstlane(mb->ldw), n, mb->pa[3], mb->pa[4], mb->f[0], mb->f[1], wv);
+            else bfgs_rows_rank2<4, BIG_MEM_BATCH, false>(mb->Hw, __builtin_amdgcn_readfirstlane(mb->ldw), n, mb->pa[3], mb->pa[4], mb->f[0], mb->f[1], wv);
             team.sync();
         } else if (op == BIG_OP_FACTOR) {
             (void)big_build_condensed<JV, 4>(mb->K, n, m, mb->H, __builtin_amdgcn_readfirstlane(mb->ldh), mb->kdiag, mb->rho, mb->jv, team, mb->red4);

@@ -598,6 +598,13 @@ struct SqpDevice {
     //   update: f, df, L, dL -> c, J (per-node blocks only), cost gradient; new lag_grad; damped BFGS on H
     __device__ __forceinline__ void linearise(bool exact, bool structure) {
         const long long l0 = now();
+        if constexpr (BIG_NW > 1) {   // (node, direction) pairs dealt over the team (big_helper_loop)
+            BigMail<JViewRT<Model>>* mail = (BigMail<JViewRT<Model>>*)big_mail;
+            if (lane_id() == 0) { mail->op = BIG_OP_STAGE1; mail->var = v.x; mail->n = n; mail->m = m; }
+            __syncthreads();
+            ocp.template stage_first_order_part<BIG_NW>(v.x, 0);
+            __syncthreads();
+        } else
         ocp.stage_first_order(v.x);
         const long long l1 = now();
         acc(10, l1 - l0);
@@ -799,11 +806,19 @@ struct SqpDevice {
     __device__ __forceinline__ void bfgs_update() {
         const int ln = lane_id();
         double* Bs = v.t1; double* r = v.t2; double* y = v.t3;
+        if constexpr (BIG_NW > 1) {   // rows dealt over the team (big_helper_loop)
+            BigMail<JViewRT<Model>>* mail = (BigMail<JViewRT<Model>>*)big_mail;
+            if (ln == 0) { mail->op = BIG_OP_BFGS_BS; mail->n = n; mail->m = m; mail->Hw = Hw; mail->ldw = ldw; mail->pa[0] = v.step; mail->pa[1] = v.lgn; mail->pa[2] = v.lg; mail->pw[0] = Bs; mail->pw[1] = y; }
+            __syncthreads();
+            bfgs_rows_products<BIG_NW, MEMCH>(Hw, ldw, n, v.step, v.lgn, v.lg, Bs, y, 0);
+            __syncthreads();
+        } else {
         for (int i = ln; i < n; i += WAVE) {
             Bs[i] = seq_dot_strided<MEMCH>(Hw, (size_t)ldw, 1, i, n, v.step);   // row i of B times s: one add chain, columns ascending, eight loads in flight
             y[i] = v.lgn[i] - v.lg[i];
         }
         wsync();
+        }
         const double sBs = seq_dot(v.step, Bs, n);
         const double sy = seq_dot(v.step, y, n);
         double sr;
@@ -817,6 +832,15 @@ struct SqpDevice {
         }
         wsync();
         if (sr < DBL_EPS) return;
+        if constexpr (BIG_NW > 1) {   // rows dealt over the team
+            const UniformDiv da(sBs), db(sr);
+            const bool fast = da.ok() && db.ok();
+            BigMail<JViewRT<Model>>* mail = (BigMail<JViewRT<Model>>*)big_mail;
+            if (ln == 0) { mail->op = BIG_OP_BFGS_R2; mail->n = n; mail->m = m; mail->Hw = Hw; mail->ldw = ldw; mail->pa[3] = Bs; mail->pa[4] = r; mail->f[0] = sBs; mail->f[1] = sr; mail->fast = fast ? 1 : 0; }
+            __syncthreads();
+            if (fast) bfgs_rows_rank2<BIG_NW, MEMCH, true>(Hw, ldw, n, Bs, r, sBs, sr, 0); else bfgs_rows_rank2<BIG_NW, MEMCH, false>(Hw, ldw, n, Bs, r, sBs, sr, 0);
+            __syncthreads();
+        } else
         rank2_update_mem(Bs, r, sBs, sr);
     }
     // Sparsity-preserving block BFGS: ContinuousOCP::hessian_update_impl<SPARSE>, continuous_ocp.hpp:2304-2431 (what the reference's

@@ -1416,3 +1416,56 @@ def test_sqp_full_size_properties_hbm_factor_kernel(ctx, oracle, case):
     xo, lo, io = oracle.sqp_solve_batch(wl["model"], P, S, wl["t0"], wl["tf"], len(sample), wl["d"][sample], wl["lbx"][sample], wl["ubx"][sample],
                                         sqp_settings=oss, pivot=_gpu_order(oracle, wl["n"], wl["m"], nodes=P * S + 1), threads=6)
     _assert_same_solve(info[sample], io, x[sample], xo, lam[sample], lo)
+
+
+def test_large_instance_team_kernel_bit_identical_to_the_one_wavefront_kernel(oracle, monkeypatch):
+    """The large-instance kernel on a workgroup of four wavefronts per instance (BigTeam, pmpc_qp_big.hpp; batches of at most one instance per CU) against
+    the one-wavefront kernel (PMPC_BIG_WG4 = 0) and against the restatement: the team deals whole fma chains — tiles of the condensed build, tile-row groups of the
+    blocked factorisation, 64-row slots / column quadruples of the triangular passes, chunks of the sparse products, entries of the second-order AD stage — so every
+    bit must be the same; with the block BFGS too (another linearisation path into the same QP)."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    B = 5
+    wl = workloads.kite_standin_batch(B)
+    for hu in (0, 1):
+        ss = pa.sqp_settings_default(); ss.max_iter = wl["max_iter"]; ss.line_search_max_iter = wl["ls_max_iter"]; ss.hessian_update = hu
+        res = []
+        for wg4 in ("1", "0"):
+            monkeypatch.setenv("PMPC_BIG_WG4", wg4)
+            c = pa.Context(0)
+            try:
+                res.append(c.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss))
+                assert c.last_route() == pa.capi.ROUTE_HBM
+            finally:
+                c.close()
+        monkeypatch.delenv("PMPC_BIG_WG4")
+        (x4, l4, i4), (x1, l1, i1) = res
+        assert _same_bits(x4, x1) and _same_bits(l4, l1) and _same_bits(i4, i1)
+        oss = oracle.sqp_default_settings(); oss.max_iter = wl["max_iter"]; oss.line_search_max_iter = wl["ls_max_iter"]; oss.hessian_update = hu
+        xo, lo, io = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss,
+                                            pivot=oracle.PIVOT_CONDENSED, threads=4)
+        _assert_same_solve(i4, io, x4, xo, l4, lo)
+
+
+def test_device_poisoning_changes_nothing(oracle):
+    """pmpc_debug_set_poison (PMPC_POISON=1): signalling NaNs in the HBM workspace, the staging buffers, every CU's LDS, every SIMD's register files and the low
+    scratch before each launch — a kernel that read what it never wrote would return NaN. One solve per kernel family with poisoning on: bit-identical to the same
+    context's solve without it (the whole suite runs under PMPC_POISON=1 as a release check; this test keeps the switch itself alive)."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    c = pa.Context(0)
+    try:
+        cases = [(workloads.robot_batch(8), {}), (workloads.robot_batch(6, P=5, S=2), {}), (workloads.cstr_batch(6), {}), (workloads.robot_batch(6, P=5, S=3), dict(hessian_update=1)),
+                 (workloads.robot_batch(6, P=4, S=1), dict(qp_solver=1)), (workloads.kite_standin_batch(2), {})]
+        for wl, kw in cases:
+            ss = pa.sqp_settings_default(); ss.max_iter = min(4, wl["max_iter"]); ss.line_search_max_iter = wl["ls_max_iter"]
+            for k, v in kw.items(): setattr(ss, k, v)
+            B = wl["lbx"].shape[0]
+            run = lambda: c.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
+            c.set_poison(False); a = run()
+            c.set_poison(True); b = run(); route = c.last_route()
+            c.set_poison(False)
+            assert _same_bits(a[0], b[0]) and _same_bits(a[1], b[1]) and _same_bits(a[2], b[2]), pa.capi.ROUTE_NAMES.get(route)
+            assert np.isfinite(b[0]).all()
+    finally:
+        c.close()

@@ -29,18 +29,11 @@ extern "C" int pmpc_internal_qp_reg2_launch(void* stream, int B, int n, int m, c
 // =====================================================================================================================
 // kernels: one 64-lane workgroup (= one wavefront) per instance; grid = batch
 // =====================================================================================================================
-__global__ __launch_bounds__(64) void qp_boxadmm_kernel(int B, int n, int m, const double* __restrict__ H,
-                                                        const double* __restrict__ h, const double* __restrict__ A,
-                                                        const double* __restrict__ Alb, const double* __restrict__ Aub,
-                                                        const double* __restrict__ xlb, const double* __restrict__ xub,
-                                                        const double* __restrict__ x0, const double* __restrict__ y0,
-                                                        pmpc_qp_settings s, double* __restrict__ x, double* __restrict__ y,
-                                                        pmpc_qp_info* __restrict__ info, int redo) {
-    extern __shared__ double smem[];
-    const int b = blockIdx.x;
-    if (b >= B) return;
-    // redo launch behind a one-row-per-lane register kernel: only the QPs that gave up at their conditioning gate (PMPC_FLAG_ILLCOND)
-    if (redo && (__builtin_amdgcn_readfirstlane(info[b].flags) & PMPC_FLAG_ILLCOND) == 0) return;
+__device__ __forceinline__ void qp_boxadmm_one(int b, int n, int m, const double* __restrict__ H, const double* __restrict__ h, const double* __restrict__ A,
+                                               const double* __restrict__ Alb, const double* __restrict__ Aub, const double* __restrict__ xlb,
+                                               const double* __restrict__ xub, const double* __restrict__ x0, const double* __restrict__ y0,
+                                               const pmpc_qp_settings& s, double* __restrict__ x, double* __restrict__ y, pmpc_qp_info* __restrict__ info,
+                                               double* smem, int extra_flags) {
     QpLds w;
     double* p = w.carve(smem, n, m);
     // stage the vectors the ADMM loop touches every iteration: h, Alb, Aub, xlb, xub
@@ -54,8 +47,35 @@ __global__ __launch_bounds__(64) void qp_boxadmm_kernel(int B, int n, int m, con
                   x0 ? x0 + (size_t)b * n : nullptr, y0 ? y0 + (size_t)b * (n + m) : nullptr, s, qi);
     for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = w.x[i];
     for (int i = ln; i < n + m; i += WAVE) y[(size_t)b * (n + m) + i] = w.y[i];
-    if (redo) qi.flags |= PMPC_FLAG_ILLCOND;   // (information for the caller: this QP took the full KKT form)
+    qi.flags |= extra_flags;
     if (ln == 0) info[b] = qi;
+    wsync();
+}
+__global__ __launch_bounds__(64) void qp_boxadmm_kernel(int B, int n, int m, const double* __restrict__ H,
+                                                        const double* __restrict__ h, const double* __restrict__ A,
+                                                        const double* __restrict__ Alb, const double* __restrict__ Aub,
+                                                        const double* __restrict__ xlb, const double* __restrict__ xub,
+                                                        const double* __restrict__ x0, const double* __restrict__ y0,
+                                                        pmpc_qp_settings s, double* __restrict__ x, double* __restrict__ y,
+                                                        pmpc_qp_info* __restrict__ info, int redo) {
+    extern __shared__ double smem[];
+    if (redo) {
+        // redo launch behind a one-row-per-lane register kernel (grid = ceil(B / 64)): this workgroup looks at 64 QPs at once — one word each — and solves,
+        // one after the other, those that gave up at their conditioning gate (PMPC_FLAG_ILLCOND; normally none: 256 workgroups that read a word and exit
+        // behind 16 384 QPs instead of 16 384 of them — the QP entry point's batches are flat and large, and a workgroup launch is not free)
+        const int base = (int)blockIdx.x * WAVE, ln = lane_id();
+        const int fl = (base + ln < B) ? info[base + ln].flags : 0;
+        unsigned long long todo = __builtin_amdgcn_ballot_w64((fl & PMPC_FLAG_ILLCOND) != 0);
+        while (todo) {
+            const int i = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            qp_boxadmm_one(base + i, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0, s, x, y, info, smem, PMPC_FLAG_ILLCOND);   // (the flag stays: this QP took the full KKT form)
+        }
+        return;
+    }
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    qp_boxadmm_one(b, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0, s, x, y, info, smem, 0);
 }
 // register-resident specialisation for compile-time (NN, MM), NN+MM <= 64
 template <int NN, int MM>
@@ -306,7 +326,7 @@ pmpc_status pmpc_qp_boxadmm_solve_batch_dev(pmpc_context* ctx, int B, int n, int
         const size_t ldsg_ = qp_kernel_lds_bytes(n, m);                                                                                      \
         if (ldsg_ <= ctx->lds_limit && !getenv("PMPC_NO_REDO_LAUNCH")) {                                                                     \
             HIPCHK(hipFuncSetAttribute((const void*)qp_boxadmm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg_));             \
-            hipLaunchKernelGGL(qp_boxadmm_kernel, dim3(B), dim3(WAVE), ldsg_, ctx->stream, B, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0,      \
+            hipLaunchKernelGGL(qp_boxadmm_kernel, dim3((B + WAVE - 1) / WAVE), dim3(WAVE), ldsg_, ctx->stream, B, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0, \
                                *settings, x, y, info, 1);                                                                                    \
         }                                                                                                                                    \
         HIPCHK(hipGetLastError());                                                                                                           \

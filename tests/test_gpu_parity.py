@@ -1469,3 +1469,26 @@ def test_device_poisoning_changes_nothing(oracle):
             assert np.isfinite(b[0]).all()
     finally:
         c.close()
+
+
+def test_qp_entry_conditioning_gate_and_its_redo_launch(ctx, oracle):
+    """The QP entry point's one-row-per-lane kernels gate numerically at every factorisation (max S_ii * max |(S^-1)_ii| > 1e10, read off the swept tiles): config A's
+    QP stream with every bound removed and the penalty started at 1e5 — every QP gives up and the redo launch (one workgroup per 64 QPs looks at their flags) solves
+    it on the LDS-resident static LDL^T: bit for bit the restatement under the same rule (PIVOT_SWEEP -> PIVOT_STATIC), flag set; with the bounds in place
+    nothing trips at any penalty and the kernel is the constraint-first sweep as before."""
+    import polympc_amd as pa
+    from oracle import cross_order as tco
+    q = tco.traced_qp_stream(oracle, "A", 200)
+    free_l, free_u = np.full_like(q["xlb"], -np.inf), np.full_like(q["xub"], np.inf)
+    for rho0 in (0.1, 1e3, 1e5):
+        qs = pa.qp_settings_sqp_default(); qs.rho = rho0
+        oqs = oracle.sqp_qp_default_settings(); oqs.rho = rho0
+        for lo, hi, free in ((q["xlb"], q["xub"], False), (free_l, free_u, True)):
+            x, y, info = ctx.qp_solve_batch(q["H"], q["h"], q["A"], q["Alb"], q["Aub"], lo, hi, settings=qs)
+            xo, yo, io = oracle.qp_solve_batch(q["H"], q["h"], q["A"], q["Alb"], q["Aub"], lo, hi, settings=oqs, pivot=oracle.PIVOT_SWEEP, threads=8)
+            fo = np.array([i.flags for i in io])
+            assert np.array_equal(info["flags"] & pa.capi.FLAG_ILLCOND, fo & oracle.FLAG_ILLCOND), (rho0, free)
+            assert np.array_equal(info["iter"], np.array([i.iter for i in io])) and np.array_equal(info["status"], np.array([i.status for i in io])), (rho0, free)
+            assert np.array_equal(x, xo) and np.array_equal(y, yo), (rho0, free, np.abs(x - xo).max())
+            if not free: assert np.all(info["flags"] == 0)
+            if free and rho0 == 1e5: assert np.all(info["flags"] & pa.capi.FLAG_ILLCOND)

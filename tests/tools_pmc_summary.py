@@ -12,7 +12,7 @@ for name in ["sq1", "sq2", "fetch", "write", "tcc", "calfetch", "calwrite"]:
     for r in csv.DictReader(open(fs[0])):
         kn = r["Kernel_Name"]
         if "sqp_kernel" in kn or "sqp_schur_kernel" in kn or "stream_rw" in kn or "qp_boxadmm" in kn:
-            agg[(kn.split("(")[0][-60:], r["Counter_Name"])].append(float(r["Counter_Value"]))
+            agg[(kn.split("(")[0][-80:], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (kn, cn), v in agg.items():
         # launches that did nothing are not part of a per-launch mean: the redo launch behind a kernel (PMPC_FLAG_ILLCOND; every workgroup reads one word and
         # exits) can be an instantiation of its own or — before round 5's final build — the same one
@@ -21,11 +21,13 @@ for name in ["sq1", "sq2", "fetch", "write", "tcc", "calfetch", "calwrite"]:
 # HBM traffic per launch of the bench kernel, corrected with the calibration run (MI355X_MICROARCH.md, HBM / rocprofv3
 # section): the counters are in KiB-sized units; the calibration kernel reads 2^30 B and writes 2^29 B with the same
 # 8-byte-per-lane access width, which gives the byte value of one counter unit for this access pattern.
+import re
+BENCH_KERNEL = re.compile(r"RobotOCP, 35, 21, false, 0(, false)+>")   # the default-policy specialisation of the bench kernel (every template flag after HU = 0 off)
 def _one(d, key):
     # the bench kernel is the default-policy specialisation (template arguments ..., PROF = false, HU = 0, KHBM = false); bench.py also
     # launches the block-BFGS specialisation (HU = 1) for its variant leg, which is reported but not used for the traffic figure
     ks = [k for k in d if k.startswith(key)]
-    pref = [k for k in ks if "stream_rw" in k or ", 35, 21, false, 0, false>" in k]
+    pref = [k for k in ks if "stream_rw" in k or BENCH_KERNEL.search(k)]
     if not pref:   # not the bench command: the kernel that moves the most data
         pref = sorted(ks, key=lambda k: -d[k]["per_launch_mean"] * d[k]["launches"])
     return d[pref[0]]["per_launch_mean"] if pref else None
@@ -36,7 +38,7 @@ try:
     write = _one(out["write"], "WRITE_SIZE") * w_unit
     out["traffic"] = {"fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "bytes_per_launch": fetch + write,
                       "bytes_per_counter_unit": {"FETCH_SIZE": f_unit, "WRITE_SIZE": w_unit},
-                      "kernel": [k for k in sorted(out["fetch"], key=lambda k: -out["fetch"][k]["per_launch_mean"] * out["fetch"][k]["launches"])][0] if not any(", 35, 21, false, 0, false>" in k for k in out["fetch"]) else "sqp_kernel<RobotOCP,35,21> (bench.py --steps 5 --warmup 1, config A, batch 4096)"}
+                      "kernel": [k for k in sorted(out["fetch"], key=lambda k: -out["fetch"][k]["per_launch_mean"] * out["fetch"][k]["launches"])][0] if not any(BENCH_KERNEL.search(k) for k in out["fetch"]) else "sqp_kernel<RobotOCP,35,21> (bench.py --steps 5 --warmup 1, config A, batch 4096)"}
 except Exception as e:  # incomplete collection
     out["traffic"] = None
 try:   # L2 hit rate of the kernel the traffic figure is about

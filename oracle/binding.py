@@ -180,16 +180,18 @@ def _schur_check(structure, n, m, H=None):
     """PIVOT_SCHUR needs the collocation structure (nx, nu, nn, P) of the QP — and a Hessian that is block diagonal per node (checked here in numpy:
     the C++ side throws inside an OpenMP region otherwise)."""
     if structure is None:
-        raise ValueError("PIVOT_SCHUR: pass structure=(nx, nu, nn, P)")
-    nx, nu, nn, P = structure
-    if (nx + nu) * nn != n or nx * nn != m or m > SCHUR_MAX_ROWS or P < 1 or (nn - 1) % P != 0:
+        raise ValueError("PIVOT_SCHUR: pass structure=(nx, nu, nn, P) or (nx, nu, nn, P, np)")
+    nx, nu, nn, P = structure[:4]
+    npar = structure[4] if len(structure) > 4 else 0   # one parameter behind the node variables: the bordered form
+    if npar not in (0, 1) or (nx + nu) * nn + npar != n or nx * nn != m or m > SCHUR_MAX_ROWS or P < 1 or (nn - 1) % P != 0:
         raise ValueError(f"PIVOT_SCHUR: structure {structure} does not describe a QP with n = {n}, m = {m} <= {SCHUR_MAX_ROWS}")
     if H is not None:
         node = np.concatenate([np.repeat(np.arange(nn), nx), np.repeat(np.arange(nn), nu)])
         off = node[:, None] != node[None, :]
-        if np.any(H.reshape(-1, n, n)[:, off] != 0.0):
+        n0 = n - npar
+        if np.any(H.reshape(-1, n, n)[:, :n0, :n0][:, off] != 0.0):
             raise ValueError("PIVOT_SCHUR: the Hessian is not block diagonal per collocation node")
-    lib().orc_set_schur_structure(nx, nu, nn, P)
+    lib().orc_set_schur_structure_np(nx, nu, nn, P, npar)
 
 
 COND_MAX_ROWS = 112     # PIVOT_CONDSWEEP restates the condensed register kernel: 65..112 variables (at most 64 also works: PIVOT_SWEEP's mat-vec), at most 64 constraint rows
@@ -315,11 +317,11 @@ def ocp_eval(model, P, S, t0, tf, var, d, lam=None, mparams=None):
 
 def _sqp_schur_check(dm, P, ss):
     """PIVOT_SCHUR inside the SQP: the Hessian must stay block diagonal per node — block BFGS or exact Hessians, no parameters, no path constraints,
-    default regularisation or the (diagonal) Gershgorin shift, no preconditioner, boxADMM."""
-    ok = (ss.hessian_update == 1 or ss.exact_hessian_every_iter) and dm["np"] == 0 and dm["ng"] == 0 and ss.regularisation in (0, 2) and \
+    at most one parameter (bordered form), default regularisation or the (diagonal) Gershgorin shift, no preconditioner, boxADMM."""
+    ok = (ss.hessian_update == 1 or ss.exact_hessian_every_iter) and dm["np"] <= 1 and dm["ng"] == 0 and ss.regularisation in (0, 2) and \
          ss.preconditioner == 0 and ss.qp_solver == 0 and dm["m"] <= SCHUR_MAX_ROWS
     if not ok:
-        raise ValueError("PIVOT_SCHUR restates the block-structured kernel: hessian_update = 1 or exact Hessians, NP = NG = 0, m <= 64, "
+        raise ValueError("PIVOT_SCHUR restates the block-structured kernel: hessian_update = 1 or exact Hessians, NP <= 1, NG = 0, m <= 64, "
                          "regularisation 0 / 2, no preconditioner, boxADMM")
 
 

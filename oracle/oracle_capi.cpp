@@ -166,7 +166,8 @@ void orc_ruiz_unscale_solution_batch(int B, int n, int m, const double* D, const
 }
 
 static BoxADMM::SchurStruct g_schur;   // collocation structure of the QPs handed to orc_qp_solve_batch with PIVOT_SCHUR (set before the call)
-void orc_set_schur_structure(int nx, int nu, int nn, int P) { g_schur.nx = nx; g_schur.nu = nu; g_schur.nn = nn; g_schur.P = P; }
+void orc_set_schur_structure(int nx, int nu, int nn, int P) { g_schur.nx = nx; g_schur.nu = nu; g_schur.nn = nn; g_schur.P = P; g_schur.np = 0; }
+void orc_set_schur_structure_np(int nx, int nu, int nn, int P, int np) { orc_set_schur_structure(nx, nu, nn, P); g_schur.np = np; }
 
 /* one KKT solve in the order of `pivot` (any policy, PIVOT_CONDENSED / PIVOT_SCHUR included): K = [P A'; A -diag(rho_inv)] given by its lower
    triangle, (n+m)^2 column-major; accuracy probes of the restated orders */
@@ -262,7 +263,7 @@ static void setup_solver(SQP<ContinuousOCP<Model>>& sqp, int b, const double* x_
     sqp.settings = to_sqp(ss);
     sqp.qp.settings = to_qp(qs);
     sqp.qp.pivot = (pivot_policy)pivot;
-    if (pivot == PIVOT_SCHUR || pivot == PIVOT_CONDSWEEP) { sqp.qp.schur.nx = Model::NX; sqp.qp.schur.nu = Model::NU; sqp.qp.schur.nn = sqp.problem.NN; sqp.qp.schur.P = sqp.problem.P; }
+    if (pivot == PIVOT_SCHUR || pivot == PIVOT_CONDSWEEP) { sqp.qp.schur.nx = Model::NX; sqp.qp.schur.nu = Model::NU; sqp.qp.schur.nn = sqp.problem.NN; sqp.qp.schur.P = sqp.problem.P; sqp.qp.schur.np = Model::NP; }
     for (int i = 0; i < Model::ND; ++i) sqp.p_static[i] = d[(size_t)b * Model::ND + i];
     if (lbx) for (int i = 0; i < n; ++i) sqp.lbx[i] = lbx[(size_t)b * n + i];
     if (ubx) for (int i = 0; i < n; ++i) sqp.ubx[i] = ubx[(size_t)b * n + i];

@@ -76,6 +76,8 @@ void orc_qp_solve_batch(int B, int n, int m, const double* H, const double* h, c
 /* PIVOT_SCHUR (7) at the QP entry: the collocation structure of the QPs of the next orc_qp_solve_batch calls — variables [x_0..x_{nn-1} | u_0..u_{nn-1}],
  * equality rows (node, state), P intervals per segment (the SQP entry points take it from the problem) */
 void orc_set_schur_structure(int nx, int nu, int nn, int P);
+/* the same with np = 1 parameter behind the node variables (n = (nx + nu) nn + np): the bordered form of the block-structured kernel */
+void orc_set_schur_structure_np(int nx, int nu, int nn, int P, int np);
 
 /* boxADMM<N, M, float> (box_admm_test.cpp:85-115): float arrays; pivot = PIVOT_EIGEN or PIVOT_STATIC; the info's floats are widened */
 void orc_qp_solve_batch_f32(int B, int n, int m, const float* H, const float* h, const float* A, const float* Alb, const float* Aub,

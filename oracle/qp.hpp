@@ -37,6 +37,8 @@
 // All matrices column-major.
 #pragma once
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <limits>
 #include <stdexcept>
@@ -316,7 +318,7 @@ struct BoxADMM {
     pivot_policy pivot = PIVOT_EIGEN;
     // PIVOT_SCHUR: the collocation structure of the QP (variables [x_0 .. x_{nn-1} | u_0 .. u_{nn-1}], equality rows (node, state), P intervals per
     // segment — continuous_ocp.hpp:757-765, :797-878); set by the SQP driver from the problem's dimensions, by tests through orc_set_schur_structure
-    struct SchurStruct { int nx = 0, nu = 0, nn = 0, P = 0; } schur;
+    struct SchurStruct { int nx = 0, nu = 0, nn = 0, P = 0, np = 0; } schur;   // np = 1: one parameter behind the node variables (bordered system, below)
     std::vector<double> x, y;  // primal N, dual M+N ([general | box])
     std::vector<double> x_tilde, q, z, z_tilde, z_prev, rho_vec, rho_inv_vec, rho_box, rho_box_inv, rho_box_prev;
     std::vector<int> constr_type, box_type;
@@ -336,7 +338,7 @@ struct BoxADMM {
     // PIVOT_SWEEP -> PIVOT_STATIC (the LDS-resident static LDL^T), PIVOT_CONDENSED -> PIVOT_BLOCKED (the (n + m)-row blocked LDL^T).
     // The register-resident SQP kernels (PIVOT_SWEEP, PIVOT_CONDSWEEP inside an SQP solve) decide ONCE per instance from its bounds instead — an unbounded
     // control or parameter sends the instance to the redo launch before any work (SQP driver, oracle_capi.cpp): a numeric gate cost those kernels 4 .. 10 %.
-    static constexpr double COND_GATE = 1e10;
+    static constexpr double COND_GATE = 1e10, SCHUR_COND_GATE = 1e7;
     bool numeric_gate = true;   // PIVOT_SWEEP: the QP entry point's kernels evaluate the gate numerically; the fused SQP kernels decide from the bounds (SQP driver) and switch this off
     bool illcond = false;
     double cond_estimate = 0.0;
@@ -447,7 +449,15 @@ struct BoxADMM {
     //   solve:      t = Q r1 (per node, fma chain c' ascending);  g_i = (own block fma chain over c, then coupled nodes k ascending) - r2_i;
     //               nu = S^{-1} g (PIVOT_SWEEP's mat-vec);  w = A' nu (own block: rows q ascending; then coupled row nodes ascending);
     //               x = Q (r1 - w);  then one refinement step on the constraint rows (kkt_solve_schur)
-    std::vector<double> Qs, gws;
+    //   np = 1 (round 5: minimal_time_test.cpp's grid): the parameter p is the last variable; H has the arrow shape (node blocks, a border row / column,
+    //   a corner) and A a dense column a_p. With K0 = [P A_z'; A_z -1/rho] the solve above (`solve0`), w = [H(p, z); a_p] and pi = H_pp + sigma + rho_p:
+    //               factorise:  (q_z, q_nu) = solve0(w);  delta = pi - w'q
+    //               solve:      (z0, nu0) = solve0(r1_z, r2);  p = (r1_p - w'[z0; nu0]) / delta;  z = z0 - p q_z  (fma),  nu = nu0 - p q_nu  (fma)
+    //   w'v is summed the way the wavefront does: lane l = 0..63 forms fma chains over its primal slots g = l + 64 e (ascending e), then its constraint
+    //   row (l < m), from 0; the 64 partial sums are added pairwise over adjacent lanes, level by level (schur_wave_dot).
+    std::vector<double> Qs, gws, bq;   // bq: [q_z (n0) | q_nu (m)] of the border
+    double bdelta = 0.0;
+    int n0() const { return N - schur.np; }
     int sg(int k, int c) const { return c < schur.nx ? k * schur.nx + c : schur.nx * schur.nn + k * schur.nu + (c - schur.nx); }
     bool coupled(int rownode, int k) const {   // Dt(rownode, k) structurally non-zero, own node excluded (its D entry lives in the block)
         const int kb = (rownode == schur.nn - 1) ? schur.nn - 1 - schur.P : (rownode / schur.P) * schur.P;
@@ -456,13 +466,14 @@ struct BoxADMM {
     double Aent(int r, int c) const { return K[(N + r) + c * (N + M)]; }
     void schur_check() const {
         const int nx = schur.nx, nu = schur.nu, nn = schur.nn, d = nx + nu, NM = N + M;
-        if (nx < 1 || nn < 2 || schur.P < 1 || (nn - 1) % schur.P != 0 || d * nn != N || nx * nn != M)
-            throw std::invalid_argument("oracle: PIVOT_SCHUR needs the collocation structure (nx, nu, nn, P) of a QP with n = (nx+nu) nn, m = nx nn");
-        std::vector<int> node(N), loc(N);
+        const int N0 = n0();
+        if (nx < 1 || nn < 2 || schur.P < 1 || (nn - 1) % schur.P != 0 || d * nn != N0 || nx * nn != M || schur.np < 0 || schur.np > 1)
+            throw std::invalid_argument("oracle: PIVOT_SCHUR needs the collocation structure (nx, nu, nn, P[, np <= 1]) of a QP with n = (nx+nu) nn + np, m = nx nn");
+        std::vector<int> node(N0), loc(N0);
         for (int k = 0; k < nn; ++k) for (int c = 0; c < d; ++c) { node[sg(k, c)] = k; loc[sg(k, c)] = c; }
-        for (int j = 0; j < N; ++j) for (int i = j; i < N; ++i)
+        for (int j = 0; j < N0; ++j) for (int i = j; i < N0; ++i)
             if (node[i] != node[j] && K[i + j * NM] != 0.0) throw std::invalid_argument("oracle: PIVOT_SCHUR: the Hessian is not block diagonal per node");
-        for (int r = 0; r < M; ++r) for (int c = 0; c < N; ++c) {
+        for (int r = 0; r < M; ++r) for (int c = 0; c < N0; ++c) {
             const int ni = r / nx, si = r % nx;
             const bool ok = node[c] == ni || (loc[c] == si && coupled(ni, node[c]));
             if (!ok && Aent(r, c) != 0.0) throw std::invalid_argument("oracle: PIVOT_SCHUR: A is not a collocation Jacobian of the given structure");
@@ -512,13 +523,30 @@ struct BoxADMM {
         }
         ldlt.n = M; ldlt.policy = PIVOT_SWEEP; ldlt.M = S; ldlt.tr.assign(M, 0); ldlt.temp.assign(M, 0.0);
         if (M > 64) throw std::invalid_argument("oracle: PIVOT_SCHUR restates a kernel with at most 64 constraint rows");
+        double smax = 0.0;
+        for (int a = 0; a < M; ++a) smax = std::fmax(smax, std::fabs(S[a + (size_t)a * M]));
         ldlt.compute_sweep(true);
+        // conditioning gate (round 5): cond(S) = rho_eq lambda_max(A Q A') once 1/rho is what keeps S regular — unbounded states whose dynamics do not depend on
+        // them (A_x singular: a constant state profile) — and the range-space solve then loses what the (n + m)-row orders keep; max S_ii max |(S^-1)_ii| off the swept tiles
+        // (x = Q (r1 - A' nu) is a difference of quantities ~ rho_eq times larger than itself: the error of a solve grows like the estimate squared — robot,
+        //  16 nodes: 2e-9 at 4e6, 2e-5 at 4e7; parking: 4e-7 at 4e8, 1e-3 at 4e9, nothing at 4e10. With the gate at 1e7 every instance this order keeps follows
+        //  exact arithmetic as closely as Eigen's pivoted order does, whatever rho (tests/test_oracle_pins.py); the redo is the static LDL^T of the (n + m)-row matrix)
+        if (gate_trips_inverse(smax, M, SCHUR_COND_GATE)) { illcond = true; info.flags |= QP_FLAG_ILLCOND; }
+        if (schur.np == 1) {   // border: (q_z, q_nu) = K0^{-1} [H(p, z); a_p], delta = (H_pp + sigma + rho_p) - w'q
+            const int N0 = n0();
+            std::vector<double> w1(N0), w2(M);
+            for (int g = 0; g < N0; ++g) w1[g] = K[N0 + (size_t)g * NM];
+            for (int i = 0; i < M; ++i) w2[i] = K[(N + i) + (size_t)N0 * NM];
+            bq.assign(N0 + M, 0.0);
+            schur_solve0(w1.data(), w2.data(), bq.data(), bq.data() + N0);
+            bdelta = K[N0 + (size_t)N0 * NM] - schur_wave_dot(bq.data(), bq.data() + N0);
+        }
     }
     // x = Q (r1 - A' nu) for a given nu: w = A' nu (own block: rows q ascending; then the coupled row nodes ascending), u = r1 - w, x = Q u
     void schur_primal(const double* rhs, const double* nu, double* xs) const {
         const int nx = schur.nx, nn = schur.nn, d = nx + schur.nu;
         auto Q = [&](int k, int i, int j) { return Qs[(size_t)k * d * d + i + j * d]; };
-        std::vector<double> u(N);
+        std::vector<double> u(n0());
         for (int k = 0; k < nn; ++k) for (int cc = 0; cc < d; ++cc) {
             double a = 0.0;
             for (int q2 = 0; q2 < nx; ++q2) a = std::fma(Aent(k * nx + q2, sg(k, cc)), nu[k * nx + q2], a);
@@ -547,23 +575,46 @@ struct BoxADMM {
     // Q^(1/2) A' (measured on config B's QPs after a rho update, cond(S) = 6e5: |dx| 2e-9 .. 2e-8 without the step, 2e-13 with it — the dense
     // orders reach 8e-12). The first block row holds to working precision by construction, so the residual lives in the second one:
     //   e = (A x - nu / rho) - r2,   nu += S^{-1} e... sign: K [dx; dnu] = [0; -e]  <=>  -S dnu = -e,   then x = Q (r1 - A' nu) again.
-    void kkt_solve_schur(const double* rhs, double* sol) {
-        const int nx = schur.nx, nn = schur.nn, d = nx + schur.nu;
+    void schur_solve0(const double* r1, const double* r2, double* xs, double* nu) {
+        const int nx = schur.nx, nn = schur.nn, d = nx + schur.nu, N0 = n0();
         auto Q = [&](int k, int i, int j) { return Qs[(size_t)k * d * d + i + j * d]; };
-        std::vector<double> t(N), gv(M), nu(M), dnu(M), xs(N);
+        std::vector<double> t(N0), gv(M), dnu(M);
         for (int k = 0; k < nn; ++k) for (int cc = 0; cc < d; ++cc) {
             double a = 0.0;
-            for (int c2 = 0; c2 < d; ++c2) a = std::fma(Q(k, cc, c2), rhs[sg(k, c2)], a);
+            for (int c2 = 0; c2 < d; ++c2) a = std::fma(Q(k, cc, c2), r1[sg(k, c2)], a);
             t[sg(k, cc)] = a;
         }
-        for (int i = 0; i < M; ++i) gv[i] = schur_rowdot(i, t.data(), 0.0) - rhs[N + i];
-        ldlt.solve(gv.data(), nu.data());
-        schur_primal(rhs, nu.data(), xs.data());
-        for (int i = 0; i < M; ++i) gv[i] = std::fma(-rho_inv_vec[i], nu[i], schur_rowdot(i, xs.data(), 0.0)) - rhs[N + i];
+        for (int i = 0; i < M; ++i) gv[i] = schur_rowdot(i, t.data(), 0.0) - r2[i];
+        ldlt.solve(gv.data(), nu);
+        schur_primal(r1, nu, xs);
+        for (int i = 0; i < M; ++i) gv[i] = std::fma(-rho_inv_vec[i], nu[i], schur_rowdot(i, xs, 0.0)) - r2[i];
         ldlt.solve(gv.data(), dnu.data());
         for (int i = 0; i < M; ++i) nu[i] = nu[i] + dnu[i];
-        schur_primal(rhs, nu.data(), xs.data());
-        for (int i = 0; i < N; ++i) sol[i] = xs[i];
+        schur_primal(r1, nu, xs);
+    }
+    // w'[z; nu] as the wavefront sums it (np = 1): w = [H(p, z) | a_p] read from K's border row / the parameter column of A
+    double schur_wave_dot(const double* z, const double* nu) const {
+        const int N0 = n0(), NM = N + M;
+        double part[64];
+        for (int l = 0; l < 64; ++l) {
+            double a = 0.0;
+            for (int g = l; g < N0; g += 64) a = std::fma(K[N0 + (size_t)g * NM], z[g], a);
+            if (l < M) a = std::fma(K[(N + l) + (size_t)N0 * NM], nu[l], a);
+            part[l] = a;
+        }
+        for (int w = 1; w < 64; w *= 2) for (int l = 0; l < 64; l += 2 * w) part[l] = part[l] + part[l + w];
+        return part[0];
+    }
+    void kkt_solve_schur(const double* rhs, double* sol) {
+        const int N0 = n0();
+        if (schur.np == 0) { schur_solve0(rhs, rhs + N, sol, sol + N); return; }
+        std::vector<double> z(N0), nu(M);
+        schur_solve0(rhs, rhs + N, z.data(), nu.data());
+        const double pv = (rhs[N0] - schur_wave_dot(z.data(), nu.data())) / bdelta;
+        for (int g = 0; g < N0; ++g) z[g] = std::fma(-pv, bq[g], z[g]);
+        for (int i = 0; i < M; ++i) nu[i] = std::fma(-pv, bq[N0 + i], nu[i]);
+        for (int g = 0; g < N0; ++g) sol[g] = z[g];
+        sol[N0] = pv;
         for (int i = 0; i < M; ++i) sol[N + i] = nu[i];
     }
     // PIVOT_SWEEP since round 4 (the one-row-per-lane register kernel, pmpc_qp_reg.hpp): the constraint block of K is diagonal, -1/rho, and is swept in
@@ -576,11 +627,11 @@ struct BoxADMM {
         cond_estimate = smax / ldlt.piv_min_abs;
         return smax > COND_GATE * ldlt.piv_min_abs;
     }
-    bool gate_trips_inverse(double smax, int nprimal) {   // the swept orders: max S_ii * max |(S^-1)_ii| from the diagonal of the swept matrix (the kernels read it off their tiles)
+    bool gate_trips_inverse(double smax, int nprimal, double gate = COND_GATE) {   // the swept orders: max S_ii * max |(S^-1)_ii| from the diagonal of the swept matrix (the kernels read it off their tiles)
         double wmax = 0.0;
         for (int a = 0; a < nprimal; ++a) wmax = std::fmax(wmax, std::fabs(ldlt.M[a + (size_t)a * ldlt.n]));
         cond_estimate = smax * wmax;
-        return smax * wmax > COND_GATE;
+        return smax * wmax > gate;
     }
     void factorise_sweep_cf() {
         const int NM = N + M;
@@ -677,7 +728,7 @@ struct BoxADMM {
         if (gate_trips(smax)) { illcond = true; info.flags |= QP_FLAG_ILLCOND; }
     }
     bool gives_up() const { return illcond; }
-    static pivot_policy redo_policy(pivot_policy p) { return p == PIVOT_SWEEP ? PIVOT_STATIC : (p == PIVOT_CONDSWEEP ? PIVOT_SWEEP2 : PIVOT_BLOCKED); }
+    static pivot_policy redo_policy(pivot_policy p) { return (p == PIVOT_SWEEP || p == PIVOT_SCHUR) ? PIVOT_STATIC : (p == PIVOT_CONDSWEEP ? PIVOT_SWEEP2 : PIVOT_BLOCKED); }
     void kkt_solve(const double* rhs, double* sol) {
         if (pivot == PIVOT_SCHUR) { kkt_solve_schur(rhs, sol); return; }
         if (pivot == PIVOT_CONDSWEEP) { kkt_solve_condsweep(rhs, sol); return; }

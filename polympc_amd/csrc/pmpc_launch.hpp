@@ -210,11 +210,11 @@ __global__ __launch_bounds__(WG4 ? 256 : 64, ((NN > 0 && NN + MM <= 64) ? PMPC_S
 }
 // ---------------------------------------------------------------------------------------------------------------------------------------------
 // Block-structured specialisation (pmpc_qp_schur.hpp): the Hessian is block diagonal per node — the block BFGS every control test of the reference
-// selects (continuous_ocp.hpp:2304-2431) or exact Hessians, NP = NG = 0 — and lives with J's per-node blocks in LDS: no HBM workspace, the QP through
+// selects (continuous_ocp.hpp:2304-2431) or exact Hessians, NG = 0, at most one parameter (arrow shape: a border row / column beside the blocks) — and lives with J's per-node blocks in LDS: no HBM workspace, the QP through
 // the m x m Schur complement. One instantiation per (model, P, S): the segment structure is a compile-time constant of the sparse products.
 template <class Model, int PP, int SS> constexpr int schur_lds_doubles_ct() {
     using SD = SchurDims<Model, PP, SS>;
-    return SD::LDS_DOUBLES + SD::NNODES * SD::DD /*hblk*/ + SD::NNODES * SD::NX * SD::JBS /*jblk*/ + 4;
+    return SD::LDS_DOUBLES + SD::NNODES * SD::DD /*hblk*/ + (SD::NPAR ? 2 * SD::N : 0) /*hbrd*/ + SD::NNODES * SD::NX * SD::JBS /*jblk*/ + 4;
 }
 template <class Model, int PP, int SS> inline size_t sqp_schur_lds_bytes() {
     using SD = SchurDims<Model, PP, SS>;
@@ -245,6 +245,7 @@ void sqp_schur_kernel(Model model, const ChebData* __restrict__ cd, int B, const
     const double* stage_end = p;
     ocp.jblk = p; p += SD::NNODES * SD::NX * SD::JBS; ocp.gblk = ocp.jblk; ocp.keep_blk = true;
     double* hblk = p; p += SD::NNODES * SD::DD;
+    double* hbrd = p; p += (SD::NPAR ? 2 * SD::N : 0);
     double* qblk = p; p += SD::NNODES * SD::DD;
     double* xsc = p; p += n + 1;
     double* dsc = p; p += m + 1;
@@ -263,7 +264,7 @@ void sqp_schur_kernel(Model model, const ChebData* __restrict__ cd, int B, const
     for (int i = ln; i < m + n; i += WAVE) v.lam[i] = lam_guess ? lam_guess[(size_t)b * (m + n) + i] : 0.0;
     wsync();
     SqpDevice<Model, n, m, PROF, 1, false, false, PP * 256 + SS> sqp(ocp, v, qw, nullptr, nullptr, ss, qs);
-    sqp.hblk = hblk; sqp.qblk = qblk; sqp.xsc = xsc; sqp.dsc = dsc; sqp.pdl = pdl; sqp.dtab = dtab;
+    sqp.hblk = hblk; sqp.hbrd = hbrd; sqp.qblk = qblk; sqp.xsc = xsc; sqp.dsc = dsc; sqp.pdl = pdl; sqp.dtab = dtab;
     schur_build_tables<Model, PP, SS>(ocp.s.D, dtab);
     sqp.trace = ss.iteration_trace ? ss.iteration_trace + (size_t)b * (size_t)ss.iteration_trace_capacity * PMPC_TRACE_DOUBLES : nullptr;
     sqp.tr = ocp.s.fval;
@@ -298,7 +299,9 @@ inline bool try_launch_schur(pmpc_context* ctx, const Model& mdl, const ChebData
     if (SchurDims<Model, PP, SS>::N + SchurDims<Model, PP, SS>::M <= WAVE && !getenv("PMPC_SCHUR_SMALL")) return false;
     const size_t lds = sqp_schur_lds_bytes<Model, PP, SS>();
     if (lds > lds_limit) return false;
-    auto kern = phase ? sqp_schur_kernel<Model, PP, SS, true> : sqp_schur_kernel<Model, PP, SS, false>;
+    auto kern = sqp_schur_kernel<Model, PP, SS, false>;
+    if constexpr (SchurDims<Model, PP, SS>::NPAR == 0) { if (phase) kern = sqp_schur_kernel<Model, PP, SS, true>; }   // (no phase-timer build of the bordered form: a developer switch already)
+    else phase = nullptr;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
     pmpc_internal_set_route(ctx, PMPC_ROUTE_SCHUR);
     hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), lds, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, *ss, *qs, x, lam, info, phase);
@@ -309,6 +312,7 @@ inline bool try_launch_schur(pmpc_context* ctx, const Model& mdl, const ChebData
 template <class Model> struct SCHUR_GRIDS { static constexpr bool value = false; };
 template <> struct SCHUR_GRIDS<RobotOCP> { static constexpr bool value = true; };
 template <> struct SCHUR_GRIDS<CstrOCP> { static constexpr bool value = true; };
+template <> struct SCHUR_GRIDS<ParkingOCP> { static constexpr bool value = true; };   // (NP = 1: the bordered form, round 5)
 template <class Model>
 bool try_launch_schur_grids(pmpc_context* ctx, const Model& mdl, const ChebData* cd, int P, int S, int B, const double* x_guess, const double* lam_guess,
                             const double* d, const double* lbx, const double* ubx, const pmpc_sqp_settings* ss, const pmpc_qp_settings* qs, double* x,
@@ -765,7 +769,12 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     if constexpr (SCHUR_GRIDS<Model>::value) {   // block-diagonal Hessian on a grid with a block-structured kernel
         if (!force_lds && !getenv("PMPC_NO_SCHUR") && schur_request_ok(ss, qs, slice_iters)) {
             pmpc_status rst = PMPC_OK;
-            if (try_launch_schur_grids<Model>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, ss, qs, x, lam, info, stream, lds_limit, phase, &rst)) return rst;
+            if (try_launch_schur_grids<Model>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, ss, qs, x, lam, info, stream, lds_limit, phase, &rst)) {
+                // redo launch: the instances whose block-structured QP gave up at its conditioning gate (PMPC_SCHUR_COND_GATE; none on any BASELINE workload) are
+                // solved again, from their guesses, on the LDS-resident static LDL^T of the (n + m)-row matrix (every compiled grid fits)
+                if (rst == PMPC_OK && !launch_redo_generic<Model>(mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit)) rst = PMPC_ERR_HIP;
+                return rst;
+            }
         }
     }
     if (!force_lds && ss->qp_solver == 0 && ss->regularisation != 1 && qs->linear_solver == 0) {   // (preconditioner / line_search = 1: the 7- and 11-node register kernels carry them, see try_launch_reg)   // node counts whose KKT system can fit 64 rows for small models (7 nodes: config A / D); Ruiz: LDS path

@@ -458,6 +458,37 @@ struct Ocp {
         wsync();
     }
 
+    // ---- NP = 1: the arrow shape — node blocks hb[k NB^2 + i NB + r] (NB = NX + NU), the border row with the corner hbrd[0 .. n) = H(p, .) and the border
+    // column hbrd[n .. 2n - 1) = H(., p) — the entries assemble_hessian writes, through the same operations (corner: the sequential chain; quirk Q4 lands on H(p, 0))
+    __device__ __forceinline__ void assemble_hessian_arrow(double* hb, double* hbrd) {
+        static_assert(NP == 1, "arrow storage of the Hessian: one parameter");
+        constexpr int NB = NX + NU;
+        const int n = dm.n;
+        double* hr = hbrd; double* hc = hbrd + n;
+        for (int e = lane_id(); e < dm.NN * NDER * NDER; e += WAVE) {
+            const int k = e / (NDER * NDER), rem = e - k * (NDER * NDER), i = rem / NDER, r = rem - i * NDER;
+            if (r >= NB && i >= NB) continue;
+            double a = 0.0;
+            if (k % P == 0 && k > 0) a += (ts * s.w[P]) * s.Lhes[(k * NDER + i) * NDER + r];
+            if (k < dm.NN - 1) a += (ts * s.w[k % P]) * s.Lhes[(k * NDER + i) * NDER + r];
+            if (k == 0) a += s.Mhes[i * NDER + r];
+            a += s.dhes[(k * NDER + i) * NDER + r];
+            if (r < NB && i < NB) hb[k * NB * NB + i * NB + r] = a;
+            else if (r >= NB) hr[dm.gidx(k, i)] = a;   // row p, column gidx(k, i)
+            else hc[dm.gidx(k, r)] = a;                // row gidx(k, r), column p
+        }
+        wsync();
+        if (lane_id() == 0) {
+            double a = 0.0;
+            for (int sg = 0; sg < S; ++sg)
+                for (int k = 0; k <= P; ++k) a += (ts * s.w[k]) * s.Lhes[((sg * P + k) * NDER + NB) * NDER + NB];
+            for (int k = 0; k < dm.NN; ++k) a += s.dhes[(k * NDER + NB) * NDER + NB];
+            hr[n - 1] = a;
+            hr[0] += s.Mhes[0 * NDER + (NDER - 1)];
+        }
+        wsync();
+    }
+
     // ---- assemble the Lagrangian Hessian H (n x n column-major in HBM) from the second-order stage
     // cost_gradient_hessian :1256-1367 (+ quirk Q4) and the lam-weighted blocks of :2128-2173
     __device__ __forceinline__ void assemble_hessian(double* __restrict__ H, int ldh) {

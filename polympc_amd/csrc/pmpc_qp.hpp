@@ -24,6 +24,7 @@ constexpr int BIG_MEM_BATCH = PMPC_BIG_MEM_BATCH;   // loads in flight per lane 
 constexpr double RHO_MIN = 1e-6, RHO_MAX = 1e+6, RHO_EQ_FACTOR = 1e+3;   // box_admm.hpp:56-59
 constexpr double LOOSE_BOUNDS_THRESH = 1e+10, EQ_TOL = 1e-4;            // qp_base.hpp:124-125
 constexpr double DIV_BY_ZERO_REGUL = 10e-10;                            // qp_base.hpp:79-82
+constexpr double PMPC_SCHUR_COND_GATE = 1e7;   // the block-structured kernel's gate on max S_ii max |(S^-1)_ii|, S = 1/rho + A Q A' (pmpc_qp_schur.hpp): below it the range-space solve follows exact arithmetic as closely as the reference's pivoted LDL^T does (robot / CSTR / parking streams at rho0 = 0.1 .. 1e3, tests/test_oracle_pins.py); the error then grows like the estimate squared (2e-5 at 4e7, 1e-3 at 4e9, nothing at 4e10)
 constexpr double PMPC_COND_GATE = 1e10;   // conditioning gate of the kernels that eliminate the constraint block first (PMPC_FLAG_ILLCOND, include/polympc_amd.h): max_i S_ii / min_k |pivot_k|
 
 // opaque on purpose: per-lane index arithmetic derived from it is recomputed where it is used instead of being hoisted
@@ -58,6 +59,26 @@ __device__ __forceinline__ double wave_max(double v) {
     v = dpp_max_step<0x140, 0xf>(v);   // row_mirror: every lane of a 16-lane row holds the row maximum
     v = dpp_max_step<0x142, 0xa>(v);   // row_bcast15 into rows 1 and 3
     v = dpp_max_step<0x143, 0xc>(v);   // row_bcast31 into rows 2 and 3: lane 63 holds the wave maximum
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 64 lanes, returned to every lane, through the same six DPP steps: the partial sums are added PAIRWISE OVER ADJACENT LANES, level by
+// level (lanes 2i and 2i+1, then quads, half rows, rows, row pairs, the two halves) — a fixed balanced tree, which the CPU restatement of the callers
+// walks (every addition is commutative, so which side a partner arrives on does not matter). Rows that a step's row mask leaves out add +0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_step(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v = dpp_add_step<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add_step<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add_step<0x141, 0xf>(v);   // row_half_mirror
+    v = dpp_add_step<0x140, 0xf>(v);   // row_mirror: every lane of a 16-lane row holds the row sum
+    v = dpp_add_step<0x142, 0xa>(v);   // row_bcast15 into rows 1 and 3
+    v = dpp_add_step<0x143, 0xc>(v);   // row_bcast31 into rows 2 and 3: lane 63 holds (row 3 + row 2) + (row 1 + row 0)
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
     return __hiloint2double(hi, lo);

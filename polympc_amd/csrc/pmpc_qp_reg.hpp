@@ -218,7 +218,7 @@ struct RegKkt {
     // returns BEFORE the conversion to the mat-vec layout: the caller gives the QP up. Costs nothing inside the sweep: the first maximum is taken from the
     // staged tiles and parked in a free LDS slot, the second from the swept tiles.
     template <int NPIV = N, bool EST = false, class KCol, class Pre = NoPre>
-    __device__ __forceinline__ bool invert(int ln_in, double* st, double diag, KCol kcol, long long* tm = nullptr, double rho_self = 0.0, Pre pre = Pre()) {
+    __device__ __forceinline__ bool invert(int ln_in, double* st, double diag, KCol kcol, long long* tm = nullptr, double rho_self = 0.0, Pre pre = Pre(), const double gate = PMPC_COND_GATE) {
         constexpr bool CF = NPIV < N;
         constexpr int NBP = (NPIV + BK - 1) / BK;     // blocks of swept pivots
         long long tq0 = tm ? clock64() : 0;
@@ -406,7 +406,7 @@ struct RegKkt {
         if constexpr (EST) {
             const double smax = X[64 * SX + ln];
             const double wmax = diag_abs_max<NPIV>(T, lr, lc);
-            if (__builtin_amdgcn_readfirstlane((int)(smax * wmax > PMPC_COND_GATE))) return true;
+            if (__builtin_amdgcn_readfirstlane((int)(smax * wmax > gate))) return true;
         }
         // accumulator tiles -> mat-vec layout, one tile row q at a time through Y (rows 16q..16q+15, all columns; blocks right of
         // the diagonal come from the mirror tiles, transposed). Columns >= N (never-consumed padding that may hold anything)

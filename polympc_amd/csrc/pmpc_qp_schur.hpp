@@ -16,6 +16,11 @@
 //   * every ADMM vector is one register per lane and slot: primal entries g = lane + 64 e (e < SLOTS, n <= 128), constraint rows on lanes [0, m).
 //     Block products go through LDS (the d entries of a node), the sparse products with A are fma chains over the own-node block and ALL nodes of
 //     the grid with the coefficient 0 outside the row's / column's segment — no divergence, and the same statement for non-finite operands.
+//   * ONE PARAMETER (NP = 1, round 5: minimal_time_test.cpp's problem): H has the arrow shape — node blocks, a border row / column, a corner — and A a dense
+//     column a_p. The parameter is the last primal entry (one more lane); with K0 the matrix above on the node variables, w = [H(p, z); a_p] and
+//     pi = H_pp + sigma + rho_p:  factorisation (q_z, q_nu) = K0^{-1} w, delta = pi - w'q;  solve (z0, nu0) = K0^{-1} [r1_z; r2],
+//     p = (r1_p - w'[z0; nu0]) / delta,  z = z0 - p q_z,  nu = nu0 - p q_nu  (fma). w'v: one fma chain per lane (primal slots ascending, then the
+//     constraint row), the 64 partial sums added pairwise over adjacent lanes by the DPP tree of wave_sum (pmpc_qp.hpp).
 //   * residuals (box_admm.hpp:398-415): H x from the blocks, A x / A' y from pmpc_jview.hpp — the non-zero products of the reference's dense chains in
 //     the same ascending order (multiply, then add).
 // The CPU restatement of exactly this order is PIVOT_SCHUR (the CPU checker of the test suite): the kernels are checked bit for bit against it, and it is tied to the
@@ -29,11 +34,12 @@ namespace pmpc {
 
 template <class Model, int PP, int SS>
 struct SchurDims {
-    enum { NX = Model::NX, NU = Model::NU, D = NX + NU, DD = D * D, JBS = OcpDims<Model>::JBS /* row stride of jblk (odd) */, NNODES = PP * SS + 1, N = D * NNODES, M = NX * NNODES, VARX = NX * NNODES,
-           SLOTS = (N + WAVE - 1) / WAVE, P1 = PP + 1, NNR = NNODES + (NNODES & 1),   // entries read per table row (two at a time)
+    enum { NX = Model::NX, NU = Model::NU, NPAR = Model::NP, D = NX + NU, DD = D * D, JBS = OcpDims<Model>::JBS /* row stride of jblk (odd) */, NNODES = PP * SS + 1,
+           N0 = D * NNODES /* node variables */, N = N0 + NPAR, M = NX * NNODES, VARX = NX * NNODES,
+           SLOTS = (N + WAVE - 1) / WAVE, PE = N0 / WAVE, PL = N0 % WAVE /* slot and lane of the parameter (NPAR = 1) */, P1 = PP + 1, NNR = NNODES + (NNODES & 1),   // entries read per table row (two at a time)
            NNP = lds_row_stride(NNODES),                                                // row stride: even, NNP / 2 odd — bank-conflict-free per-lane row bases (pmpc_jview.hpp)
            TAB = NNODES * NNP + (NNODES + 1) * NNP };
-    static_assert(Model::NP == 0 && Model::NG == 0, "block-structured QP: no parameters, no path constraints");
+    static_assert(Model::NP <= 1 && Model::NG == 0, "block-structured QP: at most one parameter (bordered form), no path constraints");
     static_assert(M <= WAVE && N <= 2 * WAVE, "block-structured QP: at most 64 constraint rows and 128 variables");
     // segment start / D row of the equality rows of node k (Ocp::seg_row) and the structural coupling of row node r with column node k
     __host__ __device__ static constexpr bool last(int k) { return k == NNODES - 1; }
@@ -80,15 +86,16 @@ __device__ __forceinline__ void schur_build_tables(const double* Dm, double* Dt)
 // node blocks of H column-major (LOWER triangle read for the KKT matrix, as Eigen::LDLT does; the full block for H x); jblk: [(k NX + q) D + c] =
 // J(k NX + q, g(k, c)); Dm: OcpLds::D; nsr: the node table of Ocp::stage_constants (pmpc_jview.hpp reads it); h / bounds: LDS vectors.
 // tr: RegKkt<M>::TRI doubles of staging; qblk / xsc / dsc / pdl: NNODES D^2 / N + 1 / M + 1 / N + 1 doubles of LDS that live through the solve;
-// Dt: the tables of schur_build_tables.
+// Dt: the tables of schur_build_tables. hbrd (NP = 1): [H(p, 0..N0-1), H(p, p) | H(0..N0-1, p)] — the border row with the corner, then the border column
+// (the KKT matrix reads the row: lower triangle; H x reads both).
 template <class Model, int PP, int SS>
-__device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const double* h, const double* jblk, const double* Dm, const int* nsr,
+__device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const double* hbrd, const double* h, const double* jblk, const double* Dm, const int* nsr,
                                                     const double* Alb, const double* Aub, const double* xlb, const double* xub,
                                                     const pmpc_qp_settings& s, pmpc_qp_info& info, double* out_x, double* out_y, double* tr,
                                                     double* qblk, double* xsc, double* dsc, double* pdl, const double* Dt, long long* dbg = nullptr,
                                                     long long* tm = nullptr) {
     using SD = SchurDims<Model, PP, SS>;
-    constexpr int NX = SD::NX, NU = SD::NU, D = SD::D, DD = SD::DD, NNODES = SD::NNODES, N = SD::N, M = SD::M, VARX = SD::VARX, SLOTS = SD::SLOTS, NNP = SD::NNP, NNR = SD::NNR;
+    constexpr int NX = SD::NX, NU = SD::NU, D = SD::D, DD = SD::DD, NNODES = SD::NNODES, N = SD::N, N0 = SD::N0, NPAR = SD::NPAR, M = SD::M, VARX = SD::VARX, SLOTS = SD::SLOTS, NNP = SD::NNP, NNR = SD::NNR;
     using d2 = double __attribute__((ext_vector_type(2)));
     const long long tp0 = dbg ? clock64() : 0;
     // ---- lane roles -------------------------------------------------------------------------------------------------------------------------
@@ -97,14 +104,17 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
     // spills inside partial-EXEC regions lose the inactive lanes' copies (DESIGN.md compiler hazard 3). The index arithmetic is a function of the
     // lane id alone; the blocks that need more of it than the ADMM loop (factorisation, residuals) re-derive it there (`roles`) instead of keeping a
     // dozen integers alive through the loop.
-    struct Role { bool pv; int g, px, k, c, xb, ub; };
+    // (NP = 1: the parameter is entry N0; it — and the clamped duplicates behind it — take node 0's addresses with all block coefficients zero: isp)
+    struct Role { bool pv, isp; int g, px, k, c, xb, ub; };
     auto role = [](int e) -> Role {
         Role r;
         const int g = lane_id() + WAVE * e;
         r.pv = g < N; r.g = r.pv ? g : N - 1; r.px = r.pv ? g : N;
-        const bool isx = r.g < VARX;
-        r.k = isx ? r.g / NX : (r.g - VARX) / NU;
-        r.c = isx ? r.g - r.k * NX : NX + (r.g - VARX) - r.k * NU;
+        r.isp = NPAR > 0 && r.g >= N0;
+        const int gz = r.isp ? 0 : r.g;
+        const bool isx = gz < VARX;
+        r.k = isx ? gz / NX : (gz - VARX) / NU;
+        r.c = isx ? gz - r.k * NX : NX + (gz - VARX) - r.k * NU;
         r.xb = r.k * NX; r.ub = VARX + r.k * NU;
         return r;
     };
@@ -117,6 +127,11 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
     // ---- per-lane problem data that the ADMM loop keeps in registers ---------------------------------------------------------------------------
     double hv[SLOTS], lo[SLOTS], hi[SLOTS], rhob[SLOTS], rhobinv[SLOTS]; int typ[SLOTS];
     double colb[SLOTS][NX];                 // column g of A inside its own node's rows
+    double qz[SLOTS], qnu = 0.0, delta = 1.0; bool ispE[SLOTS];   // NP = 1: K0^{-1} w, the pivot of the border
+    // the border itself — H(p, g) per primal slot (0 on the parameter's lanes) and the parameter's column of A on this row (0 beyond the rows) — is re-read from LDS
+    // where it is used (the opaque zero keeps the reads there): two more doubles alive across the swept inverse put a scratch reload inside it (ISA test)
+    auto border_row = [&](int e, int zo) -> double { const Role r = role(e); const double br = hbrd[zo + (r.isp ? 0 : r.g)]; return r.isp ? 0.0 : br; };
+    auto border_col = [&](int zo) -> double { const double a = jblk[zo + ci * SD::JBS + D]; return isC ? a : 0.0; };
     const double* xo[SLOTS]; const double* uo[SLOTS]; const double* dcol[SLOTS]; const double* nuo[SLOTS]; const double* nuc[SLOTS]; double* xst[SLOTS];
     double rho = s.rho;
 #pragma unroll
@@ -125,12 +140,15 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
         hv[e] = h[r.g]; lo[e] = xlb[r.g]; hi[e] = xub[r.g];
         typ[e] = classify_bounds(lo[e], hi[e]);
         rhob[e] = rho_of(typ[e], rho); rhobinv[e] = 1.0 / rhob[e];
-        double kd = hblk[r.k * DD + r.c * D + r.c]; kd += s.sigma; kd += rhob[e];   // construct_kkt_matrix, box_admm.hpp:214-216
+        double kd = hblk[r.k * DD + r.c * D + r.c];
+        ispE[e] = r.isp; qz[e] = 0.0;
+        if constexpr (NPAR > 0) { const double kc = hbrd[N0]; kd = r.isp ? kc : kd; }
+        kd += s.sigma; kd += rhob[e];   // construct_kkt_matrix, box_admm.hpp:214-216
         pdl[r.px] = kd;
 #pragma unroll
-        for (int q = 0; q < NX; ++q) colb[e][q] = jblk[(r.k * NX + q) * SD::JBS + r.c];
+        for (int q = 0; q < NX; ++q) { const double cb = jblk[(r.k * NX + q) * SD::JBS + r.c]; colb[e][q] = r.isp ? 0.0 : cb; }
         xo[e] = xsc + r.xb; uo[e] = xsc + r.ub; xst[e] = xsc + r.px;
-        dcol[e] = Dt + NNODES * NNP + (r.c < NX ? r.k : NNODES) * NNP;   // column node k of D~ (the all-zero row for a control column)
+        dcol[e] = Dt + NNODES * NNP + ((r.c < NX && !r.isp) ? r.k : NNODES) * NNP;   // column node k of D~ (the all-zero row for a control column and the parameter)
         nuo[e] = dsc + r.xb; nuc[e] = dsc + (r.c < NX ? r.c : 0);
     }
     const double loA = Alb[ci], hiA = Aub[ci];
@@ -151,6 +169,7 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
 
     RegKkt<M> K;
     double Qrow[SLOTS][D];
+    constexpr int GAVE_UP = 100;   // internal status: the conditioning gate tripped at a factorisation (reported as UNSOLVED + PMPC_FLAG_ILLCOND)
     int status = PMPC_QP_UNSOLVED, rho_updates = 1;
     const double alpha = s.alpha;
     double max_Ax_z_norm = 0.0, max_Hx_ATy_h_norm = 0.0, res_prim = 1.0, res_dual = 1.0, rho_estimate = 0.0;
@@ -207,6 +226,47 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
         return a;
     };
 
+    // K0^{-1} [r1; r2] on the node variables: the range-space solve and one step of iterative refinement on the constraint rows (sol, nu)
+    auto solve0 = [&](const double (&r1)[SLOTS], const double r2, double (&sol)[SLOTS], double& nu) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < SLOTS; ++e) *xst[e] = r1[e];
+        lds_order();
+        double tt[SLOTS];
+#pragma unroll
+        for (int e = 0; e < SLOTS; ++e) tt[e] = qprod(e);
+        lds_order();
+#pragma unroll
+        for (int e = 0; e < SLOTS; ++e) *xst[e] = tt[e];
+        lds_order();
+        const double g1 = arow() - r2;
+        nu = K.apply(isC ? g1 : 0.0);
+        lds_order();
+        *dst = nu;
+        lds_order();
+#pragma unroll
+        for (int e = 0; e < SLOTS; ++e) { const double u = r1[e] - acol(e); *xst[e] = u; }
+        lds_order();
+#pragma unroll
+        for (int e = 0; e < SLOTS; ++e) sol[e] = qprod(e);
+        lds_order();
+        // one step of iterative refinement on the constraint rows
+#pragma unroll
+        for (int e = 0; e < SLOTS; ++e) *xst[e] = sol[e];
+        lds_order();
+        const double e1 = fma(-rinvA, nu, arow()) - r2;
+        const double dnu = K.apply(isC ? e1 : 0.0);
+        nu = nu + dnu;
+        lds_order();
+        *dst = nu;
+        lds_order();
+#pragma unroll
+        for (int e = 0; e < SLOTS; ++e) { const double u = r1[e] - acol(e); *xst[e] = u; }
+        lds_order();
+#pragma unroll
+        for (int e = 0; e < SLOTS; ++e) sol[e] = qprod(e);
+        lds_order();
+    };
+
     while (running) {
         {   // ---- factorisation: Q_k, S, W = -S^{-1} (construct_kkt_matrix + factorise_kkt_matrix, box_admm.hpp:209-223, :336-341) ---------------
             const long long f0 = dbg ? clock64() : 0;
@@ -254,7 +314,7 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
             for (int e = 0; e < SLOTS; ++e) {
                 const Role r = role(e);
 #pragma unroll
-                for (int c = 0; c < D; ++c) Qrow[e][c] = qbF[r.k * DD + c * D + r.c];
+                for (int c = 0; c < D; ++c) { const double qv_ = qbF[r.k * DD + c * D + r.c]; Qrow[e][c] = r.isp ? 0.0 : qv_; }
             }
             // rows ci of G = A Q and of S = 1/rho + G A', node by node (kk ascending): g = row ci of G on the columns of node kk — own node: fma chains
             // over the block; any other node: (D~ coefficient, 0 when uncoupled) * Q_kk(si, .) — then every S(ci, j) that node kk enters: the rows j of
@@ -311,7 +371,30 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
             for (int j = 0; j < M; ++j) diag = (ci == j) ? srow[j] : diag;
             sched_fence();
             if (dbg) dbg[16] += clock64() - f1;   // (phase-profile build: rows of G and S; shares the slot of the line-search acceptance)
-            K.invert(ln, tr, diag, [&](int j, int) -> double { return srow[j < M ? j : 0]; }, tm);
+            // Conditioning gate (PMPC_FLAG_ILLCOND, round 5): cond(S) = rho_eq lambda_max(A Q A') once 1/rho is what keeps S regular — the state columns of a
+            // collocation Jacobian are nearly singular when the dynamics hardly depend on the states (D has the constant profile in its null space), and the
+            // bounded controls' Q ~ 1/rho closes the gap less and less as rho adapts upwards: the error of the range-space solve is ~ eps cond(S), whatever
+            // the refinement step does (its residual is evaluated in working precision). Beyond PMPC_SCHUR_COND_GATE the QP is given up; the SQP kernel ends
+            // the instance (PMPC_SQP_REDO) and the launcher's redo launch solves it in the (n + m)-row form. None on any BASELINE workload.
+            const bool tripped = K.template invert<M, true>(ln, tr, diag, [&](int j, int) -> double { return srow[j < M ? j : 0]; }, tm, 0.0, typename RegKkt<M>::NoPre(), PMPC_SCHUR_COND_GATE);
+            if (tripped) { status = GAVE_UP; running = false; if (dbg) dbg[0] += clock64() - f0; break; }
+            if constexpr (NPAR > 0) {   // border: (q_z, q_nu) = K0^{-1} [H(p, z); a_p],  delta = (H_pp + sigma + rho_p) - w'q
+                double sq[SLOTS], nq;
+                double bz[SLOTS];
+#pragma unroll
+                for (int e = 0; e < SLOTS; ++e) bz[e] = border_row(e, zf);
+                const double ap = border_col(zf);
+                solve0(bz, ap, sq, nq);
+                double part = 0.0;
+#pragma unroll
+                for (int e = 0; e < SLOTS; ++e) { sq[e] = ispE[e] ? 0.0 : sq[e]; part = fma(bz[e], sq[e], part); }
+                nq = isC ? nq : 0.0;
+                part = fma(ap, nq, part);
+                delta = pdF[N0] - wave_sum(part);
+#pragma unroll
+                for (int e = 0; e < SLOTS; ++e) qz[e] = ispE[e] ? -1.0 : sq[e];   // (z - p q_z leaves p itself on the parameter's lane)
+                qnu = nq;
+            }
             if (dbg) dbg[0] += clock64() - f0;
         }
         bool refactor = false;
@@ -322,45 +405,22 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
 #pragma unroll
             for (int e = 0; e < SLOTS; ++e) r1[e] = ((s.sigma * xv[e] - hv[e]) + rhob[e] * qv[e]) - yb[e];
             const double r2 = zv - rinvA * ya;
-            // range-space solve
+            // range-space solve (+ the border of the parameter)
+            double sol[SLOTS], nu;
+            solve0(r1, r2, sol, nu);
+            if constexpr (NPAR > 0) {
+                int zb = 0; asm volatile("" : "+v"(zb));
+                double part = 0.0;
 #pragma unroll
-            for (int e = 0; e < SLOTS; ++e) *xst[e] = r1[e];
-            lds_order();
-            double tt[SLOTS];
+                for (int e = 0; e < SLOTS; ++e) { sol[e] = ispE[e] ? 0.0 : sol[e]; part = fma(border_row(e, zb), sol[e], part); }
+                part = fma(border_col(zb), isC ? nu : 0.0, part);
+                const double dot = wave_sum(part);
+                const double r1p = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(r1[SD::PE]), SD::PL), __builtin_amdgcn_readlane(__double2loint(r1[SD::PE]), SD::PL));
+                const double pval = (r1p - dot) / delta;
 #pragma unroll
-            for (int e = 0; e < SLOTS; ++e) tt[e] = qprod(e);
-            lds_order();
-#pragma unroll
-            for (int e = 0; e < SLOTS; ++e) *xst[e] = tt[e];
-            lds_order();
-            const double g1 = arow() - r2;
-            double nu = K.apply(isC ? g1 : 0.0);
-            lds_order();
-            *dst = nu;
-            lds_order();
-            double sol[SLOTS];
-#pragma unroll
-            for (int e = 0; e < SLOTS; ++e) { const double u = r1[e] - acol(e); *xst[e] = u; }
-            lds_order();
-#pragma unroll
-            for (int e = 0; e < SLOTS; ++e) sol[e] = qprod(e);
-            lds_order();
-            // one step of iterative refinement on the constraint rows
-#pragma unroll
-            for (int e = 0; e < SLOTS; ++e) *xst[e] = sol[e];
-            lds_order();
-            const double e1 = fma(-rinvA, nu, arow()) - r2;
-            const double dnu = K.apply(isC ? e1 : 0.0);
-            nu = nu + dnu;
-            lds_order();
-            *dst = nu;
-            lds_order();
-#pragma unroll
-            for (int e = 0; e < SLOTS; ++e) { const double u = r1[e] - acol(e); *xst[e] = u; }
-            lds_order();
-#pragma unroll
-            for (int e = 0; e < SLOTS; ++e) sol[e] = qprod(e);
-            lds_order();
+                for (int e = 0; e < SLOTS; ++e) sol[e] = fma(-pval, qz[e], sol[e]);
+                nu = fma(-pval, qnu, nu);
+            }
             // ADMM updates, box_admm.hpp:125-147 (Q1: x = alpha x~; x += (1 - alpha) x)
             {
                 const double zprev = zv;
@@ -395,6 +455,8 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
                 const JView<Model, NNODES> jv{Dm, nsr, jbR, jbR, PP};
                 const double Ax = jv.rowdot(ci, xsc);
                 double nrmP = 0.0, rq = 0.0, rd = 0.0, nx_ = 0.0;
+                double pcur = 0.0, hxp = 0.0;   // NP = 1: the parameter, and row p of H x — the dense chain over all columns ascending (every lane forms it)
+                if constexpr (NPAR > 0) { const double* hbB = hbrd + zr; pcur = xsc[N0]; hxp = seq_dot(hbB, xsc, N); }
 #pragma unroll
                 for (int e = 0; e < SLOTS; ++e) {
                     const Role r = role(e);
@@ -408,6 +470,7 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
                     double Hx = 0.0;
 #pragma unroll
                     for (int c = 0; c < D; ++c) Hx += hb[c] * xn[c];
+                    if constexpr (NPAR > 0) { const double hc = hbrd[zr + N + (r.isp ? 0 : r.g)]; Hx += hc * pcur; Hx = r.isp ? hxp : Hx; }   // the border column is the last product of the row's chain
                     const double aty = jv.coldot(r.g, dsc, r.pv);
                     const double np_ = fmax(fmax(fabs(Hx), fabs(aty)), fmax(fabs(hv[e]), fabs(yb[e])));
                     nrmP = r.pv ? fmax(nrmP, np_) : nrmP;
@@ -453,6 +516,8 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
         }
         if (!refactor) running = false;
     }
+    const bool gave_up = status == GAVE_UP;
+    if (gave_up) status = PMPC_QP_UNSOLVED; else
     if (iter > s.max_iter) status = PMPC_QP_MAX_ITER_EXCEEDED;
     bool nf = false;
 #pragma unroll
@@ -464,7 +529,7 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
     if (isC) out_y[ci] = ya;
     nf = nf || (isC && (ya - ya) != 0.0);
     const bool bad = __builtin_amdgcn_ballot_w64(nf) != 0;
-    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info.flags = bad ? PMPC_FLAG_NONFINITE : 0;
+    info.status = status; info.iter = iter; info.rho_updates = rho_updates; info.flags = (bad ? PMPC_FLAG_NONFINITE : 0) | (gave_up ? PMPC_FLAG_ILLCOND : 0);
     info.rho_estimate = rho_estimate; info.res_prim = res_prim; info.res_dual = res_dual;
 }
 

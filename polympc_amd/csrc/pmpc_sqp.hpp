@@ -54,7 +54,7 @@ constexpr int PMPC_REDO_MODE = -0x7fffffff - 1;   // it_begin of that redo launc
 //      preconditioner (qp_preconditioners.hpp:114-220) and the filter line search (line_search.hpp:31-98); the LDS / HBM-resident kernels (NN == 0)
 //      always carry them. A separate instantiation: the default register kernels stay free of the (cold) calls and their spills.
 // PS: P * 256 + S of a BLOCK-STRUCTURED specialisation (pmpc_qp_schur.hpp; 0 = none): the Hessian is block diagonal per node (block BFGS or exact
-//      Hessians, NP = NG = 0) and lives as per-node blocks in LDS (`hblk`), J as its per-node blocks (`ocp.jblk`) + the differentiation matrix: the
+//      Hessians, NG = 0; NP = 1: the arrow shape, `hbrd` holds the border row with the corner and the border column) and lives as per-node blocks in LDS (`hblk`), J as its per-node blocks (`ocp.jblk`) + the differentiation matrix: the
 //      HBM workspace is not touched at all, and the QP is solved through the m x m Schur complement. NN, MM are the compile-time sizes there too.
 //      PS = -1: the CONDENSED register specialisation (pmpc_qp_cond.hpp) of a two-rows-per-lane kernel — everything as REG2 except the QP.
 template <class Model, int NN = 0, int MM = 0, bool PROF = false, int HU = 0, bool BIG = false, bool POL = false, int PS = 0>
@@ -81,7 +81,7 @@ struct SqpDevice {
 #endif
     static constexpr bool REG1 = !SCH && NN > 0 && NN + MM <= WAVE;    // one KKT row per lane
     static constexpr bool REG2 = !SCH && NN > 0 && NN + MM > WAVE;     // two KKT rows per lane
-    double *hblk = nullptr, *qblk = nullptr, *xsc = nullptr, *dsc = nullptr, *pdl = nullptr, *dtab = nullptr;   // SCH: Hessian blocks, Q blocks, the exchange vectors, the KKT diagonal and the D~ tables of the QP (LDS)
+    double *hblk = nullptr, *hbrd = nullptr /* NP = 1: border row + corner, border column (pmpc_qp_schur.hpp) */, *qblk = nullptr, *xsc = nullptr, *dsc = nullptr, *pdl = nullptr, *dtab = nullptr;   // SCH: Hessian blocks, Q blocks, the exchange vectors, the KKT diagonal and the D~ tables of the QP (LDS)
     static constexpr int MEMCH = BIG ? BIG_MEM_BATCH : 8;      // loads in flight per lane in the row walks over the BFGS matrix in HBM
     Ocp<Model>& ocp;
     SqpLds& v;
@@ -564,8 +564,17 @@ struct SqpDevice {
     // Gershgorin shift, dense_sparse_compare.cpp:109-122
     __device__ __forceinline__ void regularise_gershgorin() {
         if constexpr (SCH) {   // column i of H = the node's block column: |entries| added rows ascending (x rows, then u rows), as the dense loop adds them
-            constexpr int NB = Model::NX + Model::NU;
+            constexpr int NB = Model::NX + Model::NU, N0 = NN - Model::NP;
             for (int i = lane_id(); i < NN; i += WAVE) {
+                if (Model::NP > 0 && i >= N0) {   // the parameter's column: the border column rows ascending, the corner last
+                    const double aii = hbrd[N0];
+                    double ri = 0.0;
+                    for (int r = 0; r < N0; ++r) ri += fabs(hbrd[NN + r]);
+                    ri += fabs(aii);
+                    ri -= fabs(aii);
+                    if (aii - ri <= 0) hbrd[N0] = aii + ((ri - aii) + 0.01);
+                    continue;
+                }
                 const bool isx = i < Model::NX * NNODES_CT_;
                 const int k = isx ? i / Model::NX : (i - Model::NX * NNODES_CT_) / Model::NU;
                 const int c = isx ? i - k * Model::NX : Model::NX + (i - Model::NX * NNODES_CT_) - k * Model::NU;
@@ -574,6 +583,7 @@ struct SqpDevice {
                 double ri = 0.0;
 #pragma unroll
                 for (int r = 0; r < NB; ++r) ri += fabs(col[r]);
+                if constexpr (Model::NP > 0) ri += fabs(hbrd[i]);   // (row p of the column)
                 ri -= fabs(aii);
                 if (aii - ri <= 0) hblk[k * NB * NB + c * NB + c] = aii + ((ri - aii) + 0.01);
             }
@@ -621,7 +631,7 @@ struct SqpDevice {
             if constexpr (SCH) ocp.template assemble_first_order<false, false>(v.al, nullptr, v.h, 0, false);
             else ocp.template assemble_first_order<false>(v.al, Aw, v.h, ldw, structure);
             const long long l3 = now();
-            if constexpr (SCH) ocp.assemble_hessian_blocks(hblk);
+            if constexpr (SCH) { if constexpr (Model::NP > 0) ocp.assemble_hessian_arrow(hblk, hbrd); else ocp.assemble_hessian_blocks(hblk); }
             else ocp.assemble_hessian(Hw, ldw);
             const long long l4 = now();
             lagrangian_gradient(v.lg);
@@ -855,6 +865,11 @@ struct SqpDevice {
         double* vv = v.t1; double* r = v.t2; double* y = v.t3;
         if constexpr (SCH) {   // row i of B times s from the node's block: the non-zero products of the dense chain, columns ascending (x columns, then u columns)
             for (int i = ln; i < n; i += WAVE) {
+                if (NP > 0 && i >= VARX + VARU) {   // the parameter's row: the border row, columns ascending, the corner last
+                    vv[i] = seq_dot(hbrd, v.step, n);
+                    y[i] = v.lgn[i] - v.lg[i];
+                    continue;
+                }
                 const bool isx = i < VARX;
                 const int k = isx ? i / NX : (i - VARX) / NU;
                 const int c = isx ? i - k * NX : NX + (i - VARX) - k * NU;
@@ -868,6 +883,7 @@ struct SqpDevice {
                 double a = 0.0;
 #pragma unroll
                 for (int cc = 0; cc < NB; ++cc) a += hb[cc] * sv[cc];
+                if constexpr (NP > 0) a += hbrd[n + i] * v.step[VARX + VARU];   // (border column: the last product of the row's chain)
                 vv[i] = a;
                 y[i] = v.lgn[i] - v.lg[i];
             }
@@ -903,10 +919,17 @@ struct SqpDevice {
             for (int e = ln; e < a * NP; e += WAVE) {   // border: column block and its transposed copy in the rows
                 const int j = e / a, i = e - j * a;
                 const double t = term(i, a + j);
+                if constexpr (SCH) { hbrd[n + i] += t; hbrd[i] += t; }
+                else {
                 Hw[(size_t)(a + j) * ldw + i] += t;
                 Hw[(size_t)i * ldw + (a + j)] += t;
+                }
             }
-            for (int e = ln; e < NP * NP; e += WAVE) { const int j = e / NP, i = e - j * NP; Hw[(size_t)(a + j) * ldw + (a + i)] += term(a + i, a + j); }
+            for (int e = ln; e < NP * NP; e += WAVE) {
+                const int j = e / NP, i = e - j * NP;
+                if constexpr (SCH) hbrd[a] += term(a, a);
+                else Hw[(size_t)(a + j) * ldw + (a + i)] += term(a + i, a + j);
+            }
         }
         wfence();
         wsync();
@@ -981,7 +1004,7 @@ struct SqpDevice {
         }
         // 7-argument form: zero guesses (Q2)
         if constexpr (SCH) {
-            boxadmm_solve_schur<Model, SCH_P, SCH_S>(hblk, v.h, ocp.jblk, ocp.s.D, ocp.s.nsr, v.al, v.au, v.lx, v.ux, qs, qi, qw.x, qw.y, tr, qblk, xsc, dsc, pdl, dtab,
+            boxadmm_solve_schur<Model, SCH_P, SCH_S>(hblk, hbrd, v.h, ocp.jblk, ocp.s.D, ocp.s.nsr, v.al, v.au, v.lx, v.ux, qs, qi, qw.x, qw.y, tr, qblk, xsc, dsc, pdl, dtab,
                                                      PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr);
             wsync();
         } else if constexpr (CND) {
@@ -1014,7 +1037,7 @@ struct SqpDevice {
         qp_iter_total += qi.iter;
         qp_flags |= qi.flags;
         qp_iter_last = qi.iter; qp_status_last = qi.status;
-        if constexpr (BIG) { if (__builtin_amdgcn_readfirstlane(qi.flags & PMPC_FLAG_ILLCOND) != 0) { qp_flags |= FLAG_GAVE_UP; return; } }   // the QP gave up at its conditioning gate: nothing of this solve is used (solve() ends it with PMPC_SQP_REDO)
+        if constexpr (BIG || SCH) { if (__builtin_amdgcn_readfirstlane(qi.flags & PMPC_FLAG_ILLCOND) != 0) { qp_flags |= FLAG_GAVE_UP; return; } }   // the QP gave up at its conditioning gate: nothing of this solve is used (solve() ends it with PMPC_SQP_REDO)
         if constexpr (RUIZ_COMPILED) if (ruiz) {   // unscale(p, p_lambda); unscale(m_H, m_h, m_A, ...), sqp_base.hpp:608-609 / :664-665
             ruiz_unscale_solution_wave(n, m, rz.D, rz.E, rz_c, qw.x, qw.y);
             ruiz_unscale_problem_wave(n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, rz.D, rz.E, rz_c);
@@ -1050,7 +1073,7 @@ struct SqpDevice {
             linearise(iter == 1 || ss.exact_hessian_every_iter, true);
             const long long c1 = now();
             qp_and_step();
-            if constexpr (BIG) { if (qp_flags & FLAG_GAVE_UP) { status = PMPC_SQP_REDO; break; } }
+            if constexpr (BIG || SCH) { if (qp_flags & FLAG_GAVE_UP) { status = PMPC_SQP_REDO; break; } }
             const long long c2 = now();
             const bool done = __builtin_amdgcn_readfirstlane((int)termination_criteria()) != 0;
             const long long c3 = now();

@@ -871,7 +871,9 @@ def test_sqp_cstr_reference_scenario(ctx, oracle, hessian_update):
             # with every linear solve carried to exact arithmetic (PIVOT_EXACT, either function set): the unregularised indefinite Hessian, not an
             # elimination order, decides it. A change of this outcome — in either direction — must be looked at.
             assert i2["status"][0] == pa.SQP_MAX_ITER_EXCEEDED and (i2["iter"][0], i2["qp_solver_iter"][0]) == (20, 2020)
-            assert np.isfinite(x2).all() and np.isfinite(lam2).all() and i2["flags"][0] == 0
+            # (round 5: the block-structured kernel's conditioning gate trips on a QP of this indefinite stream — the instance is finished by the redo launch in the
+            #  static order, which ends it the same way: flag PMPC_FLAG_ILLCOND, nothing non-finite)
+            assert np.isfinite(x2).all() and np.isfinite(lam2).all() and i2["flags"][0] == io2[0].flags == pa.capi.FLAG_ILLCOND
         if reg == 0 and not hessian_update:
             # the dense-BFGS variant: SOLVED as :177 asserts — after an overflow (the termination test's norms drop NaNs), which the info word reports
             assert i2["status"][0] == pa.SQP_SOLVED and (i2["iter"][0], i2["qp_solver_iter"][0]) == (4, 313)
@@ -1304,6 +1306,86 @@ def _free_controls(wl, nx):
     w = dict(wl); w["lbx"] = wl["lbx"].copy(); w["ubx"] = wl["ubx"].copy()
     w["lbx"][:, nx * nn:] = -np.inf; w["ubx"][:, nx * nn:] = np.inf
     return w
+
+
+def test_block_structured_kernel_conditioning_gate_and_its_redo_launch(ctx, oracle):
+    """The block-structured kernel's gate (round 5): its range-space solve x = Q (r1 - A' nu) works through S = 1/rho + A Q A' and is a difference of quantities
+    ~ rho_eq times larger than x — the error of a solve grows like the conditioning estimate squared once the ADMM penalty adapts upwards (2e-9 at an estimate of 4e6,
+    2e-5 at 4e7, nothing at 4e10). From max S_ii max |(S^-1)_ii| = 1e7 on the QP is given up and the redo launch solves the instance on the LDS-resident static LDL^T.
+    Robot 11 / 16 nodes and CSTR with the block BFGS and the QP penalty started at 0.1 (no trip: flags clear — as on every BASELINE workload — and within 1e-8 of
+    Eigen's pivoted order), 30 and 1e3: bit for bit the restatement under the same rule (PIVOT_SCHUR -> PIVOT_STATIC), flag included."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    B = 16
+    tripped = 0
+    for wl in (workloads.robot_batch(B, P=5, S=2), workloads.robot_batch(B, P=5, S=3), workloads.cstr_batch(B)):
+        for rho0 in (0.1, 30.0, 1e3):
+            ss = pa.sqp_settings_default(); oss = oracle.sqp_default_settings()
+            for st in (ss, oss):
+                st.max_iter = 4; st.line_search_max_iter = wl["ls_max_iter"]; st.hessian_update = 1
+            qs = pa.qp_settings_sqp_default(); oqs = oracle.sqp_qp_default_settings()
+            qs.rho = rho0; oqs.rho = rho0
+            x, lam, info = ctx.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss, qp_settings=qs)
+            assert ctx.last_route() == pa.capi.ROUTE_SCHUR
+            xo, lo, io = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, qp_settings=oqs,
+                                                pivot=oracle.PIVOT_SCHUR, threads=4)
+            fo = np.array([i.flags for i in io])
+            print(wl["model"], wl["P"], wl["S"], rho0, "flags gpu", info["flags"].tolist(), "cpu", fo.tolist())
+            assert np.array_equal(info["flags"] & pa.capi.FLAG_ILLCOND, fo & oracle.FLAG_ILLCOND)
+            assert np.all(info["status"] <= pa.SQP_MAX_ITER_EXCEEDED)          # (the internal REDO status never leaves the library)
+            _assert_same_solve(info, io, x, xo, lam, lo)
+            tripped += int(np.count_nonzero(info["flags"] & pa.capi.FLAG_ILLCOND))
+            if rho0 == 0.1:
+                assert np.all(info["flags"] == 0)
+                xe, _, ie = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, qp_settings=oqs,
+                                                   pivot=oracle.PIVOT_EIGEN, threads=4)
+                assert [i.qp_solver_iter for i in ie] == info["qp_solver_iter"].tolist()
+                assert (np.abs(x - xe) / np.maximum(1.0, np.abs(xe).max(axis=0))).max() <= 1e-8
+            if rho0 == 1e3:
+                assert np.all(info["flags"] & pa.capi.FLAG_ILLCOND)
+    assert tripped >= 3 * B
+
+
+def test_sqp_bordered_block_structured_kernel_behind_its_developer_switch(ctx, oracle):
+    """NP = 1 on the block-structured kernel (round 5, PMPC_SCHUR_NP=1; pmpc_schur_parking.hip): the exact Hessian of the minimal-time parking problem has the
+    arrow shape — node blocks, a border row / column for the free final time, a corner — and A a dense parameter column; the QP is solved through the bordered
+    range-space form. (a) minimal_time_test.cpp:146-188 as the reference configures it: every instance meets the conditioning gate once the penalty adapts upwards
+    and is finished by the redo launch — SOLVED in < 20 iterations as the reference asserts, bit for bit the restatement under the same rule: which is why the switch
+    is not the default. (b) the same problems with the penalty held at 0.1 (adaptive_rho = 0): no trip, every QP of every iteration on the bordered kernel,
+    bit-identical to PIVOT_SCHUR — the arithmetic of the border itself. (c) three iterations with the block BFGS (border row / column and corner take the same
+    damped rank-2 terms, continuous_ocp.hpp:2384-2428)."""
+    import os
+    import polympc_amd as pa
+    from test_oracle_pins import _parking_batch
+    B = 12
+    lbx, ubx, xg, d = _parking_batch(B)
+    os.environ["PMPC_SCHUR_NP"] = "1"
+    try:
+        for case in ("reference", "fixed_rho", "block_bfgs"):
+            ss = pa.sqp_settings_default(); oss = oracle.sqp_default_settings()
+            qs = pa.qp_settings_sqp_default(); oqs = oracle.sqp_qp_default_settings()
+            for st in (ss, oss):
+                st.max_iter = 20; st.line_search_max_iter = 10; st.regularisation = 2
+                if case == "block_bfgs": st.hessian_update = 1; st.max_iter = 3
+                else: st.exact_hessian_every_iter = 1
+            if case != "reference":
+                qs.adaptive_rho = 0; oqs.adaptive_rho = 0
+            x, lam, info = ctx.sqp_solve_batch(pa.MODEL_PARKING, 5, 2, 0.0, 1.0, B, d, lbx, ubx, x_guess=xg, sqp_settings=ss, qp_settings=qs)
+            assert ctx.last_route() == pa.capi.ROUTE_SCHUR
+            xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_PARKING, 5, 2, 0.0, 1.0, B, d, lbx, ubx, x_guess=xg, sqp_settings=oss, qp_settings=oqs, pivot=oracle.PIVOT_SCHUR, threads=4)
+            fo = np.array([i.flags for i in io])
+            print(case, "flags", info["flags"].tolist(), "iter", info["iter"].tolist(), "status", info["status"].tolist())
+            assert np.array_equal(info["flags"], fo)
+            _assert_same_solve(info, io, x, xo, lam, lo)
+            if case == "reference":
+                assert np.all(info["flags"] & pa.capi.FLAG_ILLCOND) and (info["status"] == pa.SQP_SOLVED).sum() >= B - 1 and np.all(info["iter"][info["status"] == pa.SQP_SOLVED] < 20)
+            else:
+                assert np.all(info["flags"] == 0)
+    finally:
+        del os.environ["PMPC_SCHUR_NP"]
+    ss = pa.sqp_settings_default(); ss.max_iter = 2; ss.regularisation = 2; ss.exact_hessian_every_iter = 1
+    ctx.sqp_solve_batch(pa.MODEL_PARKING, 5, 2, 0.0, 1.0, 1, d[:1], lbx[:1], ubx[:1], x_guess=xg[:1], sqp_settings=ss)
+    assert ctx.last_route() != pa.capi.ROUTE_SCHUR   # without the switch: the dense two-rows-per-lane kernel, as before
 
 
 @pytest.mark.parametrize("case", ["robot_11", "robot_16", "cstr_11", "robot_7", "kite"])

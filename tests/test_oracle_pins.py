@@ -403,7 +403,101 @@ def _minimal_time_parking(nn=11):
     return lbx[None], ubx[None], xg[None]
 
 
-@pytest.mark.parametrize("pivot", [0, 1, 3])
+def _parking_batch(B, nn=11, seed=5):
+    """B minimal-time parking problems (NP = 1) around the reference's: start states within +-0.2 of (1.5, .5, .5), wheel bases d in [0.8, 1.2]."""
+    rng = np.random.default_rng(seed)
+    lbx, ubx, xg = (np.repeat(a, B, 0) for a in _minimal_time_parking(nn))
+    x0 = np.array([1.5, 0.5, 0.5]) + 0.2 * rng.uniform(-1, 1, (B, 3))
+    lbx[:, 3 * nn - 3:3 * nn] = x0; ubx[:, 3 * nn - 3:3 * nn] = x0
+    xg[:, :3 * nn] = np.tile(x0, nn)
+    return lbx, ubx, xg, 1.0 + 0.2 * rng.uniform(-1, 1, (B, 1))
+
+
+def test_bordered_block_structured_solve_against_a_dense_solve(oracle):
+    """PIVOT_SCHUR with one parameter (round 5): the KKT matrix of a collocation QP whose Hessian has the arrow shape (node blocks, a border row / column, a corner)
+    and whose A has a dense parameter column — the bordered range-space solve of the block-structured kernel against numpy's LU of the full matrix."""
+    rng = np.random.default_rng(0)
+    nx, nu, nn, P = 3, 2, 11, 5
+    d = nx + nu; n0 = d * nn; n = n0 + 1; m = nx * nn
+    sg = lambda k, c: k * nx + c if c < nx else nx * nn + k * nu + (c - nx)
+    H = np.zeros((n, n))
+    for k in range(nn):
+        Bk = rng.standard_normal((d, d)); idx = [sg(k, c) for c in range(d)]
+        H[np.ix_(idx, idx)] = Bk @ Bk.T + np.eye(d)
+    b = 0.3 * rng.standard_normal(n0); H[n0, :n0] = b; H[:n0, n0] = b; H[n0, n0] = 5.0 + b @ b
+    A = np.zeros((m, n))
+    for r in range(m):
+        ni, si = divmod(r, nx)
+        kb = nn - 1 - P if ni == nn - 1 else (ni // P) * P
+        for k in range(kb, kb + P + 1): A[r, k * nx + si] = rng.standard_normal()
+        for c in range(d): A[r, sg(ni, c)] = rng.standard_normal()
+        A[r, n0] = rng.standard_normal()
+    for rho in (0.1, 100.0, 1e4):
+        rv = np.full(m, rho)
+        K = np.zeros((n + m, n + m)); K[:n, :n] = H + np.eye(n) * (1e-6 + 0.1 * rho); K[n:, :n] = A; K[:n, n:] = A.T; K[n:, n:] = -np.diag(1 / rv)
+        rhs = rng.standard_normal(n + m)
+        sol = oracle.kkt_solve(K, rv, rhs, pivot=oracle.PIVOT_SCHUR, structure=(nx, nu, nn, P, 1))
+        ref = np.linalg.solve(K, rhs)
+        assert np.abs(sol - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()), rho
+    with pytest.raises(ValueError):
+        oracle.kkt_solve(K, rv, rhs, pivot=oracle.PIVOT_SCHUR, structure=(nx, nu, nn, P))   # the structure must name the parameter
+
+
+def test_sqp_parking_batch_block_structured_order_against_the_reference_order(oracle):
+    """The bordered block-structured order (PIVOT_SCHUR, NP = 1) inside the SQP on 12 minimal-time parking problems around the reference's. (a) As
+    minimal_time_test.cpp configures it (exact Hessians + Gershgorin, adaptive rho): EVERY instance meets the order's conditioning gate once the ADMM penalty adapts
+    upwards — the states hardly enter these dynamics, so the state columns of the collocation Jacobian are nearly singular — and is finished in the static order: the
+    outcome, the SQP iteration counts and the solutions (1e-5) of Eigen's pivoted order, flag set. (Without the gate: three instances need one to three more
+    iterations and end 2e-3 .. 3e-2 away.) Which is why the product keeps this problem on its dense kernel. (b) With the penalty held at 0.1 nothing trips, and the
+    bordered order is CLOSER to exact arithmetic (PIVOT_EXACT) than the reference order is."""
+    lbx, ubx, xg, d = _parking_batch(12)
+    ss = oracle.sqp_default_settings(); ss.max_iter = 20; ss.line_search_max_iter = 10; ss.regularisation = 2; ss.exact_hessian_every_iter = 1
+    run = lambda pv, qs=None: oracle.sqp_solve_batch(oracle.MODEL_PARKING, 5, 2, 0.0, 1.0, 12, d, lbx, ubx, x_guess=xg, sqp_settings=ss, qp_settings=qs, pivot=pv, threads=8)
+    xe, _, ie = run(oracle.PIVOT_EIGEN)
+    xs, _, is_ = run(oracle.PIVOT_SCHUR)
+    assert all(i.flags & oracle.FLAG_ILLCOND for i in is_) and not any(i.flags for i in ie)
+    assert [i.status for i in ie] == [i.status for i in is_] and [i.iter for i in ie] == [i.iter for i in is_]
+    solved = np.array([i.status == oracle.SQP_SOLVED for i in ie])
+    assert solved.sum() >= 10
+    assert np.abs(xe[solved] - xs[solved]).max() <= 1e-5 and np.abs(xe[solved, 55] - xs[solved, 55]).max() <= 1e-6
+    qs = oracle.sqp_qp_default_settings(); qs.adaptive_rho = 0
+    R = {pv: run(pv, qs) for pv in (oracle.PIVOT_EIGEN, oracle.PIVOT_SCHUR, oracle.PIVOT_EXACT)}
+    assert not any(i.flags for i in R[oracle.PIVOT_SCHUR][2])
+    assert [i.qp_solver_iter for i in R[oracle.PIVOT_SCHUR][2]] == [i.qp_solver_iter for i in R[oracle.PIVOT_EXACT][2]]
+    ds = np.abs(R[oracle.PIVOT_SCHUR][0] - R[oracle.PIVOT_EXACT][0]).max(); de = np.abs(R[oracle.PIVOT_EIGEN][0] - R[oracle.PIVOT_EXACT][0]).max()
+    assert ds <= 1e-10 and ds <= de, (ds, de)
+
+
+@pytest.mark.parametrize("cfg", ["cstr_11", "robot_16", "robot_11"])
+def test_block_structured_order_under_its_conditioning_gate_follows_exact_arithmetic_like_the_reference_order(oracle, cfg):
+    """PIVOT_SCHUR with its gate (max S_ii max |(S^-1)_ii| > 1e7: give up, redo in PIVOT_STATIC) against the same solves carried to exact arithmetic
+    (PIVOT_EXACT), next to Eigen's pivoted order, with the block BFGS and the QP penalty started at 0.1 .. 1e3: on every instance the order KEEPS, the
+    trajectories are those of exact arithmetic and the solutions lie within 1e-7 (scaled) of it — at worst 16 times the reference order's own distance (CSTR, rho0 = 100: 1e-7 against 6e-9), mostly closer than the reference order; a gate of 3e6 would make that factor 1 but trips on 10 of config R's 2048 instances. Without the gate
+    the range-space solve — a difference of quantities ~ rho_eq times its result — is off by 2e-5 (robot, rho0 = 100) to 2e-3 (CSTR, rho0 = 1e3)."""
+    from polympc_amd import workloads
+    B = 16
+    wl = {"cstr_11": workloads.cstr_batch(B), "robot_16": workloads.robot_batch(B, P=5, S=3), "robot_11": workloads.robot_batch(B, P=5, S=2)}[cfg]
+    kept = flagged = 0
+    for rho0 in (0.1, 1.0, 10.0, 30.0, 100.0, 1e3):
+        R = {}
+        for pv in (oracle.PIVOT_SCHUR, oracle.PIVOT_EIGEN, oracle.PIVOT_EXACT):
+            ss = oracle.sqp_default_settings(); ss.max_iter = wl["max_iter"]; ss.line_search_max_iter = wl["ls_max_iter"]; ss.hessian_update = 1
+            qs = oracle.sqp_qp_default_settings(); qs.rho = rho0
+            x, _, info = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss, qp_settings=qs, pivot=pv, threads=8)
+            R[pv] = (x, np.array([i.qp_solver_iter for i in info]), np.array([i.flags for i in info]))
+        sc = np.maximum(1.0, np.abs(R[oracle.PIVOT_EXACT][0]).max(axis=0))
+        keep = (R[oracle.PIVOT_SCHUR][2] & oracle.FLAG_ILLCOND) == 0
+        kept += int(keep.sum()); flagged += int((~keep).sum())
+        if rho0 <= 1.0: assert keep.all()
+        if not keep.any(): continue
+        assert np.array_equal(R[oracle.PIVOT_SCHUR][1][keep], R[oracle.PIVOT_EXACT][1][keep])
+        ds = (np.abs(R[oracle.PIVOT_SCHUR][0] - R[oracle.PIVOT_EXACT][0]) / sc).max(axis=1)[keep].max()
+        de = (np.abs(R[oracle.PIVOT_EIGEN][0] - R[oracle.PIVOT_EXACT][0]) / sc).max(axis=1)[keep].max()
+        assert ds <= 2e-7 and ds <= max(20.0 * de, 1e-9), (rho0, ds, de)
+    assert kept >= 3 * B and flagged >= B
+
+
+@pytest.mark.parametrize("pivot", [0, 1, 3, 7])
 def test_sqp_minimal_time_valet_parking(oracle, pivot):  # minimal_time_test.cpp:146-188 — exact Hessian every iteration + Gershgorin
     ss = oracle.sqp_default_settings(); ss.max_iter = 20; ss.line_search_max_iter = 10
     ss.regularisation = 2; ss.exact_hessian_every_iter = 1

@@ -352,6 +352,10 @@ def test_sqp_hs071_iteration_bound_is_a_last_bit_property(oracle):
                                             sqp_settings=ss, pivot=pivot)
             assert info.status == oracle.SQP_SOLVED and _is_approx(x, sol, 1e-2), (pivot, dx)
             iters[(pivot, dx)] = info.iter
+    # (round 5) with every linear solve of the ADMM carried to exact arithmetic (PIVOT_EXACT) the unperturbed run takes 41 iterations — inside the reference's
+    # bound — and its 1e-13 neighbours 64: even then the count is decided by rounding elsewhere (the eigenvalue mirroring, the products), not by the algorithm
+    x, lam, info = oracle.nlp_solve(oracle.NLP_HS071, [1.0, 5.0, 5.0, 1.0], lbx=[1.0] * 4, ubx=[5.0] * 4, lbg=[25.0], ubg=[inf], sqp_settings=ss, pivot=oracle.PIVOT_EXACT)
+    assert info.status == oracle.SQP_SOLVED and _is_approx(x, sol, 1e-2) and info.iter < 50
     eig = [v for (p, _), v in iters.items() if p == oracle.PIVOT_EIGEN]
     assert min(eig) < 50, iters                                # the reference's bound is met inside the Eigen-order ensemble ...
     assert min(iters.values()) < 50 <= max(iters.values()), iters   # ... and the ensemble straddles it: the bound is not a property of the algorithm

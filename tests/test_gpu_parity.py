@@ -1574,3 +1574,38 @@ def test_qp_entry_conditioning_gate_and_its_redo_launch(ctx, oracle):
             assert np.array_equal(x, xo) and np.array_equal(y, yo), (rho0, free, np.abs(x - xo).max())
             if not free: assert np.all(info["flags"] == 0)
             if free and rho0 == 1e5: assert np.all(info["flags"] & pa.capi.FLAG_ILLCOND)
+
+
+def test_empty_and_odd_batch_sizes(ctx, oracle):
+    """Edge cases of the batch dimension through the C ABI: an empty batch is accepted and touches nothing; batches of 1, 63, 65 and 130 instances (not multiples of
+    the 64 QPs a redo-launch workgroup scans, nor of anything else) give, instance by instance, exactly what the same instances give in a batch of 130 — on the QP
+    entry point (one-row-per-lane kernel, with and without its conditioning gate tripping) and on the fused SQP kernels of four routes."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    from oracle import cross_order as tco
+    q = tco.traced_qp_stream(oracle, "A", 130)
+    q = {k: v[:130] for k, v in q.items() if isinstance(v, np.ndarray)}
+    n, m = q["h"].shape[1], q["Alb"].shape[1]
+    x, y, info = ctx.qp_solve_batch(q["H"][:0], q["h"][:0], q["A"][:0], q["Alb"][:0], q["Aub"][:0], q["xlb"][:0], q["xub"][:0])
+    assert x.shape == (0, n) and y.shape == (0, n + m) and len(info["iter"]) == 0
+    for free in (False, True):
+        lo = np.full_like(q["xlb"], -np.inf) if free else q["xlb"]; hi = np.full_like(q["xub"], np.inf) if free else q["xub"]
+        qs = pa.qp_settings_sqp_default(); qs.rho = 1e5 if free else 0.1
+        xf, yf, inf_ = ctx.qp_solve_batch(q["H"], q["h"], q["A"], q["Alb"], q["Aub"], lo, hi, settings=qs)
+        assert bool(np.all(inf_["flags"] & pa.capi.FLAG_ILLCOND)) == free
+        for B in (1, 63, 65):
+            xb, yb, ib = ctx.qp_solve_batch(q["H"][:B], q["h"][:B], q["A"][:B], q["Alb"][:B], q["Aub"][:B], lo[:B], hi[:B], settings=qs)
+            assert np.array_equal(xb, xf[:B]) and np.array_equal(yb, yf[:B]) and np.array_equal(ib["iter"], inf_["iter"][:B]) and np.array_equal(ib["flags"], inf_["flags"][:B])
+    for wl, kw, route in ((workloads.robot_batch(130), {}, pa.capi.ROUTE_REG1), (workloads.robot_batch(130, P=5, S=2), {}, pa.capi.ROUTE_CONDREG),
+                          (workloads.robot_batch(130, P=5, S=2), dict(hessian_update=1), pa.capi.ROUTE_SCHUR), (workloads.kite_standin_batch(5), {}, pa.capi.ROUTE_HBM)):
+        ss = pa.sqp_settings_default(); ss.max_iter = 3; ss.line_search_max_iter = wl["ls_max_iter"]
+        for k, v in kw.items(): setattr(ss, k, v)
+        nB = wl["lbx"].shape[0]
+        run = lambda B: ctx.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"][:B], wl["lbx"][:B], wl["ubx"][:B], sqp_settings=ss)
+        xf, lf, inf_ = run(nB)
+        assert ctx.last_route() == route
+        x0, l0, i0 = run(0)
+        assert x0.shape[0] == 0 and l0.shape[0] == 0
+        for B in ((1, 63, 65) if nB >= 65 else (1, 3)):
+            xb, lb, ib = run(B)
+            assert np.array_equal(xb, xf[:B]) and np.array_equal(lb, lf[:B]) and np.array_equal(ib["qp_solver_iter"], inf_["qp_solver_iter"][:B])

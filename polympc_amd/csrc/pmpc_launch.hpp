@@ -189,6 +189,8 @@ __global__ __launch_bounds__(WG4 ? 256 : 64, ((NN > 0 && NN + MM <= 64) ? PMPC_S
         // instructions cost the bench kernel 2 % (same box A/B: 1.145 -> 1.17 ms; behind it 1.15), while the condensed kernels lose 3 % with the test
         // behind the solve and nothing with it in front (16-node grid 6.09 / 6.28 / 6.07 ms) — code placement. A numeric gate at every factorisation —
         // what the large-instance kernel and the QP entry point use — cost these kernels 4 .. 10 % through register pressure alone (EXPERIMENTS.md round 5).
+        // (Config B's condensed kernel, for which the round's first measurement had the test in front cost 1.5 %: the same build with the test behind the solve times the
+        //  same on one box, 26.98 / 26.86 / 26.83 against 26.96 / 26.80 / 26.82 ms — that difference was the box, not the placement.)
         if (flags0 == 0 && si.status != PMPC_SQP_IN_PROGRESS) {
             bool loose = false;
             for (int i = ocp.dm.VARX + ln; i < n; i += WAVE) loose |= classify_bounds(v.lbx[i], v.ubx[i]) == 2;
@@ -222,9 +224,9 @@ template <class Model, int PP, int SS> inline size_t sqp_schur_lds_bytes() {
     size_t stage = OcpLds<Model>::doubles(PP, SS);
     const size_t need = (size_t)RegKkt<SD::M>::TRI + OcpLds<Model>::const_doubles(PP, SS) + 8;
     if (stage < need) stage = need;
-    return (QpLds::doubles_xy(dm.n, dm.m) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8 + schur_lds_doubles_ct<Model, PP, SS>() + (Model::ND > 0 ? Model::ND : 1)) * sizeof(double);
+    return (QpLds::doubles_xy(dm.n, dm.m) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8 + schur_lds_doubles_ct<Model, PP, SS>() + (Model::ND > 0 ? Model::ND : 1) + FILTER_LDS_DOUBLES) * sizeof(double);
 }
-template <class Model, int PP, int SS, bool PROF = false>
+template <class Model, int PP, int SS, bool PROF = false, bool POL = false>   // POL: with the filter line search (line_search = 1, LSFilter carried in LDS) — the hook of the reference's tests this kernel family carries
 __global__ __launch_bounds__(64, (SchurDims<Model, PP, SS>::N + SchurDims<Model, PP, SS>::M <= 64) ? PMPC_SQP_WAVES : 1)
 void sqp_schur_kernel(Model model, const ChebData* __restrict__ cd, int B, const double* __restrict__ x_guess, const double* __restrict__ lam_guess,
                       const double* __restrict__ d, const double* __restrict__ lbx, const double* __restrict__ ubx, pmpc_sqp_settings ss,
@@ -253,8 +255,14 @@ void sqp_schur_kernel(Model model, const ChebData* __restrict__ cd, int B, const
     p += ((p - smem) & 1);   // the tables are read 16 bytes at a time
     double* dtab = p; p += SD::TAB;
     double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
+    double* filt = nullptr;   // LSFilter of this instance (POL)
+    if constexpr (POL) { filt = p; p += FILTER_LDS_DOUBLES; }
     const int ln = lane_id();
     for (int i = ln; i < Model::ND; i += WAVE) dL[i] = d[(size_t)b * Model::ND + i];
+    if constexpr (POL) {
+        const bool carried = ss.line_search == 1 && ss.filter_state != nullptr;
+        if (ln < PMPC_FILTER_STATE_DOUBLES) filt[ln] = carried ? ss.filter_state[(size_t)b * PMPC_FILTER_STATE_DOUBLES + ln] : 0.0;
+    }
     ocp.d = dL;
     ocp.stage_constants(cd);
     for (int i = ln; i < n; i += WAVE) {
@@ -263,7 +271,8 @@ void sqp_schur_kernel(Model model, const ChebData* __restrict__ cd, int B, const
     }
     for (int i = ln; i < m + n; i += WAVE) v.lam[i] = lam_guess ? lam_guess[(size_t)b * (m + n) + i] : 0.0;
     wsync();
-    SqpDevice<Model, n, m, PROF, 1, false, false, PP * 256 + SS> sqp(ocp, v, qw, nullptr, nullptr, ss, qs);
+    SqpDevice<Model, n, m, PROF, 1, false, POL, PP * 256 + SS> sqp(ocp, v, qw, nullptr, nullptr, ss, qs);
+    sqp.filt = filt;
     sqp.hblk = hblk; sqp.hbrd = hbrd; sqp.qblk = qblk; sqp.xsc = xsc; sqp.dsc = dsc; sqp.pdl = pdl; sqp.dtab = dtab;
     schur_build_tables<Model, PP, SS>(ocp.s.D, dtab);
     sqp.trace = ss.iteration_trace ? ss.iteration_trace + (size_t)b * (size_t)ss.iteration_trace_capacity * PMPC_TRACE_DOUBLES : nullptr;
@@ -280,13 +289,16 @@ void sqp_schur_kernel(Model model, const ChebData* __restrict__ cd, int B, const
     for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = v.x[i];
     for (int i = ln; i < m + n; i += WAVE) lam[(size_t)b * (m + n) + i] = v.lam[i];
     if (ln == 0) info[b] = si;
+    if constexpr (POL) {   // (an instance that gave up leaves the carried filter as it found it: the redo launch starts from the same filter)
+        if (ss.line_search == 1 && ss.filter_state != nullptr && si.status != PMPC_SQP_REDO && ln < PMPC_FILTER_STATE_DOUBLES) ss.filter_state[(size_t)b * PMPC_FILTER_STATE_DOUBLES + ln] = filt[ln];
+    }
     if constexpr (PROF) { if (phase_cycles && ln == 0) for (int i = 0; i < 24; ++i) atomicAdd(&phase_cycles[i], (unsigned long long)sqp.cyc[i]); }
 }
 // the request can take the block-structured kernel: block-diagonal Hessian throughout, default policies otherwise (pmpc_sqp_settings::kkt_form = 1
 // asks for the reference's full KKT form and keeps the dense kernels)
 inline bool schur_request_ok(const pmpc_sqp_settings* ss, const pmpc_qp_settings* qs, int slice_iters) {
     return (ss->hessian_update == 1 || ss->exact_hessian_every_iter) && (ss->regularisation == 0 || ss->regularisation == 2) && ss->preconditioner == 0 &&
-           ss->qp_solver == 0 && ss->line_search == 0 && ss->kkt_form == 0 && qs->linear_solver == 0 && slice_iters == 0;
+           ss->qp_solver == 0 && ss->kkt_form == 0 && qs->linear_solver == 0 && slice_iters == 0;   // (line_search = 1: the grids compiled with the hook, try_launch_schur)
 }
 template <class Model, int PP, int SS>
 inline bool try_launch_schur(pmpc_context* ctx, const Model& mdl, const ChebData* cd, int P, int S, int B, const double* x_guess, const double* lam_guess,
@@ -302,6 +314,11 @@ inline bool try_launch_schur(pmpc_context* ctx, const Model& mdl, const ChebData
     auto kern = sqp_schur_kernel<Model, PP, SS, false>;
     if constexpr (SchurDims<Model, PP, SS>::NPAR == 0) { if (phase) kern = sqp_schur_kernel<Model, PP, SS, true>; }   // (no phase-timer build of the bordered form: a developer switch already)
     else phase = nullptr;
+    // the filter line search (round 5): compiled for the grids of the reference's own tests with more than 64 KKT rows (11 and 16 nodes), no phase timers
+    if (ss->line_search == 1) {
+        if constexpr (SchurDims<Model, PP, SS>::NPAR == 0 && (SchurDims<Model, PP, SS>::NNODES == 11 || SchurDims<Model, PP, SS>::NNODES == 16)) { kern = sqp_schur_kernel<Model, PP, SS, false, true>; phase = nullptr; }
+        else return false;
+    }
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
     pmpc_internal_set_route(ctx, PMPC_ROUTE_SCHUR);
     hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), lds, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, *ss, *qs, x, lam, info, phase);

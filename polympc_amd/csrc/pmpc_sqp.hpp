@@ -77,7 +77,7 @@ struct SqpDevice {
 #ifdef PMPC_EXPERIMENT_CND_WITH_RUIZ
     static constexpr bool RUIZ_COMPILED = HOOKS && (int)Dm::NDER <= RUIZ_MAX_NDER;
 #else
-    static constexpr bool RUIZ_COMPILED = HOOKS && (int)Dm::NDER <= RUIZ_MAX_NDER && PS != -1;
+    static constexpr bool RUIZ_COMPILED = HOOKS && (int)Dm::NDER <= RUIZ_MAX_NDER && PS != -1 && PS <= 0;   // (PS > 0: the block-structured kernel has no dense workspace to scale — of the hooks it carries the filter line search only)
 #endif
     static constexpr bool REG1 = !SCH && NN > 0 && NN + MM <= WAVE;    // one KKT row per lane
     static constexpr bool REG2 = !SCH && NN > 0 && NN + MM > WAVE;     // two KKT rows per lane

@@ -59,7 +59,7 @@ def _schur_route(model, P, S, hessian_update=0, exact_hessian_every_iter=0, regu
                  linear_solver=0, **_):
     """Does the request take the block-structured kernel (pmpc_launch.hpp: schur_request_ok + the compiled grids)? Its restatement is PIVOT_SCHUR."""
     return (P, S) in SCHUR_GRIDS.get(model, ()) and (hessian_update == 1 or exact_hessian_every_iter) and regularisation in (0, 2) and \
-        not preconditioner and not qp_solver and not line_search and not kkt_form and not linear_solver
+        not preconditioner and not qp_solver and (not line_search or P * S + 1 in (11, 16)) and not kkt_form and not linear_solver   # (round 5: the filter line search on the 11- and 16-node builds)
 
 
 def _gpu_order(oracle, n, m, nodes=None, block_bfgs=False, kkt_form=0, schur=False, ng=0):
@@ -757,6 +757,46 @@ def test_sqp_filter_line_search_batch_vs_oracle(ctx, oracle):
     x, lam, info = ctx.sqp_solve_batch(pa.MODEL_ROBOT, 5, 2, 0.0, 2.0, 8, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
     xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 2.0, 8, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, pivot=_policy_order(oracle, 55, 33, 11))
     _assert_same_solve(info, io, x, xo, lam, lo)
+
+
+def test_sqp_filter_line_search_on_the_block_structured_kernel(ctx, oracle):
+    """line_search = 1 together with the block BFGS (two of the three hooks valet_parking_mpc_test.cpp:116-165 installs; the third, the Ruiz preconditioner, rescales a
+    dense workspace this kernel family does not have and keeps the dense kernels): since round 5 on the block-structured kernel for the 11- and 16-node grids — route
+    PMPC_ROUTE_SCHUR, identical iteration counts, bit-identical x, lambda and filter contents against PIVOT_SCHUR; a second solve from the first one's solution with
+    the carried filter agrees again."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    unflagged = 0
+    for model, P, S, B in ((pa.MODEL_ROBOT, 5, 2, 24), (pa.MODEL_ROBOT, 5, 3, 12), (pa.MODEL_CSTR, 5, 2, 12)):
+        wl = workloads.robot_batch(B, P=P, S=S) if model == pa.MODEL_ROBOT else workloads.cstr_batch(B)
+        ss = pa.sqp_settings_default(); oss = oracle.sqp_default_settings()
+        for st in (ss, oss):
+            st.max_iter = 10; st.line_search_max_iter = 10; st.line_search = 1; st.hessian_update = 1
+        handle = ctx.filter_state_create(B); ss.filter_state = handle
+        ofilt = np.zeros((B, oracle.FILTER_STATE_DOUBLES)); oracle.bind_filter_state(oss, ofilt)
+        try:
+            xg = lg = xo = lo = None
+            for rep in range(2):
+                xg, lg, info = ctx.sqp_solve_batch(model, P, S, wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], x_guess=xg, lam_guess=lg, sqp_settings=ss)
+                assert ctx.last_route() == pa.capi.ROUTE_SCHUR
+                xo, lo, io = oracle.sqp_solve_batch(model, P, S, wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], x_guess=xo, lam_guess=lo, sqp_settings=oss, pivot=oracle.PIVOT_SCHUR)
+                _assert_same_solve(info, io, xg, xo, lg, lo)
+                filt = ctx.filter_state_download(B, handle)
+                assert np.array_equal(filt, ofilt) and np.all(filt[:, 0] >= 1)
+                fo = np.array([i.flags for i in io])
+                print(model, P, S, "solve", rep, "flags", info["flags"].tolist())
+                assert np.array_equal(info["flags"], fo) and not np.any(info["flags"] & pa.capi.FLAG_NONFINITE)   # (a conditioning-gate trip sends the instance — filter included — to the redo launch: same rule on both sides)
+                unflagged += int(np.count_nonzero(info["flags"] == 0))
+                xo, lo = xg.copy(), lg.copy()
+                ofilt[:] = filt
+        finally:
+            ctx.filter_state_destroy(handle)
+    assert unflagged >= 48   # (most solves run on the block-structured kernel from start to end)
+    # a grid without the hook build keeps its previous route
+    wl = workloads.cstr_batch(4); lbx, ubx = _cstr_grid(4, 6, 1)
+    ss = pa.sqp_settings_default(); ss.max_iter = 2; ss.line_search = 1; ss.hessian_update = 1
+    ctx.sqp_solve_batch(pa.MODEL_CSTR, 6, 1, 0.0, 100.0, 4, np.zeros((4, 1)), lbx, ubx, sqp_settings=ss)
+    assert ctx.last_route() != pa.capi.ROUTE_SCHUR
 
 
 def test_filter_settings_are_validated(ctx):

@@ -784,7 +784,9 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
         (ss->line_search == 1 && (ss->filter_max_depth < 1 || ss->filter_max_depth > PMPC_FILTER_MAX_DEPTH))) return PMPC_ERR_INVALID_ARGUMENT;
     if (qs->linear_solver != 0 && qs->linear_solver != 1) return PMPC_ERR_INVALID_ARGUMENT;
     if constexpr (SCHUR_GRIDS<Model>::value) {   // block-diagonal Hessian on a grid with a block-structured kernel
-        if (!force_lds && !getenv("PMPC_NO_SCHUR") && schur_request_ok(ss, qs, slice_iters)) {
+        // (the redo launch behind this kernel's conditioning gate runs the LDS-resident kernel: a grid it does not fit — only under a developer's PMPC_LDS_LIMIT —
+        //  keeps the dense kernels, so that an instance that gave up can always be solved again)
+        if (!force_lds && !getenv("PMPC_NO_SCHUR") && schur_request_ok(ss, qs, slice_iters) && sqp_kernel_lds_bytes<Model>(P, S, 0, 0) <= lds_limit) {
             pmpc_status rst = PMPC_OK;
             if (try_launch_schur_grids<Model>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, ss, qs, x, lam, info, stream, lds_limit, phase, &rst)) {
                 // redo launch: the instances whose block-structured QP gave up at its conditioning gate (PMPC_SCHUR_COND_GATE; none on any BASELINE workload) are

@@ -409,6 +409,9 @@ public:
     double dual_norm() const noexcept { return m_dual_norm; }
     double constr_violation() const noexcept { return m_max_violation; }
     double cost() const noexcept { return m_cost; }
+    /** not in the reference: the device's information word for the last solve — PMPC_FLAG_NONFINITE (a non-finite value went through: do not trust the numbers) and
+     *  PMPC_FLAG_ILLCOND (information only: the instance was solved again in the full KKT form behind a conditioning gate), include/polympc_amd.h */
+    int info_flags() const noexcept { return m_batch.info(0).flags; }
 
     void solve() noexcept {
         std::copy(m_x.data(), m_x.data() + VAR_SIZE, m_batch.primal_solution(0));

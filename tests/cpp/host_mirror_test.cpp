@@ -239,6 +239,7 @@ static void ValetParkingTest() {
     solver.solve();
     const int cold = solver.info().iter;
     EXPECT_TRUE(solver.info().status.value == sqp_status_t::SOLVED);
+    EXPECT_TRUE(solver.info_flags() == 0);   // (the device's information word: nothing non-finite, no conditioning gate met)
     EXPECT_LT(solver.info().iter, solver.settings().max_iter);
     const size_t kept = solver.filter.entries(0).size();
     EXPECT_TRUE(kept >= 1 && kept <= 10);

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(WG4 ? 256 : 64, ((NN > 0 && NN + MM <= 64) ? PMPC_S
     // stacked workspace K0 = [H ; J] ((n+m) x n, column-major, leading dimension n+m): lane i reads row i of K0 with ONE stride
     double* K0 = Hws + (size_t)b * (size_t)(n + m) * n;
     (void)Aws;
-    SqpDevice<Model, NN, MM, PROF, HU, KHBM, POL, CND ? -1 : ((KHBM && W2) ? -2 : ((KHBM && WG4) ? -3 : 0))> sqp(ocp, v, qw, K0, K0 + n, ss, qs);
+    SqpDevice<Model, NN, MM, PROF, HU, KHBM, POL, CND ? -1 : ((KHBM && WG4) ? -3 : ((KHBM && W2) ? -2 : 0))> sqp(ocp, v, qw, K0, K0 + n, ss, qs);   // (W2 && WG4: the team kernel built for 256 registers — two workgroups per CU)
     sqp.big_mail = big_mail;
     sqp.filt = filt;
     sqp.eig = eigw;
@@ -838,8 +838,15 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
         const char* e = getenv("PMPC_BIG_WG4");
         const bool eligible = Kws && lkern == sqp_kernel<Model, 0, 0, false, 0, true> && ss->kkt_form == 0 && ss->preconditioner == 0 && ss->qp_solver == 0 && ss->regularisation != 1 &&
                               dm.n <= BIG_COND_MAX_ROWS && dm.m <= BIG_COND_MAX_ROWS && slice_iters == 0;
-        const bool want = e && e[0] ? (e[0] != '0') : (B <= BIG_WG4_MAX_BATCH * (pmpc_internal_simd_count(ctx) / 4) / 256);
-        if (eligible && want) { lkern = sqp_kernel<Model, 0, 0, false, 0, true, false, false, false, true>; threads = 4 * WAVE; }
+        // Up to one instance per CU the team kernel may use the whole register file (512 per lane); from there to TWO instances per CU a second build of it,
+        // compiled for 256 registers so that two workgroups share a CU, still beats one wavefront per instance (kite-sized, 512 instances: 11.7 against 13.4 ms;
+        // the register diet costs it 4 % at 256 instances, hence two builds); beyond that the one-wavefront kernel's throughput wins (EXPERIMENTS.md round 5).
+        const int per_cu = BIG_WG4_MAX_BATCH * (pmpc_internal_simd_count(ctx) / 4) / 256;
+        const bool want = e && e[0] ? (e[0] != '0') : (B <= 2 * per_cu);
+        if (eligible && want) {
+            lkern = (B <= per_cu) ? sqp_kernel<Model, 0, 0, false, 0, true, false, false, false, true> : sqp_kernel<Model, 0, 0, false, 0, true, true, false, false, true>;
+            threads = 4 * WAVE;
+        }
     }
     const bool team_kernel = threads != WAVE;
     if constexpr (LDS_PATH_PROFILED<Model>::value) {   // developer builds with phase timers

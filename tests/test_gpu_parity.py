@@ -1567,6 +1567,22 @@ def test_large_instance_team_kernel_bit_identical_to_the_one_wavefront_kernel(or
         xo, lo, io = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss,
                                             pivot=oracle.PIVOT_CONDENSED, threads=4)
         _assert_same_solve(i4, io, x4, xo, l4, lo)
+    # between one and two instances per CU (257 .. 512 on this device) a second build of the team kernel — compiled for 256 registers, two workgroups per CU —
+    # serves the batch by default: the same bits as one wavefront per instance
+    B = 300
+    wl = workloads.kite_standin_batch(B)
+    ss = pa.sqp_settings_default(); ss.max_iter = 3; ss.line_search_max_iter = wl["ls_max_iter"]
+    res = []
+    for wg4 in (None, "0"):
+        if wg4 is not None: monkeypatch.setenv("PMPC_BIG_WG4", wg4)
+        c = pa.Context(0)
+        try:
+            res.append(c.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss))
+        finally:
+            c.close()
+    monkeypatch.delenv("PMPC_BIG_WG4")
+    (x4, l4, i4), (x1, l1, i1) = res
+    assert _same_bits(x4, x1) and _same_bits(l4, l1) and _same_bits(i4, i1)
 
 
 def test_device_poisoning_changes_nothing(oracle):

@@ -33,6 +33,18 @@ template <int NKKT> constexpr int reg_qp_staging() {
     else return RegKkt2<NKKT>::TRI;
 }
 
+// the same for the CONDENSED register QP (pmpc_qp_cond.hpp) of NN variables, MM rows on NNODES nodes: its tile set's staging (the one-row-per-lane set up to 64
+// variables; beyond, RegKkt2<NN, PMPC_COND_NV> — NOT the (NN + MM)-row full inverse's, whose LDS-resident operand tiles the condensed kernel does not have) or
+// the exchange vectors + D~ tables that alias it, whichever is larger. (Until round 5 the condensed kernels were launched with the full inverse's staging: the
+// 16-node robot grid took 53.7 KB per instance — THREE workgroups per CU, a SIMD idle — where 33.6 KB do.)
+template <int NN, int MM, int NNODES> constexpr int cond_qp_staging() {
+    if constexpr (NN <= WAVE) return RegKkt<NN>::TRI;
+    else {
+        constexpr int a = RegKkt2<NN, PMPC_COND_NV>::TRI, b = CondDims<NN, MM>::TAB_OFF + CondDims<NN, MM>::template tab_doubles<NNODES>();
+        return a > b ? a : b;
+    }
+}
+
 // LDS doubles of the block-sparse copy of J the register-resident kernels keep (pmpc_jview.hpp): per node NX x NDER + NG x NDER
 template <class Model> __host__ __device__ inline size_t jview_doubles(int nnodes) {
     return (size_t)nnodes * (Model::NX + Model::NG) * OcpDims<Model>::JBS;
@@ -106,7 +118,7 @@ __global__ __launch_bounds__(WG4 ? 256 : 64, ((NN > 0 && NN + MM <= 64) ? PMPC_S
         p = v.carve(p, n, m, mi);
         stage0 = p;
         p = ocp.s.carve(p, P, S);
-        constexpr int QP_STAGING = (CND && NN <= WAVE) ? reg_qp_staging<(CND && NN <= WAVE) ? NN : 1>() : reg_qp_staging<NN + MM>();   // (condensed register QP on at most 64 variables: the one-row-per-lane tile set)
+        constexpr int QP_STAGING = []() constexpr { if constexpr (CND) return cond_qp_staging<NN, MM, NN / (Model::NX + Model::NU)>(); else return reg_qp_staging<NN + MM>(); }();   // (condensed register QP: its own tile set's staging)
         if (NN > 0 && (size_t)(p - stage0) < (size_t)QP_STAGING + 2 + ocp.s.const_doubles(P, S)) p = stage0 + QP_STAGING + 2 + ocp.s.const_doubles(P, S);
         stage_end = p;   // end of the per-node staging block: what follows (static parameters, filter) stays live during the line search
     }
@@ -216,15 +228,15 @@ __global__ __launch_bounds__(WG4 ? 256 : 64, ((NN > 0 && NN + MM <= 64) ? PMPC_S
 // the m x m Schur complement. One instantiation per (model, P, S): the segment structure is a compile-time constant of the sparse products.
 template <class Model, int PP, int SS> constexpr int schur_lds_doubles_ct() {
     using SD = SchurDims<Model, PP, SS>;
-    return SD::LDS_DOUBLES + SD::NNODES * SD::DD /*hblk*/ + (SD::NPAR ? 2 * SD::N : 0) /*hbrd*/ + SD::NNODES * SD::NX * SD::JBS /*jblk*/ + 4;
+    return SD::LDS_DOUBLES + SD::NNODES * SD::DD /*hblk*/ + (SD::NPAR ? 2 * SD::N : 0) /*hbrd*/ + SD::NNODES * SD::NX * SD::JBS /*jblk*/;
 }
-template <class Model, int PP, int SS> inline size_t sqp_schur_lds_bytes() {
+template <class Model, int PP, int SS> inline size_t sqp_schur_lds_bytes(bool pol = false) {   // (exactly what sqp_schur_kernel carves + 2: at 16 robot nodes 40 952 bytes — four instances per CU; 984 more were three)
     using SD = SchurDims<Model, PP, SS>;
     OcpDims<Model> dm(PP, SS);
     size_t stage = OcpLds<Model>::doubles(PP, SS);
     const size_t need = (size_t)RegKkt<SD::M>::TRI + OcpLds<Model>::const_doubles(PP, SS) + 8;
     if (stage < need) stage = need;
-    return (QpLds::doubles_xy(dm.n, dm.m) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8 + schur_lds_doubles_ct<Model, PP, SS>() + (Model::ND > 0 ? Model::ND : 1) + FILTER_LDS_DOUBLES) * sizeof(double);
+    return ((size_t)(2 * dm.n + dm.m) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + schur_lds_doubles_ct<Model, PP, SS>() + (Model::ND > 0 ? Model::ND : 1) + (pol ? FILTER_LDS_DOUBLES : 0) + 2) * sizeof(double);
 }
 template <class Model, int PP, int SS, bool PROF = false, bool POL = false>   // POL: with the filter line search (line_search = 1, LSFilter carried in LDS) — the hook of the reference's tests this kernel family carries
 __global__ __launch_bounds__(64, (SchurDims<Model, PP, SS>::N + SchurDims<Model, PP, SS>::M <= 64) ? PMPC_SQP_WAVES : 1)
@@ -251,7 +263,6 @@ void sqp_schur_kernel(Model model, const ChebData* __restrict__ cd, int B, const
     double* qblk = p; p += SD::NNODES * SD::DD;
     double* xsc = p; p += n + 1;
     double* dsc = p; p += m + 1;
-    double* pdl = p; p += n + 1;
     p += ((p - smem) & 1);   // the tables are read 16 bytes at a time
     double* dtab = p; p += SD::TAB;
     double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
@@ -273,7 +284,7 @@ void sqp_schur_kernel(Model model, const ChebData* __restrict__ cd, int B, const
     wsync();
     SqpDevice<Model, n, m, PROF, 1, false, POL, PP * 256 + SS> sqp(ocp, v, qw, nullptr, nullptr, ss, qs);
     sqp.filt = filt;
-    sqp.hblk = hblk; sqp.hbrd = hbrd; sqp.qblk = qblk; sqp.xsc = xsc; sqp.dsc = dsc; sqp.pdl = pdl; sqp.dtab = dtab;
+    sqp.hblk = hblk; sqp.hbrd = hbrd; sqp.qblk = qblk; sqp.xsc = xsc; sqp.dsc = dsc; sqp.dtab = dtab;
     schur_build_tables<Model, PP, SS>(ocp.s.D, dtab);
     sqp.trace = ss.iteration_trace ? ss.iteration_trace + (size_t)b * (size_t)ss.iteration_trace_capacity * PMPC_TRACE_DOUBLES : nullptr;
     sqp.tr = ocp.s.fval;
@@ -309,7 +320,7 @@ inline bool try_launch_schur(pmpc_context* ctx, const Model& mdl, const ChebData
     // block-structured one a chain of eight LDS exchanges and two mat-vecs (3.7 k cycles on config A) — measured 1.69 against 1.16 ms per 4096
     // config-A instances although the factorisation is three times cheaper. PMPC_SCHUR_SMALL=1: developer switch.
     if (SchurDims<Model, PP, SS>::N + SchurDims<Model, PP, SS>::M <= WAVE && !getenv("PMPC_SCHUR_SMALL")) return false;
-    const size_t lds = sqp_schur_lds_bytes<Model, PP, SS>();
+    const size_t lds = sqp_schur_lds_bytes<Model, PP, SS>(ss->line_search == 1);
     if (lds > lds_limit) return false;
     auto kern = sqp_schur_kernel<Model, PP, SS, false>;
     if constexpr (SchurDims<Model, PP, SS>::NPAR == 0) { if (phase) kern = sqp_schur_kernel<Model, PP, SS, true>; }   // (no phase-timer build of the bordered form: a developer switch already)
@@ -531,7 +542,7 @@ template <class Model> inline size_t sqp_eig_lds_bytes(int P, int S, const pmpc_
     OcpDims<Model> dm(P, S);
     return ss->regularisation == 1 ? 2 * (size_t)dm.n * dm.n * sizeof(double) : 0;
 }
-template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode, int qp_solver = 0, bool pol = false) {
+template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode, int qp_solver = 0, bool pol = false, size_t cnd_staging = 0) {   // mode 6: condensed register QP on more than 64 variables, staging = cnd_staging (cond_qp_staging)
     OcpDims<Model> dm(P, S);
     if (mode == 0 && qp_solver == 1)
         return (QpLds::doubles(dm.n, dm.m + dm.n) + SqpLds::doubles(dm.n, dm.m, dm.mi) + OcpLds<Model>::doubles(P, S) + 8 + FILTER_LDS_DOUBLES) * sizeof(double);
@@ -542,8 +553,9 @@ template <class Model> inline size_t sqp_kernel_lds_bytes(int P, int S, int mode
     if (mode == 3) { const size_t need = (size_t)RegKkt2<112>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
     if (mode == 5) { const size_t need = (size_t)RegKkt<64>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }   // condensed register QP on at most 64 variables (65..128 KKT rows)
     if (mode == 4) { const size_t need = (size_t)RegKkt2<128>::TRI + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }   // 113..128 rows: LDS-resident operand tiles
+    if (mode == 6) { const size_t need = cnd_staging + OcpLds<Model>::const_doubles(P, S) + 8; if (stage < need) stage = need; }
     return ((mode == 0 ? QpLds::doubles(dm.n, dm.m) : QpLds::doubles_xy(dm.n, dm.m)) + SqpLds::doubles(dm.n, dm.m, dm.mi) + stage + 8 +
-            ((mode == 1 || mode == 3 || mode == 4 || mode == 5) ? (mode == 1 ? 0 : jview_doubles<Model>(dm.NN)) + (pol ? FILTER_LDS_DOUBLES : 0) : FILTER_LDS_DOUBLES) + (mode == 2 ? BigKkt::LDS_DOUBLES : 0)) * sizeof(double);
+            ((mode == 1 || mode == 3 || mode == 4 || mode == 5 || mode == 6) ? (mode == 1 ? 0 : jview_doubles<Model>(dm.NN)) + (pol ? FILTER_LDS_DOUBLES : 0) : FILTER_LDS_DOUBLES) + (mode == 2 ? BigKkt::LDS_DOUBLES : 0)) * sizeof(double);
 }
 constexpr int BIG_WG4_MAX_BATCH = 256;   // instances (on a 256-CU device) up to which the four-wavefront team kernel serves a large-instance batch (see sqp_launch_dev; measured: one workgroup per CU — 256: 11.9 -> 9.9 ms, 512: 13.5 -> 19.2)
 constexpr int BIG_TWO_WAVES_MAX_ROWS = 200;   // below: two wavefronts per SIMD on the HBM-factor kernel when the batch exceeds the SIMD count (see sqp_launch_dev)
@@ -707,6 +719,7 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
         if constexpr (COND_REG_OK<Model, NN_, MM_>::value) {
             if (!pol && ss->kkt_form == 0 && !getenv("PMPC_NO_CONDREG")) {
                 if constexpr (NN_ <= WAVE) ldsq = sqp_kernel_lds_bytes<Model>(P, S, 5, 0, false);   // (two wavefronts per SIMD: a smaller staging lets more instances share a CU)
+                else ldsq = sqp_kernel_lds_bytes<Model>(P, S, 6, 0, false, (size_t)cond_qp_staging<NN_, MM_, NNODES>());   // (its own tile set's staging, not the full inverse's: four instead of three instances per CU on the 16-node grid)
                 kern = sqp_kernel<Model, NN_, MM_, false, 0, false, false, false, true>; timed = false;
                 if constexpr (LDS_PATH_PROFILED<Model>::value && !LEAN) { if (phase) { kern = sqp_kernel<Model, NN_, MM_, true, 0, false, false, false, true>; timed = true; } }
                 pmpc_internal_set_route(ctx, PMPC_ROUTE_CONDREG);
@@ -718,6 +731,7 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
             if constexpr (POLK) {   // (round 5: also the one-row-per-lane tile set — its hook build was miscompiled by the never-executed Ruiz calls, which the condensed kernels no longer carry, pmpc_sqp.hpp RUIZ_COMPILED)
                 if (pol && ss->preconditioner == 0 && ss->kkt_form == 0 && !getenv("PMPC_NO_CONDREG")) {
                     kern = sqp_kernel<Model, NN_, MM_, false, 0, false, false, true, true>; timed = false;
+                    if constexpr (NN_ > WAVE) ldsq = sqp_kernel_lds_bytes<Model>(P, S, 6, 0, true, (size_t)cond_qp_staging<NN_, MM_, NNODES>());
                     pmpc_internal_set_route(ctx, PMPC_ROUTE_CONDREG);
                 }
             }

@@ -51,8 +51,8 @@ struct SchurDims {
     // D~ as two dense tables in LDS, built once per kernel (schur_build_tables): Dt[r NNP + k] = D~(r, k) — the differentiation-matrix entry of
     // equality row node r on column node k, 0 on the own node (its entry lives in the node block) and outside the row's segment — and its transpose
     // DtT[k NNP + r] followed by one all-zero row (read by the control columns). Rows are contiguous: 16-byte reads.
-    // LDS doubles the solver needs beside the staging of RegKkt<M>: Q blocks, one primal and one dual exchange vector, the KKT diagonal, the tables
-    static constexpr int LDS_DOUBLES = NNODES * DD + (N + 1) + (M + 1) + (N + 1) + TAB + 2;
+    // LDS doubles the solver needs beside the staging of RegKkt<M>: Q blocks, one primal and one dual exchange vector, the tables
+    static constexpr int LDS_DOUBLES = NNODES * DD + (N + 1) + (M + 1) + TAB + 1;   // (round 5: the KKT diagonal lives in a register per primal slot and visits the primal exchange vector for the factorisation — 81 doubles less on the 16-node grid, whose instance then fits a quarter of a CU's LDS)
 };
 
 // boxADMM::solve_impl (7-argument form: zero guesses, box_admm.hpp:81-86) on the block structure. hblk: [k][c' * D + c] = H(g(k, c), g(k, c')), the
@@ -85,14 +85,14 @@ __device__ __forceinline__ void schur_build_tables(const double* Dm, double* Dt)
 // boxADMM::solve_impl (7-argument form: zero guesses, box_admm.hpp:81-86) on the block structure. hblk: [k][c' * D + c] = H(g(k, c), g(k, c')), the
 // node blocks of H column-major (LOWER triangle read for the KKT matrix, as Eigen::LDLT does; the full block for H x); jblk: [(k NX + q) D + c] =
 // J(k NX + q, g(k, c)); Dm: OcpLds::D; nsr: the node table of Ocp::stage_constants (pmpc_jview.hpp reads it); h / bounds: LDS vectors.
-// tr: RegKkt<M>::TRI doubles of staging; qblk / xsc / dsc / pdl: NNODES D^2 / N + 1 / M + 1 / N + 1 doubles of LDS that live through the solve;
+// tr: RegKkt<M>::TRI doubles of staging; qblk / xsc / dsc: NNODES D^2 / N + 1 / M + 1 doubles of LDS that live through the solve;
 // Dt: the tables of schur_build_tables. hbrd (NP = 1): [H(p, 0..N0-1), H(p, p) | H(0..N0-1, p)] — the border row with the corner, then the border column
 // (the KKT matrix reads the row: lower triangle; H x reads both).
 template <class Model, int PP, int SS>
 __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const double* hbrd, const double* h, const double* jblk, const double* Dm, const int* nsr,
                                                     const double* Alb, const double* Aub, const double* xlb, const double* xub,
                                                     const pmpc_qp_settings& s, pmpc_qp_info& info, double* out_x, double* out_y, double* tr,
-                                                    double* qblk, double* xsc, double* dsc, double* pdl, const double* Dt, long long* dbg = nullptr,
+                                                    double* qblk, double* xsc, double* dsc, const double* Dt, long long* dbg = nullptr,
                                                     long long* tm = nullptr) {
     using SD = SchurDims<Model, PP, SS>;
     constexpr int NX = SD::NX, NU = SD::NU, D = SD::D, DD = SD::DD, NNODES = SD::NNODES, N = SD::N, N0 = SD::N0, NPAR = SD::NPAR, M = SD::M, VARX = SD::VARX, SLOTS = SD::SLOTS, NNP = SD::NNP, NNR = SD::NNR;
@@ -100,7 +100,7 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
     const long long tp0 = dbg ? clock64() : 0;
     // ---- lane roles -------------------------------------------------------------------------------------------------------------------------
     // primal slot e: entry g = lane + 64 e of [x_0 .. x_{nn-1} | u_0 .. u_{nn-1}] = (node k, block position c); clamped duplicates beyond n.
-    // Stores of a lane without an entry go to a dummy slot behind the vector (xsc[N], dsc[M], pdl[N]) instead of through a divergent branch: VGPR
+    // Stores of a lane without an entry go to a dummy slot behind the vector (xsc[N], dsc[M]) instead of through a divergent branch: VGPR
     // spills inside partial-EXEC regions lose the inactive lanes' copies (DESIGN.md compiler hazard 3). The index arithmetic is a function of the
     // lane id alone; the blocks that need more of it than the ADMM loop (factorisation, residuals) re-derive it there (`roles`) instead of keeping a
     // dozen integers alive through the loop.
@@ -126,6 +126,7 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
 
     // ---- per-lane problem data that the ADMM loop keeps in registers ---------------------------------------------------------------------------
     double hv[SLOTS], lo[SLOTS], hi[SLOTS], rhob[SLOTS], rhobinv[SLOTS]; int typ[SLOTS];
+    double kdv[SLOTS];                      // diagonal of P = H + sigma I + rho_box per primal slot (construct_kkt_matrix / update_kkt_rho: carried, updated incrementally)
     double colb[SLOTS][NX];                 // column g of A inside its own node's rows
     double qz[SLOTS], qnu = 0.0, delta = 1.0; bool ispE[SLOTS];   // NP = 1: K0^{-1} w, the pivot of the border
     // the border itself — H(p, g) per primal slot (0 on the parameter's lanes) and the parameter's column of A on this row (0 beyond the rows) — is re-read from LDS
@@ -144,7 +145,7 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
         ispE[e] = r.isp; qz[e] = 0.0;
         if constexpr (NPAR > 0) { const double kc = hbrd[N0]; kd = r.isp ? kc : kd; }
         kd += s.sigma; kd += rhob[e];   // construct_kkt_matrix, box_admm.hpp:214-216
-        pdl[r.px] = kd;
+        kdv[e] = kd;
 #pragma unroll
         for (int q = 0; q < NX; ++q) { const double cb = jblk[(r.k * NX + q) * SD::JBS + r.c]; colb[e][q] = r.isp ? 0.0 : cb; }
         xo[e] = xsc + r.xb; uo[e] = xsc + r.ub; xst[e] = xsc + r.px;
@@ -273,7 +274,12 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
             // opaque zero on the LDS bases of this block: its reads (node blocks, differentiation matrix) are invariant across the factorisation loop and
             // would otherwise be hoisted in front of it and kept — or spilled — through every ADMM iteration (DESIGN.md compiler hazard 1)
             int zf = 0; asm volatile("" : "+v"(zf));
-            const double* hbF = hblk + zf; const double* jbF = jblk + zf; const double* DmF = Dm + zf; double* qbF = qblk + zf; const double* pdF = pdl + zf;
+            const double* hbF = hblk + zf; const double* jbF = jblk + zf; const double* DmF = Dm + zf; double* qbF = qblk + zf; const double* pdF = xsc + zf;
+            // the KKT diagonal visits the primal exchange vector (free between ADMM iterations): the per-node inverses read it across lanes
+#pragma unroll
+            for (int e = 0; e < SLOTS; ++e) *xst[e] = kdv[e];
+            lds_order();
+            const double pi_border = NPAR > 0 ? pdF[NPAR > 0 ? N0 : 0] : 0.0;   // (read before the border's inner solve reuses the vector)
             const double* DtF = Dt + zf;
             {   // one lane per node (clamped duplicates beyond the last node compute and store the last node's block again)
                 const int k = ln < NNODES ? ln : NNODES - 1;
@@ -390,7 +396,7 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
                 for (int e = 0; e < SLOTS; ++e) { sq[e] = ispE[e] ? 0.0 : sq[e]; part = fma(bz[e], sq[e], part); }
                 nq = isC ? nq : 0.0;
                 part = fma(ap, nq, part);
-                delta = pdF[N0] - wave_sum(part);
+                delta = pi_border - wave_sum(part);
 #pragma unroll
                 for (int e = 0; e < SLOTS; ++e) qz[e] = ispE[e] ? -1.0 : sq[e];   // (z - p q_z leaves p itself on the parameter's lane)
                 qnu = nq;
@@ -503,7 +509,7 @@ __device__ __forceinline__ void boxadmm_solve_schur(const double* hblk, const do
                         const Role r = role(e);
                         const double prev = rhob[e];
                         rhob[e] = rho_of(typ[e], rho); rhobinv[e] = 1.0 / rhob[e];
-                        pdl[r.px] = pdl[r.px] + (rhob[e] - prev);
+                        kdv[e] = kdv[e] + (rhob[e] - prev);
                     }
                     rhoA = rho_of(typA, rho); rinvA = 1.0 / rhoA;
                     ++rho_updates;

@@ -81,7 +81,7 @@ struct SqpDevice {
 #endif
     static constexpr bool REG1 = !SCH && NN > 0 && NN + MM <= WAVE;    // one KKT row per lane
     static constexpr bool REG2 = !SCH && NN > 0 && NN + MM > WAVE;     // two KKT rows per lane
-    double *hblk = nullptr, *hbrd = nullptr /* NP = 1: border row + corner, border column (pmpc_qp_schur.hpp) */, *qblk = nullptr, *xsc = nullptr, *dsc = nullptr, *pdl = nullptr, *dtab = nullptr;   // SCH: Hessian blocks, Q blocks, the exchange vectors, the KKT diagonal and the D~ tables of the QP (LDS)
+    double *hblk = nullptr, *hbrd = nullptr /* NP = 1: border row + corner, border column (pmpc_qp_schur.hpp) */, *qblk = nullptr, *xsc = nullptr, *dsc = nullptr, *dtab = nullptr;   // SCH: Hessian blocks, Q blocks, the exchange vectors and the D~ tables of the QP (LDS)
     static constexpr int MEMCH = BIG ? BIG_MEM_BATCH : 8;      // loads in flight per lane in the row walks over the BFGS matrix in HBM
     Ocp<Model>& ocp;
     SqpLds& v;
@@ -1004,7 +1004,7 @@ struct SqpDevice {
         }
         // 7-argument form: zero guesses (Q2)
         if constexpr (SCH) {
-            boxadmm_solve_schur<Model, SCH_P, SCH_S>(hblk, hbrd, v.h, ocp.jblk, ocp.s.D, ocp.s.nsr, v.al, v.au, v.lx, v.ux, qs, qi, qw.x, qw.y, tr, qblk, xsc, dsc, pdl, dtab,
+            boxadmm_solve_schur<Model, SCH_P, SCH_S>(hblk, hbrd, v.h, ocp.jblk, ocp.s.D, ocp.s.nsr, v.al, v.au, v.lx, v.ux, qs, qi, qw.x, qw.y, tr, qblk, xsc, dsc, dtab,
                                                      PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr);
             wsync();
         } else if constexpr (CND) {

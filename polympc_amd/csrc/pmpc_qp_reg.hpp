@@ -29,23 +29,6 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
 }
-// c <- fma(-a, x, c) on the lanes ABOVE `j` only (x wave-uniform, in SGPRs). The lane mask is a compile-time constant, so
-// it is applied with one scalar shift into EXEC instead of a compare + two selects; EXEC is restored inside the statement
-// (the compiler never sees a modified EXEC; SCC, which the scalar shift overwrites, is declared clobbered). s_nop 0 completes the v_readlane(SGPR write) -> VALU(SGPR read) wait states.
-__device__ __forceinline__ double fnma_lanes_above(double c, double a, double x_uniform, int j) {
-    asm("s_lshl_b64 exec, -1, %3\n\ts_nop 0\n\tv_fma_f64 %0, -%1, %2, %0\n\ts_mov_b64 exec, -1" : "+v"(c) : "v"(a), "s"(x_uniform), "i"(j + 1) : "scc");
-    return c;
-}
-__device__ __forceinline__ double fnma_lanes_below(double c, double a, double x_uniform, int j) {
-    asm("s_lshr_b64 exec, -1, %3\n\ts_nop 0\n\tv_fma_f64 %0, -%1, %2, %0\n\ts_mov_b64 exec, -1" : "+v"(c) : "v"(a), "s"(x_uniform), "i"(64 - j) : "scc");
-    return c;
-}
-// dst <- src on the lanes BELOW `j` only
-__device__ __forceinline__ double mov_lanes_below(double dst, double src, int j) {
-    asm("s_lshr_b64 exec, -1, %2\n\tv_mov_b64 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(dst) : "v"(src), "i"(64 - j) : "scc");
-    return dst;
-}
-
 // One wavefront per workgroup: DS operations of a wave are executed in issue order, so a write followed by a read of the
 // same LDS address needs no s_waitcnt / s_barrier — only the compiler must not reorder them.
 __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
@@ -53,13 +36,18 @@ __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
 // across phase boundaries, which otherwise inflates the register demand far beyond the algorithm's live set
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
-// dst <- src on lanes [lo, hi) only (compile-time range, hi > lo)
-__device__ __forceinline__ double mov_lanes_range(double dst, double src, int lo, int hi) {
-    asm("s_bfm_b64 exec, %2, %3\n\tv_mov_b64 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(dst) : "v"(src), "i"(hi - lo), "i"(lo));
-    return dst;
-}
-
-// a0..a6 <- 0 and l <- lk on lane `k` only (compile-time k): one EXEC switch for the eight moves
+// a0..a6 <- 0 and l <- lk on lane `k` only (compile-time k): one EXEC switch for the eight moves.
+// The statement narrows EXEC to one lane and restores it to the CONSTANT all-ones, with EXEC not in the clobber list: sound exactly where the statement is
+// emitted with every lane enabled. That is a property of the BUILT code, and it is checked there: tests/tools_exec_regions.py follows EXEC (and every saved
+// copy of it, through SGPR spill lanes too) over the control-flow graph of each shipped kernel and proves that every one of these bodies starts at full EXEC
+// (tests/test_kernel_occupancy_cpu.py). Round 6 examined it as the suspect behind round 5's miscompiled hook build (EXPERIMENTS.md): refuted — in that build
+// too every body starts at full EXEC, and the fault is identical with each of the forms below (it is a VGPR -> AGPR live-range split of the lane id that the
+// compiler placed inside the else-block of a divergent if / else: the same test now checks the built code for that pattern as well).
+// PMPC_PIVOT_SETUP_FORM (developer switch of that experiment): 0 the shipped form; 1 the same as `asm volatile`; 2 EXEC saved in an SGPR pair and restored
+// from it (correct under any EXEC); 3 no EXEC write at all: v_cndmask selects on lane == k.
+#ifndef PMPC_PIVOT_SETUP_FORM
+#define PMPC_PIVOT_SETUP_FORM 0
+#endif
 __device__ __forceinline__ void pivot_lane_setup(double& a0, double& a1, double& a2, double& a3, double& a4, double& a5, double& a6, double& l,
                                                  double lk, int k) {
     asm("s_lshl_b64 exec, 1, %9\n\tv_mov_b64 %0, 0\n\tv_mov_b64 %1, 0\n\tv_mov_b64 %2, 0\n\tv_mov_b64 %3, 0\n\tv_mov_b64 %4, 0\n\tv_mov_b64 %5, 0\n\t"
@@ -67,8 +55,20 @@ __device__ __forceinline__ void pivot_lane_setup(double& a0, double& a1, double&
         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(l) : "v"(lk), "i"(k) : "scc");
 }
 __device__ __forceinline__ void pivot_lane_setup(double& a0, double& a1, double& a2, double& l, double lk, int k) {
+#if PMPC_PIVOT_SETUP_FORM == 1
+    asm volatile("s_lshl_b64 exec, 1, %5\n\tv_mov_b64 %0, 0\n\tv_mov_b64 %1, 0\n\tv_mov_b64 %2, 0\n\tv_mov_b64 %3, %4\n\ts_mov_b64 exec, -1"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(l) : "v"(lk), "i"(k) : "scc");
+#elif PMPC_PIVOT_SETUP_FORM == 2
+    unsigned long long saved, win;
+    asm volatile("s_mov_b64 %4, exec\n\ts_lshl_b64 %5, 1, %7\n\ts_and_b64 exec, %4, %5\n\tv_mov_b64 %0, 0\n\tv_mov_b64 %1, 0\n\tv_mov_b64 %2, 0\n\tv_mov_b64 %3, %6\n\ts_mov_b64 exec, %4"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(l), "=&s"(saved), "=&s"(win) : "v"(lk), "i"(k) : "scc");
+#elif PMPC_PIVOT_SETUP_FORM == 3
+    const bool me = lane_id() == k;
+    a0 = me ? 0.0 : a0; a1 = me ? 0.0 : a1; a2 = me ? 0.0 : a2; l = me ? lk : l;
+#else
     asm("s_lshl_b64 exec, 1, %5\n\tv_mov_b64 %0, 0\n\tv_mov_b64 %1, 0\n\tv_mov_b64 %2, 0\n\tv_mov_b64 %3, %4\n\ts_mov_b64 exec, -1"
         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(l) : "v"(lk), "i"(k) : "scc");
+#endif
 }
 // 1 / d, branch-free: the generic IEEE division expansion (v_rcp_f64, two Newton steps, residual correction, v_div_fixup for
 // 0 / inf / NaN) WITHOUT its v_div_scale pre-scaling — 8 VALU operations instead of 12. The pre-scaling only matters when d or

@@ -73,12 +73,24 @@ typedef struct {
     double rho_estimate, res_prim, res_dual;
 } pmpc_qp_info;
 #define PMPC_FLAG_NONFINITE 1
-/* PMPC_FLAG_ILLCOND: information, not an error. The kernels that eliminate boxADMM's diagonal constraint block first (the defaults: they invert / factorise
- * S = H + sigma I + rho_box + A' diag(rho) A instead of the (n + m)-row KKT matrix of box_admm.hpp:209-223) estimate cond(S) at every factorisation
- * (largest diagonal entry / smallest pivot). While the directions A leaves free are bounded variables that estimate stays ~1e5 whatever rho is, and these
+/* PMPC_FLAG_ILLCOND: information, not an error — "this QP / instance was solved in the full KKT form". The default kernels eliminate boxADMM's diagonal
+ * constraint block first: they invert / factorise S = H + sigma I + rho_box + A' diag(rho) A (or, block-structured kernel, 1/rho + A Q A') instead of the
+ * (n + m)-row KKT matrix of box_admm.hpp:209-223. While the directions A leaves free are BOUNDED variables cond(S) stays ~1e5 whatever rho is and these
  * kernels follow the exact-arithmetic ADMM more closely than the reference's pivoted LDL^T does; when unbounded variables span them it grows with rho.
- * Beyond 1e10 the QP (one-row-per-lane kernels: from that factorisation on) or the whole instance (the other kernels: a second launch) is solved in the
- * full KKT form, and this bit says so. pmpc_sqp_settings::kkt_form = 1 asks for the full form from the start. */
+ * Three mechanisms hand such work to a full-form solve, each restated rule for rule by the CPU checker; all RESTART from the guesses (the QP from x0 / y0,
+ * the SQP instance from x_guess / lam_guess — nothing of the abandoned attempt is used):
+ *   (1) bounds rule — fused SQP kernels with a register-resident QP (one KKT row per lane; condensed register kernel): decided ONCE per instance, BEFORE
+ *       any work, from its bounds: a control or parameter that is unbounded on both sides (|bound| > 1e10, qp_base.hpp:195-222) sends the instance to the
+ *       redo launch (LDS-resident static LDL^T resp. the two-rows-per-lane full inverse). These kernels do NOT estimate cond(S) (a numeric gate cost them
+ *       4 .. 10 %); a batch whose controls are all free is therefore solved entirely by the redo kernel, at that kernel's (lower) speed.
+ *   (2) numeric gate, 1e10 — the QP entry point's one-row-per-lane kernels (max S_ii * max |(S^-1)_ii| off the swept tiles) and the large-instance kernel
+ *       in its condensed mode (max S_ii / min |d_k| of its LDL^T), at every factorisation: beyond 1e10 the QP (entry point: re-solved by the LDS-resident
+ *       kernel) resp. the instance (redo launch of the same kernel with kkt_form = 1) is given up.
+ *   (3) numeric gate, 1e7 (PMPC_SCHUR_COND_GATE) — the block-structured kernel, whose range-space solve loses accuracy like that estimate SQUARED: the
+ *       instance is re-solved by the LDS-resident static LDL^T.
+ * pmpc_sqp_last_route reports the kernel family of the PRIMARY launch, also for instances that were re-solved. A developer's PMPC_NO_REDO_LAUNCH=1 (timing
+ * only) skips the second launch: instances that gave up then keep status 4 (internal: "redo") with x / lam equal to their guesses.
+ * pmpc_sqp_settings::kkt_form = 1 asks for the full form from the start. */
 #define PMPC_FLAG_ILLCOND 2
 
 /* sqp_settings_t (sqp_base.hpp:24-47) + the two override points the reference's tests use:
@@ -118,8 +130,12 @@ typedef struct {
     int iteration_trace_capacity; /* records per instance (ignored when iteration_trace is NULL) */
     int kkt_form;         /* large instances (KKT factor in HBM): 0 (default) condensed — the diagonal constraint block of the KKT matrix is eliminated in
                            * closed form and the n x n matrix H + sigma I + rho_box + A' diag(rho) A is factorised (same solution in exact arithmetic,
-                           * box_admm.hpp:209-223 / :123 restated as PIVOT_CONDENSED); 1 the (n+m) x (n+m) KKT matrix as the reference builds it.
-                           * Ignored by the register- and LDS-resident kernels. (Occupies former tail padding: the struct size is unchanged.) */
+                           * box_admm.hpp:209-223 / :123 restated as PIVOT_CONDENSED); 1 the (n+m) x (n+m) KKT matrix as the reference builds it
+                           * (register kernels: the full inverse instead of the condensed / constraint-first forms; never a conditioning gate);
+                           * 2 (round 6) the block-structured range-space form wherever a specialisation is compiled, INCLUDING the grids on which
+                           * it is not the default because their instances are expected to meet its conditioning gate (parking, NP = 1, 11 nodes:
+                           * the bordered form — such instances are re-solved by the redo launch, see PMPC_FLAG_ILLCOND); elsewhere the same as 0.
+                           * (Occupies former tail padding: the struct size is unchanged.) */
 } pmpc_sqp_settings;
 #define PMPC_FILTER_MAX_DEPTH 10
 #define PMPC_FILTER_STATE_DOUBLES (1 + 2 * PMPC_FILTER_MAX_DEPTH)

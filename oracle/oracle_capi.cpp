@@ -86,6 +86,7 @@ static void qp_solve_batch_f32_impl(int B, int n, int m, const float* H, const f
 
 extern "C" {
 
+int orc_set_hx_identity(int on) { const int old = oracle::BoxADMM::hx_identity(); oracle::BoxADMM::hx_identity() = on; return old; }
 int orc_set_libm(int use_libm) { const int old = oracle::use_libm() ? 1 : 0; oracle::use_libm() = use_libm != 0; return old; }
 void orc_math_eval(int kind, int impl, int count, const double* x, double* y) {
     for (int i = 0; i < count; ++i) {

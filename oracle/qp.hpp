@@ -388,11 +388,21 @@ struct BoxADMM {
         for (int j = 0; j < cols; ++j) { double a = 0; for (int i = 0; i < rows; ++i) a += A[i + j * rows] * v[i]; out[j] = a; }
     }
 
+    // EXPERIMENT (round 6, VERDICT r5 item 1c — measured and NOT adopted, EXPERIMENTS.md): H x of the dual residual from the KKT identity
+    //   (H + sigma I + rho_box) x~ + A' nu = rhs_1   =>   H x~ = rhs_1 - (sigma + rho_box) o x~ - A' nu        (alpha = 1: x = x~)
+    // instead of a second mat-vec with H. hx_identity() is a process-wide test switch (orc_set_hx_identity); last_rhs / last_sol are the operands of the last solve.
+    static int& hx_identity() { static int v = 0; return v; }
+    std::vector<double> last_rhs, last_sol;
     void residuals_update(const double* H, const double* h, const double* A) {  // :398-415
         std::vector<double> Ax(M), Hx(N), ATy(N);
         matvec(A, M, N, x.data(), Ax.data());
         const double norm_Ax = inf_norm(Ax.data(), M), norm_z = inf_norm(z.data(), M);
         max_Ax_z_norm = std::fmax(norm_Ax, std::fmax(norm_z, inf_norm(x.data(), N)));
+        if (hx_identity() && settings.alpha == 1.0 && (int)last_sol.size() == N + M) {
+            std::vector<double> ATnu(N);
+            matTvec(A, M, N, last_sol.data() + N, ATnu.data());
+            for (int i = 0; i < N; ++i) Hx[i] = (last_rhs[i] - (settings.sigma + rho_box[i]) * x[i]) - ATnu[i];
+        } else
         matvec(H, N, N, x.data(), Hx.data());
         matTvec(A, M, N, y.data(), ATy.data());
         const double norm_Hx = inf_norm(Hx.data(), N), norm_ATy = inf_norm(ATy.data(), N);
@@ -782,6 +792,7 @@ struct BoxADMM {
             for (int i = 0; i < N; ++i) rhs[i] = ((settings.sigma * x[i] - h[i]) + rho_box[i] * q[i]) - y[M + i];
             for (int i = 0; i < M; ++i) rhs[N + i] = z[i] - rho_inv_vec[i] * y[i];
             kkt_solve(rhs.data(), sol.data());
+            if (hx_identity()) { last_rhs = rhs; last_sol = sol; }
             for (int i = 0; i < N; ++i) x_tilde[i] = sol[i];
             for (int i = 0; i < M; ++i) z_tilde[i] = z_prev[i] + rho_inv_vec[i] * (sol[N + i] - y[i]);
             // quirk Q1 (:129-130): x = alpha*x_tilde; x += (1-alpha)*x

@@ -122,6 +122,7 @@ extern "C" pmpc_status pmpc_internal_services(pmpc_context* ctx, int P, int S, d
 extern "C" int pmpc_internal_sqp_slice(pmpc_context* ctx) { return ctx ? ctx->sqp_slice : 0; }
 extern "C" int pmpc_internal_sqp_rr(pmpc_context* ctx) { return ctx ? ctx->sqp_rr : 0; }
 extern "C" int pmpc_internal_simd_count(pmpc_context* ctx) { return ctx ? ctx->simd_count : 1024; }
+extern "C" int pmpc_internal_switch(pmpc_context* ctx, int which) { return ctx ? (int)((ctx->dev_switches >> which) & 1u) : 0; }
 extern "C" void pmpc_internal_set_route(pmpc_context* ctx, int route) { if (ctx) ctx->last_route = route; }
 extern "C" int pmpc_internal_last_route(pmpc_context* ctx) { return ctx ? ctx->last_route : 0; }
 
@@ -191,6 +192,15 @@ static pmpc_status create_impl(int device, void* stream, pmpc_context* ctx) {
     { const char* e = getenv("PMPC_FORCE_LDS_PATH"); ctx->force_lds_path = (e && e[0] == '1'); }
     { const char* e = getenv("PMPC_SQP_SLICE"); if (e && e[0]) ctx->sqp_slice = atoi(e) < 0 ? 0 : atoi(e); }
     { const char* e = getenv("PMPC_SQP_RR"); if (e && e[0]) ctx->sqp_rr = atoi(e) != 0 ? 1 : 0; }
+    {   // the launcher's developer switches (pmpc_launch.hpp: pmpc_dev_switch), read once per context
+        ctx->dev_switches = 0;
+        if (getenv("PMPC_NO_REDO_LAUNCH")) ctx->dev_switches |= 1u << PMPC_SW_NO_REDO_LAUNCH;
+        if (getenv("PMPC_NO_CONDREG")) ctx->dev_switches |= 1u << PMPC_SW_NO_CONDREG;
+        if (getenv("PMPC_NO_SCHUR")) ctx->dev_switches |= 1u << PMPC_SW_NO_SCHUR;
+        if (getenv("PMPC_SCHUR_SMALL")) ctx->dev_switches |= 1u << PMPC_SW_SCHUR_SMALL;
+        const char* e = getenv("PMPC_BIG_WG4");
+        if (e && e[0]) ctx->dev_switches |= (e[0] != '0') ? (1u << PMPC_SW_BIG_WG4_ON) : (1u << PMPC_SW_BIG_WG4_OFF);
+    }
     { const char* e = getenv("PMPC_PHASE_PROFILE");
       if (e && e[0] == '1') { HIPCHK(hipMalloc((void**)&ctx->phase_cycles, 24 * sizeof(unsigned long long))); HIPCHK(hipMemset(ctx->phase_cycles, 0, 24 * sizeof(unsigned long long))); } }
     return PMPC_OK;
@@ -324,7 +334,7 @@ pmpc_status pmpc_qp_boxadmm_solve_batch_dev(pmpc_context* ctx, int B, int n, int
                            *settings, x, y, info);                                                                                           \
         /* redo launch: the QPs that gave up at the conditioning gate of the constraint-first sweep, on the LDS-resident static LDL^T */          \
         const size_t ldsg_ = qp_kernel_lds_bytes(n, m);                                                                                      \
-        if (ldsg_ <= ctx->lds_limit && !getenv("PMPC_NO_REDO_LAUNCH")) {                                                                     \
+        if (ldsg_ <= ctx->lds_limit && !pmpc_internal_switch(ctx, PMPC_SW_NO_REDO_LAUNCH)) {                                                                 \
             HIPCHK(hipFuncSetAttribute((const void*)qp_boxadmm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg_));             \
             hipLaunchKernelGGL(qp_boxadmm_kernel, dim3((B + WAVE - 1) / WAVE), dim3(WAVE), ldsg_, ctx->stream, B, n, m, H, h, A, Alb, Aub, xlb, xub, x0, y0, \
                                *settings, x, y, info, 1);                                                                                    \
@@ -532,7 +542,7 @@ static pmpc_status check_sqp_args(int model, int P, int S, const double* d, cons
     if (nd > 0 && !d) return PMPC_ERR_INVALID_ARGUMENT;
     if (ss && ss->max_iter < 1) return PMPC_ERR_INVALID_ARGUMENT;
     if (ss && ss->iteration_trace && ss->iteration_trace_capacity < 1) return PMPC_ERR_INVALID_ARGUMENT;
-    if (ss && ss->kkt_form != 0 && ss->kkt_form != 1) return PMPC_ERR_INVALID_ARGUMENT;
+    if (ss && (ss->kkt_form < 0 || ss->kkt_form > 2)) return PMPC_ERR_INVALID_ARGUMENT;
     return PMPC_OK;
 }
 

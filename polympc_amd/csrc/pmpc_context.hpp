@@ -70,6 +70,8 @@ struct pmpc_context {
                                    // file with signalling NaNs before each launch (pmpc_poison.hip) — an uninitialised read returns NaN, not a plausible stale value
     size_t lds_limit_device = 64 * 1024;   // the device's opt-in maximum of dynamic LDS per workgroup (lds_limit may be lowered by PMPC_LDS_LIMIT)
     bool force_lds_path = false;   // PMPC_FORCE_LDS_PATH=1: disable the register-resident specialisations (A/B testing)
+    unsigned dev_switches = 0;     // the launcher's developer switches (PMPC_NO_REDO_LAUNCH, PMPC_NO_CONDREG, PMPC_NO_SCHUR, PMPC_SCHUR_SMALL, PMPC_BIG_WG4), read ONCE at pmpc_create:
+                                   // no getenv on the launch path (ShardWorker threads would race a host program's setenv), see pmpc_internal_switch
     std::map<std::tuple<int, int, double, double>, ChebData*> cheb_cache;
     double* ws = nullptr; size_t ws_bytes = 0;       // SQP HBM workspace (H, J)
     void* scratch[24] = {nullptr}; size_t scratch_bytes[24] = {0};  // host-buffer API staging

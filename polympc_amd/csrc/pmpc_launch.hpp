@@ -20,6 +20,10 @@ extern "C" int pmpc_internal_sqp_slice(pmpc_context* ctx);   // SQP iterations p
 extern "C" int pmpc_internal_sqp_rr(pmpc_context* ctx);      // 1 (PMPC_SQP_RR=1, developer switch): batches beyond the resident wavefronts run one SQP iteration per work item (sqp_kernel_rr)
 extern "C" void pmpc_internal_set_route(pmpc_context* ctx, int route);   // records the kernel family of the launch (pmpc_sqp_last_route)
 extern "C" int pmpc_internal_last_route(pmpc_context* ctx);
+// developer switches of the launcher, read from the environment ONCE per context (pmpc_create): PMPC_NO_REDO_LAUNCH (timing the redo launches), PMPC_NO_CONDREG,
+// PMPC_NO_SCHUR (keep the dense kernels), PMPC_SCHUR_SMALL (block-structured kernel on at most 64 KKT rows), PMPC_BIG_WG4 = 0 / 1 (team kernel never / whenever eligible)
+enum { PMPC_SW_NO_REDO_LAUNCH = 0, PMPC_SW_NO_CONDREG = 1, PMPC_SW_NO_SCHUR = 2, PMPC_SW_SCHUR_SMALL = 3, PMPC_SW_BIG_WG4_ON = 4, PMPC_SW_BIG_WG4_OFF = 5 };
+extern "C" int pmpc_internal_switch(pmpc_context* ctx, int which);
 
 namespace pmpc {
 using ::pmpc_status;
@@ -149,9 +153,21 @@ __global__ __launch_bounds__(WG4 ? 256 : 64, ((NN > 0 && NN + MM <= 64) ? PMPC_S
         if constexpr (Model::NG == 0 && Model::NP == 0) { if (JViewRT<Model>::tab_worth_it(ocp.dm.NN)) JViewRT<Model>::build_tables(ocp.Dlds, P, ocp.dm.NN, ocp.jtab); }
     }
     double* sst = slice_state ? slice_state + (size_t)b * 2 * n : nullptr;   // [previous Lagrangian gradient | previous step]
+    // Conditioning rule of the register-resident kernels that eliminate the constraint block first (PMPC_FLAG_ILLCOND, include/polympc_amd.h), decided per instance
+    // from its BOUNDS and BEFORE any work (round 6; ADVICE r5: the one-row-per-lane kernels used to test behind the solve and throw a finished solve away): these
+    // kernels invert S = P + A' diag(rho) A (constraint-first sweep / condensed form), whose condition number rho_eq |A|^2 / lambda_min(P on null A) stays ~1e5
+    // whatever rho is as long as the directions the collocation Jacobian leaves free — the controls and parameters — are BOUNDED (rho_box scales with rho), and
+    // grows with rho when one of them is not (rho_box = RHO_MIN). Such an instance is handed to the redo launch (full KKT form) untouched. The test rides on the
+    // loop that loads the bounds — two compares on values that are in registers anyway; round 5's separate loop over the LDS copies (130 instructions) cost the
+    // bench kernel 2 % in front of the solve. A numeric gate at every factorisation — what the large-instance kernel and the QP entry point use — cost these
+    // kernels 4 .. 10 % through register pressure alone (EXPERIMENTS.md round 5).
+    constexpr bool BOUNDS_RULE = NN > 0 && (CND || NN + MM <= WAVE);
+    bool loose = false;
     for (int i = ln; i < n; i += WAVE) {
         v.x[i] = (it_begin > 0) ? x[(size_t)b * n + i] : (x_guess ? x_guess[(size_t)b * n + i] : 0.0);
-        v.lbx[i] = lbx[(size_t)b * n + i]; v.ubx[i] = ubx[(size_t)b * n + i];
+        const double lbi = lbx[(size_t)b * n + i], ubi = ubx[(size_t)b * n + i];
+        v.lbx[i] = lbi; v.ubx[i] = ubi;
+        if constexpr (BOUNDS_RULE) loose |= (i >= ocp.dm.VARX) && (lbi < -LOOSE_BOUNDS_THRESH) && (ubi > LOOSE_BOUNDS_THRESH);   // classify_bounds(...) == 2 on a control / parameter
         if (it_begin > 0) { v.lg[i] = sst[i]; v.step[i] = sst[n + i]; }
     }
     for (int i = ln; i < m + n; i += WAVE)
@@ -161,14 +177,13 @@ __global__ __launch_bounds__(WG4 ? 256 : 64, ((NN > 0 && NN + MM <= 64) ? PMPC_S
         v.ubg[i] = ubg ? ubg[(size_t)b * mi + i] : INFINITY;
     }
     wsync();
-    if constexpr (NN > 0 && CND) {   // the conditioning rule of the register-resident kernels (see the epilogue below) for the condensed kernels: before any work
-        if (it_begin == 0 && flags0 == 0) {
-            bool loose = false;
-            for (int i = ocp.dm.VARX + ln; i < n; i += WAVE) loose |= classify_bounds(v.lbx[i], v.ubx[i]) == 2;
-            if (__builtin_amdgcn_ballot_w64(loose) != 0) {
-                if (ln == 0) { pmpc_sqp_info r; r.iter = 0; r.qp_solver_iter = 0; r.status = PMPC_SQP_REDO; r.flags = PMPC_FLAG_ILLCOND; r.primal_norm = 0.0; r.dual_norm = 0.0; r.max_violation = 0.0; r.cost = 0.0; info[b] = r; }
-                return;
-            }
+    if constexpr (BOUNDS_RULE) {
+        if (it_begin == 0 && flags0 == 0 && __builtin_amdgcn_ballot_w64(loose) != 0) {
+            // (x and lam leave as the guesses: the outputs of an instance that gave up are defined even when a developer's PMPC_NO_REDO_LAUNCH skips the launch that re-solves it)
+            for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = v.x[i];
+            for (int i = ln; i < m + n; i += WAVE) lam[(size_t)b * (m + n) + i] = v.lam[i];
+            if (ln == 0) { pmpc_sqp_info r; r.iter = 0; r.qp_solver_iter = 0; r.status = PMPC_SQP_REDO; r.flags = PMPC_FLAG_ILLCOND; r.primal_norm = 0.0; r.dual_norm = 0.0; r.max_violation = 0.0; r.cost = 0.0; info[b] = r; }
+            return;
         }
     }
     // stacked workspace K0 = [H ; J] ((n+m) x n, column-major, leading dimension n+m): lane i reads row i of K0 with ONE stride
@@ -192,23 +207,6 @@ __global__ __launch_bounds__(WG4 ? 256 : 64, ((NN > 0 && NN + MM <= 64) ? PMPC_S
     sqp.qp_flags = flags0;
     if (it_begin > 0) { const pmpc_sqp_info prev = info[b]; sqp.qp_iter_total = prev.qp_solver_iter; sqp.qp_flags = prev.flags; sqp.cost_log = prev.cost; }
     sqp.solve(si, it_begin, it_end);
-    if constexpr (NN > 0 && NN + MM <= WAVE && !CND) {   // (the constraint-first one-row-per-lane kernels; the condensed kernels test in their prologue, see there)
-        // Conditioning rule of the register-resident kernels (PMPC_FLAG_ILLCOND, include/polympc_amd.h), decided per instance from its BOUNDS: these
-        // kernels invert S = P + A' diag(rho) A (constraint-first sweep / condensed form), whose condition number rho_eq |A|^2 / lambda_min(P on null A)
-        // stays ~1e5 whatever rho is as long as the directions the collocation Jacobian leaves free — the controls and parameters — are BOUNDED
-        // (rho_box scales with rho), and grows with rho when one of them is not (rho_box = RHO_MIN). Such an instance is handed to the redo launch
-        // (full KKT form); what this kernel computed for it is discarded. Where the test sits is measured, not chosen: in FRONT of the solve its 130
-        // instructions cost the bench kernel 2 % (same box A/B: 1.145 -> 1.17 ms; behind it 1.15), while the condensed kernels lose 3 % with the test
-        // behind the solve and nothing with it in front (16-node grid 6.09 / 6.28 / 6.07 ms) — code placement. A numeric gate at every factorisation —
-        // what the large-instance kernel and the QP entry point use — cost these kernels 4 .. 10 % through register pressure alone (EXPERIMENTS.md round 5).
-        // (Config B's condensed kernel, for which the round's first measurement had the test in front cost 1.5 %: the same build with the test behind the solve times the
-        //  same on one box, 26.98 / 26.86 / 26.83 against 26.96 / 26.80 / 26.82 ms — that difference was the box, not the placement.)
-        if (flags0 == 0 && si.status != PMPC_SQP_IN_PROGRESS) {
-            bool loose = false;
-            for (int i = ocp.dm.VARX + ln; i < n; i += WAVE) loose |= classify_bounds(v.lbx[i], v.ubx[i]) == 2;
-            if (__builtin_amdgcn_ballot_w64(loose) != 0) { si.status = PMPC_SQP_REDO; si.flags = PMPC_FLAG_ILLCOND; }
-        }
-    }
     if (si.status == PMPC_SQP_IN_PROGRESS && sst) for (int i = ln; i < n; i += WAVE) { sst[i] = v.lg[i]; sst[n + i] = v.step[i]; }
     for (int i = ln; i < n; i += WAVE) x[(size_t)b * n + i] = v.x[i];
     for (int i = ln; i < m + n; i += WAVE) lam[(size_t)b * (m + n) + i] = v.lam[i];
@@ -309,7 +307,7 @@ void sqp_schur_kernel(Model model, const ChebData* __restrict__ cd, int B, const
 // asks for the reference's full KKT form and keeps the dense kernels)
 inline bool schur_request_ok(const pmpc_sqp_settings* ss, const pmpc_qp_settings* qs, int slice_iters) {
     return (ss->hessian_update == 1 || ss->exact_hessian_every_iter) && (ss->regularisation == 0 || ss->regularisation == 2) && ss->preconditioner == 0 &&
-           ss->qp_solver == 0 && ss->kkt_form == 0 && qs->linear_solver == 0 && slice_iters == 0;   // (line_search = 1: the grids compiled with the hook, try_launch_schur)
+           ss->qp_solver == 0 && (ss->kkt_form == 0 || ss->kkt_form == 2) && qs->linear_solver == 0 && slice_iters == 0;   // (line_search = 1: the grids compiled with the hook, try_launch_schur)
 }
 template <class Model, int PP, int SS>
 inline bool try_launch_schur(pmpc_context* ctx, const Model& mdl, const ChebData* cd, int P, int S, int B, const double* x_guess, const double* lam_guess,
@@ -319,7 +317,7 @@ inline bool try_launch_schur(pmpc_context* ctx, const Model& mdl, const ChebData
     // Systems of at most 64 KKT rows stay on the one-row-per-lane dense kernel: its ADMM iteration is ONE register mat-vec (600 cycles), the
     // block-structured one a chain of eight LDS exchanges and two mat-vecs (3.7 k cycles on config A) — measured 1.69 against 1.16 ms per 4096
     // config-A instances although the factorisation is three times cheaper. PMPC_SCHUR_SMALL=1: developer switch.
-    if (SchurDims<Model, PP, SS>::N + SchurDims<Model, PP, SS>::M <= WAVE && !getenv("PMPC_SCHUR_SMALL")) return false;
+    if (SchurDims<Model, PP, SS>::N + SchurDims<Model, PP, SS>::M <= WAVE && !pmpc_internal_switch(ctx, PMPC_SW_SCHUR_SMALL)) return false;
     const size_t lds = sqp_schur_lds_bytes<Model, PP, SS>(ss->line_search == 1);
     if (lds > lds_limit) return false;
     auto kern = sqp_schur_kernel<Model, PP, SS, false>;
@@ -466,11 +464,15 @@ __global__ __launch_bounds__(64, PMPC_SQP_WAVES) void sqp_kernel_rr(Model model,
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         for (int i = ln; i < Model::ND; i += WAVE) dL[i] = d[(size_t)b * Model::ND + i];
         double* sst = slice_state + (size_t)b * 2 * n;   // [previous Lagrangian gradient | previous step]
+        bool loose = false;   // the conditioning rule of the register-resident kernels (see sqp_kernel): unbounded controls / parameters -> the redo launch, before any work
         for (int i = ln; i < n; i += WAVE) {
             v.x[i] = (pass > 0) ? x[(size_t)b * n + i] : (x_guess ? x_guess[(size_t)b * n + i] : 0.0);
-            v.lbx[i] = lbx[(size_t)b * n + i]; v.ubx[i] = ubx[(size_t)b * n + i];
+            const double lbi = lbx[(size_t)b * n + i], ubi = ubx[(size_t)b * n + i];
+            v.lbx[i] = lbi; v.ubx[i] = ubi;
+            loose |= (i >= ocp.dm.VARX) && (lbi < -LOOSE_BOUNDS_THRESH) && (ubi > LOOSE_BOUNDS_THRESH);
             if (pass > 0) { v.lg[i] = sst[i]; v.step[i] = sst[n + i]; }
         }
+        const bool gave_up = __builtin_amdgcn_ballot_w64(loose) != 0;
         for (int i = ln; i < m + n; i += WAVE)
             v.lam[i] = (pass > 0) ? lam[(size_t)b * (m + n) + i] : (lam_guess ? lam_guess[(size_t)b * (m + n) + i] : 0.0);
         for (int i = ln; i < mi; i += WAVE) {
@@ -482,7 +484,8 @@ __global__ __launch_bounds__(64, PMPC_SQP_WAVES) void sqp_kernel_rr(Model model,
         double* K0 = Hws + (size_t)b * (size_t)(n + m) * n;
         pmpc_sqp_info si;
         int done_iters = pass;
-        {
+        if (gave_up) { si.iter = 0; si.qp_solver_iter = 0; si.status = PMPC_SQP_REDO; si.flags = PMPC_FLAG_ILLCOND; si.primal_norm = 0.0; si.dual_norm = 0.0; si.max_violation = 0.0; si.cost = 0.0; }
+        else {
             SqpDevice<Model, NN, MM, false, HU, false> sqp(ocp, v, qw, K0, K0 + n, ss, qs);
             sqp.filt = nullptr;
             sqp.eig = nullptr;
@@ -503,11 +506,6 @@ __global__ __launch_bounds__(64, PMPC_SQP_WAVES) void sqp_kernel_rr(Model model,
                 cyc_sum += c1; ++cyc_items;
                 if (!hard) break;
             }
-        }
-        if (si.status != PMPC_SQP_IN_PROGRESS) {   // the conditioning rule of the register-resident kernels (see sqp_kernel): unbounded controls / parameters -> the redo launch
-            bool loose = false;
-            for (int i = ocp.dm.VARX + ln; i < n; i += WAVE) loose |= classify_bounds(v.lbx[i], v.ubx[i]) == 2;
-            if (__builtin_amdgcn_ballot_w64(loose) != 0) { si.status = PMPC_SQP_REDO; si.flags = PMPC_FLAG_ILLCOND; }
         }
         RR_T(t3);
 #ifdef PMPC_RR_PROFILE   // per-item wall-clock stamps (100 MHz) in the alpha / primal_norm / dual_norm fields of the iteration record
@@ -631,11 +629,11 @@ template <> struct LDS_PATH_PROFILED<KiteStandInOCP> { static constexpr bool val
 // its conditioning gate (none on any BASELINE workload) are solved again, from their guesses, by the LDS-resident kernel — static LDL^T of the
 // (n + m)-row KKT matrix with substitutions; every other workgroup reads one word and exits. PMPC_NO_REDO_LAUNCH=1: developer switch (timing the launch).
 template <class Model>
-inline bool launch_redo_generic(const Model& mdl, const ChebData* cd, int P, int S, int B, const double* x_guess, const double* lam_guess, const double* d,
+inline bool launch_redo_generic(pmpc_context* ctx, const Model& mdl, const ChebData* cd, int P, int S, int B, const double* x_guess, const double* lam_guess, const double* d,
                                 const double* lbx, const double* ubx, const double* lbg, const double* ubg, const pmpc_sqp_settings* ss,
                                 const pmpc_qp_settings* qs, double* Hws, double* Aws, double* x, double* lam, pmpc_sqp_info* info, hipStream_t stream,
                                 size_t lds_limit) {
-    if (getenv("PMPC_NO_REDO_LAUNCH")) return true;
+    if (pmpc_internal_switch(ctx, PMPC_SW_NO_REDO_LAUNCH)) return true;
     const size_t ldsg = sqp_kernel_lds_bytes<Model>(P, S, 0, 0);
     if (ldsg > lds_limit) return true;   // (systems of at most 64 rows always fit)
     auto gk = sqp_kernel<Model>;
@@ -694,7 +692,7 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
                 // resume mode: a no-op per instance unless something was left in progress (see sqp_kernel_rr)
                 hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), ldsr, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
                                    *ss, *qs, Hws, Aws, x, lam, info, phase, (double*)nullptr, -1, ss->max_iter, slice_state, (unsigned)(ldsr / sizeof(double)));
-                if (!launch_redo_generic<Model>(mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit)) { *st = PMPC_ERR_HIP; return true; }
+                if (!launch_redo_generic<Model>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit)) { *st = PMPC_ERR_HIP; return true; }
                 *st = (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
                 return true;
             }
@@ -702,7 +700,7 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
         for (int it = 0; it < ss->max_iter; it += slice)
             hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), ldsr, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
                                *ss, *qs, Hws, Aws, x, lam, info, phase, (double*)nullptr, it, it + slice, slice_state, (unsigned)(ldsr / sizeof(double)));
-        if (!launch_redo_generic<Model>(mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit)) { *st = PMPC_ERR_HIP; return true; }
+        if (!launch_redo_generic<Model>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit)) { *st = PMPC_ERR_HIP; return true; }
         *st = (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
         return true;
     } else if constexpr (NN_ + MM_ <= 128) {   // two KKT rows per lane (pmpc_qp_reg2.hpp); the Hessian-update policy is a run-time choice there
@@ -717,7 +715,7 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
         // condensed register QP (pmpc_qp_cond.hpp): 65..112 variables, at most 64 constraint rows, the default policies; kkt_form = 1 keeps the full inverse
         size_t ldsq = ldsr;
         if constexpr (COND_REG_OK<Model, NN_, MM_>::value) {
-            if (!pol && ss->kkt_form == 0 && !getenv("PMPC_NO_CONDREG")) {
+            if (!pol && ss->kkt_form == 0 && !pmpc_internal_switch(ctx, PMPC_SW_NO_CONDREG)) {
                 if constexpr (NN_ <= WAVE) ldsq = sqp_kernel_lds_bytes<Model>(P, S, 5, 0, false);   // (two wavefronts per SIMD: a smaller staging lets more instances share a CU)
                 else ldsq = sqp_kernel_lds_bytes<Model>(P, S, 6, 0, false, (size_t)cond_qp_staging<NN_, MM_, NNODES>());   // (its own tile set's staging, not the full inverse's: four instead of three instances per CU on the 16-node grid)
                 kern = sqp_kernel<Model, NN_, MM_, false, 0, false, false, false, true>; timed = false;
@@ -729,7 +727,7 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
             }
             // the filter line search alone (no Ruiz scaling: that rescales the workspace the per-node blocks of A mirror) keeps the condensed QP
             if constexpr (POLK) {   // (round 5: also the one-row-per-lane tile set — its hook build was miscompiled by the never-executed Ruiz calls, which the condensed kernels no longer carry, pmpc_sqp.hpp RUIZ_COMPILED)
-                if (pol && ss->preconditioner == 0 && ss->kkt_form == 0 && !getenv("PMPC_NO_CONDREG")) {
+                if (pol && ss->preconditioner == 0 && ss->kkt_form == 0 && !pmpc_internal_switch(ctx, PMPC_SW_NO_CONDREG)) {
                     kern = sqp_kernel<Model, NN_, MM_, false, 0, false, false, true, true>; timed = false;
                     if constexpr (NN_ > WAVE) ldsq = sqp_kernel_lds_bytes<Model>(P, S, 6, 0, true, (size_t)cond_qp_staging<NN_, MM_, NNODES>());
                     pmpc_internal_set_route(ctx, PMPC_ROUTE_CONDREG);
@@ -743,7 +741,7 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
         for (int it = 0; it < ss->max_iter; it += slice)
             hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), ldsq, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
                                *ss, *qs, Hws, Aws, x, lam, info, timed ? phase : (unsigned long long*)nullptr, (double*)nullptr, it, it + slice, slice_state, (unsigned)(ldsq / sizeof(double)));
-        if (pmpc_internal_last_route(ctx) == PMPC_ROUTE_CONDREG && !getenv("PMPC_NO_REDO_LAUNCH")) {
+        if (pmpc_internal_last_route(ctx) == PMPC_ROUTE_CONDREG && !pmpc_internal_switch(ctx, PMPC_SW_NO_REDO_LAUNCH)) {
             // redo launch: the instances whose condensed solve gave up at its conditioning gate (PMPC_FLAG_ILLCOND; none on any BASELINE workload) are solved
             // again, from their guesses, by the full-inverse kernel of this size — every other workgroup reads one word and exits
             if (hipFuncSetAttribute((const void*)kern_full, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
@@ -800,16 +798,19 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     if constexpr (SCHUR_GRIDS<Model>::value) {   // block-diagonal Hessian on a grid with a block-structured kernel
         // (the redo launch behind this kernel's conditioning gate runs the LDS-resident kernel: a grid it does not fit — only under a developer's PMPC_LDS_LIMIT —
         //  keeps the dense kernels, so that an instance that gave up can always be solved again)
-        if (!force_lds && !getenv("PMPC_NO_SCHUR") && schur_request_ok(ss, qs, slice_iters) && sqp_kernel_lds_bytes<Model>(P, S, 0, 0) <= lds_limit) {
+        if (!force_lds && !pmpc_internal_switch(ctx, PMPC_SW_NO_SCHUR) && schur_request_ok(ss, qs, slice_iters) && sqp_kernel_lds_bytes<Model>(P, S, 0, 0) <= lds_limit) {
             pmpc_status rst = PMPC_OK;
             if (try_launch_schur_grids<Model>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, ss, qs, x, lam, info, stream, lds_limit, phase, &rst)) {
                 // redo launch: the instances whose block-structured QP gave up at its conditioning gate (PMPC_SCHUR_COND_GATE; none on any BASELINE workload) are
                 // solved again, from their guesses, on the LDS-resident static LDL^T of the (n + m)-row matrix (every compiled grid fits)
-                if (rst == PMPC_OK && !launch_redo_generic<Model>(mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit)) rst = PMPC_ERR_HIP;
+                if (rst == PMPC_OK && !launch_redo_generic<Model>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit)) rst = PMPC_ERR_HIP;
                 return rst;
             }
         }
     }
+    // kkt_form = 2 asks for the block-structured range-space form where a specialisation is compiled (above); everywhere else it means the default
+    pmpc_sqp_settings ss_default_form;
+    if (ss->kkt_form == 2) { ss_default_form = *ss; ss_default_form.kkt_form = 0; ss = &ss_default_form; }
     if (!force_lds && ss->qp_solver == 0 && ss->regularisation != 1 && qs->linear_solver == 0) {   // (preconditioner / line_search = 1: the 7- and 11-node register kernels carry them, see try_launch_reg)   // node counts whose KKT system can fit 64 rows for small models (7 nodes: config A / D); Ruiz: LDS path
         pmpc_status rst = PMPC_OK;
         if (try_launch_reg<Model, 7>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;
@@ -849,14 +850,14 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     // PMPC_BIG_WG4 = 0 / 1: developer switch (never / whenever eligible).
     unsigned threads = WAVE;
     if constexpr (Model::NG == 0 && Model::NP == 0) {
-        const char* e = getenv("PMPC_BIG_WG4");
+        const int wg4_on = pmpc_internal_switch(ctx, PMPC_SW_BIG_WG4_ON), wg4_off = pmpc_internal_switch(ctx, PMPC_SW_BIG_WG4_OFF);
         const bool eligible = Kws && lkern == sqp_kernel<Model, 0, 0, false, 0, true> && ss->kkt_form == 0 && ss->preconditioner == 0 && ss->qp_solver == 0 && ss->regularisation != 1 &&
                               dm.n <= BIG_COND_MAX_ROWS && dm.m <= BIG_COND_MAX_ROWS && slice_iters == 0;
         // Up to one instance per CU the team kernel may use the whole register file (512 per lane); from there to TWO instances per CU a second build of it,
         // compiled for 256 registers so that two workgroups share a CU, still beats one wavefront per instance (kite-sized, 512 instances: 11.7 against 13.4 ms;
         // the register diet costs it 4 % at 256 instances, hence two builds); beyond that the one-wavefront kernel's throughput wins (EXPERIMENTS.md round 5).
         const int per_cu = BIG_WG4_MAX_BATCH * (pmpc_internal_simd_count(ctx) / 4) / 256;
-        const bool want = e && e[0] ? (e[0] != '0') : (B <= 2 * per_cu);
+        const bool want = (wg4_on || wg4_off) ? (wg4_on != 0) : (B <= 2 * per_cu);
         if (eligible && want) {
             lkern = (B <= per_cu) ? sqp_kernel<Model, 0, 0, false, 0, true, false, false, false, true> : sqp_kernel<Model, 0, 0, false, 0, true, true, false, false, true>;
             threads = 4 * WAVE;
@@ -874,7 +875,7 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     for (int it = 0; it < ss->max_iter; it += slice)
         hipLaunchKernelGGL(lkern, dim3(B), dim3(threads), lds, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, *ss, *qs, Hws, Aws,
                            x, lam, info, phase, Kws, it, it + slice, slice_state, (unsigned)(lds / sizeof(double)));
-    if (Kws && ss->kkt_form == 0 && ss->qp_solver == 0 && !getenv("PMPC_NO_REDO_LAUNCH")) {
+    if (Kws && ss->kkt_form == 0 && ss->qp_solver == 0 && !pmpc_internal_switch(ctx, PMPC_SW_NO_REDO_LAUNCH)) {
         // redo launch (large-instance kernel, condensed mode): the instances whose QP gave up at its conditioning gate (PMPC_FLAG_ILLCOND; none on any
         // BASELINE workload) are solved again, from their guesses, by the same kernel in the (n + m)-row KKT form — every other workgroup reads one word and exits
         pmpc_sqp_settings ss_full = *ss; ss_full.kkt_form = 1;

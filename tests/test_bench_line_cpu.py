@@ -63,3 +63,24 @@ def test_contract_line_stays_small_with_long_notes():
     d["cpu_baseline"]["sample"] = "x" * 5000
     d["config"]["note"] = "y" * 5000
     assert len(json.dumps(bench.contract_line(d, "p"))) < 4096
+
+
+def test_round6_record_is_consistent_and_carries_the_new_keys():
+    """VERDICT r5 item 6, on this round's detailed record (profiles/r06_bench.json, written by bench.py on the MI355X): the dominant kernel's duration comes from the
+    MEDIAN block and cannot exceed the step it is part of; config A has small-batch records with the single-core CPU time of the same instances beside them (the honest
+    crossover for BASELINE configs[0], ONE Solver<OCP>::solve()); the GPU / CPU-all-cores ratio exists once, labelled baseline-only."""
+    import bench
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_bench.json")))
+    assert d["roofline"]["kernel_ms"] <= d["ms_per_step"] * 1.01
+    assert abs(d["roofline"]["kernel_ms"] - d["step_ms"]["mean"]) < 1e-12 and "mean_all_blocks" in d["step_ms"]
+    sb = d["small_batches"]
+    assert set(sb) == {"1", "64", "512"}
+    for rec in sb.values():
+        assert rec["route"] == "reg1" and rec["cpu_single_core_ms"] > 0 and rec["ms_per_batch"]["median"] > 0
+        assert abs(rec["gpu_over_cpu_single_core"] - rec["cpu_single_core_ms"] / rec["ms_per_batch"]["median"]) < 1e-9
+    g = d["gpu_over_cpu_all_cores"]
+    assert "baseline only" in g["note"] and abs(g["value"] - d["value"] / d["cpu_baseline"]["value"]) < 1e-6 * g["value"]
+    line = bench.contract_line(d, "gpurun_out/bench_detail.json")
+    assert len(json.dumps(line)) < 4096
+    assert set(line["small_batches_ms"]) == {"1", "64", "512"} and line["gpu_over_cpu_all_cores"] > 1
+    assert line["roofline"]["kernel_ms"] <= line["ms_per_step"] * 1.01

@@ -1386,12 +1386,13 @@ def test_block_structured_kernel_conditioning_gate_and_its_redo_launch(ctx, orac
     assert tripped >= 3 * B
 
 
-def test_sqp_bordered_block_structured_kernel_behind_its_developer_switch(ctx, oracle):
-    """NP = 1 on the block-structured kernel (round 5, PMPC_SCHUR_NP=1; pmpc_schur_parking.hip): the exact Hessian of the minimal-time parking problem has the
+def test_sqp_bordered_block_structured_kernel_on_request(ctx, oracle):
+    """NP = 1 on the block-structured kernel (round 5; since round 6 requested through the API, pmpc_sqp_settings::kkt_form = 2, not an environment switch;
+    pmpc_schur_parking.hip): the exact Hessian of the minimal-time parking problem has the
     arrow shape — node blocks, a border row / column for the free final time, a corner — and A a dense parameter column; the QP is solved through the bordered
     range-space form. (a) minimal_time_test.cpp:146-188 as the reference configures it: every instance meets the conditioning gate once the penalty adapts upwards
-    and is finished by the redo launch — SOLVED in < 20 iterations as the reference asserts, bit for bit the restatement under the same rule: which is why the switch
-    is not the default. (b) the same problems with the penalty held at 0.1 (adaptive_rho = 0): no trip, every QP of every iteration on the bordered kernel,
+    and is finished by the redo launch — SOLVED in < 20 iterations as the reference asserts, bit for bit the restatement under the same rule: which is why this form
+    is not the default for that problem. (b) the same problems with the penalty held at 0.1 (adaptive_rho = 0): no trip, every QP of every iteration on the bordered kernel,
     bit-identical to PIVOT_SCHUR — the arithmetic of the border itself. (c) three iterations with the block BFGS (border row / column and corner take the same
     damped rank-2 terms, continuous_ocp.hpp:2384-2428)."""
     import os
@@ -1399,10 +1400,10 @@ def test_sqp_bordered_block_structured_kernel_behind_its_developer_switch(ctx, o
     from test_oracle_pins import _parking_batch
     B = 12
     lbx, ubx, xg, d = _parking_batch(B)
-    os.environ["PMPC_SCHUR_NP"] = "1"
-    try:
+    if True:
         for case in ("reference", "fixed_rho", "block_bfgs"):
             ss = pa.sqp_settings_default(); oss = oracle.sqp_default_settings()
+            ss.kkt_form = 2
             qs = pa.qp_settings_sqp_default(); oqs = oracle.sqp_qp_default_settings()
             for st in (ss, oss):
                 st.max_iter = 20; st.line_search_max_iter = 10; st.regularisation = 2
@@ -1421,11 +1422,9 @@ def test_sqp_bordered_block_structured_kernel_behind_its_developer_switch(ctx, o
                 assert np.all(info["flags"] & pa.capi.FLAG_ILLCOND) and (info["status"] == pa.SQP_SOLVED).sum() >= B - 1 and np.all(info["iter"][info["status"] == pa.SQP_SOLVED] < 20)
             else:
                 assert np.all(info["flags"] == 0)
-    finally:
-        del os.environ["PMPC_SCHUR_NP"]
     ss = pa.sqp_settings_default(); ss.max_iter = 2; ss.regularisation = 2; ss.exact_hessian_every_iter = 1
     ctx.sqp_solve_batch(pa.MODEL_PARKING, 5, 2, 0.0, 1.0, 1, d[:1], lbx[:1], ubx[:1], x_guess=xg[:1], sqp_settings=ss)
-    assert ctx.last_route() != pa.capi.ROUTE_SCHUR   # without the switch: the dense two-rows-per-lane kernel, as before
+    assert ctx.last_route() != pa.capi.ROUTE_SCHUR   # without the request: the dense two-rows-per-lane kernel, as before
 
 
 @pytest.mark.parametrize("case", ["robot_11", "robot_16", "cstr_11", "robot_7", "kite"])
@@ -1583,6 +1582,28 @@ def test_large_instance_team_kernel_bit_identical_to_the_one_wavefront_kernel(or
     monkeypatch.delenv("PMPC_BIG_WG4")
     (x4, l4, i4), (x1, l1, i1) = res
     assert _same_bits(x4, x1) and _same_bits(l4, l1) and _same_bits(i4, i1)
+    # a MID-SIZE instance (round 6, ADVICE r5: the team's thresholds were measured on the kite-sized 464-row system only): the 21-node robot grid, 105 + 63 =
+    # 168 KKT rows, which the launcher also hands to the team for batches of at most two instances per CU — lone instance, one and two instances per CU, against
+    # the one-wavefront kernel (same-box timings: profiles/r06_ab_prologue_rule_and_midsize_team.txt — the team is faster at 1 / 64 / 256 / 512 instances)
+    for B in (1, 256, 300):
+        wl = workloads.robot_batch(B, P=5, S=4)
+        ss = pa.sqp_settings_default(); ss.max_iter = 4; ss.line_search_max_iter = wl["ls_max_iter"]
+        res = []
+        for wg4 in (None, "0"):
+            if wg4 is not None: monkeypatch.setenv("PMPC_BIG_WG4", wg4)
+            c = pa.Context(0)
+            try:
+                res.append(c.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss))
+                assert c.last_route() == pa.capi.ROUTE_HBM
+            finally:
+                c.close()
+        monkeypatch.delenv("PMPC_BIG_WG4")
+        (x4, l4, i4), (x1, l1, i1) = res
+        assert _same_bits(x4, x1) and _same_bits(l4, l1) and _same_bits(i4, i1), B
+    oss = oracle.sqp_default_settings(); oss.max_iter = 4; oss.line_search_max_iter = wl["ls_max_iter"]
+    xo, lo, io = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], 16, wl["d"][:16], wl["lbx"][:16], wl["ubx"][:16], sqp_settings=oss,
+                                        pivot=oracle.PIVOT_CONDENSED, threads=4)
+    _assert_same_solve(i4[:16], io, x4[:16], xo, l4[:16], lo)
 
 
 def test_device_poisoning_changes_nothing(oracle):

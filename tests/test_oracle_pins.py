@@ -1244,3 +1244,32 @@ def test_condensed_policy_follows_the_eigen_order_trajectories(oracle):
         r = tco.cross_order_stats(cfg, wl, xc, lc, ic, xr, lr, ir)
         assert r["different_trajectories"] == 0, (cfg, r)
         assert r["max_abs_dx"] <= tol and r["max_abs_d_constraint_violation"] <= 1e-9 and r["max_rel_d_cost"] <= 1e-9, (cfg, r)
+
+
+def test_null_space_form_cannot_serve_the_minimal_time_problem(oracle):
+    """VERDICT r5 item 4 asked for a null-space / reduced-Hessian variant of the block-structured kernel — eliminate the STATES through the state block A_x of
+    the collocation Jacobian instead of the multipliers through S = 1/rho + A Q A' — for the reference's NP = 1 problems, "or show why it cannot work". It
+    cannot, on exactly the problem it was meant for (minimal_time_test.cpp:146-188): A_x = D (x) I - t_s df/dx is SQUARE (NX nn x NX nn) and SINGULAR there — the
+    differentiation matrix annihilates constant profiles and the parking dynamics do not depend on the position states at all — at the reference's guess and at
+    its solution alike (sigma_min ~ 1e-16, rank deficiency >= 2). What makes the problem well posed are the BOUNDS that pin the initial state (lbx = ubx on the last
+    node): with those three columns removed the remaining 33 x 30 block has full column rank and a condition number below 100 — but which columns are pinned is
+    known to boxADMM only through rho_box (an active-set property), not to an elimination of the equality rows. The range-space form's own difficulty on this
+    problem (every instance meets its conditioning gate once rho adapts beyond ~25, EXPERIMENTS.md round 5) is the same singularity seen from the other side: S
+    is regular only through 1/rho_eq and the bounded controls' Q ~ 1/rho. The dense kernels factorise the quasi-definite (n + m)-row matrix, where the pinned
+    states' rho_box = 1e3 rho does the regularising, and stay the default for this problem."""
+    lbx, ubx, xg = _minimal_time_parking(11)
+    nn, nx = 11, 3
+    ss = oracle.sqp_default_settings(); ss.max_iter = 20; ss.line_search_max_iter = 10; ss.exact_hessian_every_iter = 1; ss.regularisation = 2
+    d = np.array([[1.0]])
+    x, lam, info = oracle.sqp_solve_batch(oracle.MODEL_PARKING, 5, 2, 0.0, 1.0, 1, d, lbx, ubx, x_guess=xg, sqp_settings=ss, pivot=oracle.PIVOT_EIGEN)
+    assert info[0].status == 0 and info[0].iter < 20
+    pinned = [i for i in range(nx * nn) if lbx[0, i] == ubx[0, i]]
+    assert len(pinned) == nx
+    free = [i for i in range(nx * nn) if i not in pinned]
+    for pt in (xg[0], x[0]):
+        J = oracle.ocp_eval(oracle.MODEL_PARKING, 5, 2, 0.0, 1.0, pt, d[0], lam=np.zeros(33 + 56))["jac"]
+        Ax = J[:, :nx * nn]
+        sv = np.linalg.svd(Ax, compute_uv=False)
+        assert Ax.shape == (33, 33) and sv[-1] < 1e-12 * sv[0] and sv[-2] < 1e-12 * sv[0]      # singular, twice over
+        svf = np.linalg.svd(Ax[:, free], compute_uv=False)
+        assert svf[0] / svf[-1] < 100.0                                                          # regular once the pinned columns are known

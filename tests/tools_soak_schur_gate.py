@@ -29,7 +29,6 @@ def main():
     lbx, ubx, xg, d = _parking_batch(B)
     cases = [("cstr 11", workloads.cstr_batch(B), None), ("robot 16", workloads.robot_batch(B, P=5, S=3), None), ("robot 11", workloads.robot_batch(B, P=5, S=2), None),
              ("parking 11", dict(model=pa.MODEL_PARKING, P=5, S=2, t0=0.0, tf=1.0, d=d, lbx=lbx, ubx=ubx, ls_max_iter=10), xg)]
-    os.environ["PMPC_SCHUR_NP"] = "1"
     for name, wl, guess in cases:
         for skw in SQP_VARIANTS:
             if name.startswith("parking") and skw.get("line_search"): continue   # (no hook build of the bordered form)
@@ -40,6 +39,7 @@ def main():
                         st.max_iter = 5; st.line_search_max_iter = wl["ls_max_iter"]
                         if name.startswith("parking") and skw.get("hessian_update"): st.max_iter = 3   # (quasi-Newton updates diverge on the minimal-time problem from the fourth iteration on — NaN on both sides; the reference solves it with exact Hessians)
                         for k, v in skw.items(): setattr(st, k, v)
+                    if name.startswith("parking"): ss.kkt_form = 2   # the bordered NP = 1 form is served on request (pmpc_sqp_settings::kkt_form = 2)
                     qs = pa.qp_settings_sqp_default(); oqs = ob.sqp_qp_default_settings()
                     for k, v in dict(qkw, rho=rho0).items():
                         setattr(qs, k, v); setattr(oqs, k, v)
@@ -63,7 +63,6 @@ def main():
                     except AssertionError as e:
                         res = "MISMATCH " + str(e).split("\n")[0][:90]; bad += 1
                     print(f"{name:10s} {str(skw):62s} rho0={rho0:<6g} {str(qkw):58s} redone {int(np.count_nonzero(info['flags'] & pa.capi.FLAG_ILLCOND)):3d}/{B}  {res}", flush=True)
-    del os.environ["PMPC_SCHUR_NP"]
     ctx.close()
     print("mismatches:", bad)
     sys.exit(1 if bad else 0)

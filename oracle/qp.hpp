@@ -388,9 +388,14 @@ struct BoxADMM {
         for (int j = 0; j < cols; ++j) { double a = 0; for (int i = 0; i < rows; ++i) a += A[i + j * rows] * v[i]; out[j] = a; }
     }
 
-    // EXPERIMENT (round 6, VERDICT r5 item 1c — measured and NOT adopted, EXPERIMENTS.md): H x of the dual residual from the KKT identity
-    //   (H + sigma I + rho_box) x~ + A' nu = rhs_1   =>   H x~ = rhs_1 - (sigma + rho_box) o x~ - A' nu        (alpha = 1: x = x~)
-    // instead of a second mat-vec with H. hx_identity() is a process-wide test switch (orc_set_hx_identity); last_rhs / last_sol are the operands of the last solve.
+    // H x of the dual residual from the KKT identity instead of a second mat-vec with H (round 6):
+    //   (H + sigma I + rho_box) x~ + A' nu = rhs_1   =>   H x~ = (rhs_1 - A' nu) - (sigma + rho_box) o x~        (alpha = 1: x = x~, quirk Q1)
+    // * PIVOT_CONDSWEEP restates the condensed register kernel (pmpc_qp_cond.hpp), which does this whenever alpha == 1 and the iterate is finite: A' nu is the
+    //   fma chain of kkt_solve_condsweep's first product started from 0, then one subtraction, one product, one subtraction. The reference (and every other
+    //   order here) multiplies by H: qp_base.hpp:240-252. The two differ by the linear solve's own residual; on the streams of configs A / D / B / R no instance
+    //   changes an iteration count (tests/test_oracle_pins.py::test_dual_residual_from_the_kkt_identity_changes_no_trajectory).
+    // * hx_identity() — a process-wide TEST switch (orc_set_hx_identity) that applies the same identity, with dense products, under any order: the experiment
+    //   behind the statement above. last_rhs / last_sol: the operands of the last solve.
     static int& hx_identity() { static int v = 0; return v; }
     std::vector<double> last_rhs, last_sol;
     void residuals_update(const double* H, const double* h, const double* A) {  // :398-415
@@ -398,7 +403,24 @@ struct BoxADMM {
         matvec(A, M, N, x.data(), Ax.data());
         const double norm_Ax = inf_norm(Ax.data(), M), norm_z = inf_norm(z.data(), M);
         max_Ax_z_norm = std::fmax(norm_Ax, std::fmax(norm_z, inf_norm(x.data(), N)));
-        if (hx_identity() && settings.alpha == 1.0 && (int)last_sol.size() == N + M) {
+        bool finite_iterate = true;   // (the kernel's test: x and the constraint multipliers)
+        for (int i = 0; i < N; ++i) finite_iterate = finite_iterate && std::isfinite(x[i]);
+        for (int i = 0; i < M; ++i) finite_iterate = finite_iterate && std::isfinite(y[i]);
+        if (pivot == PIVOT_CONDSWEEP && settings.alpha == 1.0 && finite_iterate && (int)last_sol.size() == N + M) {
+            const int NM = N + M, nx = schur.nx, nu = schur.nu, nn = schur.nn, VARX = nx * nn;
+            const double* nuv = last_sol.data() + N;
+            for (int c = 0; c < N; ++c) {
+                const bool xcol = c < VARX;
+                const int jn = xcol ? c / nx : (c - VARX) / nu, qx = xcol ? c - jn * nx : 0;
+                double a = 0.0;
+                if (c < 64 || VARX > 64)
+                    for (int k = 0; k < nn; ++k) { const double coef = (xcol && k != jn) ? K[(N + k * nx + qx) + c * NM] : 0.0; a = std::fma(coef, nuv[k * nx + qx], a); }
+                for (int q = 0; q < nx; ++q) a = std::fma(K[(N + jn * nx + q) + c * NM], nuv[jn * nx + q], a);
+                double hx = last_rhs[c] - a;
+                hx -= (settings.sigma + rho_box[c]) * x[c];
+                Hx[c] = hx;
+            }
+        } else if (hx_identity() && settings.alpha == 1.0 && (int)last_sol.size() == N + M) {
             std::vector<double> ATnu(N);
             matTvec(A, M, N, last_sol.data() + N, ATnu.data());
             for (int i = 0; i < N; ++i) Hx[i] = (last_rhs[i] - (settings.sigma + rho_box[i]) * x[i]) - ATnu[i];
@@ -792,7 +814,7 @@ struct BoxADMM {
             for (int i = 0; i < N; ++i) rhs[i] = ((settings.sigma * x[i] - h[i]) + rho_box[i] * q[i]) - y[M + i];
             for (int i = 0; i < M; ++i) rhs[N + i] = z[i] - rho_inv_vec[i] * y[i];
             kkt_solve(rhs.data(), sol.data());
-            if (hx_identity()) { last_rhs = rhs; last_sol = sol; }
+            last_rhs = rhs; last_sol = sol;
             for (int i = 0; i < N; ++i) x_tilde[i] = sol[i];
             for (int i = 0; i < M; ++i) z_tilde[i] = z_prev[i] + rho_inv_vec[i] * (sol[N + i] - y[i]);
             // quirk Q1 (:129-130): x = alpha*x_tilde; x += (1-alpha)*x

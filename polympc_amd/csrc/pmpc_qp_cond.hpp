@@ -219,6 +219,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
     int status = PMPC_QP_UNSOLVED;
     const double alpha = s.alpha;
     double max_Ax_z_norm = 0.0, max_Hx_ATy_h_norm = 0.0, res_prim = 1.0, res_dual = 1.0, rho_estimate = 0.0;
+    double r1l[2] = {0.0, 0.0}, nul = 0.0;   // first right-hand side and multipliers nu of the LAST solve (the residual evaluation's H x, see there)
     int iter = 1;
     int until_check = s.check_termination, until_adapt = s.adaptive_rho_interval;
     bool running = true;
@@ -261,6 +262,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                     const double rhs1 = ((s.sigma * xv[e] - hve) + rhob[e] * qv[e]) - yb[e];
                     const double a = coldot_fma(e, rhs1);
                     t[e] = isP[e] ? a : 0.0;
+                    r1l[e] = rhs1;
                 }
                 lds_order();
                 if constexpr (SMALL) sol[0] = K.apply(t[0]);
@@ -270,6 +272,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                 lds_order();
                 const double ax = rowdot_fma();
                 const double nu = rhoc * (ax - r2);
+                nul = nu;
                 lds_order();
                 {
                     const double zt = zprev + rhocinv * (nu - ya);
@@ -306,6 +309,27 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                 constexpr int NP1 = SMALL ? 0 : NN - 64;   // primal rows of the second slot
                 constexpr bool FEW1 = !SMALL && NP1 <= 4;   // few of them: products through LDS; otherwise their lanes load their rows
                 constexpr int RCS = 22;
+                // H x of the dual residual (qp_base.hpp:240-252) WITHOUT re-reading H (round 6): the solve that produced x satisfies
+                //     (H + sigma I + rho_box) x~ + A' nu = r1      =>      H x~ = (r1 - A' nu) - (sigma + rho_box) o x~ ,
+                // and x = x~ for alpha = 1 (quirk Q1: x = alpha (2 - alpha) x~). r1 and nu are the last solve's, A' nu is one more fma chain over the tables
+                // (the first product of the solve, started from 0). The reference forms H x by a second mat-vec with H; the two differ by the linear solve's own
+                // residual (~1e-13 relative). Measured with the CPU restatement (PIVOT_CONDSWEEP restates this; EXPERIMENTS.md round 6) on the streams of configs
+                // A / D / B / R: NO instance changes its SQP or ADMM iteration counts, max |dx| 2e-10 (A) .. 2e-7 absolute on a control bounded by 9000 (B).
+                // What it buys: the 35 KB of H (config B) were re-read from L2 / HBM at each of the ~6 residual evaluations per QP — 193 KB fetched per QP against
+                // 62 KB algorithmic — behind 66 + dependent broadcast / multiply / add chains. alpha != 1 or a non-finite iterate: the mat-vec with H, as before.
+                const bool ident = finite && __builtin_amdgcn_readfirstlane((int)(alpha == 1.0)) != 0;
+                if (ident) {
+                    if (isC) us[rc] = nul;
+                    lds_order();
+#pragma unroll
+                    for (int e = 0; e < SL; ++e) {
+                        const double atnu = coldot_fma(e, 0.0);
+                        double hx = r1l[e] - atnu;
+                        hx -= (s.sigma + rhob[e]) * xv[e];
+                        acc[e] = isP[e] ? hx : 0.0;
+                    }
+                    lds_order();
+                }
                 if (finite) {
 #pragma unroll
                     for (int e = 0; e < SL; ++e) if (isP[e]) xs[lp[e]] = xv[e];
@@ -377,7 +401,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                     axz = isC ? a : 0.0;
                 }
                 // H x: the rows of the first slot — RCS loads in flight per batch
-                {
+                if (!ident) {
                     double hx = 0.0;
 #pragma unroll
                     for (int j0 = 0; j0 < NN; j0 += RCS) {
@@ -394,7 +418,8 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                     }
                     acc[0] = hx;
                 }
-                if constexpr (SMALL) {
+                if (ident) {
+                } else if constexpr (SMALL) {
                 } else if constexpr (!FEW1) {   // many primal rows in the second slot: lane l < NP1 loads row 64 + l (the other lanes re-read row 64)
                     double hx1 = 0.0;
 #pragma unroll

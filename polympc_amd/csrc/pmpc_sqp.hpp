@@ -21,6 +21,10 @@
 #include "pmpc_ruiz.hpp"
 #include "pmpc_admm.hpp"
 
+#ifndef PMPC_EXPERIMENT_FORCE_SYMLOWER
+#define PMPC_EXPERIMENT_FORCE_SYMLOWER 0   /* 1: developer experiment (round 6, EXPERIMENTS.md) — the headline kernel's KKT build reads the LOWER triangle of H only (one address select per load): what any
+                                              half / packed storage of the BFGS matrix would cost on the read side */
+#endif
 namespace pmpc {
 
 struct SqpLds {
@@ -1015,7 +1019,7 @@ struct SqpDevice {
             if constexpr (POL) boxadmm_solve_reg2<NN, MM, true, true>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr);
             else boxadmm_solve_reg2<NN, MM, true, true>(Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr, jview());
             wsync();
-        } else if constexpr (REG1) { boxadmm_solve_reg<NN, MM, true, (HU == 1) || POL>(   /* lower-triangle read of H: the block BFGS and a Ruiz-scaled H (D_i H_ij D_j) are not bitwise symmetric */ Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr); wsync(); }
+        } else if constexpr (REG1) { boxadmm_solve_reg<NN, MM, true, (HU == 1) || POL || PMPC_EXPERIMENT_FORCE_SYMLOWER>(   /* lower-triangle read of H: the block BFGS and a Ruiz-scaled H (D_i H_ij D_j) are not bitwise symmetric */ Hw, v.h, Aw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi, qw.x, qw.y, tr, PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr); wsync(); }
         else {
             // Solver<Problem, ADMM<...>>: the launcher sized the QP's LDS for the stacked (2n+m)-row system when qp_solver = 1
             if (RUIZ_COMPILED && __builtin_amdgcn_readfirstlane(ss.qp_solver) == 1) admm_solve(qw, n, m, Hw, ldw, v.h, Aw, ldw, v.al, v.au, v.lx, v.ux, nullptr, nullptr, qs, qi);

@@ -1273,3 +1273,27 @@ def test_null_space_form_cannot_serve_the_minimal_time_problem(oracle):
         assert Ax.shape == (33, 33) and sv[-1] < 1e-12 * sv[0] and sv[-2] < 1e-12 * sv[0]      # singular, twice over
         svf = np.linalg.svd(Ax[:, free], compute_uv=False)
         assert svf[0] / svf[-1] < 100.0                                                          # regular once the pinned columns are known
+
+
+def test_dual_residual_from_the_kkt_identity_changes_no_trajectory(oracle):
+    """Round 6: the condensed register kernels take H x of boxADMM's dual residual from the KKT identity
+    H x~ = (rhs_1 - A' nu) - (sigma + rho_box) o x~ instead of multiplying by H again (qp_base.hpp:240-252) — PIVOT_CONDSWEEP restates exactly that. Admission test,
+    with the order held fixed and the identity switched on and off (orc_set_hx_identity, dense products): on the instance streams of configs A, B and the 16-node
+    robot grid NO instance changes its SQP iterations, status or total ADMM iterations; the iterates move by the rounding of the adaptive-rho estimate only
+    (<= 1e-9 on A and R; config B: <= 1e-4 absolute on controls bounded by 9000, i.e. 1e-8 of their range — measured 3.7e-5 under the Eigen order, 2e-7 under the kernel's)."""
+    import ctypes as C
+    from polympc_amd import workloads
+    L = oracle.lib(); L.orc_set_hx_identity.argtypes = [C.c_int]; L.orc_set_hx_identity.restype = C.c_int
+    for wl, B, model, tol in ((workloads.robot_batch(1024), 1024, oracle.MODEL_ROBOT, 1e-9), (workloads.cstr_batch(512), 512, oracle.MODEL_CSTR, 1e-4),
+                              (workloads.robot_batch(256, P=5, S=3), 256, oracle.MODEL_ROBOT, 1e-9)):
+        ss = oracle.sqp_default_settings(); ss.max_iter = wl["max_iter"]; ss.line_search_max_iter = wl["ls_max_iter"]
+        res = []
+        for on in (0, 1):
+            old = L.orc_set_hx_identity(on)
+            try:
+                res.append(oracle.sqp_solve_batch(model, wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss, pivot=oracle.PIVOT_EIGEN, threads=4))
+            finally:
+                L.orc_set_hx_identity(old)
+        (x0, l0, i0), (x1, l1, i1) = res
+        assert [(i.iter, i.status, i.qp_solver_iter) for i in i0] == [(i.iter, i.status, i.qp_solver_iter) for i in i1]
+        assert np.abs(x0 - x1).max() <= tol and np.abs(x0 - x1).max() > 0.0    # (the switch does something)

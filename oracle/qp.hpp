@@ -390,7 +390,8 @@ struct BoxADMM {
 
     // H x of the dual residual from the KKT identity instead of a second mat-vec with H (round 6):
     //   (H + sigma I + rho_box) x~ + A' nu = rhs_1   =>   H x~ = (rhs_1 - A' nu) - (sigma + rho_box) o x~        (alpha = 1: x = x~, quirk Q1)
-    // * PIVOT_CONDSWEEP restates the condensed register kernel (pmpc_qp_cond.hpp), which does this whenever alpha == 1 and the iterate is finite: A' nu is the
+    // * PIVOT_CONDSWEEP and PIVOT_CONDENSED restate the condensed register kernel (pmpc_qp_cond.hpp) and the large-instance kernel's condensed mode
+    //   (pmpc_qp.hpp, qp_residuals_sparse), which do this whenever alpha == 1 and the iterate is finite: A' nu is the
     //   fma chain of kkt_solve_condsweep's first product started from 0, then one subtraction, one product, one subtraction. The reference (and every other
     //   order here) multiplies by H: qp_base.hpp:240-252. The two differ by the linear solve's own residual; on the streams of configs A / D / B / R no instance
     //   changes an iteration count (tests/test_oracle_pins.py::test_dual_residual_from_the_kkt_identity_changes_no_trajectory).
@@ -416,6 +417,18 @@ struct BoxADMM {
                 if (c < 64 || VARX > 64)
                     for (int k = 0; k < nn; ++k) { const double coef = (xcol && k != jn) ? K[(N + k * nx + qx) + c * NM] : 0.0; a = std::fma(coef, nuv[k * nx + qx], a); }
                 for (int q = 0; q < nx; ++q) a = std::fma(K[(N + jn * nx + q) + c * NM], nuv[jn * nx + q], a);
+                double hx = last_rhs[c] - a;
+                hx -= (settings.sigma + rho_box[c]) * x[c];
+                Hx[c] = hx;
+            }
+        } else if (pivot == PIVOT_CONDENSED && settings.alpha == 1.0 && finite_iterate && (int)last_sol.size() == N + M) {
+            // the large-instance kernel's condensed mode (pmpc_qp.hpp qp_residuals_sparse, ident): A' nu as the fma chain of kkt_solve's first product — the entries of
+            // column c that are not exactly zero, rows ascending — started from 0
+            const int NM = N + M;
+            const double* nuv = last_sol.data() + N;
+            for (int c = 0; c < N; ++c) {
+                double a = 0.0;
+                for (int r = 0; r < M; ++r) { const double v = K[(N + r) + c * NM]; if (v != 0.0) a = std::fma(v, nuv[r], a); }
                 double hx = last_rhs[c] - a;
                 hx -= (settings.sigma + rho_box[c]) * x[c];
                 Hx[c] = hx;

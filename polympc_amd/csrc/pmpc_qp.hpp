@@ -720,9 +720,13 @@ template <bool SLIM, int NW, class JV> __device__ __forceinline__ void big_cond_
 // with the two products formed from the view (pmpc_qp_big.hpp, big_build_condensed; CPU restatement: PIVOT_CONDENSED).
 // residuals_update with A x and A' y formed from the block-sparse view of A (large-instance kernel, condensed mode): the same products in the same
 // order as qp_residuals for finite x, y — the caller tests that — without reading the dense A (two passes over m x n doubles per evaluation)
+// ident (round 6): H x from the KKT identity of the last solve instead of a pass over H (n^2 doubles from HBM per evaluation — config C: 512 KB):
+//     (H + sigma I + rho_box) x~ + A' nu = r1   =>   H x~ = (r1 - A' nu) - (sigma + rho_box) o x~        (alpha = 1: x = x~)
+// r1: the first right-hand side of that solve (the caller saved it in w.t1), nu: its multipliers (w.rhs + n, LDS), A' nu: the fma chain of the solve's first
+// product (big_cond_solve) started from 0. Restated by the CPU checker (PIVOT_CONDENSED); see pmpc_qp_cond.hpp for the admission measurements.
 template <class JV>
 __device__ __forceinline__ void qp_residuals_sparse(const QpLds& w, int n, int m, const double* __restrict__ H, int ldh, const double* __restrict__ h,
-                                                   const JV& jv, QpResidualState& r) {
+                                                   const JV& jv, QpResidualState& r, bool ident = false, double sigma = 0.0) {
     const int ln = lane_id();
     double nAx = 0, nz = 0, nx = 0, rp = 0;
     for (int i0 = 0; i0 < m; i0 += WAVE) {
@@ -740,7 +744,14 @@ __device__ __forceinline__ void qp_residuals_sparse(const QpLds& w, int n, int m
         const typename JV::Col cc = jv.column(ic);
         double bv[JV::NCB > 0 ? JV::NCB : 1];
         jv.col_block(cc, bv);
-        const double a = seq_dot_strided<BIG_MEM_BATCH>(H, (size_t)ldh, 1, ic, n, w.x);
+        double a;
+        if (ident) {
+            double atnu;
+            if constexpr ((int)JV::NG == 0 && (int)JV::NP == 0) atnu = jv.tab ? jv.coldot_fma_tab(cc, bv, w.rhs + n, 0.0) : jv.coldot_fma(cc, bv, w.rhs + n, 0.0);
+            else atnu = jv.coldot_fma(cc, bv, w.rhs + n, 0.0);
+            a = w.t1[ic] - atnu;
+            a -= (sigma + w.rhob[ic]) * w.x[ic];
+        } else a = seq_dot_strided<BIG_MEM_BATCH>(H, (size_t)ldh, 1, ic, n, w.x);
         const double b = jv.coldot_ma(cc, bv, w.y);
         if (i < n) {
             nx = fmax(nx, fabs(w.x[i])); nHx = fmax(nHx, fabs(a)); nATy = fmax(nATy, fabs(b));
@@ -834,7 +845,7 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
                 double pr = 0.0;
                 for (int i = ln; i < n; i += WAVE) pr += w.x[i] - w.x[i];
                 for (int i = ln; i < m; i += WAVE) pr += w.y[i] - w.y[i];
-                if (__builtin_amdgcn_ballot_w64(pr != 0.0) == 0) { qp_residuals_sparse(w, n, m, H, ldh, h, jv, rs); return; }
+                if (__builtin_amdgcn_ballot_w64(pr != 0.0) == 0) { qp_residuals_sparse(w, n, m, H, ldh, h, jv, rs, __builtin_amdgcn_readfirstlane((int)(alpha == 1.0)) != 0, s.sigma); return; }
             }
         }
         qp_residuals(w, n, m, H, ldh, h, A, lda, rs);
@@ -844,6 +855,10 @@ __device__ __forceinline__ void boxadmm_solve(QpLds& w, int n, int m, const doub
     for (iter = 1; iter <= s.max_iter && !gave_up; ++iter) {
         // compute_kkt_rhs (:351-355), z_prev = z
         for (int i = ln; i < n; i += WAVE) w.rhs[i] = ((s.sigma * w.x[i] - h[i]) + w.rhob[i] * w.q[i]) - w.y[m + i];
+        if constexpr (HASJ) {   // condensed mode: the residual evaluation behind this iteration (if any) takes H x from the KKT identity and needs r1 (qp_residuals_sparse)
+            if (cond && ((s.check_termination != 0 && iter % s.check_termination == 0) || (s.adaptive_rho && iter % s.adaptive_rho_interval == 0)))
+                for (int i = ln; i < n; i += WAVE) w.t1[i] = w.rhs[i];
+        }
         for (int i = ln; i < m; i += WAVE) { w.zprev[i] = w.z[i]; w.rhs[n + i] = w.z[i] - w.rhoinv[i] * w.y[i]; }
         wsync();
         { const long long t0 = tick();

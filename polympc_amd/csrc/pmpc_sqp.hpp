@@ -120,6 +120,9 @@ struct SqpDevice {
     __device__ __forceinline__ static long long now() { if constexpr (PROF) return clock64(); else return 0; }
     __device__ __forceinline__ void acc(int i, long long dt) { if constexpr (PROF) cyc[i] += dt; }   // shader-clock cycles: 0 linearise(+BFGS) 1 QP 2 line search 3 termination 4 total 5 BFGS 6 KKT build+factor 7 QP residuals 8 ls node evaluation 9 ls scalar sums 10 first-order staging 11 second-order staging 12 first-order assembly 13 Hessian assembly 14 Lagrangian gradient 16..20 KKT inverse: row loads+staging, panel moves, sweeps, MFMA updates, final conversion 21 ls prologue (mu, grad'p) 22 ls acceptance
 
+#ifdef PMPC_EXPERIMENT_WG_STAMPS
+    long long t_start_stamp = wall_clock64();
+#endif
     __device__ SqpDevice(Ocp<Model>& o, SqpLds& v_, QpLds& q_, double* H_, double* A_, const pmpc_sqp_settings& s, const pmpc_qp_settings& q)
         : ocp(o), v(v_), qw(q_), Hw(H_), Aw(A_), ldw(o.dm.n + o.dm.m), ss(s), qs(q), n(o.dm.n), m(o.dm.m), me(o.dm.me), mi(o.dm.mi) {}
 
@@ -1086,6 +1089,10 @@ struct SqpDevice {
                 double* r = trace + (size_t)(iter - 1) * PMPC_TRACE_DOUBLES;
                 r[0] = (double)iter; r[1] = alpha_log; r[2] = primal_norm; r[3] = dual_norm; r[4] = cost_log;
                 r[5] = (double)qp_iter_last; r[6] = (double)qp_status_last; r[7] = max_violation;
+#ifdef PMPC_EXPERIMENT_WG_STAMPS   /* developer build (tests/experiments/launch_timeline.py): wall-clock stamps (100 MHz) instead of alpha / the step norms — when this iteration ended, when the workgroup started, where it ran */
+                r[1] = (double)wall_clock64(); r[2] = (double)t_start_stamp;
+                { unsigned xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc_)); r[3] = (double)(xcc_ & 7u); }
+#endif
             }
             if (done) { status = PMPC_SQP_SOLVED; break; }
             if (iter >= ss.max_iter) break;

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(WG4 ? 256 : 64, ((NN > 0 && NN + MM <= 64) ? PMPC_S
         if (NN > 0 && (size_t)(p - stage0) < (size_t)QP_STAGING + 2 + ocp.s.const_doubles(P, S)) p = stage0 + QP_STAGING + 2 + ocp.s.const_doubles(P, S);
         stage_end = p;   // end of the per-node staging block: what follows (static parameters, filter) stays live during the line search
     }
-    if constexpr (NN > 0 && NN + MM > WAVE) {   // block-sparse copy of J (pmpc_jview.hpp) for the two-rows-per-lane kernels: lives through the QP, behind the staging its LDS buffers alias
+    if constexpr (NN > 0 && (NN + MM > WAVE || CND)) {   // block-sparse copy of J (pmpc_jview.hpp) for the two-rows-per-lane and the condensed kernels: lives through the QP, behind the staging its LDS buffers alias
         ocp.jblk = p; p += jview_doubles<Model>(ocp.dm.NN); ocp.gblk = ocp.jblk + (size_t)ocp.dm.NN * Model::NX * OcpDims<Model>::JBS; ocp.keep_blk = true;
     }
     double* dL = p; p += (Model::ND > 0 ? Model::ND : 1);
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(WG4 ? 256 : 64, ((NN > 0 && NN + MM <= 64) ? PMPC_S
         if (ln < PMPC_FILTER_STATE_DOUBLES) filt[ln] = carried ? ss.filter_state[(size_t)b * PMPC_FILTER_STATE_DOUBLES + ln] : 0.0;
     }
     double* eigw = nullptr;   // eigenvalue-mirroring regulariser (regularisation = 1): A and V of the Jacobi iteration, 2 n^2 doubles; allocated on request only
-    if constexpr (NN == 0) { if (ss.regularisation == 1) { eigw = p; p += 2 * (size_t)n * n; } }
+    if constexpr (NN == 0 || POL) { if (ss.regularisation == 1) { eigw = p; p += 2 * (size_t)n * n; } }   // (round 6: the hook builds of the register kernels carry the policy too)
     ocp.stage_constants(cd);
     if constexpr (NN == 0 && KHBM) {
         for (int i = ln; i < (P + 1) * (P + 2); i += WAVE) ocp.Dlds[i] = ocp.s.D[i];
@@ -622,6 +622,9 @@ template <> struct LDS_PATH_PROFILED<CstrOCP> { static constexpr bool value = tr
 template <> struct LDS_PATH_PROFILED<KiteStandInOCP> { static constexpr bool value = true; };
 
 // Launch the fused SQP kernel for `Model` on DEVICE buffers (asynchronous on the context's stream).
+#ifndef PMPC_EXPERIMENT_COND_SMALL
+#define PMPC_EXPERIMENT_COND_SMALL 0
+#endif
 #ifndef PMPC_EXPERIMENT_SMALL_POL
 #define PMPC_EXPERIMENT_SMALL_POL 0   /* 2: developer switch — the hook build of the small condensed kernel also under the DEFAULT policies (the bisection of EXPERIMENTS.md round 5, with -DPMPC_EXPERIMENT_CND_WITH_RUIZ) */
 #endif
@@ -634,7 +637,7 @@ inline bool launch_redo_generic(pmpc_context* ctx, const Model& mdl, const ChebD
                                 const pmpc_qp_settings* qs, double* Hws, double* Aws, double* x, double* lam, pmpc_sqp_info* info, hipStream_t stream,
                                 size_t lds_limit) {
     if (pmpc_internal_switch(ctx, PMPC_SW_NO_REDO_LAUNCH)) return true;
-    const size_t ldsg = sqp_kernel_lds_bytes<Model>(P, S, 0, 0);
+    const size_t ldsg = sqp_kernel_lds_bytes<Model>(P, S, 0, 0) + sqp_eig_lds_bytes<Model>(P, S, ss);
     if (ldsg > lds_limit) return true;   // (systems of at most 64 rows always fit)
     auto gk = sqp_kernel<Model>;
     if (hipFuncSetAttribute((const void*)gk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg) != hipSuccess) return false;
@@ -657,12 +660,12 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
     // the policy hooks the reference's tests install beside the defaults — Ruiz preconditioner, filter line search — exist on the register paths
     // for the grids of its own tests (7, 11 and — where the model fits 128 rows — 16 nodes) as separate kernels (POL); any other grid takes the LDS /
     // HBM-resident kernels for them
-    const bool pol = ss->preconditioner == 1 || ss->line_search == 1;
+    const bool pol = ss->preconditioner == 1 || ss->line_search == 1 || ss->regularisation == 1;   // (regularisation = 1, eigenvalue mirroring — sqp_test_autodiff.cpp:29-45: Jacobi workspace of 16 n^2 bytes of LDS, round 6)
     constexpr bool POLK = ((!LEAN && (NNODES == 7 || NNODES == 11)) || NNODES == 16) && (int)OcpDims<Model>::NDER <= RUIZ_MAX_NDER;   // (16 nodes: the reference's mpc_wrapper_test grid, round 4)
     if (pol && !POLK) return false;
     if constexpr (NN_ + MM_ <= WAVE) {
         if (P * S + 1 != NNODES) return false;
-        const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, 1, 0, pol);
+        const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, 1, 0, pol) + sqp_eig_lds_bytes<Model>(P, S, ss);
         if (ldsr > lds_limit) return false;
         if (LEAN && (ss->hessian_update == 1 || phase)) return false;
         pmpc_internal_set_route(ctx, PMPC_ROUTE_REG1);
@@ -671,6 +674,24 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
             kern = (ss->hessian_update == 1) ? sqp_kernel<Model, NN_, MM_, false, 1>   // (no phase timers in the block-BFGS specialisation)
                                              : (phase ? sqp_kernel<Model, NN_, MM_, true> : sqp_kernel<Model, NN_, MM_, false>);
         if constexpr (POLK) { if (pol) kern = (ss->hessian_update == 1) ? sqp_kernel<Model, NN_, MM_, false, 1, false, false, true> : sqp_kernel<Model, NN_, MM_, false, 0, false, false, true>; }
+#if PMPC_EXPERIMENT_COND_SMALL   /* developer experiment (round 6, EXPERIMENTS.md): the CONDENSED register QP (pmpc_qp_cond.hpp) on a grid of at most 64 KKT rows — config A on 35 instead of 56 rows */
+        size_t ldsc = ldsr;
+        if constexpr (!LEAN && NNODES == 7 && Model::NP == 0 && Model::NG == 0) {
+            if (!pol && ss->kkt_form == 0 && ss->hessian_update == 0 && !phase && !pmpc_internal_switch(ctx, PMPC_SW_NO_CONDREG)) {
+                kern = sqp_kernel<Model, NN_, MM_, false, 0, false, false, false, true>;
+                ldsc = sqp_kernel_lds_bytes<Model>(P, S, 5, 0, false);
+                pmpc_internal_set_route(ctx, PMPC_ROUTE_CONDREG);
+            }
+        }
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
+        if (pmpc_internal_last_route(ctx) == PMPC_ROUTE_CONDREG) {
+            hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), ldsc, stream, mdl, cd, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg,
+                               *ss, *qs, Hws, Aws, x, lam, info, phase, (double*)nullptr, 0, ss->max_iter, (double*)nullptr, (unsigned)(ldsc / sizeof(double)));
+            if (!launch_redo_generic<Model>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit)) { *st = PMPC_ERR_HIP; return true; }
+            *st = (hipGetLastError() == hipSuccess) ? PMPC_OK : PMPC_ERR_HIP;
+            return true;
+        }
+#endif
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) { *st = PMPC_ERR_HIP; return true; }
         const int slice = (slice_state && slice_iters > 0) ? slice_iters : ss->max_iter;
         if constexpr (!LEAN) {
@@ -705,7 +726,7 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
         return true;
     } else if constexpr (NN_ + MM_ <= 128) {   // two KKT rows per lane (pmpc_qp_reg2.hpp); the Hessian-update policy is a run-time choice there
         if (P * S + 1 != NNODES) return false;
-        const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, NN_ + MM_ <= 112 ? 3 : 4, 0, pol);
+        const size_t ldsr = sqp_kernel_lds_bytes<Model>(P, S, NN_ + MM_ <= 112 ? 3 : 4, 0, pol) + sqp_eig_lds_bytes<Model>(P, S, ss);
         if (ldsr > lds_limit) return false;
         pmpc_internal_set_route(ctx, PMPC_ROUTE_REG2);
         auto kern = sqp_kernel<Model, NN_, MM_, false>;
@@ -729,7 +750,7 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
             if constexpr (POLK) {   // (round 5: also the one-row-per-lane tile set — its hook build was miscompiled by the never-executed Ruiz calls, which the condensed kernels no longer carry, pmpc_sqp.hpp RUIZ_COMPILED)
                 if (pol && ss->preconditioner == 0 && ss->kkt_form == 0 && !pmpc_internal_switch(ctx, PMPC_SW_NO_CONDREG)) {
                     kern = sqp_kernel<Model, NN_, MM_, false, 0, false, false, true, true>; timed = false;
-                    if constexpr (NN_ > WAVE) ldsq = sqp_kernel_lds_bytes<Model>(P, S, 6, 0, true, (size_t)cond_qp_staging<NN_, MM_, NNODES>());
+                    if constexpr (NN_ > WAVE) ldsq = sqp_kernel_lds_bytes<Model>(P, S, 6, 0, true, (size_t)cond_qp_staging<NN_, MM_, NNODES>()) + sqp_eig_lds_bytes<Model>(P, S, ss);
                     pmpc_internal_set_route(ctx, PMPC_ROUTE_CONDREG);
                 }
             }
@@ -811,7 +832,7 @@ inline pmpc_status sqp_launch_dev(pmpc_context* ctx, const Model& mdl, int P, in
     // kkt_form = 2 asks for the block-structured range-space form where a specialisation is compiled (above); everywhere else it means the default
     pmpc_sqp_settings ss_default_form;
     if (ss->kkt_form == 2) { ss_default_form = *ss; ss_default_form.kkt_form = 0; ss = &ss_default_form; }
-    if (!force_lds && ss->qp_solver == 0 && ss->regularisation != 1 && qs->linear_solver == 0) {   // (preconditioner / line_search = 1: the 7- and 11-node register kernels carry them, see try_launch_reg)   // node counts whose KKT system can fit 64 rows for small models (7 nodes: config A / D); Ruiz: LDS path
+    if (!force_lds && ss->qp_solver == 0 && qs->linear_solver == 0) {   // (preconditioner / line_search = 1: the 7- and 11-node register kernels carry them, see try_launch_reg)   // node counts whose KKT system can fit 64 rows for small models (7 nodes: config A / D); Ruiz: LDS path
         pmpc_status rst = PMPC_OK;
         if (try_launch_reg<Model, 7>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;
         if (try_launch_reg<Model, 5>(ctx, mdl, cd, P, S, B, x_guess, lam_guess, d, lbx, ubx, lbg, ubg, ss, qs, Hws, Aws, x, lam, info, stream, lds_limit, phase, &rst, slice_state, slice_iters)) return rst;

@@ -36,7 +36,7 @@ template <int NN> using CondKkt = typename CondKktSel<NN>::type;
 // LDS the solver needs beside the staging of CondKkt<NN>: nothing — the exchange vectors alias the staging (free between factorisations)
 template <int NN, int MM>
 struct CondDims {
-    static_assert(NN > 0 && NN <= 128 && MM > 0 && MM <= WAVE && NN + MM > WAVE, "condensed register QP: at most 128 variables and 64 constraint rows, more than 64 KKT rows");
+    static_assert(NN > 0 && NN <= 128 && MM > 0 && MM <= WAVE, "condensed register QP: at most 128 variables and 64 constraint rows");
     static constexpr int N = NN + MM;
     static constexpr bool SMALL = NN <= WAVE;
     static constexpr int SL = SMALL ? 1 : 2;                      // primal slots per lane

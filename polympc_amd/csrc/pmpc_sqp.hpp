@@ -644,7 +644,7 @@ struct SqpDevice {
             lagrangian_gradient(v.lg);
             acc(11, l2 - l1); acc(12, l3 - l2); acc(13, l4 - l3); acc(14, now() - l4);
             if (ss.regularisation == 2) regularise_gershgorin();
-            if constexpr (NN == 0) { if (ss.regularisation == 1) regularise_eig_mirror(); }   // (LDS / HBM-resident kernels only: the launcher routes this policy there)
+            if constexpr (HOOKS) { if (ss.regularisation == 1) regularise_eig_mirror(); }   // (LDS / HBM-resident kernels and, since round 6, the hook builds of the register kernels: the launcher routes this policy there)
         } else {
             // J's zeros and D entries are already in place — unless the Ruiz preconditioner scaled and unscaled the workspace around the
             // last QP (sqp_base.hpp:605-609): the round trip leaves rounding noise on every entry, and the reference rebuilds J from

@@ -1091,16 +1091,18 @@ def test_sqp_warm_start_and_gershgorin(ctx, oracle):
 def test_sqp_eigenvalue_mirroring_regulariser(ctx, oracle):
     """regularisation = 1 (the eigenvalue-mirroring hook of sqp_test_autodiff.cpp:29-45) on the device: exact Lagrangian Hessian every iteration
     — indefinite along the way — mirrored by the in-LDS Jacobi iteration, against the CPU restatement's Jacobi: identical trajectories and
-    bit-identical solutions (7- and 5-node robot grids; the policy is served by the LDS-resident kernels)."""
+    bit-identical solutions. Round 6: on the grids of the reference's own tests the policy runs on the hook builds of the REGISTER kernels (7 nodes: one KKT row
+    per lane, the constraint-first sweep; 11 nodes: the condensed register kernel), the Jacobi workspace in their LDS; elsewhere (5 nodes) on the LDS-resident kernel."""
     from polympc_amd import workloads
     import polympc_amd as pa
-    for P, S, B in ((6, 1, 24), (4, 1, 16)):
+    for P, S, B, route, order in ((6, 1, 24, pa.capi.ROUTE_REG1, oracle.PIVOT_SWEEP), (4, 1, 16, pa.capi.ROUTE_LDS, oracle.PIVOT_STATIC), (5, 2, 12, pa.capi.ROUTE_CONDREG, oracle.PIVOT_CONDSWEEP)):
         wl = workloads.robot_batch(B, P=P, S=S)
         ss = pa.sqp_settings_default(); oss = oracle.sqp_default_settings()
         for st in (ss, oss):
             st.max_iter = 6; st.line_search_max_iter = 10; st.regularisation = 1; st.exact_hessian_every_iter = 1
         x, lam, info = ctx.sqp_solve_batch(wl["model"], P, S, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
-        xo, lo, io = oracle.sqp_solve_batch(wl["model"], P, S, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, pivot=oracle.PIVOT_STATIC, threads=8)
+        assert ctx.last_route() == route, (P, S, pa.capi.ROUTE_NAMES.get(ctx.last_route()))
+        xo, lo, io = oracle.sqp_solve_batch(wl["model"], P, S, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, pivot=order, threads=8)
         _assert_same_solve(info, io, x, xo, lam, lo)
         assert np.all(info["flags"] == 0)
     # the Jacobi workspace is 16 n^2 bytes of LDS: a grid that does not leave room for it is refused, not mis-solved

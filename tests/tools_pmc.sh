@@ -6,8 +6,8 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r02}
-CMD=${2:-"python $R/bench.py --steps 5 --warmup 1 --cpu-sample 0 --configs= --no-replay"}
-CMDT=${2:-"python $R/bench.py --steps 10 --warmup 2 --cpu-sample 0 --configs= --no-replay"}
+CMD=${2:-"python $R/bench.py --steps 5 --warmup 1 --cpu-sample 0 --configs= --no-replay --detail-out= "}
+CMDT=${2:-"python $R/bench.py --steps 10 --warmup 2 --cpu-sample 0 --configs= --no-replay --detail-out= "}
 cd $R
 run() { name=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${TAG}_$name -o $name -- $CMD > $R/gpurun_out/pmc_${TAG}_$name.log 2>&1; }
 # ONLY=tcc tests/tools_pmc.sh TAG [CMD]: just the L2 hit / miss pass (added to an existing collection of the same tag)

@@ -173,7 +173,8 @@ struct sqp_settings_t {   // sqp_base.hpp:24-47 (+ the two override points as fl
     int line_search = 0;               // step_size_selection_impl: 0 l1-merit backtracking (sqp_base.hpp:380-419), 1 the filter line search
                                        // of valet_parking_mpc_test.cpp:116-158 on LSFilter (line_search.hpp:31-98)
     int kkt_form = 0;                  // pmpc_sqp_settings::kkt_form: 0 the kernels' default (large instances solve the condensed n x n system), 1 the
-                                       // reference's quasi-definite (n + m)-row KKT matrix of box_admm.hpp:209-223 on every route
+                                       // reference's quasi-definite (n + m)-row KKT matrix of box_admm.hpp:209-223 on every route, 2 the block-structured
+                                       // range-space form wherever it is compiled — including the bordered NP = 1 form (parking, 11 nodes), which is not a default
     void (*iteration_callback)(void* solver) = nullptr;   // sqp_base.hpp:33, called at :685-686 once per iteration from the second one on. The fused
                                        // kernel records what the callback can read (pmpc_sqp_settings::iteration_trace); Solver<OCP>::solve() then
                                        // calls it once per recorded iteration with info().iter, primal_norm(), dual_norm(), cost() and

@@ -563,8 +563,9 @@ def _sqp_both(ctx, oracle, wl, B, **kw):
     n = wl["lbx"].shape[1]; dm = oracle.ocp_dims(wl["model"], wl["P"], wl["S"])
     # (preconditioner = 1, qp_solver = 1 and line_search = 1 are served by the LDS-resident QP kernels whatever the size: static LDL^T
     #  order; hessian_update = 1 has register-resident specialisations like the default)
+    # (regularisation = 1, eigenvalue mirroring: the hook builds of the register kernels since round 6 — the same routing as the other two hooks)
     if kw.get("qp_solver", 0): order = oracle.PIVOT_STATIC
-    elif kw.get("preconditioner", 0) or kw.get("line_search", 0): order = _policy_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, ruiz=bool(kw.get("preconditioner", 0)), block_bfgs=bool(kw.get("hessian_update", 0)), kkt_form=kf, ng=dm["ng"])
+    elif kw.get("preconditioner", 0) or kw.get("line_search", 0) or kw.get("regularisation", 0) == 1: order = _policy_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, ruiz=bool(kw.get("preconditioner", 0)), block_bfgs=bool(kw.get("hessian_update", 0)), kkt_form=kf, ng=dm["ng"])
     else: order = _gpu_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, block_bfgs=bool(kw.get("hessian_update", 0)), kkt_form=kf, ng=dm["ng"],
                              schur=_schur_route(wl["model"], wl["P"], wl["S"], **kw))
     xo, lo, io = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"],

@@ -22,7 +22,8 @@ def main():
     ctx = pa.Context(0)
     bad = 0
     grids = [(P, S) for P in range(2, 8) for S in range(1, 4) if 3 <= P * S + 1 <= 16]
-    policies = [dict(), dict(hessian_update=1), dict(preconditioner=1), dict(line_search=1), dict(qp_solver=1), dict(preconditioner=1, line_search=1, hessian_update=1), dict(kkt_form=1)]
+    policies = [dict(), dict(hessian_update=1), dict(preconditioner=1), dict(line_search=1), dict(qp_solver=1), dict(preconditioner=1, line_search=1, hessian_update=1), dict(kkt_form=1),
+                dict(regularisation=1, exact_hessian_every_iter=1)]   # (round 6: eigenvalue mirroring — the hook builds of the register kernels on 7 / 11 / 16 nodes, the LDS / HBM-resident kernels elsewhere)
     for model in (0, 1):
         for P, S in grids:
             dm = ob.ocp_dims(model, P, S)
@@ -33,6 +34,7 @@ def main():
                 wl = dict(model=1, P=P, S=S, t0=0.0, tf=100.0, d=np.zeros((B, 1)), lbx=lbx, ubx=ubx, max_iter=6, ls_max_iter=20)
             for kw in policies:
                 if kw.get("qp_solver") and 2 * dm["n"] + dm["m"] > 190: continue    # the stacked system lives in LDS only
+                if kw.get("regularisation") == 1 and dm["n"] > 80: continue          # the Jacobi workspace is 16 n^2 bytes of LDS
                 try:
                     (x, lam, info), (xo, lo, io) = T._sqp_both(ctx, ob, wl, B, **kw)
                     T._assert_same_solve(info, io, x, xo, lam, lo)

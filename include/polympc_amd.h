@@ -131,7 +131,8 @@ typedef struct {
     int kkt_form;         /* large instances (KKT factor in HBM): 0 (default) condensed — the diagonal constraint block of the KKT matrix is eliminated in
                            * closed form and the n x n matrix H + sigma I + rho_box + A' diag(rho) A is factorised (same solution in exact arithmetic,
                            * box_admm.hpp:209-223 / :123 restated as PIVOT_CONDENSED); 1 the (n+m) x (n+m) KKT matrix as the reference builds it
-                           * (register kernels: the full inverse instead of the condensed / constraint-first forms; never a conditioning gate);
+                           * (grids of 65 .. 128 KKT rows: the two-rows-per-lane full inverse instead of the condensed register kernel, no conditioning
+                           * rule; grids of at most 64 rows keep their constraint-first sweep and its bounds rule, whose redo launch IS the full form);
                            * 2 (round 6) the block-structured range-space form wherever a specialisation is compiled, INCLUDING the grids on which
                            * it is not the default because their instances are expected to meet its conditioning gate (parking, NP = 1, 11 nodes:
                            * the bordered form — such instances are re-solved by the redo launch, see PMPC_FLAG_ILLCOND); elsewhere the same as 0.

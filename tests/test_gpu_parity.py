@@ -1304,6 +1304,36 @@ def test_cstr_short_horizon_tight_pin_against_the_reference_order(ctx, oracle, h
     assert r["scaled_dx_per_instance"]["max"] <= 1e-9 and r["scaled_dlam_per_instance"]["max"] <= 1e-9 and r["max_abs_d_constraint_violation"] <= 1e-10
 
 
+@pytest.mark.parametrize("alpha", [1.0, 1.6])
+def test_dual_residual_identity_and_its_fallback(ctx, oracle, alpha):
+    """Round 6: the condensed kernels take H x of boxADMM's dual residual from the KKT identity of the last solve when alpha == 1 (x = x~, quirk Q1) and multiply by
+    H, as the reference does (qp_base.hpp:240-252), for any other relaxation parameter. Both branches against the restatement that states the same rule — config B and
+    the 16-node robot grid on the condensed register kernel (PIVOT_CONDSWEEP), two kite-sized instances on the large-instance kernel (PIVOT_CONDENSED) — bit for bit;
+    with alpha = 1 the residuals the QPs report must also agree with the reference order's to 1e-8 although they are formed differently."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    from oracle import cross_order as tco
+    cases = [(tco.config_workload("B", B=48)[0], 48, pa.capi.ROUTE_CONDREG, oracle.PIVOT_CONDSWEEP, 3),
+             (workloads.robot_batch(32, P=5, S=3), 32, pa.capi.ROUTE_CONDREG, oracle.PIVOT_CONDSWEEP, 3),
+             (workloads.kite_standin_batch(2), 2, pa.capi.ROUTE_HBM, oracle.PIVOT_CONDENSED, 2)]
+    for wl, B, route, order, iters in cases:
+        ss = pa.sqp_settings_default(); oss = oracle.sqp_default_settings()
+        for st in (ss, oss):
+            st.max_iter = iters; st.line_search_max_iter = wl["ls_max_iter"]
+        qs = pa.qp_settings_sqp_default(); oqs = oracle.sqp_qp_default_settings()
+        qs.alpha = alpha; oqs.alpha = alpha
+        x, lam, info = ctx.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss, qp_settings=qs)
+        assert ctx.last_route() == route
+        xo, lo, io = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, qp_settings=oqs,
+                                            pivot=order, threads=8)
+        _assert_same_solve(info, io, x, xo, lam, lo)
+        if alpha == 1.0:   # the identity changes no count against the reference order either
+            with oracle.libm():
+                xr, lr, ir = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=oss, qp_settings=oqs,
+                                                    pivot=oracle.PIVOT_EIGEN, threads=8)
+            assert [(int(a), int(b)) for a, b in zip(info["iter"], info["qp_solver_iter"])] == [(i.iter, i.qp_solver_iter) for i in ir]
+
+
 @pytest.mark.parametrize("rho0", [10.0, 1e3, 1e5])
 def test_condensed_register_kernel_under_a_large_penalty(ctx, oracle, rho0):
     """The condensed register kernel with the QP's penalty started at rho = 10 / 1e3 / 1e5 (rho_eq up to 1e8; RHO_MAX = 1e6, box_admm.hpp:56-59): the kernel

@@ -408,9 +408,14 @@ struct BoxADMM {
         for (int i = 0; i < N; ++i) finite_iterate = finite_iterate && std::isfinite(x[i]);
         for (int i = 0; i < M; ++i) finite_iterate = finite_iterate && std::isfinite(y[i]);
         if (pivot == PIVOT_CONDSWEEP && settings.alpha == 1.0 && finite_iterate && (int)last_sol.size() == N + M) {
-            const int NM = N + M, nx = schur.nx, nu = schur.nu, nn = schur.nn, VARX = nx * nn;
+            const int NM = N + M, nx = schur.nx, nu = schur.nu, nn = schur.nn, VARX = nx * nn, N0 = N - schur.np;
             const double* nuv = last_sol.data() + N;
-            for (int c = 0; c < N; ++c) {
+            if (schur.np) {   // the parameter's column: the wavefront's tree (cond_wave_dot)
+                double hx = last_rhs[N0] - cond_wave_dot(nuv);
+                hx -= (settings.sigma + rho_box[N0]) * x[N0];
+                Hx[N0] = hx;
+            }
+            for (int c = 0; c < N0; ++c) {
                 const bool xcol = c < VARX;
                 const int jn = xcol ? c / nx : (c - VARX) / nu, qx = xcol ? c - jn * nx : 0;
                 double a = 0.0;
@@ -729,12 +734,22 @@ struct BoxADMM {
     // the two products as the kernel forms them (pmpc_qp_cond.hpp): fma chains — the differentiation-matrix entries of the column / row over the nodes
     // ascending (0 on the own node and outside the segments; a control column of the first 64 variables walks zeros), then the own node's block. Needs the
     // collocation structure (schur.nx, .nu, .nn): no path constraints, no parameters.
+    // NP = 1 (round 6): the parameter is the last primal variable, its column of A is DENSE. Its entry of the first product is formed the way the wavefront forms it —
+    // lane r multiplies A(r, p) with its own u_r, the 64 products are added pairwise over adjacent lanes, level by level (cond_wave_dot; the tree of wave_sum,
+    // pmpc_qp.hpp) — and every row of the second product takes A(r, p) x_p as its last term (the parameter is the last column).
+    double cond_wave_dot(const double* u) const {
+        const int NM = N + M, N0 = N - schur.np;
+        double part[64];
+        for (int l = 0; l < 64; ++l) part[l] = (l < M) ? K[(N + l) + (size_t)N0 * NM] * u[l] : 0.0;
+        for (int w = 1; w < 64; w *= 2) for (int l = 0; l < 64; l += 2 * w) part[l] = part[l] + part[l + w];
+        return part[0];
+    }
     void kkt_solve_condsweep(const double* rhs, double* sol) {
-        const int NM = N + M, nx = schur.nx, nu = schur.nu, nn = schur.nn, VARX = nx * nn;
-        if (nx < 1 || nn < 1 || nx * nn != M || (nx + nu) * nn != N) throw std::invalid_argument("oracle: PIVOT_CONDSWEEP needs the collocation structure of the QP (nx, nu, nn)");
+        const int NM = N + M, nx = schur.nx, nu = schur.nu, nn = schur.nn, VARX = nx * nn, np_ = schur.np, N0 = N - np_;
+        if (nx < 1 || nn < 1 || np_ < 0 || np_ > 1 || nx * nn != M || (nx + nu) * nn + np_ != N) throw std::invalid_argument("oracle: PIVOT_CONDSWEEP needs the collocation structure of the QP (nx, nu, nn[, np <= 1])");
         std::vector<double> u(M), t(N), xs(N);
         for (int r = 0; r < M; ++r) u[r] = rho_vec[r] * rhs[N + r];
-        for (int c = 0; c < N; ++c) {
+        for (int c = 0; c < N0; ++c) {
             const bool xcol = c < VARX;
             const int jn = xcol ? c / nx : (c - VARX) / nu, qx = xcol ? c - jn * nx : 0;
             double a = rhs[c];
@@ -743,6 +758,7 @@ struct BoxADMM {
             for (int q = 0; q < nx; ++q) a = std::fma(K[(N + jn * nx + q) + c * NM], u[jn * nx + q], a);
             t[c] = a;
         }
+        if (np_) t[N0] = rhs[N0] + cond_wave_dot(u.data());
         ldlt.solve(t.data(), xs.data());
         for (int i = 0; i < N; ++i) sol[i] = xs[i];
         for (int r = 0; r < M; ++r) {
@@ -751,6 +767,7 @@ struct BoxADMM {
             for (int j = 0; j < nn; ++j) { const double coef = (j != k) ? K[(N + r) + (j * nx + q) * NM] : 0.0; a = std::fma(coef, xs[j * nx + q], a); }
             for (int i = 0; i < nx; ++i) a = std::fma(K[(N + r) + (k * nx + i) * NM], xs[k * nx + i], a);
             for (int i = 0; i < nu; ++i) a = std::fma(K[(N + r) + (VARX + k * nu + i) * NM], xs[VARX + k * nu + i], a);
+            if (np_) a = std::fma(K[(N + r) + (size_t)N0 * NM], xs[N0], a);
             sol[N + r] = rho_vec[r] * (a - rhs[N + r]);
         }
     }

@@ -150,17 +150,20 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
     //   column c of node jn, state qx:  t = r1;  t = fma(D~(k, jn), u(k, qx), t) for the nodes k ascending (0 on the own node and outside the segments
     //                                   that hold jn; a control column reads the all-zero row);  t = fma(J((jn, q), c), u(jn, q), t) for q ascending
     //   row (k, q):                     a = 0;   a = fma(D~(k, j), x(j, q), a) for the nodes j ascending;  then the own node's block, columns ascending
-    constexpr int NX = JV::NX, NU = JV::NU, NDER = JV::NDER, JBS = JV::JBS, NNODES = MM / NX, NNP = lds_row_stride(NNODES), VARX = NX * NNODES;
-    static_assert((int)JV::NG == 0 && (int)JV::NP == 0 && NNODES * NX == MM && NNODES * (NX + NU) == NN, "condensed register QP: no path constraints, no parameters");
+    constexpr int NX = JV::NX, NU = JV::NU, NPAR = JV::NP, NDER = JV::NDER, JBS = JV::JBS, NNODES = MM / NX, NNP = lds_row_stride(NNODES), VARX = NX * NNODES;
+    constexpr int P0 = (NX + NU) * NNODES;   // NP = 1 (round 6): the parameter is the last primal variable, its column of A is DENSE (rows ascending: entry NX + NU of every row's block)
+    static_assert((int)JV::NG == 0 && NPAR <= 1 && NNODES * NX == MM && P0 + NPAR == NN, "condensed register QP: no path constraints, at most one parameter");
     double* Dt = tr + CD::TAB_OFF;
     static_assert(CD::TAB_OFF + CD::template tab_doubles<NNODES>() <= CondKkt<NN>::TRI, "tables fit the staging");
     const double* DtT = Dt + NNODES * NNP;
     const double *cD[2] = {nullptr, nullptr}, *cU[2] = {nullptr, nullptr}, *cB[2] = {nullptr, nullptr}, *cV[2] = {nullptr, nullptr};   // per primal slot: D~ column, u at the column's state index, own-node block column, u of the own node
+    bool isp[2] = {false, false};   // this slot holds the parameter (NP = 1): its entry of A' u is a wave reduction, not a chain over the tables
 #pragma unroll
     for (int e = 0; e < SL; ++e) {
         const int c = lp[e];
         const bool xcol = c < VARX;
-        const int cu = c - VARX;
+        isp[e] = NPAR > 0 && isP[e] && c >= P0;
+        const int cu = isp[e] ? 0 : c - VARX;     // (the parameter's lane walks a control column's addresses: its chain is discarded)
         const int jn = xcol ? c / NX : cu / NU;
         const int dcol = xcol ? c - jn * NX : NX + (cu - jn * NU);
         cD[e] = xcol ? DtT + jn * NNP : Dt + 4 * NNODES * NNP;
@@ -174,6 +177,10 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
     const double* rB = jv.jblk + rc * JBS;
     const double* rV = xs + rk * NX;
     const double* rW = xs + VARX + rk * NU;
+    // NP = 1: A(r, p) of this lane's row — constant over the QP (one LDS read), 0 on the lanes without a row
+    double arp = 0.0;
+    if constexpr (NPAR > 0) { const double v_ = jv.jblk[rc * JBS + NX + NU]; arp = isC ? v_ : 0.0; }
+    (void)arp;
     constexpr bool SLOT1_STATES = VARX > 64;       // state columns in the second slot?
     constexpr int CH = SMALL ? 4 : NNODES;         // D~ entries per batch of LDS reads in the two products
     auto coldot_fma = [&](int e, double init) -> double {
@@ -213,7 +220,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
 #pragma unroll
         for (int i = 0; i < NU; ++i) { bv[NX + i] = rB[NX + i]; xb[NX + i] = rW[i]; }
 #pragma unroll
-        for (int i = 0; i < NDER; ++i) a = fma(bv[i], xb[i], a);
+        for (int i = 0; i < NX + NU; ++i) a = fma(bv[i], xb[i], a);   // (NP = 1: the caller appends the parameter's term)
         return a;
     };
     int status = PMPC_QP_UNSOLVED;
@@ -251,8 +258,11 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
             for (int kk = 0; kk < nrun; ++kk) {
                 const double zprev = zv;
                 const double r2 = zv - rhocinv * ya;                       // compute_kkt_rhs, box_admm.hpp:351-355
-                if (isC) us[rc] = rhoc * r2;
+                const double uval = rhoc * r2;
+                if (isC) us[rc] = uval;
                 lds_order();
+                double psum = 0.0;   // NP = 1: sum_r A(r, p) u_r — lane r forms its product, the 64 products are added by the DPP tree of wave_sum (restated: cond_wave_dot)
+                if constexpr (NPAR > 0) psum = wave_sum(arp * uval);
                 double t[2] = {0.0, 0.0}, sol[2] = {0.0, 0.0};
 #pragma unroll
                 for (int e = 0; e < SL; ++e) {
@@ -262,6 +272,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                     const double rhs1 = ((s.sigma * xv[e] - hve) + rhob[e] * qv[e]) - yb[e];
                     const double a = coldot_fma(e, rhs1);
                     t[e] = isP[e] ? a : 0.0;
+                    if constexpr (NPAR > 0) t[e] = isp[e] ? rhs1 + psum : t[e];
                     r1l[e] = rhs1;
                 }
                 lds_order();
@@ -270,7 +281,8 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
 #pragma unroll
                 for (int e = 0; e < SL; ++e) if (isP[e]) xs[lp[e]] = sol[e];
                 lds_order();
-                const double ax = rowdot_fma();
+                double ax = rowdot_fma();
+                if constexpr (NPAR > 0) ax = fma(arp, xs[P0], ax);         // the parameter: the last column of the row
                 const double nu = rhoc * (ax - r2);
                 nul = nu;
                 lds_order();
@@ -321,9 +333,12 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                 if (ident) {
                     if (isC) us[rc] = nul;
                     lds_order();
+                    double pnu = 0.0;
+                    if constexpr (NPAR > 0) pnu = wave_sum(arp * nul);
 #pragma unroll
                     for (int e = 0; e < SL; ++e) {
-                        const double atnu = coldot_fma(e, 0.0);
+                        double atnu = coldot_fma(e, 0.0);
+                        if constexpr (NPAR > 0) atnu = isp[e] ? pnu : atnu;
                         double hx = r1l[e] - atnu;
                         hx -= (s.sigma + rhob[e]) * xv[e];
                         acc[e] = isP[e] ? hx : 0.0;
@@ -363,6 +378,20 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                         }
                         aty[e] = isP[e] ? a : 0.0;
                     }
+                    if constexpr (NPAR > 0) {   // the parameter's column in the reference's order: sum_r A(r, p) y_r, rows ascending (multiply, then add) — a serial chain every lane walks, the parameter's lane keeps it
+                        double a = 0.0;
+                        constexpr int CHP = 11;
+#pragma unroll
+                        for (int r0 = 0; r0 < MM; r0 += CHP) {
+                            double av[CHP], yv[CHP];
+#pragma unroll
+                            for (int r = 0; r < CHP; ++r) { const int rr = (r0 + r < MM) ? r0 + r : 0; av[r] = jv.jblk[rr * JBS + NX + NU]; yv[r] = us[rr]; }
+#pragma unroll
+                            for (int r = 0; r < CHP; ++r) if (r0 + r < MM) a += av[r] * yv[r];
+                        }
+#pragma unroll
+                        for (int e = 0; e < SL; ++e) aty[e] = isp[e] ? a : aty[e];
+                    }
                     {
                         double a = 0.0;
                         const double* rl = Dlo + rk * NNP;
@@ -380,7 +409,8 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
 #pragma unroll
                         for (int j = 0; j < NNODES; ++j) a += (dv[j] - lv[j]) * xq[j];
 #pragma unroll
-                        for (int i = NX; i < NDER; ++i) a += bv[i] * xb[i];
+                        for (int i = NX; i < NX + NU; ++i) a += bv[i] * xb[i];
+                        if constexpr (NPAR > 0) a += arp * xs[P0];   // the last column
                         axz = isC ? a : 0.0;
                     }
                     (void)Dlo; (void)DtTlo;

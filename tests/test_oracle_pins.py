@@ -1297,3 +1297,23 @@ def test_dual_residual_from_the_kkt_identity_changes_no_trajectory(oracle):
         (x0, l0, i0), (x1, l1, i1) = res
         assert [(i.iter, i.status, i.qp_solver_iter) for i in i0] == [(i.iter, i.status, i.qp_solver_iter) for i in i1]
         assert np.abs(x0 - x1).max() <= tol and np.abs(x0 - x1).max() > 0.0    # (the switch does something)
+
+
+def test_condensed_register_order_with_one_parameter_on_the_minimal_time_problem(oracle):
+    """Round 6: PIVOT_CONDSWEEP with NP = 1 (the parameter's dense column of A' u as the wavefront's tree sum, its term last in every row of A x) — the order of the
+    condensed register kernel that now serves the reference's minimal-time parking test (minimal_time_test.cpp:146-188: exact Hessians, Gershgorin, NP = 1) by default.
+    Admission on 32 perturbed instances of that problem, as the reference configures it: every instance keeps the SQP / ADMM iteration counts and the status of the run
+    as the reference computes (Eigen-style pivoted LDL^T, glibc) — and it is the condensed order that stays with exact arithmetic (PIVOT_EXACT: every linear solve refined
+    in long double): 1e-7 against the reference order's own 1e-5 .. 1e-4. (No conditioning rule trips: controls and the parameter are bounded.)"""
+    B = 32
+    lbx, ubx, xg, d = _parking_batch(B)
+    ss = oracle.sqp_default_settings(); ss.max_iter = 20; ss.line_search_max_iter = 10; ss.regularisation = 2; ss.exact_hessian_every_iter = 1
+    run = lambda piv: oracle.sqp_solve_batch(oracle.MODEL_PARKING, 5, 2, 0.0, 1.0, B, d, lbx, ubx, x_guess=xg, sqp_settings=ss, pivot=piv, threads=4)
+    xc, lc, ic = run(oracle.PIVOT_CONDSWEEP)
+    xe, le, ie = run(oracle.PIVOT_EIGEN)
+    xx, lx, ix = run(oracle.PIVOT_EXACT)
+    key = lambda info: [(i.iter, i.status, i.qp_solver_iter) for i in info]
+    assert key(ic) == key(ie) == key(ix)
+    assert all(i.flags == 0 for i in ic) and sum(i.status == 0 for i in ic) >= B - 4
+    dc, de = np.abs(xc - xx).max(), np.abs(xe - xx).max()
+    assert dc < 1e-7 and dc < 0.01 * de, (dc, de)

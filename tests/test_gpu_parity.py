@@ -555,8 +555,13 @@ def _sqp_both(ctx, oracle, wl, B, **kw):
     ss = pa.sqp_settings_default(); ss.max_iter = wl["max_iter"]; ss.line_search_max_iter = wl["ls_max_iter"]
     for k, v in kw.items():
         setattr(ss, k, v)
-    x, lam, info = ctx.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss)
+    for k, v in wl.get("settings", {}).items():   # (settings of the workload itself, e.g. the minimal-time problem's exact Hessians + Gershgorin shift)
+        if k not in kw: setattr(ss, k, v)
+    gk = dict(x_guess=wl["x_guess"]) if "x_guess" in wl else {}
+    x, lam, info = ctx.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss, **gk)
     oss = oracle.sqp_default_settings(); oss.max_iter = wl["max_iter"]; oss.line_search_max_iter = wl["ls_max_iter"]
+    for k, v in wl.get("settings", {}).items():
+        if k not in kw: setattr(oss, k, v)
     for k, v in kw.items():
         if k != "kkt_form": setattr(oss, k, v)   # (how the large-instance kernel arranges its linear algebra: a pivot policy on the CPU side)
     kf = kw.get("kkt_form", 0)
@@ -569,7 +574,7 @@ def _sqp_both(ctx, oracle, wl, B, **kw):
     else: order = _gpu_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, block_bfgs=bool(kw.get("hessian_update", 0)), kkt_form=kf, ng=dm["ng"],
                              schur=_schur_route(wl["model"], wl["P"], wl["S"], **kw))
     xo, lo, io = oracle.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"],
-                                        sqp_settings=oss, pivot=order, threads=8)
+                                        sqp_settings=oss, pivot=order, threads=8, **gk)
     return (x, lam, info), (xo, lo, io)
 
 

@@ -1,4 +1,4 @@
-"""Developer tool (GPU): GPU vs CPU restatement over the routing table of the fused SQP kernel — every grid of 3..16 nodes of the robot and CSTR models
+"""Developer tool (GPU): GPU vs CPU restatement over the routing table of the fused SQP kernel — every grid of 3..16 nodes of the robot, CSTR and (NP = 1) parking models
 (register paths, LDS-resident kernel, HBM-factor kernel) under the default policy and the policies that change the route (block BFGS, Ruiz, filter line
 search, OSQP-form ADMM). Prints one line per combination; exits non-zero when anything is not bit-identical.
 
@@ -24,11 +24,15 @@ def main():
     grids = [(P, S) for P in range(2, 8) for S in range(1, 4) if 3 <= P * S + 1 <= 16]
     policies = [dict(), dict(hessian_update=1), dict(preconditioner=1), dict(line_search=1), dict(qp_solver=1), dict(preconditioner=1, line_search=1, hessian_update=1), dict(kkt_form=1),
                 dict(regularisation=1, exact_hessian_every_iter=1)]   # (round 6: eigenvalue mirroring — the hook builds of the register kernels on 7 / 11 / 16 nodes, the LDS / HBM-resident kernels elsewhere)
-    for model in (0, 1):
+    from test_oracle_pins import _parking_batch
+    for model in (0, 1, pa.MODEL_PARKING):
         for P, S in grids:
             dm = ob.ocp_dims(model, P, S)
             if model == 0:
                 wl = workloads.robot_batch(B, P=P, S=S); wl["max_iter"] = 6
+            elif model == pa.MODEL_PARKING:   # (round 6) NP = 1: the reference's minimal-time problem, perturbed per instance, on every grid its register kernels exist for
+                lbx, ubx, xg, d = _parking_batch(B, P * S + 1)
+                wl = dict(model=model, P=P, S=S, t0=0.0, tf=1.0, d=d, lbx=lbx, ubx=ubx, x_guess=xg, max_iter=6, ls_max_iter=10, settings=dict(regularisation=2, exact_hessian_every_iter=1))
             else:
                 lbx, ubx = T._cstr_grid(B, P, S)
                 wl = dict(model=1, P=P, S=S, t0=0.0, tf=100.0, d=np.zeros((B, 1)), lbx=lbx, ubx=ubx, max_iter=6, ls_max_iter=20)

@@ -202,7 +202,7 @@ def _cond_check(structure, n, m):
     if structure is None:
         raise ValueError("PIVOT_CONDSWEEP: pass structure=(nx, nu, nn, P)")
     nx, nu, nn, P = structure[:4]
-    if (nx + nu) * nn != n or nx * nn != m or m > 64 or n > COND_MAX_ROWS:
+    if (nx + nu) * nn != n or m < nx * nn or (m - nx * nn) % nn != 0 or m > 64 or n > COND_MAX_ROWS:
         raise ValueError(f"PIVOT_CONDSWEEP: structure {structure} does not describe a QP with n = {n} <= {COND_MAX_ROWS}, m = {m} <= 64")
     lib().orc_set_schur_structure(nx, nu, nn, P)
 
@@ -338,8 +338,8 @@ def sqp_solve_batch(model, P, S, t0, tf, B, d, lbx, ubx, lbg=None, ubg=None, x_g
     ss = sqp_settings or sqp_default_settings(); qs = qp_settings or sqp_qp_default_settings()
     if pivot == PIVOT_SCHUR:
         _sqp_schur_check(dm, P, ss)
-    if pivot == PIVOT_CONDSWEEP and (dm["np"] > 1 or dm["ng"] != 0 or m > 64 or n > COND_MAX_ROWS):
-        raise ValueError("PIVOT_CONDSWEEP restates the condensed register kernel: NP <= 1, NG = 0, n <= 112, m <= 64")
+    if pivot == PIVOT_CONDSWEEP and (dm["np"] > 1 or m > 64 or n > COND_MAX_ROWS):
+        raise ValueError("PIVOT_CONDSWEEP restates the condensed register kernel: NP <= 1, n <= 112, m <= 64")
     x = np.zeros((B, n)); lam = np.zeros((B, m + n)); info = (SQPInfo * B)()
     mp = _f(mparams) if mparams is not None else None
     dp = C.POINTER(C.c_double)

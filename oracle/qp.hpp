@@ -408,7 +408,7 @@ struct BoxADMM {
         for (int i = 0; i < N; ++i) finite_iterate = finite_iterate && std::isfinite(x[i]);
         for (int i = 0; i < M; ++i) finite_iterate = finite_iterate && std::isfinite(y[i]);
         if (pivot == PIVOT_CONDSWEEP && settings.alpha == 1.0 && finite_iterate && (int)last_sol.size() == N + M) {
-            const int NM = N + M, nx = schur.nx, nu = schur.nu, nn = schur.nn, VARX = nx * nn, N0 = N - schur.np;
+            const int NM = N + M, nx = schur.nx, nu = schur.nu, nn = schur.nn, VARX = nx * nn, N0 = N - schur.np, ME = nx * nn, ng = (M - ME) / nn;
             const double* nuv = last_sol.data() + N;
             if (schur.np) {   // the parameter's column: the wavefront's tree (cond_wave_dot)
                 double hx = last_rhs[N0] - cond_wave_dot(nuv);
@@ -422,6 +422,7 @@ struct BoxADMM {
                 if (c < 64 || VARX > 64)
                     for (int k = 0; k < nn; ++k) { const double coef = (xcol && k != jn) ? K[(N + k * nx + qx) + c * NM] : 0.0; a = std::fma(coef, nuv[k * nx + qx], a); }
                 for (int q = 0; q < nx; ++q) a = std::fma(K[(N + jn * nx + q) + c * NM], nuv[jn * nx + q], a);
+                for (int g = 0; g < ng; ++g) a = std::fma(K[(N + ME + jn * ng + g) + c * NM], nuv[ME + jn * ng + g], a);
                 double hx = last_rhs[c] - a;
                 hx -= (settings.sigma + rho_box[c]) * x[c];
                 Hx[c] = hx;
@@ -733,7 +734,7 @@ struct BoxADMM {
     }
     // the two products as the kernel forms them (pmpc_qp_cond.hpp): fma chains — the differentiation-matrix entries of the column / row over the nodes
     // ascending (0 on the own node and outside the segments; a control column of the first 64 variables walks zeros), then the own node's block. Needs the
-    // collocation structure (schur.nx, .nu, .nn): no path constraints, no parameters.
+    // collocation structure (schur.nx, .nu, .nn; ng from m = (nx + ng) nn).
     // NP = 1 (round 6): the parameter is the last primal variable, its column of A is DENSE. Its entry of the first product is formed the way the wavefront forms it —
     // lane r multiplies A(r, p) with its own u_r, the 64 products are added pairwise over adjacent lanes, level by level (cond_wave_dot; the tree of wave_sum,
     // pmpc_qp.hpp) — and every row of the second product takes A(r, p) x_p as its last term (the parameter is the last column).
@@ -746,7 +747,10 @@ struct BoxADMM {
     }
     void kkt_solve_condsweep(const double* rhs, double* sol) {
         const int NM = N + M, nx = schur.nx, nu = schur.nu, nn = schur.nn, VARX = nx * nn, np_ = schur.np, N0 = N - np_;
-        if (nx < 1 || nn < 1 || np_ < 0 || np_ > 1 || nx * nn != M || (nx + nu) * nn + np_ != N) throw std::invalid_argument("oracle: PIVOT_CONDSWEEP needs the collocation structure of the QP (nx, nu, nn[, np <= 1])");
+        if (nx < 1 || nn < 1 || np_ < 0 || np_ > 1 || M < nx * nn || (M - nx * nn) % nn != 0 || (nx + nu) * nn + np_ != N) throw std::invalid_argument("oracle: PIVOT_CONDSWEEP needs the collocation structure of the QP (nx, nu, nn[, np <= 1]; m = (nx + ng) nn)");
+        // NG > 0 (round 6): the path-constraint rows ME + k ng + g follow the equality rows; such a row holds its own node's block only — a column takes its own node's
+        // path rows behind the equality rows of its chain, a path row's product is its block (states, controls, the parameter)
+        const int ME = nx * nn, ng = (M - ME) / nn;
         std::vector<double> u(M), t(N), xs(N);
         for (int r = 0; r < M; ++r) u[r] = rho_vec[r] * rhs[N + r];
         for (int c = 0; c < N0; ++c) {
@@ -756,15 +760,17 @@ struct BoxADMM {
             if (c < 64 || VARX > 64)
                 for (int k = 0; k < nn; ++k) { const double coef = (xcol && k != jn) ? K[(N + k * nx + qx) + c * NM] : 0.0; a = std::fma(coef, u[k * nx + qx], a); }
             for (int q = 0; q < nx; ++q) a = std::fma(K[(N + jn * nx + q) + c * NM], u[jn * nx + q], a);
+            for (int g = 0; g < ng; ++g) a = std::fma(K[(N + ME + jn * ng + g) + c * NM], u[ME + jn * ng + g], a);
             t[c] = a;
         }
         if (np_) t[N0] = rhs[N0] + cond_wave_dot(u.data());
         ldlt.solve(t.data(), xs.data());
         for (int i = 0; i < N; ++i) sol[i] = xs[i];
         for (int r = 0; r < M; ++r) {
-            const int k = r / nx, q = r - k * nx;
+            const bool eq = r < ME;
+            const int k = eq ? r / nx : (r - ME) / ng, q = eq ? r - k * nx : 0;
             double a = 0.0;
-            for (int j = 0; j < nn; ++j) { const double coef = (j != k) ? K[(N + r) + (j * nx + q) * NM] : 0.0; a = std::fma(coef, xs[j * nx + q], a); }
+            for (int j = 0; j < nn; ++j) { const double coef = (eq && j != k) ? K[(N + r) + (j * nx + q) * NM] : 0.0; a = std::fma(coef, xs[j * nx + q], a); }
             for (int i = 0; i < nx; ++i) a = std::fma(K[(N + r) + (k * nx + i) * NM], xs[k * nx + i], a);
             for (int i = 0; i < nu; ++i) a = std::fma(K[(N + r) + (VARX + k * nu + i) * NM], xs[VARX + k * nu + i], a);
             if (np_) a = std::fma(K[(N + r) + (size_t)N0 * NM], xs[N0], a);

@@ -646,7 +646,7 @@ inline bool launch_redo_generic(pmpc_context* ctx, const Model& mdl, const ChebD
                        (unsigned long long*)nullptr, (double*)nullptr, PMPC_REDO_MODE, ss->max_iter, (double*)nullptr, (unsigned)(ldsg / sizeof(double)));
     return true;
 }
-template <class Model, int NN_, int MM_> struct COND_REG_OK { static constexpr bool value = NN_ + MM_ > WAVE && NN_ <= 112 && MM_ > 0 && MM_ <= WAVE && Model::NP <= 1 && Model::NG == 0; };   // (NP = 1 since round 6: the parameter's dense column of A as a wave reduction)
+template <class Model, int NN_, int MM_> struct COND_REG_OK { static constexpr bool value = NN_ + MM_ > WAVE && NN_ <= 112 && MM_ > 0 && MM_ <= WAVE && Model::NP <= 1; };   // (NP = 1 and NG > 0 since round 6: the parameter's dense column of A as a wave reduction, the path-constraint rows as own-node blocks without a D~ row)
 // Register-resident QP specialisations are selected from the compile-time model dimensions and the runtime node count
 // when the KKT system has at most 64 rows; otherwise the LDS-resident path is used.
 template <class Model, int NNODES, bool LEAN = false>   // LEAN: no phase-timer and no block-BFGS specialisation (pmpc_grids.hpp: those requests take the LDS-resident kernel)

@@ -150,13 +150,16 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
     //   column c of node jn, state qx:  t = r1;  t = fma(D~(k, jn), u(k, qx), t) for the nodes k ascending (0 on the own node and outside the segments
     //                                   that hold jn; a control column reads the all-zero row);  t = fma(J((jn, q), c), u(jn, q), t) for q ascending
     //   row (k, q):                     a = 0;   a = fma(D~(k, j), x(j, q), a) for the nodes j ascending;  then the own node's block, columns ascending
-    constexpr int NX = JV::NX, NU = JV::NU, NPAR = JV::NP, NDER = JV::NDER, JBS = JV::JBS, NNODES = MM / NX, NNP = lds_row_stride(NNODES), VARX = NX * NNODES;
+    constexpr int NX = JV::NX, NU = JV::NU, NPAR = JV::NP, NG = JV::NG, NDER = JV::NDER, JBS = JV::JBS, NNODES = MM / (NX + NG), NNP = lds_row_stride(NNODES), VARX = NX * NNODES;
     constexpr int P0 = (NX + NU) * NNODES;   // NP = 1 (round 6): the parameter is the last primal variable, its column of A is DENSE (rows ascending: entry NX + NU of every row's block)
-    static_assert((int)JV::NG == 0 && NPAR <= 1 && NNODES * NX == MM && P0 + NPAR == NN, "condensed register QP: no path constraints, at most one parameter");
+    constexpr int ME = NX * NNODES;          // NG > 0 (round 6): the path-constraint rows ME + k NG + g follow the equality rows (continuous_ocp.hpp:546-575); such a row holds its own node's block only
+    constexpr int NGC = NG > 0 ? NG : 1;
+    static_assert(NPAR <= 1 && NNODES * (NX + NG) == MM && P0 + NPAR == NN, "condensed register QP: at most one parameter");
     double* Dt = tr + CD::TAB_OFF;
     static_assert(CD::TAB_OFF + CD::template tab_doubles<NNODES>() <= CondKkt<NN>::TRI, "tables fit the staging");
     const double* DtT = Dt + NNODES * NNP;
     const double *cD[2] = {nullptr, nullptr}, *cU[2] = {nullptr, nullptr}, *cB[2] = {nullptr, nullptr}, *cV[2] = {nullptr, nullptr};   // per primal slot: D~ column, u at the column's state index, own-node block column, u of the own node
+    const double *cG[2] = {nullptr, nullptr}, *cW[2] = {nullptr, nullptr};   // NG > 0: the column inside its own node's path-constraint rows, u of those rows
     bool isp[2] = {false, false};   // this slot holds the parameter (NP = 1): its entry of A' u is a wave reduction, not a chain over the tables
 #pragma unroll
     for (int e = 0; e < SL; ++e) {
@@ -170,9 +173,12 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
         cU[e] = us + (xcol ? dcol : 0);
         cB[e] = jv.jblk + (jn * NX) * JBS + dcol;
         cV[e] = us + jn * NX;
+        cG[e] = jv.jblk + (ME + jn * NG) * JBS + dcol;   // (gblk = jblk + ME JBS: the launcher carves them as one array, pmpc_launch.hpp)
+        cW[e] = us + ME + jn * NG;
     }
-    const int rk = rc / NX, rq = rc - rk * NX;
-    const double* rD = Dt + rk * NNP;              // constraint row: D~ row, x at the row's state index, own-node block row, x / u of the own node
+    const bool req = NG == 0 || rc < ME;           // equality row (node rk, state rq) or path-constraint row (node rk): the latter reads the all-zero row of the D~ tables
+    const int rk = req ? rc / NX : (rc - ME) / NGC, rq = req ? rc - rk * NX : 0;
+    const double* rD = req ? Dt + rk * NNP : Dt + 4 * NNODES * NNP;   // constraint row: D~ row, x at the row's state index, own-node block row, x / u of the own node
     const double* rX = xs + rq;
     const double* rB = jv.jblk + rc * JBS;
     const double* rV = xs + rk * NX;
@@ -201,6 +207,13 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
         for (int q = 0; q < NX; ++q) { bv[q] = cB[e][q * JBS]; vv[q] = cV[e][q]; }
 #pragma unroll
         for (int q = 0; q < NX; ++q) a = fma(bv[q], vv[q], a);
+        if constexpr (NG > 0) {   // the own node's path-constraint rows, behind the equality rows
+            double gv[NGC], wv[NGC];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) { gv[g] = cG[e][g * JBS]; wv[g] = cW[e][g]; }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) a = fma(gv[g], wv[g], a);
+        }
         return a;
     };
     auto rowdot_fma = [&]() -> double {
@@ -376,6 +389,13 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
 #pragma unroll
                             for (int k = 0; k < NNODES; ++k) a += (dv[k] - lv[k]) * uv[k];
                         }
+                        if constexpr (NG > 0) {   // rows ME + jn NG + g: the last rows of the column
+                            double gv[NGC], wv[NGC];
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) { gv[g] = cG[e][g * JBS]; wv[g] = cW[e][g]; }
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) a += gv[g] * wv[g];
+                        }
                         aty[e] = isP[e] ? a : 0.0;
                     }
                     if constexpr (NPAR > 0) {   // the parameter's column in the reference's order: sum_r A(r, p) y_r, rows ascending (multiply, then add) — a serial chain every lane walks, the parameter's lane keeps it
@@ -394,7 +414,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                     }
                     {
                         double a = 0.0;
-                        const double* rl = Dlo + rk * NNP;
+                        const double* rl = req ? Dlo + rk * NNP : Dt + 4 * NNODES * NNP;
                         double dv[NNODES], lv[NNODES], xq[NNODES], bv[NDER], xb[NDER];
 #pragma unroll
                         for (int j = 0; j < NNODES; ++j) { dv[j] = rD[j]; lv[j] = rl[j]; xq[j] = rX[j * NX]; }

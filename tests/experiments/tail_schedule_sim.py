@@ -48,3 +48,15 @@ print("random permutations: mean %.0f min %.0f max %.0f p10 %.0f p90 %.0f; index
 long_idx=np.argsort(-tot)[:50]; print("indices of the 50 longest:",np.sort(long_idx)[-12:], "their durations", np.round(tot[np.sort(long_idx)[-6:]]))
 # reversed order, interleaved orders
 print("reversed %.0f  evens-then-odds %.0f  second-half-first %.0f"%(sched(range(B-1,-1,-1),tot),sched(list(range(0,B,2))+list(range(1,B,2)),tot),sched(list(range(2048,B))+list(range(2048)),tot)))
+# (late round 6) sliced launches in index order: every pass runs at most k SQP iterations of every unfinished instance (the slice mechanism of the MPC step), no ordering knowledge
+cw=np.cumsum(work,axis=1)/2400.0
+def sliced(cuts,ovh=8.0):
+    t=0.0; prev=np.zeros(B); lo=0
+    for hi in cuts:
+        w=(cw[:,hi-1]-(cw[:,lo-1] if lo else 0.0))
+        live=np.nonzero(it>lo)[0]
+        t+=sched(live,w)+ovh; lo=hi
+    return t
+for cuts in ((10,),(5,10),(6,10),(7,10),(4,7,10),(3,6,10),(3,5,7,10),(2,4,6,8,10),tuple(range(1,11))):
+    print("passes ending at iterations %-22s -> %.0f us (8 us per relaunch)"%(cuts,sliced(cuts)))
+print("iteration histogram:",np.bincount(it,minlength=11))

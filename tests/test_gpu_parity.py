@@ -77,7 +77,7 @@ def _gpu_order(oracle, n, m, nodes=None, block_bfgs=False, kkt_form=0, schur=Fal
     if n + m <= 64 and nodes in ((5, 7) if block_bfgs else REG_NODE_COUNTS):   # (the block-BFGS one-row-per-lane specialisation exists for 5 and 7 nodes)
         return oracle.PIVOT_SWEEP
     if 64 < n + m <= 128 and nodes in REG_NODE_COUNTS:      # two-rows-per-lane register path (113..128 rows: part of the operand tiles in LDS) (the Hessian update is a run-time choice there)
-        if n <= 112 and m <= 64 and kkt_form == 0 and ng == 0 and (n % nodes == 0 or (n - 1) % nodes == 0):    # (no path constraints, at most one parameter — NP = 1 since round 6) condensed register kernel (pmpc_qp_cond.hpp): only S = H + sigma I + rho_box + A' diag(rho) A is inverted
+        if n <= 112 and m <= 64 and kkt_form == 0 and (n % nodes == 0 or (n - 1) % nodes == 0):    # (at most one parameter — NP = 1 and path constraints since round 6) condensed register kernel (pmpc_qp_cond.hpp): only S = H + sigma I + rho_box + A' diag(rho) A is inverted
             return oracle.PIVOT_CONDSWEEP
         return oracle.PIVOT_SWEEP2
     return _lds_order(oracle, n + m, kkt_form=kkt_form)
@@ -90,7 +90,7 @@ def _policy_order(oracle, n, m, nodes, ruiz=False, block_bfgs=False, kkt_form=0,
     """preconditioner = 1 / line_search = 1: on the grids of the reference's own tests (7 and 11 nodes) the register-resident kernels carry these hooks
     since round 3 (their sweep orders); every other grid takes the LDS / HBM-resident kernels for them."""
     if (nodes in POLICY_REG_NODE_COUNTS and n + m <= 112) or (nodes == 16 and n + m <= 128):   # (16 nodes, round 4: the reference's mpc_wrapper_test grid)
-        if n + m > 64 and not ruiz and kkt_form == 0 and n <= 112 and m <= 64 and ng == 0 and (n % nodes == 0 or (n - 1) % nodes == 0):
+        if n + m > 64 and not ruiz and kkt_form == 0 and n <= 112 and m <= 64 and (n % nodes == 0 or (n - 1) % nodes == 0):
             return oracle.PIVOT_CONDSWEEP   # the filter line search alone keeps the condensed register QP (Ruiz rescales the workspace: full inverse); since round 5 also on at most 64 variables
         return oracle.PIVOT_SWEEP if n + m <= 64 else oracle.PIVOT_SWEEP2
     return _lds_order(oracle, n + m, ruiz=ruiz, kkt_form=kkt_form)
@@ -557,7 +557,7 @@ def _sqp_both(ctx, oracle, wl, B, **kw):
         setattr(ss, k, v)
     for k, v in wl.get("settings", {}).items():   # (settings of the workload itself, e.g. the minimal-time problem's exact Hessians + Gershgorin shift)
         if k not in kw: setattr(ss, k, v)
-    gk = dict(x_guess=wl["x_guess"]) if "x_guess" in wl else {}
+    gk = {k: wl[k] for k in ("x_guess", "lbg", "ubg") if k in wl}
     x, lam, info = ctx.sqp_solve_batch(wl["model"], wl["P"], wl["S"], wl["t0"], wl["tf"], B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss, **gk)
     oss = oracle.sqp_default_settings(); oss.max_iter = wl["max_iter"]; oss.line_search_max_iter = wl["ls_max_iter"]
     for k, v in wl.get("settings", {}).items():
@@ -667,7 +667,9 @@ def test_sqp_parking_nonlinear_path_constraint(ctx, oracle, P, S, ubg, qp_max):
     oqs = oracle.sqp_qp_default_settings(); oqs.max_iter = qp_max
     x, lam, info = ctx.sqp_solve_batch(pa.MODEL_PARKING_NG, P, S, 0.0, 1.0, 1, [[1.0]], lbx, ubx, lbg=lbg, ubg=ubgv, x_guess=xg,
                                        sqp_settings=ss, qp_settings=qs)
-    pivot = _gpu_order(oracle, 5 * nn + 1, 4 * nn, nn, ng=1)   # 7 nodes: 64 rows, one row per lane; 11 nodes: 100 rows, two rows per lane
+    pivot = _gpu_order(oracle, 5 * nn + 1, 4 * nn, nn, ng=1)   # 7 nodes: 64 rows, one row per lane; 11 nodes: 100 rows — round 6: the condensed register kernel (56 variables, one per lane; the path-constraint rows as own-node blocks), before: two rows per lane
+    assert ctx.last_route() == (pa.capi.ROUTE_CONDREG if nn == 11 else pa.capi.ROUTE_REG1)
+    assert pivot == (oracle.PIVOT_CONDSWEEP if nn == 11 else oracle.PIVOT_SWEEP)
     xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_PARKING_NG, P, S, 0.0, 1.0, 1, [[1.0]], lbx, ubx, lbg=lbg, ubg=ubgv, x_guess=xg,
                                         sqp_settings=oss, qp_settings=oqs, pivot=pivot)
     _assert_same_solve(info, io, x, xo, lam, lo)

@@ -1299,6 +1299,29 @@ def test_dual_residual_from_the_kkt_identity_changes_no_trajectory(oracle):
         assert np.abs(x0 - x1).max() <= tol and np.abs(x0 - x1).max() > 0.0    # (the switch does something)
 
 
+@pytest.mark.parametrize("ubg", [10.0, 1.2])
+def test_condensed_register_order_with_a_path_constraint_and_a_parameter(oracle, ubg):
+    """Round 6: PIVOT_CONDSWEEP with NG = 1 beside NP = 1 — the path-constraint rows behind the equality rows, each holding its own node's block only (no row of the
+    differentiation matrix) — the order of the condensed register kernel that serves nonlinear_constraints_test.cpp:159-184 by default since round 6. Admission on 16 perturbed
+    instances of that problem with the reference's bound (10: inactive) and a binding one (1.2), configured as the reference does (exact Hessians, Gershgorin): every instance keeps
+    the SQP / ADMM iteration counts and the status of the run in the reference order (Eigen-style pivoted LDL^T) and of the run refined to exact arithmetic (PIVOT_EXACT), and the condensed
+    order is the one that stays with exact arithmetic — 1e-8 against the reference order's 1e-6 and the full two-rows-per-lane inverse's (the kernel it replaces) 1e-5 .. 1e-4."""
+    B, nn = 16, 11
+    lbx, ubx, xg, d = _parking_batch(B, nn)
+    lbg = np.full((B, nn), -10.0); ubgv = np.full((B, nn), ubg)
+    ss = oracle.sqp_default_settings(); ss.max_iter = 20; ss.line_search_max_iter = 10; ss.regularisation = 2; ss.exact_hessian_every_iter = 1
+    run = lambda piv: oracle.sqp_solve_batch(oracle.MODEL_PARKING_NG, 5, 2, 0.0, 1.0, B, d, lbx, ubx, lbg=lbg, ubg=ubgv, x_guess=xg, sqp_settings=ss, pivot=piv, threads=4)
+    xc, lc, ic = run(oracle.PIVOT_CONDSWEEP)
+    xe, le, ie = run(oracle.PIVOT_EIGEN)
+    xx, lx, ix = run(oracle.PIVOT_EXACT)
+    x2, l2, i2 = run(oracle.PIVOT_SWEEP2)
+    key = lambda info: [(i.iter, i.status, i.qp_solver_iter) for i in info]
+    assert key(ic) == key(ie) == key(ix)
+    assert all(i.flags == 0 for i in ic)
+    dc, de, d2 = np.abs(xc - xx).max(), np.abs(xe - xx).max(), np.abs(x2 - xx).max()
+    assert dc < 1e-7 and dc < 0.05 * de and dc < 0.01 * d2, (dc, de, d2)
+
+
 def test_condensed_register_order_with_one_parameter_on_the_minimal_time_problem(oracle):
     """Round 6: PIVOT_CONDSWEEP with NP = 1 (the parameter's dense column of A' u as the wavefront's tree sum, its term last in every row of A x) — the order of the
     condensed register kernel that now serves the reference's minimal-time parking test (minimal_time_test.cpp:146-188: exact Hessians, Gershgorin, NP = 1) by default.

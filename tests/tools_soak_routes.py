@@ -25,19 +25,23 @@ def main():
     policies = [dict(), dict(hessian_update=1), dict(preconditioner=1), dict(line_search=1), dict(qp_solver=1), dict(preconditioner=1, line_search=1, hessian_update=1), dict(kkt_form=1),
                 dict(regularisation=1, exact_hessian_every_iter=1)]   # (round 6: eigenvalue mirroring — the hook builds of the register kernels on 7 / 11 / 16 nodes, the LDS / HBM-resident kernels elsewhere)
     from test_oracle_pins import _parking_batch
-    for model in (0, 1, pa.MODEL_PARKING):
+    for model in (0, 1, pa.MODEL_PARKING, pa.MODEL_PARKING_NG, pa.MODEL_ROBOT_NG):
         for P, S in grids:
             dm = ob.ocp_dims(model, P, S)
             if model == 0:
                 wl = workloads.robot_batch(B, P=P, S=S); wl["max_iter"] = 6
-            elif model == pa.MODEL_PARKING:   # (round 6) NP = 1: the reference's minimal-time problem, perturbed per instance, on every grid its register kernels exist for
+            elif model in (pa.MODEL_PARKING, pa.MODEL_PARKING_NG):   # (round 6) NP = 1 (and NG = 1: the path constraint of nonlinear_constraints_test.cpp, binding): the reference's minimal-time problem, perturbed per instance
                 lbx, ubx, xg, d = _parking_batch(B, P * S + 1)
                 wl = dict(model=model, P=P, S=S, t0=0.0, tf=1.0, d=d, lbx=lbx, ubx=ubx, x_guess=xg, max_iter=6, ls_max_iter=10, settings=dict(regularisation=2, exact_hessian_every_iter=1))
+                if model == pa.MODEL_PARKING_NG: wl["lbg"] = np.full((B, P * S + 1), -10.0); wl["ubg"] = np.full((B, P * S + 1), 1.2)
+            elif model == pa.MODEL_ROBOT_NG:
+                wl = workloads.robot_batch(B, P=P, S=S); wl["max_iter"] = 6; wl["model"] = model
+                wl["lbg"] = np.full((B, P * S + 1), -1e3); wl["ubg"] = np.full((B, P * S + 1), 3.0)
             else:
                 lbx, ubx = T._cstr_grid(B, P, S)
                 wl = dict(model=1, P=P, S=S, t0=0.0, tf=100.0, d=np.zeros((B, 1)), lbx=lbx, ubx=ubx, max_iter=6, ls_max_iter=20)
             for kw in policies:
-                if kw.get("qp_solver") and 2 * dm["n"] + dm["m"] > 190: continue    # the stacked system lives in LDS only
+                if kw.get("qp_solver") and 2 * dm["n"] + dm["m"] > 180: continue    # the stacked system lives in LDS only
                 if kw.get("regularisation") == 1 and dm["n"] > 80: continue          # the Jacobi workspace is 16 n^2 bytes of LDS
                 try:
                     (x, lam, info), (xo, lo, io) = T._sqp_both(ctx, ob, wl, B, **kw)

@@ -86,6 +86,8 @@ static void qp_solve_batch_f32_impl(int B, int n, int m, const float* H, const f
 
 extern "C" {
 
+double orc_set_schur_refine_gate(double g) { const double old = oracle::BoxADMM::schur_refine_gate(); oracle::BoxADMM::schur_refine_gate() = g; return old; }
+void orc_schur_refine_counts(long long* out, int reset) { auto* c = oracle::BoxADMM::schur_refine_counts(); out[0] = c[0]; out[1] = c[1]; if (reset) { c[0] = 0; c[1] = 0; } }
 int orc_set_hx_identity(int on) { const int old = oracle::BoxADMM::hx_identity(); oracle::BoxADMM::hx_identity() = on; return old; }
 int orc_set_libm(int use_libm) { const int old = oracle::use_libm() ? 1 : 0; oracle::use_libm() = use_libm != 0; return old; }
 void orc_math_eval(int kind, int impl, int count, const double* x, double* y) {

@@ -52,6 +52,8 @@ enum { ORC_NLP_CONSTRAINED_ROSENBROCK = 0, ORC_NLP_ROSENBROCK = 1, ORC_NLP_SIMPL
 /* sin / cos / exp used by the model evaluations: 0 (default) = pmpc::detmath, the IEEE-only restatement the HIP kernels share
  * (GPU-vs-oracle comparisons are bit for bit); 1 = glibc, what the reference binary calls. Process-wide; returns the old value. */
 int  orc_set_libm(int use_libm);
+double orc_set_schur_refine_gate(double gate);   /* experiment switch (round 6): PIVOT_SCHUR's refinement step only above this conditioning estimate (0: always); returns the previous value */
+void orc_schur_refine_counts(long long* out2, int reset);   /* solves with / without the refinement step since the last reset */
 int  orc_set_hx_identity(int on);   /* experiment switch (round 6): H x of boxADMM's dual residual from the KKT identity instead of a mat-vec; returns the previous value */
 /* kind 0 sin, 1 cos, 2 exp; impl 0 detmath, 1 glibc: y[i] = f(x[i]) */
 void orc_math_eval(int kind, int impl, int count, const double* x, double* y);

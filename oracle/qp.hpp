@@ -43,6 +43,7 @@
 #include <limits>
 #include <stdexcept>
 #include <vector>
+#include <atomic>
 
 namespace oracle {
 
@@ -626,6 +627,10 @@ struct BoxADMM {
     // Q^(1/2) A' (measured on config B's QPs after a rho update, cond(S) = 6e5: |dx| 2e-9 .. 2e-8 without the step, 2e-13 with it — the dense
     // orders reach 8e-12). The first block row holds to working precision by construction, so the residual lives in the second one:
     //   e = (A x - nu / rho) - r2,   nu += S^{-1} e... sign: K [dx; dnu] = [0; -e]  <=>  -S dnu = -e,   then x = Q (r1 - A' nu) again.
+    // schur_refine_gate() — a process-wide TEST switch (orc_set_schur_refine_gate): the refinement step only when the factorisation's conditioning estimate exceeds it
+    // (0: always, the shipped order). schur_refine_counts(): solves with / without the step since the last reset (the experiment's statistics).
+    static double& schur_refine_gate() { static double v = 0.0; return v; }
+    static std::atomic<long long>* schur_refine_counts() { static std::atomic<long long> c[2]; return c; }
     void schur_solve0(const double* r1, const double* r2, double* xs, double* nu) {
         const int nx = schur.nx, nn = schur.nn, d = nx + schur.nu, N0 = n0();
         auto Q = [&](int k, int i, int j) { return Qs[(size_t)k * d * d + i + j * d]; };
@@ -638,6 +643,9 @@ struct BoxADMM {
         for (int i = 0; i < M; ++i) gv[i] = schur_rowdot(i, t.data(), 0.0) - r2[i];
         ldlt.solve(gv.data(), nu);
         schur_primal(r1, nu, xs);
+        const bool refine = !(cond_estimate <= schur_refine_gate());
+        schur_refine_counts()[refine ? 0 : 1]++;
+        if (!refine) return;
         for (int i = 0; i < M; ++i) gv[i] = std::fma(-rho_inv_vec[i], nu[i], schur_rowdot(i, xs, 0.0)) - r2[i];
         ldlt.solve(gv.data(), dnu.data());
         for (int i = 0; i < M; ++i) nu[i] = nu[i] + dnu[i];

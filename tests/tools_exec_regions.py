@@ -307,9 +307,35 @@ def _step(state, mn, ops, ident):
                     regs.pop(("a", r_), None)
                 else:
                     regs[("a", r_)] = (ex, 2)
+    # ---- the same for private (scratch) slots addressed by a constant offset — `scratch_store_dwordxN off, v[..], off offset:K`: a VGPR spilled to scratch inside a
+    # partial-EXEC block keeps only the active lanes' copies, exactly like the AGPR case. Slots addressed through a register (private arrays) are not followed.
+    if TRACK_AGPR and mn.startswith("scratch_store_dword"):
+        sl = _scratch_slots(mn, ops, 0)
+        if sl:
+            for r_ in sl:
+                prev = regs.get(("m", r_))
+                if prev is not None and ex is not None and _contains(prev[0], ex):
+                    continue
+                if ex is None:
+                    regs.pop(("m", r_), None)
+                else:
+                    regs[("m", r_)] = (ex, 2)
     if mn == "s_swappc_b64":                     # a call: the callee may clobber the caller-saved SGPRs; EXEC is preserved by the ABI
         regs = {x: v for x, v in regs.items() if not isinstance(x, int) or x >= 30 or x == -1}
     return (ex, regs)
+
+
+def _scratch_slots(mn, ops, first):
+    """dword slots of a scratch access with a constant address (`off ... off offset:K`), else None. ops: [off, data, off offset:K] (store) / [data, off, off offset:K] (load)"""
+    addr = [o.strip() for o in ops[first:first + 1] + ops[first + 2:]] if first == 0 else [o.strip() for o in ops[1:]]
+    if len(addr) < 2 or addr[0] != "off" or not addr[1].startswith("off"):
+        return None
+    m2 = re.search(r"offset:(\d+)", " ".join(addr))
+    k = int(m2.group(1)) if m2 else 0
+    w = {"": 1, "x2": 2, "x3": 3, "x4": 4}.get(mn.split("dword")[-1], None)
+    if w is None or k % 4:
+        return None
+    return list(range(k // 4, k // 4 + w))
 
 
 def _run_block(b, st, i, visit=None):
@@ -410,7 +436,7 @@ def full_report(text, want=None):
             if want and want not in name:
                 continue
             found, blocks, entry = analyse(lines)
-            bad_agpr = _agpr_violations(blocks, entry) if any(mn.startswith("v_accvgpr") for b in blocks for mn, _, _ in b["insts"]) else []
+            bad_agpr = _agpr_violations(blocks, entry) if any(mn.startswith(("v_accvgpr", "scratch_load")) for b in blocks for mn, _, _ in b["insts"]) else []
             if found or bad_agpr:
                 out.append((name, found, [f for f in found if f["state"] != "full"], bad_agpr))
         return out
@@ -425,6 +451,13 @@ def _agpr_violations(blocks, entry):
             continue
 
         def visit(k, mn, ops, raw, st, b=b, i=i):
+            if mn.startswith("scratch_load_dword"):
+                for r_ in (_scratch_slots(mn, ops, 1) or []):
+                    w = st[1].get(("m", r_))
+                    if w is None or w[0] == FULL or st[0] is None or not _exact(w[0]) or not _exact(st[0]):
+                        continue
+                    if not _contains(w[0], st[0]):
+                        bad.append((b["label"] or f"#{i}", raw, str(w[0])[:80], str(st[0])[:80]))
             srcs = ops[1:] if not mn.startswith(("ds_write", "global_store", "scratch_store", "flat_store", "buffer_store")) else ops
             for o in srcs:
                 m2 = re.match(r"a\[(\d+):(\d+)\]$|a(\d+)$", o.strip())

@@ -147,6 +147,8 @@ def contract_line(out, detail_path=None):
         cfgs[key.split("_")[0]] = e
     if cfgs:
         line["configs"] = cfgs
+    if out.get("reference_tests"):   # the reference's two NP = 1 control tests as batches of 4096: [ms per batch, lone instance ms, route, bit-identical to the restatement]
+        line["reference_tests"] = {k: [_r(v["ms_per_batch"]["median"]), _r(v["lone_instance_ms"]), v.get("route"), (v.get("parity") or {}).get("bit_identical_x")] for k, v in out["reference_tests"].items()}
     line["library_build_id"] = out.get("library_build_id")
     if detail_path:
         line["detail"] = detail_path
@@ -183,7 +185,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="OCP instances per GPU")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="instances per pass of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="minimum wall time of the all-core CPU-baseline sample (single core: half)")
-    ap.add_argument("--configs", default="B,C,D,R", help="sub-records beside the headline (N = 1 only): any of B, C, D (BASELINE.json configs[2..4]) and R (the reference's own 16-node robot grid, 128 KKT rows); '' = none")
+    ap.add_argument("--configs", default="B,C,D,R,P", help="sub-records beside the headline (N = 1 only): any of B, C, D (BASELINE.json configs[2..4]) R (the reference's own 16-node robot grid, 128 KKT rows) and P (the problems of the reference's two NP = 1 control tests as batches); '' = none")
     ap.add_argument("--no-replay", action="store_true", help="skip the QP-only replay record")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the timed block of --steps steps until this much timed work has run; the median block is reported (0 = one block)")
     ap.add_argument("--max-blocks", type=int, default=400)
@@ -302,12 +304,13 @@ def main():
         """A few launches of another configuration on this rank's context: ms per batch (median of HIP-event times), QP/s, rooflines."""
         cn, cm = cwl["n"], cwl["m"]
         css = pa.sqp_settings_default(); css.max_iter = cwl["max_iter"]; css.line_search_max_iter = cwl["ls_max_iter"]
-        for k, v in settings.items():
+        for k, v in {**cwl.get("settings", {}), **settings}.items():   # (a workload's own solver configuration, e.g. the reference tests' exact Hessians + Gershgorin shift)
             setattr(css, k, v)
         cd, cl, cu = t(cwl["d"]), t(cwl["lbx"]), t(cwl["ubx"])
+        extra = {k: t(cwl[k]) for k in ("x_guess", "lbg", "ubg") if k in cwl}
         cx = torch.zeros(Bc, cn, dtype=torch.float64, device=dev); clam = torch.zeros(Bc, cm + cn, dtype=torch.float64, device=dev)
         ci = torch.zeros(Bc, 48, dtype=torch.uint8, device=dev)
-        run = lambda: ctx.sqp_solve_batch_dev(cwl["model"], cwl["P"], cwl["S"], cwl["t0"], cwl["tf"], Bc, cd, cl, cu, cx, clam, ci, css, qs)
+        run = lambda: ctx.sqp_solve_batch_dev(cwl["model"], cwl["P"], cwl["S"], cwl["t0"], cwl["tf"], Bc, cd, cl, cu, cx, clam, ci, css, qs, **extra)
         for _ in range(warmup):
             run()
         torch.cuda.synchronize(dev)
@@ -380,6 +383,7 @@ def main():
             want = [c for c in args.configs.split(",") if c]
             cfg = {}
             cfg_runs = {}   # key -> (letter, workload, batch, GPU solution) for the CPU leg below
+            cfg_ref_runs = {}   # key -> (workload, GPU solution) of the reference-test problems
             def add(key, letter, cwl, Bc, steps, warmup, kernel_name, workload):
                 cfg[key] = sqp_record(cwl, Bc, steps, warmup, kernel_name)
                 cfg[key]["workload"] = workload
@@ -411,6 +415,21 @@ def main():
                     "mobile robot on the reference's mpc_wrapper_test grid, P=5 S=3 (16 nodes, n=80, m=48), 2048 instances (not a BASELINE.json configuration: the mid-size path)")
             if cfg:
                 out["configs"] = cfg
+            if "P" in want:
+                # ---- the reference's two NP = 1 control tests as batches (not BASELINE.json configurations): minimal_time_test.cpp:146-188 and nonlinear_constraints_test.cpp:159-184,
+                # configured as those tests configure the solver; a lone instance beside each (what the reference's test solves). Checked against the restatement in the CPU leg.
+                rt = {}
+                for key, pc in (("minimal_time_parking_np1", False), ("nonlinear_constraints_parking_np1_ng1", True)):
+                    rwl = workloads.parking_reference_tests_batch(4096, path_constraint=pc)
+                    r_ = sqp_record(rwl, 4096, 6, 1, "sqp_kernel<Parking%sOCP,56,%d,...,CND>" % ("NG" if pc else "", rwl["m"]))
+                    gsol_ = sol[0]
+                    l_ = sqp_record(workloads.parking_reference_tests_batch(1, path_constraint=pc), 1, 10, 2, "")
+                    rt[key] = {"batch": 4096, "n": rwl["n"], "m": rwl["m"], "ms_per_batch": r_["ms_per_batch"], "qp_solves_per_s": r_["qp_solves_per_s"], "qp_solves_per_batch": r_["qp_solves_per_batch"],
+                               "admm_iters_per_qp": r_["admm_iters_per_qp"], "sqp_solved_fraction": r_["sqp_solved_fraction"], "route": r_["route"],
+                               "lone_instance_ms": l_["ms_per_batch"]["median"], "lone_instance_route": l_["route"],
+                               "settings": "max_iter 20, ls 10, exact Hessians every iteration, Gershgorin shift (as the reference's tests configure the solver); perturbed start states and wheel bases"}
+                    cfg_ref_runs[key] = (rwl, gsol_)
+                out["reference_tests"] = rt
             if not args.no_replay:
                 # ---- QP-only replay: a flat batch of QPs with the collocation structure, through pmpc_qp_boxadmm_solve_batch_dev.
                 # The QPs are built by the PRODUCT (pmpc_ocp_linearise_batch at seeded random points, lam = 0): H = cost Hessian, A = collocation
@@ -551,6 +570,20 @@ def main():
                                                         "identical_trajectory_fraction": float(((it_k == gi["iter"][:n_all]) & (qi_k == gi["qp_solver_iter"][:n_all])).mean()),
                                                         "bit_identical_x": bool(np.array_equal(gx[:n_all], xk)), "bit_identical_lam": bool(np.array_equal(gl[:n_all], lk)),
                                                         "max_abs_dx": float(np.abs(gx[:n_all] - xk).max())}
+            for key, (rwl, (gx, gl, gi)) in (cfg_ref_runs.items() if world == 1 and "reference_tests" in out else []):
+                # the reference-test problems: the first 32 instances against the restatement in the kernel's order (bit for bit) and as the reference computes
+                nr = 32
+                ross = ob.sqp_default_settings(); ross.max_iter = rwl["max_iter"]; ross.line_search_max_iter = rwl["ls_max_iter"]
+                for k_, v_ in rwl["settings"].items(): setattr(ross, k_, v_)
+                kw_ = {k_: rwl[k_][:nr] for k_ in ("x_guess", "lbg", "ubg") if k_ in rwl}
+                rrun = lambda piv: ob.sqp_solve_batch(rwl["model"], rwl["P"], rwl["S"], rwl["t0"], rwl["tf"], nr, rwl["d"][:nr], rwl["lbx"][:nr], rwl["ubx"][:nr], sqp_settings=ross, pivot=piv, threads=cores, **kw_)
+                rorder = ob.PIVOT_CONDSWEEP if out["reference_tests"][key]["route"] == "condreg" else ob.PIVOT_SWEEP2
+                xk, lk, ik = rrun(rorder)
+                with ob.libm():
+                    xr, lr, ir = rrun(ob.PIVOT_EIGEN)
+                same = lambda io_: float(np.mean([(a.iter == b_ and a.qp_solver_iter == c_) for a, b_, c_ in zip(io_, gi["iter"][:nr], gi["qp_solver_iter"][:nr])]))
+                out["reference_tests"][key]["parity"] = {"instances": nr, "order": int(rorder), "bit_identical_x": bool(np.array_equal(gx[:nr], xk)), "bit_identical_lam": bool(np.array_equal(gl[:nr], lk)),
+                                                         "identical_trajectory_fraction_vs_reference_order": same(ir), "max_abs_dx_vs_reference_order": float(np.abs(gx[:nr] - xr).max())}
             if "qp_replay" in out:
                 # ---- north_star's criterion on its own unit (one box-ADMM solve; SURVEY 8d: "max |D| of (x, y, res_prim, res_dual) GPU-vs-CPU"): the QPs the
                 # reference-order SQP emits for every configuration, through pmpc_qp_boxadmm_solve_batch (default kernels) against PIVOT_EIGEN. Not timed.

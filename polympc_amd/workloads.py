@@ -54,6 +54,44 @@ def cstr_batch(B, seed=SEED, first=0):
     return dict(model=1, P=P, S=S, t0=0.0, tf=100.0, d=np.zeros((B, 1)), lbx=lbx, ubx=ubx, n=n, m=4 * nn, max_iter=20, ls_max_iter=20)
 
 
+def minimal_time_parking(nn=11):
+    """minimal_time_test.cpp:146-184: parking OCP with a free time-scaling parameter (NP = 1), P=5 S=2 (nn = 11 nodes), d = 1,
+    x0 = (1.5, .5, .5) pinned on the last node, final state within +-0.05 (first nx entries, mpc_wrapper.hpp:132-137), p in [0, 10],
+    guesses p = 0.5 and x = x0 at every node. -> (lbx, ubx, x_guess), one instance each."""
+    n = 5 * nn + 1
+    lbx = np.full(n, -np.inf); ubx = np.full(n, np.inf)
+    lbx[3 * nn:5 * nn] = np.tile([-1.5, -0.75], nn); ubx[3 * nn:5 * nn] = np.tile([1.5, 0.75], nn)
+    lbx[5 * nn] = 0.0; ubx[5 * nn] = 10.0
+    lbx[0:3] = -0.05; ubx[0:3] = 0.05
+    lbx[3 * nn - 3:3 * nn] = [1.5, 0.5, 0.5]; ubx[3 * nn - 3:3 * nn] = [1.5, 0.5, 0.5]
+    xg = np.zeros(n); xg[:3 * nn] = np.tile([1.5, 0.5, 0.5], nn); xg[5 * nn] = 0.5
+    return lbx[None], ubx[None], xg[None]
+
+
+def parking_batch(B, nn=11, seed=5):
+    """B minimal-time parking problems (NP = 1) around the reference's: start states within +-0.2 of (1.5, .5, .5), wheel bases d in [0.8, 1.2].
+    -> (lbx, ubx, x_guess, d)"""
+    rng = np.random.default_rng(seed)
+    lbx, ubx, xg = (np.repeat(a, B, 0) for a in minimal_time_parking(nn))
+    x0 = np.array([1.5, 0.5, 0.5]) + 0.2 * rng.uniform(-1, 1, (B, 3))
+    lbx[:, 3 * nn - 3:3 * nn] = x0; ubx[:, 3 * nn - 3:3 * nn] = x0
+    xg[:, :3 * nn] = np.tile(x0, nn)
+    return lbx, ubx, xg, 1.0 + 0.2 * rng.uniform(-1, 1, (B, 1))
+
+
+def parking_reference_tests_batch(B, path_constraint=False, ubg=1.2):
+    """The problems of the reference's two NP = 1 control tests as batches of perturbed instances, configured as those tests configure the solver (exact Hessians every
+    iteration + Gershgorin shift, max_iter 20, ls 10): minimal_time_test.cpp:146-188 (model 2) and, with path_constraint, nonlinear_constraints_test.cpp:159-184
+    (model 5: g = u0^2 cos u1 in [-10, ubg] per node). P=5 S=2."""
+    nn = 11
+    lbx, ubx, xg, d = parking_batch(B, nn)
+    wl = dict(model=5 if path_constraint else 2, P=5, S=2, t0=0.0, tf=1.0, d=d, lbx=lbx, ubx=ubx, x_guess=xg, n=5 * nn + 1, m=(4 if path_constraint else 3) * nn,
+              max_iter=20, ls_max_iter=10, settings=dict(regularisation=2, exact_hessian_every_iter=1))
+    if path_constraint:
+        wl["lbg"] = np.full((B, nn), -10.0); wl["ubg"] = np.full((B, nn), ubg)
+    return wl
+
+
 def kite_standin_batch(B, seed=SEED, first=0):
     """Config C dimension stand-in: SYNTHETIC 13-state / 3-input smooth dynamics (the reference's KiteDynamics is not in
     the reference tree), P=5 S=3 -> 16 nodes, n=256, m=208, KKT 464 rows; u in [-1,1]^3, x0 = 0.3*U^13."""

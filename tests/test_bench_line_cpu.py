@@ -84,3 +84,11 @@ def test_round6_record_is_consistent_and_carries_the_new_keys():
     assert len(json.dumps(line)) < 4096
     assert set(line["small_batches_ms"]) == {"1", "64", "512"} and line["gpu_over_cpu_all_cores"] > 1
     assert line["roofline"]["kernel_ms"] <= line["ms_per_step"] * 1.01
+    # the problems of the reference's two NP = 1 control tests as batches (late round 6): served by the condensed register kernel, bit-identical to its restatement,
+    # the same trajectories as the run in the reference order
+    rt = d["reference_tests"]
+    assert set(rt) == {"minimal_time_parking_np1", "nonlinear_constraints_parking_np1_ng1"}
+    for rec in rt.values():
+        assert rec["route"] == rec["lone_instance_route"] == "condreg" and rec["batch"] == 4096 and 0 < rec["lone_instance_ms"] < rec["ms_per_batch"]["median"]
+        assert rec["parity"]["bit_identical_x"] and rec["parity"]["bit_identical_lam"] and rec["parity"]["identical_trajectory_fraction_vs_reference_order"] == 1.0
+    assert set(line["reference_tests"]) == set(rt) and all(v[2] == "condreg" and v[3] is True for v in line["reference_tests"].values())

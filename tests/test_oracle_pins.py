@@ -394,27 +394,15 @@ def test_sqp_robot_mpc_warm_start(oracle, pivot):  # mpc_wrapper_test.cpp:120-16
 
 
 def _minimal_time_parking(nn=11):
-    """minimal_time_test.cpp:146-184: parking OCP with a free time-scaling parameter (NP = 1), P=5 S=2 (nn = 11 nodes), d = 1,
-    x0 = (1.5, .5, .5) pinned on the last node, final state within +-0.05 (first nx entries, mpc_wrapper.hpp:132-137), p in [0, 10],
-    guesses p = 0.5 and x = x0 at every node."""
-    n = 5 * nn + 1
-    lbx = np.full(n, -inf); ubx = np.full(n, inf)
-    lbx[3 * nn:5 * nn] = np.tile([-1.5, -0.75], nn); ubx[3 * nn:5 * nn] = np.tile([1.5, 0.75], nn)
-    lbx[5 * nn] = 0.0; ubx[5 * nn] = 10.0
-    lbx[0:3] = -0.05; ubx[0:3] = 0.05
-    lbx[3 * nn - 3:3 * nn] = [1.5, 0.5, 0.5]; ubx[3 * nn - 3:3 * nn] = [1.5, 0.5, 0.5]
-    xg = np.zeros(n); xg[:3 * nn] = np.tile([1.5, 0.5, 0.5], nn); xg[5 * nn] = 0.5
-    return lbx[None], ubx[None], xg[None]
+    """minimal_time_test.cpp:146-184 (polympc_amd/workloads.py minimal_time_parking)"""
+    from polympc_amd import workloads
+    return workloads.minimal_time_parking(nn)
 
 
 def _parking_batch(B, nn=11, seed=5):
-    """B minimal-time parking problems (NP = 1) around the reference's: start states within +-0.2 of (1.5, .5, .5), wheel bases d in [0.8, 1.2]."""
-    rng = np.random.default_rng(seed)
-    lbx, ubx, xg = (np.repeat(a, B, 0) for a in _minimal_time_parking(nn))
-    x0 = np.array([1.5, 0.5, 0.5]) + 0.2 * rng.uniform(-1, 1, (B, 3))
-    lbx[:, 3 * nn - 3:3 * nn] = x0; ubx[:, 3 * nn - 3:3 * nn] = x0
-    xg[:, :3 * nn] = np.tile(x0, nn)
-    return lbx, ubx, xg, 1.0 + 0.2 * rng.uniform(-1, 1, (B, 1))
+    """B minimal-time parking problems (NP = 1) around the reference's (polympc_amd/workloads.py parking_batch)"""
+    from polympc_amd import workloads
+    return workloads.parking_batch(B, nn, seed)
 
 
 def test_bordered_block_structured_solve_against_a_dense_solve(oracle):

@@ -197,6 +197,7 @@ static pmpc_status create_impl(int device, void* stream, pmpc_context* ctx) {
         if (getenv("PMPC_NO_REDO_LAUNCH")) ctx->dev_switches |= 1u << PMPC_SW_NO_REDO_LAUNCH;
         if (getenv("PMPC_NO_CONDREG")) ctx->dev_switches |= 1u << PMPC_SW_NO_CONDREG;
         if (getenv("PMPC_NO_SCHUR")) ctx->dev_switches |= 1u << PMPC_SW_NO_SCHUR;
+        if (getenv("PMPC_NO_CONDREG_RUIZ")) ctx->dev_switches |= 1u << PMPC_SW_NO_CONDREG_RUIZ;   // (A/B timing: preconditioner = 1 on the full two-rows-per-lane inverse as before round 6)
         if (getenv("PMPC_SCHUR_SMALL")) ctx->dev_switches |= 1u << PMPC_SW_SCHUR_SMALL;
         const char* e = getenv("PMPC_BIG_WG4");
         if (e && e[0]) ctx->dev_switches |= (e[0] != '0') ? (1u << PMPC_SW_BIG_WG4_ON) : (1u << PMPC_SW_BIG_WG4_OFF);

@@ -22,7 +22,7 @@ extern "C" void pmpc_internal_set_route(pmpc_context* ctx, int route);   // reco
 extern "C" int pmpc_internal_last_route(pmpc_context* ctx);
 // developer switches of the launcher, read from the environment ONCE per context (pmpc_create): PMPC_NO_REDO_LAUNCH (timing the redo launches), PMPC_NO_CONDREG,
 // PMPC_NO_SCHUR (keep the dense kernels), PMPC_SCHUR_SMALL (block-structured kernel on at most 64 KKT rows), PMPC_BIG_WG4 = 0 / 1 (team kernel never / whenever eligible)
-enum { PMPC_SW_NO_REDO_LAUNCH = 0, PMPC_SW_NO_CONDREG = 1, PMPC_SW_NO_SCHUR = 2, PMPC_SW_SCHUR_SMALL = 3, PMPC_SW_BIG_WG4_ON = 4, PMPC_SW_BIG_WG4_OFF = 5 };
+enum { PMPC_SW_NO_REDO_LAUNCH = 0, PMPC_SW_NO_CONDREG = 1, PMPC_SW_NO_SCHUR = 2, PMPC_SW_SCHUR_SMALL = 3, PMPC_SW_BIG_WG4_ON = 4, PMPC_SW_BIG_WG4_OFF = 5, PMPC_SW_NO_CONDREG_RUIZ = 6 };
 extern "C" int pmpc_internal_switch(pmpc_context* ctx, int which);
 
 namespace pmpc {
@@ -47,6 +47,12 @@ template <int NN, int MM, int NNODES> constexpr int cond_qp_staging() {
         constexpr int a = RegKkt2<NN, PMPC_COND_NV>::TRI, b = CondDims<NN, MM>::TAB_OFF + CondDims<NN, MM>::template tab_doubles<NNODES>();
         return a > b ? a : b;
     }
+}
+
+// the hook builds (POL): D~ tables per state index from the workspace (pmpc_qp_cond.hpp WS) — 4 NX tables instead of 4, which no longer fit the sweep's staging
+template <int NN, int MM, int NNODES, int NX> constexpr int cond_qp_staging_ws() {
+    constexpr int a = cond_qp_staging<NN, MM, NNODES>(), b = CondDims<NN, MM>::TAB_OFF + CondDims<NN, MM>::template tab_doubles_ws<NNODES, NX>();
+    return a > b ? a : b;
 }
 
 // LDS doubles of the block-sparse copy of J the register-resident kernels keep (pmpc_jview.hpp): per node NX x NDER + NG x NDER
@@ -122,7 +128,10 @@ __global__ __launch_bounds__(WG4 ? 256 : 64, ((NN > 0 && NN + MM <= 64) ? PMPC_S
         p = v.carve(p, n, m, mi);
         stage0 = p;
         p = ocp.s.carve(p, P, S);
-        constexpr int QP_STAGING = []() constexpr { if constexpr (CND) return cond_qp_staging<NN, MM, NN / (Model::NX + Model::NU)>(); else return reg_qp_staging<NN + MM>(); }();   // (condensed register QP: its own tile set's staging)
+        constexpr int QP_STAGING = []() constexpr {   // (condensed register QP: its own tile set's staging; its hook builds: room for the tables per state index)
+            if constexpr (CND && POL) return cond_qp_staging_ws<NN, MM, NN / (Model::NX + Model::NU), Model::NX>();
+            else if constexpr (CND) return cond_qp_staging<NN, MM, NN / (Model::NX + Model::NU)>();
+            else return reg_qp_staging<NN + MM>(); }();
         if (NN > 0 && (size_t)(p - stage0) < (size_t)QP_STAGING + 2 + ocp.s.const_doubles(P, S)) p = stage0 + QP_STAGING + 2 + ocp.s.const_doubles(P, S);
         stage_end = p;   // end of the per-node staging block: what follows (static parameters, filter) stays live during the line search
     }
@@ -746,12 +755,16 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
                 if constexpr (POLK && NN_ <= WAVE) { kern = sqp_kernel<Model, NN_, MM_, false, 0, false, false, true, true>; ldsq = sqp_kernel_lds_bytes<Model>(P, S, 3, 0, true); }
 #endif
             }
-            // the filter line search alone (no Ruiz scaling: that rescales the workspace the per-node blocks of A mirror) keeps the condensed QP
-            if constexpr (POLK) {   // (round 5: also the one-row-per-lane tile set — its hook build was miscompiled by the never-executed Ruiz calls, which the condensed kernels no longer carry, pmpc_sqp.hpp RUIZ_COMPILED)
-                if (pol && ss->preconditioner == 0 && ss->kkt_form == 0 && !pmpc_internal_switch(ctx, PMPC_SW_NO_CONDREG)) {
-                    kern = sqp_kernel<Model, NN_, MM_, false, 0, false, false, true, true>; timed = false;
-                    if constexpr (NN_ > WAVE) ldsq = sqp_kernel_lds_bytes<Model>(P, S, 6, 0, true, (size_t)cond_qp_staging<NN_, MM_, NNODES>()) + sqp_eig_lds_bytes<Model>(P, S, ss);
-                    pmpc_internal_set_route(ctx, PMPC_ROUTE_CONDREG);
+            // the hooks keep the condensed QP — the filter line search and eigenvalue mirroring since rounds 4 / 6, the Ruiz preconditioner since late round 6: it rescales the
+            // workspace, so the hook builds read their D~ tables (one set per state index) and, after an equilibration, the node blocks back from it (pmpc_qp_cond.hpp WS)
+            if constexpr (POLK) {
+                if (pol && ss->kkt_form == 0 && !pmpc_internal_switch(ctx, PMPC_SW_NO_CONDREG) && !(ss->preconditioner == 1 && pmpc_internal_switch(ctx, PMPC_SW_NO_CONDREG_RUIZ))) {
+                    const size_t ldsw = sqp_kernel_lds_bytes<Model>(P, S, 6, 0, true, (size_t)cond_qp_staging_ws<NN_, MM_, NNODES, Model::NX>()) + sqp_eig_lds_bytes<Model>(P, S, ss);
+                    if (ldsw <= lds_limit) {
+                        kern = sqp_kernel<Model, NN_, MM_, false, 0, false, false, true, true>; timed = false;
+                        ldsq = ldsw;
+                        pmpc_internal_set_route(ctx, PMPC_ROUTE_CONDREG);
+                    }
                 }
             }
         }

@@ -47,6 +47,8 @@ struct CondDims {
     static constexpr int TAB_OFF = PB_OFF + (SMALL ? 0 : 4 * NN); // D~ tables of the sparse products (cond_build_tables), rebuilt at every QP
     template <int NNODES> static constexpr int nnp() { return lds_row_stride(NNODES); }   // bank-conflict-free row stride (pmpc_jview.hpp)
     template <int NNODES> static constexpr int tab_doubles() { return (4 * NNODES + 1) * nnp<NNODES>(); }
+    // WS (the hook builds, round 6): one set of four tables PER STATE INDEX, filled from the workspace (a Ruiz-scaled A(r, c) = E_r D~ D_c is no longer a function of the two nodes alone)
+    template <int NNODES, int NX> static constexpr int tab_doubles_ws() { return (4 * NNODES * NX + 1) * nnp<NNODES>(); }
 };
 
 // D~ as two dense tables in LDS: Dt[r NNP + k] = D~(r, k) — the differentiation-matrix entry of equality row node r on the state columns of node k
@@ -81,10 +83,36 @@ __device__ __forceinline__ void cond_build_tables(const double* Dm, int P, doubl
     lds_order();
 }
 
+// The same tables from the WORKSPACE, one set per state index q (set q at q * 4 * NNODES * NNP; one all-zero row behind the last set): entry (r, k) of set q is
+// A((r, q), (k, q)) as it stands in the stacked workspace — the Ruiz preconditioner (qp_preconditioners.hpp:114-220) has rescaled it by the row's and the column's factor,
+// which differ from state to state. Without scaling the entries ARE D~(r, k): the hook builds of the condensed kernel use this form whatever the policy.
+// Hs: the stacked workspace [H ; A] (leading dimension N = NN + MM), A(r, c) at Hs[c N + NN + r].
+template <int NNODES, int NX, int NN, int MM>
+__device__ __forceinline__ void cond_build_tables_ws(const double* __restrict__ Hs, int P, double* Dt) {
+    constexpr int NNP = lds_row_stride(NNODES), SET = 4 * NNODES * NNP, N = NN + MM;
+    for (int e = lane_id(); e < NX * SET + NNP; e += WAVE) Dt[e] = 0.0;
+    lds_order();
+    for (int e = lane_id(); e < NX * NNODES * NNODES; e += WAVE) {
+        const int q = e / (NNODES * NNODES), rk = e - q * (NNODES * NNODES);
+        const int r = rk / NNODES, k = rk - r * NNODES;
+        const bool lastr = r == NNODES - 1;
+        const int kbr = lastr ? NNODES - 1 - P : (r / P) * P;
+        const bool cpl = k != r && (unsigned)(k - kbr) <= (unsigned)P;
+        const double av = Hs[(size_t)(k * NX + q) * N + NN + (r * NX + q)];
+        const double v = cpl ? av : 0.0;
+        double* T = Dt + q * SET;
+        T[r * NNP + k] = v;
+        T[NNODES * NNP + k * NNP + r] = v;
+        T[2 * NNODES * NNP + r * NNP + k] = (k < r) ? v : 0.0;
+        T[3 * NNODES * NNP + k * NNP + r] = (r < k) ? v : 0.0;
+    }
+    lds_order();
+}
+
 // boxADMM::solve_impl (7-argument form: zero guesses, box_admm.hpp:81-86). H: the stacked workspace [H ; A] of the fused SQP kernel ((NN + MM) x NN,
 // column-major, leading dimension NN + MM; the LOWER triangle of H is read for S, as Eigen::LDLT does; the full rows for H x); h / bounds: LDS vectors;
 // tr: CondKkt<NN>::TRI doubles of LDS; jv: the block-sparse view of A.
-template <int NN, int MM, class JV>
+template <int NN, int MM, class JV, bool WS = false>   // WS: the D~ tables per state index from the workspace (the hook builds: the workspace may be Ruiz-scaled; the caller has refreshed the node blocks from it)
 __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H, const double* h, const double* Alb, const double* Aub, const double* xlb,
                                                    const double* xub, const pmpc_qp_settings& s, pmpc_qp_info& info, double* out_x, double* out_y, double* tr,
                                                    const JV& jv, long long* dbg = nullptr, long long* tm = nullptr) {
@@ -156,7 +184,9 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
     constexpr int NGC = NG > 0 ? NG : 1;
     static_assert(NPAR <= 1 && NNODES * (NX + NG) == MM && P0 + NPAR == NN, "condensed register QP: at most one parameter");
     double* Dt = tr + CD::TAB_OFF;
-    static_assert(CD::TAB_OFF + CD::template tab_doubles<NNODES>() <= CondKkt<NN>::TRI, "tables fit the staging");
+    static_assert(WS || CD::TAB_OFF + CD::template tab_doubles<NNODES>() <= CondKkt<NN>::TRI, "tables fit the staging");   // (WS: the launcher sizes the staging, cond_qp_staging_ws)
+    constexpr int SET = 4 * NNODES * NNP;                      // one set of four tables
+    const double* ZROW = Dt + (WS ? NX : 1) * SET;             // the all-zero row
     const double* DtT = Dt + NNODES * NNP;
     const double *cD[2] = {nullptr, nullptr}, *cU[2] = {nullptr, nullptr}, *cB[2] = {nullptr, nullptr}, *cV[2] = {nullptr, nullptr};   // per primal slot: D~ column, u at the column's state index, own-node block column, u of the own node
     const double *cG[2] = {nullptr, nullptr}, *cW[2] = {nullptr, nullptr};   // NG > 0: the column inside its own node's path-constraint rows, u of those rows
@@ -169,7 +199,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
         const int cu = isp[e] ? 0 : c - VARX;     // (the parameter's lane walks a control column's addresses: its chain is discarded)
         const int jn = xcol ? c / NX : cu / NU;
         const int dcol = xcol ? c - jn * NX : NX + (cu - jn * NU);
-        cD[e] = xcol ? DtT + jn * NNP : Dt + 4 * NNODES * NNP;
+        cD[e] = xcol ? DtT + (WS ? dcol * SET : 0) + jn * NNP : ZROW;
         cU[e] = us + (xcol ? dcol : 0);
         cB[e] = jv.jblk + (jn * NX) * JBS + dcol;
         cV[e] = us + jn * NX;
@@ -178,7 +208,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
     }
     const bool req = NG == 0 || rc < ME;           // equality row (node rk, state rq) or path-constraint row (node rk): the latter reads the all-zero row of the D~ tables
     const int rk = req ? rc / NX : (rc - ME) / NGC, rq = req ? rc - rk * NX : 0;
-    const double* rD = req ? Dt + rk * NNP : Dt + 4 * NNODES * NNP;   // constraint row: D~ row, x at the row's state index, own-node block row, x / u of the own node
+    const double* rD = req ? Dt + (WS ? rq * SET : 0) + rk * NNP : ZROW;   // constraint row: D~ row, x at the row's state index, own-node block row, x / u of the own node
     const double* rX = xs + rq;
     const double* rB = jv.jblk + rc * JBS;
     const double* rV = xs + rk * NX;
@@ -260,7 +290,8 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                                                          [&](int j) -> double { return bcast_lane(rc_now, j); });
                          });
             }
-            cond_build_tables<NNODES>(jv.D, jv.P, Dt);   // (the staging they live in was the sweep's)
+            if constexpr (WS) cond_build_tables_ws<NNODES, NX, NN, MM>(H, jv.P, Dt);
+            else cond_build_tables<NNODES>(jv.D, jv.P, Dt);   // (the staging they live in was the sweep's)
             if (dbg) dbg[0] += clock64() - f0;
         }
         bool refactor = false;
@@ -373,7 +404,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                         const bool dpart = (e == 0 || SLOT1_STATES);
                         double dv[NNODES], lv[NNODES], uv[NNODES], bv[NX], vv[NX];
                         if (dpart) {
-                            const double* cl = cD[e] + ((cD[e] < DtT + NNODES * NNP) ? 2 * NNODES * NNP : 0);   // (a control column keeps the all-zero row)
+                            const double* cl = cD[e] + ((cD[e] != ZROW) ? 2 * NNODES * NNP : 0);   // (a control column keeps the all-zero row)
 #pragma unroll
                             for (int k = 0; k < NNODES; ++k) { dv[k] = cD[e][k]; lv[k] = cl[k]; uv[k] = cU[e][k * NX]; }
                         }
@@ -414,7 +445,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                     }
                     {
                         double a = 0.0;
-                        const double* rl = req ? Dlo + rk * NNP : Dt + 4 * NNODES * NNP;
+                        const double* rl = req ? rD + 2 * NNODES * NNP : ZROW;
                         double dv[NNODES], lv[NNODES], xq[NNODES], bv[NDER], xb[NDER];
 #pragma unroll
                         for (int j = 0; j < NNODES; ++j) { dv[j] = rD[j]; lv[j] = rl[j]; xq[j] = rX[j * NX]; }

@@ -90,8 +90,8 @@ def _policy_order(oracle, n, m, nodes, ruiz=False, block_bfgs=False, kkt_form=0,
     """preconditioner = 1 / line_search = 1: on the grids of the reference's own tests (7 and 11 nodes) the register-resident kernels carry these hooks
     since round 3 (their sweep orders); every other grid takes the LDS / HBM-resident kernels for them."""
     if (nodes in POLICY_REG_NODE_COUNTS and n + m <= 112) or (nodes == 16 and n + m <= 128):   # (16 nodes, round 4: the reference's mpc_wrapper_test grid)
-        if n + m > 64 and not ruiz and kkt_form == 0 and n <= 112 and m <= 64 and (n % nodes == 0 or (n - 1) % nodes == 0):
-            return oracle.PIVOT_CONDSWEEP   # the filter line search alone keeps the condensed register QP (Ruiz rescales the workspace: full inverse); since round 5 also on at most 64 variables
+        if n + m > 64 and kkt_form == 0 and n <= 112 and m <= 64 and (n % nodes == 0 or (n - 1) % nodes == 0):
+            return oracle.PIVOT_CONDSWEEP   # the hooks keep the condensed register QP (since round 5 also on at most 64 variables; since late round 6 also with the Ruiz preconditioner: tables and node blocks from the scaled workspace)
         return oracle.PIVOT_SWEEP if n + m <= 64 else oracle.PIVOT_SWEEP2
     return _lds_order(oracle, n + m, ruiz=ruiz, kkt_form=kkt_form)
 
@@ -696,6 +696,7 @@ def test_sqp_valet_parking_with_ruiz(ctx, oracle):
                                            qp_settings=qs, mparams=[1.0])
         xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 2.0, 1, [[2.0]], lbx, ubx, x_guess=xo, lam_guess=lo, sqp_settings=oss,
                                             qp_settings=oqs, pivot=_policy_order(oracle, 55, 33, 11, ruiz=True), mparams=[1.0])
+        assert ctx.last_route() == pa.capi.ROUTE_CONDREG and _policy_order(oracle, 55, 33, 11, ruiz=True) == oracle.PIVOT_CONDSWEEP   # late round 6: the condensed hook kernel; before: the full two-rows-per-lane inverse
         assert info["status"][0] == pa.SQP_SOLVED and info["iter"][0] < 10
         _assert_same_solve(info, io, xg, xo, lg, lo)
 
@@ -722,6 +723,7 @@ def test_sqp_valet_parking_as_the_reference_runs_it(ctx, oracle):
                                                qp_settings=qs, mparams=[1.0])
             xo, lo, io = oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 2.0, 1, [[2.0]], lbx, ubx, x_guess=xo, lam_guess=lo, sqp_settings=oss,
                                                 qp_settings=oqs, pivot=_policy_order(oracle, 55, 33, 11, ruiz=True, block_bfgs=True), mparams=[1.0])
+            assert ctx.last_route() == pa.capi.ROUTE_CONDREG   # late round 6: all three hooks of the reference's test on the condensed register kernel
             assert info["status"][0] == pa.SQP_SOLVED and info["iter"][0] < 10
             _assert_same_solve(info, io, xg, xo, lg, lo)
             filt = ctx.filter_state_download(1, handle)
@@ -1536,14 +1538,16 @@ def test_last_route_reports_the_kernel_family(ctx):
     assert route(workloads.robot_batch(4, P=5, S=3), exact_hessian_every_iter=1) == pa.capi.ROUTE_SCHUR
     assert route(workloads.robot_batch(4, P=4, S=1), hessian_update=1) == pa.capi.ROUTE_REG1      # no block-structured kernel for this grid
     assert route(workloads.robot_batch(4, P=5, S=2), hessian_update=1, kkt_form=1) == pa.capi.ROUTE_REG2
-    assert route(workloads.robot_batch(4, P=5, S=2), preconditioner=1, line_search=1) == pa.capi.ROUTE_REG2
-    assert route(workloads.robot_batch(4, P=5, S=2), line_search=1) == pa.capi.ROUTE_CONDREG            # round 5: the hook build of the small condensed kernel — compiled WITHOUT the Ruiz calls a condensed kernel never executes (they were what miscompiled it, EXPERIMENTS.md)
+    assert route(workloads.robot_batch(4, P=5, S=2), preconditioner=1, line_search=1) == pa.capi.ROUTE_CONDREG   # late round 6: the Ruiz preconditioner on the condensed hook kernels (tables and node blocks from the scaled workspace); before: the full two-rows-per-lane inverse
+    assert route(workloads.robot_batch(4, P=5, S=2), preconditioner=1, line_search=1, kkt_form=1) == pa.capi.ROUTE_REG2
+    assert route(workloads.robot_batch(4, P=5, S=2), line_search=1) == pa.capi.ROUTE_CONDREG            # round 5: the hook build of the small condensed kernel — then compiled WITHOUT the Ruiz calls (they were what miscompiled it, EXPERIMENTS.md)
     assert route(workloads.cstr_batch(4), line_search=1) == pa.capi.ROUTE_CONDREG
     assert route(workloads.robot_batch(4, P=4, S=2), preconditioner=1) == pa.capi.ROUTE_LDS
     assert route(workloads.robot_batch(4, P=5, S=3)) == pa.capi.ROUTE_CONDREG
     assert route(workloads.robot_batch(4, P=5, S=3), kkt_form=1) == pa.capi.ROUTE_REG2
     assert route(workloads.robot_batch(4, P=5, S=3), line_search=1) == pa.capi.ROUTE_CONDREG             # round 4: the policy hooks on the 16-node register kernels; the filter line search alone keeps the condensed QP
-    assert route(workloads.robot_batch(4, P=5, S=3), preconditioner=1) == pa.capi.ROUTE_REG2
+    assert route(workloads.robot_batch(4, P=5, S=3), preconditioner=1) == pa.capi.ROUTE_CONDREG
+    assert route(workloads.robot_batch(4, P=5, S=3), preconditioner=1, kkt_form=1) == pa.capi.ROUTE_REG2
     assert route(workloads.robot_batch(4, P=5, S=4), line_search=1) == pa.capi.ROUTE_HBM
     assert route(workloads.kite_standin_batch(2)) == pa.capi.ROUTE_HBM
 

@@ -1310,6 +1310,29 @@ def test_condensed_register_order_with_a_path_constraint_and_a_parameter(oracle,
     assert dc < 1e-7 and dc < 0.05 * de and dc < 0.01 * d2, (dc, de, d2)
 
 
+@pytest.mark.parametrize("policy", [dict(preconditioner=1), dict(preconditioner=1, line_search=1, hessian_update=1)], ids=["ruiz", "valet_parking_hooks"])
+def test_condensed_register_order_under_the_ruiz_preconditioner(oracle, policy):
+    """Late round 6: PIVOT_CONDSWEEP on a Ruiz-equilibrated QP (qp_preconditioners.hpp:114-220 either side of the solve, sqp_base.hpp:605-611) — the order of the condensed hook
+    kernels that serve valet_parking_mpc_test.cpp's policy set by default (the kernel reads its D~ tables, one set per state index, and the node blocks back from the scaled workspace;
+    the restatement reads the scaled KKT matrix anyway). Admission on 32 robot OCPs of that test's grid (11 nodes), Ruiz alone and with the filter line search + block BFGS: every
+    instance keeps the SQP / ADMM iteration counts and the status of the run in the reference order and of the run refined to exact arithmetic, and the condensed order is at least as
+    close to exact arithmetic as the reference order."""
+    from polympc_amd import workloads
+    B = 32
+    wl = workloads.robot_batch(B, P=5, S=2)
+    ss = oracle.sqp_default_settings(); ss.max_iter = 10; ss.line_search_max_iter = 10
+    for k, v in policy.items(): setattr(ss, k, v)
+    qs = oracle.sqp_qp_default_settings(); qs.max_iter = 1000
+    run = lambda piv: oracle.sqp_solve_batch(oracle.MODEL_ROBOT, 5, 2, 0.0, 2.0, B, wl["d"], wl["lbx"], wl["ubx"], sqp_settings=ss, qp_settings=qs, pivot=piv, threads=4)
+    xc, lc, ic = run(oracle.PIVOT_CONDSWEEP)
+    xe, le, ie = run(oracle.PIVOT_EIGEN)
+    xx, lx, ix = run(oracle.PIVOT_EXACT)
+    key = lambda info: [(i.iter, i.status, i.qp_solver_iter) for i in info]
+    assert key(ic) == key(ie) == key(ix)
+    dc, de = np.abs(xc - xx).max(), np.abs(xe - xx).max()
+    assert dc < 1e-9 and dc <= 2 * de, (dc, de)
+
+
 def test_condensed_register_order_with_one_parameter_on_the_minimal_time_problem(oracle):
     """Round 6: PIVOT_CONDSWEEP with NP = 1 (the parameter's dense column of A' u as the wavefront's tree sum, its term last in every row of A x) — the order of the
     condensed register kernel that now serves the reference's minimal-time parking test (minimal_time_test.cpp:146-188: exact Hessians, Gershgorin, NP = 1) by default.

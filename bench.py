@@ -308,9 +308,12 @@ def main():
             setattr(css, k, v)
         cd, cl, cu = t(cwl["d"]), t(cwl["lbx"]), t(cwl["ubx"])
         extra = {k: t(cwl[k]) for k in ("x_guess", "lbg", "ubg") if k in cwl}
+        cqs = qs
+        if "qp_max_iter" in cwl:
+            cqs = pa.qp_settings_sqp_default(); cqs.max_iter = cwl["qp_max_iter"]
         cx = torch.zeros(Bc, cn, dtype=torch.float64, device=dev); clam = torch.zeros(Bc, cm + cn, dtype=torch.float64, device=dev)
         ci = torch.zeros(Bc, 48, dtype=torch.uint8, device=dev)
-        run = lambda: ctx.sqp_solve_batch_dev(cwl["model"], cwl["P"], cwl["S"], cwl["t0"], cwl["tf"], Bc, cd, cl, cu, cx, clam, ci, css, qs, **extra)
+        run = lambda: ctx.sqp_solve_batch_dev(cwl["model"], cwl["P"], cwl["S"], cwl["t0"], cwl["tf"], Bc, cd, cl, cu, cx, clam, ci, css, cqs, **extra)
         for _ in range(warmup):
             run()
         torch.cuda.synchronize(dev)
@@ -416,18 +419,21 @@ def main():
             if cfg:
                 out["configs"] = cfg
             if "P" in want:
-                # ---- the reference's two NP = 1 control tests as batches (not BASELINE.json configurations): minimal_time_test.cpp:146-188 and nonlinear_constraints_test.cpp:159-184,
-                # configured as those tests configure the solver; a lone instance beside each (what the reference's test solves). Checked against the restatement in the CPU leg.
+                # ---- the reference's control tests that are no BASELINE.json configuration, as batches: minimal_time_test.cpp:146-188 and nonlinear_constraints_test.cpp:159-184 (NP = 1)
+                # and the policy set of valet_parking_mpc_test.cpp (Ruiz + filter + block BFGS), configured as those tests configure the solver; a lone instance beside each (what the
+                # reference's test solves). (cstr_control_test / mpc_wrapper_test: configs B / R with the block BFGS, above.) Checked against the restatement in the CPU leg.
                 rt = {}
-                for key, pc in (("minimal_time_parking_np1", False), ("nonlinear_constraints_parking_np1_ng1", True)):
-                    rwl = workloads.parking_reference_tests_batch(4096, path_constraint=pc)
-                    r_ = sqp_record(rwl, 4096, 6, 1, "sqp_kernel<Parking%sOCP,56,%d,...,CND>" % ("NG" if pc else "", rwl["m"]))
+                for key, pc in (("minimal_time_parking_np1", False), ("nonlinear_constraints_parking_np1_ng1", True), ("valet_parking_policy_set_robot_11_nodes", None)):
+                    mk = (lambda Bq: workloads.valet_parking_policy_batch(Bq)) if pc is None else (lambda Bq: workloads.parking_reference_tests_batch(Bq, path_constraint=pc))
+                    rwl = mk(4096)
+                    r_ = sqp_record(rwl, 4096, 6, 1, "sqp_kernel<...,CND>")
                     gsol_ = sol[0]
-                    l_ = sqp_record(workloads.parking_reference_tests_batch(1, path_constraint=pc), 1, 10, 2, "")
+                    l_ = sqp_record(mk(1), 1, 10, 2, "")
                     rt[key] = {"batch": 4096, "n": rwl["n"], "m": rwl["m"], "ms_per_batch": r_["ms_per_batch"], "qp_solves_per_s": r_["qp_solves_per_s"], "qp_solves_per_batch": r_["qp_solves_per_batch"],
                                "admm_iters_per_qp": r_["admm_iters_per_qp"], "sqp_solved_fraction": r_["sqp_solved_fraction"], "route": r_["route"],
                                "lone_instance_ms": l_["ms_per_batch"]["median"], "lone_instance_route": l_["route"],
-                               "settings": "max_iter 20, ls 10, exact Hessians every iteration, Gershgorin shift (as the reference's tests configure the solver); perturbed start states and wheel bases"}
+                               "settings": ("Ruiz preconditioner + filter line search + block BFGS, QP cap 1000 (valet_parking_mpc_test.cpp:161-165,183-241) on randomised robot OCPs of that test's grid" if pc is None else
+                                            "max_iter 20, ls 10, exact Hessians every iteration, Gershgorin shift (as the reference's tests configure the solver); perturbed start states and wheel bases")}
                     cfg_ref_runs[key] = (rwl, gsol_)
                 out["reference_tests"] = rt
             if not args.no_replay:
@@ -576,6 +582,8 @@ def main():
                 ross = ob.sqp_default_settings(); ross.max_iter = rwl["max_iter"]; ross.line_search_max_iter = rwl["ls_max_iter"]
                 for k_, v_ in rwl["settings"].items(): setattr(ross, k_, v_)
                 kw_ = {k_: rwl[k_][:nr] for k_ in ("x_guess", "lbg", "ubg") if k_ in rwl}
+                if "qp_max_iter" in rwl:
+                    kw_["qp_settings"] = ob.sqp_qp_default_settings(); kw_["qp_settings"].max_iter = rwl["qp_max_iter"]
                 rrun = lambda piv: ob.sqp_solve_batch(rwl["model"], rwl["P"], rwl["S"], rwl["t0"], rwl["tf"], nr, rwl["d"][:nr], rwl["lbx"][:nr], rwl["ubx"][:nr], sqp_settings=ross, pivot=piv, threads=cores, **kw_)
                 rorder = ob.PIVOT_CONDSWEEP if out["reference_tests"][key]["route"] == "condreg" else ob.PIVOT_SWEEP2
                 xk, lk, ik = rrun(rorder)

@@ -204,7 +204,8 @@ pmpc_status pmpc_debug_set_poison(pmpc_context* ctx, int on);
  *   PMPC_ROUTE_SCHUR block-structured kernel: Hessian block diagonal per node (hessian_update = 1 or exact Hessians, NP = NG = 0, kkt_form = 0) on a
  *                    grid with a compiled specialisation — per-node blocks in LDS, QP through the m x m Schur complement (m <= 64)
  *   PMPC_ROUTE_CONDREG condensed register-resident QP: 65..128 KKT rows with at most 112 variables and 64 constraint rows (at most one parameter; path constraints included) on a grid with a compiled specialisation,
- *                    default policies, kkt_form = 0 — only H + sigma I + rho_box + A' diag(rho) A is inverted (n instead of n + m rows)
+ *                    kkt_form = 0 — only H + sigma I + rho_box + A' diag(rho) A is inverted (n instead of n + m rows); with the policy hooks (Ruiz preconditioner, filter line search,
+ *                    eigenvalue mirroring) on the 7- / 11- / 16-node grids
  * PMPC_ROUTE_NONE before the first call. */
 typedef enum { PMPC_ROUTE_NONE = 0, PMPC_ROUTE_REG1 = 1, PMPC_ROUTE_REG2 = 2, PMPC_ROUTE_LDS = 3, PMPC_ROUTE_HBM = 4, PMPC_ROUTE_SCHUR = 5, PMPC_ROUTE_CONDREG = 6 } pmpc_route;
 int pmpc_sqp_last_route(pmpc_context* ctx);

@@ -92,6 +92,15 @@ def parking_reference_tests_batch(B, path_constraint=False, ubg=1.2):
     return wl
 
 
+def valet_parking_policy_batch(B):
+    """The solver configuration of valet_parking_mpc_test.cpp:161-165,183-241 — Ruiz preconditioner, filter line search, ContinuousOCP's block BFGS, QP iteration cap 1000 — on B
+    randomised robot OCPs of that test's grid (P=5 S=2, 11 nodes; robot_batch's start states and bounds)."""
+    wl = robot_batch(B, P=5, S=2)
+    wl["settings"] = dict(preconditioner=1, line_search=1, hessian_update=1)
+    wl["qp_max_iter"] = 1000
+    return wl
+
+
 def kite_standin_batch(B, seed=SEED, first=0):
     """Config C dimension stand-in: SYNTHETIC 13-state / 3-input smooth dynamics (the reference's KiteDynamics is not in
     the reference tree), P=5 S=3 -> 16 nodes, n=256, m=208, KKT 464 rows; u in [-1,1]^3, x0 = 0.3*U^13."""

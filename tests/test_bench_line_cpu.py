@@ -87,7 +87,7 @@ def test_round6_record_is_consistent_and_carries_the_new_keys():
     # the problems of the reference's two NP = 1 control tests as batches (late round 6): served by the condensed register kernel, bit-identical to its restatement,
     # the same trajectories as the run in the reference order
     rt = d["reference_tests"]
-    assert set(rt) == {"minimal_time_parking_np1", "nonlinear_constraints_parking_np1_ng1"}
+    assert set(rt) == {"minimal_time_parking_np1", "nonlinear_constraints_parking_np1_ng1", "valet_parking_policy_set_robot_11_nodes"}
     for rec in rt.values():
         assert rec["route"] == rec["lone_instance_route"] == "condreg" and rec["batch"] == 4096 and 0 < rec["lone_instance_ms"] < rec["ms_per_batch"]["median"]
         assert rec["parity"]["bit_identical_x"] and rec["parity"]["bit_identical_lam"] and rec["parity"]["identical_trajectory_fraction_vs_reference_order"] == 1.0

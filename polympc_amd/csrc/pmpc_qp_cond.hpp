@@ -15,6 +15,8 @@
 // (the test suite's checker) — the kernels are checked against it bit for bit.
 // The QP entry points without structure information (pmpc_qp_solve_batch) stay on the full two-rows-per-lane inverse: the products with a dense A
 // would cost more than the rows they save.
+// Round 6: one parameter (NP = 1: its dense column of A as a wave reduction), path-constraint rows (NG > 0: own-node blocks without a D~ row), H x of the dual residual from the KKT
+// identity of the last solve, and — hook builds (WS) — the D~ tables per state index and the node blocks read back from a Ruiz-scaled workspace.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "pmpc_qp_reg2.hpp"

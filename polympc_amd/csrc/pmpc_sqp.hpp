@@ -71,13 +71,13 @@ struct SqpDevice {
     static constexpr int SCH_P = PS / 256, SCH_S = PS % 256;
     static constexpr bool HOOKS = (NN == 0) || POL;
     using Dm = OcpDims<Model>;
-    // Ruiz scaling is compiled into the LDS / HBM-resident QP kernels only: the launcher routes preconditioner = 1 there. In the
+    // Ruiz scaling is compiled into the kernels that carry the hooks (HOOKS: the LDS / HBM-resident kernels and the hook builds, POL, of the register kernels): in the default
     // register-resident kernels its three (cold, out-of-line) calls cost private-memory frames and call-ABI spills on the hot path.
-    // Not in the condensed register kernels either (PS = -1): the launcher never routes preconditioner = 1 to them (Ruiz rescales the workspace the
-    // per-node blocks of A mirror), so the calls were dead code there — and they were what MISCOMPILED the hook build of the small condensed kernel
-    // (robot 11 nodes, 55 + 33, one row per lane; round 4: "wrong iterates, different from run to run", EXPERIMENTS.md round 5): with the three
-    // never-executed out-of-line calls compiled in, the QP step of the lanes that are primal-only (the control columns) is lost; without them the same
-    // source is bit-identical under the device-poisoning harness. -DPMPC_EXPERIMENT_CND_WITH_RUIZ compiles them in again (developer switch: reproduces the fault).
+    // History of the condensed kernels (PS = -1): until late round 6 the launcher never routed preconditioner = 1 to them (Ruiz rescales the workspace the per-node blocks of A mirror),
+    // the calls were dead code there — and in round 4 / 5 they were what MISCOMPILED the hook build of the small condensed kernel (robot 11 nodes, 55 + 33, one row per lane: with the three
+    // never-executed calls compiled in, the QP step of the primal-only lanes was lost — a VGPR -> AGPR copy of the lane id placed inside a partial-EXEC block, DESIGN.md hazard 3 /
+    // EXPERIMENTS.md round 6), so round 5 compiled them out. -DPMPC_EXPERIMENT_CND_WITH_RUIZ restores exactly that round-5 build (developer switch: reproduces the fault on hipcc 7.2
+    // when the allocator makes the same choice).
 #ifdef PMPC_EXPERIMENT_CND_WITH_RUIZ
     static constexpr bool RUIZ_COMPILED = HOOKS && (int)Dm::NDER <= RUIZ_MAX_NDER;
 #else

@@ -128,10 +128,13 @@ __global__ __launch_bounds__(WG4 ? 256 : 64, ((NN > 0 && NN + MM <= 64) ? PMPC_S
         p = v.carve(p, n, m, mi);
         stage0 = p;
         p = ocp.s.carve(p, P, S);
-        constexpr int QP_STAGING = []() constexpr {   // (condensed register QP: its own tile set's staging; its hook builds: room for the tables per state index)
-            if constexpr (CND && POL) return cond_qp_staging_ws<NN, MM, NN / (Model::NX + Model::NU), Model::NX>();
-            else if constexpr (CND) return cond_qp_staging<NN, MM, NN / (Model::NX + Model::NU)>();
+        constexpr int QP_STAGING0 = []() constexpr {   // (condensed register QP: its own tile set's staging)
+            if constexpr (CND) return cond_qp_staging<NN, MM, NN / (Model::NX + Model::NU)>();
             else return reg_qp_staging<NN + MM>(); }();
+        int QP_STAGING = QP_STAGING0;
+        if constexpr (CND && POL) {   // its hook builds with the Ruiz preconditioner on: room for the tables per state index (the launcher sized the allocation by the same rule)
+            if (ss.preconditioner == 1) QP_STAGING = cond_qp_staging_ws<NN, MM, NN / (Model::NX + Model::NU), Model::NX>();
+        }
         if (NN > 0 && (size_t)(p - stage0) < (size_t)QP_STAGING + 2 + ocp.s.const_doubles(P, S)) p = stage0 + QP_STAGING + 2 + ocp.s.const_doubles(P, S);
         stage_end = p;   // end of the per-node staging block: what follows (static parameters, filter) stays live during the line search
     }
@@ -759,7 +762,8 @@ inline bool try_launch_reg(pmpc_context* ctx, const Model& mdl, const ChebData* 
             // workspace, so the hook builds read their D~ tables (one set per state index) and, after an equilibration, the node blocks back from it (pmpc_qp_cond.hpp WS)
             if constexpr (POLK) {
                 if (pol && ss->kkt_form == 0 && !pmpc_internal_switch(ctx, PMPC_SW_NO_CONDREG) && !(ss->preconditioner == 1 && pmpc_internal_switch(ctx, PMPC_SW_NO_CONDREG_RUIZ))) {
-                    const size_t ldsw = sqp_kernel_lds_bytes<Model>(P, S, 6, 0, true, (size_t)cond_qp_staging_ws<NN_, MM_, NNODES, Model::NX>()) + sqp_eig_lds_bytes<Model>(P, S, ss);
+                    const size_t stg = ss->preconditioner == 1 ? (size_t)cond_qp_staging_ws<NN_, MM_, NNODES, Model::NX>() : (size_t)cond_qp_staging<NN_, MM_, NNODES>();   // (the tables per state index only with the Ruiz preconditioner: the other hooks keep the smaller staging — more instances per CU)
+                    const size_t ldsw = sqp_kernel_lds_bytes<Model>(P, S, 6, 0, true, stg) + sqp_eig_lds_bytes<Model>(P, S, ss);
                     if (ldsw <= lds_limit) {
                         kern = sqp_kernel<Model, NN_, MM_, false, 0, false, false, true, true>; timed = false;
                         ldsq = ldsw;

@@ -114,11 +114,12 @@ __device__ __forceinline__ void cond_build_tables_ws(const double* __restrict__ 
 // boxADMM::solve_impl (7-argument form: zero guesses, box_admm.hpp:81-86). H: the stacked workspace [H ; A] of the fused SQP kernel ((NN + MM) x NN,
 // column-major, leading dimension NN + MM; the LOWER triangle of H is read for S, as Eigen::LDLT does; the full rows for H x); h / bounds: LDS vectors;
 // tr: CondKkt<NN>::TRI doubles of LDS; jv: the block-sparse view of A.
-template <int NN, int MM, class JV, bool WS = false>   // WS: the D~ tables per state index from the workspace (the hook builds: the workspace may be Ruiz-scaled; the caller has refreshed the node blocks from it)
+template <int NN, int MM, class JV, bool WS = false>   // WS: a hook build — with ws_on (wave-uniform; the Ruiz preconditioner has rescaled the workspace, the caller has refreshed the node blocks from it and sized the staging for it) the D~ tables are built per state index from the workspace
 __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H, const double* h, const double* Alb, const double* Aub, const double* xlb,
                                                    const double* xub, const pmpc_qp_settings& s, pmpc_qp_info& info, double* out_x, double* out_y, double* tr,
-                                                   const JV& jv, long long* dbg = nullptr, long long* tm = nullptr) {
+                                                   const JV& jv, long long* dbg = nullptr, long long* tm = nullptr, bool ws_on = false) {
     using CD = CondDims<NN, MM>;
+    const bool ws = WS && __builtin_amdgcn_readfirstlane((int)ws_on) != 0;
     constexpr int N = CD::N, SL = CD::SL;
     constexpr bool SMALL = CD::SMALL;
     const int ln = lane_id();
@@ -186,9 +187,9 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
     constexpr int NGC = NG > 0 ? NG : 1;
     static_assert(NPAR <= 1 && NNODES * (NX + NG) == MM && P0 + NPAR == NN, "condensed register QP: at most one parameter");
     double* Dt = tr + CD::TAB_OFF;
-    static_assert(WS || CD::TAB_OFF + CD::template tab_doubles<NNODES>() <= CondKkt<NN>::TRI, "tables fit the staging");   // (WS: the launcher sizes the staging, cond_qp_staging_ws)
+    static_assert(CD::TAB_OFF + CD::template tab_doubles<NNODES>() <= CondKkt<NN>::TRI, "tables fit the staging");   // (ws: the launcher sizes the staging, cond_qp_staging_ws)
     constexpr int SET = 4 * NNODES * NNP;                      // one set of four tables
-    const double* ZROW = Dt + (WS ? NX : 1) * SET;             // the all-zero row
+    const double* ZROW = Dt + (ws ? NX : 1) * SET;             // the all-zero row
     const double* DtT = Dt + NNODES * NNP;
     const double *cD[2] = {nullptr, nullptr}, *cU[2] = {nullptr, nullptr}, *cB[2] = {nullptr, nullptr}, *cV[2] = {nullptr, nullptr};   // per primal slot: D~ column, u at the column's state index, own-node block column, u of the own node
     const double *cG[2] = {nullptr, nullptr}, *cW[2] = {nullptr, nullptr};   // NG > 0: the column inside its own node's path-constraint rows, u of those rows
@@ -201,7 +202,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
         const int cu = isp[e] ? 0 : c - VARX;     // (the parameter's lane walks a control column's addresses: its chain is discarded)
         const int jn = xcol ? c / NX : cu / NU;
         const int dcol = xcol ? c - jn * NX : NX + (cu - jn * NU);
-        cD[e] = xcol ? DtT + (WS ? dcol * SET : 0) + jn * NNP : ZROW;
+        cD[e] = xcol ? DtT + (ws ? dcol * SET : 0) + jn * NNP : ZROW;
         cU[e] = us + (xcol ? dcol : 0);
         cB[e] = jv.jblk + (jn * NX) * JBS + dcol;
         cV[e] = us + jn * NX;
@@ -210,7 +211,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
     }
     const bool req = NG == 0 || rc < ME;           // equality row (node rk, state rq) or path-constraint row (node rk): the latter reads the all-zero row of the D~ tables
     const int rk = req ? rc / NX : (rc - ME) / NGC, rq = req ? rc - rk * NX : 0;
-    const double* rD = req ? Dt + (WS ? rq * SET : 0) + rk * NNP : ZROW;   // constraint row: D~ row, x at the row's state index, own-node block row, x / u of the own node
+    const double* rD = req ? Dt + (ws ? rq * SET : 0) + rk * NNP : ZROW;   // constraint row: D~ row, x at the row's state index, own-node block row, x / u of the own node
     const double* rX = xs + rq;
     const double* rB = jv.jblk + rc * JBS;
     const double* rV = xs + rk * NX;
@@ -292,7 +293,7 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
                                                          [&](int j) -> double { return bcast_lane(rc_now, j); });
                          });
             }
-            if constexpr (WS) cond_build_tables_ws<NNODES, NX, NN, MM>(H, jv.P, Dt);
+            if (ws) { if constexpr (WS) cond_build_tables_ws<NNODES, NX, NN, MM>(H, jv.P, Dt); }
             else cond_build_tables<NNODES>(jv.D, jv.P, Dt);   // (the staging they live in was the sweep's)
             if (dbg) dbg[0] += clock64() - f0;
         }

@@ -1019,7 +1019,7 @@ struct SqpDevice {
         } else if constexpr (CND) {
             if constexpr (POL) {
                 // the node blocks of the sparse view mirror the workspace: after the equilibration they are read back from it (E_r A(r, c) D_c, the entries the
-                // dense orders see); the D~ tables of the hook builds come from the workspace anyway (WS)
+                // dense orders see), and the D~ tables are then built from the workspace, one set per state index (ws_on; the launcher sized the staging for them)
                 if (ruiz) {
                     constexpr int NXc = Model::NX, NUc = Model::NU, NDERc = Dm::NDER, JBSc = Dm::JBS, NNc = NNODES_CT_, VXc = NXc * NNc, P0c = (NXc + NUc) * NNc;
                     for (int e = ln; e < MM * NDERc; e += WAVE) {
@@ -1030,7 +1030,7 @@ struct SqpDevice {
                     }
                     wsync();
                 }
-                boxadmm_solve_cond<NN, MM, JV, true>(Hw, v.h, v.al, v.au, v.lx, v.ux, qs, qi, qw.x, qw.y, tr, jview(), PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr);
+                boxadmm_solve_cond<NN, MM, JV, true>(Hw, v.h, v.al, v.au, v.lx, v.ux, qs, qi, qw.x, qw.y, tr, jview(), PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr, ruiz);
             } else
             boxadmm_solve_cond<NN, MM>(Hw, v.h, v.al, v.au, v.lx, v.ux, qs, qi, qw.x, qw.y, tr, jview(), PROF ? &cyc[PROF ? 6 : 0] : nullptr, PROF ? &cyc[PROF ? 16 : 0] : nullptr);
             wsync();

@@ -10,7 +10,7 @@ dev = torch.device("cuda", 0); stream = torch.cuda.Stream(dev); torch.cuda.set_s
 ctx = pa.Context(0, stream=stream.cuda_stream)
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 for P, S, B in ((5, 2, 4096), (5, 2, 1), (5, 3, 2048)):
-    for pol in (dict(preconditioner=1, line_search=1, hessian_update=1), dict(preconditioner=1)):
+    for pol in (dict(preconditioner=1, line_search=1, hessian_update=1), dict(preconditioner=1), dict(line_search=1), dict(regularisation=1, exact_hessian_every_iter=1)):
         wl = workloads.robot_batch(B, P=P, S=S)
         n, m = wl["n"], wl["m"]
         x = torch.zeros(B, n, dtype=torch.float64, device=dev); lam = torch.zeros(B, n + m, dtype=torch.float64, device=dev); info = torch.zeros(B, 48, dtype=torch.uint8, device=dev)

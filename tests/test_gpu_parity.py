@@ -701,6 +701,31 @@ def test_sqp_valet_parking_with_ruiz(ctx, oracle):
         _assert_same_solve(info, io, xg, xo, lg, lo)
 
 
+@pytest.mark.parametrize("case", ["robot_16_nodes", "cstr_11_nodes", "parking_np1_11_nodes", "parking_np1_ng1_11_nodes", "robot_11_nodes_all_hooks"])
+def test_sqp_ruiz_on_the_condensed_hook_kernels(ctx, oracle, case):
+    """Late round 6: preconditioner = 1 (RuizEquilibration either side of the QP, sqp_base.hpp:605-611) on the hook builds of the condensed register kernel — the D~ tables per state
+    index and the node blocks read back from the scaled workspace (pmpc_qp_cond.hpp WS). Grids of 65 .. 128 KKT rows of four models, incl. one parameter and path-constraint rows, and the
+    three hooks of valet_parking_mpc_test.cpp together: route PMPC_ROUTE_CONDREG, bit-identical to PIVOT_CONDSWEEP on the scaled KKT matrix on every instance."""
+    import polympc_amd as pa
+    from polympc_amd import workloads
+    B = 6
+    kw = dict(preconditioner=1)
+    if case == "robot_16_nodes":
+        wl = workloads.robot_batch(B, P=5, S=3); wl["max_iter"] = 6
+    elif case == "robot_11_nodes_all_hooks":
+        wl = workloads.valet_parking_policy_batch(B); wl["max_iter"] = 8; kw = dict(wl.pop("settings")); wl.pop("qp_max_iter")
+    elif case == "cstr_11_nodes":
+        lbx, ubx = _cstr_grid(B, 5, 2)
+        wl = dict(model=1, P=5, S=2, t0=0.0, tf=100.0, d=np.zeros((B, 1)), lbx=lbx, ubx=ubx, max_iter=6, ls_max_iter=20)
+    else:
+        wl = workloads.parking_reference_tests_batch(B, path_constraint=(case == "parking_np1_ng1_11_nodes")); wl["max_iter"] = 6
+    (x, lam, info), (xo, lo, io) = _sqp_both(ctx, oracle, wl, B, **kw)
+    assert ctx.last_route() == pa.capi.ROUTE_CONDREG
+    dm = oracle.ocp_dims(wl["model"], wl["P"], wl["S"])
+    assert _policy_order(oracle, dm["n"], dm["m"], wl["P"] * wl["S"] + 1, ruiz=True, ng=dm["ng"]) == oracle.PIVOT_CONDSWEEP
+    _assert_same_solve(info, io, x, xo, lam, lo)
+
+
 def test_sqp_valet_parking_as_the_reference_runs_it(ctx, oracle):
     """valet_parking_mpc_test.cpp:183-240 through the GPU path with every hook that test installs: Ruiz preconditioner, QP max_iter
     1000, the filter line search on LSFilter (beta = 0.1, carried from the cold solve into the warm-started one in a device buffer)

@@ -45,22 +45,53 @@ inline void BFGS_update(double* B, const double* s, const double* y, int n) {
     for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) B[i + j * n] += (r[i] * r[j]) / sr;
 }
 
-// cyclic Jacobi eigen-decomposition of a symmetric matrix (stand-in for Eigen::EigenSolver on a symmetric H)
+// Jacobi eigen-decomposition of a symmetric matrix (stand-in for Eigen::EigenSolver on a symmetric H) in the ROUND-ROBIN order of the kernel (pmpc_sqp.hpp regularise_eig_mirror,
+// late round 6): a tournament over np = n (+ 1 bye when n is odd) players; in round r pair 0 is (np - 1, r), pair i >= 1 is ((r + i) mod (np - 1), (r - i) mod (np - 1)); the pairs
+// of a round are disjoint and rotate together — angles from the matrix at the start of the round, then every pair mixes its two COLUMNS of A and V over all rows, then every pair
+// its two ROWS of A over all columns, then the pair's own off-diagonal entry is set to the exact zero. Stops when max |a_ij|^2 < 1e-300 (i != j): ~10 sweeps. For n = 2 (the reference's own use, sqp_test_autodiff.cpp) this is the one rotation of the cyclic order.
 inline void jacobi_eig(std::vector<double> A, int n, std::vector<double>& w, std::vector<double>& V) {
     V.assign(n * n, 0.0); for (int i = 0; i < n; ++i) V[i + i * n] = 1.0;
+    const int np = n + (n & 1), m2 = np / 2, nr = np - 1;
+    auto pair_of = [&](int r, int i, int& p, int& q) {
+        const int a = (i == 0) ? np - 1 : (r + i) % nr, b = (i == 0) ? r : (r - i + nr) % nr;
+        p = a < b ? a : b; q = a < b ? b : a;
+    };
+    std::vector<double> cs(2 * m2);
     for (int sweep = 0; sweep < 100; ++sweep) {
-        double off = 0; for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) off += A[i + j * n] * A[i + j * n];
-        if (off < 1e-300) break;
-        for (int p = 0; p < n; ++p)
-            for (int q = p + 1; q < n; ++q) {
-                double apq = A[p + q * n]; if (std::fabs(apq) < 1e-300) continue;
-                double theta = (A[q + q * n] - A[p + p * n]) / (2 * apq);
-                double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
-                double c = 1 / std::sqrt(t * t + 1), s = t * c;
+        double amax = 0; for (int j = 0; j < n; ++j) for (int i = j + 1; i < n; ++i) amax = std::fmax(amax, std::fabs(A[i + j * n]));
+        if (amax * amax < 1e-300) break;
+        for (int r = 0; r < nr; ++r) {
+            for (int i = 0; i < m2; ++i) {
+                int p, q; pair_of(r, i, p, q);
+                double c = 1.0, s = 0.0;
+                if (q < n) {
+                    const double apq = A[p + q * n];
+                    if (!(std::fabs(apq) < 1e-300)) {
+                        const double theta = (A[q + q * n] - A[p + p * n]) / (2 * apq);
+                        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
+                        c = 1 / std::sqrt(t * t + 1); s = t * c;
+                    }
+                }
+                cs[i] = c; cs[m2 + i] = s;
+            }
+            for (int i = 0; i < m2; ++i) {
+                int p, q; pair_of(r, i, p, q);
+                const double c = cs[i], s = cs[m2 + i];
+                if (!(q < n && s != 0.0)) continue;
                 for (int k = 0; k < n; ++k) { double akp = A[k + p * n], akq = A[k + q * n]; A[k + p * n] = c * akp - s * akq; A[k + q * n] = s * akp + c * akq; }
-                for (int k = 0; k < n; ++k) { double apk = A[p + k * n], aqk = A[q + k * n]; A[p + k * n] = c * apk - s * aqk; A[q + k * n] = s * apk + c * aqk; }
                 for (int k = 0; k < n; ++k) { double vkp = V[k + p * n], vkq = V[k + q * n]; V[k + p * n] = c * vkp - s * vkq; V[k + q * n] = s * vkp + c * vkq; }
             }
+            for (int i = 0; i < m2; ++i) {
+                int p, q; pair_of(r, i, p, q);
+                const double c = cs[i], s = cs[m2 + i];
+                if (!(q < n && s != 0.0)) continue;
+                for (int k = 0; k < n; ++k) { double apk = A[p + k * n], aqk = A[q + k * n]; A[p + k * n] = c * apk - s * aqk; A[q + k * n] = s * apk + c * aqk; }
+            }
+            for (int i = 0; i < m2; ++i) {   // the annihilated entries as exact zeros (what the mixes leave there is the rounding of the diagonal entries, which never decays)
+                int p, q; pair_of(r, i, p, q);
+                if (q < n && cs[m2 + i] != 0.0) { A[p + q * n] = 0.0; A[q + p * n] = 0.0; }
+            }
+        }
     }
     w.resize(n); for (int i = 0; i < n; ++i) w[i] = A[i + i * n];
 }

@@ -194,24 +194,33 @@ __device__ __forceinline__ void boxadmm_solve_cond(const double* __restrict__ H,
     const double *cD[2] = {nullptr, nullptr}, *cU[2] = {nullptr, nullptr}, *cB[2] = {nullptr, nullptr}, *cV[2] = {nullptr, nullptr};   // per primal slot: D~ column, u at the column's state index, own-node block column, u of the own node
     const double *cG[2] = {nullptr, nullptr}, *cW[2] = {nullptr, nullptr};   // NG > 0: the column inside its own node's path-constraint rows, u of those rows
     bool isp[2] = {false, false};   // this slot holds the parameter (NP = 1): its entry of A' u is a wave reduction, not a chain over the tables
+    // The per-lane index arithmetic below is written WITHOUT lane-divergent control flow (both quotients are formed, a bit mask selects): a ternary around an integer division
+    // becomes an if / else over the lanes, and a divergent block in a kernel at the register limit is where hipcc 7.2 has twice placed the copy of a live-range split that then
+    // keeps only the active lanes' values (DESIGN.md hazard 3: round 5 in the column setup, late round 6 in the row setup of the first NG > 0 hook build)
+    auto isel = [](bool cnd, int a, int b) -> int { const int mk = -(int)cnd; return (a & mk) | (b & ~mk); };
 #pragma unroll
     for (int e = 0; e < SL; ++e) {
         const int c = lp[e];
         const bool xcol = c < VARX;
         isp[e] = NPAR > 0 && isP[e] && c >= P0;
-        const int cu = isp[e] ? 0 : c - VARX;     // (the parameter's lane walks a control column's addresses: its chain is discarded)
-        const int jn = xcol ? c / NX : cu / NU;
-        const int dcol = xcol ? c - jn * NX : NX + (cu - jn * NU);
-        cD[e] = xcol ? DtT + (ws ? dcol * SET : 0) + jn * NNP : ZROW;
-        cU[e] = us + (xcol ? dcol : 0);
+        const int cu = isel(isp[e], 0, c - VARX);     // (the parameter's lane walks a control column's addresses: its chain is discarded)
+        const int cuc = cu < 0 ? 0 : cu;              // (a state column: any valid control index, discarded by the select)
+        const int jnx = c / NX, jnu = cuc / NU;
+        const int jn = isel(xcol, jnx, jnu);
+        const int dcol = isel(xcol, c - jnx * NX, NX + (cuc - jnu * NU));
+        const int doff = isel(xcol, (ws ? dcol * SET : 0) + jn * NNP + NNODES * NNP, (ws ? NX : 1) * SET);   // offset from Dt: the column's row of the transposed table / the all-zero row
+        cD[e] = Dt + doff;
+        cU[e] = us + isel(xcol, dcol, 0);
         cB[e] = jv.jblk + (jn * NX) * JBS + dcol;
         cV[e] = us + jn * NX;
         cG[e] = jv.jblk + (ME + jn * NG) * JBS + dcol;   // (gblk = jblk + ME JBS: the launcher carves them as one array, pmpc_launch.hpp)
         cW[e] = us + ME + jn * NG;
     }
     const bool req = NG == 0 || rc < ME;           // equality row (node rk, state rq) or path-constraint row (node rk): the latter reads the all-zero row of the D~ tables
-    const int rk = req ? rc / NX : (rc - ME) / NGC, rq = req ? rc - rk * NX : 0;
-    const double* rD = req ? Dt + (ws ? rq * SET : 0) + rk * NNP : ZROW;   // constraint row: D~ row, x at the row's state index, own-node block row, x / u of the own node
+    const int rcg = rc < ME ? 0 : rc - ME;         // (index among the path rows; an equality row: 0, discarded by the select)
+    const int rke = rc / NX, rkg = rcg / NGC;
+    const int rk = isel(req, rke, rkg), rq = isel(req, rc - rke * NX, 0);
+    const double* rD = Dt + isel(req, (ws ? rq * SET : 0) + rk * NNP, (ws ? NX : 1) * SET);   // constraint row: D~ row (a path row: the all-zero row), x at the row's state index, own-node block row, x / u of the own node
     const double* rX = xs + rq;
     const double* rB = jv.jblk + rc * JBS;
     const double* rV = xs + rk * NX;

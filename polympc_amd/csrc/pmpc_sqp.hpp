@@ -529,29 +529,69 @@ struct SqpDevice {
     // lower triangle drops below 1e-300 (at most 100). A (n x n) and V (n x n) live in LDS (`eig`, 2 n^2 doubles, allocated by the
     // launcher only when regularisation = 1); every lane evaluates the wave-uniform scalars redundantly, the O(n) updates run one entry per lane.
     double* eig = nullptr;
+    // Eigenvalue mirroring (sqp_test_autodiff.cpp:29-45): H = V D V' with the non-positive eigenvalues w replaced by -w + 0.1. The reference calls Eigen::EigenSolver; here a Jacobi
+    // iteration in LDS (A = eig[0, n^2), V behind it) — since late round 6 in the ROUND-ROBIN order: the n / 2 disjoint pairs of a round rotate together (their angles from the matrix
+    // at the start of the round; then every pair mixes its two COLUMNS of A and V over all rows, then every pair mixes its two ROWS of A over all columns), n - 1 rounds per sweep,
+    // so that all 64 lanes work, and the annihilated entry is written as an exact zero — the pair-by-pair cyclic order of rounds 2 .. 6 left its rounding residue there, never met its
+    // stopping rule and ran all 100 sweeps: 7 (n = 35) .. 33 ms (n = 80) per SQP iteration. Restated by oracle/sqp.hpp jacobi_eig
+    // (each entry sees the same operations in the same order: the pairs of a round touch disjoint columns in the first phase and disjoint rows in the second).
     __device__ __forceinline__ void regularise_eig_mirror() {
         const int ln = lane_id();
+        const int n = n_ct();
         double* A = eig; double* V = eig + (size_t)n * n;
         for (int e = ln; e < n * n; e += WAVE) { const int j = e / n, i = e - j * n; A[e] = Hw[(size_t)j * ldw + i]; V[e] = (i == j) ? 1.0 : 0.0; }
         wsync();
+        const int np = n + (n & 1), m2 = np / 2, nr = np - 1;   // round-robin tournament over np players (np - 1 = n: a bye when n is odd)
+        double* cs = v.t1;                                       // c of pair i at [i], s at [m2 + i] (m2 <= n / 2 + 1 entries each)
+        auto pair_of = [&](int r, int i, int& p, int& q) {
+            const int a = (i == 0) ? np - 1 : (r + i) % nr, b = (i == 0) ? r : (r - i + nr) % nr;
+            p = a < b ? a : b; q = a < b ? b : a;
+        };
         for (int sweep = 0; sweep < 100; ++sweep) {
-            double off = 0.0;
-            for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) { const double a = A[i + j * n]; off += a * a; }
-            if (__builtin_amdgcn_readfirstlane((int)(off < 1e-300))) break;
-            for (int p = 0; p < n; ++p)
-                for (int q = p + 1; q < n; ++q) {
-                    const double apq = A[p + q * n];
-                    if (__builtin_amdgcn_readfirstlane((int)(fabs(apq) < 1e-300))) continue;
-                    const double theta = (A[q + q * n] - A[p + p * n]) / (2 * apq);
-                    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + ::sqrt(theta * theta + 1));
-                    const double c = 1 / ::sqrt(t * t + 1), sn = t * c;
-                    wsync();
-                    for (int k = ln; k < n; k += WAVE) { const double akp = A[k + p * n], akq = A[k + q * n]; A[k + p * n] = c * akp - sn * akq; A[k + q * n] = sn * akp + c * akq; }
-                    wsync();
-                    for (int k = ln; k < n; k += WAVE) { const double apk = A[p + k * n], aqk = A[q + k * n]; A[p + k * n] = c * apk - sn * aqk; A[q + k * n] = sn * apk + c * aqk; }
-                    for (int k = ln; k < n; k += WAVE) { const double vkp = V[k + p * n], vkq = V[k + q * n]; V[k + p * n] = c * vkp - sn * vkq; V[k + q * n] = sn * vkp + c * vkq; }
-                    wsync();
+            double amax = 0.0;
+            for (int e = ln; e < n * n; e += WAVE) { const int j = e / n, i = e - j * n; if (i > j) amax = fmax(amax, fabs(A[e])); }
+            amax = wave_max(amax);
+            if (__builtin_amdgcn_readfirstlane((int)(amax * amax < 1e-300))) break;
+            for (int r = 0; r < nr; ++r) {
+                for (int i = ln; i < m2; i += WAVE) {
+                    int p, q; pair_of(r, i, p, q);
+                    double c = 1.0, sn = 0.0;
+                    if (q < n) {
+                        const double apq = A[p + q * n];
+                        if (!(fabs(apq) < 1e-300)) {
+                            const double theta = (A[q + q * n] - A[p + p * n]) / (2 * apq);
+                            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + ::sqrt(theta * theta + 1));
+                            c = 1 / ::sqrt(t * t + 1); sn = t * c;
+                        }
+                    }
+                    cs[i] = c; cs[m2 + i] = sn;
                 }
+                wsync();
+                for (int it = ln; it < m2 * n; it += WAVE) {   // columns p, q of A and V, every row k
+                    const int i = it / n, k = it - i * n;
+                    int p, q; pair_of(r, i, p, q);
+                    const double c = cs[i], sn = cs[m2 + i];
+                    if (q < n && sn != 0.0) {
+                        const double akp = A[k + p * n], akq = A[k + q * n]; A[k + p * n] = c * akp - sn * akq; A[k + q * n] = sn * akp + c * akq;
+                        const double vkp = V[k + p * n], vkq = V[k + q * n]; V[k + p * n] = c * vkp - sn * vkq; V[k + q * n] = sn * vkp + c * vkq;
+                    }
+                }
+                wsync();
+                for (int it = ln; it < m2 * n; it += WAVE) {   // rows p, q of A, every column k
+                    const int i = it / n, k = it - i * n;
+                    int p, q; pair_of(r, i, p, q);
+                    const double c = cs[i], sn = cs[m2 + i];
+                    if (q < n && sn != 0.0) { const double apk = A[p + k * n], aqk = A[q + k * n]; A[p + k * n] = c * apk - sn * aqk; A[q + k * n] = sn * apk + c * aqk; }
+                }
+                wsync();
+                // the rotated pair's off-diagonal entry is zero by construction; what the two mixes leave there is the rounding of the DIAGONAL entries (eps |a_pp|), which
+                // never decays — written as the exact zero, the off-diagonal mass falls quadratically to underflow (~10 sweeps) instead of stalling at eps |A| for all 100
+                for (int i = ln; i < m2; i += WAVE) {
+                    int p, q; pair_of(r, i, p, q);
+                    if (q < n && cs[m2 + i] != 0.0) { A[p + q * n] = 0.0; A[q + p * n] = 0.0; }
+                }
+                wsync();
+            }
         }
         double mn = A[0];
         for (int i = 1; i < n; ++i) mn = fmin(mn, A[i + i * n]);

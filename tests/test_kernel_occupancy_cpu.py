@@ -176,7 +176,8 @@ def test_exec_window_helpers_start_with_every_lane_enabled_and_no_spill_loses_la
     bad = [b for r in res for b in r[2]]
     bad_agpr = [b for r in res for b in r[3]]
     assert kernels >= 100 and bodies >= 5000, (kernels, bodies)     # every register-resident QP kernel carries them (35 + 21: 32 bodies per inverse site)
-    assert not bad, f"{len(bad)} EXEC-window helper bodies where EXEC is not proven full: {bad[:3]}"
+    assert not bad and not bad_agpr, (f"{len(bad)} EXEC-window helper bodies where EXEC is not proven full: {bad[:3]}; {len(bad_agpr)} accumulation-register / scratch-slot reads with "
+                                      f"lanes enabled that the last write provably did not cover (a spill inside a partial-EXEC block): {bad_agpr[:3]}")
     assert not bad_agpr, f"{len(bad_agpr)} accumulation-register / scratch-slot reads with lanes enabled that the last write provably did not cover (a spill inside a partial-EXEC block): {bad_agpr[:3]}"
 
 

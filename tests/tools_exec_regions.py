@@ -360,7 +360,12 @@ def _run_block(b, st, i, visit=None):
             st = (e0, regs)
             continue
         if mn not in ("s_cbranch_execnz", "s_cbranch_execz") and -1 in st[1]:
-            st = (st[0], {r: v for r, v in st[1].items() if r != -1})
+            # the pending restore survives instructions that touch neither EXEC nor the accumulated mask (the scheduler moves unrelated scalar moves in between)
+            pend = _regs(st[1][-1][0]) or set()
+            dst = ops[0].strip() if ops else ""
+            wr = _regs(dst) or set()
+            if dst.startswith("exec") or (wr & pend) or mn.endswith("_saveexec_b64") or mn.startswith(("v_cmpx", "s_swappc", "s_setpc", "s_branch", "s_cbranch")):
+                st = (st[0], {r: v for r, v in st[1].items() if r != -1})
         st = _step(st, mn, ops, (i, k))
     return st
 

@@ -95,9 +95,9 @@ typedef struct {
 
 /* sqp_settings_t (sqp_base.hpp:24-47) + the two override points the reference's tests use:
  * regularisation: 0 none (default hook, sqp_base.hpp:305), 1 eigenvalue mirroring (sqp_test_autodiff.cpp:29-45; Jacobi iteration in LDS, needs
- *                 16 n^2 bytes of LDS per instance: PMPC_ERR_UNSUPPORTED_SIZE beyond that; a cyclic Jacobi iteration on one wavefront, rotation by rotation in the
- *                 restatement's order — the reference uses it on a 2-variable NLP; on an OCP it costs ~7 ms (n = 35) .. ~15 ms (n = 55) .. ~33 ms (n = 80) per SQP iteration
- *                 and instance slot: a correctness path, not a fast one), 2 Gershgorin shift (dense_sparse_compare.cpp:109-122)
+ *                 16 n^2 bytes of LDS per instance: PMPC_ERR_UNSUPPORTED_SIZE beyond that; a round-robin Jacobi iteration on one wavefront in the restatement's
+ *                 order — the reference uses it on a 2-variable NLP; on an OCP it costs ~0.6 ms (n = 35) .. ~1.7 ms (n = 55) .. ~4.5 ms (n = 80) per SQP iteration of a
+ *                 lone instance), 2 Gershgorin shift (dense_sparse_compare.cpp:109-122)
  * exact_hessian_every_iter: update_linearisation_dense_impl overridden to linearisation_dense_impl
  *                           (codegen_test.cpp:381-398) instead of damped BFGS (bfgs.hpp:23-52). */
 typedef struct {

@@ -48,8 +48,32 @@ inline void BFGS_update(double* B, const double* s, const double* y, int n) {
 // Jacobi eigen-decomposition of a symmetric matrix (stand-in for Eigen::EigenSolver on a symmetric H) in the ROUND-ROBIN order of the kernel (pmpc_sqp.hpp regularise_eig_mirror,
 // late round 6): a tournament over np = n (+ 1 bye when n is odd) players; in round r pair 0 is (np - 1, r), pair i >= 1 is ((r + i) mod (np - 1), (r - i) mod (np - 1)); the pairs
 // of a round are disjoint and rotate together — angles from the matrix at the start of the round, then every pair mixes its two COLUMNS of A and V over all rows, then every pair
-// its two ROWS of A over all columns, then the pair's own off-diagonal entry is set to the exact zero. Stops when max |a_ij|^2 < 1e-300 (i != j): ~10 sweeps. For n = 2 (the reference's own use, sqp_test_autodiff.cpp) this is the one rotation of the cyclic order.
+// its two ROWS of A over all columns, then the pair's own off-diagonal entry is set to the exact zero. Stops when max |a_ij|^2 < 1e-300 (i != j): ~10 sweeps.
+// n <= JACOBI_CYCLIC_MAX (the sizes of the reference's own uses: the 2- and 4-variable NLPs of sqp_test_autodiff.cpp) keeps the pair-by-pair cyclic iteration of rounds 1 .. 6, bit for bit:
+// HS071's Hessian has an eigenvalue that is zero in exact arithmetic, the rule `w <= 0 -> -w + 0.1` is discontinuous there, and the known-answer tests of that problem were pinned
+// with the rounding of that iteration (test_sqp_hs071_iteration_bound_is_a_last_bit_property says what that means). The kernel runs the round-robin order at every size; no OCP grid has 8 variables or fewer
+// (3 nodes of a one-state, one-input model have 6: such a model would need this switch in the kernel too).
+constexpr int JACOBI_CYCLIC_MAX = 8;
+inline void jacobi_eig_cyclic(std::vector<double> A, int n, std::vector<double>& w, std::vector<double>& V) {
+    V.assign(n * n, 0.0); for (int i = 0; i < n; ++i) V[i + i * n] = 1.0;
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0; for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) off += A[i + j * n] * A[i + j * n];
+        if (off < 1e-300) break;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                double apq = A[p + q * n]; if (std::fabs(apq) < 1e-300) continue;
+                double theta = (A[q + q * n] - A[p + p * n]) / (2 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
+                double c = 1 / std::sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < n; ++k) { double akp = A[k + p * n], akq = A[k + q * n]; A[k + p * n] = c * akp - s * akq; A[k + q * n] = s * akp + c * akq; }
+                for (int k = 0; k < n; ++k) { double apk = A[p + k * n], aqk = A[q + k * n]; A[p + k * n] = c * apk - s * aqk; A[q + k * n] = s * apk + c * aqk; }
+                for (int k = 0; k < n; ++k) { double vkp = V[k + p * n], vkq = V[k + q * n]; V[k + p * n] = c * vkp - s * vkq; V[k + q * n] = s * vkp + c * vkq; }
+            }
+    }
+    w.resize(n); for (int i = 0; i < n; ++i) w[i] = A[i + i * n];
+}
 inline void jacobi_eig(std::vector<double> A, int n, std::vector<double>& w, std::vector<double>& V) {
+    if (n <= JACOBI_CYCLIC_MAX) { jacobi_eig_cyclic(A, n, w, V); return; }
     V.assign(n * n, 0.0); for (int i = 0; i < n; ++i) V[i + i * n] = 1.0;
     const int np = n + (n & 1), m2 = np / 2, nr = np - 1;
     auto pair_of = [&](int r, int i, int& p, int& q) {

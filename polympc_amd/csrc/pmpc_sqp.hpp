@@ -533,7 +533,7 @@ struct SqpDevice {
     // iteration in LDS (A = eig[0, n^2), V behind it) — since late round 6 in the ROUND-ROBIN order: the n / 2 disjoint pairs of a round rotate together (their angles from the matrix
     // at the start of the round; then every pair mixes its two COLUMNS of A and V over all rows, then every pair mixes its two ROWS of A over all columns), n - 1 rounds per sweep,
     // so that all 64 lanes work, and the annihilated entry is written as an exact zero — the pair-by-pair cyclic order of rounds 2 .. 6 left its rounding residue there, never met its
-    // stopping rule and ran all 100 sweeps: 7 (n = 35) .. 33 ms (n = 80) per SQP iteration. Restated by oracle/sqp.hpp jacobi_eig
+    // stopping rule and ran all 100 sweeps: 7 (n = 35) .. 33 ms (n = 80) per SQP iteration. Restated by the test suite's CPU checker (jacobi_eig; it keeps the pair-by-pair iteration for n <= 8, the sizes of the reference's own NLP tests — no OCP grid is that small)
     // (each entry sees the same operations in the same order: the pairs of a round touch disjoint columns in the first phase and disjoint rows in the second).
     __device__ __forceinline__ void regularise_eig_mirror() {
         const int ln = lane_id();

@@ -1756,3 +1756,18 @@ def test_empty_and_odd_batch_sizes(ctx, oracle):
         for B in ((1, 63, 65) if nB >= 65 else (1, 3)):
             xb, lb, ib = run(B)
             assert np.array_equal(xb, xf[:B]) and np.array_equal(lb, lf[:B]) and np.array_equal(ib["qp_solver_iter"], inf_["qp_solver_iter"][:B])
+
+
+@pytest.mark.gpu
+def test_routing_table_soak_under_poison():
+    """The developer soak as a test (late round 6): tests/tools_soak_routes.py in its own process with PMPC_POISON=1 — every grid of 3 .. 16 nodes of five models (robot, CSTR,
+    parking with one parameter, parking and robot with a path constraint) under the default policy and the seven policy sets that change the route, every launch preceded by
+    signalling NaNs in workspaces, LDS and register files: every combination bit-identical to the restatement in the order the dispatch rule names for it. This is the run that
+    showed compiler hazard 3 in a second kernel the moment it appeared; the CPU suite's ISA check named the same kernel."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, PMPC_POISON="1")
+    r = subprocess.run([sys.executable, os.path.join(here, "tools_soak_routes.py"), "4"], capture_output=True, text=True, env=env, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("model ")]
+    bad = [l for l in lines if "MISMATCH" in l]
+    assert r.returncode == 0 and not bad and len(lines) >= 600 and r.stdout.strip().endswith("mismatches: 0"), (r.returncode, bad[:5], r.stdout[-400:], r.stderr[-400:])
